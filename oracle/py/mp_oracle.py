@@ -277,15 +277,16 @@ def pt_tobytes(P):
 
 
 def pt_wire(P):
-    """boundary ("wire") encoding: x LE || y LE, 64 B; infinity = all zero with bit 6 of byte 63 set."""
+    """boundary ("wire") encoding: x LE || y LE, 64 B; infinity = 64 zero bytes ((0,0) is on none of
+    the curves since b != 0; a flag bit would collide with y on the 256-bit secp256k1 field)."""
     if P is None:
-        return bytes(63) + b"\x40"
+        return bytes(64)
     return fe_bytes(P[0]) + fe_bytes(P[1])
 
 
 def pt_from_wire(b):
     assert len(b) == 64
-    if b[63] & 0x40:
+    if b == bytes(64):
         return None
     return (int.from_bytes(b[:32], "little"), int.from_bytes(b[32:], "little"))
 

@@ -1,0 +1,178 @@
+"""CPU tests (-m "not gpu"): pin the oracles.
+
+The reference holds no golden vectors and cannot be run here, so the pins are:
+ * published constants / KATs: secp256k1 2G, RFC 7539 ChaCha20 block, the ChaCha20 zero-key keystream,
+   SURVEY App. C values (checked there with independent arithmetic);
+ * the committed fixtures in tests/golden (made by tests/golden/gen_golden.py from the Python oracle);
+ * agreement of two independent restatements (Python big-int vs C++ 4x64 Montgomery + Pippenger);
+ * the reference's behavioural pins: accept honest / reject a wrong deck as "Hadamard Product (5.1)"
+   [REF barnett-smart-card-protocol/src/discrete_log_cards/tests.rs:175-227].
+"""
+import copy
+import hashlib
+import os
+import struct
+
+import pytest
+
+from conftest import GOLDEN, golden_cases, load_json
+
+import mp_oracle as po
+
+K = 0x0123456789abcdef0fedcba9876543210123456789abcdef0fedcba987654321
+
+
+def test_curve_constants_and_kats_python():
+    for cv in po.CURVES.values():
+        assert cv.is_on_curve(cv.G)
+        assert po.pt_mul(cv, cv.q, cv.G) is None
+        assert po.pt_mul(cv, cv.q - 1, cv.G) == po.pt_neg(cv, cv.G)
+    # universally published secp256k1 2G
+    assert po.pt_mul(po.SECP256K1, 2, po.SECP256K1.G) == (
+        0xc6047f9441ed7d6d3045406e95c07cd85c778e4b8cef3ca7abac09b95c709ee5,
+        0x1ae168fea63dc339a3c58419466ceaeef7f632653266d0e1236431a950cfe52a)
+    # SURVEY App. C
+    assert po.pt_mul(po.STARK, K, po.STARK.G) == (
+        0x56a347111c423fb2deff8678925ded9c8ba03b0f577a589cef9f3d3936877c1,
+        0x2d58166ea0e2c7447739de2ba33a84aa8729176f2ee470c3c5b6526e8cae8c1)
+    assert po.pt_mul(po.BN254, K, po.BN254.G) == (
+        0x15b653a46cb336794237e1cdcf6cf7e899315229adf895acb32cb7013887531,
+        0x28506bd1fd0c2ffafeab89b1fe80056432a5977ab1f03cea6568591ca9576d15)
+
+
+def test_hash_kats_python():
+    key = struct.unpack("<8I", bytes(range(32)))
+    out = po.chacha20_block(key, 1, w13=0x09000000, w14=0x4a000000, w15=0)  # RFC 7539 2.3.2
+    assert out[:4] == [0xe4e7f110, 0x15593bd1, 0x1fdd0f50, 0xc47120a3]
+    assert out[12:] == [0xd19c12b5, 0xb94e16de, 0xe883d0cb, 0x4e3c50a2]
+    assert po.blake2s(b"Shuffle Proof").hex() == "99df86eeefd21867b5ea2a0194c5e8dd819aa01221dcdcbc5ff6b16f9303b656"
+
+
+def test_curve_kats_c(coracle):
+    kats = load_json(os.path.join(GOLDEN, "curve_kats.json"))
+    for name, k in kats.items():
+        G = bytes.fromhex(k["G"])
+        assert coracle.on_curve(name, G) == 1
+        one = (1).to_bytes(32, "little")
+        two = (2).to_bytes(32, "little")
+        for algo in (0, 1):
+            assert coracle.msm(name, two, G, algo).hex() == k["twoG"]
+            assert coracle.msm(name, bytes.fromhex(k["k"]), G, algo).hex() == k["kG"]
+            assert coracle.msm(name, one + one, G + G, algo).hex() == k["twoG"]
+        qm1 = (int(k["q"], 16) - 1).to_bytes(32, "little")
+        assert coracle.msm(name, qm1, G, 0).hex() == k["qm1G"]
+        # G + (q-1)G = infinity (all-zero wire encoding)
+        assert coracle.msm(name, one + qm1, G + G, 0) == bytes(64)
+        r = k["remask"]
+        out = coracle.remask_deck(name, G, bytes.fromhex(r["pk"]), bytes.fromhex(r["ct"]), bytes.fromhex(r["alpha"]))
+        assert out.hex() == r["out"]
+
+
+def test_fs_kats_c(coracle):
+    kats = load_json(os.path.join(GOLDEN, "fs_kats.json"))
+    assert coracle.blake2s(b"Shuffle Proof").hex() == kats["blake2s_shuffle_proof"]
+    for n in (0, 1, 63, 64, 65, 127, 128, 129, 1000):
+        data = bytes((i * 7 + 3) & 0xFF for i in range(n))
+        assert coracle.blake2s(data) == hashlib.blake2s(data).digest()
+    ks = b"".join(struct.pack("<16I", *coracle.chacha20_block(bytes(32), c)) for c in range(1))
+    assert ks.hex() == kats["chacha20_zero_key_first64"]
+    for name in po.CURVES:
+        k = kats["challenges_" + name]
+        assert [hex(v) for v in coracle.fs_challenges(name, b"Shuffle Proof", None, 3)] == k["after_seed"]
+        assert [hex(v) for v in coracle.fs_challenges(name, b"Shuffle Proof", bytes(range(200)), 3)] == k["after_absorb_0_199"]
+
+
+@pytest.mark.parametrize("path", golden_cases(), ids=os.path.basename)
+def test_c_oracle_matches_golden(coracle, path):
+    g = load_json(path)
+    cv, m, n = g["curve"], g["m"], g["n"]
+    gi = coracle.gen_inputs(cv, m, n, g["seed"])
+    for key in ("params", "pk", "deck", "rho", "prover_seed"):
+        assert gi[key].hex() == g[key], key
+    assert gi["perm"] == g["perm"]
+    sh, pf = coracle.shuffle_and_remask(cv, m, n, **gi)
+    assert sh.hex() == g["shuffled"]
+    assert pf.hex() == g["proof"]
+    assert len(pf) == coracle.proof_size(m, n) == po.proof_size(m, n)
+    assert coracle.verify_shuffle(cv, m, n, gi["params"], gi["pk"], gi["deck"], sh, pf) == 0
+    # [REF tests.rs:213-226] a random wrong deck is rejected by name
+    wrong = coracle.gen_inputs(cv, m, n, g["seed"] + 1000)["deck"]
+    rc = coracle.verify_shuffle(cv, m, n, gi["params"], gi["pk"], gi["deck"], wrong, pf)
+    assert coracle.CHECK_NAMES[rc] == "Hadamard Product (5.1)"
+
+
+@pytest.mark.parametrize("name", ["shuffle_stark_m2_n3_s1.json", "shuffle_bn254_m2_n4_s3.json",
+                                  "shuffle_secp256k1_m3_n3_s5.json"])
+def test_python_oracle_matches_golden(name):
+    g = load_json(os.path.join(GOLDEN, name))
+    cv = po.CURVES[g["curve"]]
+    pp, pk, deck, rho, perm, ps = po.gen_inputs(cv, g["m"], g["n"], g["seed"])
+    assert po.params_to_bytes(pp).hex() == g["params"]
+    sh, pf = po.shuffle_and_remask(pp, pk, deck, rho, perm, ps)
+    assert po.deck_to_bytes(sh).hex() == g["shuffled"]
+    assert po.proof_to_bytes(pf).hex() == g["proof"]
+    assert po.verify_shuffle(pp, pk, deck, sh, pf) == 0
+
+
+def test_tampering_names_the_failing_check(coracle):
+    g = load_json(os.path.join(GOLDEN, "shuffle_stark_m3_n4_s11.json"))
+    cv, m, n = g["curve"], g["m"], g["n"]
+    b = {k: bytes.fromhex(g[k]) for k in ("params", "pk", "deck", "shuffled", "proof")}
+    pf = po.proof_from_bytes(b["proof"], m, n)
+    q = po.CURVES[cv].q
+
+    def check(mut):
+        p2 = copy.deepcopy(pf)
+        mut(p2)
+        return coracle.CHECK_NAMES[coracle.verify_shuffle(cv, m, n, b["params"], b["pk"], b["deck"], b["shuffled"],
+                                                          po.proof_to_bytes(p2))]
+
+    def bump(d, k, i=None):
+        if i is None:
+            d[k] = (d[k] + 1) % q
+        else:
+            d[k][i] = (d[k][i] + 1) % q
+
+    assert check(lambda p: None) == "Ok"
+    assert check(lambda p: bump(p["mexp"], "taubar")) == "Multi-Exponentiation Argument (4)"
+    assert check(lambda p: bump(p["mexp"], "abar", 1)) == "Multi-Exponentiation Argument (4)"
+    assert check(lambda p: bump(p["product"]["svp"], "rt")) == "Single Value Product (5.3)"
+    assert check(lambda p: bump(p["product"]["svp"], "bt", 0)) == "Single Value Product (5.3)"
+    assert check(lambda p: bump(p["product"]["had"]["zero"], "tbar")) == "Zero Argument (5.2)"
+    assert check(lambda p: bump(p["product"]["had"]["zero"], "abar", 2)) == "Zero Argument (5.2)"
+    # swapping two shuffled cards breaks the statement hash -> first check to fail is Hadamard's
+    sh = bytearray(b["shuffled"])
+    sh[0:128], sh[128:256] = sh[128:256], sh[0:128]
+    rc = coracle.verify_shuffle(cv, m, n, b["params"], b["pk"], b["deck"], bytes(sh), b["proof"])
+    assert coracle.CHECK_NAMES[rc] == "Hadamard Product (5.1)"
+
+
+def test_edge_inputs_c_vs_python(coracle):
+    """identity permutation, rho in {0, 1, q-1}, duplicate cards, an infinity component."""
+    cvn, m, n = "stark", 2, 3
+    cv = po.CURVES[cvn]
+    pp, pk, deck, rho, perm, ps = po.gen_inputs(cv, m, n, 42)
+    deck[1] = deck[0]                       # duplicate card
+    deck[2] = (None, deck[2][1])            # infinity component
+    rho = [0, 1, cv.q - 1, rho[3], rho[4], 0]
+    perm = list(range(m * n))               # identity permutation
+    sh, pf = po.shuffle_and_remask(pp, pk, deck, rho, perm, ps)
+    assert po.verify_shuffle(pp, pk, deck, sh, pf) == 0
+    csh, cpf = coracle.shuffle_and_remask(cvn, m, n, po.params_to_bytes(pp), po.pt_wire(pk), po.deck_to_bytes(deck),
+                                          b"".join(po.fe_bytes(r) for r in rho), perm, ps)
+    assert csh == po.deck_to_bytes(sh)
+    assert cpf == po.proof_to_bytes(pf)
+    assert coracle.verify_shuffle(cvn, m, n, po.params_to_bytes(pp), po.pt_wire(pk), po.deck_to_bytes(deck), csh, cpf) == 0
+
+
+def test_c_oracle_rejects_bad_usage(coracle):
+    g = load_json(os.path.join(GOLDEN, "shuffle_stark_m2_n3_s1.json"))
+    gi = coracle.gen_inputs("stark", 2, 3, 1)
+    bad = dict(gi)
+    bad["perm"] = [0, 0, 1, 2, 3, 4]  # not a permutation
+    with pytest.raises(ValueError):
+        coracle.shuffle_and_remask("stark", 2, 3, **bad)
+    # non-canonical scalar in the proof (>= q) is a usage error, not a verification failure
+    pf = bytearray(bytes.fromhex(g["proof"]))
+    pf[-32:] = b"\xff" * 32
+    assert coracle.verify_shuffle("stark", 2, 3, gi["params"], gi["pk"], gi["deck"], bytes.fromhex(g["shuffled"]), bytes(pf)) < 0
