@@ -1,0 +1,119 @@
+/*
+ * mpshuffle.h -- C ABI of libmpshuffle.so: the MI355X (gfx950) shuffle-proof engine that replaces, for the
+ * hot path only, the `BarnettSmartProtocol` implementation of geometryxyz/mental-poker:
+ *
+ *     DLCards::setup               [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:105-121]
+ *     DLCards::shuffle_and_remask  [REF .../discrete_log_cards/mod.rs:380-418, trait decl src/lib.rs:181-188]
+ *     DLCards::verify_shuffle      [REF .../discrete_log_cards/mod.rs:420-443, trait decl src/lib.rs:191-197]
+ *
+ * The reference has no FFI seam -- its seam is the Rust trait (a second `impl BarnettSmartProtocol`); these are
+ * the entry points such an impl binds through `extern "C"` (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - plain pointers and sizes; the CALLER allocates every buffer (sizes: mp_proof_size, mp_params_size);
+ *   - all multi-byte buffers must be 4-byte aligned;
+ *   - return value / status word: 0 = Ok; > 0 = proof rejected, value = code of the first failing check
+ *     (mp_check_name: 1 "Hadamard Product (5.1)" [REF tests.rs:223-225], 2 "Zero Argument (5.2)",
+ *     3 "Single Value Product (5.3)", 4 "Multi-Exponentiation Argument (4)") <-> CryptoError::ProofVerificationError;
+ *     < 0 = usage / encoding error <-> CardProtocolError::IoError [REF src/error.rs:6-12]
+ *     (MP_ERR_*; text via mp_last_error);
+ *   - wire encodings ("mpshuffle wire v1"):
+ *       scalar (Fr)      32 B little-endian canonical integer, must be < group order
+ *       point            64 B: x LE || y LE (canonical, affine); point at infinity = 64 zero bytes
+ *       ciphertext/card  128 B: c0 || c1                                  (el_gamal::Ciphertext(pub Affine, pub Affine))
+ *       deck             N ciphertexts back to back, N = m*n
+ *       parameters       (n+3) points: G | ck_0 .. ck_{n-1} | H | gen     (enc generator, Pedersen key, extra generator)
+ *       permutation      N uint32, out[i] = in[perm[i]]                   (Permutation::permute_array)
+ *       proof            mp_proof_size(m, n) bytes, element order in DESIGN.md ("proof wire order")
+ *   - prover randomness is an explicit 32-byte seed: the prover draws `Fr::rand` from
+ *     ChaCha20Rng::from_seed(seed) in the documented order (the reference takes `rng: &mut R`, mod.rs:381).
+ *   - thread-safety: a context owns one HIP stream; calls on one context/table are serialised by the caller.
+ *     Different contexts may be used from different host threads.
+ */
+#ifndef MPSHUFFLE_H
+#define MPSHUFFLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MP_CURVE_STARK 0      /* starknet_curve::Projective: every reference test + examples/round.rs */
+#define MP_CURVE_BN254 1
+#define MP_CURVE_SECP256K1 2
+
+#define MP_OK 0
+#define MP_ERR_BAD_ENCODING (-1)     /* non-canonical scalar / coordinate, point not on the curve */
+#define MP_ERR_BAD_PERMUTATION (-2)
+#define MP_ERR_BAD_ARGUMENT (-3)     /* null pointer, m < 2, n < 2, N > 4096, wrong proof length ... */
+#define MP_ERR_NO_DEVICE (-4)        /* no usable MI355X / HIP runtime error: the engine never falls back to a CPU path */
+#define MP_ERR_INTERNAL (-5)
+
+typedef struct mp_ctx mp_ctx;       /* one GPU + stream + curve */
+typedef struct mp_table mp_table;   /* shared parameters + shared key of one card table, with their device tables */
+
+/* ---- context ---------------------------------------------------------------------------------------- */
+int mp_ctx_create(int curve_id, int device, mp_ctx** out);
+void mp_ctx_destroy(mp_ctx* ctx);
+const char* mp_last_error(void);                 /* thread-local text of the last error */
+const char* mp_check_name(int code);             /* "Ok", "Hadamard Product (5.1)", ... */
+size_t mp_proof_size(uint32_t m, uint32_t n);    /* (11m+8) points + (5n+9) scalars */
+size_t mp_params_size(uint32_t n);               /* (n+3) * 64 */
+
+/* ---- DLCards::setup -----------------------------------------------------------------------------------
+ * Derives G, ck_0..ck_{n-1}, H, gen = k * G_std with k = Fr::rand(ChaCha20Rng::from_seed(seed)) in that order. */
+int mp_setup(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out_params);
+
+/* ---- table context: Parameters + aggregate public key -> fixed-base window tables in HBM ------------------ */
+int mp_table_create(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, const uint8_t* shared_key,
+                    mp_table** out);
+void mp_table_destroy(mp_table* t);
+
+/* ---- DLCards::shuffle_and_remask / verify_shuffle (one proof; host buffers) --------------------------------- */
+int mp_shuffle_and_remask(mp_table* t, const uint8_t* deck, const uint8_t* masking_factors,
+                          const uint32_t* permutation, const uint8_t prover_seed[32], uint8_t* out_deck,
+                          uint8_t* out_proof);
+int mp_verify_shuffle(mp_table* t, const uint8_t* deck, const uint8_t* shuffled_deck, const uint8_t* proof,
+                      size_t proof_len);
+
+/* ---- batched forms: B independent proofs, arrays of the single-proof buffers back to back -------------------
+ * status[b] receives the per-proof result; the return value is < 0 only for call-level errors. */
+int mp_shuffle_and_remask_batch(mp_table* t, size_t B, const uint8_t* decks, const uint8_t* masking_factors,
+                                const uint32_t* permutations, const uint8_t* prover_seeds, uint8_t* out_decks,
+                                uint8_t* out_proofs, int32_t* status);
+int mp_verify_shuffle_batch(mp_table* t, size_t B, const uint8_t* decks, const uint8_t* shuffled_decks,
+                            const uint8_t* proofs, int32_t* status);
+
+/* ---- device-resident forms: every pointer is a DEVICE pointer (HBM); asynchronous on the context's stream;
+ * mp_sync waits.  These are what bench.py times (inputs already in HBM). */
+int mp_shuffle_and_remask_batch_dev(mp_table* t, size_t B, const void* d_decks, const void* d_masking_factors,
+                                    const void* d_permutations, const void* d_prover_seeds, void* d_out_decks,
+                                    void* d_out_proofs, void* d_status);
+int mp_verify_shuffle_batch_dev(mp_table* t, size_t B, const void* d_decks, const void* d_shuffled_decks,
+                                const void* d_proofs, void* d_status);
+int mp_sync(mp_ctx* ctx);
+int mp_reserve(mp_table* t, size_t B);           /* pre-allocate the batch workspace for B proofs */
+
+/* ---- building blocks (host buffers) ------------------------------------------------------------------------
+ * mp_remask_batch: out[i] = in[i] + (rho_i * G, rho_i * pk)        [REF remasking.rs:16-18]
+ * mp_msm:          n_msm independent variable-base MSMs of k terms: out[j] = sum_t scalars[j][t] * points[j][t]
+ * mp_commit_batch: Pedersen com(v; r) = r*H + sum v_l * ck_l, `count` commitments of `len` <= n values each */
+int mp_remask_batch(mp_table* t, size_t count, const uint8_t* cards, const uint8_t* masking_factors, uint8_t* out);
+int mp_msm(mp_table* t, size_t n_msm, size_t k, const uint8_t* scalars, const uint8_t* points, uint8_t* out);
+int mp_commit_batch(mp_table* t, size_t count, size_t len, const uint8_t* values, const uint8_t* r, uint8_t* out);
+
+/* ---- measurement hooks ---------------------------------------------------------------------------------------
+ * With profiling on, every kernel launch is bracketed by HIP events on the context's stream;
+ * mp_profile_report writes "name count total_ms\n" lines (and resets) -- bench.py's roofline source. */
+int mp_profile_enable(mp_ctx* ctx, int on);
+int mp_profile_report(mp_ctx* ctx, char* buf, size_t buf_len);
+/* static work census of one prove / verify for this table: number of scalar*point terms and point operations */
+int mp_work_census(mp_table* t, uint64_t* prove_terms, uint64_t* verify_terms, uint64_t* prove_point_ops,
+                   uint64_t* verify_point_ops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPSHUFFLE_H */

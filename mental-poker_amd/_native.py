@@ -1,0 +1,250 @@
+"""ctypes binding of libmpshuffle.so (include/mpshuffle.h).  Plumbing only: bytes in, bytes out.
+
+The library is the HIP engine; there is no CPU path.  `load()` raises if the shared object is missing
+and `Engine(...)` raises `NoDeviceError` if no MI355X is visible.
+"""
+import ctypes
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmpshuffle.so")
+ROOT = os.path.dirname(HERE)
+
+CURVE_IDS = {"stark": 0, "bn254": 1, "secp256k1": 2}
+MP_ERR_BAD_ENCODING, MP_ERR_BAD_PERMUTATION, MP_ERR_BAD_ARGUMENT, MP_ERR_NO_DEVICE, MP_ERR_INTERNAL = -1, -2, -3, -4, -5
+
+SYMBOLS = [
+    "mp_ctx_create", "mp_ctx_destroy", "mp_last_error", "mp_check_name", "mp_proof_size", "mp_params_size",
+    "mp_setup", "mp_table_create", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
+    "mp_shuffle_and_remask_batch", "mp_verify_shuffle_batch", "mp_shuffle_and_remask_batch_dev",
+    "mp_verify_shuffle_batch_dev", "mp_sync", "mp_reserve", "mp_remask_batch", "mp_msm", "mp_commit_batch",
+    "mp_profile_enable", "mp_profile_report", "mp_work_census",
+]
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("mpshuffle error %d: %s" % (code, text))
+        self.code = code
+
+
+class NoDeviceError(NativeError):
+    pass
+
+
+def build(verbose=False):
+    """compile the HIP engine for gfx950 in-tree -> mental-poker_amd/libmpshuffle.so"""
+    src = os.path.join(HERE, "csrc", "engine.hip")
+    deps = [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))]
+    deps.append(os.path.join(ROOT, "include", "mpshuffle.h"))
+    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH, src]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def bind(cdll):
+    """declare prototypes on an already opened library"""
+    c = ctypes
+    u8p, u32p, i32p = c.c_void_p, c.c_void_p, c.c_void_p
+    cdll.mp_ctx_create.argtypes = [c.c_int, c.c_int, c.POINTER(c.c_void_p)]
+    cdll.mp_ctx_destroy.argtypes = [c.c_void_p]
+    cdll.mp_ctx_destroy.restype = None
+    cdll.mp_last_error.restype = c.c_char_p
+    cdll.mp_check_name.argtypes = [c.c_int]
+    cdll.mp_check_name.restype = c.c_char_p
+    cdll.mp_proof_size.argtypes = [c.c_uint32, c.c_uint32]
+    cdll.mp_proof_size.restype = c.c_size_t
+    cdll.mp_params_size.argtypes = [c.c_uint32]
+    cdll.mp_params_size.restype = c.c_size_t
+    cdll.mp_setup.argtypes = [c.c_void_p, c.c_uint32, c.c_uint32, u8p, u8p]
+    cdll.mp_table_create.argtypes = [c.c_void_p, c.c_uint32, c.c_uint32, u8p, u8p, c.POINTER(c.c_void_p)]
+    cdll.mp_table_destroy.argtypes = [c.c_void_p]
+    cdll.mp_table_destroy.restype = None
+    cdll.mp_shuffle_and_remask.argtypes = [c.c_void_p, u8p, u8p, u32p, u8p, u8p, u8p]
+    cdll.mp_verify_shuffle.argtypes = [c.c_void_p, u8p, u8p, u8p, c.c_size_t]
+    cdll.mp_shuffle_and_remask_batch.argtypes = [c.c_void_p, c.c_size_t, u8p, u8p, u32p, u8p, u8p, u8p, i32p]
+    cdll.mp_verify_shuffle_batch.argtypes = [c.c_void_p, c.c_size_t, u8p, u8p, u8p, i32p]
+    cdll.mp_shuffle_and_remask_batch_dev.argtypes = [c.c_void_p, c.c_size_t] + [c.c_void_p] * 7
+    cdll.mp_verify_shuffle_batch_dev.argtypes = [c.c_void_p, c.c_size_t] + [c.c_void_p] * 4
+    cdll.mp_sync.argtypes = [c.c_void_p]
+    cdll.mp_reserve.argtypes = [c.c_void_p, c.c_size_t]
+    cdll.mp_remask_batch.argtypes = [c.c_void_p, c.c_size_t, u8p, u8p, u8p]
+    cdll.mp_msm.argtypes = [c.c_void_p, c.c_size_t, c.c_size_t, u8p, u8p, u8p]
+    cdll.mp_commit_batch.argtypes = [c.c_void_p, c.c_size_t, c.c_size_t, u8p, u8p, u8p]
+    cdll.mp_profile_enable.argtypes = [c.c_void_p, c.c_int]
+    cdll.mp_profile_report.argtypes = [c.c_void_p, c.c_char_p, c.c_size_t]
+    cdll.mp_work_census.argtypes = [c.c_void_p] + [c.POINTER(c.c_uint64)] * 4
+    return cdll
+
+
+_LIB = None
+
+
+def load():
+    """open libmpshuffle.so (raises if it was not built: there is no fallback)"""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libmpshuffle.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                              "the engine has no CPU fallback")
+        _LIB = bind(ctypes.CDLL(LIB_PATH))
+    return _LIB
+
+
+def _in(b):
+    b = bytes(b)
+    return (ctypes.c_uint8 * max(len(b), 1)).from_buffer_copy(b if b else b"\0")
+
+
+class Engine:
+    """one mp_ctx (GPU + stream + curve)"""
+
+    def __init__(self, curve="stark", device=0, lib=None):
+        self.lib = lib if lib is not None else load()
+        self.curve = curve
+        h = ctypes.c_void_p()
+        rc = self.lib.mp_ctx_create(CURVE_IDS[curve], device, ctypes.byref(h))
+        if rc != 0:
+            text = self.lib.mp_last_error().decode()
+            raise (NoDeviceError if rc == MP_ERR_NO_DEVICE else NativeError)(rc, text)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise NativeError(rc, self.lib.mp_last_error().decode())
+        return rc
+
+    def check_name(self, code):
+        return self.lib.mp_check_name(code).decode()
+
+    def proof_size(self, m, n):
+        return self.lib.mp_proof_size(m, n)
+
+    def setup(self, m, n, seed):
+        out = (ctypes.c_uint8 * self.lib.mp_params_size(n))()
+        self._chk(self.lib.mp_setup(self.h, m, n, _in(seed), out))
+        return bytes(out)
+
+    def table(self, m, n, params, shared_key):
+        return Table(self, m, n, params, shared_key)
+
+    def sync(self):
+        self._chk(self.lib.mp_sync(self.h))
+
+    def profile_enable(self, on=True):
+        self._chk(self.lib.mp_profile_enable(self.h, 1 if on else 0))
+
+    def profile_report(self):
+        buf = ctypes.create_string_buffer(1 << 16)
+        self._chk(self.lib.mp_profile_report(self.h, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.split()
+            out[name] = (int(cnt), float(ms))
+        return out
+
+
+class Table:
+    """one mp_table: Parameters + aggregate key with their fixed-base tables in HBM"""
+
+    def __init__(self, eng, m, n, params, shared_key):
+        self.eng, self.lib, self.m, self.n, self.N = eng, eng.lib, m, n, m * n
+        self.params, self.shared_key = bytes(params), bytes(shared_key)
+        if len(self.params) != 64 * (n + 3) or len(self.shared_key) != 64:
+            raise NativeError(MP_ERR_BAD_ARGUMENT, "parameters / shared key have the wrong length")
+        h = ctypes.c_void_p()
+        eng._chk(self.lib.mp_table_create(eng.h, m, n, _in(self.params), _in(self.shared_key), ctypes.byref(h)))
+        self.h = h
+        self.proof_bytes = self.lib.mp_proof_size(m, n)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mp_table_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-buffer API
+    def shuffle_and_remask_batch(self, decks, factors, perms, seeds):
+        """B proofs; decks: B*N*128 bytes, factors: B*N*32, perms: list of B*N ints, seeds: B*32 -> (decks, proofs, status)"""
+        B = len(seeds) // 32
+        N = self.N
+        assert len(decks) == B * N * 128 and len(factors) == B * N * 32 and len(perms) == B * N
+        out_d = (ctypes.c_uint8 * (B * N * 128))()
+        out_p = (ctypes.c_uint8 * (B * self.proof_bytes))()
+        st = (ctypes.c_int32 * B)()
+        pm = (ctypes.c_uint32 * (B * N))(*perms)
+        self.eng._chk(self.lib.mp_shuffle_and_remask_batch(self.h, B, _in(decks), _in(factors), pm, _in(seeds), out_d, out_p, st))
+        return bytes(out_d), bytes(out_p), list(st)
+
+    def verify_shuffle_batch(self, decks, shuffled, proofs):
+        N = self.N
+        B = len(decks) // (N * 128)
+        assert len(shuffled) == len(decks) and len(proofs) == B * self.proof_bytes
+        st = (ctypes.c_int32 * B)()
+        self.eng._chk(self.lib.mp_verify_shuffle_batch(self.h, B, _in(decks), _in(shuffled), _in(proofs), st))
+        return list(st)
+
+    def shuffle_and_remask(self, deck, factors, perm, seed):
+        out_d = (ctypes.c_uint8 * (self.N * 128))()
+        out_p = (ctypes.c_uint8 * self.proof_bytes)()
+        pm = (ctypes.c_uint32 * self.N)(*perm)
+        rc = self.lib.mp_shuffle_and_remask(self.h, _in(deck), _in(factors), pm, _in(seed), out_d, out_p)
+        self.eng._chk(rc)
+        return bytes(out_d), bytes(out_p)
+
+    def verify_shuffle(self, deck, shuffled, proof):
+        rc = self.lib.mp_verify_shuffle(self.h, _in(deck), _in(shuffled), _in(proof), len(proof))
+        return self.eng._chk(rc)
+
+    def remask_batch(self, cards, factors):
+        count = len(cards) // 128
+        out = (ctypes.c_uint8 * (count * 128))()
+        self.eng._chk(self.lib.mp_remask_batch(self.h, count, _in(cards), _in(factors), out))
+        return bytes(out)
+
+    def msm(self, n_msm, k, scalars, points):
+        out = (ctypes.c_uint8 * (n_msm * 64))()
+        self.eng._chk(self.lib.mp_msm(self.h, n_msm, k, _in(scalars), _in(points), out))
+        return bytes(out)
+
+    def commit_batch(self, count, length, values, r):
+        out = (ctypes.c_uint8 * (count * 64))()
+        self.eng._chk(self.lib.mp_commit_batch(self.h, count, length, _in(values), _in(r), out))
+        return bytes(out)
+
+    # ---- device-pointer API (ints = HBM addresses, e.g. torch tensor .data_ptr())
+    def reserve(self, B):
+        self.eng._chk(self.lib.mp_reserve(self.h, B))
+
+    def shuffle_and_remask_batch_dev(self, B, d_decks, d_factors, d_perms, d_seeds, d_out_decks, d_out_proofs, d_status):
+        self.eng._chk(self.lib.mp_shuffle_and_remask_batch_dev(self.h, B, d_decks, d_factors, d_perms, d_seeds, d_out_decks, d_out_proofs, d_status))
+
+    def verify_shuffle_batch_dev(self, B, d_decks, d_shuffled, d_proofs, d_status):
+        self.eng._chk(self.lib.mp_verify_shuffle_batch_dev(self.h, B, d_decks, d_shuffled, d_proofs, d_status))
+
+    def work_census(self):
+        v = [ctypes.c_uint64() for _ in range(4)]
+        self.eng._chk(self.lib.mp_work_census(self.h, *[ctypes.byref(x) for x in v]))
+        return dict(prove_terms=v[0].value, verify_terms=v[1].value, prove_point_ops=v[2].value, verify_point_ops=v[3].value)

@@ -1,0 +1,865 @@
+// libmpshuffle.so: host orchestration of the gfx950 shuffle-proof engine and its C ABI (include/mpshuffle.h).
+//
+// A batch of B independent proofs goes through a fixed sequence of kernels on one HIP stream with NO host
+// round-trip inside a batch: Fiat-Shamir challenges are derived on the device.  The prover's group work is
+// packed into four dependency levels (everything that can be computed between two squeeze points runs in one
+// launch of each kernel class), the verifier's into one.
+//
+//   prove : load -> init(rand, perm) -> remask -> [A: c_A] -> FS x -> scal1 -> [B: c_B, multi-exp msg] -> FS y,z
+//           -> scal2 -> [C: c_b, Hadamard, SVP msgs] -> FS hx,hy -> scal3 -> [D: zero-arg msgs] -> FS zx,svx,mx
+//           -> scal4 (responses) -> store
+//   verify: load -> FS (all challenges) -> scalars (MSM coefficients, direct checks) -> [MSMs == O] -> verdict
+//
+// Mirrors DLCards::{setup, shuffle_and_remask, verify_shuffle}
+// [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:105-121, 380-418, 420-443].
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/mpshuffle.h"
+#include "kernels_proto.hpp"
+
+namespace mp {
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() {}
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { rt::dfree(p); }
+  void alloc(size_t count, rt::Stream s, bool zero = true) {
+    if (count <= n) return;
+    rt::dfree(p);
+    p = nullptr;
+    p = (T*)rt::dmalloc(count * sizeof(T));
+    n = count;
+    if (zero) rt::dzero(p, count * sizeof(T), s);
+  }
+  void upload(const std::vector<T>& v, rt::Stream s) {
+    alloc(v.size() ? v.size() : 1, s, false);
+    if (!v.empty()) rt::h2d(p, v.data(), v.size() * sizeof(T), s);
+  }
+};
+
+struct Profiler {
+  bool on = false;
+  struct Rec {
+    const char* name;
+    rt::Event a, b;
+  };
+  std::vector<Rec> recs;
+  std::vector<rt::Event> pool;
+  rt::Event get() {
+    if (!pool.empty()) {
+      rt::Event e = pool.back();
+      pool.pop_back();
+      return e;
+    }
+    return rt::event_create();
+  }
+  void begin(const char* name, rt::Stream s) {
+    if (!on) return;
+    Rec r{name, get(), get()};
+    rt::event_record(r.a, s);
+    recs.push_back(r);
+  }
+  void end(rt::Stream s) {
+    if (!on) return;
+    rt::event_record(recs.back().b, s);
+  }
+  std::string report() {
+    std::map<std::string, std::pair<long, double>> acc;
+    std::vector<std::string> order;
+    for (auto& r : recs) {
+      float ms = rt::event_ms(r.a, r.b);
+      if (!acc.count(r.name)) order.push_back(r.name);
+      acc[r.name].first += 1;
+      acc[r.name].second += ms;
+      pool.push_back(r.a);
+      pool.push_back(r.b);
+    }
+    recs.clear();
+    std::ostringstream os;
+    for (auto& k : order) os << k << " " << acc[k].first << " " << acc[k].second << "\n";
+    return os.str();
+  }
+  ~Profiler() {
+    for (auto& r : recs) {
+      rt::event_destroy(r.a);
+      rt::event_destroy(r.b);
+    }
+    for (auto e : pool) rt::event_destroy(e);
+  }
+};
+
+}  // namespace mp
+
+struct mp_ctx {
+  int curve = 0;
+  int device = 0;
+  mp::rt::Stream stream{};
+  mp::Profiler prof;
+};
+
+#define MP_RUN(NAME, C, nx, ny, args)                      \
+  do {                                                     \
+    ctx->prof.begin(#NAME, ctx->stream);                   \
+    MP_LAUNCH(NAME, C, ctx->stream, (nx), (ny), (args));   \
+    ctx->prof.end(ctx->stream);                            \
+  } while (0)
+
+struct mp_table {
+  mp_ctx* ctx = nullptr;
+  uint32_t m = 0, n = 0, N = 0;
+  virtual ~mp_table() {}
+  virtual void reserve(size_t B) = 0;
+  virtual void prove_dev(size_t B, const uint8_t* decks, const uint8_t* rho, const uint32_t* perm, const uint8_t* seeds,
+                         uint8_t* out_decks, uint8_t* out_proofs, int32_t* status) = 0;
+  virtual void verify_dev(size_t B, const uint8_t* decks, const uint8_t* shuf, const uint8_t* proofs, int32_t* status) = 0;
+  virtual void remask_host(size_t count, const uint8_t* cards, const uint8_t* rho, uint8_t* out) = 0;
+  virtual void msm_host(size_t n_msm, size_t k, const uint8_t* scalars, const uint8_t* points, uint8_t* out) = 0;
+  virtual void commit_host(size_t count, size_t len, const uint8_t* values, const uint8_t* r, uint8_t* out) = 0;
+  virtual void census(uint64_t* pt, uint64_t* vt, uint64_t* po, uint64_t* vo) = 0;
+};
+
+namespace mp {
+
+static const uint32_t FCHUNK = 8;     // fixed-base terms per sub-job   (8 x 32 mixed additions)
+static const uint32_t VCHUNK = 13;    // variable-base terms per sub-job (13 x 51 mixed additions + 255 doublings)
+static const uint32_t NORM_CHUNK = 16;
+
+struct PhaseDev {
+  DevBuf<Term> recode, tables, fterms, vterms, cterms;
+  DevBuf<Job> fjobs, vjobs, cjobs;
+  uint32_t n_recode = 0, n_tables = 0, n_f = 0, n_v = 0, n_c = 0, n_tslots = 0, n_dslots = 0;
+  std::vector<std::pair<uint32_t, uint32_t>> normalize;
+  void upload(const Phase& ph, rt::Stream s) {
+    recode.upload(ph.recode, s);
+    tables.upload(ph.tables, s);
+    fterms.upload(ph.fterms, s);
+    vterms.upload(ph.vterms, s);
+    cterms.upload(ph.cterms, s);
+    fjobs.upload(ph.fjobs, s);
+    vjobs.upload(ph.vjobs, s);
+    cjobs.upload(ph.cjobs, s);
+    n_recode = (uint32_t)ph.recode.size();
+    n_tables = (uint32_t)ph.tables.size();
+    n_f = (uint32_t)ph.fjobs.size();
+    n_v = (uint32_t)ph.vjobs.size();
+    n_c = (uint32_t)ph.cjobs.size();
+    n_tslots = ph.n_tslots;
+    n_dslots = ph.n_dslots;
+    normalize = ph.normalize;
+  }
+};
+
+// per-batch arenas
+struct Workspace {
+  uint32_t Bpad = 0;
+  uint32_t nS = 0, nP = 0, nJ = 0, nD = 0, nT = 0, nwin = 0, stage_words = 0;
+  DevBuf<uint32_t> S, P, J, T, TJ, NS, stage, seed, direct;
+  DevBuf<int8_t> D;
+  DevBuf<int32_t> status;
+  void ensure(uint32_t B, uint32_t nS_, uint32_t nP_, uint32_t nJ_, uint32_t nD_, uint32_t nT_, uint32_t nwin_,
+              uint32_t stage_words_, rt::Stream s) {
+    uint32_t need = (B + 63u) & ~63u;
+    if (need <= Bpad && nS_ <= nS && nP_ <= nP && nJ_ <= nJ && nD_ <= nD && nT_ <= nT && stage_words_ <= stage_words) return;
+    Bpad = std::max(Bpad, need);
+    nS = std::max(nS, nS_); nP = std::max(nP, nP_); nJ = std::max(nJ, nJ_); nD = std::max(nD, nD_); nT = std::max(nT, nT_);
+    nwin = nwin_;
+    stage_words = std::max(stage_words, stage_words_);
+    // re-allocate everything (capacity grows monotonically); zero-filled so padding lanes hold valid data
+    S.n = P.n = J.n = T.n = TJ.n = NS.n = stage.n = seed.n = direct.n = 0;
+    D.n = 0;
+    status.n = 0;
+    S.alloc((size_t)nS * Bpad * 8, s);
+    P.alloc((size_t)nP * Bpad * 16, s);
+    J.alloc((size_t)nJ * Bpad * 24, s);
+    D.alloc((size_t)std::max(nD, 1u) * nwin * Bpad, s);
+    T.alloc((size_t)std::max(nT, 1u) * VB_ENTRIES * Bpad * 16, s);
+    TJ.alloc((size_t)std::max(nT, 1u) * VB_ENTRIES * Bpad * 24, s);
+    size_t norm_max = std::max((size_t)nT * VB_ENTRIES, (size_t)nP) * Bpad;
+    NS.alloc(norm_max * 8, s);
+    stage.alloc((size_t)stage_words * Bpad, s);
+    seed.alloc((size_t)8 * Bpad, s);
+    direct.alloc(Bpad, s);
+    status.alloc(Bpad, s);
+  }
+};
+
+template <class C>
+struct Table : mp_table {
+  typedef typename C::FqP F;
+  typedef typename C::FrP R;
+
+  ProvePlan pplan;
+  VerifyPlan vplan;
+  PhaseDev pph[4], vph;
+  DevBuf<uint32_t> draws;
+  DevBuf<ProofElem> pwire, vwire;
+  DevBuf<uint32_t> fbpts;    // (n+5) affine base points
+  DevBuf<uint32_t> FB;       // fixed-base window tables
+  Workspace ws;
+  uint32_t nwin = 0;
+  uint32_t init_seed[8];
+  // staging for the host-buffer API
+  DevBuf<uint8_t> io_a, io_b, io_c, io_d, io_e, io_f;
+  DevBuf<int32_t> io_status;
+
+  // ---------------------------------------------------------------- construction
+  static bool wire_point_host(const uint8_t* p, Aff<C>& out) {
+    // host-side use of the same MP_HD conversion (alignment: copy to an aligned temp)
+    alignas(8) uint8_t tmp[64];
+    memcpy(tmp, p, 64);
+    return wire_to_aff<C>(tmp, out);
+  }
+
+  int init(mp_ctx* c, uint32_t m_, uint32_t n_, const uint8_t* params, const uint8_t* pk) {
+    ctx = c;
+    m = m_; n = n_; N = m * n;
+    nwin = (uint32_t)vb_windows(R::BITS);
+    FixedBases fb{n};
+    std::vector<Aff<C>> bases(fb.count());
+    bool ok = true;
+    Aff<C> G, H, gen, pkp;
+    ok &= wire_point_host(params, G);
+    for (uint32_t j = 0; j < n; ++j) ok &= wire_point_host(params + 64 * (1 + j), bases[fb.ck(j)]);
+    ok &= wire_point_host(params + 64 * (1 + n), H);
+    ok &= wire_point_host(params + 64 * (2 + n), gen);
+    ok &= wire_point_host(pk, pkp);
+    if (!ok) return fail(MP_ERR_BAD_ENCODING, "parameters / shared key: bad point encoding");
+    bases[fb.H()] = H; bases[fb.G()] = G; bases[fb.pk()] = pkp; bases[fb.gen()] = gen;
+    Jac<C> gs = jac_inf<C>();
+    for (uint32_t j = 0; j < n; ++j) gs = jac_madd<C>(gs, bases[fb.ck(j)]);
+    if (jac_is_inf<C>(gs)) {
+      bases[fb.gsum()] = aff_inf<C>();
+    } else {
+      bases[fb.gsum()] = jac_to_aff_with_zinv<C>(gs, fe_inv<F>(gs.Z));
+    }
+    for (uint32_t i = 0; i < fb.count(); ++i)
+      if (i != fb.gsum() && aff_is_inf<C>(bases[i])) return fail(MP_ERR_BAD_ENCODING, "parameters: a base is the point at infinity");
+
+    rt::Stream s = ctx->stream;
+    std::vector<uint32_t> flat(fb.count() * 16);
+    for (uint32_t i = 0; i < fb.count(); ++i) {
+      memcpy(&flat[i * 16], bases[i].x.v, 32);
+      memcpy(&flat[i * 16 + 8], bases[i].y.v, 32);
+    }
+    fbpts.upload(flat, s);
+    build_fixed_tables(fb.count());
+
+    pplan = make_prove_plan(m, n, FCHUNK, VCHUNK);
+    vplan = make_verify_plan(m, n, FCHUNK, VCHUNK);
+    for (int i = 0; i < 4; ++i) pph[i].upload(pplan.ph[i], s);
+    vph.upload(vplan.ph, s);
+    draws.upload(pplan.draws, s);
+    pwire.upload(pplan.wire, s);
+    vwire.upload(vplan.wire, s);
+    // Blake2s("Shuffle Proof")  [REF mod.rs:84]
+    {
+      Blake2sState st;
+      blake2s_init(st);
+      uint32_t mblk[16] = {0};
+      memcpy(mblk, "Shuffle Proof", 13);
+      blake2s_compress(st, mblk, 13, true);
+      memcpy(init_seed, st.h, 32);
+    }
+    rt::stream_sync(s);
+    return MP_OK;
+  }
+
+  void normalize_flat(const uint32_t* src, uint32_t* dst, uint32_t* scratch, size_t count) {
+    if (!count) return;
+    NormArgs a{src, dst, scratch, (uint32_t)count, (uint32_t)((count + NORM_CHUNK - 1) / NORM_CHUNK), NORM_CHUNK};
+    MP_RUN(k_normalize, C, a.nthreads, 1, a);
+  }
+
+  void build_fixed_tables(uint32_t nb) {
+    rt::Stream s = ctx->stream;
+    DevBuf<uint32_t> WJ, W, EJ, scratch;
+    const size_t nwinpts = (size_t)nb * FB_WINDOWS, nent = nwinpts * FB_ENTRIES;
+    WJ.alloc(nwinpts * 24, s);
+    W.alloc(nwinpts * 16, s);
+    EJ.alloc(nent * 24, s);
+    scratch.alloc(nent * 8, s);
+    FB.alloc(nent * 16, s);
+    FbWinArgs wa{fbpts.p, WJ.p};
+    MP_RUN(k_fb_windows, C, nb, 1, wa);
+    normalize_flat(WJ.p, W.p, scratch.p, nwinpts);
+    FbFillArgs fa{W.p, EJ.p};
+    MP_RUN(k_fb_fill, C, (uint32_t)nwinpts, 1, fa);
+    normalize_flat(EJ.p, FB.p, scratch.p, nent);
+    rt::stream_sync(s);
+  }
+
+  uint32_t stage_words_needed() const {
+    size_t bytes = (size_t)(3 + n + 1 + 4 * N) * 65 + 16 + 32;
+    bytes = std::max(bytes, (size_t)(1 + 6 * m) * 65 + 32);
+    return (uint32_t)(bytes / 4 + 4);
+  }
+
+  void reserve(size_t B) override {
+    uint32_t nS = std::max(pplan.lay.nS, vplan.lay.nS), nP = std::max(pplan.lay.nP, vplan.lay.nP);
+    uint32_t nJ = std::max(pplan.nJ, vplan.nJ), nD = vph.n_dslots, nT = vph.n_tslots;
+    for (int i = 0; i < 4; ++i) {
+      nD = std::max(nD, pph[i].n_dslots);
+      nT = std::max(nT, pph[i].n_tslots);
+    }
+    ws.ensure((uint32_t)B, nS, nP, nJ, nD, nT, nwin, stage_words_needed(), ctx->stream);
+  }
+
+  // ---------------------------------------------------------------- one dependency level of group work
+  void run_phase(PhaseDev& ph, Workspace& w, uint32_t B) {
+    if (ph.n_recode) {
+      RecodeArgs a{w.S.p, w.D.p, ph.recode.p, w.Bpad, nwin};
+      MP_RUN(k_recode, C, B, ph.n_recode, a);
+    }
+    if (ph.n_tables) {
+      TableArgs a{w.P.p, w.TJ.p, ph.tables.p, w.Bpad};
+      MP_RUN(k_table, C, B, ph.n_tables, a);
+      normalize_flat(w.TJ.p, w.T.p, w.NS.p, (size_t)ph.n_tslots * VB_ENTRIES * w.Bpad);
+    }
+    if (ph.n_f) {
+      FixedArgs a{w.S.p, w.J.p, FB.p, ph.fjobs.p, ph.fterms.p, w.Bpad};
+      MP_RUN(k_fixed_msm, C, B, ph.n_f, a);
+    }
+    if (ph.n_v) {
+      VarArgs a{w.D.p, w.T.p, w.J.p, ph.vjobs.p, ph.vterms.p, w.Bpad, nwin};
+      MP_RUN(k_var_msm, C, B, ph.n_v, a);
+    }
+    if (ph.n_c) {
+      CombineArgs a{w.J.p, w.P.p, ph.cjobs.p, ph.cterms.p, w.Bpad};
+      MP_RUN(k_combine, C, B, ph.n_c, a);
+    }
+    for (auto& r : ph.normalize)
+      normalize_flat(w.J.p + j_off(r.first, w.Bpad, 0), w.P.p + p_off(r.first, w.Bpad, 0), w.NS.p, (size_t)r.second * w.Bpad);
+  }
+
+  FsStatementArgs statement_args(Workspace& w, uint32_t p_deck, uint32_t p_shuf, uint32_t p_cA, uint32_t s_x) {
+    FsStatementArgs a{};
+    a.f = FsDev{w.stage.p, w.seed.p, w.Bpad};
+    a.S = w.S.p;
+    a.P = w.P.p;
+    a.fbpts = fbpts.p;
+    memcpy(a.init_seed, init_seed, 32);
+    a.m = m; a.n = n; a.N = N;
+    a.p_deck = p_deck; a.p_shuf = p_shuf; a.p_cA = p_cA; a.s_x = s_x;
+    return a;
+  }
+
+  // ---------------------------------------------------------------- prove
+  void prove_dev(size_t B_, const uint8_t* decks, const uint8_t* rho, const uint32_t* perm, const uint8_t* seeds,
+                 uint8_t* out_decks, uint8_t* out_proofs, int32_t* status) override {
+    const uint32_t B = (uint32_t)B_;
+    reserve(B);
+    Workspace& w = ws;
+    const ProveLay& l = pplan.lay;
+    rt::Stream s = ctx->stream;
+    FixedBases fb{n};
+    rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
+    {
+      LoadPointsArgs a{decks, w.P.p, w.status.p, w.Bpad, 2 * N, l.deck};
+      MP_RUN(k_load_points, C, B, 2 * N, a);
+      LoadScalarsArgs sa{rho, w.S.p, w.status.p, w.Bpad, N, l.rho};
+      MP_RUN(k_load_scalars, C, B, N, sa);
+      ProveInitArgs ia{w.S.p, w.status.p, perm, seeds, draws.p, l, w.Bpad};
+      MP_RUN(k_prove_init, C, B, 1, ia);
+      RemaskArgs ra{w.S.p, w.P.p, w.J.p, FB.p, perm, w.Bpad, N, l.rho, l.deck, l.shuf, fb.G(), fb.pk()};
+      MP_RUN(k_remask, C, B, 2 * N, ra);
+    }
+    run_phase(pph[0], w, B);
+    {
+      FsStatementArgs a = statement_args(w, l.deck, l.shuf, l.cA, l.x);
+      MP_RUN(k_fs_round1, C, B, 1, a);
+    }
+    ProveScalArgs sc{w.S.p, perm, l, w.Bpad};
+    MP_RUN(k_prove_scal1, C, B, 1, sc);
+    run_phase(pph[1], w, B);
+    const FsDev f{w.stage.p, w.seed.p, w.Bpad};
+    {
+      FsRoundArgs a{};
+      a.f = f; a.S = w.S.p; a.P = w.P.p;
+      a.step[0] = FsStep{l.cB, m, 0, 0, l.y, l.z};
+      a.nsteps = 1;
+      a.copy_from = NO_SLOT; a.copy_to = NO_SLOT;
+      MP_RUN(k_fs_round, C, B, 1, a);
+    }
+    MP_RUN(k_prove_scal2, C, B, 1, sc);
+    run_phase(pph[2], w, B);
+    {
+      FsRoundArgs a{};
+      a.f = f; a.S = w.S.p; a.P = w.P.p;
+      a.copy_from = l.cb; a.copy_to = l.hB + m - 1;
+      a.step[0] = FsStep{l.cb, 1, 0, 0, NO_SLOT, NO_SLOT};
+      a.step[1] = FsStep{l.hB, m, 0, 0, l.hx, l.hy};
+      a.nsteps = 2;
+      MP_RUN(k_fs_round, C, B, 1, a);
+    }
+    MP_RUN(k_prove_scal3, C, B, 1, sc);
+    run_phase(pph[3], w, B);
+    {
+      FsRoundArgs a{};
+      a.f = f; a.S = w.S.p; a.P = w.P.p;
+      a.copy_from = NO_SLOT; a.copy_to = NO_SLOT;
+      a.step[0] = FsStep{l.zcA0, 2 + 2 * m + 1, 0, 0, l.zx, NO_SLOT};
+      a.step[1] = FsStep{l.svcd, 3, 0, 0, l.svx, NO_SLOT};
+      a.step[2] = FsStep{l.mecA0, 1 + 6 * m, 0, 0, l.mx, NO_SLOT};
+      a.nsteps = 3;
+      MP_RUN(k_fs_round, C, B, 1, a);
+    }
+    MP_RUN(k_prove_scal4, C, B, 1, sc);
+    {
+      StorePointsArgs a{out_decks, w.P.p, w.Bpad, 2 * N, l.shuf};
+      MP_RUN(k_store_points, C, B, 2 * N, a);
+      ProofIoArgs pa{out_proofs, w.S.p, w.P.p, w.status.p, pwire.p, w.Bpad, (uint32_t)proof_size_bytes(m, n)};
+      MP_RUN(k_store_proof, C, B, (uint32_t)pplan.wire.size(), pa);
+    }
+    rt::d2d(status, w.status.p, (size_t)B * 4, s);
+  }
+
+  // ---------------------------------------------------------------- verify
+  void verify_dev(size_t B_, const uint8_t* decks, const uint8_t* shuf, const uint8_t* proofs, int32_t* status) override {
+    const uint32_t B = (uint32_t)B_;
+    reserve(B);
+    Workspace& w = ws;
+    const VerifyLay& l = vplan.lay;
+    rt::Stream s = ctx->stream;
+    rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
+    {
+      LoadPointsArgs a{decks, w.P.p, w.status.p, w.Bpad, 2 * N, l.deck};
+      MP_RUN(k_load_points, C, B, 2 * N, a);
+      LoadPointsArgs b{shuf, w.P.p, w.status.p, w.Bpad, 2 * N, l.shuf};
+      MP_RUN(k_load_points, C, B, 2 * N, b);
+      ProofIoArgs pa{const_cast<uint8_t*>(proofs), w.S.p, w.P.p, w.status.p, vwire.p, w.Bpad, (uint32_t)proof_size_bytes(m, n)};
+      MP_RUN(k_load_proof, C, B, (uint32_t)vplan.wire.size(), pa);
+    }
+    {
+      VerifyFsArgs a{};
+      a.st = statement_args(w, l.deck, l.shuf, l.cA, l.x);
+      a.l = l;
+      MP_RUN(k_verify_fs, C, B, 1, a);
+      VerifyScalArgs sa{w.S.p, w.P.p, w.direct.p, l, vplan.cm, w.Bpad};
+      MP_RUN(k_verify_scal, C, B, 1, sa);
+    }
+    run_phase(vph, w, B);
+    {
+      VerdictArgs a{w.J.p, w.direct.p, w.status.p, w.Bpad, l.chk_first};
+      MP_RUN(k_verdict, C, B, 1, a);
+    }
+    rt::d2d(status, w.status.p, (size_t)B * 4, s);
+  }
+
+  // ---------------------------------------------------------------- building blocks (ad-hoc plans)
+  struct Adhoc {
+    Phase ph;
+    PhaseDev dev;
+    Workspace w;
+  };
+  void run_adhoc(Adhoc& ad, uint32_t B, uint32_t nS, uint32_t nP, uint32_t nJ) {
+    ad.dev.upload(ad.ph, ctx->stream);
+    ad.w.ensure(B, nS, nP, nJ, ad.ph.n_dslots, ad.ph.n_tslots, nwin, 4, ctx->stream);
+  }
+
+  void remask_host(size_t count, const uint8_t* cards, const uint8_t* rho, uint8_t* out) override {
+    // `count` cards = `count` batch lanes with N = 1
+    rt::Stream s = ctx->stream;
+    const uint32_t B = (uint32_t)count;
+    Adhoc ad;
+    run_adhoc(ad, B, 1, 4, 4);
+    Workspace& w = ad.w;
+    DevBuf<uint8_t> din, drho, dout;
+    din.alloc(count * 128, s, false); drho.alloc(count * 32, s, false); dout.alloc(count * 128, s, false);
+    rt::h2d(din.p, cards, count * 128, s);
+    rt::h2d(drho.p, rho, count * 32, s);
+    rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
+    FixedBases fb{n};
+    LoadPointsArgs a{din.p, w.P.p, w.status.p, w.Bpad, 2, 0};
+    MP_RUN(k_load_points, C, B, 2, a);
+    LoadScalarsArgs sa{drho.p, w.S.p, w.status.p, w.Bpad, 1, 0};
+    MP_RUN(k_load_scalars, C, B, 1, sa);
+    RemaskArgs ra{w.S.p, w.P.p, w.J.p, FB.p, nullptr, w.Bpad, 1, 0, 0, 2, fb.G(), fb.pk()};
+    MP_RUN(k_remask, C, B, 2, ra);
+    normalize_flat(w.J.p + j_off(2, w.Bpad, 0), w.P.p + p_off(2, w.Bpad, 0), w.NS.p, (size_t)2 * w.Bpad);
+    StorePointsArgs st{dout.p, w.P.p, w.Bpad, 2, 2};
+    MP_RUN(k_store_points, C, B, 2, st);
+    std::vector<int32_t> hs(B);
+    rt::d2h(out, dout.p, count * 128, s);
+    rt::d2h(hs.data(), w.status.p, (size_t)B * 4, s);
+    rt::stream_sync(s);
+    for (auto v : hs)
+      if (v < 0) throw std::invalid_argument("remask: bad encoding in input");
+  }
+
+  void msm_host(size_t n_msm, size_t k, const uint8_t* scalars, const uint8_t* points, uint8_t* out) override {
+    rt::Stream s = ctx->stream;
+    const uint32_t B = (uint32_t)n_msm, K = (uint32_t)k;
+    Adhoc ad;
+    uint32_t next_partial = K + 1;
+    {
+      PhaseBuilder pb(ad.ph, next_partial, FCHUNK, VCHUNK);
+      pb.begin(K);
+      for (uint32_t t = 0; t < K; ++t) pb.var(t, t);
+      pb.end();
+      pb.normalize(K, 1);
+    }
+    run_adhoc(ad, B, K, K + 1, next_partial);
+    Workspace& w = ad.w;
+    DevBuf<uint8_t> dsc, dpt, dout;
+    dsc.alloc(n_msm * k * 32, s, false); dpt.alloc(n_msm * k * 64, s, false); dout.alloc(n_msm * 64, s, false);
+    rt::h2d(dsc.p, scalars, n_msm * k * 32, s);
+    rt::h2d(dpt.p, points, n_msm * k * 64, s);
+    rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
+    LoadPointsArgs la{dpt.p, w.P.p, w.status.p, w.Bpad, K, 0};
+    MP_RUN(k_load_points, C, B, K, la);
+    LoadScalarsArgs sa{dsc.p, w.S.p, w.status.p, w.Bpad, K, 0};
+    MP_RUN(k_load_scalars, C, B, K, sa);
+    run_phase(ad.dev, w, B);
+    StorePointsArgs so{dout.p, w.P.p, w.Bpad, 1, K};
+    MP_RUN(k_store_points, C, B, 1, so);
+    std::vector<int32_t> hs(B);
+    rt::d2h(out, dout.p, n_msm * 64, s);
+    rt::d2h(hs.data(), w.status.p, (size_t)B * 4, s);
+    rt::stream_sync(s);
+    for (auto v : hs)
+      if (v < 0) throw std::invalid_argument("msm: bad encoding in input");
+  }
+
+  void commit_host(size_t count, size_t len, const uint8_t* values, const uint8_t* r, uint8_t* out) override {
+    rt::Stream s = ctx->stream;
+    const uint32_t B = (uint32_t)count, L = (uint32_t)len;
+    FixedBases fb{n};
+    Adhoc ad;
+    uint32_t next_partial = 1;
+    {
+      PhaseBuilder pb(ad.ph, next_partial, FCHUNK, VCHUNK);
+      pb.begin(0);
+      for (uint32_t t = 0; t < L; ++t) pb.fixed(t, fb.ck(t));
+      pb.fixed(L, fb.H());
+      pb.end();
+      pb.normalize(0, 1);
+    }
+    run_adhoc(ad, B, L + 1, 1, next_partial);
+    Workspace& w = ad.w;
+    DevBuf<uint8_t> dv, dr, dout;
+    dv.alloc(std::max<size_t>(count * len * 32, 4), s, false); dr.alloc(count * 32, s, false); dout.alloc(count * 64, s, false);
+    if (len) rt::h2d(dv.p, values, count * len * 32, s);
+    rt::h2d(dr.p, r, count * 32, s);
+    rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
+    if (L) {
+      LoadScalarsArgs sa{dv.p, w.S.p, w.status.p, w.Bpad, L, 0};
+      MP_RUN(k_load_scalars, C, B, L, sa);
+    }
+    LoadScalarsArgs sr{dr.p, w.S.p, w.status.p, w.Bpad, 1, L};
+    MP_RUN(k_load_scalars, C, B, 1, sr);
+    run_phase(ad.dev, w, B);
+    StorePointsArgs so{dout.p, w.P.p, w.Bpad, 1, 0};
+    MP_RUN(k_store_points, C, B, 1, so);
+    std::vector<int32_t> hs(B);
+    rt::d2h(out, dout.p, count * 64, s);
+    rt::d2h(hs.data(), w.status.p, (size_t)B * 4, s);
+    rt::stream_sync(s);
+    for (auto v : hs)
+      if (v < 0) throw std::invalid_argument("commit: bad encoding in input");
+  }
+
+  void census(uint64_t* pt, uint64_t* vt, uint64_t* po, uint64_t* vo) override {
+    auto count = [&](const Phase& ph, uint64_t& terms, uint64_t& ops) {
+      terms += ph.fterms.size() + ph.vterms.size();
+      ops += (uint64_t)ph.fterms.size() * FB_WINDOWS;                       // mixed additions
+      ops += (uint64_t)ph.vterms.size() * nwin;                             // mixed additions
+      ops += (uint64_t)ph.vjobs.size() * (nwin - 1) * VB_WINDOW_BITS;       // doublings
+      ops += (uint64_t)ph.tables.size() * (VB_ENTRIES - 1);                 // table construction
+      ops += ph.cterms.size();                                              // combines
+    };
+    uint64_t t = 0, o = 0;
+    for (int i = 0; i < 4; ++i) count(pplan.ph[i], t, o);
+    t += 2 * N;
+    o += (uint64_t)2 * N * (FB_WINDOWS + 1);   // remask
+    *pt = t; *po = o;
+    t = 0; o = 0;
+    count(vplan.ph, t, o);
+    *vt = t; *vo = o;
+  }
+};
+
+// host-side DLCards::setup: k * G_std with the MP_HD group law (a few dozen scalar-muls, once per table)
+template <class C>
+static int setup_host(uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out) {
+  typedef typename C::FqP F;
+  typedef typename C::FrP R;
+  uint32_t key[8];
+  memcpy(key, seed, 32);
+  FrStream st;
+  frstream_init(st, key);
+  Aff<C> g;
+  memcpy(g.x.v, C::GX_MONT, 32);
+  memcpy(g.y.v, C::GY_MONT, 32);
+  for (uint32_t i = 0; i < n + 3; ++i) {
+    Fe<R> kf = frstream_next<R>(st);
+    uint32_t k[8];
+    fe_to_canonical<R>(kf, k);
+    Jac<C> acc = jac_inf<C>();
+    for (int bit = 255; bit >= 0; --bit) {
+      acc = jac_dbl<C>(acc);
+      if ((k[bit >> 5] >> (bit & 31)) & 1u) acc = jac_madd<C>(acc, g);
+    }
+    Aff<C> a = jac_is_inf<C>(acc) ? aff_inf<C>() : jac_to_aff_with_zinv<C>(acc, fe_inv<F>(acc.Z));
+    alignas(8) uint8_t tmp[64];
+    aff_to_wire<C>(a, tmp);
+    memcpy(out + 64 * i, tmp, 64);
+  }
+  return MP_OK;
+}
+
+}  // namespace mp
+
+using namespace mp;
+
+#define MP_TRY try {
+#define MP_CATCH                                                                     \
+  }                                                                                  \
+  catch (const std::invalid_argument& e) { return fail(MP_ERR_BAD_ENCODING, e.what()); } \
+  catch (const std::exception& e) { return fail(MP_ERR_INTERNAL, e.what()); }
+
+extern "C" {
+
+const char* mp_last_error(void) { return g_err.c_str(); }
+const char* mp_check_name(int code) {
+  switch (code) {
+    case 0: return "Ok";
+    case 1: return "Hadamard Product (5.1)";
+    case 2: return "Zero Argument (5.2)";
+    case 3: return "Single Value Product (5.3)";
+    case 4: return "Multi-Exponentiation Argument (4)";
+    case MP_ERR_BAD_ENCODING: return "IoError: bad encoding";
+    case MP_ERR_BAD_PERMUTATION: return "IoError: not a permutation";
+    case MP_ERR_BAD_ARGUMENT: return "IoError: bad argument";
+    case MP_ERR_NO_DEVICE: return "IoError: no MI355X device";
+    default: return "IoError: internal";
+  }
+}
+size_t mp_proof_size(uint32_t m, uint32_t n) { return proof_size_bytes(m, n); }
+size_t mp_params_size(uint32_t n) { return (size_t)(n + 3) * 64; }
+
+int mp_ctx_create(int curve_id, int device, mp_ctx** out) {
+  if (!out) return fail(MP_ERR_BAD_ARGUMENT, "null out pointer");
+  if (curve_id < 0 || curve_id > 2) return fail(MP_ERR_BAD_ARGUMENT, "unknown curve id");
+  MP_TRY
+  int ndev = rt::device_count();
+  if (ndev <= 0 || device < 0 || device >= ndev)
+    return fail(MP_ERR_NO_DEVICE, "no HIP device: libmpshuffle has no CPU path (runtime " MP_RT_NAME ")");
+  rt::set_device(device);
+  mp_ctx* c = new mp_ctx();
+  c->curve = curve_id;
+  c->device = device;
+  c->stream = rt::stream_create();
+  *out = c;
+  return MP_OK;
+  MP_CATCH
+}
+void mp_ctx_destroy(mp_ctx* ctx) {
+  if (!ctx) return;
+  rt::stream_destroy(ctx->stream);
+  delete ctx;
+}
+
+int mp_setup(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out_params) {
+  if (!ctx || !seed || !out_params || m < 2 || n < 2) return fail(MP_ERR_BAD_ARGUMENT, "mp_setup: bad argument");
+  MP_TRY
+  switch (ctx->curve) {
+    case 0: return setup_host<Stark>(m, n, seed, out_params);
+    case 1: return setup_host<Bn254>(m, n, seed, out_params);
+    default: return setup_host<Secp256k1>(m, n, seed, out_params);
+  }
+  MP_CATCH
+}
+
+int mp_table_create(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, const uint8_t* shared_key, mp_table** out) {
+  if (!ctx || !params || !shared_key || !out) return fail(MP_ERR_BAD_ARGUMENT, "mp_table_create: null pointer");
+  if (m < 2 || n < 2 || (uint64_t)m * n > 4096) return fail(MP_ERR_BAD_ARGUMENT, "mp_table_create: need m >= 2, n >= 2, m*n <= 4096");
+  MP_TRY
+  rt::set_device(ctx->device);
+  int rc;
+  mp_table* t = nullptr;
+  switch (ctx->curve) {
+    case 0: { auto* p = new Table<Stark>(); rc = p->init(ctx, m, n, params, shared_key); t = p; break; }
+    case 1: { auto* p = new Table<Bn254>(); rc = p->init(ctx, m, n, params, shared_key); t = p; break; }
+    default: { auto* p = new Table<Secp256k1>(); rc = p->init(ctx, m, n, params, shared_key); t = p; break; }
+  }
+  if (rc != MP_OK) {
+    delete t;
+    return rc;
+  }
+  *out = t;
+  return MP_OK;
+  MP_CATCH
+}
+void mp_table_destroy(mp_table* t) { delete t; }
+
+int mp_reserve(mp_table* t, size_t B) {
+  if (!t || !B) return fail(MP_ERR_BAD_ARGUMENT, "mp_reserve: bad argument");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  t->reserve(B);
+  rt::stream_sync(t->ctx->stream);
+  return MP_OK;
+  MP_CATCH
+}
+
+int mp_shuffle_and_remask_batch_dev(mp_table* t, size_t B, const void* d_decks, const void* d_masking_factors,
+                                    const void* d_permutations, const void* d_prover_seeds, void* d_out_decks,
+                                    void* d_out_proofs, void* d_status) {
+  if (!t || !B || !d_decks || !d_masking_factors || !d_permutations || !d_prover_seeds || !d_out_decks || !d_out_proofs || !d_status)
+    return fail(MP_ERR_BAD_ARGUMENT, "mp_shuffle_and_remask_batch_dev: bad argument");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  t->prove_dev(B, (const uint8_t*)d_decks, (const uint8_t*)d_masking_factors, (const uint32_t*)d_permutations,
+               (const uint8_t*)d_prover_seeds, (uint8_t*)d_out_decks, (uint8_t*)d_out_proofs, (int32_t*)d_status);
+  return MP_OK;
+  MP_CATCH
+}
+int mp_verify_shuffle_batch_dev(mp_table* t, size_t B, const void* d_decks, const void* d_shuffled_decks,
+                                const void* d_proofs, void* d_status) {
+  if (!t || !B || !d_decks || !d_shuffled_decks || !d_proofs || !d_status)
+    return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_batch_dev: bad argument");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  t->verify_dev(B, (const uint8_t*)d_decks, (const uint8_t*)d_shuffled_decks, (const uint8_t*)d_proofs, (int32_t*)d_status);
+  return MP_OK;
+  MP_CATCH
+}
+int mp_sync(mp_ctx* ctx) {
+  if (!ctx) return fail(MP_ERR_BAD_ARGUMENT, "mp_sync: null");
+  MP_TRY
+  rt::stream_sync(ctx->stream);
+  return MP_OK;
+  MP_CATCH
+}
+
+int mp_shuffle_and_remask_batch(mp_table* t, size_t B, const uint8_t* decks, const uint8_t* masking_factors,
+                                const uint32_t* permutations, const uint8_t* prover_seeds, uint8_t* out_decks,
+                                uint8_t* out_proofs, int32_t* status) {
+  if (!t || !B || !decks || !masking_factors || !permutations || !prover_seeds || !out_decks || !out_proofs || !status)
+    return fail(MP_ERR_BAD_ARGUMENT, "mp_shuffle_and_remask_batch: bad argument");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  rt::Stream s = t->ctx->stream;
+  const size_t N = t->N, psz = proof_size_bytes(t->m, t->n);
+  DevBuf<uint8_t> dd, dr, ds, dod, dop;
+  DevBuf<uint32_t> dp;
+  DevBuf<int32_t> dst;
+  dd.alloc(B * N * 128, s, false); dr.alloc(B * N * 32, s, false); dp.alloc(B * N, s, false); ds.alloc(B * 32, s, false);
+  dod.alloc(B * N * 128, s, false); dop.alloc(B * psz, s, false); dst.alloc(B, s, false);
+  rt::h2d(dd.p, decks, B * N * 128, s);
+  rt::h2d(dr.p, masking_factors, B * N * 32, s);
+  rt::h2d(dp.p, permutations, B * N * 4, s);
+  rt::h2d(ds.p, prover_seeds, B * 32, s);
+  t->prove_dev(B, dd.p, dr.p, dp.p, ds.p, dod.p, dop.p, dst.p);
+  rt::d2h(out_decks, dod.p, B * N * 128, s);
+  rt::d2h(out_proofs, dop.p, B * psz, s);
+  rt::d2h(status, dst.p, B * 4, s);
+  rt::stream_sync(s);
+  return MP_OK;
+  MP_CATCH
+}
+int mp_verify_shuffle_batch(mp_table* t, size_t B, const uint8_t* decks, const uint8_t* shuffled_decks,
+                            const uint8_t* proofs, int32_t* status) {
+  if (!t || !B || !decks || !shuffled_decks || !proofs || !status) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_batch: bad argument");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  rt::Stream s = t->ctx->stream;
+  const size_t N = t->N, psz = proof_size_bytes(t->m, t->n);
+  DevBuf<uint8_t> dd, dsh, dpf;
+  DevBuf<int32_t> dst;
+  dd.alloc(B * N * 128, s, false); dsh.alloc(B * N * 128, s, false); dpf.alloc(B * psz, s, false); dst.alloc(B, s, false);
+  rt::h2d(dd.p, decks, B * N * 128, s);
+  rt::h2d(dsh.p, shuffled_decks, B * N * 128, s);
+  rt::h2d(dpf.p, proofs, B * psz, s);
+  t->verify_dev(B, dd.p, dsh.p, dpf.p, dst.p);
+  rt::d2h(status, dst.p, B * 4, s);
+  rt::stream_sync(s);
+  return MP_OK;
+  MP_CATCH
+}
+
+int mp_shuffle_and_remask(mp_table* t, const uint8_t* deck, const uint8_t* masking_factors, const uint32_t* permutation,
+                          const uint8_t prover_seed[32], uint8_t* out_deck, uint8_t* out_proof) {
+  int32_t st = 0;
+  int rc = mp_shuffle_and_remask_batch(t, 1, deck, masking_factors, permutation, prover_seed, out_deck, out_proof, &st);
+  if (rc != MP_OK) return rc;
+  if (st < 0) return fail(st, mp_check_name(st));
+  return st;
+}
+int mp_verify_shuffle(mp_table* t, const uint8_t* deck, const uint8_t* shuffled_deck, const uint8_t* proof, size_t proof_len) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle: null table");
+  if (proof_len != proof_size_bytes(t->m, t->n)) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle: wrong proof length");
+  int32_t st = 0;
+  int rc = mp_verify_shuffle_batch(t, 1, deck, shuffled_deck, proof, &st);
+  if (rc != MP_OK) return rc;
+  if (st < 0) return fail(st, mp_check_name(st));
+  return st;
+}
+
+int mp_remask_batch(mp_table* t, size_t count, const uint8_t* cards, const uint8_t* masking_factors, uint8_t* out) {
+  if (!t || !count || !cards || !masking_factors || !out) return fail(MP_ERR_BAD_ARGUMENT, "mp_remask_batch: bad argument");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  t->remask_host(count, cards, masking_factors, out);
+  return MP_OK;
+  MP_CATCH
+}
+int mp_msm(mp_table* t, size_t n_msm, size_t k, const uint8_t* scalars, const uint8_t* points, uint8_t* out) {
+  if (!t || !n_msm || !k || !scalars || !points || !out) return fail(MP_ERR_BAD_ARGUMENT, "mp_msm: bad argument");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  t->msm_host(n_msm, k, scalars, points, out);
+  return MP_OK;
+  MP_CATCH
+}
+int mp_commit_batch(mp_table* t, size_t count, size_t len, const uint8_t* values, const uint8_t* r, uint8_t* out) {
+  if (!t || !count || !r || !out || (len && !values) || len > t->n) return fail(MP_ERR_BAD_ARGUMENT, "mp_commit_batch: bad argument");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  t->commit_host(count, len, values, r, out);
+  return MP_OK;
+  MP_CATCH
+}
+
+int mp_profile_enable(mp_ctx* ctx, int on) {
+  if (!ctx) return fail(MP_ERR_BAD_ARGUMENT, "null ctx");
+  MP_TRY
+  rt::stream_sync(ctx->stream);
+  ctx->prof.report();
+  ctx->prof.on = on != 0;
+  return MP_OK;
+  MP_CATCH
+}
+int mp_profile_report(mp_ctx* ctx, char* buf, size_t buf_len) {
+  if (!ctx || !buf || !buf_len) return fail(MP_ERR_BAD_ARGUMENT, "mp_profile_report: bad argument");
+  MP_TRY
+  rt::stream_sync(ctx->stream);
+  std::string r = ctx->prof.report();
+  if (r.size() + 1 > buf_len) r.resize(buf_len - 1);
+  memcpy(buf, r.c_str(), r.size() + 1);
+  return MP_OK;
+  MP_CATCH
+}
+int mp_work_census(mp_table* t, uint64_t* prove_terms, uint64_t* verify_terms, uint64_t* prove_point_ops, uint64_t* verify_point_ops) {
+  if (!t || !prove_terms || !verify_terms || !prove_point_ops || !verify_point_ops) return fail(MP_ERR_BAD_ARGUMENT, "mp_work_census: bad argument");
+  t->census(prove_terms, verify_terms, prove_point_ops, verify_point_ops);
+  return MP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,326 @@
+// Group-arithmetic kernels of the shuffle engine (gfx950).  One lane = one (proof, job): the 64 lanes of
+// a wave run the SAME job of 64 consecutive proofs, so control flow is wave-uniform (only the window
+// digits differ per lane) and every arena access is a contiguous run (slot-major arenas, layout.hpp).
+//
+//   body_fixed_msm   sum_t k_t * B_t over bases shared by the whole batch (commit key, G, pk, gen):
+//                    8-bit windows over precomputed tables -> 32 mixed additions per term, no doublings.
+//                    Replaces the Pedersen commits / ElGamal encrypt scalar-muls inside the reference's
+//                    prover and verifier [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:409-415,437-442]
+//   body_remask      out[i] = deck[pi(i)] + rho_i * (G, pk)          [REF mod.rs:388-395, remasking.rs:16-18]
+//   body_var_msm     sum_t k_t * P_t over per-proof bases (the decks, proof elements): Straus interleaving
+//                    with signed 5-bit windows over per-proof 16-entry affine tables (ark-ec's
+//                    VariableBaseMSM bucket method is hopeless at 26..52 terms on a SIMT machine:
+//                    SURVEY.md App. D), doubling chain shared by the terms of a job.
+//   body_table / body_recode / body_combine / body_normalize: their supporting passes.
+#pragma once
+#include "curve.hpp"
+#include "layout.hpp"
+
+namespace mp {
+
+// ---- arena access (16-byte vector loads/stores; arenas are 256-byte aligned, elements 32/64/96 B) ----
+struct U4 {
+  uint32_t a, b, c, d;
+};
+MP_HD void ld_words8(const uint32_t* p, uint32_t v[8]) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 lo = q[0], hi = q[1];
+  v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+  v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+}
+MP_HD void st_words8(uint32_t* p, const uint32_t v[8]) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(v[0], v[1], v[2], v[3]);
+  q[1] = make_uint4(v[4], v[5], v[6], v[7]);
+}
+template <class F>
+MP_HD Fe<F> ld_fe(const uint32_t* p) {
+  Fe<F> r;
+  ld_words8(p, r.v);
+  return r;
+}
+template <class F>
+MP_HD void st_fe(uint32_t* p, const Fe<F>& a) {
+  st_words8(p, a.v);
+}
+template <class C>
+MP_HD Aff<C> ld_aff(const uint32_t* p) {
+  Aff<C> a;
+  ld_words8(p, a.x.v);
+  ld_words8(p + 8, a.y.v);
+  return a;
+}
+template <class C>
+MP_HD void st_aff(uint32_t* p, const Aff<C>& a) {
+  st_words8(p, a.x.v);
+  st_words8(p + 8, a.y.v);
+}
+template <class C>
+MP_HD Jac<C> ld_jac(const uint32_t* p) {
+  Jac<C> j;
+  ld_words8(p, j.X.v);
+  ld_words8(p + 8, j.Y.v);
+  ld_words8(p + 16, j.Z.v);
+  return j;
+}
+template <class C>
+MP_HD void st_jac(uint32_t* p, const Jac<C>& j) {
+  st_words8(p, j.X.v);
+  st_words8(p + 8, j.Y.v);
+  st_words8(p + 16, j.Z.v);
+}
+
+MP_HD size_t s_off(uint32_t slot, uint32_t Bpad, uint32_t b) { return ((size_t)slot * Bpad + b) * 8; }
+MP_HD size_t p_off(uint32_t slot, uint32_t Bpad, uint32_t b) { return ((size_t)slot * Bpad + b) * 16; }
+MP_HD size_t j_off(uint32_t slot, uint32_t Bpad, uint32_t b) { return ((size_t)slot * Bpad + b) * 24; }
+
+// ---- fixed-base MSM ---------------------------------------------------------------------------------
+struct FixedArgs {
+  const uint32_t* S;
+  uint32_t* J;
+  const uint32_t* FB;   // [base][window][entry(1..255)] affine, 16 words each
+  const Job* jobs;
+  const Term* terms;
+  uint32_t Bpad;
+};
+MP_HD const uint32_t* fb_entry(const uint32_t* FB, uint32_t base, uint32_t w, uint32_t d) {
+  return FB + (((size_t)base * FB_WINDOWS + w) * FB_ENTRIES + (d - 1)) * 16;
+}
+template <class C>
+MP_HD void body_fixed_msm(const FixedArgs& a, uint32_t b, uint32_t y) {
+  typedef typename C::FrP R;
+  const Job job = a.jobs[y];
+  Jac<C> acc = jac_inf<C>();
+  for (uint32_t t = 0; t < job.count; ++t) {
+    const Term term = a.terms[job.begin + t];
+    uint32_t k[8];
+    fe_to_canonical<R>(ld_fe<R>(a.S + s_off(term.s, a.Bpad, b)), k);
+#pragma unroll 1
+    for (uint32_t w = 0; w < (uint32_t)FB_WINDOWS; ++w) {
+      const uint32_t d = (k[w >> 2] >> ((w & 3) * 8)) & 0xFFu;
+      if (d) acc = jac_madd<C>(acc, ld_aff<C>(fb_entry(a.FB, term.b, w, d)));
+    }
+  }
+  st_jac<C>(a.J + j_off(job.out, a.Bpad, b), acc);
+}
+MP_KERNEL(k_fixed_msm, FixedArgs, body_fixed_msm)
+
+// ---- re-encryption (remask) -------------------------------------------------------------------------
+struct RemaskArgs {
+  const uint32_t* S;
+  const uint32_t* P;
+  uint32_t* J;
+  const uint32_t* FB;
+  const uint32_t* perm;   // [B][N] (caller's layout), may be null = identity
+  uint32_t Bpad, N;
+  uint32_t s_rho, p_deck, j_out;
+  uint32_t base_G, base_pk;
+};
+// y = 2*i + component
+template <class C>
+MP_HD void body_remask(const RemaskArgs& a, uint32_t b, uint32_t y) {
+  typedef typename C::FrP R;
+  const uint32_t i = y >> 1, comp = y & 1;
+  uint32_t src = a.perm ? a.perm[(size_t)b * a.N + i] : i;
+  if (src >= a.N) src = 0;  // an invalid permutation is reported through the status word; stay in bounds
+  uint32_t k[8];
+  fe_to_canonical<R>(ld_fe<R>(a.S + s_off(a.s_rho + i, a.Bpad, b)), k);
+  const uint32_t base = comp ? a.base_pk : a.base_G;
+  Jac<C> acc = jac_inf<C>();
+#pragma unroll 1
+  for (uint32_t w = 0; w < (uint32_t)FB_WINDOWS; ++w) {
+    const uint32_t d = (k[w >> 2] >> ((w & 3) * 8)) & 0xFFu;
+    if (d) acc = jac_madd<C>(acc, ld_aff<C>(fb_entry(a.FB, base, w, d)));
+  }
+  acc = jac_madd<C>(acc, ld_aff<C>(a.P + p_off(a.p_deck + 2 * src + comp, a.Bpad, b)));
+  st_jac<C>(a.J + j_off(a.j_out + y, a.Bpad, b), acc);
+}
+MP_KERNEL(k_remask, RemaskArgs, body_remask)
+
+// ---- signed-window recoding of the variable-base scalars -------------------------------------------
+struct RecodeArgs {
+  const uint32_t* S;
+  int8_t* D;            // [dslot][window][Bpad]
+  const Term* list;     // {S slot, digit slot}
+  uint32_t Bpad, nwin;
+};
+template <class C>
+MP_HD void body_recode(const RecodeArgs& a, uint32_t b, uint32_t y) {
+  typedef typename C::FrP R;
+  const Term t = a.list[y];
+  uint32_t k[9];
+  fe_to_canonical<R>(ld_fe<R>(a.S + s_off(t.s, a.Bpad, b)), k);
+  k[8] = 0;
+  int carry = 0;
+  for (uint32_t w = 0; w < a.nwin; ++w) {
+    const uint32_t bit = w * VB_WINDOW_BITS;
+    const uint32_t lo = k[bit >> 5] >> (bit & 31);
+    const uint32_t hi = (bit & 31) > 27 ? k[(bit >> 5) + 1] << (32 - (bit & 31)) : 0u;
+    int d = (int)((lo | hi) & 31u) + carry;
+    carry = 0;
+    if (d > 16) {
+      d -= 32;
+      carry = 1;
+    }
+    a.D[((size_t)t.b * a.nwin + w) * a.Bpad + b] = (int8_t)d;
+  }
+}
+MP_KERNEL(k_recode, RecodeArgs, body_recode)
+
+// ---- per-proof window tables: multiples 1P..16P in Jacobian form (normalised by k_normalize) --------
+struct TableArgs {
+  const uint32_t* P;
+  uint32_t* TJ;          // [tslot][entry][Bpad] Jacobian
+  const Term* list;      // {P slot, table slot}
+  uint32_t Bpad;
+};
+template <class C>
+MP_HD void body_table(const TableArgs& a, uint32_t b, uint32_t y) {
+  const Term t = a.list[y];
+  const Aff<C> p = ld_aff<C>(a.P + p_off(t.s, a.Bpad, b));
+  Jac<C> acc = jac_from_aff<C>(p);
+  uint32_t* out = a.TJ + j_off(t.b * VB_ENTRIES, a.Bpad, b);
+  st_jac<C>(out, acc);
+  acc = jac_dbl<C>(acc);
+  st_jac<C>(out + (size_t)a.Bpad * 24, acc);
+#pragma unroll 1
+  for (uint32_t e = 2; e < (uint32_t)VB_ENTRIES; ++e) {
+    acc = jac_madd<C>(acc, p);
+    st_jac<C>(out + (size_t)e * a.Bpad * 24, acc);
+  }
+}
+MP_KERNEL(k_table, TableArgs, body_table)
+
+// ---- variable-base MSM (Straus) -----------------------------------------------------------------------
+struct VarArgs {
+  const int8_t* D;
+  const uint32_t* T;     // [tslot][entry][Bpad] affine
+  uint32_t* J;
+  const Job* jobs;
+  const Term* terms;     // {digit slot, table slot}
+  uint32_t Bpad, nwin;
+};
+template <class C>
+MP_HD void body_var_msm(const VarArgs& a, uint32_t b, uint32_t y) {
+  const Job job = a.jobs[y];
+  Jac<C> acc = jac_inf<C>();
+#pragma unroll 1
+  for (int w = (int)a.nwin - 1; w >= 0; --w) {
+    if (w != (int)a.nwin - 1) {
+#pragma unroll 1
+      for (int q = 0; q < VB_WINDOW_BITS; ++q) acc = jac_dbl<C>(acc);
+    }
+#pragma unroll 1
+    for (uint32_t t = 0; t < job.count; ++t) {
+      const Term term = a.terms[job.begin + t];
+      const int d = a.D[((size_t)term.s * a.nwin + w) * a.Bpad + b];
+      if (d != 0) {
+        const uint32_t e = (uint32_t)(d < 0 ? -d : d) - 1;
+        Aff<C> q = ld_aff<C>(a.T + p_off(term.b * VB_ENTRIES + e, a.Bpad, b));
+        if (d < 0) q = aff_neg<C>(q);
+        acc = jac_madd<C>(acc, q);
+      }
+    }
+  }
+  st_jac<C>(a.J + j_off(job.out, a.Bpad, b), acc);
+}
+MP_KERNEL(k_var_msm, VarArgs, body_var_msm)
+
+// ---- combine partial sums ---------------------------------------------------------------------------
+struct CombineArgs {
+  uint32_t* J;
+  const uint32_t* P;
+  const Job* jobs;
+  const Term* terms;
+  uint32_t Bpad;
+};
+template <class C>
+MP_HD void body_combine(const CombineArgs& a, uint32_t b, uint32_t y) {
+  const Job job = a.jobs[y];
+  Jac<C> acc = jac_inf<C>();
+  for (uint32_t t = 0; t < job.count; ++t) {
+    const uint32_t s = a.terms[job.begin + t].s;
+    if (s & AFF_FLAG)
+      acc = jac_madd<C>(acc, ld_aff<C>(a.P + p_off(s & ~AFF_FLAG, a.Bpad, b)));
+    else
+      acc = jac_add<C>(acc, ld_jac<C>(a.J + j_off(s, a.Bpad, b)));
+  }
+  st_jac<C>(a.J + j_off(job.out, a.Bpad, b), acc);
+}
+MP_KERNEL(k_combine, CombineArgs, body_combine)
+
+// ---- batch normalisation Jacobian -> affine (Montgomery's trick, one inversion per `chunk` points) ----
+// Works on FLAT arrays: element e of the source is 24 words at src + 24 e; a slot range of an arena is
+// such an array.  Thread x owns elements x, x + nthreads, x + 2 nthreads, ... so accesses stay coalesced;
+// prefix products go through `scratch` (8 words per element, same indexing).
+struct NormArgs {
+  const uint32_t* src;
+  uint32_t* dst;
+  uint32_t* scratch;
+  uint32_t count, nthreads, chunk;
+};
+template <class C>
+MP_HD void body_normalize(const NormArgs& a, uint32_t x, uint32_t y) {
+  typedef typename C::FqP F;
+  Fe<F> prod = fe_one<F>();
+  uint32_t nmine = 0;
+  for (uint32_t i = 0; i < a.chunk; ++i) {
+    const size_t e = (size_t)x + (size_t)i * a.nthreads;
+    if (e >= a.count) break;
+    st_fe<F>(a.scratch + e * 8, prod);               // product of the Z's before this element
+    Fe<F> z = ld_fe<F>(a.src + e * 24 + 16);
+    if (!fe_is_zero(z)) prod = fe_mul<F>(prod, z);
+    nmine = i + 1;
+  }
+  Fe<F> inv = fe_inv<F>(prod);
+  for (uint32_t i = nmine; i-- > 0;) {
+    const size_t e = (size_t)x + (size_t)i * a.nthreads;
+    Jac<C> j = ld_jac<C>(a.src + e * 24);
+    Aff<C> out = aff_inf<C>();
+    if (!fe_is_zero(j.Z)) {
+      Fe<F> before = ld_fe<F>(a.scratch + e * 8);
+      Fe<F> zinv = fe_mul<F>(inv, before);
+      inv = fe_mul<F>(inv, j.Z);
+      out = jac_to_aff_with_zinv<C>(j, zinv);
+    }
+    st_aff<C>(a.dst + e * 16, out);
+  }
+}
+MP_KERNEL(k_normalize, NormArgs, body_normalize)
+
+// ---- construction of the fixed-base tables (setup time, once per table context) -------------------------
+// pass 1: window bases W_w = 2^(8w) * B for every base (thread = base), Jacobian out -> normalise
+struct FbWinArgs {
+  const uint32_t* bases;   // [nbases] affine
+  uint32_t* WJ;            // [base][window] Jacobian
+};
+template <class C>
+MP_HD void body_fb_windows(const FbWinArgs& a, uint32_t x, uint32_t y) {
+  Jac<C> acc = jac_from_aff<C>(ld_aff<C>(a.bases + (size_t)x * 16));
+  for (uint32_t w = 0; w < (uint32_t)FB_WINDOWS; ++w) {
+    st_jac<C>(a.WJ + ((size_t)x * FB_WINDOWS + w) * 24, acc);
+    for (int q = 0; q < FB_WINDOW_BITS; ++q) acc = jac_dbl<C>(acc);
+  }
+}
+MP_KERNEL(k_fb_windows, FbWinArgs, body_fb_windows)
+// pass 2: entries e * W_w, e = 1..255 (thread = (base, window)), Jacobian out -> normalise
+struct FbFillArgs {
+  const uint32_t* W;       // [base*window] affine
+  uint32_t* EJ;            // [base*window][255] Jacobian
+};
+template <class C>
+MP_HD void body_fb_fill(const FbFillArgs& a, uint32_t x, uint32_t y) {
+  const Aff<C> w = ld_aff<C>(a.W + (size_t)x * 16);
+  Jac<C> acc = jac_from_aff<C>(w);
+  uint32_t* out = a.EJ + (size_t)x * FB_ENTRIES * 24;
+  st_jac<C>(out, acc);
+  acc = jac_dbl<C>(acc);
+  st_jac<C>(out + 24, acc);
+  for (uint32_t e = 2; e < (uint32_t)FB_ENTRIES; ++e) {
+    acc = jac_madd<C>(acc, w);
+    st_jac<C>(out + (size_t)e * 24, acc);
+  }
+}
+MP_KERNEL(k_fb_fill, FbFillArgs, body_fb_fill)
+
+}  // namespace mp

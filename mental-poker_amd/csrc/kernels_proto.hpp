@@ -1,0 +1,720 @@
+// Protocol-side kernels of the shuffle engine: everything of the Bayer-Groth prover / verifier that is NOT
+// group arithmetic.  One lane = one proof (64 proofs per wave, all doing identical control flow).
+//   * wire <-> arena conversion with validation (canonical range, on-curve, permutation)
+//   * prover randomness: ChaCha20Rng(prover_seed) -> Fr::rand draws in transcript-v1 order
+//   * Fiat-Shamir rounds: FiatShamirRng<Blake2s> absorb / squeeze on device (hash.hpp)
+//   * the Fr vector algebra between rounds (powers, Hadamard products, bilinear map, responses)
+//   * verifier: challenge recomputation, MSM coefficients, direct checks and the verdict
+// Restates what `shuffle::ShuffleArgument::prove / verify` do between their group operations
+// [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:409-415, 437-442]; the algebra follows
+// Bayer-Groth sections 4-5.3 as frozen in oracle/py/mp_oracle.py (transcript v1).
+#pragma once
+#include "hash.hpp"
+#include "kernels_msm.hpp"
+
+namespace mp {
+
+enum : int32_t { ST_OK = 0, ST_BAD_ENCODING = -1, ST_BAD_PERMUTATION = -2 };
+
+MP_HD void status_fail(int32_t* status, uint32_t b, int32_t code) {
+  // several lanes may report the same proof; any of the (negative) codes is acceptable
+  status[b] = code;
+}
+
+// wire field element (32 B little-endian canonical) -> Montgomery; false if >= modulus
+template <class F>
+MP_HD bool wire_to_fe(const uint8_t* p, Fe<F>& out) {
+  uint32_t k[8];
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(p);   // wire buffers are 4-byte aligned (API contract)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) k[i] = q[i];
+  const bool ok = fe_canonical_in_range<F>(k);
+  out = fe_from_canonical<F>(k);
+  return ok;
+}
+template <class F>
+MP_HD void fe_to_wire(const Fe<F>& a, uint8_t* p) {
+  uint32_t k[8];
+  fe_to_canonical<F>(a, k);
+  uint32_t* q = reinterpret_cast<uint32_t*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) q[i] = k[i];
+}
+// wire point: x || y (64 B); infinity = 64 zero bytes.  false if a coordinate is out of range or the point
+// is not on the curve.
+template <class C>
+MP_HD bool wire_to_aff(const uint8_t* p, Aff<C>& out) {
+  typedef typename C::FqP F;
+  bool ok = wire_to_fe<F>(p, out.x);
+  ok &= wire_to_fe<F>(p + 32, out.y);
+  if (aff_is_inf<C>(out)) return ok;
+  return ok && aff_on_curve<C>(out);
+}
+template <class C>
+MP_HD void aff_to_wire(const Aff<C>& a, uint8_t* p) {
+  typedef typename C::FqP F;
+  fe_to_wire<F>(a.x, p);       // (0,0) Montgomery = (0,0) canonical = the infinity encoding
+  fe_to_wire<F>(a.y, p + 32);
+}
+
+// ---- load / store -------------------------------------------------------------------------------------
+struct LoadPointsArgs {
+  const uint8_t* src;    // [B][count][64]
+  uint32_t* P;
+  int32_t* status;
+  uint32_t Bpad, count, p_slot;
+};
+// x = proof, y = point index (a deck of N cards is 2N points: c0, c1 of card i at 2i, 2i+1)
+template <class C>
+MP_HD void body_load_points(const LoadPointsArgs& a, uint32_t b, uint32_t y) {
+  Aff<C> pt;
+  const bool ok = wire_to_aff<C>(a.src + ((size_t)b * a.count + y) * 64, pt);
+  if (!ok) {
+    status_fail(a.status, b, ST_BAD_ENCODING);
+    pt = aff_inf<C>();
+  }
+  st_aff<C>(a.P + p_off(a.p_slot + y, a.Bpad, b), pt);
+}
+MP_KERNEL(k_load_points, LoadPointsArgs, body_load_points)
+
+struct LoadScalarsArgs {
+  const uint8_t* src;    // [B][count][32]
+  uint32_t* S;
+  int32_t* status;
+  uint32_t Bpad, count, s_slot;
+};
+template <class C>
+MP_HD void body_load_scalars(const LoadScalarsArgs& a, uint32_t b, uint32_t y) {
+  typedef typename C::FrP R;
+  Fe<R> v;
+  if (!wire_to_fe<R>(a.src + ((size_t)b * a.count + y) * 32, v)) {
+    status_fail(a.status, b, ST_BAD_ENCODING);
+    v = fe_zero<R>();
+  }
+  st_fe<R>(a.S + s_off(a.s_slot + y, a.Bpad, b), v);
+}
+MP_KERNEL(k_load_scalars, LoadScalarsArgs, body_load_scalars)
+
+struct ProofIoArgs {
+  uint8_t* proof;        // [B][proof_bytes]
+  uint32_t* S;
+  uint32_t* P;
+  int32_t* status;
+  const ProofElem* map;
+  uint32_t Bpad, proof_bytes;
+};
+template <class C>
+MP_HD void body_load_proof(const ProofIoArgs& a, uint32_t b, uint32_t y) {
+  typedef typename C::FrP R;
+  const ProofElem e = a.map[y];
+  const uint8_t* src = a.proof + (size_t)b * a.proof_bytes + e.offset;
+  if (e.is_point) {
+    Aff<C> pt;
+    if (!wire_to_aff<C>(src, pt)) {
+      status_fail(a.status, b, ST_BAD_ENCODING);
+      pt = aff_inf<C>();
+    }
+    st_aff<C>(a.P + p_off(e.slot, a.Bpad, b), pt);
+  } else {
+    Fe<R> v;
+    if (!wire_to_fe<R>(src, v)) {
+      status_fail(a.status, b, ST_BAD_ENCODING);
+      v = fe_zero<R>();
+    }
+    st_fe<R>(a.S + s_off(e.slot, a.Bpad, b), v);
+  }
+}
+MP_KERNEL(k_load_proof, ProofIoArgs, body_load_proof)
+template <class C>
+MP_HD void body_store_proof(const ProofIoArgs& a, uint32_t b, uint32_t y) {
+  typedef typename C::FrP R;
+  const ProofElem e = a.map[y];
+  uint8_t* dst = a.proof + (size_t)b * a.proof_bytes + e.offset;
+  if (e.is_point)
+    aff_to_wire<C>(ld_aff<C>(a.P + p_off(e.slot, a.Bpad, b)), dst);
+  else
+    fe_to_wire<R>(ld_fe<R>(a.S + s_off(e.slot, a.Bpad, b)), dst);
+}
+MP_KERNEL(k_store_proof, ProofIoArgs, body_store_proof)
+
+struct StorePointsArgs {
+  uint8_t* dst;          // [B][count][64]
+  const uint32_t* P;
+  uint32_t Bpad, count, p_slot;
+};
+template <class C>
+MP_HD void body_store_points(const StorePointsArgs& a, uint32_t b, uint32_t y) {
+  aff_to_wire<C>(ld_aff<C>(a.P + p_off(a.p_slot + y, a.Bpad, b)), a.dst + ((size_t)b * a.count + y) * 64);
+}
+MP_KERNEL(k_store_points, StorePointsArgs, body_store_points)
+
+// ---- prover: permutation check, a = pi + 1, randomness ---------------------------------------------
+struct ProveInitArgs {
+  uint32_t* S;
+  int32_t* status;
+  const uint32_t* perm;         // [B][N]
+  const uint8_t* seeds;         // [B][32]
+  const uint32_t* draw_slots;   // [n_draws]
+  ProveLay l;
+  uint32_t Bpad;
+};
+template <class C>
+MP_HD void body_prove_init(const ProveInitArgs& a, uint32_t b, uint32_t y) {
+  typedef typename C::FrP R;
+  const ProveLay& l = a.l;
+  // permutation: every value < N and distinct.  N <= 4096: 128-word bitmap in private memory.
+  uint32_t seen[128];
+  for (uint32_t i = 0; i < 128; ++i) seen[i] = 0;
+  bool ok = true;
+  for (uint32_t i = 0; i < l.N; ++i) {
+    uint32_t v = a.perm[(size_t)b * l.N + i];
+    if (v >= l.N) {
+      ok = false;
+      v = 0;
+    } else {
+      if (seen[v >> 5] & (1u << (v & 31))) ok = false;
+      seen[v >> 5] |= 1u << (v & 31);
+    }
+    st_fe<R>(a.S + s_off(l.a + i, a.Bpad, b), fe_from_u32<R>(v + 1));
+  }
+  if (!ok) status_fail(a.status, b, ST_BAD_PERMUTATION);
+  // prover randomness
+  uint32_t key[8];
+  const uint32_t* sw = reinterpret_cast<const uint32_t*>(a.seeds + (size_t)b * 32);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) key[i] = sw[i];
+  FrStream st;
+  frstream_init(st, key);
+  for (uint32_t i = 0; i < l.n_draws; ++i) {
+    Fe<R> v = frstream_next<R>(st);
+    st_fe<R>(a.S + s_off(a.draw_slots[i], a.Bpad, b), v);
+  }
+  // fixed values of transcript v1
+  st_fe<R>(a.S + s_off(l.zt + l.m + 1, a.Bpad, b), fe_zero<R>());
+  st_fe<R>(a.S + s_off(l.meb + l.m, a.Bpad, b), fe_zero<R>());
+  st_fe<R>(a.S + s_off(l.mes + l.m, a.Bpad, b), fe_zero<R>());
+  st_fe<R>(a.S + s_off(l.svdelta + l.n - 1, a.Bpad, b), fe_zero<R>());
+}
+MP_KERNEL(k_prove_init, ProveInitArgs, body_prove_init)
+
+// ---- Fiat-Shamir helpers ------------------------------------------------------------------------------
+struct FsDev {
+  uint32_t* stage;       // [stage_words][Bpad]
+  uint32_t* seed;        // [8][Bpad]
+  uint32_t Bpad;
+};
+template <class C>
+MP_HD void fs_put_point(StageWriter& w, const Aff<C>& p) {
+  typedef typename C::FqP F;
+  uint32_t k[8];
+  if (aff_is_inf<C>(p)) {   // GroupAffine::zero() = (0, 1, infinity = true)
+    for (int i = 0; i < 8; ++i) stage_word(w, 0);
+    stage_word(w, 1);
+    for (int i = 1; i < 8; ++i) stage_word(w, 0);
+    stage_byte(w, 1);
+    return;
+  }
+  fe_to_canonical<F>(p.x, k);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) stage_word(w, k[i]);
+  fe_to_canonical<F>(p.y, k);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) stage_word(w, k[i]);
+  stage_byte(w, 0);
+}
+MP_HD void fs_load_seed(const FsDev& f, uint32_t b, uint32_t seed[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) seed[i] = f.seed[(size_t)i * f.Bpad + b];
+}
+MP_HD void fs_store_seed(const FsDev& f, uint32_t b, const uint32_t seed[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f.seed[(size_t)i * f.Bpad + b] = seed[i];
+}
+// finish an absorb: append the old seed, hash, new seed
+MP_HD void fs_finish_absorb(StageWriter& w, uint32_t seed[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) stage_word(w, seed[i]);
+  blake2s_staged(w, seed);
+}
+// absorb the P slots [first, first+count)
+template <class C>
+MP_HD void fs_absorb_points(const FsDev& f, const uint32_t* P, uint32_t b, uint32_t seed[8], uint32_t first, uint32_t count) {
+  StageWriter w = stage_begin(f.stage, f.Bpad, b);
+  for (uint32_t i = 0; i < count; ++i) fs_put_point<C>(w, ld_aff<C>(P + p_off(first + i, f.Bpad, b)));
+  fs_finish_absorb(w, seed);
+}
+template <class C>
+MP_HD void fs_challenges(const uint32_t seed[8], uint32_t* S, uint32_t Bpad, uint32_t b, uint32_t slot0, uint32_t slot1) {
+  typedef typename C::FrP R;
+  FrStream st;
+  frstream_init(st, seed);
+  st_fe<R>(S + s_off(slot0, Bpad, b), frstream_next<R>(st));
+  if (slot1 != NO_SLOT) st_fe<R>(S + s_off(slot1, Bpad, b), frstream_next<R>(st));
+}
+
+// statement absorb + c_A absorb -> x        (shared by prover and verifier)
+struct FsStatementArgs {
+  FsDev f;
+  uint32_t* S;
+  const uint32_t* P;
+  const uint32_t* fbpts;       // fixed base points (affine): ck.., H, G, pk, gen, gsum
+  uint32_t init_seed[8];       // Blake2s("Shuffle Proof")
+  uint32_t m, n, N;
+  uint32_t p_deck, p_shuf, p_cA, s_x;
+};
+template <class C>
+MP_HD void fs_statement_and_x(const FsStatementArgs& a, uint32_t b, uint32_t seed[8]) {
+  const FixedBases fb{a.n};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) seed[i] = a.init_seed[i];
+  StageWriter w = stage_begin(a.f.stage, a.f.Bpad, b);
+  fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.G() * 16));
+  fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.pk() * 16));
+  fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.gen() * 16));
+  for (uint32_t j = 0; j < a.n; ++j) fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.ck(j) * 16));
+  fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.H() * 16));
+  for (uint32_t i = 0; i < 2 * a.N; ++i) fs_put_point<C>(w, ld_aff<C>(a.P + p_off(a.p_deck + i, a.f.Bpad, b)));
+  for (uint32_t i = 0; i < 2 * a.N; ++i) fs_put_point<C>(w, ld_aff<C>(a.P + p_off(a.p_shuf + i, a.f.Bpad, b)));
+  stage_word(w, a.m); stage_word(w, 0); stage_word(w, a.n); stage_word(w, 0);   // u64 m, u64 n
+  fs_finish_absorb(w, seed);
+  fs_absorb_points<C>(a.f, a.P, b, seed, a.p_cA, a.m);
+  fs_challenges<C>(seed, a.S, a.f.Bpad, b, a.s_x, NO_SLOT);
+}
+template <class C>
+MP_HD void body_fs_round1(const FsStatementArgs& a, uint32_t b, uint32_t y) {
+  uint32_t seed[8];
+  fs_statement_and_x<C>(a, b, seed);
+  fs_store_seed(a.f, b, seed);
+}
+MP_KERNEL(k_fs_round1, FsStatementArgs, body_fs_round1)
+
+// generic later rounds: up to 3 consecutive (absorb slot range -> challenges) steps in one kernel
+struct FsStep {
+  uint32_t first, count;       // P slots absorbed
+  uint32_t first2, count2;     // optional second range absorbed in the same message
+  uint32_t slot0, slot1;       // challenge destinations (slot0 == NO_SLOT: absorb only)
+};
+struct FsRoundArgs {
+  FsDev f;
+  uint32_t* S;
+  uint32_t* P;
+  FsStep step[4];
+  uint32_t nsteps;
+  uint32_t copy_from, copy_to;   // optional P-slot copy done first (NO_SLOT = none)
+};
+template <class C>
+MP_HD void fs_run_steps(const FsRoundArgs& a, uint32_t b, uint32_t seed[8]) {
+  for (uint32_t s = 0; s < a.nsteps; ++s) {
+    const FsStep st = a.step[s];
+    StageWriter w = stage_begin(a.f.stage, a.f.Bpad, b);
+    for (uint32_t i = 0; i < st.count; ++i) fs_put_point<C>(w, ld_aff<C>(a.P + p_off(st.first + i, a.f.Bpad, b)));
+    for (uint32_t i = 0; i < st.count2; ++i) fs_put_point<C>(w, ld_aff<C>(a.P + p_off(st.first2 + i, a.f.Bpad, b)));
+    fs_finish_absorb(w, seed);
+    if (st.slot0 != NO_SLOT) fs_challenges<C>(seed, a.S, a.f.Bpad, b, st.slot0, st.slot1);
+  }
+}
+template <class C>
+MP_HD void body_fs_round(const FsRoundArgs& a, uint32_t b, uint32_t y) {
+  if (a.copy_from != NO_SLOT)
+    st_aff<C>(a.P + p_off(a.copy_to, a.f.Bpad, b), ld_aff<C>(a.P + p_off(a.copy_from, a.f.Bpad, b)));
+  uint32_t seed[8];
+  fs_load_seed(a.f, b, seed);
+  fs_run_steps<C>(a, b, seed);
+  fs_store_seed(a.f, b, seed);
+}
+MP_KERNEL(k_fs_round, FsRoundArgs, body_fs_round)
+
+// ---- prover scalar programs -----------------------------------------------------------------------------
+struct ProveScalArgs {
+  uint32_t* S;
+  const uint32_t* perm;
+  ProveLay l;
+  uint32_t Bpad;
+};
+#define MP_LD(slot) ld_fe<R>(a.S + s_off((slot), a.Bpad, b))
+#define MP_ST(slot, val) st_fe<R>(a.S + s_off((slot), a.Bpad, b), (val))
+
+// after x: b_i = x^(pi(i)+1), rho_hat = -sum rho_i b_i -> tau[m]
+template <class C>
+MP_HD void body_prove_scal1(const ProveScalArgs& a, uint32_t b, uint32_t y) {
+  typedef typename C::FrP R;
+  const ProveLay& l = a.l;
+  const Fe<R> x = MP_LD(l.x);
+  Fe<R> acc = fe_one<R>();
+  MP_ST(l.tmp + 0, acc);
+  for (uint32_t j = 1; j <= l.N; ++j) {
+    acc = fe_mul<R>(acc, x);
+    MP_ST(l.tmp + j, acc);
+  }
+  Fe<R> rho_hat = fe_zero<R>();
+  for (uint32_t i = 0; i < l.N; ++i) {
+    uint32_t pi = a.perm[(size_t)b * l.N + i];
+    if (pi >= l.N) pi = 0;
+    const Fe<R> bi = MP_LD(l.tmp + pi + 1);
+    MP_ST(l.b + i, bi);
+    rho_hat = fe_sub<R>(rho_hat, fe_mul<R>(MP_LD(l.rho + i), bi));
+  }
+  MP_ST(l.metau + l.m, rho_hat);
+}
+MP_KERNEL(k_prove_scal1, ProveScalArgs, body_prove_scal1)
+
+// after y, z: d - z, t, Hadamard partial products, single-value-product first-message vectors
+template <class C>
+MP_HD void body_prove_scal2(const ProveScalArgs& a, uint32_t b, uint32_t y_) {
+  typedef typename C::FrP R;
+  const ProveLay& l = a.l;
+  const uint32_t m = l.m, n = l.n;
+  const Fe<R> y = MP_LD(l.y), z = MP_LD(l.z);
+  for (uint32_t i = 0; i < l.N; ++i)
+    MP_ST(l.dz + i, fe_sub<R>(fe_add<R>(fe_mul<R>(y, MP_LD(l.a + i)), MP_LD(l.b + i)), z));
+  for (uint32_t k = 0; k < m; ++k) MP_ST(l.t + k, fe_add<R>(fe_mul<R>(y, MP_LD(l.r + k)), MP_LD(l.s + k)));
+  MP_ST(l.hs + 0, MP_LD(l.t + 0));
+  MP_ST(l.hs + m - 1, MP_LD(l.sb));
+  for (uint32_t j = 0; j < n; ++j) {
+    Fe<R> acc = MP_LD(l.dz + j);
+    MP_ST(l.bp + j, acc);
+    for (uint32_t k = 1; k < m; ++k) {
+      acc = fe_mul<R>(acc, MP_LD(l.dz + k * n + j));
+      MP_ST(l.bp + k * n + j, acc);
+    }
+  }
+  // single value product on a = bvec = bp[m-1], randomness sb
+  const uint32_t av = l.bp + (m - 1) * n;
+  Fe<R> pref = MP_LD(av);
+  MP_ST(l.svbp + 0, pref);
+  for (uint32_t i = 1; i < n; ++i) {
+    pref = fe_mul<R>(pref, MP_LD(av + i));
+    MP_ST(l.svbp + i, pref);
+  }
+  MP_ST(l.svdelta + 0, MP_LD(l.svd + 0));
+  for (uint32_t i = 0; i + 1 < n; ++i) {
+    const Fe<R> di1 = MP_LD(l.svd + i + 1), deli = MP_LD(l.svdelta + i);
+    MP_ST(l.svv1 + i, fe_neg<R>(fe_mul<R>(deli, di1)));
+    Fe<R> v2 = fe_sub<R>(MP_LD(l.svdelta + i + 1), fe_mul<R>(MP_LD(av + i + 1), deli));
+    v2 = fe_sub<R>(v2, fe_mul<R>(MP_LD(l.svbp + i), di1));
+    MP_ST(l.svv2 + i, v2);
+  }
+}
+MP_KERNEL(k_prove_scal2, ProveScalArgs, body_prove_scal2)
+
+// zero-argument witness accessors (rows a_0..a_m and b_0..b_m of section 5.2)
+template <class C>
+MP_HD Fe<typename C::FrP> zero_Aa(const ProveScalArgs& a, uint32_t b, uint32_t i, uint32_t j) {
+  typedef typename C::FrP R;
+  const ProveLay& l = a.l;
+  if (i == 0) return MP_LD(l.za0 + j);
+  if (i == l.m) return fe_neg<R>(fe_one<R>());
+  return MP_LD(l.dz + i * l.n + j);
+}
+template <class C>
+MP_HD Fe<typename C::FrP> zero_Bb(const ProveScalArgs& a, uint32_t b, uint32_t i, uint32_t j) {
+  typedef typename C::FrP R;
+  const ProveLay& l = a.l;
+  if (i == l.m) return MP_LD(l.zbm + j);
+  return MP_LD(l.zB + i * l.n + j);
+}
+
+// after the Hadamard challenges (hx, hy): zero-argument statement witness and the d_k
+template <class C>
+MP_HD void body_prove_scal3(const ProveScalArgs& a, uint32_t b, uint32_t y_) {
+  typedef typename C::FrP R;
+  const ProveLay& l = a.l;
+  const uint32_t m = l.m, n = l.n;
+  const Fe<R> hx = MP_LD(l.hx), hy = MP_LD(l.hy);
+  // tmp: [0, m] powers of hx ; [m+1, m+1+n) y^(j+1) ; then (m+1) weighted B rows
+  const uint32_t t_xp = l.tmp, t_yp = l.tmp + m + 1, t_wb = l.tmp + m + 1 + n;
+  Fe<R> acc = fe_one<R>();
+  for (uint32_t i = 0; i <= m; ++i) {
+    MP_ST(t_xp + i, acc);
+    acc = fe_mul<R>(acc, hx);
+  }
+  acc = hy;
+  for (uint32_t j = 0; j < n; ++j) {
+    MP_ST(t_yp + j, acc);
+    acc = fe_mul<R>(acc, hy);
+  }
+  // zB rows and zs
+  for (uint32_t j = 0; j < n; ++j) {
+    Fe<R> last = fe_zero<R>();
+    for (uint32_t i = 0; i + 1 < m; ++i) {
+      const Fe<R> xi = MP_LD(t_xp + i + 1);
+      MP_ST(l.zB + i * n + j, fe_mul<R>(xi, MP_LD(l.bp + i * n + j)));
+      last = fe_add<R>(last, fe_mul<R>(xi, MP_LD(l.bp + (i + 1) * n + j)));
+    }
+    MP_ST(l.zB + (m - 1) * n + j, last);
+  }
+  {
+    Fe<R> last = fe_zero<R>();
+    for (uint32_t i = 0; i + 1 < m; ++i) {
+      const Fe<R> xi = MP_LD(t_xp + i + 1);
+      MP_ST(l.zs + i, fe_mul<R>(xi, MP_LD(l.hs + i)));
+      last = fe_add<R>(last, fe_mul<R>(xi, MP_LD(l.hs + i + 1)));
+    }
+    MP_ST(l.zs + m - 1, last);
+  }
+  // weighted rows wb[jj][j] = Bb[jj][j] * y^(j+1)
+  for (uint32_t jj = 0; jj <= m; ++jj)
+    for (uint32_t j = 0; j < n; ++j) MP_ST(t_wb + jj * n + j, fe_mul<R>(zero_Bb<C>(a, b, jj, j), MP_LD(t_yp + j)));
+  // d_k = sum_{i,jj : k = m - jj + i} Aa[i] . wb[jj]
+  for (uint32_t k = 0; k <= 2 * m; ++k) {
+    Fe<R> d = fe_zero<R>();
+    for (uint32_t i = 0; i <= m; ++i) {
+      const int64_t jj = (int64_t)m + (int64_t)i - (int64_t)k;
+      if (jj < 0 || jj > (int64_t)m) continue;
+      for (uint32_t j = 0; j < n; ++j) d = fe_add<R>(d, fe_mul<R>(zero_Aa<C>(a, b, i, j), MP_LD(t_wb + (uint32_t)jj * n + j)));
+    }
+    MP_ST(l.zd + k, d);
+  }
+}
+MP_KERNEL(k_prove_scal3, ProveScalArgs, body_prove_scal3)
+
+// after the last challenges: all responses
+template <class C>
+MP_HD void body_prove_scal4(const ProveScalArgs& a, uint32_t b, uint32_t y_) {
+  typedef typename C::FrP R;
+  const ProveLay& l = a.l;
+  const uint32_t m = l.m, n = l.n;
+  const uint32_t t_xp = l.tmp;   // powers, up to 2m+1
+  // --- zero argument
+  {
+    const Fe<R> x = MP_LD(l.zx);
+    Fe<R> acc = fe_one<R>();
+    for (uint32_t i = 0; i <= 2 * m; ++i) {
+      MP_ST(t_xp + i, acc);
+      acc = fe_mul<R>(acc, x);
+    }
+    for (uint32_t j = 0; j < n; ++j) {
+      Fe<R> ab = fe_zero<R>(), bb = fe_zero<R>();
+      for (uint32_t i = 0; i <= m; ++i) {
+        ab = fe_add<R>(ab, fe_mul<R>(MP_LD(t_xp + i), zero_Aa<C>(a, b, i, j)));
+        bb = fe_add<R>(bb, fe_mul<R>(MP_LD(t_xp + m - i), zero_Bb<C>(a, b, i, j)));
+      }
+      MP_ST(l.zabar + j, ab);
+      MP_ST(l.zbbar + j, bb);
+    }
+    Fe<R> rb = MP_LD(l.zr0), sbar = fe_zero<R>(), tb = fe_zero<R>();
+    for (uint32_t i = 1; i < m; ++i) rb = fe_add<R>(rb, fe_mul<R>(MP_LD(t_xp + i), MP_LD(l.t + i)));   // r' = (t_1..t_{m-1}, 0)
+    for (uint32_t j = 0; j < m; ++j) sbar = fe_add<R>(sbar, fe_mul<R>(MP_LD(t_xp + m - j), MP_LD(l.zs + j)));
+    sbar = fe_add<R>(sbar, MP_LD(l.zsm));
+    for (uint32_t k = 0; k <= 2 * m; ++k) tb = fe_add<R>(tb, fe_mul<R>(MP_LD(t_xp + k), MP_LD(l.zt + k)));
+    MP_ST(l.zrbar, rb);
+    MP_ST(l.zsbar, sbar);
+    MP_ST(l.ztbar, tb);
+  }
+  // --- single value product
+  {
+    const Fe<R> x = MP_LD(l.svx);
+    const uint32_t av = l.bp + (m - 1) * n;
+    for (uint32_t i = 0; i < n; ++i) {
+      MP_ST(l.svat + i, fe_add<R>(fe_mul<R>(x, MP_LD(av + i)), MP_LD(l.svd + i)));
+      MP_ST(l.svbt + i, fe_add<R>(fe_mul<R>(x, MP_LD(l.svbp + i)), MP_LD(l.svdelta + i)));
+    }
+    MP_ST(l.svrt, fe_add<R>(fe_mul<R>(x, MP_LD(l.sb)), MP_LD(l.svrd)));
+    MP_ST(l.svst, fe_add<R>(fe_mul<R>(x, MP_LD(l.svsx)), MP_LD(l.svs1)));
+  }
+  // --- multi-exponentiation
+  {
+    const Fe<R> x = MP_LD(l.mx);
+    Fe<R> acc = fe_one<R>();
+    for (uint32_t i = 0; i < 2 * m; ++i) {
+      MP_ST(t_xp + i, acc);
+      acc = fe_mul<R>(acc, x);
+    }
+    for (uint32_t j = 0; j < n; ++j) {
+      Fe<R> ab = MP_LD(l.mea0 + j);
+      for (uint32_t i = 1; i <= m; ++i) ab = fe_add<R>(ab, fe_mul<R>(MP_LD(t_xp + i), MP_LD(l.b + (i - 1) * n + j)));
+      MP_ST(l.meabar + j, ab);
+    }
+    Fe<R> rb = MP_LD(l.mer0);
+    for (uint32_t i = 1; i <= m; ++i) rb = fe_add<R>(rb, fe_mul<R>(MP_LD(t_xp + i), MP_LD(l.s + i - 1)));
+    Fe<R> bb = fe_zero<R>(), sbar = fe_zero<R>(), tb = fe_zero<R>();
+    for (uint32_t k = 0; k < 2 * m; ++k) {
+      const Fe<R> xk = MP_LD(t_xp + k);
+      bb = fe_add<R>(bb, fe_mul<R>(xk, MP_LD(l.meb + k)));
+      sbar = fe_add<R>(sbar, fe_mul<R>(xk, MP_LD(l.mes + k)));
+      tb = fe_add<R>(tb, fe_mul<R>(xk, MP_LD(l.metau + k)));
+    }
+    MP_ST(l.merbar, rb);
+    MP_ST(l.mebbar, bb);
+    MP_ST(l.mesbar, sbar);
+    MP_ST(l.metaubar, tb);
+  }
+}
+MP_KERNEL(k_prove_scal4, ProveScalArgs, body_prove_scal4)
+
+// ---- verifier -------------------------------------------------------------------------------------------
+struct VerifyFsArgs {
+  FsStatementArgs st;
+  VerifyLay l;
+};
+template <class C>
+MP_HD void body_verify_fs(const VerifyFsArgs& a, uint32_t b, uint32_t y) {
+  const VerifyLay& l = a.l;
+  const uint32_t m = l.m;
+  uint32_t seed[8];
+  fs_statement_and_x<C>(a.st, b, seed);
+  const FsDev& f = a.st.f;
+  uint32_t* S = a.st.S;
+  const uint32_t* P = a.st.P;
+  fs_absorb_points<C>(f, P, b, seed, l.cB, m);
+  fs_challenges<C>(seed, S, f.Bpad, b, l.y, l.z);
+  fs_absorb_points<C>(f, P, b, seed, l.cb, 1);
+  fs_absorb_points<C>(f, P, b, seed, l.hB, m);
+  fs_challenges<C>(seed, S, f.Bpad, b, l.hx, l.hy);
+  fs_absorb_points<C>(f, P, b, seed, l.zcA0, 2 + 2 * m + 1);       // zcA0, zcBm, zcD[0..2m] are consecutive slots
+  fs_challenges<C>(seed, S, f.Bpad, b, l.zx, NO_SLOT);
+  fs_absorb_points<C>(f, P, b, seed, l.svcd, 3);
+  fs_challenges<C>(seed, S, f.Bpad, b, l.svx, NO_SLOT);
+  fs_absorb_points<C>(f, P, b, seed, l.mecA0, 1 + 2 * m + 4 * m);  // mecA0, mecB[2m], meE[4m] consecutive
+  fs_challenges<C>(seed, S, f.Bpad, b, l.mx, NO_SLOT);
+}
+MP_KERNEL(k_verify_fs, VerifyFsArgs, body_verify_fs)
+
+struct VerifyScalArgs {
+  uint32_t* S;
+  const uint32_t* P;
+  uint32_t* direct;      // [Bpad] bit i set = direct check i failed
+  VerifyLay l;
+  VCoefMap c;
+  uint32_t Bpad;
+};
+template <class C>
+MP_HD void body_verify_scal(const VerifyScalArgs& a, uint32_t b, uint32_t y_) {
+  typedef typename C::FrP R;
+  const VerifyLay& l = a.l;
+  const VCoefMap& c = a.c;
+  const uint32_t m = l.m, n = l.n, N = l.N;
+  uint32_t fail = 0;
+  const Fe<R> one = fe_one<R>();
+  MP_ST(l.one, one);
+  MP_ST(c.minus_one, fe_neg<R>(one));
+  const Fe<R> x = MP_LD(l.x), y = MP_LD(l.y), z = MP_LD(l.z);
+  // --- Hadamard: first commitment, last commitment
+  MP_ST(c.had_y, y);
+  MP_ST(c.had_mz, fe_neg<R>(z));
+  if (!aff_eq<C>(ld_aff<C>(a.P + p_off(l.hB + m - 1, a.Bpad, b)), ld_aff<C>(a.P + p_off(l.cb, a.Bpad, b)))) fail |= 1u << VC_HAD_BM;
+  // --- zero argument
+  {
+    const Fe<R> hx = MP_LD(l.hx), hy = MP_LD(l.hy), zx = MP_LD(l.zx);
+    if (!aff_is_inf<C>(ld_aff<C>(a.P + p_off(l.zcD + m + 1, a.Bpad, b)))) fail |= 1u << VC_ZERO_DM1;
+    const uint32_t t_zx = l.tmp, t_hx = l.tmp + 2 * m + 1;     // zx^0..zx^2m ; hx^0..hx^m
+    Fe<R> acc = one;
+    for (uint32_t i = 0; i <= 2 * m; ++i) {
+      MP_ST(t_zx + i, acc);
+      acc = fe_mul<R>(acc, zx);
+    }
+    acc = one;
+    for (uint32_t i = 0; i <= m; ++i) {
+      MP_ST(t_hx + i, acc);
+      acc = fe_mul<R>(acc, hx);
+    }
+    // VC_ZERO_A
+    Fe<R> gs = fe_zero<R>();
+    for (uint32_t i = 1; i < m; ++i) {
+      const Fe<R> zi = MP_LD(t_zx + i);
+      MP_ST(c.za_cA + i, fe_mul<R>(zi, y));
+      MP_ST(c.za_cB + i, zi);
+      gs = fe_add<R>(gs, zi);
+    }
+    gs = fe_neg<R>(fe_add<R>(fe_mul<R>(gs, z), MP_LD(t_zx + m)));
+    MP_ST(c.za_gsum, gs);
+    for (uint32_t j = 0; j < n; ++j) MP_ST(c.za_ck + j, fe_neg<R>(MP_LD(l.zabar + j)));
+    MP_ST(c.za_H, fe_neg<R>(MP_LD(l.zrbar)));
+    // VC_ZERO_B: hB[j] gets [j <= m-2] zx^(m-j) hx^(j+1) + [j >= 1] zx hx^j
+    for (uint32_t j = 0; j < m; ++j) {
+      Fe<R> co = fe_zero<R>();
+      if (j + 2 <= m) co = fe_mul<R>(MP_LD(t_zx + m - j), MP_LD(t_hx + j + 1));
+      if (j >= 1) co = fe_add<R>(co, fe_mul<R>(zx, MP_LD(t_hx + j)));
+      MP_ST(c.zb_hB + j, co);
+    }
+    for (uint32_t j = 0; j < n; ++j) MP_ST(c.zb_ck + j, fe_neg<R>(MP_LD(l.zbbar + j)));
+    MP_ST(c.zb_H, fe_neg<R>(MP_LD(l.zsbar)));
+    // VC_ZERO_D
+    for (uint32_t k = 0; k <= 2 * m; ++k) MP_ST(c.zd_cD + k, MP_LD(t_zx + k));
+    Fe<R> bil = fe_zero<R>(), yp = hy;
+    for (uint32_t j = 0; j < n; ++j) {
+      bil = fe_add<R>(bil, fe_mul<R>(fe_mul<R>(MP_LD(l.zabar + j), MP_LD(l.zbbar + j)), yp));
+      yp = fe_mul<R>(yp, hy);
+    }
+    MP_ST(c.zd_ck0, fe_neg<R>(bil));
+    MP_ST(c.zd_H, fe_neg<R>(MP_LD(l.ztbar)));
+  }
+  // --- single value product; product value prod_{i=1..N} (y i + x^i - z)
+  {
+    const Fe<R> sx = MP_LD(l.svx);
+    MP_ST(c.sa_x, sx);
+    for (uint32_t j = 0; j < n; ++j) MP_ST(c.sa_ck + j, fe_neg<R>(MP_LD(l.svat + j)));
+    MP_ST(c.sa_H, fe_neg<R>(MP_LD(l.svrt)));
+    MP_ST(c.sd_x, sx);
+    for (uint32_t j = 0; j + 1 < n; ++j) {
+      // -(x bt_{j+1} - bt_j at_{j+1})
+      const Fe<R> v = fe_sub<R>(fe_mul<R>(MP_LD(l.svbt + j), MP_LD(l.svat + j + 1)), fe_mul<R>(sx, MP_LD(l.svbt + j + 1)));
+      MP_ST(c.sd_ck + j, v);
+    }
+    MP_ST(c.sd_H, fe_neg<R>(MP_LD(l.svst)));
+    Fe<R> prod = one, xi = one, yi = fe_zero<R>();
+    for (uint32_t i = 1; i <= N; ++i) {
+      xi = fe_mul<R>(xi, x);
+      yi = fe_add<R>(yi, y);
+      prod = fe_mul<R>(prod, fe_sub<R>(fe_add<R>(yi, xi), z));
+      MP_ST(c.em_x + i - 1, xi);                      // x^i: coefficient of deck[i-1] in Cx
+    }
+    if (!fe_eq(MP_LD(l.svbt + 0), MP_LD(l.svat + 0)) || !fe_eq(MP_LD(l.svbt + n - 1), fe_mul<R>(sx, prod))) fail |= 1u << VC_SVP_SCALARS;
+  }
+  // --- multi-exponentiation
+  {
+    const Fe<R> mx = MP_LD(l.mx);
+    if (!aff_is_inf<C>(ld_aff<C>(a.P + p_off(l.mecB + m, a.Bpad, b)))) fail |= 1u << VC_ME_BM;
+    const uint32_t t_mx = l.tmp;    // mx^0 .. mx^(2m-1)
+    Fe<R> acc = one;
+    for (uint32_t k = 0; k < 2 * m; ++k) {
+      MP_ST(t_mx + k, acc);
+      MP_ST(c.mb_x + k, acc);
+      MP_ST(c.me_x + k, acc);
+      acc = fe_mul<R>(acc, mx);
+    }
+    for (uint32_t j = 0; j <= m; ++j) MP_ST(c.ma_x + j, MP_LD(t_mx + j));
+    for (uint32_t j = 0; j < n; ++j) MP_ST(c.ma_ck + j, fe_neg<R>(MP_LD(l.meabar + j)));
+    MP_ST(c.ma_H, fe_neg<R>(MP_LD(l.merbar)));
+    MP_ST(c.mb_ck0, fe_neg<R>(MP_LD(l.mebbar)));
+    MP_ST(c.mb_H, fe_neg<R>(MP_LD(l.mesbar)));
+    for (uint32_t i = 1; i <= m; ++i) {
+      const Fe<R> co = fe_neg<R>(MP_LD(t_mx + m - i));
+      for (uint32_t j = 0; j < n; ++j) MP_ST(c.me_c + (i - 1) * n + j, fe_mul<R>(co, MP_LD(l.meabar + j)));
+    }
+    const Fe<R> ntau = fe_neg<R>(MP_LD(l.metaubar));
+    MP_ST(c.me_tauG, ntau);
+    MP_ST(c.me_taupk, ntau);
+    MP_ST(c.me_bgen, fe_neg<R>(MP_LD(l.mebbar)));
+  }
+  a.direct[b] = fail;
+}
+MP_KERNEL(k_verify_scal, VerifyScalArgs, body_verify_scal)
+
+struct VerdictArgs {
+  const uint32_t* J;
+  const uint32_t* direct;
+  int32_t* status;
+  uint32_t Bpad, chk_first;
+};
+template <class C>
+MP_HD void body_verdict(const VerdictArgs& a, uint32_t b, uint32_t y) {
+  if (a.status[b] < 0) return;   // usage error already recorded
+  const uint32_t direct = a.direct[b];
+  int32_t code = 0;
+  for (int cidx = 0; cidx < (int)VC_COUNT && code == 0; ++cidx) {
+    bool failed;
+    if (vcheck_is_msm(cidx))
+      failed = !fe_is_zero(ld_fe<typename C::FqP>(a.J + j_off(a.chk_first + cidx, a.Bpad, b) + 16));
+    else
+      failed = (direct >> cidx) & 1u;
+    if (failed) code = vcheck_code(cidx);
+  }
+  a.status[b] = code;
+}
+MP_KERNEL(k_verdict, VerdictArgs, body_verdict)
+
+#undef MP_LD
+#undef MP_ST
+
+}  // namespace mp

@@ -1,0 +1,525 @@
+// Data layout of one batch of B independent shuffle proofs in HBM, and the static "job tables" that
+// describe every multi-scalar multiplication of the Bayer-Groth prover / verifier for given (m, n).
+//
+// Arenas are SLOT-MAJOR: element `slot` of proof `b` lives at arena[(slot * Bpad + b) * words], so the 64
+// lanes of a wave (64 consecutive proofs, same slot) read one contiguous 2-6 KB run -- every global access
+// of the MSM kernels is coalesced.  Three arenas: S (Fr scalars, 8 words, Montgomery), P (affine points,
+// 16 words), J (Jacobian points, 24 words; slots [0, nP) mirror P, slots >= nP are partial sums).
+//
+// The reference computes these quantities inside `shuffle::ShuffleArgument::prove/verify`
+// [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:409-415, 437-442]; naming follows
+// oracle/py/mp_oracle.py (transcript v1).
+#pragma once
+#include <cstdint>
+#include <map>
+#include <stdexcept>
+#include <vector>
+
+#include "rt.hpp"
+
+namespace mp {
+
+// ---- device-visible descriptors -------------------------------------------------------------------
+struct Job {
+  uint32_t out;    // J slot written
+  uint32_t begin;  // first term
+  uint32_t count;  // number of terms
+};
+struct Term {
+  uint32_t s;  // fixed: S slot of the scalar        | var: digit slot        | combine: J slot or (AFF_FLAG | P slot)
+  uint32_t b;  // fixed: index of the fixed base     | var: table slot        | combine: unused
+};
+static const uint32_t AFF_FLAG = 0x80000000u;
+static const uint32_t NO_SLOT = 0xFFFFFFFFu;
+
+// fixed bases of one table context: ck_0..ck_{n-1}, H, G, pk, gen, gsum
+struct FixedBases {
+  uint32_t n;
+  MP_HD uint32_t ck(uint32_t j) const { return j; }
+  MP_HD uint32_t H() const { return n; }
+  MP_HD uint32_t G() const { return n + 1; }
+  MP_HD uint32_t pk() const { return n + 2; }
+  MP_HD uint32_t gen() const { return n + 3; }
+  MP_HD uint32_t gsum() const { return n + 4; }
+  MP_HD uint32_t count() const { return n + 5; }
+};
+
+static const int FB_WINDOW_BITS = 8;     // fixed-base tables: 32 windows x 255 entries per base
+static const int FB_WINDOWS = 32;
+static const int FB_ENTRIES = 255;
+static const int VB_WINDOW_BITS = 5;     // variable-base (Straus) signed windows: digits in [-15, 16]
+static const int VB_ENTRIES = 16;
+static inline int vb_windows(int scalar_bits) { return (scalar_bits + 1 + VB_WINDOW_BITS - 1) / VB_WINDOW_BITS; }
+
+// One phase = everything that can run between two Fiat-Shamir squeeze points.
+struct Phase {
+  std::vector<Term> recode;   // {S slot, digit slot}
+  std::vector<Term> tables;   // {P slot, table slot}
+  std::vector<Job> fjobs, vjobs, cjobs;
+  std::vector<Term> fterms, vterms, cterms;
+  std::vector<std::pair<uint32_t, uint32_t>> normalize;  // [first slot, count) J -> P
+  uint32_t n_dslots = 0, n_tslots = 0;
+};
+
+// Host-side builder: msm(out) { fixed(..) var(..) addend(..) } -> chunked sub-jobs + one combine job.
+class PhaseBuilder {
+ public:
+  PhaseBuilder(Phase& ph, uint32_t& next_partial, uint32_t fchunk, uint32_t vchunk)
+      : ph_(ph), next_partial_(next_partial), fchunk_(fchunk), vchunk_(vchunk) {}
+  void begin(uint32_t out_slot) {
+    out_ = out_slot;
+    f_.clear();
+    v_.clear();
+    a_.clear();
+  }
+  void fixed(uint32_t sslot, uint32_t base) { f_.push_back(Term{sslot, base}); }
+  void var(uint32_t sslot, uint32_t pslot) {
+    uint32_t d = dslot(sslot), t = tslot(pslot);
+    v_.push_back(Term{d, t});
+  }
+  void addend(uint32_t pslot) { a_.push_back(pslot); }
+  void end() {
+    size_t nf = (f_.size() + fchunk_ - 1) / fchunk_, nv = (v_.size() + vchunk_ - 1) / vchunk_;
+    size_t pieces = nf + nv + a_.size();
+    if (pieces == 0) throw std::logic_error("empty msm");
+    bool direct = pieces == 1 && a_.empty();
+    std::vector<uint32_t> parts;
+    for (size_t c = 0; c < nf; ++c) {
+      uint32_t out = direct ? out_ : next_partial_++;
+      size_t b = c * fchunk_, e = std::min(f_.size(), b + fchunk_);
+      ph_.fjobs.push_back(Job{out, (uint32_t)ph_.fterms.size(), (uint32_t)(e - b)});
+      ph_.fterms.insert(ph_.fterms.end(), f_.begin() + b, f_.begin() + e);
+      parts.push_back(out);
+    }
+    for (size_t c = 0; c < nv; ++c) {
+      uint32_t out = direct ? out_ : next_partial_++;
+      size_t b = c * vchunk_, e = std::min(v_.size(), b + vchunk_);
+      ph_.vjobs.push_back(Job{out, (uint32_t)ph_.vterms.size(), (uint32_t)(e - b)});
+      ph_.vterms.insert(ph_.vterms.end(), v_.begin() + b, v_.begin() + e);
+      parts.push_back(out);
+    }
+    if (!direct) {
+      ph_.cjobs.push_back(Job{out_, (uint32_t)ph_.cterms.size(), (uint32_t)(parts.size() + a_.size())});
+      for (uint32_t p : parts) ph_.cterms.push_back(Term{p, 0});
+      for (uint32_t p : a_) ph_.cterms.push_back(Term{AFF_FLAG | p, 0});
+    }
+  }
+  void normalize(uint32_t first, uint32_t count) {
+    if (count) ph_.normalize.push_back({first, count});
+  }
+
+ private:
+  uint32_t dslot(uint32_t sslot) {
+    auto it = dmap_.find(sslot);
+    if (it != dmap_.end()) return it->second;
+    uint32_t d = ph_.n_dslots++;
+    dmap_[sslot] = d;
+    ph_.recode.push_back(Term{sslot, d});
+    return d;
+  }
+  uint32_t tslot(uint32_t pslot) {
+    auto it = tmap_.find(pslot);
+    if (it != tmap_.end()) return it->second;
+    uint32_t t = ph_.n_tslots++;
+    tmap_[pslot] = t;
+    ph_.tables.push_back(Term{pslot, t});
+    return t;
+  }
+  Phase& ph_;
+  uint32_t& next_partial_;
+  uint32_t fchunk_, vchunk_;
+  uint32_t out_ = 0;
+  std::vector<Term> f_, v_;
+  std::vector<uint32_t> a_;
+  std::map<uint32_t, uint32_t> dmap_, tmap_;
+};
+
+// ---- slot maps (plain data: passed by value to the protocol kernels) --------------------------------
+struct ProveLay {
+  uint32_t m, n, N;
+  // S arena
+  uint32_t rho, a, b, tmp, r, s, sb, hs, dz, t, bp, zB, zs, za0, zbm, zr0, zsm, zt, zd;
+  uint32_t svbp, svd, svrd, svdelta, svs1, svsx, svv1, svv2;
+  uint32_t mea0, mer0, meb, mes, metau;
+  uint32_t x, y, z, hx, hy, zx, svx, mx;
+  uint32_t zabar, zbbar, zrbar, zsbar, ztbar, svat, svbt, svrt, svst, meabar, merbar, mebbar, mesbar, metaubar;
+  uint32_t nS, tmp_len;
+  // P arena (J arena mirrors [0, nP))
+  uint32_t deck, shuf, cA, cB, cb, hB, zcA0, zcBm, zcD, svcd, svcdelta, svcDelta, mecA0, mecB, meE;
+  uint32_t nP;
+  uint32_t n_draws;
+};
+
+struct VerifyLay {
+  uint32_t m, n, N;
+  // proof scalars
+  uint32_t zabar, zbbar, zrbar, zsbar, ztbar, svat, svbt, svrt, svst, meabar, merbar, mebbar, mesbar, metaubar;
+  // challenges, scratch, coefficients
+  uint32_t x, y, z, hx, hy, zx, svx, mx, one, tmp, coef;
+  uint32_t nS, tmp_len, n_coef;
+  // points
+  uint32_t deck, shuf, cA, cB, cb, hB, zcA0, zcBm, zcD, svcd, svcdelta, svcDelta, mecA0, mecB, meE;
+  uint32_t nP;
+  // result slots of the "== O" checks (J arena, >= nP) and their codes
+  uint32_t chk_first, n_chk;
+};
+
+// wire order of the proof: element = (is_point, slot); identical for prover (source) and verifier (destination)
+struct ProofElem {
+  uint32_t is_point;
+  uint32_t slot;
+  uint32_t offset;  // byte offset in the wire proof
+};
+
+template <class L>
+static inline std::vector<ProofElem> proof_wire_map(const L& l) {
+  std::vector<ProofElem> v;
+  uint32_t off = 0;
+  auto P = [&](uint32_t s) { v.push_back(ProofElem{1, s, off}); off += 64; };
+  auto S = [&](uint32_t s) { v.push_back(ProofElem{0, s, off}); off += 32; };
+  const uint32_t m = l.m, n = l.n;
+  for (uint32_t k = 0; k < m; ++k) P(l.cA + k);
+  for (uint32_t k = 0; k < m; ++k) P(l.cB + k);
+  P(l.cb);
+  for (uint32_t k = 0; k < m; ++k) P(l.hB + k);
+  P(l.zcA0); P(l.zcBm);
+  for (uint32_t k = 0; k < 2 * m + 1; ++k) P(l.zcD + k);
+  for (uint32_t i = 0; i < n; ++i) S(l.zabar + i);
+  for (uint32_t i = 0; i < n; ++i) S(l.zbbar + i);
+  S(l.zrbar); S(l.zsbar); S(l.ztbar);
+  P(l.svcd); P(l.svcdelta); P(l.svcDelta);
+  for (uint32_t i = 0; i < n; ++i) S(l.svat + i);
+  for (uint32_t i = 0; i < n; ++i) S(l.svbt + i);
+  S(l.svrt); S(l.svst);
+  P(l.mecA0);
+  for (uint32_t k = 0; k < 2 * m; ++k) P(l.mecB + k);
+  for (uint32_t k = 0; k < 4 * m; ++k) P(l.meE + k);
+  for (uint32_t i = 0; i < n; ++i) S(l.meabar + i);
+  S(l.merbar); S(l.mebbar); S(l.mesbar); S(l.metaubar);
+  return v;
+}
+
+static inline size_t proof_size_bytes(uint32_t m, uint32_t n) { return (size_t)(11 * m + 8) * 64 + (size_t)(5 * n + 9) * 32; }
+
+static inline ProveLay make_prove_lay(uint32_t m, uint32_t n) {
+  ProveLay l{};
+  l.m = m; l.n = n; l.N = m * n;
+  const uint32_t N = l.N;
+  uint32_t s = 0;
+  auto A = [&](uint32_t cnt) { uint32_t r = s; s += cnt; return r; };
+  l.rho = A(N); l.a = A(N); l.b = A(N);
+  l.tmp_len = (m + 3) * n + 2 * m + N + 8;
+  l.tmp = A(l.tmp_len);
+  l.r = A(m); l.s = A(m); l.sb = A(1); l.hs = A(m);
+  l.dz = A(N); l.t = A(m); l.bp = A(N); l.zB = A(N); l.zs = A(m);
+  l.za0 = A(n); l.zbm = A(n); l.zr0 = A(1); l.zsm = A(1); l.zt = A(2 * m + 1); l.zd = A(2 * m + 1);
+  l.svbp = A(n); l.svd = A(n); l.svrd = A(1); l.svdelta = A(n); l.svs1 = A(1); l.svsx = A(1); l.svv1 = A(n); l.svv2 = A(n);
+  l.mea0 = A(n); l.mer0 = A(1); l.meb = A(2 * m); l.mes = A(2 * m); l.metau = A(2 * m);
+  l.x = A(1); l.y = A(1); l.z = A(1); l.hx = A(1); l.hy = A(1); l.zx = A(1); l.svx = A(1); l.mx = A(1);
+  l.zabar = A(n); l.zbbar = A(n); l.zrbar = A(1); l.zsbar = A(1); l.ztbar = A(1);
+  l.svat = A(n); l.svbt = A(n); l.svrt = A(1); l.svst = A(1);
+  l.meabar = A(n); l.merbar = A(1); l.mebbar = A(1); l.mesbar = A(1); l.metaubar = A(1);
+  l.nS = s;
+  uint32_t p = 0;
+  auto Pn = [&](uint32_t cnt) { uint32_t r = p; p += cnt; return r; };
+  l.deck = Pn(2 * N); l.shuf = Pn(2 * N); l.cA = Pn(m); l.cB = Pn(m); l.cb = Pn(1); l.hB = Pn(m);
+  l.zcA0 = Pn(1); l.zcBm = Pn(1); l.zcD = Pn(2 * m + 1); l.svcd = Pn(1); l.svcdelta = Pn(1); l.svcDelta = Pn(1);
+  l.mecA0 = Pn(1); l.mecB = Pn(2 * m); l.meE = Pn(4 * m);
+  l.nP = p;
+  return l;
+}
+
+// prover randomness: the i-th `Fr::rand` draw of the prover stream goes to slot draws[i] (transcript v1
+// order: r, s | sb | hadamard s_2..s_{m-1} | zero a0, bm, r0, sm, t | svp d, rd, delta_2..n-1, s1, sx |
+// mexp a0, r0, b, s, tau)
+static inline std::vector<uint32_t> prove_draw_slots(const ProveLay& l) {
+  std::vector<uint32_t> d;
+  const uint32_t m = l.m, n = l.n;
+  auto R = [&](uint32_t first, uint32_t cnt) { for (uint32_t i = 0; i < cnt; ++i) d.push_back(first + i); };
+  R(l.r, m); R(l.s, m);
+  R(l.sb, 1);
+  if (m > 2) R(l.hs + 1, m - 2);
+  R(l.za0, n); R(l.zbm, n); R(l.zr0, 1); R(l.zsm, 1); R(l.zt, 2 * m + 1);
+  R(l.svd, n); R(l.svrd, 1);
+  if (n > 2) R(l.svdelta + 1, n - 2);
+  R(l.svs1, 1); R(l.svsx, 1);
+  R(l.mea0, n); R(l.mer0, 1); R(l.meb, 2 * m); R(l.mes, 2 * m); R(l.metau, 2 * m);
+  return d;
+}
+
+struct ProvePlan {
+  ProveLay lay;
+  Phase ph[4];          // A (cA), B (cB + multi-exp first message), C (product first messages), D (zero argument)
+  uint32_t nJ;          // J arena slots (nP + partial sums)
+  std::vector<uint32_t> draws;
+  std::vector<ProofElem> wire;
+};
+
+static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk) {
+  ProvePlan pl;
+  pl.lay = make_prove_lay(m, n);
+  const ProveLay& l = pl.lay;
+  FixedBases fb{n};
+  uint32_t next_partial = l.nP;
+  auto commit = [&](PhaseBuilder& B, uint32_t out, uint32_t vec, uint32_t len, uint32_t rslot) {
+    B.begin(out);
+    for (uint32_t j = 0; j < len; ++j) B.fixed(vec + j, fb.ck(j));
+    B.fixed(rslot, fb.H());
+    B.end();
+  };
+  {  // phase A: c_A (the re-encryption itself is the dedicated remask kernel)
+    PhaseBuilder B(pl.ph[0], next_partial, fchunk, vchunk);
+    for (uint32_t k = 0; k < m; ++k) commit(B, l.cA + k, l.a + k * n, n, l.r + k);
+    B.normalize(l.shuf, 2 * l.N);
+    B.normalize(l.cA, m);
+  }
+  {  // phase B: c_B, multi-exponentiation first message
+    PhaseBuilder B(pl.ph[1], next_partial, fchunk, vchunk);
+    for (uint32_t k = 0; k < m; ++k) commit(B, l.cB + k, l.b + k * n, n, l.s + k);
+    commit(B, l.mecA0, l.mea0, n, l.mer0);
+    for (uint32_t k = 0; k < 2 * m; ++k) commit(B, l.mecB + k, l.meb + k, 1, l.mes + k);
+    for (uint32_t k = 0; k < 2 * m; ++k) {
+      for (uint32_t c = 0; c < 2; ++c) {
+        B.begin(l.meE + 2 * k + c);
+        if (c == 0) {
+          B.fixed(l.metau + k, fb.G());
+        } else {
+          B.fixed(l.meb + k, fb.gen());
+          B.fixed(l.metau + k, fb.pk());
+        }
+        for (uint32_t i = 1; i <= m; ++i) {
+          int64_t j = (int64_t)k - (int64_t)m + (int64_t)i;
+          if (j < 0 || j > (int64_t)m) continue;
+          uint32_t vec = j == 0 ? l.mea0 : l.b + (uint32_t)(j - 1) * n;   // a_j: a_0 random, a_j = row j of b
+          for (uint32_t t = 0; t < n; ++t) B.var(vec + t, l.shuf + 2 * ((i - 1) * n + t) + c);
+        }
+        B.end();
+      }
+    }
+    B.normalize(l.cB, m);
+    B.normalize(l.mecA0, 1 + 2 * m + 4 * m);
+  }
+  {  // phase C: product-argument first messages that do not depend on later challenges
+    PhaseBuilder B(pl.ph[2], next_partial, fchunk, vchunk);
+    commit(B, l.cb, l.bp + (m - 1) * n, n, l.sb);
+    commit(B, l.hB + 0, l.dz, n, l.t);                       // = c_A[0] of the product statement (c_D0 + c_{-z})
+    for (uint32_t i = 1; i + 1 < m; ++i) commit(B, l.hB + i, l.bp + i * n, n, l.hs + i);
+    commit(B, l.svcd, l.svd, n, l.svrd);
+    commit(B, l.svcdelta, l.svv1, n - 1, l.svs1);
+    commit(B, l.svcDelta, l.svv2, n - 1, l.svsx);
+    B.normalize(l.cb, 1);
+    B.normalize(l.hB, m - 1);
+    B.normalize(l.svcd, 3);
+  }
+  {  // phase D: zero-argument first message
+    PhaseBuilder B(pl.ph[3], next_partial, fchunk, vchunk);
+    commit(B, l.zcA0, l.za0, n, l.zr0);
+    commit(B, l.zcBm, l.zbm, n, l.zsm);
+    for (uint32_t k = 0; k < 2 * m + 1; ++k) commit(B, l.zcD + k, l.zd + k, 1, l.zt + k);
+    B.normalize(l.zcA0, 2 + 2 * m + 1);
+  }
+  pl.nJ = next_partial;
+  pl.draws = prove_draw_slots(l);
+  pl.lay.n_draws = (uint32_t)pl.draws.size();
+  pl.wire = proof_wire_map(l);
+  return pl;
+}
+
+// ---- verifier ------------------------------------------------------------------------------------
+// Every group equation is evaluated as one MSM that must equal the identity.  Check order (= the order in
+// which the oracle's verifier would fail) and the code reported:
+enum VCheck {
+  VC_HAD_B1 = 0,      // 1  c_B1 == c_A1 of the product statement          (MSM)
+  VC_HAD_BM,          // 1  c_Bm == c_b                                    (direct)
+  VC_ZERO_DM1,        // 2  c_D[m+1] == O                                  (direct)
+  VC_ZERO_A,          // 2  sum x^i c_Ai == com(abar; rbar)                (MSM)
+  VC_ZERO_B,          // 2  sum x^(m-j) c_Bj == com(bbar; sbar)            (MSM)
+  VC_ZERO_D,          // 2  sum x^k c_Dk == com(abar*bbar; tbar)           (MSM)
+  VC_SVP_A,           // 3  x c_a + c_d == com(at; rt)                     (MSM)
+  VC_SVP_D,           // 3  x c_Delta + c_delta == com(..; st)             (MSM)
+  VC_SVP_SCALARS,     // 3  bt_1 == at_1, bt_n == x b                      (direct)
+  VC_ME_BM,           // 4  c_B[m] == O                                    (direct)
+  VC_ME_EM0,          // 4  E[m].c0 == Cx.c0                               (MSM)
+  VC_ME_EM1,          // 4  E[m].c1 == Cx.c1                               (MSM)
+  VC_ME_A,            // 4  c_A0 + sum x^j c_Aj == com(abar; rbar)         (MSM)
+  VC_ME_B,            // 4  sum x^k c_Bk == com(bbar; sbar)                (MSM)
+  VC_ME_E0,           // 4  ciphertext equation, component 0               (MSM)
+  VC_ME_E1,           // 4  ciphertext equation, component 1               (MSM)
+  VC_COUNT
+};
+MP_HD int vcheck_code(int c) {
+  if (c <= VC_HAD_BM) return 1;
+  if (c <= VC_ZERO_D) return 2;
+  if (c <= VC_SVP_SCALARS) return 3;
+  return 4;
+}
+MP_HD bool vcheck_is_msm(int c) {
+  return !(c == VC_HAD_BM || c == VC_ZERO_DM1 || c == VC_SVP_SCALARS || c == VC_ME_BM);
+}
+
+static inline VerifyLay make_verify_lay(uint32_t m, uint32_t n) {
+  VerifyLay l{};
+  l.m = m; l.n = n; l.N = m * n;
+  const uint32_t N = l.N;
+  uint32_t s = 0;
+  auto A = [&](uint32_t cnt) { uint32_t r = s; s += cnt; return r; };
+  l.zabar = A(n); l.zbbar = A(n); l.zrbar = A(1); l.zsbar = A(1); l.ztbar = A(1);
+  l.svat = A(n); l.svbt = A(n); l.svrt = A(1); l.svst = A(1);
+  l.meabar = A(n); l.merbar = A(1); l.mebbar = A(1); l.mesbar = A(1); l.metaubar = A(1);
+  l.x = A(1); l.y = A(1); l.z = A(1); l.hx = A(1); l.hy = A(1); l.zx = A(1); l.svx = A(1); l.mx = A(1); l.one = A(1);
+  l.tmp_len = N + 2 * n + 4 * m + 8;
+  l.tmp = A(l.tmp_len);
+  // coefficient block: sized generously; exact use is fixed by make_verify_plan / body_verify_scalars
+  l.n_coef = 2 * N + 6 * n + 16 * m + 32;
+  l.coef = A(l.n_coef);
+  l.nS = s;
+  uint32_t p = 0;
+  auto Pn = [&](uint32_t cnt) { uint32_t r = p; p += cnt; return r; };
+  l.deck = Pn(2 * N); l.shuf = Pn(2 * N); l.cA = Pn(m); l.cB = Pn(m); l.cb = Pn(1); l.hB = Pn(m);
+  l.zcA0 = Pn(1); l.zcBm = Pn(1); l.zcD = Pn(2 * m + 1); l.svcd = Pn(1); l.svcdelta = Pn(1); l.svcDelta = Pn(1);
+  l.mecA0 = Pn(1); l.mecB = Pn(2 * m); l.meE = Pn(4 * m);
+  l.nP = p;
+  l.chk_first = l.nP;
+  l.n_chk = VC_COUNT;
+  return l;
+}
+
+// Coefficient slots.  body_verify_scalars (kernels_proto.hpp) fills them; make_verify_plan consumes them in
+// the SAME order through this little allocator, so both sides are generated from one description:
+struct VCoef {
+  uint32_t base, next;
+  explicit VCoef(uint32_t b) : base(b), next(b) {}
+  uint32_t take(uint32_t cnt = 1) {
+    uint32_t r = next;
+    next += cnt;
+    return r;
+  }
+};
+// Layout of the coefficient block (c = coef base); all values are the scalars of the "== O" MSMs.
+struct VCoefMap {
+  uint32_t had_y, had_m1, had_mz;                        // VC_HAD_B1: y*cA0 + 1*cB0 - 1*hB0 - z*gsum
+  uint32_t za_cA, za_cB, za_gsum, za_ck, za_H;           // VC_ZERO_A: 1*zcA0 + sum_{i=1}^{m-1} zx^i (y cA_i + cB_i) + gsum*(..) - abar.ck - rbar H
+  uint32_t zb_hB, zb_ck, zb_H;                           // VC_ZERO_B: coefficients of hB[0..m-1], 1*zcBm, -bbar.ck, -sbar H
+  uint32_t zd_cD, zd_ck0, zd_H;                          // VC_ZERO_D: zx^k (k=0..2m), -(abar*bbar), -tbar
+  uint32_t sa_x, sa_ck, sa_H;                            // VC_SVP_A: x*cb + 1*cd - at.ck - rt H
+  uint32_t sd_x, sd_ck, sd_H;                            // VC_SVP_D: x*cDelta + 1*cdelta - v.ck - st H
+  uint32_t em_x;                                         // VC_ME_EM*: x^{i+1} (N values); -1*E[m]
+  uint32_t ma_x, ma_ck, ma_H;                            // VC_ME_A: 1*mecA0 + mx^j cB_{j-1} - abar.ck - rbar H
+  uint32_t mb_x, mb_ck0, mb_H;                           // VC_ME_B: mx^k mecB_k - bbar ck0 - sbar H
+  uint32_t me_x, me_c, me_tauG, me_bgen, me_taupk;       // VC_ME_E*: mx^k E_k ; -(mx^{m-i} abar_l) (N) ; -taubar G ; -bbar gen ; -taubar pk
+  uint32_t minus_one;
+  uint32_t end;
+};
+static inline VCoefMap make_vcoef_map(const VerifyLay& l) {
+  VCoefMap c{};
+  const uint32_t m = l.m, n = l.n, N = l.N;
+  VCoef a(l.coef);
+  c.minus_one = a.take();
+  c.had_y = a.take(); c.had_mz = a.take();
+  c.za_cA = a.take(m); c.za_cB = a.take(m); c.za_gsum = a.take(); c.za_ck = a.take(n); c.za_H = a.take();
+  c.zb_hB = a.take(m); c.zb_ck = a.take(n); c.zb_H = a.take();
+  c.zd_cD = a.take(2 * m + 1); c.zd_ck0 = a.take(); c.zd_H = a.take();
+  c.sa_x = a.take(); c.sa_ck = a.take(n); c.sa_H = a.take();
+  c.sd_x = a.take(); c.sd_ck = a.take(n); c.sd_H = a.take();
+  c.em_x = a.take(N);
+  c.ma_x = a.take(m + 1); c.ma_ck = a.take(n); c.ma_H = a.take();
+  c.mb_x = a.take(2 * m); c.mb_ck0 = a.take(); c.mb_H = a.take();
+  c.me_x = a.take(2 * m); c.me_c = a.take(N); c.me_tauG = a.take(); c.me_bgen = a.take(); c.me_taupk = a.take();
+  c.end = a.next;
+  if (c.end - l.coef > l.n_coef) throw std::logic_error("coefficient block too small");
+  return c;
+}
+
+struct VerifyPlan {
+  VerifyLay lay;
+  VCoefMap cm;
+  Phase ph;
+  uint32_t nJ;
+  std::vector<ProofElem> wire;
+};
+
+static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk) {
+  VerifyPlan pl;
+  pl.lay = make_verify_lay(m, n);
+  const VerifyLay& l = pl.lay;
+  pl.cm = make_vcoef_map(l);
+  const VCoefMap& c = pl.cm;
+  const uint32_t N = l.N;
+  FixedBases fb{n};
+  uint32_t next_partial = l.chk_first + l.n_chk;
+  PhaseBuilder B(pl.ph, next_partial, fchunk, vchunk);
+  auto chk = [&](int id) { return l.chk_first + (uint32_t)id; };
+  // VC_HAD_B1
+  B.begin(chk(VC_HAD_B1));
+  B.var(c.had_y, l.cA + 0); B.var(l.one, l.cB + 0); B.var(c.minus_one, l.hB + 0); B.fixed(c.had_mz, fb.gsum());
+  B.end();
+  // VC_ZERO_A
+  B.begin(chk(VC_ZERO_A));
+  B.var(l.one, l.zcA0);
+  for (uint32_t i = 1; i < m; ++i) { B.var(c.za_cA + i, l.cA + i); B.var(c.za_cB + i, l.cB + i); }
+  B.fixed(c.za_gsum, fb.gsum());
+  for (uint32_t j = 0; j < n; ++j) B.fixed(c.za_ck + j, fb.ck(j));
+  B.fixed(c.za_H, fb.H());
+  B.end();
+  // VC_ZERO_B
+  B.begin(chk(VC_ZERO_B));
+  for (uint32_t j = 0; j < m; ++j) B.var(c.zb_hB + j, l.hB + j);
+  B.var(l.one, l.zcBm);
+  for (uint32_t j = 0; j < n; ++j) B.fixed(c.zb_ck + j, fb.ck(j));
+  B.fixed(c.zb_H, fb.H());
+  B.end();
+  // VC_ZERO_D
+  B.begin(chk(VC_ZERO_D));
+  for (uint32_t k = 0; k < 2 * m + 1; ++k) B.var(c.zd_cD + k, l.zcD + k);
+  B.fixed(c.zd_ck0, fb.ck(0)); B.fixed(c.zd_H, fb.H());
+  B.end();
+  // VC_SVP_A
+  B.begin(chk(VC_SVP_A));
+  B.var(c.sa_x, l.cb); B.var(l.one, l.svcd);
+  for (uint32_t j = 0; j < n; ++j) B.fixed(c.sa_ck + j, fb.ck(j));
+  B.fixed(c.sa_H, fb.H());
+  B.end();
+  // VC_SVP_D
+  B.begin(chk(VC_SVP_D));
+  B.var(c.sd_x, l.svcDelta); B.var(l.one, l.svcdelta);
+  for (uint32_t j = 0; j + 1 < n; ++j) B.fixed(c.sd_ck + j, fb.ck(j));
+  B.fixed(c.sd_H, fb.H());
+  B.end();
+  // VC_ME_EM0/1 : sum x^{i+1} deck_i - E[m] == O
+  for (uint32_t comp = 0; comp < 2; ++comp) {
+    B.begin(chk(VC_ME_EM0 + comp));
+    for (uint32_t i = 0; i < N; ++i) B.var(c.em_x + i, l.deck + 2 * i + comp);
+    B.var(c.minus_one, l.meE + 2 * m + comp);
+    B.end();
+  }
+  // VC_ME_A
+  B.begin(chk(VC_ME_A));
+  B.var(l.one, l.mecA0);
+  for (uint32_t j = 1; j <= m; ++j) B.var(c.ma_x + j, l.cB + (j - 1));
+  for (uint32_t j = 0; j < n; ++j) B.fixed(c.ma_ck + j, fb.ck(j));
+  B.fixed(c.ma_H, fb.H());
+  B.end();
+  // VC_ME_B
+  B.begin(chk(VC_ME_B));
+  for (uint32_t k = 0; k < 2 * m; ++k) B.var(c.mb_x + k, l.mecB + k);
+  B.fixed(c.mb_ck0, fb.ck(0)); B.fixed(c.mb_H, fb.H());
+  B.end();
+  // VC_ME_E0/1
+  for (uint32_t comp = 0; comp < 2; ++comp) {
+    B.begin(chk(VC_ME_E0 + comp));
+    for (uint32_t k = 0; k < 2 * m; ++k) B.var(c.me_x + k, l.meE + 2 * k + comp);
+    for (uint32_t i = 0; i < N; ++i) B.var(c.me_c + i, l.shuf + 2 * i + comp);
+    if (comp == 0) {
+      B.fixed(c.me_tauG, fb.G());
+    } else {
+      B.fixed(c.me_bgen, fb.gen());
+      B.fixed(c.me_taupk, fb.pk());
+    }
+    B.end();
+  }
+  pl.nJ = next_partial;
+  pl.wire = proof_wire_map(l);
+  return pl;
+}
+
+}  // namespace mp

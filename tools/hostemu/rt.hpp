@@ -1,0 +1,65 @@
+// DEVELOPMENT AID ONLY -- not part of the product.  Shadows mental-poker_amd/csrc/rt.hpp (same include guard,
+// force-included first) so that the engine's kernel BODIES run as plain CPU loops: lets the kernels be debugged
+// against the oracle on a machine without a GPU.  libmpemu.so is never shipped, never loaded by the
+// `mental-poker_amd` package and never timed; the product library has no CPU path (mp_ctx_create fails without
+// a HIP device).
+#ifndef MP_RT_HPP
+#define MP_RT_HPP
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#define MP_HD inline
+#define MP_HD_NOINLINE inline
+#define MP_GLOBAL
+#define MP_RT_NAME "host-emulator (development aid)"
+
+struct uint4 {
+  uint32_t x, y, z, w;
+};
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+
+namespace mp {
+namespace rt {
+typedef int Stream;
+typedef double* Event;
+inline int device_count() { return 1; }
+inline void set_device(int) {}
+inline void* dmalloc(size_t bytes) {
+  void* p = calloc(bytes ? bytes : 1, 1);
+  if (!p) throw std::runtime_error("emulator: out of memory");
+  return p;
+}
+inline void dfree(void* p) { free(p); }
+inline void h2d(void* d, const void* h, size_t n, Stream) { memcpy(d, h, n); }
+inline void d2h(void* h, const void* d, size_t n, Stream) { memcpy(h, d, n); }
+inline void d2d(void* d, const void* s_, size_t n, Stream) { memcpy(d, s_, n); }
+inline void dzero(void* d, size_t n, Stream) { memset(d, 0, n); }
+inline Stream stream_create() { return 0; }
+inline void stream_destroy(Stream) {}
+inline void stream_sync(Stream) {}
+inline Event event_create() { return new double(0); }
+inline void event_destroy(Event e) { delete e; }
+inline void event_record(Event e, Stream) {
+  *e = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline float event_ms(Event a, Event b) { return (float)(*b - *a); }
+inline void launch_check(const char*) {}
+}  // namespace rt
+}  // namespace mp
+
+#define MP_KERNEL(NAME, ARGS, BODY)                         \
+  template <class C>                                        \
+  void NAME(const ARGS& a, uint32_t nx, uint32_t ny) {      \
+    for (uint32_t y = 0; y < ny; ++y) {                     \
+      _Pragma("omp parallel for schedule(dynamic, 1)")      \
+      for (uint32_t x = 0; x < nx; ++x) BODY<C>(a, x, y);   \
+    }                                                       \
+  }
+#define MP_LAUNCH(NAME, C, stream, nx, ny, args) NAME<C>((args), (uint32_t)(nx), (uint32_t)(ny))
+
+#endif  // MP_RT_HPP
