@@ -113,6 +113,12 @@ int mp_profile_report(mp_ctx* ctx, char* buf, size_t buf_len);
 int mp_work_census(mp_table* t, uint64_t* prove_terms, uint64_t* verify_terms, uint64_t* prove_point_ops,
                    uint64_t* verify_point_ops);
 
+/* static plan statistics for this table (what one proof costs, per kernel class); out[16]:
+ *  [0..5]  prove : fixed terms, var terms, fixed jobs, var jobs, table bases, combine terms
+ *  [6..11] verify: same six
+ *  [12] variable-base windows per scalar  [13] fixed-base windows per scalar  [14] N  [15] reserved */
+int mp_plan_stats(mp_table* t, uint64_t out[16]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ SYMBOLS = [
     "mp_setup", "mp_table_create", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
     "mp_shuffle_and_remask_batch", "mp_verify_shuffle_batch", "mp_shuffle_and_remask_batch_dev",
     "mp_verify_shuffle_batch_dev", "mp_sync", "mp_reserve", "mp_remask_batch", "mp_msm", "mp_commit_batch",
-    "mp_profile_enable", "mp_profile_report", "mp_work_census",
+    "mp_profile_enable", "mp_profile_report", "mp_work_census", "mp_plan_stats",
 ]
 
 
@@ -80,6 +80,7 @@ def bind(cdll):
     cdll.mp_profile_enable.argtypes = [c.c_void_p, c.c_int]
     cdll.mp_profile_report.argtypes = [c.c_void_p, c.c_char_p, c.c_size_t]
     cdll.mp_work_census.argtypes = [c.c_void_p] + [c.POINTER(c.c_uint64)] * 4
+    cdll.mp_plan_stats.argtypes = [c.c_void_p, c.POINTER(c.c_uint64)]
     return cdll
 
 
@@ -243,6 +244,14 @@ class Table:
 
     def verify_shuffle_batch_dev(self, B, d_decks, d_shuffled, d_proofs, d_status):
         self.eng._chk(self.lib.mp_verify_shuffle_batch_dev(self.h, B, d_decks, d_shuffled, d_proofs, d_status))
+
+    def plan_stats(self):
+        v = (ctypes.c_uint64 * 16)()
+        self.eng._chk(self.lib.mp_plan_stats(self.h, v))
+        keys = ["fixed_terms", "var_terms", "fixed_jobs", "var_jobs", "table_bases", "combine_terms"]
+        out = {"prove": dict(zip(keys, v[0:6])), "verify": dict(zip(keys, v[6:12]))}
+        out.update(var_windows=v[12], fixed_windows=v[13], N=v[14])
+        return out
 
     def work_census(self):
         v = [ctypes.c_uint64() for _ in range(4)]

@@ -132,6 +132,7 @@ struct mp_table {
   virtual void msm_host(size_t n_msm, size_t k, const uint8_t* scalars, const uint8_t* points, uint8_t* out) = 0;
   virtual void commit_host(size_t count, size_t len, const uint8_t* values, const uint8_t* r, uint8_t* out) = 0;
   virtual void census(uint64_t* pt, uint64_t* vt, uint64_t* po, uint64_t* vo) = 0;
+  virtual void plan_stats(uint64_t out[16]) = 0;
 };
 
 namespace mp {
@@ -574,6 +575,16 @@ struct Table : mp_table {
       if (v < 0) throw std::invalid_argument("commit: bad encoding in input");
   }
 
+  void plan_stats(uint64_t out[16]) override {
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    auto add = [&](const Phase& ph, uint64_t* o) {
+      o[0] += ph.fterms.size(); o[1] += ph.vterms.size(); o[2] += ph.fjobs.size(); o[3] += ph.vjobs.size();
+      o[4] += ph.tables.size(); o[5] += ph.cterms.size();
+    };
+    for (int i = 0; i < 4; ++i) add(pplan.ph[i], out);
+    add(vplan.ph, out + 6);
+    out[12] = nwin; out[13] = FB_WINDOWS; out[14] = N;
+  }
   void census(uint64_t* pt, uint64_t* vt, uint64_t* po, uint64_t* vo) override {
     auto count = [&](const Phase& ph, uint64_t& terms, uint64_t& ops) {
       terms += ph.fterms.size() + ph.vterms.size();
@@ -859,6 +870,12 @@ int mp_profile_report(mp_ctx* ctx, char* buf, size_t buf_len) {
 int mp_work_census(mp_table* t, uint64_t* prove_terms, uint64_t* verify_terms, uint64_t* prove_point_ops, uint64_t* verify_point_ops) {
   if (!t || !prove_terms || !verify_terms || !prove_point_ops || !verify_point_ops) return fail(MP_ERR_BAD_ARGUMENT, "mp_work_census: bad argument");
   t->census(prove_terms, verify_terms, prove_point_ops, verify_point_ops);
+  return MP_OK;
+}
+
+int mp_plan_stats(mp_table* t, uint64_t out[16]) {
+  if (!t || !out) return fail(MP_ERR_BAD_ARGUMENT, "mp_plan_stats: bad argument");
+  t->plan_stats(out);
   return MP_OK;
 }
 

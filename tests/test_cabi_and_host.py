@@ -1,0 +1,105 @@
+"""CPU tests (-m "not gpu"): the C-ABI library loads and exports every declared symbol (no compute without a
+GPU), the engine refuses to run without a device (no CPU fallback), the host-side planners are sane, and the
+development emulator (kernel bodies as CPU loops, tools/hostemu) reproduces the oracle byte for byte."""
+import ctypes
+import importlib
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT, load_json
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "mpshuffle.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mp_[a-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def native(mp):
+    mp.build()
+    return mp
+
+
+def test_library_exports_every_declared_symbol(native):
+    lib = native.load()
+    syms = _header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert sorted(native._native.SYMBOLS) == syms
+    assert lib.mp_proof_size(2, 26) == (11 * 2 + 8) * 64 + (5 * 26 + 9) * 32 == 6368
+    assert lib.mp_params_size(26) == 29 * 64
+    assert lib.mp_check_name(1) == b"Hadamard Product (5.1)"
+    assert lib.mp_check_name(0) == b"Ok"
+
+
+def test_no_cpu_fallback_without_a_device(native):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(native.NoDeviceError):
+        native.Engine("stark", 0)
+    with pytest.raises(native.NoDeviceError):
+        native.DLCards("stark")
+
+
+def test_mirror_types(native):
+    p = native.Permutation([2, 0, 1])
+    assert p.permute_array(["a", "b", "c"]) == ["c", "a", "b"]
+    rng = native.ChaCha20Rng(bytes(32))
+    assert rng.next_u64().to_bytes(8, "little").hex() == "76b8e0ada0f13d90"
+    q = native.Permutation.new(native.ChaCha20Rng(bytes(32)), 52)
+    assert sorted(q.mapping) == list(range(52))
+    assert native.CryptoError("x") == native.CryptoError("x") != native.CryptoError("y")
+    with pytest.raises(native.CardProtocolError):
+        native.Parameters(2, 3, b"\0" * 5)
+
+
+@pytest.fixture(scope="module")
+def emu(native):
+    d = os.path.join(ROOT, "tools", "hostemu")
+    subprocess.check_call(["make", "-s", "-C", d])
+    lib = native._native.bind(ctypes.CDLL(os.path.join(d, "libmpemu.so")))
+    return lambda curve: native._native.Engine(curve, 0, lib=lib)
+
+
+@pytest.mark.parametrize("name", ["shuffle_stark_m2_n3_s1.json", "shuffle_stark_m3_n4_s11.json", "shuffle_bn254_m2_n4_s3.json",
+                                  "shuffle_secp256k1_m3_n3_s5.json", "shuffle_stark_m4_n13_s9.json"])
+def test_kernel_bodies_under_emulation_match_golden(emu, name):
+    g = load_json(os.path.join(GOLDEN, name))
+    eng = emu(g["curve"])
+    m, n = g["m"], g["n"]
+    t = eng.table(m, n, bytes.fromhex(g["params"]), bytes.fromhex(g["pk"]))
+    deck, proof = t.shuffle_and_remask(bytes.fromhex(g["deck"]), bytes.fromhex(g["rho"]), g["perm"], bytes.fromhex(g["prover_seed"]))
+    assert deck.hex() == g["shuffled"]
+    assert proof.hex() == g["proof"]
+    assert t.verify_shuffle(bytes.fromhex(g["deck"]), deck, proof) == 0
+    bad = bytearray(proof)
+    bad[-1] ^= 0          # unchanged copy still verifies
+    swapped = deck[128:256] + deck[0:128] + deck[256:]
+    assert eng.check_name(t.verify_shuffle(bytes.fromhex(g["deck"]), swapped, proof)) == "Hadamard Product (5.1)"
+    t.close()
+
+
+def test_emulated_batch_and_status(emu, coracle):
+    cv, m, n = "stark", 2, 3
+    eng = emu(cv)
+    ins = [coracle.gen_inputs(cv, m, n, 300 + b) for b in range(3)]
+    t = eng.table(m, n, ins[0]["params"], ins[0]["pk"])
+    perms = [v for g in ins for v in g["perm"]]
+    perms[6:12] = [0, 0, 1, 2, 3, 4]          # proof 1: invalid permutation
+    d, p, st = t.shuffle_and_remask_batch(b"".join(g["deck"] for g in ins), b"".join(g["rho"] for g in ins), perms,
+                                          b"".join(g["prover_seed"] for g in ins))
+    assert st == [0, -2, 0]
+    ps = t.proof_bytes
+    for b in (0, 2):
+        g = ins[b]
+        ed, ep = coracle.shuffle_and_remask(cv, m, n, ins[0]["params"], ins[0]["pk"], g["deck"], g["rho"], g["perm"], g["prover_seed"])
+        assert d[b * 6 * 128:(b + 1) * 6 * 128] == ed and p[b * ps:(b + 1) * ps] == ep
+    st = t.verify_shuffle_batch(b"".join(g["deck"] for g in ins), d, p)
+    assert st[0] == 0 and st[2] == 0 and st[1] != 0
+    t.close()

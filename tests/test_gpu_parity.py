@@ -1,0 +1,268 @@
+"""-m gpu: parity of the HIP engine (through the C ABI) with the oracle.  Bit-exact everywhere: the path is
+integer arithmetic, so proofs, decks and verdicts must be byte-identical to the oracle's.
+
+Mirrors the reference's `test_shuffle` [REF barnett-smart-card-protocol/src/discrete_log_cards/tests.rs:175-227]
+(accept honest / reject a wrong deck with "Hadamard Product (5.1)") and adds what the reference lacks:
+fixed vectors, edge inputs, tamper cases per check, usage errors, batch-position independence and
+full-size round trips."""
+import copy
+import os
+
+import pytest
+
+from conftest import GOLDEN, golden_cases, load_json
+
+import mp_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _split(b, sz):
+    return [b[i:i + sz] for i in range(0, len(b), sz)]
+
+
+@pytest.fixture(scope="module")
+def engines(mp):
+    cache = {}
+
+    def get(curve):
+        if curve not in cache:
+            cache[curve] = mp.DLCards(curve, device=0)
+        return cache[curve]
+    return get
+
+
+def test_native_library_is_the_one_running(mp, engines):
+    engines("stark")
+    maps = open("/proc/self/maps").read()
+    assert "libmpshuffle.so" in maps
+    assert "libmpemu" not in maps
+
+
+@pytest.mark.parametrize("path", golden_cases(), ids=os.path.basename)
+def test_golden_vectors(mp, engines, path):
+    g = load_json(path)
+    cv, m, n = g["curve"], g["m"], g["n"]
+    cards = engines(cv)
+    pp = mp.Parameters(m, n, bytes.fromhex(g["params"]))
+    pk = bytes.fromhex(g["pk"])
+    deck = _split(bytes.fromhex(g["deck"]), 128)
+    rho = [int.from_bytes(x, "little") for x in _split(bytes.fromhex(g["rho"]), 32)]
+    shuffled, proof = cards.shuffle_and_remask(bytes.fromhex(g["prover_seed"]), pp, pk, deck, rho, mp.Permutation(g["perm"]))
+    assert b"".join(shuffled).hex() == g["shuffled"]
+    assert proof.hex() == g["proof"]
+    assert cards.verify_shuffle(pp, pk, deck, shuffled, proof) is None
+    wrong = _split(po.deck_to_bytes(po.gen_inputs(po.CURVES[cv], m, n, g["seed"] + 1000)[2]), 128)
+    with pytest.raises(mp.CryptoError) as ei:
+        cards.verify_shuffle(pp, pk, deck, wrong, proof)
+    assert ei.value == mp.CryptoError("Hadamard Product (5.1)")
+
+
+@pytest.mark.parametrize("curve,m,n,B", [("stark", 2, 26, 6), ("stark", 4, 13, 5), ("stark", 6, 5, 3),
+                                         ("bn254", 3, 5, 3), ("secp256k1", 2, 7, 3)])
+def test_batch_matches_oracle(mp, engines, coracle, curve, m, n, B):
+    cards = engines(curve)
+    g0 = coracle.gen_inputs(curve, m, n, 100)
+    pp = mp.Parameters(m, n, g0["params"])
+    pk = g0["pk"]
+    ins = []
+    for b in range(B):
+        g = coracle.gen_inputs(curve, m, n, 200 + b)     # same draw order => same params? no: own params per seed
+        ins.append(g)
+    # all proofs of a batch share the table's (params, pk): take decks / rho / perm / seeds from each input set
+    res = cards.shuffle_and_remask_batch([g["prover_seed"] for g in ins], pp, pk,
+                                         [_split(g["deck"], 128) for g in ins],
+                                         [[int.from_bytes(x, "little") for x in _split(g["rho"], 32)] for g in ins],
+                                         [mp.Permutation(g["perm"]) for g in ins])
+    decks, shufs, proofs = [], [], []
+    for g, r in zip(ins, res):
+        assert not isinstance(r, Exception), r
+        exp_deck, exp_proof = coracle.shuffle_and_remask(curve, m, n, g0["params"], pk, g["deck"], g["rho"], g["perm"], g["prover_seed"])
+        assert b"".join(r[0]) == exp_deck
+        assert r[1] == exp_proof
+        decks.append(_split(g["deck"], 128)); shufs.append(r[0]); proofs.append(r[1])
+    assert cards.verify_shuffle_batch(pp, pk, decks, shufs, proofs) == [None] * B
+    # mixed batch: proof b checked against the deck of proof b+1 must fail by name, the others pass
+    rot = shufs[1:] + shufs[:1]
+    out = cards.verify_shuffle_batch(pp, pk, decks, rot, proofs)
+    assert all(o == mp.CryptoError("Hadamard Product (5.1)") for o in out)
+
+
+def test_tampering_names_the_failing_check(mp, engines):
+    g = load_json(os.path.join(GOLDEN, "shuffle_stark_m3_n4_s11.json"))
+    m, n = g["m"], g["n"]
+    cards = engines("stark")
+    pp = mp.Parameters(m, n, bytes.fromhex(g["params"]))
+    pk = bytes.fromhex(g["pk"])
+    deck, shuf = _split(bytes.fromhex(g["deck"]), 128), _split(bytes.fromhex(g["shuffled"]), 128)
+    pf = po.proof_from_bytes(bytes.fromhex(g["proof"]), m, n)
+    q = po.STARK.q
+    G = po.STARK.G
+
+    def name(mut):
+        p2 = copy.deepcopy(pf)
+        mut(p2)
+        try:
+            cards.verify_shuffle(pp, pk, deck, shuf, po.proof_to_bytes(p2))
+            return "Ok"
+        except mp.CryptoError as e:
+            return e.check
+
+    def bump(d, k, i=None):
+        if i is None:
+            d[k] = (d[k] + 1) % q
+        else:
+            d[k][i] = (d[k][i] + 1) % q
+
+    def setpt(d, k, i=None):
+        if i is None:
+            d[k] = G
+        else:
+            d[k][i] = G
+
+    assert name(lambda p: None) == "Ok"
+    assert name(lambda p: setpt(p["product"]["had"], "cB", 0)) == "Hadamard Product (5.1)"
+    assert name(lambda p: setpt(p["product"]["had"], "cB", m - 1)) == "Hadamard Product (5.1)"
+    assert name(lambda p: bump(p["product"]["had"]["zero"], "tbar")) == "Zero Argument (5.2)"
+    assert name(lambda p: bump(p["product"]["had"]["zero"], "abar", 2)) == "Zero Argument (5.2)"
+    assert name(lambda p: bump(p["product"]["had"]["zero"], "bbar", 0)) == "Zero Argument (5.2)"
+    assert name(lambda p: setpt(p["product"]["had"]["zero"], "cD", m + 1)) == "Zero Argument (5.2)"
+    assert name(lambda p: bump(p["product"]["svp"], "rt")) == "Single Value Product (5.3)"
+    assert name(lambda p: bump(p["product"]["svp"], "st")) == "Single Value Product (5.3)"
+    assert name(lambda p: bump(p["product"]["svp"], "bt", 0)) == "Single Value Product (5.3)"
+    assert name(lambda p: bump(p["mexp"], "taubar")) == "Multi-Exponentiation Argument (4)"
+    assert name(lambda p: bump(p["mexp"], "abar", 1)) == "Multi-Exponentiation Argument (4)"
+    assert name(lambda p: bump(p["mexp"], "sbar")) == "Multi-Exponentiation Argument (4)"
+    assert name(lambda p: setpt(p["mexp"], "cB", m)) == "Multi-Exponentiation Argument (4)"
+    # the oracle names the same check for every one of these
+    for mut in (lambda p: bump(p["mexp"], "rbar"), lambda p: bump(p["product"]["svp"], "at", 1)):
+        p2 = copy.deepcopy(pf)
+        mut(p2)
+        exp = po.CHECK_NAMES[po.verify_shuffle(*_po_args(g), po.deck_from_bytes(bytes.fromhex(g["shuffled"])), p2)]
+        assert name(mut) == exp
+
+
+def _po_args(g):
+    cv = po.CURVES[g["curve"]]
+    pp, pk, deck, rho, perm, ps = po.gen_inputs(cv, g["m"], g["n"], g["seed"])
+    return pp, pk, deck
+
+
+def test_edge_inputs(mp, engines):
+    """identity permutation, rho in {0, 1, q-1}, duplicate cards, a point-at-infinity component"""
+    cvn, m, n = "stark", 2, 3
+    cv = po.CURVES[cvn]
+    pp, pk, deck, rho, perm, ps = po.gen_inputs(cv, m, n, 42)
+    deck[1] = deck[0]
+    deck[2] = (None, deck[2][1])
+    rho = [0, 1, cv.q - 1, rho[3], rho[4], 0]
+    perm = list(range(m * n))
+    sh, pf = po.shuffle_and_remask(pp, pk, deck, rho, perm, ps)
+    cards = engines(cvn)
+    P = mp.Parameters(m, n, po.params_to_bytes(pp))
+    wdeck = _split(po.deck_to_bytes(deck), 128)
+    shuffled, proof = cards.shuffle_and_remask(ps, P, po.pt_wire(pk), wdeck, rho, mp.Permutation(perm))
+    assert b"".join(shuffled) == po.deck_to_bytes(sh)
+    assert proof == po.proof_to_bytes(pf)
+    assert cards.verify_shuffle(P, po.pt_wire(pk), wdeck, shuffled, proof) is None
+
+
+def test_usage_errors_are_io_errors(mp, engines, coracle):
+    cv, m, n = "stark", 2, 3
+    g = coracle.gen_inputs(cv, m, n, 5)
+    cards = engines(cv)
+    pp = mp.Parameters(m, n, g["params"])
+    deck = _split(g["deck"], 128)
+    rho = [int.from_bytes(x, "little") for x in _split(g["rho"], 32)]
+    good = cards.shuffle_and_remask(g["prover_seed"], pp, g["pk"], deck, rho, mp.Permutation(g["perm"]))
+    with pytest.raises(mp.CardProtocolError) as e:
+        cards.shuffle_and_remask(g["prover_seed"], pp, g["pk"], deck, rho, mp.Permutation([0, 0, 1, 2, 3, 4]))
+    assert e.value.kind == "IoError"
+    with pytest.raises(mp.CardProtocolError):
+        cards.shuffle_and_remask(g["prover_seed"], pp, g["pk"], deck, [po.STARK.q] + rho[1:], mp.Permutation(g["perm"]))
+    bad_card = bytearray(deck[0])
+    bad_card[0] ^= 1   # x changed: not on the curve any more
+    with pytest.raises(mp.CardProtocolError):
+        cards.shuffle_and_remask(g["prover_seed"], pp, g["pk"], [bytes(bad_card)] + deck[1:], rho, mp.Permutation(g["perm"]))
+    pf = bytearray(good[1])
+    pf[-32:] = b"\xff" * 32          # non-canonical scalar
+    with pytest.raises(mp.CardProtocolError):
+        cards.verify_shuffle(pp, g["pk"], deck, good[0], bytes(pf))
+    with pytest.raises(mp.CardProtocolError):
+        cards.verify_shuffle(pp, g["pk"], deck, good[0], good[1][:-1])   # wrong length
+
+
+def test_setup_matches_oracle(mp, engines):
+    for cvn in ("stark", "bn254", "secp256k1"):
+        seed = bytes(range(7, 39))
+        pp = engines(cvn).setup(seed, 3, 5)
+        exp = po.setup(po.CURVES[cvn], 3, 5, po.ChaCha20Rng(seed))
+        assert pp.raw == po.params_to_bytes(exp)
+
+
+def test_building_blocks(mp, engines, coracle):
+    cv, m, n = "stark", 2, 6
+    g = coracle.gen_inputs(cv, m, n, 77)
+    t = engines(cv).table(mp.Parameters(m, n, g["params"]), g["pk"])
+    # remask (K3)
+    assert t.remask_batch(g["deck"], g["rho"]) == coracle.remask_deck(cv, g["params"][:64], g["pk"], g["deck"], g["rho"])
+    # variable-base MSM (K5): 5 MSMs of 7 terms, 3 of 33 terms, with zero / one / q-1 scalars
+    pts = [g["deck"][i * 64:(i + 1) * 64] for i in range(2 * m * n)]
+    for n_msm, k in ((5, 7), (3, 33), (2, 1)):
+        sc, pt, exp = b"", b"", b""
+        for j in range(n_msm):
+            s_j = [int.from_bytes(g["rho"][((j + t_) % (m * n)) * 32:((j + t_) % (m * n) + 1) * 32], "little") for t_ in range(k)]
+            s_j[0] = 0
+            if k > 2:
+                s_j[1] = 1
+                s_j[2] = po.STARK.q - 1
+            p_j = [pts[(3 * j + t_) % len(pts)] for t_ in range(k)]
+            sb = b"".join(v.to_bytes(32, "little") for v in s_j)
+            sc += sb
+            pt += b"".join(p_j)
+            exp += coracle.msm(cv, sb, b"".join(p_j), 0)
+        assert t.msm(n_msm, k, sc, pt) == exp
+    # Pedersen commitments (K4)
+    vals = g["rho"][:32 * n]
+    r = g["rho"][32 * n:32 * (n + 1)]
+    for length in (n, n - 1, 1):
+        exp = coracle.commit(cv, n, g["params"], vals[:32 * length], r)
+        assert t.commit_batch(1, length, vals[:32 * length], r) == exp
+
+
+def test_full_size_properties(mp, engines, coracle):
+    """BASELINE size (52 cards, m=2, n=26), a few hundred proofs: every honest proof verifies, outputs do not
+    depend on the position in the batch, a chain of dependent shuffles (deck_{j+1} = output_j) verifies, and
+    spot proofs equal the oracle's."""
+    cv, m, n, B = "stark", 2, 26, 192
+    N = m * n
+    g = coracle.gen_inputs(cv, m, n, 31337)
+    cards = engines(cv)
+    pp = mp.Parameters(m, n, g["params"])
+    deck = _split(g["deck"], 128)
+    rng = mp.ChaCha20Rng(b"\x05" * 32)
+    q = po.STARK.q
+    seeds, rhos, perms = [], [], []
+    for b in range(B):
+        seeds.append(b"".join((rng.next_u64()).to_bytes(8, "little") for _ in range(4)))
+        rhos.append([(rng.next_u64() | (rng.next_u64() << 64) | (rng.next_u64() << 128) | ((rng.next_u64() >> 6) << 192)) % q for _ in range(N)])
+        perms.append(mp.Permutation.new(rng, N))
+    # duplicate entry 0 at the end: same inputs at a different batch position
+    seeds.append(seeds[0]); rhos.append(rhos[0]); perms.append(perms[0])
+    res = cards.shuffle_and_remask_batch(seeds, pp, g["pk"], [deck] * (B + 1), rhos, perms)
+    assert all(not isinstance(r, Exception) for r in res)
+    assert res[0] == res[B]
+    for b in (0, B // 2, B - 1):
+        exp_deck, exp_proof = coracle.shuffle_and_remask(cv, m, n, g["params"], g["pk"], g["deck"],
+                                                         b"".join(v.to_bytes(32, "little") for v in rhos[b]), perms[b].mapping, seeds[b])
+        assert b"".join(res[b][0]) == exp_deck and res[b][1] == exp_proof
+    out = cards.verify_shuffle_batch(pp, g["pk"], [deck] * (B + 1), [r[0] for r in res], [r[1] for r in res])
+    assert out == [None] * (B + 1)
+    # chain: each player shuffles the previous output [REF examples/round.rs:263-350]
+    cur = deck
+    for j in range(3):
+        nxt, proof = cards.shuffle_and_remask(seeds[j], pp, g["pk"], cur, rhos[j], perms[j])
+        assert cards.verify_shuffle(pp, g["pk"], cur, nxt, proof) is None
+        with pytest.raises(mp.CryptoError):
+            cards.verify_shuffle(pp, g["pk"], deck if j else nxt, nxt if j else cur, proof)
+        cur = nxt
