@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""bench.py -- shuffle proofs/sec (prove + verify) on MI355X, BASELINE.json's metric.
+
+One step = one pass of the hot path over one batch: B independent 52-card decks (m=2, n=26, STARK curve
+[REF barnett-smart-card-protocol/examples/round.rs:229-230]) each go through `shuffle_and_remask` (ElGamal
+re-encryption + Bayer-Groth prover) and `verify_shuffle`, with every input already resident in HBM.
+Synthetic data: random ciphertext decks [REF src/discrete_log_cards/tests.rs:187] obtained by re-encrypting one
+random base deck on the GPU; masking factors uniform below 2^251; uniform permutations; random prover seeds.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Proofs are independent, so ranks shard the batch with no data-path collective (weak scaling: B proofs per GPU
+per step); the shared parameters are produced on rank 0 and broadcast once over RCCL.  Rank 0 prints one JSON
+line.  `roofline` is measured live with HIP events on the engine's own stream around every kernel launch of the
+timed region; `cpu_baseline` times the oracle's single-threaded C++ restatement (arkworks-style algorithms) on a
+bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "py")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+INT_MAD_PEAK_G = 18000.0       # v_mad_u64_u32 issue rate measured with tools/microbench/intrate.hip (Gmad/s)
+MADS_PER_POINT_OP = 856        # mixed addition 7M + 4S on the STARK base field, 88 / 60 limb products
+
+
+# ---- distributed helpers (backend-agnostic: RCCL on GPUs, gloo in the CPU tests) -----------------------------
+def dist_info():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+
+
+def bcast_bytes(data, nbytes, src, device):
+    """broadcast a byte string from rank `src` to every rank (shared parameters, once per session)"""
+    import torch
+    import torch.distributed as dist
+    if data is not None:
+        t = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(device)
+    else:
+        t = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(t, src=src)
+    return bytes(t.cpu().numpy().tobytes())
+
+
+def reduce_max(x, device):
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def reduce_sum(x, device):
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def shard_range(total, rank, world):
+    """static contiguous block partition of proof indices"""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+# ---- the benchmark -----------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8192, help="proofs per GPU per step")
+    ap.add_argument("--m", type=int, default=2)
+    ap.add_argument("--n", type=int, default=26)
+    ap.add_argument("--curve", default="stark")
+    ap.add_argument("--cpu-iters", type=int, default=96, help="prove+verify pairs timed for cpu_baseline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank, world, local = dist_info()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    mp = importlib.import_module("mental-poker_amd")
+    m, n, curve, B = args.m, args.n, args.curve, args.batch
+    N = m * n
+    eng = mp.Engine(curve, device=local)
+
+    # ---- shared parameters: rank 0 runs `setup`, everyone receives them over RCCL (once)
+    psz = 64 * (n + 3)
+    blob = None
+    if rank == 0:
+        params = eng.setup(m, n, bytes([1] * 32))
+        pk = eng.setup(m, 2, bytes([2] * 32))[:64]                  # aggregate key: a random group element
+        base_deck = eng.setup(m, 2 * N - 3, bytes([3] * 32))        # 2N random points = N random ciphertexts
+        blob = params + pk + base_deck
+    blob = bcast_bytes(blob, psz + 64 + 128 * N, 0, dev)
+    params, pk, base_deck = blob[:psz], blob[psz:psz + 64], blob[psz + 64:]
+    table = eng.table(m, n, params, pk)
+    table.reserve(B)
+    proof_bytes = table.proof_bytes
+
+    # ---- synthetic inputs, resident in HBM
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+
+    def rand_bytes(*shape):
+        return torch.randint(0, 256, shape, dtype=torch.uint8, device=dev, generator=gen)
+
+    def rand_factors():
+        f = rand_bytes(B, N, 32)
+        f[:, :, 31] &= 0x07            # < 2^251 < group order
+        return f.contiguous()
+
+    def rand_perms():
+        return torch.argsort(torch.rand(B, N, device=dev, generator=gen), dim=1).to(torch.int32).contiguous()
+
+    base = torch.frombuffer(bytearray(base_deck), dtype=torch.uint8).to(dev)
+    decks0 = base.repeat(B, 1).contiguous()
+    decks = torch.empty(B, N * 128, dtype=torch.uint8, device=dev)
+    out_decks = torch.empty(B, N * 128, dtype=torch.uint8, device=dev)
+    out_proofs = torch.empty(B, proof_bytes, dtype=torch.uint8, device=dev)
+    st_p = torch.empty(B, dtype=torch.int32, device=dev)
+    st_v = torch.empty(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    # prime: B different random decks = re-encryptions of the base deck (untimed input generation)
+    f0, p0, s0 = rand_factors(), rand_perms(), rand_bytes(B, 32)
+    torch.cuda.synchronize()
+    table.shuffle_and_remask_batch_dev(B, decks0.data_ptr(), f0.data_ptr(), p0.data_ptr(), s0.data_ptr(),
+                                       decks.data_ptr(), out_proofs.data_ptr(), st_p.data_ptr())
+    eng.sync()
+    assert int(st_p.abs().sum().item()) == 0, "priming pass failed"
+    factors, perms, seeds = rand_factors(), rand_perms(), rand_bytes(B, 32)
+    torch.cuda.synchronize()
+
+    def step():
+        table.shuffle_and_remask_batch_dev(B, decks.data_ptr(), factors.data_ptr(), perms.data_ptr(), seeds.data_ptr(),
+                                           out_decks.data_ptr(), out_proofs.data_ptr(), st_p.data_ptr())
+        table.verify_shuffle_batch_dev(B, decks.data_ptr(), out_decks.data_ptr(), out_proofs.data_ptr(), st_v.data_ptr())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.sync()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_report()
+    eng.profile_enable(False)
+    elapsed = reduce_max(elapsed, dev)
+
+    # ---- correctness of what was timed (outside the timed region)
+    bad = int((st_p != 0).sum().item()) + int((st_v != 0).sum().item())
+    assert bad == 0, "%d proofs failed on rank %d" % (bad, rank)
+    parity = None
+    if rank == 0:
+        import coracle as co
+        co.build()
+        b = B // 2
+        exp_deck, exp_proof = co.shuffle_and_remask(curve, m, n, params, pk, bytes(decks[b].cpu().numpy().tobytes()),
+                                                    bytes(factors[b].cpu().numpy().tobytes()),
+                                                    [int(v) for v in perms[b].cpu().tolist()],
+                                                    bytes(seeds[b].cpu().numpy().tobytes()))
+        parity = (bytes(out_decks[b].cpu().numpy().tobytes()) == exp_deck and
+                  bytes(out_proofs[b].cpu().numpy().tobytes()) == exp_proof)
+        assert parity, "timed output differs from the oracle"
+
+    total_proofs = reduce_sum(B * args.steps, dev)
+    value = total_proofs / elapsed
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (live HIP-event timings of the timed region)
+    stats = table.plan_stats()
+    census = table.work_census()
+    dom = max(prof.items(), key=lambda kv: kv[1][1])
+    dom_name, (dom_count, dom_ms) = dom
+    kernel_ms_total = sum(v[1] for v in prof.values())
+
+    def alg_bytes_per_proof(kernel):
+        """ALGORITHMIC bytes one proof needs from this kernel class in one step (prove + verify launches):
+        scalars 32 B, points 64 B, Jacobian results 96 B ("algorithmic bytes")."""
+        pv = [stats["prove"], stats["verify"]]
+        if kernel == "k_var_msm":
+            return sum(s["var_terms"] * (32 + 64) + s["var_jobs"] * 96 for s in pv)
+        if kernel == "k_fixed_msm":
+            return sum(s["fixed_terms"] * 32 + s["fixed_jobs"] * 96 for s in pv)
+        if kernel == "k_table":
+            return sum(s["table_bases"] * (64 + 16 * 96) for s in pv)
+        if kernel == "k_normalize":
+            return sum(s["table_bases"] * 16 * (96 + 64) for s in pv)
+        return 45 * 1024
+    dom_bytes = alg_bytes_per_proof(dom_name) * B * args.steps
+    achieved_gbs = dom_bytes / (dom_ms * 1e-3) / 1e9
+    point_ops = (census["prove_point_ops"] + census["verify_point_ops"]) * B * args.steps
+    mads = point_ops * MADS_PER_POINT_OP
+    whole_path_bytes = 45 * 1024 if (m, n) == (2, 26) else None
+    roofline = {
+        "bound": "hbm", "kernel": dom_name, "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+        "avg_launch_ms": dom_ms / dom_count, "launches": dom_count,
+        "alg_bytes_per_launch": dom_bytes / dom_count,
+        "note": "path is integer-ALU bound (SURVEY 8d3): see int_mul",
+        "int_mul": {"bound": "v_mad_u64_u32 issue", "achieved": round(mads / (kernel_ms_total * 1e-3) / 1e9, 1),
+                    "peak": INT_MAD_PEAK_G, "unit": "Gmad/s",
+                    "frac": mads / (kernel_ms_total * 1e-3) / 1e9 / INT_MAD_PEAK_G},
+        "whole_path_hbm_frac": (value * whole_path_bytes / 1e9 / HBM_PEAK_GBS) if whole_path_bytes else None,
+        "kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
+    }
+
+    # ---- CPU baseline: the oracle's C++ restatement (port), single thread, bounded sample
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        import coracle as co
+        it = args.cpu_iters
+        t_p, t_v = co.bench(curve, m, n, 99, it)
+        cpu = {"value": it / (t_p + t_v), "unit": "proofs/s", "cores": 1, "kind": "port",
+               "sample": "%d prove+verify pairs, %d-card deck (m=%d,n=%d), %s, single thread; prove %.1f ms verify %.1f ms each"
+                         % (it, N, m, n, curve, 1e3 * t_p / it, 1e3 * t_v / it),
+               "host_cores_available": os.cpu_count()}
+
+    out = {
+        "metric": "shuffle proofs/sec (prove+verify)", "value": value, "unit": "proofs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (256-bit Montgomery, 8x32 limbs)",
+        "data": "synthetic",
+        "config": {"workload": "%d-card deck, m=%d n=%d, %s curve, shuffle_and_remask + verify_shuffle" % (N, m, n, curve),
+                   "proofs_per_gpu_per_step": B, "parity_vs_oracle": parity},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
