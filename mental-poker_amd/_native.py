@@ -33,18 +33,41 @@ class NoDeviceError(NativeError):
     pass
 
 
+SOURCES = ["capi.hip", "curve_stark.hip", "curve_bn254.hip", "curve_secp256k1.hip"]
+
+
 def build(verbose=False):
-    """compile the HIP engine for gfx950 in-tree -> mental-poker_amd/libmpshuffle.so"""
-    src = os.path.join(HERE, "csrc", "engine.hip")
-    deps = [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))]
-    deps.append(os.path.join(ROOT, "include", "mpshuffle.h"))
-    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    """compile the HIP engine for gfx950 in-tree -> mental-poker_amd/libmpshuffle.so
+    (one translation unit per curve, compiled in parallel, objects cached under csrc/_obj)"""
+    from concurrent.futures import ThreadPoolExecutor
+    csrc = os.path.join(HERE, "csrc")
+    objdir = os.path.join(csrc, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
+    headers.append(os.path.join(ROOT, "include", "mpshuffle.h"))
+    hdr_time = max(os.path.getmtime(h) for h in headers)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH, src]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        spath = os.path.join(csrc, src)
+        if os.path.exists(obj) and os.path.getmtime(obj) >= max(hdr_time, os.path.getmtime(spath)):
+            return obj, False
+        cmd = [hipcc] + flags + ["-c", spath, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj, True
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        res = list(ex.map(compile_one, SOURCES))
+    objs = [r[0] for r in res]
+    if any(r[1] for r in res) or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(o) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return LIB_PATH
 
 

@@ -1,0 +1,3 @@
+// curve_bn254.hip -- instantiates the engine for one curve (separate TU: the curves compile in parallel)
+#include "engine_core.hpp"
+MP_DEFINE_CURVE(Bn254)

@@ -1,0 +1,3 @@
+// curve_secp256k1.hip -- instantiates the engine for one curve (separate TU: the curves compile in parallel)
+#include "engine_core.hpp"
+MP_DEFINE_CURVE(Secp256k1)

@@ -1,0 +1,149 @@
+#pragma once
+// engine_base.hpp -- shared declarations of libmpshuffle.so
+// libmpshuffle.so: host orchestration of the gfx950 shuffle-proof engine and its C ABI (include/mpshuffle.h).
+//
+// A batch of B independent proofs goes through a fixed sequence of kernels on one HIP stream with NO host
+// round-trip inside a batch: Fiat-Shamir challenges are derived on the device.  The prover's group work is
+// packed into four dependency levels (everything that can be computed between two squeeze points runs in one
+// launch of each kernel class), the verifier's into one.
+//
+//   prove : load -> init(rand, perm) -> remask -> [A: c_A] -> FS x -> scal1 -> [B: c_B, multi-exp msg] -> FS y,z
+//           -> scal2 -> [C: c_b, Hadamard, SVP msgs] -> FS hx,hy -> scal3 -> [D: zero-arg msgs] -> FS zx,svx,mx
+//           -> scal4 (responses) -> store
+//   verify: load -> FS (all challenges) -> scalars (MSM coefficients, direct checks) -> [MSMs == O] -> verdict
+//
+// Mirrors DLCards::{setup, shuffle_and_remask, verify_shuffle}
+// [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:105-121, 380-418, 420-443].
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/mpshuffle.h"
+#include "layout.hpp"
+
+namespace mp {
+
+std::string& last_error();
+inline int fail(int code, const std::string& msg) {
+  last_error() = msg;
+  return code;
+}
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() {}
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { rt::dfree(p); }
+  void alloc(size_t count, rt::Stream s, bool zero = true) {
+    if (count <= n) return;
+    rt::dfree(p);
+    p = nullptr;
+    p = (T*)rt::dmalloc(count * sizeof(T));
+    n = count;
+    if (zero) rt::dzero(p, count * sizeof(T), s);
+  }
+  void upload(const std::vector<T>& v, rt::Stream s) {
+    alloc(v.size() ? v.size() : 1, s, false);
+    if (!v.empty()) rt::h2d(p, v.data(), v.size() * sizeof(T), s);
+  }
+};
+
+struct Profiler {
+  bool on = false;
+  struct Rec {
+    const char* name;
+    rt::Event a, b;
+  };
+  std::vector<Rec> recs;
+  std::vector<rt::Event> pool;
+  rt::Event get() {
+    if (!pool.empty()) {
+      rt::Event e = pool.back();
+      pool.pop_back();
+      return e;
+    }
+    return rt::event_create();
+  }
+  void begin(const char* name, rt::Stream s) {
+    if (!on) return;
+    Rec r{name, get(), get()};
+    rt::event_record(r.a, s);
+    recs.push_back(r);
+  }
+  void end(rt::Stream s) {
+    if (!on) return;
+    rt::event_record(recs.back().b, s);
+  }
+  std::string report() {
+    std::map<std::string, std::pair<long, double>> acc;
+    std::vector<std::string> order;
+    for (auto& r : recs) {
+      float ms = rt::event_ms(r.a, r.b);
+      if (!acc.count(r.name)) order.push_back(r.name);
+      acc[r.name].first += 1;
+      acc[r.name].second += ms;
+      pool.push_back(r.a);
+      pool.push_back(r.b);
+    }
+    recs.clear();
+    std::ostringstream os;
+    for (auto& k : order) os << k << " " << acc[k].first << " " << acc[k].second << "\n";
+    return os.str();
+  }
+  ~Profiler() {
+    for (auto& r : recs) {
+      rt::event_destroy(r.a);
+      rt::event_destroy(r.b);
+    }
+    for (auto e : pool) rt::event_destroy(e);
+  }
+};
+
+}  // namespace mp
+
+struct mp_ctx {
+  int curve = 0;
+  int device = 0;
+  mp::rt::Stream stream{};
+  mp::Profiler prof;
+};
+
+#define MP_RUN(NAME, C, nx, ny, args)                      \
+  do {                                                     \
+    ctx->prof.begin(#NAME, ctx->stream);                   \
+    MP_LAUNCH(NAME, C, ctx->stream, (nx), (ny), (args));   \
+    ctx->prof.end(ctx->stream);                            \
+  } while (0)
+
+struct mp_table {
+  mp_ctx* ctx = nullptr;
+  uint32_t m = 0, n = 0, N = 0;
+  virtual ~mp_table() {}
+  virtual void reserve(size_t B) = 0;
+  virtual void prove_dev(size_t B, const uint8_t* decks, const uint8_t* rho, const uint32_t* perm, const uint8_t* seeds,
+                         uint8_t* out_decks, uint8_t* out_proofs, int32_t* status) = 0;
+  virtual void verify_dev(size_t B, const uint8_t* decks, const uint8_t* shuf, const uint8_t* proofs, int32_t* status) = 0;
+  virtual void remask_host(size_t count, const uint8_t* cards, const uint8_t* rho, uint8_t* out) = 0;
+  virtual void msm_host(size_t n_msm, size_t k, const uint8_t* scalars, const uint8_t* points, uint8_t* out) = 0;
+  virtual void commit_host(size_t count, size_t len, const uint8_t* values, const uint8_t* r, uint8_t* out) = 0;
+  virtual void census(uint64_t* pt, uint64_t* vt, uint64_t* po, uint64_t* vo) = 0;
+  virtual void plan_stats(uint64_t out[16]) = 0;
+};
+
+
+namespace mp {
+// per-curve factories (one translation unit per curve so that the curves compile in parallel)
+#define MP_DECLARE_CURVE(NAME)                                                                                          \
+  mp_table* make_table_##NAME(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, const uint8_t* pk, int* rc);  \
+  int setup_##NAME(uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out);
+MP_DECLARE_CURVE(Stark)
+MP_DECLARE_CURVE(Bn254)
+MP_DECLARE_CURVE(Secp256k1)
+}  // namespace mp

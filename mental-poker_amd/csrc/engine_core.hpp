@@ -1,139 +1,8 @@
-// libmpshuffle.so: host orchestration of the gfx950 shuffle-proof engine and its C ABI (include/mpshuffle.h).
-//
-// A batch of B independent proofs goes through a fixed sequence of kernels on one HIP stream with NO host
-// round-trip inside a batch: Fiat-Shamir challenges are derived on the device.  The prover's group work is
-// packed into four dependency levels (everything that can be computed between two squeeze points runs in one
-// launch of each kernel class), the verifier's into one.
-//
-//   prove : load -> init(rand, perm) -> remask -> [A: c_A] -> FS x -> scal1 -> [B: c_B, multi-exp msg] -> FS y,z
-//           -> scal2 -> [C: c_b, Hadamard, SVP msgs] -> FS hx,hy -> scal3 -> [D: zero-arg msgs] -> FS zx,svx,mx
-//           -> scal4 (responses) -> store
-//   verify: load -> FS (all challenges) -> scalars (MSM coefficients, direct checks) -> [MSMs == O] -> verdict
-//
-// Mirrors DLCards::{setup, shuffle_and_remask, verify_shuffle}
-// [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:105-121, 380-418, 420-443].
-#include <algorithm>
-#include <cstring>
-#include <map>
-#include <memory>
-#include <sstream>
-#include <string>
-#include <vector>
-
-#include "../../include/mpshuffle.h"
+// engine_core.hpp -- the per-curve engine: batch workspace, plans on the device, prove / verify pipelines.
+// Included by one translation unit per curve (curve_*.hip).
+#pragma once
+#include "engine_base.hpp"
 #include "kernels_proto.hpp"
-
-namespace mp {
-
-static thread_local std::string g_err;
-static int fail(int code, const std::string& msg) {
-  g_err = msg;
-  return code;
-}
-
-template <class T>
-struct DevBuf {
-  T* p = nullptr;
-  size_t n = 0;
-  DevBuf() {}
-  DevBuf(const DevBuf&) = delete;
-  DevBuf& operator=(const DevBuf&) = delete;
-  ~DevBuf() { rt::dfree(p); }
-  void alloc(size_t count, rt::Stream s, bool zero = true) {
-    if (count <= n) return;
-    rt::dfree(p);
-    p = nullptr;
-    p = (T*)rt::dmalloc(count * sizeof(T));
-    n = count;
-    if (zero) rt::dzero(p, count * sizeof(T), s);
-  }
-  void upload(const std::vector<T>& v, rt::Stream s) {
-    alloc(v.size() ? v.size() : 1, s, false);
-    if (!v.empty()) rt::h2d(p, v.data(), v.size() * sizeof(T), s);
-  }
-};
-
-struct Profiler {
-  bool on = false;
-  struct Rec {
-    const char* name;
-    rt::Event a, b;
-  };
-  std::vector<Rec> recs;
-  std::vector<rt::Event> pool;
-  rt::Event get() {
-    if (!pool.empty()) {
-      rt::Event e = pool.back();
-      pool.pop_back();
-      return e;
-    }
-    return rt::event_create();
-  }
-  void begin(const char* name, rt::Stream s) {
-    if (!on) return;
-    Rec r{name, get(), get()};
-    rt::event_record(r.a, s);
-    recs.push_back(r);
-  }
-  void end(rt::Stream s) {
-    if (!on) return;
-    rt::event_record(recs.back().b, s);
-  }
-  std::string report() {
-    std::map<std::string, std::pair<long, double>> acc;
-    std::vector<std::string> order;
-    for (auto& r : recs) {
-      float ms = rt::event_ms(r.a, r.b);
-      if (!acc.count(r.name)) order.push_back(r.name);
-      acc[r.name].first += 1;
-      acc[r.name].second += ms;
-      pool.push_back(r.a);
-      pool.push_back(r.b);
-    }
-    recs.clear();
-    std::ostringstream os;
-    for (auto& k : order) os << k << " " << acc[k].first << " " << acc[k].second << "\n";
-    return os.str();
-  }
-  ~Profiler() {
-    for (auto& r : recs) {
-      rt::event_destroy(r.a);
-      rt::event_destroy(r.b);
-    }
-    for (auto e : pool) rt::event_destroy(e);
-  }
-};
-
-}  // namespace mp
-
-struct mp_ctx {
-  int curve = 0;
-  int device = 0;
-  mp::rt::Stream stream{};
-  mp::Profiler prof;
-};
-
-#define MP_RUN(NAME, C, nx, ny, args)                      \
-  do {                                                     \
-    ctx->prof.begin(#NAME, ctx->stream);                   \
-    MP_LAUNCH(NAME, C, ctx->stream, (nx), (ny), (args));   \
-    ctx->prof.end(ctx->stream);                            \
-  } while (0)
-
-struct mp_table {
-  mp_ctx* ctx = nullptr;
-  uint32_t m = 0, n = 0, N = 0;
-  virtual ~mp_table() {}
-  virtual void reserve(size_t B) = 0;
-  virtual void prove_dev(size_t B, const uint8_t* decks, const uint8_t* rho, const uint32_t* perm, const uint8_t* seeds,
-                         uint8_t* out_decks, uint8_t* out_proofs, int32_t* status) = 0;
-  virtual void verify_dev(size_t B, const uint8_t* decks, const uint8_t* shuf, const uint8_t* proofs, int32_t* status) = 0;
-  virtual void remask_host(size_t count, const uint8_t* cards, const uint8_t* rho, uint8_t* out) = 0;
-  virtual void msm_host(size_t n_msm, size_t k, const uint8_t* scalars, const uint8_t* points, uint8_t* out) = 0;
-  virtual void commit_host(size_t count, size_t len, const uint8_t* values, const uint8_t* r, uint8_t* out) = 0;
-  virtual void census(uint64_t* pt, uint64_t* vt, uint64_t* po, uint64_t* vo) = 0;
-  virtual void plan_stats(uint64_t out[16]) = 0;
-};
 
 namespace mp {
 
@@ -636,247 +505,13 @@ static int setup_host(uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* o
 
 }  // namespace mp
 
-using namespace mp;
 
-#define MP_TRY try {
-#define MP_CATCH                                                                     \
-  }                                                                                  \
-  catch (const std::invalid_argument& e) { return fail(MP_ERR_BAD_ENCODING, e.what()); } \
-  catch (const std::exception& e) { return fail(MP_ERR_INTERNAL, e.what()); }
-
-extern "C" {
-
-const char* mp_last_error(void) { return g_err.c_str(); }
-const char* mp_check_name(int code) {
-  switch (code) {
-    case 0: return "Ok";
-    case 1: return "Hadamard Product (5.1)";
-    case 2: return "Zero Argument (5.2)";
-    case 3: return "Single Value Product (5.3)";
-    case 4: return "Multi-Exponentiation Argument (4)";
-    case MP_ERR_BAD_ENCODING: return "IoError: bad encoding";
-    case MP_ERR_BAD_PERMUTATION: return "IoError: not a permutation";
-    case MP_ERR_BAD_ARGUMENT: return "IoError: bad argument";
-    case MP_ERR_NO_DEVICE: return "IoError: no MI355X device";
-    default: return "IoError: internal";
+#define MP_DEFINE_CURVE(NAME)                                                                                           \
+  namespace mp {                                                                                                        \
+  mp_table* make_table_##NAME(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, const uint8_t* pk, int* rc) { \
+    auto* p = new Table<NAME>();                                                                                        \
+    *rc = p->init(ctx, m, n, params, pk);                                                                               \
+    return p;                                                                                                           \
+  }                                                                                                                     \
+  int setup_##NAME(uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out) { return setup_host<NAME>(m, n, seed, out); } \
   }
-}
-size_t mp_proof_size(uint32_t m, uint32_t n) { return proof_size_bytes(m, n); }
-size_t mp_params_size(uint32_t n) { return (size_t)(n + 3) * 64; }
-
-int mp_ctx_create(int curve_id, int device, mp_ctx** out) {
-  if (!out) return fail(MP_ERR_BAD_ARGUMENT, "null out pointer");
-  if (curve_id < 0 || curve_id > 2) return fail(MP_ERR_BAD_ARGUMENT, "unknown curve id");
-  MP_TRY
-  int ndev = rt::device_count();
-  if (ndev <= 0 || device < 0 || device >= ndev)
-    return fail(MP_ERR_NO_DEVICE, "no HIP device: libmpshuffle has no CPU path (runtime " MP_RT_NAME ")");
-  rt::set_device(device);
-  mp_ctx* c = new mp_ctx();
-  c->curve = curve_id;
-  c->device = device;
-  c->stream = rt::stream_create();
-  *out = c;
-  return MP_OK;
-  MP_CATCH
-}
-void mp_ctx_destroy(mp_ctx* ctx) {
-  if (!ctx) return;
-  rt::stream_destroy(ctx->stream);
-  delete ctx;
-}
-
-int mp_setup(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out_params) {
-  if (!ctx || !seed || !out_params || m < 2 || n < 2) return fail(MP_ERR_BAD_ARGUMENT, "mp_setup: bad argument");
-  MP_TRY
-  switch (ctx->curve) {
-    case 0: return setup_host<Stark>(m, n, seed, out_params);
-    case 1: return setup_host<Bn254>(m, n, seed, out_params);
-    default: return setup_host<Secp256k1>(m, n, seed, out_params);
-  }
-  MP_CATCH
-}
-
-int mp_table_create(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, const uint8_t* shared_key, mp_table** out) {
-  if (!ctx || !params || !shared_key || !out) return fail(MP_ERR_BAD_ARGUMENT, "mp_table_create: null pointer");
-  if (m < 2 || n < 2 || (uint64_t)m * n > 4096) return fail(MP_ERR_BAD_ARGUMENT, "mp_table_create: need m >= 2, n >= 2, m*n <= 4096");
-  MP_TRY
-  rt::set_device(ctx->device);
-  int rc;
-  mp_table* t = nullptr;
-  switch (ctx->curve) {
-    case 0: { auto* p = new Table<Stark>(); rc = p->init(ctx, m, n, params, shared_key); t = p; break; }
-    case 1: { auto* p = new Table<Bn254>(); rc = p->init(ctx, m, n, params, shared_key); t = p; break; }
-    default: { auto* p = new Table<Secp256k1>(); rc = p->init(ctx, m, n, params, shared_key); t = p; break; }
-  }
-  if (rc != MP_OK) {
-    delete t;
-    return rc;
-  }
-  *out = t;
-  return MP_OK;
-  MP_CATCH
-}
-void mp_table_destroy(mp_table* t) { delete t; }
-
-int mp_reserve(mp_table* t, size_t B) {
-  if (!t || !B) return fail(MP_ERR_BAD_ARGUMENT, "mp_reserve: bad argument");
-  MP_TRY
-  rt::set_device(t->ctx->device);
-  t->reserve(B);
-  rt::stream_sync(t->ctx->stream);
-  return MP_OK;
-  MP_CATCH
-}
-
-int mp_shuffle_and_remask_batch_dev(mp_table* t, size_t B, const void* d_decks, const void* d_masking_factors,
-                                    const void* d_permutations, const void* d_prover_seeds, void* d_out_decks,
-                                    void* d_out_proofs, void* d_status) {
-  if (!t || !B || !d_decks || !d_masking_factors || !d_permutations || !d_prover_seeds || !d_out_decks || !d_out_proofs || !d_status)
-    return fail(MP_ERR_BAD_ARGUMENT, "mp_shuffle_and_remask_batch_dev: bad argument");
-  MP_TRY
-  rt::set_device(t->ctx->device);
-  t->prove_dev(B, (const uint8_t*)d_decks, (const uint8_t*)d_masking_factors, (const uint32_t*)d_permutations,
-               (const uint8_t*)d_prover_seeds, (uint8_t*)d_out_decks, (uint8_t*)d_out_proofs, (int32_t*)d_status);
-  return MP_OK;
-  MP_CATCH
-}
-int mp_verify_shuffle_batch_dev(mp_table* t, size_t B, const void* d_decks, const void* d_shuffled_decks,
-                                const void* d_proofs, void* d_status) {
-  if (!t || !B || !d_decks || !d_shuffled_decks || !d_proofs || !d_status)
-    return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_batch_dev: bad argument");
-  MP_TRY
-  rt::set_device(t->ctx->device);
-  t->verify_dev(B, (const uint8_t*)d_decks, (const uint8_t*)d_shuffled_decks, (const uint8_t*)d_proofs, (int32_t*)d_status);
-  return MP_OK;
-  MP_CATCH
-}
-int mp_sync(mp_ctx* ctx) {
-  if (!ctx) return fail(MP_ERR_BAD_ARGUMENT, "mp_sync: null");
-  MP_TRY
-  rt::stream_sync(ctx->stream);
-  return MP_OK;
-  MP_CATCH
-}
-
-int mp_shuffle_and_remask_batch(mp_table* t, size_t B, const uint8_t* decks, const uint8_t* masking_factors,
-                                const uint32_t* permutations, const uint8_t* prover_seeds, uint8_t* out_decks,
-                                uint8_t* out_proofs, int32_t* status) {
-  if (!t || !B || !decks || !masking_factors || !permutations || !prover_seeds || !out_decks || !out_proofs || !status)
-    return fail(MP_ERR_BAD_ARGUMENT, "mp_shuffle_and_remask_batch: bad argument");
-  MP_TRY
-  rt::set_device(t->ctx->device);
-  rt::Stream s = t->ctx->stream;
-  const size_t N = t->N, psz = proof_size_bytes(t->m, t->n);
-  DevBuf<uint8_t> dd, dr, ds, dod, dop;
-  DevBuf<uint32_t> dp;
-  DevBuf<int32_t> dst;
-  dd.alloc(B * N * 128, s, false); dr.alloc(B * N * 32, s, false); dp.alloc(B * N, s, false); ds.alloc(B * 32, s, false);
-  dod.alloc(B * N * 128, s, false); dop.alloc(B * psz, s, false); dst.alloc(B, s, false);
-  rt::h2d(dd.p, decks, B * N * 128, s);
-  rt::h2d(dr.p, masking_factors, B * N * 32, s);
-  rt::h2d(dp.p, permutations, B * N * 4, s);
-  rt::h2d(ds.p, prover_seeds, B * 32, s);
-  t->prove_dev(B, dd.p, dr.p, dp.p, ds.p, dod.p, dop.p, dst.p);
-  rt::d2h(out_decks, dod.p, B * N * 128, s);
-  rt::d2h(out_proofs, dop.p, B * psz, s);
-  rt::d2h(status, dst.p, B * 4, s);
-  rt::stream_sync(s);
-  return MP_OK;
-  MP_CATCH
-}
-int mp_verify_shuffle_batch(mp_table* t, size_t B, const uint8_t* decks, const uint8_t* shuffled_decks,
-                            const uint8_t* proofs, int32_t* status) {
-  if (!t || !B || !decks || !shuffled_decks || !proofs || !status) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_batch: bad argument");
-  MP_TRY
-  rt::set_device(t->ctx->device);
-  rt::Stream s = t->ctx->stream;
-  const size_t N = t->N, psz = proof_size_bytes(t->m, t->n);
-  DevBuf<uint8_t> dd, dsh, dpf;
-  DevBuf<int32_t> dst;
-  dd.alloc(B * N * 128, s, false); dsh.alloc(B * N * 128, s, false); dpf.alloc(B * psz, s, false); dst.alloc(B, s, false);
-  rt::h2d(dd.p, decks, B * N * 128, s);
-  rt::h2d(dsh.p, shuffled_decks, B * N * 128, s);
-  rt::h2d(dpf.p, proofs, B * psz, s);
-  t->verify_dev(B, dd.p, dsh.p, dpf.p, dst.p);
-  rt::d2h(status, dst.p, B * 4, s);
-  rt::stream_sync(s);
-  return MP_OK;
-  MP_CATCH
-}
-
-int mp_shuffle_and_remask(mp_table* t, const uint8_t* deck, const uint8_t* masking_factors, const uint32_t* permutation,
-                          const uint8_t prover_seed[32], uint8_t* out_deck, uint8_t* out_proof) {
-  int32_t st = 0;
-  int rc = mp_shuffle_and_remask_batch(t, 1, deck, masking_factors, permutation, prover_seed, out_deck, out_proof, &st);
-  if (rc != MP_OK) return rc;
-  if (st < 0) return fail(st, mp_check_name(st));
-  return st;
-}
-int mp_verify_shuffle(mp_table* t, const uint8_t* deck, const uint8_t* shuffled_deck, const uint8_t* proof, size_t proof_len) {
-  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle: null table");
-  if (proof_len != proof_size_bytes(t->m, t->n)) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle: wrong proof length");
-  int32_t st = 0;
-  int rc = mp_verify_shuffle_batch(t, 1, deck, shuffled_deck, proof, &st);
-  if (rc != MP_OK) return rc;
-  if (st < 0) return fail(st, mp_check_name(st));
-  return st;
-}
-
-int mp_remask_batch(mp_table* t, size_t count, const uint8_t* cards, const uint8_t* masking_factors, uint8_t* out) {
-  if (!t || !count || !cards || !masking_factors || !out) return fail(MP_ERR_BAD_ARGUMENT, "mp_remask_batch: bad argument");
-  MP_TRY
-  rt::set_device(t->ctx->device);
-  t->remask_host(count, cards, masking_factors, out);
-  return MP_OK;
-  MP_CATCH
-}
-int mp_msm(mp_table* t, size_t n_msm, size_t k, const uint8_t* scalars, const uint8_t* points, uint8_t* out) {
-  if (!t || !n_msm || !k || !scalars || !points || !out) return fail(MP_ERR_BAD_ARGUMENT, "mp_msm: bad argument");
-  MP_TRY
-  rt::set_device(t->ctx->device);
-  t->msm_host(n_msm, k, scalars, points, out);
-  return MP_OK;
-  MP_CATCH
-}
-int mp_commit_batch(mp_table* t, size_t count, size_t len, const uint8_t* values, const uint8_t* r, uint8_t* out) {
-  if (!t || !count || !r || !out || (len && !values) || len > t->n) return fail(MP_ERR_BAD_ARGUMENT, "mp_commit_batch: bad argument");
-  MP_TRY
-  rt::set_device(t->ctx->device);
-  t->commit_host(count, len, values, r, out);
-  return MP_OK;
-  MP_CATCH
-}
-
-int mp_profile_enable(mp_ctx* ctx, int on) {
-  if (!ctx) return fail(MP_ERR_BAD_ARGUMENT, "null ctx");
-  MP_TRY
-  rt::stream_sync(ctx->stream);
-  ctx->prof.report();
-  ctx->prof.on = on != 0;
-  return MP_OK;
-  MP_CATCH
-}
-int mp_profile_report(mp_ctx* ctx, char* buf, size_t buf_len) {
-  if (!ctx || !buf || !buf_len) return fail(MP_ERR_BAD_ARGUMENT, "mp_profile_report: bad argument");
-  MP_TRY
-  rt::stream_sync(ctx->stream);
-  std::string r = ctx->prof.report();
-  if (r.size() + 1 > buf_len) r.resize(buf_len - 1);
-  memcpy(buf, r.c_str(), r.size() + 1);
-  return MP_OK;
-  MP_CATCH
-}
-int mp_work_census(mp_table* t, uint64_t* prove_terms, uint64_t* verify_terms, uint64_t* prove_point_ops, uint64_t* verify_point_ops) {
-  if (!t || !prove_terms || !verify_terms || !prove_point_ops || !verify_point_ops) return fail(MP_ERR_BAD_ARGUMENT, "mp_work_census: bad argument");
-  t->census(prove_terms, verify_terms, prove_point_ops, verify_point_ops);
-  return MP_OK;
-}
-
-int mp_plan_stats(mp_table* t, uint64_t out[16]) {
-  if (!t || !out) return fail(MP_ERR_BAD_ARGUMENT, "mp_plan_stats: bad argument");
-  t->plan_stats(out);
-  return MP_OK;
-}
-
-}  // extern "C"
