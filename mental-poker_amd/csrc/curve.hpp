@@ -95,9 +95,10 @@ MP_HD Jac<C> jac_dbl(const Jac<C>& p) {
   r.Y = fe_sub<F>(fe_mul<F>(M, fe_sub<F>(S, r.X)), Y8);
   return r;
 }
-// out-of-line copy for the rare P + P branch inside additions (keeps the hot path small)
+// the rare P + P branch inside additions.  Inlined on purpose: an out-of-line call makes every value that is
+// live across it pay the call ABI (196 VGPRs / 2 waves per SIMD in k_var_msm instead of 128 / 4).
 template <class C>
-MP_HD_NOINLINE Jac<C> jac_dbl_rare(const Jac<C>& p) {
+MP_HD Jac<C> jac_dbl_rare(const Jac<C>& p) {
   return jac_dbl<C>(p);
 }
 

@@ -7,8 +7,8 @@
 namespace mp {
 
 static const uint32_t FCHUNK = 8;     // fixed-base terms per sub-job   (8 x 32 mixed additions)
-static const uint32_t VCHUNK = 13;    // variable-base terms per sub-job (13 x 51 mixed additions + 255 doublings)
-static const uint32_t NORM_CHUNK = 16;
+static const uint32_t VCHUNK = 26;    // variable-base terms per sub-job (26 x 51 mixed additions + 255 doublings)
+static const uint32_t NORM_CHUNK = 64;   // points per Fermat inversion in k_normalize
 
 struct PhaseDev {
   DevBuf<Term> recode, tables, fterms, vterms, cterms;

@@ -179,6 +179,25 @@ MP_HD void frstream_init(FrStream& s, const uint32_t key[8]) {
   s.counter = 0;
   s.half = 2;
 }
+// one candidate: true (and the value) if it is accepted
+template <class P>
+MP_HD bool frstream_try(FrStream& s, Fe<P>& f) {
+  if (s.half >= 2) {
+    chacha20_block(s.key, s.counter, s.blk);
+    s.counter++;
+    s.half = 0;
+  }
+  if (s.half == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f.v[i] = s.blk[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f.v[i] = s.blk[8 + i];
+  }
+  s.half++;
+  if (P::BITS < 256) f.v[7] &= 0xFFFFFFFFu >> (256 - P::BITS);
+  return fe_canonical_in_range<P>(f.v);
+}
 template <class P>
 MP_HD Fe<P> frstream_next(FrStream& s) {
   for (;;) {

@@ -103,7 +103,7 @@ MP_HD void body_fixed_msm(const FixedArgs& a, uint32_t b, uint32_t y) {
   }
   st_jac<C>(a.J + j_off(job.out, a.Bpad, b), acc);
 }
-MP_KERNEL(k_fixed_msm, FixedArgs, body_fixed_msm)
+MP_KERNEL_OCC(k_fixed_msm, FixedArgs, body_fixed_msm, 4)
 
 // ---- re-encryption (remask) -------------------------------------------------------------------------
 struct RemaskArgs {
@@ -135,7 +135,7 @@ MP_HD void body_remask(const RemaskArgs& a, uint32_t b, uint32_t y) {
   acc = jac_madd<C>(acc, ld_aff<C>(a.P + p_off(a.p_deck + 2 * src + comp, a.Bpad, b)));
   st_jac<C>(a.J + j_off(a.j_out + y, a.Bpad, b), acc);
 }
-MP_KERNEL(k_remask, RemaskArgs, body_remask)
+MP_KERNEL_OCC(k_remask, RemaskArgs, body_remask, 4)
 
 // ---- signed-window recoding of the variable-base scalars -------------------------------------------
 struct RecodeArgs {
@@ -189,7 +189,7 @@ MP_HD void body_table(const TableArgs& a, uint32_t b, uint32_t y) {
     st_jac<C>(out + (size_t)e * a.Bpad * 24, acc);
   }
 }
-MP_KERNEL(k_table, TableArgs, body_table)
+MP_KERNEL_OCC(k_table, TableArgs, body_table, 4)
 
 // ---- variable-base MSM (Straus) -----------------------------------------------------------------------
 struct VarArgs {
@@ -224,7 +224,7 @@ MP_HD void body_var_msm(const VarArgs& a, uint32_t b, uint32_t y) {
   }
   st_jac<C>(a.J + j_off(job.out, a.Bpad, b), acc);
 }
-MP_KERNEL(k_var_msm, VarArgs, body_var_msm)
+MP_KERNEL_OCC(k_var_msm, VarArgs, body_var_msm, 4)
 
 // ---- combine partial sums ---------------------------------------------------------------------------
 struct CombineArgs {
@@ -247,7 +247,7 @@ MP_HD void body_combine(const CombineArgs& a, uint32_t b, uint32_t y) {
   }
   st_jac<C>(a.J + j_off(job.out, a.Bpad, b), acc);
 }
-MP_KERNEL(k_combine, CombineArgs, body_combine)
+MP_KERNEL_OCC(k_combine, CombineArgs, body_combine, 4)
 
 // ---- batch normalisation Jacobian -> affine (Montgomery's trick, one inversion per `chunk` points) ----
 // Works on FLAT arrays: element e of the source is 24 words at src + 24 e; a slot range of an arena is

@@ -183,11 +183,18 @@ MP_HD void body_prove_init(const ProveInitArgs& a, uint32_t b, uint32_t y) {
   const uint32_t* sw = reinterpret_cast<const uint32_t*>(a.seeds + (size_t)b * 32);
 #pragma unroll
   for (int i = 0; i < 8; ++i) key[i] = sw[i];
+  // Rejection sampling, lane-efficiently: loop over CANDIDATES, not draws -- a lane whose candidate is rejected
+  // simply keeps its draw index, so no lane waits for the unluckiest one of the wave at every draw
+  // (Fr::rand accepts ~1/2 of the candidates on the STARK curve).
   FrStream st;
   frstream_init(st, key);
-  for (uint32_t i = 0; i < l.n_draws; ++i) {
-    Fe<R> v = frstream_next<R>(st);
-    st_fe<R>(a.S + s_off(a.draw_slots[i], a.Bpad, b), v);
+  uint32_t got = 0;
+  while (got < l.n_draws) {
+    Fe<R> v;
+    if (frstream_try<R>(st, v)) {
+      st_fe<R>(a.S + s_off(a.draw_slots[got], a.Bpad, b), v);
+      ++got;
+    }
   }
   // fixed values of transcript v1
   st_fe<R>(a.S + s_off(l.zt + l.m + 1, a.Bpad, b), fe_zero<R>());

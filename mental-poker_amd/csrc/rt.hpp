@@ -78,6 +78,14 @@ inline void launch_check(const char* name) { check(hipGetLastError(), name); }
     if (x < nx) BODY<C>(a, x, blockIdx.y);                                        \
   }
 
+// same, with a register budget for >= WAVES waves per SIMD (the group-arithmetic kernels: 4 waves = 128 VGPRs)
+#define MP_KERNEL_OCC(NAME, ARGS, BODY, WAVES)                                    \
+  template <class C>                                                              \
+  MP_GLOBAL void __launch_bounds__(256, WAVES) NAME(ARGS a, uint32_t nx) {        \
+    uint32_t x = blockIdx.x * 256u + threadIdx.x;                                 \
+    if (x < nx) BODY<C>(a, x, blockIdx.y);                                        \
+  }
+
 #define MP_LAUNCH(NAME, C, stream, nx, ny, args)                                  \
   do {                                                                            \
     if ((nx) > 0 && (ny) > 0) {                                                   \

@@ -60,6 +60,7 @@ inline void launch_check(const char*) {}
       for (uint32_t x = 0; x < nx; ++x) BODY<C>(a, x, y);   \
     }                                                       \
   }
+#define MP_KERNEL_OCC(NAME, ARGS, BODY, WAVES) MP_KERNEL(NAME, ARGS, BODY)
 #define MP_LAUNCH(NAME, C, stream, nx, ny, args) NAME<C>((args), (uint32_t)(nx), (uint32_t)(ny))
 
 #endif  // MP_RT_HPP
