@@ -22,10 +22,7 @@ struct Jac {
 
 template <class C>
 MP_HD bool aff_is_inf(const Aff<C>& a) {
-  uint32_t o = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) o |= a.x.v[i] | a.y.v[i];
-  return o == 0;
+  return fe_is_zero(a.x) && fe_is_zero(a.y);
 }
 template <class C>
 MP_HD Aff<C> aff_inf() {
@@ -49,9 +46,7 @@ template <class C>
 MP_HD bool aff_on_curve(const Aff<C>& a) {
   typedef typename C::FqP F;
   if (aff_is_inf<C>(a)) return true;
-  Fe<F> b;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) b.v[i] = C::B_MONT[i];
+  const Fe<F> b = fe_unpack<F>(C::B_MONT);
   Fe<F> rhs = fe_add<F>(fe_mul<F>(fe_sqr<F>(a.x), a.x), b);
   if (C::A == 1) rhs = fe_add<F>(rhs, a.x);
   return fe_eq(fe_sqr<F>(a.y), rhs);

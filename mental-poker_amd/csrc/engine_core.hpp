@@ -124,8 +124,8 @@ struct Table : mp_table {
     rt::Stream s = ctx->stream;
     std::vector<uint32_t> flat(fb.count() * 16);
     for (uint32_t i = 0; i < fb.count(); ++i) {
-      memcpy(&flat[i * 16], bases[i].x.v, 32);
-      memcpy(&flat[i * 16 + 8], bases[i].y.v, 32);
+      fe_pack<F>(bases[i].x, &flat[i * 16]);
+      fe_pack<F>(bases[i].y, &flat[i * 16 + 8]);
     }
     fbpts.upload(flat, s);
     build_fixed_tables(fb.count());
@@ -484,8 +484,8 @@ static int setup_host(uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* o
   FrStream st;
   frstream_init(st, key);
   Aff<C> g;
-  memcpy(g.x.v, C::GX_MONT, 32);
-  memcpy(g.y.v, C::GY_MONT, 32);
+  g.x = fe_unpack<F>(C::GX_MONT);
+  g.y = fe_unpack<F>(C::GY_MONT);
   for (uint32_t i = 0; i < n + 3; ++i) {
     Fe<R> kf = frstream_next<R>(st);
     uint32_t k[8];

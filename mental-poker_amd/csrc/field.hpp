@@ -1,9 +1,23 @@
-// 256-bit prime-field arithmetic on 8 x 32-bit limbs, Montgomery form (R = 2^256), written for the
-// gfx950 vector ALU: every limb product is one v_mad_u64_u32 (32x32+64 -> 64), all loops are fully
-// unrolled over compile-time moduli so that zero limbs of a sparse modulus (STARK p = 2^251 + 17*2^192
-// + 1, secp256k1 p) cost nothing.  Replaces ark-ff 0.3 `Fp256` (4x64 limbs) used by every reference
-// call on the hot path [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:7-8].
-// Values are always fully reduced (in [0, p)), so equality is limb equality.
+// 256-bit prime-field arithmetic for the gfx950 vector ALU.  Two representations, chosen per modulus at compile
+// time (curve_params.hpp, `P::L29`); everything else in the engine goes through the fe_* functions below and the
+// packed 8-word memory format, never through the limbs.
+//
+//  (1) 8 x 32-bit limbs, Montgomery R = 2^256, always fully reduced.  Product = product scanning (Comba) with a
+//      96-bit column accumulator: one v_mad_u64_u32 (32x32+64 -> 64, carry-out to VCC) + one v_addc_co_u32 per limb
+//      product (inline asm: hipcc cannot express the carry-out of the mad from C).  Used for the scalar fields
+//      and the dense base fields (bn254, secp256k1).
+//
+//  (2) 9 x 29-bit limbs, Montgomery R = 2^261, LAZILY reduced: limbs < 2^29, value in [0, 4p).  A column sum of
+//      9 limb products fits a 64-bit accumulator (9 * 2^58 < 2^62), so the whole product is a chain of plain
+//      `acc = a*b + acc` mads with NO carry handling (81 for a product, 45 for a square, +2 per column for the
+//      Montgomery step on the sparse STARK prime 2^251 + 17*2^192 + 1); additions / subtractions fold a weak
+//      reduction into their single signed carry pass.  Plain C, identical on host and device.
+//      Measured on MI355X (tools/microbench/fmul.hip, products per second, STARK Fq):
+//      C CIOS 101 G/s, (1) 171 G/s, (2) 216 G/s.
+//
+// Replaces ark-ff 0.3 `Fp256` (4x64 limbs) used by every reference call on the hot path
+// [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:7-8].
+// Memory format of a field element: 8 little-endian 32-bit words holding the CANONICAL (< p) Montgomery residue.
 #pragma once
 #include <cstdint>
 
@@ -14,38 +28,14 @@ namespace mp {
 
 template <class P>
 struct Fe {
-  uint32_t v[8];
+  uint32_t v[P::L29 ? 9 : 8];
 };
 
-template <class P>
-MP_HD Fe<P> fe_zero() {
-  Fe<P> r;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) r.v[i] = 0;
-  return r;
-}
-template <class P>
-MP_HD Fe<P> fe_one() {
-  Fe<P> r;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) r.v[i] = P::R1[i];
-  return r;
-}
-template <class P>
-MP_HD bool fe_is_zero(const Fe<P>& a) {
-  uint32_t o = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) o |= a.v[i];
-  return o == 0;
-}
-template <class P>
-MP_HD bool fe_eq(const Fe<P>& a, const Fe<P>& b) {
-  uint32_t o = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) o |= a.v[i] ^ b.v[i];
-  return o == 0;
-}
+static constexpr uint32_t M29 = (1u << 29) - 1;
 
+// =====================================================================================================
+// helpers of representation (1)
+// =====================================================================================================
 // r = a - MOD if a >= MOD (a given with an extra top carry word `hi`), branch-free
 template <class P>
 MP_HD void fe_cond_sub(uint32_t r[8], const uint32_t a[8], uint32_t hi) {
@@ -57,70 +47,24 @@ MP_HD void fe_cond_sub(uint32_t r[8], const uint32_t a[8], uint32_t hi) {
     d[i] = (uint32_t)t;
     br = (t >> 32) & 1;
   }
-  // subtract when no borrow, or when the carry word absorbs it
   bool ge = (br == 0) || (hi != 0);
 #pragma unroll
   for (int i = 0; i < 8; ++i) r[i] = ge ? d[i] : a[i];
 }
 
+// Montgomery product on 8x32 limbs, CIOS in plain C (host / development emulator form)
 template <class P>
-MP_HD Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
-  uint32_t s[8];
-  uint64_t c = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    c += (uint64_t)a.v[i] + b.v[i];
-    s[i] = (uint32_t)c;
-    c >>= 32;
-  }
-  Fe<P> r;
-  fe_cond_sub<P>(r.v, s, P::SPARE ? 0u : (uint32_t)c);
-  return r;
-}
-template <class P>
-MP_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
-  uint32_t d[8];
-  uint64_t br = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    uint64_t t = (uint64_t)a.v[i] - b.v[i] - br;
-    d[i] = (uint32_t)t;
-    br = (t >> 32) & 1;
-  }
-  // add MOD back if we borrowed
-  uint32_t mask = (uint32_t)0 - (uint32_t)br;
-  Fe<P> r;
-  uint64_t c = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    c += (uint64_t)d[i] + (P::MOD[i] & mask);
-    r.v[i] = (uint32_t)c;
-    c >>= 32;
-  }
-  return r;
-}
-template <class P>
-MP_HD Fe<P> fe_neg(const Fe<P>& a) {
-  return fe_sub<P>(fe_zero<P>(), a);
-}
-template <class P>
-MP_HD Fe<P> fe_dbl(const Fe<P>& a) {
-  return fe_add<P>(a, a);
-}
-
-// Montgomery product, host / reference form: CIOS in plain C (also what the development emulator runs).
-template <class P>
-MP_HD Fe<P> fe_mul_cios(const Fe<P>& a, const Fe<P>& b) {
+MP_HD void mul32_cios(uint32_t r[8], const uint32_t a[8], const uint32_t b[8]) {
   uint32_t t[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) t[i] = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     uint64_t c = 0;
-    const uint32_t bi = b.v[i];
+    const uint32_t bi = b[i];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      c += (uint64_t)a.v[j] * bi + t[j];
+      c += (uint64_t)a[j] * bi + t[j];
       t[j] = (uint32_t)c;
       c >>= 32;
     }
@@ -140,23 +84,16 @@ MP_HD Fe<P> fe_mul_cios(const Fe<P>& a, const Fe<P>& b) {
     t[7] = (uint32_t)c;
     t[8] = t9 + (uint32_t)(c >> 32);
   }
-  Fe<P> r;
-  fe_cond_sub<P>(r.v, t, t[8]);
-  return r;
+  fe_cond_sub<P>(r, t, t[8]);
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// gfx950 form: product scanning (Comba).  Each column sum lives in a 96-bit accumulator {acc2 : acc}; one limb
-// product is ONE v_mad_u64_u32 (32x32+64 with carry-out to VCC) plus one v_addc_co_u32 that banks the carry in
-// the third word -- hipcc cannot express the carry-out of the mad from C (the CIOS loop above compiles to ~580
-// VALU instructions per product for the same 72 multiplies; this form to ~290).  Montgomery reduction is
-// interleaved per column; reduction products with zero modulus limbs vanish at compile time.
-// Measured on MI355X (tools/microbench/fmul.hip, STARK Fq): 101 -> 171 G products/s.
 MP_HD void fe_mac96(uint64_t& acc, uint32_t& acc2, uint32_t x, uint32_t y) {
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(acc2) : "v"(x), "v"(y) : "vcc");
 }
+// gfx950 form of the 8x32 product (see header comment)
 template <class P>
-MP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+MP_HD void mul32(uint32_t r[8], const uint32_t a[8], const uint32_t b[8]) {
   uint64_t acc = 0;
   uint32_t acc2 = 0;
   uint32_t t[8], m[8];
@@ -166,7 +103,7 @@ MP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
     for (int i = 0; i < 8; ++i) {
       const int j = k - i;
       if (j < 0 || j > 7) continue;
-      fe_mac96(acc, acc2, a.v[i], b.v[j]);
+      fe_mac96(acc, acc2, a[i], b[j]);
     }
     if (k < 8) {
 #pragma unroll
@@ -175,7 +112,6 @@ MP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
         fe_mac96(acc, acc2, m[i], P::MOD[k - i]);
       }
       if (P::INV == 0xFFFFFFFFu && P::MOD[0] == 1u) {
-        // m = -acc_lo; adding m * 1 clears the low word and carries iff it was non-zero
         m[k] = 0u - (uint32_t)acc;
         const uint32_t c = (uint32_t)acc != 0;
         acc = (uint64_t)(uint32_t)(acc >> 32) + c + ((uint64_t)acc2 << 32);
@@ -197,40 +133,295 @@ MP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
     }
   }
   t[7] = (uint32_t)acc;
-  Fe<P> r;
-  fe_cond_sub<P>(r.v, t, (uint32_t)(acc >> 32));
-  return r;
+  fe_cond_sub<P>(r, t, (uint32_t)(acc >> 32));
 }
 #else
 template <class P>
-MP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
-  return fe_mul_cios<P>(a, b);
+MP_HD void mul32(uint32_t r[8], const uint32_t a[8], const uint32_t b[8]) {
+  mul32_cios<P>(r, a, b);
 }
 #endif
-template <class P>
-MP_HD Fe<P> fe_sqr(const Fe<P>& a) {
-  return fe_mul<P>(a, a);
-}
 
-// canonical integer (8 x u32, little-endian limbs) <-> Montgomery form
-template <class P>
-MP_HD Fe<P> fe_from_canonical(const uint32_t a[8]) {
-  Fe<P> t, r2;
+// =====================================================================================================
+// helpers of representation (2)
+// =====================================================================================================
+// one signed carry pass: s (each |s_i| < 2^31) -> limbs < 2^29, the top limb keeps the rest (must be >= 0)
+MP_HD void carry29(int32_t s[9], uint32_t out[9]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    t.v[i] = a[i];
-    r2.v[i] = P::R2[i];
+    const int32_t c = s[i] >> 29;
+    out[i] = (uint32_t)s[i] & M29;
+    s[i + 1] += c;
+  }
+  out[8] = (uint32_t)s[8];
+}
+// weak reduction folded into the carry pass: subtract max(q - 2, 0) * p with q = s_8 >> TOP29 (an estimate of
+// floor(value / 2^(232+TOP29)) that is off by at most one either way before the carries are propagated):
+// any value in [0, 8p) comes out in [0, 4p).
+template <class P>
+MP_HD void reduce_carry29(int32_t s[9], uint32_t out[9]) {
+  int32_t q = (s[8] >> P::TOP29) - 2;
+  q = q < 0 ? 0 : q;
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+    if (P::MOD29[i] != 0) s[i] -= q * (int32_t)P::MOD29[i];
+  carry29(s, out);
+}
+// bring a lazily reduced value (< 8p, normalised limbs) to the canonical residue in [0, p)
+template <class P>
+MP_HD void canonical29(const uint32_t a[9], uint32_t out[9]) {
+  int32_t s[9];
+  const int32_t q = (int32_t)(a[8] >> P::TOP29);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) s[i] = (int32_t)a[i] - (P::MOD29[i] != 0 ? q * (int32_t)P::MOD29[i] : 0);
+  uint32_t t[9];
+  carry29(s, t);
+  // now in (-p, p): add p back if negative
+  const int32_t neg = (int32_t)t[8] < 0 ? 1 : 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) s[i] = (int32_t)t[i] + (P::MOD29[i] != 0 ? neg * (int32_t)P::MOD29[i] : 0);
+  carry29(s, out);
+}
+MP_HD void pack29(const uint32_t l[9], uint32_t w[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = (32 * j) / 29, off = (32 * j) % 29;
+    w[j] = (l[k] >> off) | (l[k + 1] << (29 - off));
+  }
+}
+MP_HD void unpack29(const uint32_t w[8], uint32_t l[9]) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int k = (29 * i) / 32, off = (29 * i) % 32;
+    uint32_t x = w[k] >> off;
+    if (off > 3 && k + 1 < 8) x |= w[k + 1] << (32 - off);
+    l[i] = i < 8 ? (x & M29) : x;
+  }
+}
+// Montgomery product (R = 2^261): inputs with limbs < 2^29 and value < 4p, output < 2p with limbs < 2^29
+template <class P>
+MP_HD void mul29(uint32_t r[9], const uint32_t a[9], const uint32_t b[9]) {
+  uint64_t c[18];
+#pragma unroll
+  for (int k = 0; k < 18; ++k) c[k] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) c[i + j] += (uint64_t)a[i] * b[j];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const uint32_t m = ((uint32_t)c[k] * P::INV29) & M29;
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+      if (P::MOD29[i] != 0) c[k + i] += (uint64_t)m * P::MOD29[i];
+    c[k + 1] += c[k] >> 29;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; ++k) {
+    r[k - 9] = (uint32_t)c[k] & M29;
+    c[k + 1] += c[k] >> 29;
+  }
+  r[8] = (uint32_t)c[17];
+}
+template <class P>
+MP_HD void sqr29(uint32_t r[9], const uint32_t a[9]) {
+  uint64_t c[18];
+  uint32_t a2[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) a2[i] = a[i] << 1;
+#pragma unroll
+  for (int k = 0; k < 18; ++k) c[k] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    c[2 * i] += (uint64_t)a[i] * a[i];
+#pragma unroll
+    for (int j = i + 1; j < 9; ++j) c[i + j] += (uint64_t)a2[i] * a[j];
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const uint32_t m = ((uint32_t)c[k] * P::INV29) & M29;
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+      if (P::MOD29[i] != 0) c[k + i] += (uint64_t)m * P::MOD29[i];
+    c[k + 1] += c[k] >> 29;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; ++k) {
+    r[k - 9] = (uint32_t)c[k] & M29;
+    c[k + 1] += c[k] >> 29;
+  }
+  r[8] = (uint32_t)c[17];
+}
+
+// =====================================================================================================
+// the field API
+// =====================================================================================================
+template <class P>
+MP_HD Fe<P> fe_zero() {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < (P::L29 ? 9 : 8); ++i) r.v[i] = 0;
+  return r;
+}
+template <class P>
+MP_HD Fe<P> fe_one() {
+  Fe<P> r;
+  if constexpr (P::L29) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v[i] = P::R1_29[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = P::R1[i];
+  }
+  return r;
+}
+// a == 0 (mod p)
+template <class P>
+MP_HD bool fe_is_zero(const Fe<P>& a) {
+  if constexpr (P::L29) {
+    // lazily reduced: a is one of 0, p, 2p, ... ; the limbs of k*p are k*MOD29[i] (no carries: sparse p)
+    const uint32_t k = a.v[8] >> P::TOP29;
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o |= a.v[i] ^ (k * P::MOD29[i]);
+    return o == 0;
+  } else {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o |= a.v[i];
+    return o == 0;
+  }
+}
+template <class P>
+MP_HD Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
+  Fe<P> r;
+  if constexpr (P::L29) {
+    int32_t s[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s[i] = (int32_t)(a.v[i] + b.v[i]);
+    reduce_carry29<P>(s, r.v);
+  } else {
+    uint32_t s[8];
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      c += (uint64_t)a.v[i] + b.v[i];
+      s[i] = (uint32_t)c;
+      c >>= 32;
+    }
+    fe_cond_sub<P>(r.v, s, P::SPARE ? 0u : (uint32_t)c);
+  }
+  return r;
+}
+template <class P>
+MP_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
+  Fe<P> r;
+  if constexpr (P::L29) {
+    // a - b + 4p in (0, 8p)
+    int32_t s[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s[i] = (int32_t)a.v[i] - (int32_t)b.v[i] + 4 * (int32_t)P::MOD29[i];
+    reduce_carry29<P>(s, r.v);
+  } else {
+    uint32_t d[8];
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      uint64_t t = (uint64_t)a.v[i] - b.v[i] - br;
+      d[i] = (uint32_t)t;
+      br = (t >> 32) & 1;
+    }
+    uint32_t mask = (uint32_t)0 - (uint32_t)br;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      c += (uint64_t)d[i] + (P::MOD[i] & mask);
+      r.v[i] = (uint32_t)c;
+      c >>= 32;
+    }
+  }
+  return r;
+}
+template <class P>
+MP_HD Fe<P> fe_neg(const Fe<P>& a) {
+  return fe_sub<P>(fe_zero<P>(), a);
+}
+template <class P>
+MP_HD Fe<P> fe_dbl(const Fe<P>& a) {
+  return fe_add<P>(a, a);
+}
+template <class P>
+MP_HD bool fe_eq(const Fe<P>& a, const Fe<P>& b) {
+  if constexpr (P::L29) {
+    return fe_is_zero<P>(fe_sub<P>(a, b));
+  } else {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o |= a.v[i] ^ b.v[i];
+    return o == 0;
+  }
+}
+template <class P>
+MP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+  Fe<P> r;
+  if constexpr (P::L29)
+    mul29<P>(r.v, a.v, b.v);
+  else
+    mul32<P>(r.v, a.v, b.v);
+  return r;
+}
+template <class P>
+MP_HD Fe<P> fe_sqr(const Fe<P>& a) {
+  Fe<P> r;
+  if constexpr (P::L29)
+    sqr29<P>(r.v, a.v);
+  else
+    mul32<P>(r.v, a.v, a.v);
+  return r;
+}
+
+// ---- memory format: 8 packed words, canonical Montgomery residue -------------------------------------------
+template <class P>
+MP_HD Fe<P> fe_unpack(const uint32_t w[8]) {
+  Fe<P> r;
+  if constexpr (P::L29) {
+    unpack29(w, r.v);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = w[i];
+  }
+  return r;
+}
+template <class P>
+MP_HD void fe_pack(const Fe<P>& a, uint32_t w[8]) {
+  if constexpr (P::L29) {
+    uint32_t c[9];
+    canonical29<P>(a.v, c);
+    pack29(c, w);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = a.v[i];
+  }
+}
+
+// ---- canonical integer (8 x u32, little-endian) <-> Montgomery form ---------------------------------------------
+template <class P>
+MP_HD Fe<P> fe_from_canonical(const uint32_t a[8]) {
+  Fe<P> t = fe_unpack<P>(a), r2;
+  if constexpr (P::L29) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r2.v[i] = P::R2_29[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r2.v[i] = P::R2[i];
   }
   return fe_mul<P>(t, r2);
 }
 template <class P>
 MP_HD void fe_to_canonical(const Fe<P>& a, uint32_t out[8]) {
-  Fe<P> one;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) one.v[i] = i == 0 ? 1u : 0u;
-  Fe<P> r = fe_mul<P>(a, one);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) out[i] = r.v[i];
+  Fe<P> one = fe_zero<P>();
+  one.v[0] = 1u;
+  fe_pack<P>(fe_mul<P>(a, one), out);
 }
 template <class P>
 MP_HD Fe<P> fe_from_u32(uint32_t x) {

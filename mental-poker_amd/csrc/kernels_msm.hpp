@@ -33,41 +33,44 @@ MP_HD void st_words8(uint32_t* p, const uint32_t v[8]) {
   q[0] = make_uint4(v[0], v[1], v[2], v[3]);
   q[1] = make_uint4(v[4], v[5], v[6], v[7]);
 }
+// memory format of a field element = 8 packed words (canonical Montgomery residue, field.hpp)
 template <class F>
 MP_HD Fe<F> ld_fe(const uint32_t* p) {
-  Fe<F> r;
-  ld_words8(p, r.v);
-  return r;
+  uint32_t w[8];
+  ld_words8(p, w);
+  return fe_unpack<F>(w);
 }
 template <class F>
 MP_HD void st_fe(uint32_t* p, const Fe<F>& a) {
-  st_words8(p, a.v);
+  uint32_t w[8];
+  fe_pack<F>(a, w);
+  st_words8(p, w);
 }
 template <class C>
 MP_HD Aff<C> ld_aff(const uint32_t* p) {
   Aff<C> a;
-  ld_words8(p, a.x.v);
-  ld_words8(p + 8, a.y.v);
+  a.x = ld_fe<typename C::FqP>(p);
+  a.y = ld_fe<typename C::FqP>(p + 8);
   return a;
 }
 template <class C>
 MP_HD void st_aff(uint32_t* p, const Aff<C>& a) {
-  st_words8(p, a.x.v);
-  st_words8(p + 8, a.y.v);
+  st_fe<typename C::FqP>(p, a.x);
+  st_fe<typename C::FqP>(p + 8, a.y);
 }
 template <class C>
 MP_HD Jac<C> ld_jac(const uint32_t* p) {
   Jac<C> j;
-  ld_words8(p, j.X.v);
-  ld_words8(p + 8, j.Y.v);
-  ld_words8(p + 16, j.Z.v);
+  j.X = ld_fe<typename C::FqP>(p);
+  j.Y = ld_fe<typename C::FqP>(p + 8);
+  j.Z = ld_fe<typename C::FqP>(p + 16);
   return j;
 }
 template <class C>
 MP_HD void st_jac(uint32_t* p, const Jac<C>& j) {
-  st_words8(p, j.X.v);
-  st_words8(p + 8, j.Y.v);
-  st_words8(p + 16, j.Z.v);
+  st_fe<typename C::FqP>(p, j.X);
+  st_fe<typename C::FqP>(p + 8, j.Y);
+  st_fe<typename C::FqP>(p + 16, j.Z);
 }
 
 MP_HD size_t s_off(uint32_t slot, uint32_t Bpad, uint32_t b) { return ((size_t)slot * Bpad + b) * 8; }
