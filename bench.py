@@ -29,7 +29,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "py")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 INT_MAD_PEAK_G = 18000.0       # v_mad_u64_u32 issue rate measured with tools/microbench/intrate.hip (Gmad/s)
-MADS_PER_POINT_OP = 856        # mixed addition 7M + 4S on the STARK base field, 88 / 60 limb products
+MADS_PER_POINT_OP = 900        # 9x29-bit limbs: product 99 / square 63 mads; mixed addition 7M+4S = 945, doubling 1M+8S = 603
 
 
 # ---- distributed helpers (backend-agnostic: RCCL on GPUs, gloo in the CPU tests) -----------------------------
@@ -81,10 +81,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8192, help="proofs per GPU per step")
+    ap.add_argument("--batch", type=int, default=65536, help="proofs per GPU per step (~0.9 MB of HBM each)")
     ap.add_argument("--m", type=int, default=2)
     ap.add_argument("--n", type=int, default=26)
     ap.add_argument("--curve", default="stark")
+    ap.add_argument("--streams", type=int, default=1, help="independent engine contexts (HIP streams) per GPU; the batch is split evenly")
+    ap.add_argument("--fb-bits", type=int, default=16, help="fixed-base window width (8 or 16)")
     ap.add_argument("--cpu-iters", type=int, default=96, help="prove+verify pairs timed for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -117,8 +119,15 @@ def main():
         blob = params + pk + base_deck
     blob = bcast_bytes(blob, psz + 64 + 128 * N, 0, dev)
     params, pk, base_deck = blob[:psz], blob[psz:psz + 64], blob[psz + 64:]
-    table = eng.table(m, n, params, pk)
-    table.reserve(B)
+    # ---- S independent contexts (one HIP stream each); each owns 1/S of the batch
+    S = max(1, args.streams)
+    Bs = B // S
+    assert Bs * S == B, "--batch must be a multiple of --streams"
+    engines = [eng] + [mp.Engine(curve, device=local) for _ in range(S - 1)]
+    tables = [e.table(m, n, params, pk, fb_bits=args.fb_bits) for e in engines]
+    for t in tables:
+        t.reserve(Bs)
+    table = tables[0]
     proof_bytes = table.proof_bytes
 
     # ---- synthetic inputs, resident in HBM
@@ -144,38 +153,52 @@ def main():
     st_p = torch.empty(B, dtype=torch.int32, device=dev)
     st_v = torch.empty(B, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
+
+    def sl(t, i):
+        return t[i * Bs:(i + 1) * Bs].data_ptr()
+
+    def sync_all():
+        for e in engines:
+            e.sync()
+
     # prime: B different random decks = re-encryptions of the base deck (untimed input generation)
     f0, p0, s0 = rand_factors(), rand_perms(), rand_bytes(B, 32)
     torch.cuda.synchronize()
-    table.shuffle_and_remask_batch_dev(B, decks0.data_ptr(), f0.data_ptr(), p0.data_ptr(), s0.data_ptr(),
-                                       decks.data_ptr(), out_proofs.data_ptr(), st_p.data_ptr())
-    eng.sync()
+    for i, t in enumerate(tables):
+        t.shuffle_and_remask_batch_dev(Bs, sl(decks0, i), sl(f0, i), sl(p0, i), sl(s0, i), sl(decks, i), sl(out_proofs, i), sl(st_p, i))
+    sync_all()
     assert int(st_p.abs().sum().item()) == 0, "priming pass failed"
     factors, perms, seeds = rand_factors(), rand_perms(), rand_bytes(B, 32)
     torch.cuda.synchronize()
 
     def step():
-        table.shuffle_and_remask_batch_dev(B, decks.data_ptr(), factors.data_ptr(), perms.data_ptr(), seeds.data_ptr(),
-                                           out_decks.data_ptr(), out_proofs.data_ptr(), st_p.data_ptr())
-        table.verify_shuffle_batch_dev(B, decks.data_ptr(), out_decks.data_ptr(), out_proofs.data_ptr(), st_v.data_ptr())
+        for i, t in enumerate(tables):
+            t.shuffle_and_remask_batch_dev(Bs, sl(decks, i), sl(factors, i), sl(perms, i), sl(seeds, i), sl(out_decks, i),
+                                           sl(out_proofs, i), sl(st_p, i))
+            t.verify_shuffle_batch_dev(Bs, sl(decks, i), sl(out_decks, i), sl(out_proofs, i), sl(st_v, i))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        eng.sync()
+        sync_all()
 
     for _ in range(args.warmup):
         step()
     barrier()
-    eng.profile_enable(True)
+    for e in engines:
+        e.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = eng.profile_report()
-    eng.profile_enable(False)
+    prof = {}
+    for e in engines:
+        for k, (cnt, ms) in e.profile_report().items():
+            c0, m0 = prof.get(k, (0, 0.0))
+            prof[k] = (c0 + cnt, m0 + ms)
+        e.profile_enable(False)
     elapsed = reduce_max(elapsed, dev)
 
     # ---- correctness of what was timed (outside the timed region)
@@ -222,6 +245,7 @@ def main():
         if kernel == "k_normalize":
             return sum(s["table_bases"] * 16 * (96 + 64) for s in pv)
         return 45 * 1024
+    # per-launch figures: one launch covers Bs = B / streams proofs; summed over the launches of the timed region
     dom_bytes = alg_bytes_per_proof(dom_name) * B * args.steps
     achieved_gbs = dom_bytes / (dom_ms * 1e-3) / 1e9
     point_ops = (census["prove_point_ops"] + census["verify_point_ops"]) * B * args.steps
@@ -257,7 +281,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (256-bit Montgomery, 8x32 limbs)",
         "data": "synthetic",
         "config": {"workload": "%d-card deck, m=%d n=%d, %s curve, shuffle_and_remask + verify_shuffle" % (N, m, n, curve),
-                   "proofs_per_gpu_per_step": B, "parity_vs_oracle": parity},
+                   "proofs_per_gpu_per_step": B, "streams": S, "fixed_base_window_bits": args.fb_bits,
+                   "parity_vs_oracle": parity},
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(out))

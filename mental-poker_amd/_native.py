@@ -16,7 +16,7 @@ MP_ERR_BAD_ENCODING, MP_ERR_BAD_PERMUTATION, MP_ERR_BAD_ARGUMENT, MP_ERR_NO_DEVI
 
 SYMBOLS = [
     "mp_ctx_create", "mp_ctx_destroy", "mp_last_error", "mp_check_name", "mp_proof_size", "mp_params_size",
-    "mp_setup", "mp_table_create", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
+    "mp_setup", "mp_table_create", "mp_table_create_ex", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
     "mp_shuffle_and_remask_batch", "mp_verify_shuffle_batch", "mp_shuffle_and_remask_batch_dev",
     "mp_verify_shuffle_batch_dev", "mp_sync", "mp_reserve", "mp_remask_batch", "mp_msm", "mp_commit_batch",
     "mp_profile_enable", "mp_profile_report", "mp_work_census", "mp_plan_stats",
@@ -87,6 +87,7 @@ def bind(cdll):
     cdll.mp_params_size.restype = c.c_size_t
     cdll.mp_setup.argtypes = [c.c_void_p, c.c_uint32, c.c_uint32, u8p, u8p]
     cdll.mp_table_create.argtypes = [c.c_void_p, c.c_uint32, c.c_uint32, u8p, u8p, c.POINTER(c.c_void_p)]
+    cdll.mp_table_create_ex.argtypes = [c.c_void_p, c.c_uint32, c.c_uint32, u8p, u8p, c.c_uint32, c.POINTER(c.c_void_p)]
     cdll.mp_table_destroy.argtypes = [c.c_void_p]
     cdll.mp_table_destroy.restype = None
     cdll.mp_shuffle_and_remask.argtypes = [c.c_void_p, u8p, u8p, u32p, u8p, u8p, u8p]
@@ -166,8 +167,8 @@ class Engine:
         self._chk(self.lib.mp_setup(self.h, m, n, _in(seed), out))
         return bytes(out)
 
-    def table(self, m, n, params, shared_key):
-        return Table(self, m, n, params, shared_key)
+    def table(self, m, n, params, shared_key, fb_bits=8):
+        return Table(self, m, n, params, shared_key, fb_bits)
 
     def sync(self):
         self._chk(self.lib.mp_sync(self.h))
@@ -188,13 +189,14 @@ class Engine:
 class Table:
     """one mp_table: Parameters + aggregate key with their fixed-base tables in HBM"""
 
-    def __init__(self, eng, m, n, params, shared_key):
+    def __init__(self, eng, m, n, params, shared_key, fb_bits=8):
         self.eng, self.lib, self.m, self.n, self.N = eng, eng.lib, m, n, m * n
+        self.fb_bits = fb_bits
         self.params, self.shared_key = bytes(params), bytes(shared_key)
         if len(self.params) != 64 * (n + 3) or len(self.shared_key) != 64:
             raise NativeError(MP_ERR_BAD_ARGUMENT, "parameters / shared key have the wrong length")
         h = ctypes.c_void_p()
-        eng._chk(self.lib.mp_table_create(eng.h, m, n, _in(self.params), _in(self.shared_key), ctypes.byref(h)))
+        eng._chk(self.lib.mp_table_create_ex(eng.h, m, n, _in(self.params), _in(self.shared_key), fb_bits, ctypes.byref(h)))
         self.h = h
         self.proof_bytes = self.lib.mp_proof_size(m, n)
 

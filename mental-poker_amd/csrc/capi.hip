@@ -73,6 +73,10 @@ int mp_setup(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_
 }
 
 int mp_table_create(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, const uint8_t* shared_key, mp_table** out) {
+  return mp_table_create_ex(ctx, m, n, params, shared_key, 8, out);
+}
+int mp_table_create_ex(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, const uint8_t* shared_key,
+                       uint32_t fb_window_bits, mp_table** out) {
   if (!ctx || !params || !shared_key || !out) return fail(MP_ERR_BAD_ARGUMENT, "mp_table_create: null pointer");
   if (m < 2 || n < 2 || (uint64_t)m * n > 4096) return fail(MP_ERR_BAD_ARGUMENT, "mp_table_create: need m >= 2, n >= 2, m*n <= 4096");
   MP_TRY
@@ -80,9 +84,9 @@ int mp_table_create(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, 
   int rc;
   mp_table* t = nullptr;
   switch (ctx->curve) {
-    case 0: t = make_table_Stark(ctx, m, n, params, shared_key, &rc); break;
-    case 1: t = make_table_Bn254(ctx, m, n, params, shared_key, &rc); break;
-    default: t = make_table_Secp256k1(ctx, m, n, params, shared_key, &rc); break;
+    case 0: t = make_table_Stark(ctx, m, n, params, shared_key, fb_window_bits, &rc); break;
+    case 1: t = make_table_Bn254(ctx, m, n, params, shared_key, fb_window_bits, &rc); break;
+    default: t = make_table_Secp256k1(ctx, m, n, params, shared_key, fb_window_bits, &rc); break;
   }
   if (rc != MP_OK) {
     delete t;

@@ -83,6 +83,7 @@ struct Table : mp_table {
   DevBuf<uint32_t> FB;       // fixed-base window tables
   Workspace ws;
   uint32_t nwin = 0;
+  FbGeom fbg{8, 32, 255};
   uint32_t init_seed[8];
   // staging for the host-buffer API
   DevBuf<uint8_t> io_a, io_b, io_c, io_d, io_e, io_f;
@@ -96,8 +97,10 @@ struct Table : mp_table {
     return wire_to_aff<C>(tmp, out);
   }
 
-  int init(mp_ctx* c, uint32_t m_, uint32_t n_, const uint8_t* params, const uint8_t* pk) {
+  int init(mp_ctx* c, uint32_t m_, uint32_t n_, const uint8_t* params, const uint8_t* pk, uint32_t fb_bits) {
     ctx = c;
+    if (fb_bits != 8 && fb_bits != 16) return fail(MP_ERR_BAD_ARGUMENT, "fixed-base window width must be 8 or 16 bits");
+    fbg = FbGeom{fb_bits, 256u / fb_bits, (1u << fb_bits) - 1u};
     m = m_; n = n_; N = m * n;
     nwin = (uint32_t)vb_windows(R::BITS);
     FixedBases fb{n};
@@ -171,6 +174,25 @@ struct Table : mp_table {
     FbFillArgs fa{W.p, EJ.p};
     MP_RUN(k_fb_fill, C, (uint32_t)nwinpts, 1, fa);
     normalize_flat(EJ.p, FB.p, scratch.p, nent);
+    if (fbg.bits == 16) {
+      // widen: 16 windows x 65535 entries per base (2 GB at n = 26); the 8-bit table is only a stepping stone
+      rt::stream_sync(s);
+      const size_t nent16 = (size_t)nb * 16 * 65535;
+      DevBuf<uint32_t> EJ16, FB16, scratch16;
+      EJ16.alloc(nent16 * 24, s, false);
+      scratch16.alloc(nent16 * 8, s, false);
+      FB16.alloc(nent16 * 16, s, false);
+      FbWidenArgs wa16{FB.p, EJ16.p};
+      const size_t per = (size_t)1 << 26;                     // normalise in slices of 64 M points
+      MP_RUN(k_fb_widen, C, (uint32_t)nent16, 1, wa16);      // nb * 16 * 65535 < 2^32 threads for nb <= 4096
+      for (size_t off = 0; off < nent16; off += per) {
+        const size_t cnt = std::min(per, nent16 - off);
+        normalize_flat(EJ16.p + off * 24, FB16.p + off * 16, scratch16.p + off * 8, cnt);
+      }
+      rt::stream_sync(s);
+      std::swap(FB.p, FB16.p);
+      std::swap(FB.n, FB16.n);
+    }
     rt::stream_sync(s);
   }
 
@@ -202,7 +224,7 @@ struct Table : mp_table {
       normalize_flat(w.TJ.p, w.T.p, w.NS.p, (size_t)ph.n_tslots * VB_ENTRIES * w.Bpad);
     }
     if (ph.n_f) {
-      FixedArgs a{w.S.p, w.J.p, FB.p, ph.fjobs.p, ph.fterms.p, w.Bpad};
+      FixedArgs a{w.S.p, w.J.p, FB.p, ph.fjobs.p, ph.fterms.p, w.Bpad, fbg};
       MP_RUN(k_fixed_msm, C, B, ph.n_f, a);
     }
     if (ph.n_v) {
@@ -246,7 +268,7 @@ struct Table : mp_table {
       MP_RUN(k_load_scalars, C, B, N, sa);
       ProveInitArgs ia{w.S.p, w.status.p, perm, seeds, draws.p, l, w.Bpad};
       MP_RUN(k_prove_init, C, B, 1, ia);
-      RemaskArgs ra{w.S.p, w.P.p, w.J.p, FB.p, perm, w.Bpad, N, l.rho, l.deck, l.shuf, fb.G(), fb.pk()};
+      RemaskArgs ra{w.S.p, w.P.p, w.J.p, FB.p, perm, w.Bpad, N, l.rho, l.deck, l.shuf, fb.G(), fb.pk(), fbg};
       MP_RUN(k_remask, C, B, 2 * N, ra);
     }
     run_phase(pph[0], w, B);
@@ -359,7 +381,7 @@ struct Table : mp_table {
     MP_RUN(k_load_points, C, B, 2, a);
     LoadScalarsArgs sa{drho.p, w.S.p, w.status.p, w.Bpad, 1, 0};
     MP_RUN(k_load_scalars, C, B, 1, sa);
-    RemaskArgs ra{w.S.p, w.P.p, w.J.p, FB.p, nullptr, w.Bpad, 1, 0, 0, 2, fb.G(), fb.pk()};
+    RemaskArgs ra{w.S.p, w.P.p, w.J.p, FB.p, nullptr, w.Bpad, 1, 0, 0, 2, fb.G(), fb.pk(), fbg};
     MP_RUN(k_remask, C, B, 2, ra);
     normalize_flat(w.J.p + j_off(2, w.Bpad, 0), w.P.p + p_off(2, w.Bpad, 0), w.NS.p, (size_t)2 * w.Bpad);
     StorePointsArgs st{dout.p, w.P.p, w.Bpad, 2, 2};
@@ -452,12 +474,12 @@ struct Table : mp_table {
     };
     for (int i = 0; i < 4; ++i) add(pplan.ph[i], out);
     add(vplan.ph, out + 6);
-    out[12] = nwin; out[13] = FB_WINDOWS; out[14] = N;
+    out[12] = nwin; out[13] = fbg.windows; out[14] = N;
   }
   void census(uint64_t* pt, uint64_t* vt, uint64_t* po, uint64_t* vo) override {
     auto count = [&](const Phase& ph, uint64_t& terms, uint64_t& ops) {
       terms += ph.fterms.size() + ph.vterms.size();
-      ops += (uint64_t)ph.fterms.size() * FB_WINDOWS;                       // mixed additions
+      ops += (uint64_t)ph.fterms.size() * fbg.windows;                      // mixed additions
       ops += (uint64_t)ph.vterms.size() * nwin;                             // mixed additions
       ops += (uint64_t)ph.vjobs.size() * (nwin - 1) * VB_WINDOW_BITS;       // doublings
       ops += (uint64_t)ph.tables.size() * (VB_ENTRIES - 1);                 // table construction
@@ -466,7 +488,7 @@ struct Table : mp_table {
     uint64_t t = 0, o = 0;
     for (int i = 0; i < 4; ++i) count(pplan.ph[i], t, o);
     t += 2 * N;
-    o += (uint64_t)2 * N * (FB_WINDOWS + 1);   // remask
+    o += (uint64_t)2 * N * (fbg.windows + 1);  // remask
     *pt = t; *po = o;
     t = 0; o = 0;
     count(vplan.ph, t, o);
@@ -508,9 +530,10 @@ static int setup_host(uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* o
 
 #define MP_DEFINE_CURVE(NAME)                                                                                           \
   namespace mp {                                                                                                        \
-  mp_table* make_table_##NAME(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, const uint8_t* pk, int* rc) { \
+  mp_table* make_table_##NAME(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, const uint8_t* pk,          \
+                              uint32_t fb_bits, int* rc) {                                                              \
     auto* p = new Table<NAME>();                                                                                        \
-    *rc = p->init(ctx, m, n, params, pk);                                                                               \
+    *rc = p->init(ctx, m, n, params, pk, fb_bits);                                                                      \
     return p;                                                                                                           \
   }                                                                                                                     \
   int setup_##NAME(uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out) { return setup_host<NAME>(m, n, seed, out); } \

@@ -78,16 +78,26 @@ MP_HD size_t p_off(uint32_t slot, uint32_t Bpad, uint32_t b) { return ((size_t)s
 MP_HD size_t j_off(uint32_t slot, uint32_t Bpad, uint32_t b) { return ((size_t)slot * Bpad + b) * 24; }
 
 // ---- fixed-base MSM ---------------------------------------------------------------------------------
+// geometry of the fixed-base tables of a table context: `bits`-wide unsigned windows (8 or 16)
+struct FbGeom {
+  uint32_t bits, windows, entries;   // windows = 256 / bits, entries = 2^bits - 1
+};
 struct FixedArgs {
   const uint32_t* S;
   uint32_t* J;
-  const uint32_t* FB;   // [base][window][entry(1..255)] affine, 16 words each
+  const uint32_t* FB;   // [base][window][entry(1..entries)] affine, 16 words each
   const Job* jobs;
   const Term* terms;
   uint32_t Bpad;
+  FbGeom g;
 };
-MP_HD const uint32_t* fb_entry(const uint32_t* FB, uint32_t base, uint32_t w, uint32_t d) {
-  return FB + (((size_t)base * FB_WINDOWS + w) * FB_ENTRIES + (d - 1)) * 16;
+MP_HD const uint32_t* fb_entry(const uint32_t* FB, const FbGeom& g, uint32_t base, uint32_t w, uint32_t d) {
+  return FB + (((size_t)base * g.windows + w) * g.entries + (d - 1)) * 16;
+}
+// window w of the canonical scalar k (bits divides 32)
+MP_HD uint32_t fb_digit(const uint32_t k[8], const FbGeom& g, uint32_t w) {
+  const uint32_t bit = w * g.bits;
+  return (k[bit >> 5] >> (bit & 31)) & ((1u << g.bits) - 1u);
 }
 template <class C>
 MP_HD void body_fixed_msm(const FixedArgs& a, uint32_t b, uint32_t y) {
@@ -99,9 +109,9 @@ MP_HD void body_fixed_msm(const FixedArgs& a, uint32_t b, uint32_t y) {
     uint32_t k[8];
     fe_to_canonical<R>(ld_fe<R>(a.S + s_off(term.s, a.Bpad, b)), k);
 #pragma unroll 1
-    for (uint32_t w = 0; w < (uint32_t)FB_WINDOWS; ++w) {
-      const uint32_t d = (k[w >> 2] >> ((w & 3) * 8)) & 0xFFu;
-      if (d) acc = jac_madd<C>(acc, ld_aff<C>(fb_entry(a.FB, term.b, w, d)));
+    for (uint32_t w = 0; w < a.g.windows; ++w) {
+      const uint32_t d = fb_digit(k, a.g, w);
+      if (d) acc = jac_madd<C>(acc, ld_aff<C>(fb_entry(a.FB, a.g, term.b, w, d)));
     }
   }
   st_jac<C>(a.J + j_off(job.out, a.Bpad, b), acc);
@@ -118,6 +128,7 @@ struct RemaskArgs {
   uint32_t Bpad, N;
   uint32_t s_rho, p_deck, j_out;
   uint32_t base_G, base_pk;
+  FbGeom g;
 };
 // y = 2*i + component
 template <class C>
@@ -131,9 +142,9 @@ MP_HD void body_remask(const RemaskArgs& a, uint32_t b, uint32_t y) {
   const uint32_t base = comp ? a.base_pk : a.base_G;
   Jac<C> acc = jac_inf<C>();
 #pragma unroll 1
-  for (uint32_t w = 0; w < (uint32_t)FB_WINDOWS; ++w) {
-    const uint32_t d = (k[w >> 2] >> ((w & 3) * 8)) & 0xFFu;
-    if (d) acc = jac_madd<C>(acc, ld_aff<C>(fb_entry(a.FB, base, w, d)));
+  for (uint32_t w = 0; w < a.g.windows; ++w) {
+    const uint32_t d = fb_digit(k, a.g, w);
+    if (d) acc = jac_madd<C>(acc, ld_aff<C>(fb_entry(a.FB, a.g, base, w, d)));
   }
   acc = jac_madd<C>(acc, ld_aff<C>(a.P + p_off(a.p_deck + 2 * src + comp, a.Bpad, b)));
   st_jac<C>(a.J + j_off(a.j_out + y, a.Bpad, b), acc);
@@ -325,5 +336,24 @@ MP_HD void body_fb_fill(const FbFillArgs& a, uint32_t x, uint32_t y) {
   }
 }
 MP_KERNEL(k_fb_fill, FbFillArgs, body_fb_fill)
+
+// pass 3 (16-bit windows only): entry d = hi * 256 + lo of 16-bit window w is T8[2w+1][hi] + T8[2w][lo]
+// (thread = (base * 16 + w) * 65535 + d - 1), Jacobian out -> normalise
+struct FbWidenArgs {
+  const uint32_t* T8;      // [base][32][255] affine
+  uint32_t* EJ;            // [base][16][65535] Jacobian
+};
+template <class C>
+MP_HD void body_fb_widen(const FbWidenArgs& a, uint32_t x, uint32_t y) {
+  const uint32_t d = x % 65535u + 1u;
+  const uint32_t bw = x / 65535u;            // base * 16 + w
+  const uint32_t hi = d >> 8, lo = d & 255u;
+  const uint32_t* t8 = a.T8 + (size_t)bw * 2 * FB_ENTRIES * 16;   // window 2w of this base
+  Jac<C> acc = jac_inf<C>();
+  if (lo) acc = jac_from_aff<C>(ld_aff<C>(t8 + (size_t)(lo - 1) * 16));
+  if (hi) acc = jac_madd<C>(acc, ld_aff<C>(t8 + ((size_t)FB_ENTRIES + hi - 1) * 16));
+  st_jac<C>(a.EJ + (size_t)x * 24, acc);
+}
+MP_KERNEL(k_fb_widen, FbWidenArgs, body_fb_widen)
 
 }  // namespace mp

@@ -97,8 +97,9 @@ class DLCards:
     """`impl BarnettSmartProtocol for DLCards<C>` -- hot-path members only (setup, shuffle_and_remask,
     verify_shuffle and their batched forms).  One instance = one curve on one GPU."""
 
-    def __init__(self, curve="stark", device=0):
+    def __init__(self, curve="stark", device=0, fb_bits=8):
         self.curve = curve
+        self.fb_bits = fb_bits      # fixed-base window width of the table contexts (8: compact, 16: throughput)
         self.engine = _native.Engine(curve, device)
         self._tables = {}
 
@@ -114,7 +115,7 @@ class DLCards:
         t = self._tables.get(key)
         if t is None:
             try:
-                t = self.engine.table(pp.m, pp.n, pp.raw, shared_key)
+                t = self.engine.table(pp.m, pp.n, pp.raw, shared_key, self.fb_bits)
             except _native.NativeError as e:
                 raise CardProtocolError.io(str(e))
             if len(self._tables) >= 4:

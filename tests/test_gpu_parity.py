@@ -88,6 +88,25 @@ def test_batch_matches_oracle(mp, engines, coracle, curve, m, n, B):
     assert all(o == mp.CryptoError("Hadamard Product (5.1)") for o in out)
 
 
+def test_wide_fixed_base_windows_match_oracle(mp, coracle):
+    """the throughput configuration of bench.py (16-bit fixed-base windows, 2 GB of tables) is bit-identical too"""
+    cv, m, n, B = "stark", 2, 26, 4
+    cards = mp.DLCards(cv, device=0, fb_bits=16)
+    g0 = coracle.gen_inputs(cv, m, n, 100)
+    pp = mp.Parameters(m, n, g0["params"])
+    ins = [coracle.gen_inputs(cv, m, n, 700 + b) for b in range(B)]
+    res = cards.shuffle_and_remask_batch([g["prover_seed"] for g in ins], pp, g0["pk"], [_split(g["deck"], 128) for g in ins],
+                                         [[int.from_bytes(x, "little") for x in _split(g["rho"], 32)] for g in ins],
+                                         [mp.Permutation(g["perm"]) for g in ins])
+    for g, r in zip(ins, res):
+        exp_deck, exp_proof = coracle.shuffle_and_remask(cv, m, n, g0["params"], g0["pk"], g["deck"], g["rho"], g["perm"], g["prover_seed"])
+        assert b"".join(r[0]) == exp_deck and r[1] == exp_proof
+    assert cards.verify_shuffle_batch(pp, g0["pk"], [_split(g["deck"], 128) for g in ins], [r[0] for r in res], [r[1] for r in res]) == [None] * B
+    wrong = [res[(b + 1) % B][0] for b in range(B)]
+    out = cards.verify_shuffle_batch(pp, g0["pk"], [_split(g["deck"], 128) for g in ins], wrong, [r[1] for r in res])
+    assert all(o == mp.CryptoError("Hadamard Product (5.1)") for o in out)
+
+
 def test_tampering_names_the_failing_check(mp, engines):
     g = load_json(os.path.join(GOLDEN, "shuffle_stark_m3_n4_s11.json"))
     m, n = g["m"], g["n"]
