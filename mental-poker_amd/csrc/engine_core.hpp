@@ -7,7 +7,7 @@
 namespace mp {
 
 static const uint32_t FCHUNK = 8;     // fixed-base terms per sub-job   (8 x 32 mixed additions)
-static const uint32_t VCHUNK = 26;    // variable-base terms per sub-job (26 x 51 mixed additions + 255 doublings)
+static const uint32_t VCHUNK = 64;    // variable-base terms per sub-job: the terms of a job share one 250-doubling chain
 static const uint32_t NORM_CHUNK = 64;   // points per Fermat inversion in k_normalize
 
 struct PhaseDev {
@@ -39,7 +39,7 @@ struct PhaseDev {
 struct Workspace {
   uint32_t Bpad = 0;
   uint32_t nS = 0, nP = 0, nJ = 0, nD = 0, nT = 0, nwin = 0, stage_words = 0;
-  DevBuf<uint32_t> S, P, J, T, TJ, NS, stage, seed, direct;
+  DevBuf<uint32_t> S, P, J, T, NS, stage, seed, direct;
   DevBuf<int8_t> D;
   DevBuf<int32_t> status;
   void ensure(uint32_t B, uint32_t nS_, uint32_t nP_, uint32_t nJ_, uint32_t nD_, uint32_t nT_, uint32_t nwin_,
@@ -51,7 +51,7 @@ struct Workspace {
     nwin = nwin_;
     stage_words = std::max(stage_words, stage_words_);
     // re-allocate everything (capacity grows monotonically); zero-filled so padding lanes hold valid data
-    S.n = P.n = J.n = T.n = TJ.n = NS.n = stage.n = seed.n = direct.n = 0;
+    S.n = P.n = J.n = T.n = NS.n = stage.n = seed.n = direct.n = 0;
     D.n = 0;
     status.n = 0;
     S.alloc((size_t)nS * Bpad * 8, s);
@@ -59,8 +59,7 @@ struct Workspace {
     J.alloc((size_t)nJ * Bpad * 24, s);
     D.alloc((size_t)std::max(nD, 1u) * nwin * Bpad, s);
     T.alloc((size_t)std::max(nT, 1u) * VB_ENTRIES * Bpad * 16, s);
-    TJ.alloc((size_t)std::max(nT, 1u) * VB_ENTRIES * Bpad * 24, s);
-    size_t norm_max = std::max((size_t)nT * VB_ENTRIES, (size_t)nP) * Bpad;
+    size_t norm_max = std::max((size_t)nT, (size_t)nJ) * Bpad;   // k_table prefix products, k_normalize ranges
     NS.alloc(norm_max * 8, s);
     stage.alloc((size_t)stage_words * Bpad, s);
     seed.alloc((size_t)8 * Bpad, s);
@@ -219,9 +218,8 @@ struct Table : mp_table {
       MP_RUN(k_recode, C, B, ph.n_recode, a);
     }
     if (ph.n_tables) {
-      TableArgs a{w.P.p, w.TJ.p, ph.tables.p, w.Bpad};
-      MP_RUN(k_table, C, B, ph.n_tables, a);
-      normalize_flat(w.TJ.p, w.T.p, w.NS.p, (size_t)ph.n_tslots * VB_ENTRIES * w.Bpad);
+      TableArgs a{w.P.p, w.T.p, w.NS.p, ph.tables.p, w.Bpad, ph.n_tables};
+      MP_RUN(k_table, C, B, (ph.n_tables + TABLE_GROUP - 1) / TABLE_GROUP, a);
     }
     if (ph.n_f) {
       FixedArgs a{w.S.p, w.J.p, FB.p, ph.fjobs.p, ph.fterms.p, w.Bpad, fbg};
@@ -482,7 +480,7 @@ struct Table : mp_table {
       ops += (uint64_t)ph.fterms.size() * fbg.windows;                      // mixed additions
       ops += (uint64_t)ph.vterms.size() * nwin;                             // mixed additions
       ops += (uint64_t)ph.vjobs.size() * (nwin - 1) * VB_WINDOW_BITS;       // doublings
-      ops += (uint64_t)ph.tables.size() * (VB_ENTRIES - 1);                 // table construction
+      ops += (uint64_t)ph.tables.size() * (VB_ENTRIES - 1);                 // table construction (affine additions)
       ops += ph.cterms.size();                                              // combines
     };
     uint64_t t = 0, o = 0;
