@@ -251,9 +251,18 @@ def main():
     point_ops = (census["prove_point_ops"] + census["verify_point_ops"]) * B * args.steps
     mads = point_ops * MADS_PER_POINT_OP
     whole_path_bytes = 45 * 1024 if (m, n) == (2, 26) else None
+    # HBM traffic of the dominant kernel from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+    # --pmc WRITE_SIZE in separate runs, gfx950 x2 correction applied to FETCH_SIZE), scaled to this batch
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["kernels"].get(dom_name)
+        if pmc and (m, n) == (2, 26):
+            traffic = pmc["hbm_bytes_per_proof_per_step_corrected"] * B * args.steps / dom_count
+    except (OSError, ValueError, KeyError):
+        traffic = None
     roofline = {
         "bound": "hbm", "kernel": dom_name, "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+        "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
         "avg_launch_ms": dom_ms / dom_count, "launches": dom_count,
         "alg_bytes_per_launch": dom_bytes / dom_count,
         "note": "path is integer-ALU bound (SURVEY 8d3): see int_mul",
