@@ -74,76 +74,106 @@ MP_HD Jac<C> jac_from_aff(const Aff<C>& a) {
   return j;
 }
 
-// 2P.  (Y = 0 cannot happen on a prime-order group of odd order, but is handled.)
+// The group law updates the accumulator IN PLACE and has a single exit per special case: returning the struct
+// by value from several paths made hipcc keep two field elements on the stack (scratch traffic in the MSM loops).
+
+// p <- 2p.  (Y = 0 cannot happen on a prime-order group of odd order, but is handled.)
 template <class C>
-MP_HD Jac<C> jac_dbl(const Jac<C>& p) {
+MP_HD void jac_dbl_ip(Jac<C>& p) {
   typedef typename C::FqP F;
-  if (fe_is_zero(p.Z) || fe_is_zero(p.Y)) return jac_inf<C>();
-  Fe<F> XX = fe_sqr<F>(p.X), YY = fe_sqr<F>(p.Y);
-  Fe<F> S = fe_dbl<F>(fe_dbl<F>(fe_mul<F>(p.X, YY)));
+  if (fe_is_zero(p.Z)) return;
+  if (fe_is_zero(p.Y)) {
+    p.Z = fe_zero<F>();
+    return;
+  }
+  const Fe<F> XX = fe_sqr<F>(p.X), YY = fe_sqr<F>(p.Y);
+  const Fe<F> S = fe_dbl<F>(fe_dbl<F>(fe_mul<F>(p.X, YY)));
   Fe<F> M = fe_add<F>(fe_dbl<F>(XX), XX);
   if (C::A == 1) M = fe_add<F>(M, fe_sqr<F>(fe_sqr<F>(p.Z)));
-  Jac<C> r;
-  r.X = fe_sub<F>(fe_sqr<F>(M), fe_dbl<F>(S));
-  Fe<F> Y8 = fe_dbl<F>(fe_dbl<F>(fe_dbl<F>(fe_sqr<F>(YY))));
-  r.Z = fe_dbl<F>(fe_mul<F>(p.Y, p.Z));
-  r.Y = fe_sub<F>(fe_mul<F>(M, fe_sub<F>(S, r.X)), Y8);
+  const Fe<F> X3 = fe_sub<F>(fe_sqr<F>(M), fe_dbl<F>(S));
+  const Fe<F> Y8 = fe_dbl<F>(fe_dbl<F>(fe_dbl<F>(fe_sqr<F>(YY))));
+  p.Z = fe_dbl<F>(fe_mul<F>(p.Y, p.Z));
+  p.Y = fe_sub<F>(fe_mul<F>(M, fe_sub<F>(S, X3)), Y8);
+  p.X = X3;
+}
+template <class C>
+MP_HD Jac<C> jac_dbl(const Jac<C>& p) {
+  Jac<C> r = p;
+  jac_dbl_ip<C>(r);
   return r;
 }
-// the rare P + P branch inside additions.  Inlined on purpose: an out-of-line call makes every value that is
-// live across it pay the call ABI (196 VGPRs / 2 waves per SIMD in k_var_msm instead of 128 / 4).
-template <class C>
-MP_HD Jac<C> jac_dbl_rare(const Jac<C>& p) {
-  return jac_dbl<C>(p);
-}
 
-// P + Q, Q affine
+// p <- p + q, q affine
+template <class C>
+MP_HD void jac_madd_ip(Jac<C>& p, const Aff<C>& q) {
+  typedef typename C::FqP F;
+  if (aff_is_inf<C>(q)) return;
+  if (fe_is_zero(p.Z)) {
+    p.X = q.x;
+    p.Y = q.y;
+    p.Z = fe_one<F>();
+    return;
+  }
+  const Fe<F> Z1Z1 = fe_sqr<F>(p.Z);
+  const Fe<F> U2 = fe_mul<F>(q.x, Z1Z1);
+  const Fe<F> S2 = fe_mul<F>(fe_mul<F>(q.y, p.Z), Z1Z1);
+  const Fe<F> H = fe_sub<F>(U2, p.X);
+  const Fe<F> Rr = fe_sub<F>(S2, p.Y);
+  if (fe_is_zero(H)) {
+    if (fe_is_zero(Rr))
+      jac_dbl_ip<C>(p);          // P + P
+    else
+      p.Z = fe_zero<F>();        // P + (-P)
+    return;
+  }
+  const Fe<F> HH = fe_sqr<F>(H);
+  const Fe<F> HHH = fe_mul<F>(H, HH);
+  const Fe<F> V = fe_mul<F>(p.X, HH);
+  const Fe<F> X3 = fe_sub<F>(fe_sub<F>(fe_sqr<F>(Rr), HHH), fe_dbl<F>(V));
+  p.Y = fe_sub<F>(fe_mul<F>(Rr, fe_sub<F>(V, X3)), fe_mul<F>(p.Y, HHH));
+  p.Z = fe_mul<F>(p.Z, H);
+  p.X = X3;
+}
 template <class C>
 MP_HD Jac<C> jac_madd(const Jac<C>& p, const Aff<C>& q) {
-  typedef typename C::FqP F;
-  if (aff_is_inf<C>(q)) return p;
-  if (fe_is_zero(p.Z)) return jac_from_aff<C>(q);
-  Fe<F> Z1Z1 = fe_sqr<F>(p.Z);
-  Fe<F> U2 = fe_mul<F>(q.x, Z1Z1);
-  Fe<F> S2 = fe_mul<F>(fe_mul<F>(q.y, p.Z), Z1Z1);
-  Fe<F> H = fe_sub<F>(U2, p.X);
-  Fe<F> Rr = fe_sub<F>(S2, p.Y);
-  if (fe_is_zero(H)) {
-    if (fe_is_zero(Rr)) return jac_dbl_rare<C>(p);
-    return jac_inf<C>();
-  }
-  Fe<F> HH = fe_sqr<F>(H);
-  Fe<F> HHH = fe_mul<F>(H, HH);
-  Fe<F> V = fe_mul<F>(p.X, HH);
-  Jac<C> r;
-  r.X = fe_sub<F>(fe_sub<F>(fe_sqr<F>(Rr), HHH), fe_dbl<F>(V));
-  r.Y = fe_sub<F>(fe_mul<F>(Rr, fe_sub<F>(V, r.X)), fe_mul<F>(p.Y, HHH));
-  r.Z = fe_mul<F>(p.Z, H);
+  Jac<C> r = p;
+  jac_madd_ip<C>(r, q);
   return r;
 }
 
-// P + Q, both Jacobian
+// p <- p + q, both Jacobian
+template <class C>
+MP_HD void jac_add_ip(Jac<C>& p, const Jac<C>& q) {
+  typedef typename C::FqP F;
+  if (fe_is_zero(q.Z)) return;
+  if (fe_is_zero(p.Z)) {
+    p = q;
+    return;
+  }
+  const Fe<F> Z1Z1 = fe_sqr<F>(p.Z), Z2Z2 = fe_sqr<F>(q.Z);
+  const Fe<F> U1 = fe_mul<F>(p.X, Z2Z2), U2 = fe_mul<F>(q.X, Z1Z1);
+  const Fe<F> S1 = fe_mul<F>(fe_mul<F>(p.Y, q.Z), Z2Z2), S2 = fe_mul<F>(fe_mul<F>(q.Y, p.Z), Z1Z1);
+  const Fe<F> H = fe_sub<F>(U2, U1);
+  const Fe<F> Rr = fe_sub<F>(S2, S1);
+  if (fe_is_zero(H)) {
+    if (fe_is_zero(Rr))
+      jac_dbl_ip<C>(p);
+    else
+      p.Z = fe_zero<F>();
+    return;
+  }
+  const Fe<F> HH = fe_sqr<F>(H);
+  const Fe<F> HHH = fe_mul<F>(H, HH);
+  const Fe<F> V = fe_mul<F>(U1, HH);
+  const Fe<F> X3 = fe_sub<F>(fe_sub<F>(fe_sqr<F>(Rr), HHH), fe_dbl<F>(V));
+  p.Y = fe_sub<F>(fe_mul<F>(Rr, fe_sub<F>(V, X3)), fe_mul<F>(S1, HHH));
+  p.Z = fe_mul<F>(fe_mul<F>(p.Z, q.Z), H);
+  p.X = X3;
+}
 template <class C>
 MP_HD Jac<C> jac_add(const Jac<C>& p, const Jac<C>& q) {
-  typedef typename C::FqP F;
-  if (fe_is_zero(p.Z)) return q;
-  if (fe_is_zero(q.Z)) return p;
-  Fe<F> Z1Z1 = fe_sqr<F>(p.Z), Z2Z2 = fe_sqr<F>(q.Z);
-  Fe<F> U1 = fe_mul<F>(p.X, Z2Z2), U2 = fe_mul<F>(q.X, Z1Z1);
-  Fe<F> S1 = fe_mul<F>(fe_mul<F>(p.Y, q.Z), Z2Z2), S2 = fe_mul<F>(fe_mul<F>(q.Y, p.Z), Z1Z1);
-  Fe<F> H = fe_sub<F>(U2, U1);
-  Fe<F> Rr = fe_sub<F>(S2, S1);
-  if (fe_is_zero(H)) {
-    if (fe_is_zero(Rr)) return jac_dbl_rare<C>(p);
-    return jac_inf<C>();
-  }
-  Fe<F> HH = fe_sqr<F>(H);
-  Fe<F> HHH = fe_mul<F>(H, HH);
-  Fe<F> V = fe_mul<F>(U1, HH);
-  Jac<C> r;
-  r.X = fe_sub<F>(fe_sub<F>(fe_sqr<F>(Rr), HHH), fe_dbl<F>(V));
-  r.Y = fe_sub<F>(fe_mul<F>(Rr, fe_sub<F>(V, r.X)), fe_mul<F>(S1, HHH));
-  r.Z = fe_mul<F>(fe_mul<F>(p.Z, q.Z), H);
+  Jac<C> r = p;
+  jac_add_ip<C>(r, q);
   return r;
 }
 

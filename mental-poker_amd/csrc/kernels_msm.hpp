@@ -111,7 +111,7 @@ MP_HD void body_fixed_msm(const FixedArgs& a, uint32_t b, uint32_t y) {
 #pragma unroll 1
     for (uint32_t w = 0; w < a.g.windows; ++w) {
       const uint32_t d = fb_digit(k, a.g, w);
-      if (d) acc = jac_madd<C>(acc, ld_aff<C>(fb_entry(a.FB, a.g, term.b, w, d)));
+      if (d) jac_madd_ip<C>(acc, ld_aff<C>(fb_entry(a.FB, a.g, term.b, w, d)));
     }
   }
   st_jac<C>(a.J + j_off(job.out, a.Bpad, b), acc);
@@ -144,9 +144,9 @@ MP_HD void body_remask(const RemaskArgs& a, uint32_t b, uint32_t y) {
 #pragma unroll 1
   for (uint32_t w = 0; w < a.g.windows; ++w) {
     const uint32_t d = fb_digit(k, a.g, w);
-    if (d) acc = jac_madd<C>(acc, ld_aff<C>(fb_entry(a.FB, a.g, base, w, d)));
+    if (d) jac_madd_ip<C>(acc, ld_aff<C>(fb_entry(a.FB, a.g, base, w, d)));
   }
-  acc = jac_madd<C>(acc, ld_aff<C>(a.P + p_off(a.p_deck + 2 * src + comp, a.Bpad, b)));
+  jac_madd_ip<C>(acc, ld_aff<C>(a.P + p_off(a.p_deck + 2 * src + comp, a.Bpad, b)));
   st_jac<C>(a.J + j_off(a.j_out + y, a.Bpad, b), acc);
 }
 MP_KERNEL_OCC(k_remask, RemaskArgs, body_remask, 4)
@@ -272,7 +272,7 @@ MP_HD void body_var_msm(const VarArgs& a, uint32_t b, uint32_t y) {
   for (int w = (int)a.nwin - 1; w >= 0; --w) {
     if (w != (int)a.nwin - 1) {
 #pragma unroll 1
-      for (int q = 0; q < VB_WINDOW_BITS; ++q) acc = jac_dbl<C>(acc);
+      for (int q = 0; q < VB_WINDOW_BITS; ++q) jac_dbl_ip<C>(acc);
     }
 #pragma unroll 1
     for (uint32_t t = 0; t < job.count; ++t) {
@@ -282,7 +282,7 @@ MP_HD void body_var_msm(const VarArgs& a, uint32_t b, uint32_t y) {
         const uint32_t e = (uint32_t)(d < 0 ? -d : d) - 1;
         Aff<C> q = ld_aff<C>(a.T + p_off(term.b * VB_ENTRIES + e, a.Bpad, b));
         if (d < 0) q = aff_neg<C>(q);
-        acc = jac_madd<C>(acc, q);
+        jac_madd_ip<C>(acc, q);
       }
     }
   }
@@ -305,9 +305,9 @@ MP_HD void body_combine(const CombineArgs& a, uint32_t b, uint32_t y) {
   for (uint32_t t = 0; t < job.count; ++t) {
     const uint32_t s = a.terms[job.begin + t].s;
     if (s & AFF_FLAG)
-      acc = jac_madd<C>(acc, ld_aff<C>(a.P + p_off(s & ~AFF_FLAG, a.Bpad, b)));
+      jac_madd_ip<C>(acc, ld_aff<C>(a.P + p_off(s & ~AFF_FLAG, a.Bpad, b)));
     else
-      acc = jac_add<C>(acc, ld_jac<C>(a.J + j_off(s, a.Bpad, b)));
+      jac_add_ip<C>(acc, ld_jac<C>(a.J + j_off(s, a.Bpad, b)));
   }
   st_jac<C>(a.J + j_off(job.out, a.Bpad, b), acc);
 }
