@@ -59,7 +59,7 @@ struct Workspace {
     J.alloc((size_t)nJ * Bpad * 24, s);
     D.alloc((size_t)std::max(nD, 1u) * nwin * Bpad, s);
     T.alloc((size_t)std::max(nT, 1u) * VB_ENTRIES * Bpad * 16, s);
-    size_t norm_max = std::max((size_t)nT, (size_t)nJ) * Bpad;   // k_table prefix products, k_normalize ranges
+    size_t norm_max = std::max((size_t)nT * 8, (size_t)nJ) * Bpad;   // k_table prefix products (8 per base), k_normalize ranges
     NS.alloc(norm_max * 8, s);
     stage.alloc((size_t)stage_words * Bpad, s);
     seed.alloc((size_t)8 * Bpad, s);

@@ -182,74 +182,94 @@ MP_HD void body_recode(const RecodeArgs& a, uint32_t b, uint32_t y) {
 MP_KERNEL(k_recode, RecodeArgs, body_recode)
 
 // ---- per-proof window tables: multiples 1P..16P of every variable base, AFFINE, built with batched affine
-// additions: one lane owns a group of up to TABLE_GROUP bases of one proof and walks e = 2..16; at each step the
-// TABLE_GROUP slopes share ONE Fermat inversion (Montgomery's trick; prefix products through HBM scratch).
-// ~5M + 1S per entry plus 1/64 of an inversion, against 7M+4S (Jacobian chain) + ~13M (normalisation) before.
+// additions.  One lane owns a group of up to TABLE_GROUP bases of one proof.  The multiples are produced in four
+// rounds -- {2P}, {3P,4P}, {5P..8P}, {9P..16P}: tP = 2*(t/2)P for even t, tP = 2^k P + (t-2^k)P for odd t, so
+// every operand comes from an earlier round -- and ALL slopes of a round (up to 8 x TABLE_GROUP) share ONE
+// Fermat inversion (Montgomery's trick; prefix products through HBM scratch).
+// ~5M + 1S per entry plus 4/15 of 1/64 of an inversion, against 7M+4S (Jacobian chain) + ~13M (normalisation).
 static const uint32_t TABLE_GROUP = 64;
 struct TableArgs {
   const uint32_t* P;
   uint32_t* T;           // [tslot][entry][Bpad] affine
-  uint32_t* scratch;     // [tslot][Bpad] field elements (prefix products)
+  uint32_t* scratch;     // [tslot][8][Bpad] field elements (prefix products)
   const Term* list;      // {P slot, table slot}; table slots are 0..n_tables-1 in list order
   uint32_t Bpad, n_tables;
 };
+// operands of target multiple t (entry index t-1) in the round that starts at multiple e0+1 (e0 = 1, 2, 4, 8)
+MP_HD void table_operands(uint32_t t, uint32_t e0, uint32_t& ia, uint32_t& ib, bool& dbl) {
+  dbl = (t & 1u) == 0;
+  if (dbl) {
+    ia = ib = t / 2 - 1;
+  } else {
+    ia = e0 - 1;          // (2^k) P
+    ib = t - e0 - 1;      // (t - 2^k) P
+  }
+}
 template <class C>
 MP_HD void body_table(const TableArgs& a, uint32_t b, uint32_t y) {
   typedef typename C::FqP F;
   const uint32_t g0 = y * TABLE_GROUP;
   const uint32_t g1 = g0 + TABLE_GROUP < a.n_tables ? g0 + TABLE_GROUP : a.n_tables;
-  // entry 0 = P
-  for (uint32_t g = g0; g < g1; ++g) {
+  for (uint32_t g = g0; g < g1; ++g) {   // entry 0 = P
     const Term t = a.list[g];
     st_aff<C>(a.T + p_off(t.b * VB_ENTRIES, a.Bpad, b), ld_aff<C>(a.P + p_off(t.s, a.Bpad, b)));
   }
 #pragma unroll 1
-  for (uint32_t e = 1; e < (uint32_t)VB_ENTRIES; ++e) {
-    // pass 1: denominators (2y for the doubling, x_e - x_1 afterwards) and their running product
+  for (uint32_t e0 = 1; e0 < (uint32_t)VB_ENTRIES; e0 *= 2) {   // targets: entries e0 .. 2*e0-1
+    // pass 1: denominators (2y for a doubling, x_b - x_a for an addition) and their running product
     Fe<F> prod = fe_one<F>();
     for (uint32_t g = g0; g < g1; ++g) {
       const uint32_t ts = a.list[g].b;
-      const Aff<C> p1 = ld_aff<C>(a.T + p_off(ts * VB_ENTRIES, a.Bpad, b));
-      Fe<F> den;
-      if (e == 1) {
-        den = fe_dbl<F>(p1.y);
-      } else {
-        const Fe<F> xe = ld_fe<F>(a.T + p_off(ts * VB_ENTRIES + e - 1, a.Bpad, b));
-        den = fe_sub<F>(xe, p1.x);
+#pragma unroll 1
+      for (uint32_t i = 0; i < e0; ++i) {
+        uint32_t ia, ib;
+        bool dbl;
+        table_operands(e0 + i + 1, e0, ia, ib, dbl);
+        Fe<F> den;
+        if (dbl)
+          den = fe_dbl<F>(ld_fe<F>(a.T + p_off(ts * VB_ENTRIES + ia, a.Bpad, b) + 8));
+        else
+          den = fe_sub<F>(ld_fe<F>(a.T + p_off(ts * VB_ENTRIES + ib, a.Bpad, b)), ld_fe<F>(a.T + p_off(ts * VB_ENTRIES + ia, a.Bpad, b)));
+        st_fe<F>(a.scratch + s_off(ts * 8 + i, a.Bpad, b), prod);
+        if (!fe_is_zero(den)) prod = fe_mul<F>(prod, den);   // zero only for P = infinity (prime-order group)
       }
-      st_fe<F>(a.scratch + s_off(ts, a.Bpad, b), prod);
-      if (!fe_is_zero(den)) prod = fe_mul<F>(prod, den);     // zero only for P = infinity (prime-order group)
     }
     Fe<F> inv = fe_inv<F>(prod);
-    // pass 2 (reverse): slope, new point
+    // pass 2 (exact reverse order): slope, new point
     for (uint32_t g = g1; g-- > g0;) {
       const uint32_t ts = a.list[g].b;
-      const Aff<C> p1 = ld_aff<C>(a.T + p_off(ts * VB_ENTRIES, a.Bpad, b));
-      Aff<C> pe = p1;
-      Fe<F> den;
-      if (e == 1) {
-        den = fe_dbl<F>(p1.y);
-      } else {
-        pe = ld_aff<C>(a.T + p_off(ts * VB_ENTRIES + e - 1, a.Bpad, b));
-        den = fe_sub<F>(pe.x, p1.x);
-      }
-      Aff<C> out = aff_inf<C>();
-      if (!fe_is_zero(den)) {
-        const Fe<F> dinv = fe_mul<F>(inv, ld_fe<F>(a.scratch + s_off(ts, a.Bpad, b)));
-        inv = fe_mul<F>(inv, den);
-        Fe<F> num;
-        if (e == 1) {
-          const Fe<F> xx = fe_sqr<F>(p1.x);
-          num = fe_add<F>(fe_dbl<F>(xx), xx);
-          if (C::A == 1) num = fe_add<F>(num, fe_one<F>());
+#pragma unroll 1
+      for (uint32_t i = e0; i-- > 0;) {
+        uint32_t ia, ib;
+        bool dbl;
+        table_operands(e0 + i + 1, e0, ia, ib, dbl);
+        const Aff<C> pa = ld_aff<C>(a.T + p_off(ts * VB_ENTRIES + ia, a.Bpad, b));
+        Aff<C> pb = pa;
+        Fe<F> den;
+        if (dbl) {
+          den = fe_dbl<F>(pa.y);
         } else {
-          num = fe_sub<F>(pe.y, p1.y);
+          pb = ld_aff<C>(a.T + p_off(ts * VB_ENTRIES + ib, a.Bpad, b));
+          den = fe_sub<F>(pb.x, pa.x);
         }
-        const Fe<F> lam = fe_mul<F>(num, dinv);
-        out.x = fe_sub<F>(fe_sub<F>(fe_sqr<F>(lam), p1.x), pe.x);
-        out.y = fe_sub<F>(fe_mul<F>(lam, fe_sub<F>(p1.x, out.x)), p1.y);
+        Aff<C> out = aff_inf<C>();
+        if (!fe_is_zero(den)) {
+          const Fe<F> dinv = fe_mul<F>(inv, ld_fe<F>(a.scratch + s_off(ts * 8 + i, a.Bpad, b)));
+          inv = fe_mul<F>(inv, den);
+          Fe<F> num;
+          if (dbl) {
+            const Fe<F> xx = fe_sqr<F>(pa.x);
+            num = fe_add<F>(fe_dbl<F>(xx), xx);
+            if (C::A == 1) num = fe_add<F>(num, fe_one<F>());
+          } else {
+            num = fe_sub<F>(pb.y, pa.y);
+          }
+          const Fe<F> lam = fe_mul<F>(num, dinv);
+          out.x = fe_sub<F>(fe_sub<F>(fe_sqr<F>(lam), pa.x), pb.x);
+          out.y = fe_sub<F>(fe_mul<F>(lam, fe_sub<F>(pa.x, out.x)), pa.y);
+        }
+        st_aff<C>(a.T + p_off(ts * VB_ENTRIES + e0 + i, a.Bpad, b), out);
       }
-      st_aff<C>(a.T + p_off(ts * VB_ENTRIES + e, a.Bpad, b), out);
     }
   }
 }
