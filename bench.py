@@ -287,7 +287,7 @@ def main():
     out = {
         "metric": "shuffle proofs/sec (prove+verify)", "value": value, "unit": "proofs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (256-bit Montgomery, 8x32 limbs)",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery: 9x29-bit lazy base field, 8x32 scalar field)",
         "data": "synthetic",
         "config": {"workload": "%d-card deck, m=%d n=%d, %s curve, shuffle_and_remask + verify_shuffle" % (N, m, n, curve),
                    "proofs_per_gpu_per_step": B, "streams": S, "fixed_base_window_bits": args.fb_bits,

@@ -64,10 +64,11 @@ void mp_ctx_destroy(mp_ctx* ctx) {
 int mp_setup(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out_params) {
   if (!ctx || !seed || !out_params || m < 2 || n < 2) return fail(MP_ERR_BAD_ARGUMENT, "mp_setup: bad argument");
   MP_TRY
+  rt::set_device(ctx->device);
   switch (ctx->curve) {
-    case 0: return setup_Stark(m, n, seed, out_params);
-    case 1: return setup_Bn254(m, n, seed, out_params);
-    default: return setup_Secp256k1(m, n, seed, out_params);
+    case 0: return setup_Stark(ctx, m, n, seed, out_params);
+    case 1: return setup_Bn254(ctx, m, n, seed, out_params);
+    default: return setup_Secp256k1(ctx, m, n, seed, out_params);
   }
   MP_CATCH
 }

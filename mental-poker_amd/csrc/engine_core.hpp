@@ -494,45 +494,49 @@ struct Table : mp_table {
   }
 };
 
-// host-side DLCards::setup: k * G_std with the MP_HD group law (a few dozen scalar-muls, once per table)
+// DLCards::setup: the scalars come from ChaCha20Rng(seed) on the host (stream logic only); the n+3 scalar
+// multiplications k_i * G_std run on the GPU as n+3 one-term variable-base MSMs (same kernels as mp_msm).
 template <class C>
-static int setup_host(uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out) {
+static int setup_device(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out) {
   typedef typename C::FqP F;
   typedef typename C::FrP R;
   uint32_t key[8];
   memcpy(key, seed, 32);
   FrStream st;
   frstream_init(st, key);
+  const uint32_t cnt = n + 3;
   Aff<C> g;
   g.x = fe_unpack<F>(C::GX_MONT);
   g.y = fe_unpack<F>(C::GY_MONT);
-  for (uint32_t i = 0; i < n + 3; ++i) {
+  alignas(8) uint8_t gw[64];
+  aff_to_wire<C>(g, gw);
+  std::vector<uint8_t> scalars((size_t)cnt * 32), points((size_t)cnt * 64);
+  for (uint32_t i = 0; i < cnt; ++i) {
     Fe<R> kf = frstream_next<R>(st);
     uint32_t k[8];
     fe_to_canonical<R>(kf, k);
-    Jac<C> acc = jac_inf<C>();
-    for (int bit = 255; bit >= 0; --bit) {
-      acc = jac_dbl<C>(acc);
-      if ((k[bit >> 5] >> (bit & 31)) & 1u) acc = jac_madd<C>(acc, g);
-    }
-    Aff<C> a = jac_is_inf<C>(acc) ? aff_inf<C>() : jac_to_aff_with_zinv<C>(acc, fe_inv<F>(acc.Z));
-    alignas(8) uint8_t tmp[64];
-    aff_to_wire<C>(a, tmp);
-    memcpy(out + 64 * i, tmp, 64);
+    memcpy(&scalars[(size_t)i * 32], k, 32);
+    memcpy(&points[(size_t)i * 64], gw, 64);
   }
+  Table<C> t;
+  t.ctx = ctx;
+  t.m = m; t.n = n; t.N = m * n;
+  t.nwin = (uint32_t)vb_windows(R::BITS);
+  t.msm_host(cnt, 1, scalars.data(), points.data(), out);
   return MP_OK;
 }
 
 }  // namespace mp
 
-
-#define MP_DEFINE_CURVE(NAME)                                                                                           \
-  namespace mp {                                                                                                        \
-  mp_table* make_table_##NAME(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, const uint8_t* pk,          \
-                              uint32_t fb_bits, int* rc) {                                                              \
-    auto* p = new Table<NAME>();                                                                                        \
-    *rc = p->init(ctx, m, n, params, pk, fb_bits);                                                                      \
-    return p;                                                                                                           \
-  }                                                                                                                     \
-  int setup_##NAME(uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out) { return setup_host<NAME>(m, n, seed, out); } \
+#define MP_DEFINE_CURVE(NAME)                                                                                  \
+  namespace mp {                                                                                               \
+  mp_table* make_table_##NAME(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, const uint8_t* pk,  \
+                              uint32_t fb_bits, int* rc) {                                                     \
+    auto* p = new Table<NAME>();                                                                               \
+    *rc = p->init(ctx, m, n, params, pk, fb_bits);                                                             \
+    return p;                                                                                                  \
+  }                                                                                                            \
+  int setup_##NAME(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out) {                \
+    return setup_device<NAME>(ctx, m, n, seed, out);                                                           \
+  }                                                                                                            \
   }
