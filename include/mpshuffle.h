@@ -108,6 +108,19 @@ int mp_remask_batch(mp_table* t, size_t count, const uint8_t* cards, const uint8
 int mp_msm(mp_table* t, size_t n_msm, size_t k, const uint8_t* scalars, const uint8_t* points, uint8_t* out);
 int mp_commit_batch(mp_table* t, size_t count, size_t len, const uint8_t* values, const uint8_t* r, uint8_t* out);
 
+/* ---- sigma protocols behind the rest of DLCards (host buffers) -------------------------------------
+ * nbases = 1: Schnorr identification (prove/verify_key_ownership, [REF mod.rs:132-165]);
+ * nbases = 2: Chaum-Pedersen DL equality (mask / remask / reveal proofs and their verifiers, [REF mod.rs:182-357]).
+ * Per proof: bases g_i, publics a_i = x * g_i (nbases points each), witness x, `fs_init` = Blake2s digest of the bytes the
+ * reference seeds its FiatShamirRng with (mp_blake2s of e.g. b"Masking Proof"), prover seed; proof = A_1..A_nb || z.
+ * verify status: 0 Ok, 5 "Schnorr Identification", 6 "Chaum-Pedersen" [REF tests.rs:74-76,120,170], < 0 usage error. */
+int mp_sigma_prove_batch(mp_table* t, size_t B, uint32_t nbases, const uint8_t* bases, const uint8_t* publics,
+                         const uint8_t* witness, const uint8_t* fs_init, const uint8_t* prover_seeds, uint8_t* out_proofs,
+                         int32_t* status);
+int mp_sigma_verify_batch(mp_table* t, size_t B, uint32_t nbases, const uint8_t* bases, const uint8_t* publics,
+                          const uint8_t* proofs, const uint8_t* fs_init, int32_t* status);
+int mp_blake2s(const uint8_t* in, size_t len, uint8_t out[32]);   /* host helper: BLAKE2s-256 */
+
 /* ---- measurement hooks ---------------------------------------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by HIP events on the context's stream;
  * mp_profile_report writes "name count total_ms\n" lines (and resets) -- bench.py's roofline source. */

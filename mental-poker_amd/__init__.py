@@ -6,7 +6,7 @@ Everything is computed by libmpshuffle.so (hand-written HIP for gfx950); importi
 creating an engine does not (no CPU fallback)."""
 from . import _native
 from ._native import Engine, NativeError, NoDeviceError, build, load
-from .protocol import (CardProtocolError, ChaCha20Rng, CryptoError, DLCards, Parameters, Permutation)
+from .protocol import (CardProtocolError, ChaCha20Rng, CryptoError, DLCards, Parameters, Permutation, fr_rand)
 
 __all__ = ["Engine", "NativeError", "NoDeviceError", "build", "load", "DLCards", "Parameters", "Permutation",
-           "CryptoError", "CardProtocolError", "ChaCha20Rng", "_native"]
+           "CryptoError", "CardProtocolError", "ChaCha20Rng", "fr_rand", "_native"]

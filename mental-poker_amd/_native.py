@@ -19,7 +19,8 @@ SYMBOLS = [
     "mp_setup", "mp_table_create", "mp_table_create_ex", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
     "mp_shuffle_and_remask_batch", "mp_verify_shuffle_batch", "mp_shuffle_and_remask_batch_dev",
     "mp_verify_shuffle_batch_dev", "mp_sync", "mp_reserve", "mp_remask_batch", "mp_msm", "mp_commit_batch",
-    "mp_profile_enable", "mp_profile_report", "mp_work_census", "mp_plan_stats",
+    "mp_profile_enable", "mp_profile_report", "mp_work_census", "mp_plan_stats", "mp_sigma_prove_batch",
+    "mp_sigma_verify_batch", "mp_blake2s",
 ]
 
 
@@ -105,6 +106,9 @@ def bind(cdll):
     cdll.mp_profile_report.argtypes = [c.c_void_p, c.c_char_p, c.c_size_t]
     cdll.mp_work_census.argtypes = [c.c_void_p] + [c.POINTER(c.c_uint64)] * 4
     cdll.mp_plan_stats.argtypes = [c.c_void_p, c.POINTER(c.c_uint64)]
+    cdll.mp_sigma_prove_batch.argtypes = [c.c_void_p, c.c_size_t, c.c_uint32, u8p, u8p, u8p, u8p, u8p, u8p, i32p]
+    cdll.mp_sigma_verify_batch.argtypes = [c.c_void_p, c.c_size_t, c.c_uint32, u8p, u8p, u8p, u8p, i32p]
+    cdll.mp_blake2s.argtypes = [u8p, c.c_size_t, u8p]
     return cdll
 
 
@@ -161,6 +165,11 @@ class Engine:
 
     def proof_size(self, m, n):
         return self.lib.mp_proof_size(m, n)
+
+    def blake2s(self, data):
+        out = (ctypes.c_uint8 * 32)()
+        self._chk(self.lib.mp_blake2s(_in(data), len(data), out))
+        return bytes(out)
 
     def setup(self, m, n, seed):
         out = (ctypes.c_uint8 * self.lib.mp_params_size(n))()
@@ -269,6 +278,20 @@ class Table:
 
     def verify_shuffle_batch_dev(self, B, d_decks, d_shuffled, d_proofs, d_status):
         self.eng._chk(self.lib.mp_verify_shuffle_batch_dev(self.h, B, d_decks, d_shuffled, d_proofs, d_status))
+
+    def sigma_prove_batch(self, nbases, bases, publics, witness, fs_init, seeds):
+        B = len(witness) // 32
+        out = (ctypes.c_uint8 * (B * (nbases * 64 + 32)))()
+        st = (ctypes.c_int32 * B)()
+        self.eng._chk(self.lib.mp_sigma_prove_batch(self.h, B, nbases, _in(bases), _in(publics), _in(witness), _in(fs_init),
+                                                    _in(seeds), out, st))
+        return bytes(out), list(st)
+
+    def sigma_verify_batch(self, nbases, bases, publics, proofs, fs_init):
+        B = len(proofs) // (nbases * 64 + 32)
+        st = (ctypes.c_int32 * B)()
+        self.eng._chk(self.lib.mp_sigma_verify_batch(self.h, B, nbases, _in(bases), _in(publics), _in(proofs), _in(fs_init), st))
+        return list(st)
 
     def plan_stats(self):
         v = (ctypes.c_uint64 * 16)()

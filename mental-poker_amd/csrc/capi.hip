@@ -1,6 +1,8 @@
 // capi.hip -- the C ABI of libmpshuffle.so (include/mpshuffle.h): argument checking, error mapping and
 // dispatch to the per-curve engines (curve_*.hip).  Mirrors DLCards::{setup, shuffle_and_remask, verify_shuffle}
 // [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:105-121, 380-418, 420-443].
+#include <cstring>
+
 #include "engine_base.hpp"
 
 namespace mp {
@@ -29,6 +31,8 @@ const char* mp_check_name(int code) {
     case 2: return "Zero Argument (5.2)";
     case 3: return "Single Value Product (5.3)";
     case 4: return "Multi-Exponentiation Argument (4)";
+    case 5: return "Schnorr Identification";
+    case 6: return "Chaum-Pedersen";
     case MP_ERR_BAD_ENCODING: return "IoError: bad encoding";
     case MP_ERR_BAD_PERMUTATION: return "IoError: not a permutation";
     case MP_ERR_BAD_ARGUMENT: return "IoError: bad argument";
@@ -251,6 +255,45 @@ int mp_work_census(mp_table* t, uint64_t* prove_terms, uint64_t* verify_terms, u
   if (!t || !prove_terms || !verify_terms || !prove_point_ops || !verify_point_ops) return fail(MP_ERR_BAD_ARGUMENT, "mp_work_census: bad argument");
   t->census(prove_terms, verify_terms, prove_point_ops, verify_point_ops);
   return MP_OK;
+}
+
+int mp_blake2s(const uint8_t* in, size_t len, uint8_t out[32]) {
+  if ((!in && len) || !out) return fail(MP_ERR_BAD_ARGUMENT, "mp_blake2s: bad argument");
+  Blake2sState st;
+  blake2s_init(st);
+  size_t off = 0;
+  uint32_t m[16];
+  while (len - off > 64) {
+    memcpy(m, in + off, 64);
+    off += 64;
+    blake2s_compress(st, m, off, false);
+  }
+  memset(m, 0, 64);
+  if (len - off) memcpy(m, in + off, len - off);
+  blake2s_compress(st, m, len, true);
+  memcpy(out, st.h, 32);
+  return MP_OK;
+}
+int mp_sigma_prove_batch(mp_table* t, size_t B, uint32_t nbases, const uint8_t* bases, const uint8_t* publics,
+                         const uint8_t* witness, const uint8_t* fs_init, const uint8_t* prover_seeds, uint8_t* out_proofs,
+                         int32_t* status) {
+  if (!t || !B || (nbases != 1 && nbases != 2) || !bases || !publics || !witness || !fs_init || !prover_seeds || !out_proofs || !status)
+    return fail(MP_ERR_BAD_ARGUMENT, "mp_sigma_prove_batch: bad argument");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  t->sigma_host(true, B, nbases, bases, publics, witness, fs_init, prover_seeds, out_proofs, status);
+  return MP_OK;
+  MP_CATCH
+}
+int mp_sigma_verify_batch(mp_table* t, size_t B, uint32_t nbases, const uint8_t* bases, const uint8_t* publics,
+                          const uint8_t* proofs, const uint8_t* fs_init, int32_t* status) {
+  if (!t || !B || (nbases != 1 && nbases != 2) || !bases || !publics || !proofs || !fs_init || !status)
+    return fail(MP_ERR_BAD_ARGUMENT, "mp_sigma_verify_batch: bad argument");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  t->sigma_host(false, B, nbases, bases, publics, nullptr, fs_init, nullptr, const_cast<uint8_t*>(proofs), status);
+  return MP_OK;
+  MP_CATCH
 }
 
 int mp_plan_stats(mp_table* t, uint64_t out[16]) {

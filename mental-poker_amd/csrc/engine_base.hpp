@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/mpshuffle.h"
+#include "hash.hpp"
 #include "layout.hpp"
 
 namespace mp {
@@ -133,6 +134,8 @@ struct mp_table {
   virtual void remask_host(size_t count, const uint8_t* cards, const uint8_t* rho, uint8_t* out) = 0;
   virtual void msm_host(size_t n_msm, size_t k, const uint8_t* scalars, const uint8_t* points, uint8_t* out) = 0;
   virtual void commit_host(size_t count, size_t len, const uint8_t* values, const uint8_t* r, uint8_t* out) = 0;
+  virtual void sigma_host(bool prove, size_t B, uint32_t nb, const uint8_t* bases, const uint8_t* publics, const uint8_t* witness,
+                          const uint8_t* fs_init, const uint8_t* seeds, uint8_t* proofs, int32_t* status) = 0;
   virtual void census(uint64_t* pt, uint64_t* vt, uint64_t* po, uint64_t* vo) = 0;
   virtual void plan_stats(uint64_t out[16]) = 0;
 };

@@ -2,7 +2,7 @@
 // Included by one translation unit per curve (curve_*.hip).
 #pragma once
 #include "engine_base.hpp"
-#include "kernels_proto.hpp"
+#include "kernels_sigma.hpp"
 
 namespace mp {
 
@@ -474,6 +474,78 @@ struct Table : mp_table {
     add(vplan.ph, out + 6);
     out[12] = nwin; out[13] = fbg.windows; out[14] = N;
   }
+  // ---------------------------------------------------------------- sigma protocols
+  void sigma_host(bool prove, size_t B_, uint32_t nb, const uint8_t* bases, const uint8_t* publics, const uint8_t* witness,
+                  const uint8_t* fs_init, const uint8_t* seeds, uint8_t* proofs, int32_t* status) override {
+    rt::Stream s = ctx->stream;
+    const uint32_t B = (uint32_t)B_;
+    const SigmaLay l = make_sigma_lay(nb);
+    const size_t psz = (size_t)nb * 64 + 32;
+    Adhoc ad;
+    uint32_t next_partial = l.chk + nb;
+    {
+      PhaseBuilder pb(ad.ph, next_partial, FCHUNK, VCHUNK);
+      if (prove) {
+        for (uint32_t i = 0; i < nb; ++i) {
+          pb.begin(l.A + i);
+          pb.var(l.r, l.g + i);
+          pb.end();
+        }
+        pb.normalize(l.A, nb);
+      } else {
+        for (uint32_t i = 0; i < nb; ++i) {
+          pb.begin(l.chk + i);
+          pb.var(l.z, l.g + i);
+          pb.var(l.negc, l.a + i);
+          pb.var(l.minus_one, l.A + i);
+          pb.end();
+        }
+      }
+    }
+    ad.dev.upload(ad.ph, s);
+    ad.w.ensure(B, 6, 3 * nb, next_partial, ad.ph.n_dslots, ad.ph.n_tslots, nwin, (3 * nb * 65 + 32) / 4 + 4, s);
+    Workspace& w = ad.w;
+    DevBuf<uint8_t> dg, da, dx, dfs, dseed, dpf;
+    DevBuf<int32_t> dst;
+    dg.alloc((size_t)B * nb * 64, s, false); da.alloc((size_t)B * nb * 64, s, false); dfs.alloc((size_t)B * 32, s, false);
+    dpf.alloc((size_t)B * psz, s, false);
+    rt::h2d(dg.p, bases, (size_t)B * nb * 64, s);
+    rt::h2d(da.p, publics, (size_t)B * nb * 64, s);
+    rt::h2d(dfs.p, fs_init, (size_t)B * 32, s);
+    rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
+    LoadPointsArgs lg{dg.p, w.P.p, w.status.p, w.Bpad, nb, l.g};
+    MP_RUN(k_load_points, C, B, nb, lg);
+    LoadPointsArgs la{da.p, w.P.p, w.status.p, w.Bpad, nb, l.a};
+    MP_RUN(k_load_points, C, B, nb, la);
+    const FsDev f{w.stage.p, w.seed.p, w.Bpad};
+    if (prove) {
+      dx.alloc((size_t)B * 32, s, false); dseed.alloc((size_t)B * 32, s, false);
+      rt::h2d(dx.p, witness, (size_t)B * 32, s);
+      rt::h2d(dseed.p, seeds, (size_t)B * 32, s);
+      LoadScalarsArgs lx{dx.p, w.S.p, w.status.p, w.Bpad, 1, l.x};
+      MP_RUN(k_load_scalars, C, B, 1, lx);
+      SigmaInitArgs ia{w.S.p, dseed.p, l, w.Bpad};
+      MP_RUN(k_sigma_init, C, B, 1, ia);
+      run_phase(ad.dev, w, B);
+      SigmaFsArgs fa{f, w.S.p, w.P.p, dfs.p, l, 1};
+      MP_RUN(k_sigma_fs, C, B, 1, fa);
+      SigmaIoArgs io{dpf.p, w.S.p, w.P.p, w.status.p, l, w.Bpad};
+      MP_RUN(k_sigma_store, C, B, nb + 1, io);
+      rt::d2h(proofs, dpf.p, (size_t)B * psz, s);
+    } else {
+      rt::h2d(dpf.p, proofs, (size_t)B * psz, s);
+      SigmaIoArgs io{dpf.p, w.S.p, w.P.p, w.status.p, l, w.Bpad};
+      MP_RUN(k_sigma_load, C, B, nb + 1, io);
+      SigmaFsArgs fa{f, w.S.p, w.P.p, dfs.p, l, 0};
+      MP_RUN(k_sigma_fs, C, B, 1, fa);
+      run_phase(ad.dev, w, B);
+      SigmaVerdictArgs va{w.J.p, w.status.p, l, w.Bpad, nb == 1 ? 5 : 6};
+      MP_RUN(k_sigma_verdict, C, B, 1, va);
+    }
+    rt::d2h(status, w.status.p, (size_t)B * 4, s);
+    rt::stream_sync(s);
+  }
+
   void census(uint64_t* pt, uint64_t* vt, uint64_t* po, uint64_t* vo) override {
     auto count = [&](const Phase& ph, uint64_t& terms, uint64_t& ops) {
       terms += ph.fterms.size() + ph.vterms.size();

@@ -149,6 +149,104 @@ class DLCards:
             raise CryptoError(self.engine.check_name(rc))
         return None
 
+    # ================= SURVEY.md 8f1: the rest of the trait (batched sigma protocols on the GPU) =================
+    def _t(self, pp, shared_key=None):
+        return self.table(pp, shared_key if shared_key is not None else pp.enc_parameters)
+
+    def _mul(self, t, terms):
+        """one MSM: sum k_i * P_i, terms = [(k, P)] -> point bytes"""
+        sc = _scalar_bytes([k % CURVE_ORDERS[self.curve] for k, _ in terms])
+        return t.msm(1, len(terms), sc, b"".join(P for _, P in terms))
+
+    def _sigma_verify(self, t, nb, bases, publics, proof, seed_bytes):
+        try:
+            st = t.sigma_verify_batch(nb, bases, publics, proof, self.engine.blake2s(seed_bytes))[0]
+        except _native.NativeError as e:
+            raise CardProtocolError.io(str(e))
+        if st > 0:
+            raise CryptoError(self.engine.check_name(st))
+        if st < 0:
+            raise CardProtocolError.io(self.engine.check_name(st))
+
+    def _sigma_prove(self, t, nb, bases, publics, x, seed_bytes, rng_seed):
+        try:
+            pf, st = t.sigma_prove_batch(nb, bases, publics, _scalar_bytes([x]), self.engine.blake2s(seed_bytes), rng_seed)
+        except _native.NativeError as e:
+            raise CardProtocolError.io(str(e))
+        if st[0] != 0:
+            raise CardProtocolError.io(self.engine.check_name(st[0]))
+        return pf
+
+    # -- fn player_keygen(rng, pp) -> (PlayerPublicKey, PlayerSecretKey)                  [REF mod.rs:123-130]
+    def player_keygen(self, rng, pp):
+        sk = fr_rand(self.curve, rng)
+        return self._mul(self._t(pp), [(sk, pp.enc_parameters)]), sk
+
+    # -- fn prove_key_ownership(rng, pp, pk, sk, player_public_info) -> ZKProofKeyOwnership  [REF mod.rs:132-149]
+    def prove_key_ownership(self, rng_seed, pp, pk, sk, player_public_info):
+        return self._sigma_prove(self._t(pp), 1, pp.enc_parameters, pk, sk, KEY_OWN_RNG_SEED + bytes(player_public_info), rng_seed)
+
+    # -- fn verify_key_ownership(pp, pk, player_public_info, proof) -> Result<(), CryptoError>  [REF mod.rs:151-165]
+    def verify_key_ownership(self, pp, pk, player_public_info, proof):
+        self._sigma_verify(self._t(pp), 1, pp.enc_parameters, pk, proof, KEY_OWN_RNG_SEED + bytes(player_public_info))
+
+    # -- fn compute_aggregate_key(pp, player_keys_proof_info) -> Result<AggregatePublicKey, CardProtocolError>  [REF mod.rs:167-180]
+    def compute_aggregate_key(self, pp, player_keys_proof_info):
+        t = self._t(pp)
+        for pk, proof, info in player_keys_proof_info:
+            try:
+                self.verify_key_ownership(pp, pk, info, proof)
+            except CryptoError as e:
+                raise CardProtocolError("ProofVerificationError", e)
+        return self._mul(t, [(1, pk) for pk, _, _ in player_keys_proof_info])
+
+    # -- fn mask(rng, pp, shared_key, original_card, r) -> (MaskedCard, ZKProofMasking)      [REF mod.rs:182-211]
+    def mask(self, rng_seed, pp, shared_key, original_card, r):
+        t = self._t(pp, shared_key)
+        c0 = self._mul(t, [(r, pp.enc_parameters)])
+        c1 = self._mul(t, [(1, original_card), (r, shared_key)])
+        stmt = c0 + self._mul(t, [(1, c1), (-1, original_card)])
+        proof = self._sigma_prove(t, 2, pp.enc_parameters + shared_key, stmt, r, MASKING_RNG_SEED, rng_seed)
+        return c0 + c1, proof
+
+    # -- fn verify_mask(pp, shared_key, card, masked_card, proof) -> Result<(), CryptoError>  [REF mod.rs:213-240]
+    def verify_mask(self, pp, shared_key, card, masked_card, proof):
+        t = self._t(pp, shared_key)
+        stmt = masked_card[:64] + self._mul(t, [(1, masked_card[64:]), (-1, card)])
+        self._sigma_verify(t, 2, pp.enc_parameters + shared_key, stmt, proof, MASKING_RNG_SEED)
+
+    # -- fn remask(rng, pp, shared_key, original_card, alpha) -> (MaskedCard, ZKProofRemasking)  [REF mod.rs:242-272]
+    def remask(self, rng_seed, pp, shared_key, original_card, alpha):
+        t = self._t(pp, shared_key)
+        remasked = t.remask_batch(original_card, _scalar_bytes([alpha]))
+        stmt = self._mul(t, [(1, remasked[:64]), (-1, original_card[:64])]) + self._mul(t, [(1, remasked[64:]), (-1, original_card[64:])])
+        return remasked, self._sigma_prove(t, 2, pp.enc_parameters + shared_key, stmt, alpha, REMASKING_RNG_SEED, rng_seed)
+
+    # -- fn verify_remask(pp, shared_key, original_masked, remasked, proof) -> Result<(), CryptoError>  [REF mod.rs:274-298]
+    def verify_remask(self, pp, shared_key, original_masked, remasked, proof):
+        t = self._t(pp, shared_key)
+        stmt = self._mul(t, [(1, remasked[:64]), (-1, original_masked[:64])]) + self._mul(t, [(1, remasked[64:]), (-1, original_masked[64:])])
+        self._sigma_verify(t, 2, pp.enc_parameters + shared_key, stmt, proof, REMASKING_RNG_SEED)
+
+    # -- fn compute_reveal_token(rng, pp, sk, pk, masked_card) -> (RevealToken, ZKProofReveal)  [REF mod.rs:300-330]
+    def compute_reveal_token(self, rng_seed, pp, sk, pk, masked_card):
+        t = self._t(pp)
+        token = self._mul(t, [(sk, masked_card[:64])])
+        return token, self._sigma_prove(t, 2, masked_card[:64] + pp.enc_parameters, token + pk, sk, REVEAL_RNG_SEED, rng_seed)
+
+    # -- fn verify_reveal(pp, pk, reveal_token, masked_card, proof) -> Result<(), CryptoError>  [REF mod.rs:332-357]
+    def verify_reveal(self, pp, pk, reveal_token, masked_card, proof):
+        self._sigma_verify(self._t(pp), 2, masked_card[:64] + pp.enc_parameters, reveal_token + pk, proof, REVEAL_RNG_SEED)
+
+    # -- fn unmask(pp, decryption_key, masked_card) -> Result<Card, CardProtocolError>     [REF mod.rs:359-378; reveal.rs:14-16]
+    def unmask(self, pp, decryption_key, masked_card):
+        for token, proof, pk in decryption_key:
+            try:
+                self.verify_reveal(pp, pk, token, masked_card, proof)
+            except CryptoError as e:
+                raise CardProtocolError("ProofVerificationError", e)
+        return self._mul(self._t(pp), [(1, masked_card[64:])] + [(-1, tok) for tok, _, _ in decryption_key])
+
     # -- batched forms (the data-parallel axis: independent proofs of one table)
     def shuffle_and_remask_batch(self, rng_seeds, pp, shared_key, decks, masking_factors, permutations):
         t = self.table(pp, shared_key)
@@ -184,6 +282,31 @@ class DLCards:
             else:
                 res.append(CardProtocolError.io(self.engine.check_name(s)))
         return res
+
+
+# group orders -- host-side only for `Fr::rand` of key generation and for the scalar -1
+CURVE_ORDERS = {
+    "stark": 0x0800000000000010ffffffffffffffffb781126dcae7b2321e66a241adc64d2f,
+    "bn254": 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+    "secp256k1": 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141,
+}
+KEY_OWN_RNG_SEED = b"Key Ownership Proof"   # [REF mod.rs:80-83]
+MASKING_RNG_SEED = b"Masking Proof"
+REMASKING_RNG_SEED = b"Remasking Proof"
+REVEAL_RNG_SEED = b"Reveal Proof"
+
+
+def fr_rand(curve, rng):
+    """arkworks-0.3 `Fr::rand(rng)`: 4 u64 limbs, top bits shaved, accepted limbs = Montgomery representation"""
+    q = CURVE_ORDERS[curve]
+    shave = 256 - q.bit_length()
+    while True:
+        limbs = [rng.next_u64() for _ in range(4)]
+        if shave:
+            limbs[3] &= (1 << (64 - shave)) - 1
+        v = limbs[0] | (limbs[1] << 64) | (limbs[2] << 128) | (limbs[3] << 192)
+        if v < q:
+            return v * pow(1 << 256, -1, q) % q
 
 
 class ChaCha20Rng:

@@ -103,3 +103,66 @@ def test_emulated_batch_and_status(emu, coracle):
     st = t.verify_shuffle_batch(b"".join(g["deck"] for g in ins), d, p)
     assert st[0] == 0 and st[2] == 0 and st[1] != 0
     t.close()
+
+
+def test_sigma_oracle_roundtrip():
+    """SURVEY 8f1 oracle: keygen, Schnorr, Chaum-Pedersen mask / remask / reveal, unmask (Python big-int spec)"""
+    import mp_oracle as po
+    cv = po.STARK
+    pp = po.setup(cv, 2, 3, po.ChaCha20Rng(bytes(range(32))))
+    rng = po.ChaCha20Rng(b"\x01" * 32)
+    players = [po.player_keygen(pp, rng) for _ in range(3)]
+    infos = [b"p%d" % i for i in range(3)]
+    proofs = [po.prove_key_ownership(pp, pk, sk, info, bytes([i]) * 32) for i, ((pk, sk), info) in enumerate(zip(players, infos))]
+    agg = po.compute_aggregate_key(pp, [(pk, pr, info) for (pk, sk), pr, info in zip(players, proofs, infos)])
+    with pytest.raises(po.VerifyError) as e:
+        po.compute_aggregate_key(pp, [(players[0][0], proofs[1], infos[0])])
+    assert str(e.value) == "Schnorr Identification"
+    card = po.pt_mul(cv, 4242, cv.G)
+    masked, mpf = po.mask(pp, agg, card, 777, bytes(32))
+    assert po.verify_mask(pp, agg, card, masked, mpf) and not po.verify_mask(pp, agg, po.pt_mul(cv, 2, card), masked, mpf)
+    rem, rpf = po.remask_with_proof(pp, agg, masked, 999, b"\x02" * 32)
+    assert po.verify_remask(pp, agg, masked, rem, rpf)
+    toks = []
+    for i, (pk, sk) in enumerate(players):
+        t, pf = po.compute_reveal_token(pp, sk, pk, rem, bytes([9 + i]) * 32)
+        assert po.verify_reveal(pp, pk, t, rem, pf)
+        toks.append((t, pf, pk))
+    assert po.unmask(pp, toks, rem) == card
+    toks[1] = (po.pt_mul(cv, 5, cv.G), toks[1][1], toks[1][2])
+    with pytest.raises(po.VerifyError) as e:
+        po.unmask(pp, toks, rem)
+    assert str(e.value) == "Chaum-Pedersen"
+    assert po.sigma_proof_from_bytes(po.sigma_proof_bytes(mpf), 2) == mpf
+
+
+def test_emulated_sigma_engine_matches_oracle(emu):
+    import hashlib
+    import mp_oracle as po
+    cv = po.STARK
+    eng = emu("stark")
+    for k in (0, 1, 63, 64, 65, 200):
+        assert eng.blake2s(bytes(range(k))) == hashlib.blake2s(bytes(range(k))).digest()
+    pp, pk0, _, _, _, _ = po.gen_inputs(cv, 2, 3, 5)
+    t = eng.table(2, 3, po.params_to_bytes(pp), po.pt_wire(pk0))
+    rng = po.ChaCha20Rng(bytes(range(32)))
+    bases = pubs = wit = seeds = exp = b""
+    for i in range(3):
+        x = po.fr_rand(cv, rng)
+        g, h = po.pt_mul(cv, po.fr_rand(cv, rng), cv.G), po.pt_mul(cv, po.fr_rand(cv, rng), cv.G)
+        a = [po.pt_mul(cv, x, g), po.pt_mul(cv, x, h)]
+        seed = bytes([i + 1]) * 32
+        bases += po.pt_wire(g) + po.pt_wire(h)
+        pubs += po.pt_wire(a[0]) + po.pt_wire(a[1])
+        wit += po.fe_bytes(x)
+        seeds += seed
+        exp += po.sigma_proof_bytes(po.sigma_prove(cv, [g, h], a, x, po.MASKING_RNG_SEED, seed))
+    fsi = eng.blake2s(po.MASKING_RNG_SEED) * 3
+    got, st = t.sigma_prove_batch(2, bases, pubs, wit, fsi, seeds)
+    assert got == exp and st == [0, 0, 0]
+    assert t.sigma_verify_batch(2, bases, pubs, got, fsi) == [0, 0, 0]
+    bad = bytearray(got)
+    bad[-1] ^= 1
+    assert t.sigma_verify_batch(2, bases, pubs, bytes(bad), fsi) == [0, 0, 6]
+    assert eng.check_name(5) == "Schnorr Identification" and eng.check_name(6) == "Chaum-Pedersen"
+    t.close()
