@@ -29,7 +29,11 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "py")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 INT_MAD_PEAK_G = 18000.0       # v_mad_u64_u32 issue rate measured with tools/microbench/intrate.hip (Gmad/s)
-MADS_PER_POINT_OP = 900        # 9x29-bit limbs: product 99 / square 63 mads; mixed addition 7M+4S = 945, doubling 1M+8S = 603
+# exact v_mad_u64_u32 counts of the compiled STARK group law (llvm -S of jac_madd_ip / jac_dbl_ip / fe_mul / fe_sqr,
+# 9x29-bit limbs): product 90, square 54; mixed addition 8M+3S = 882, doubling 3M+6S = 594, batched-affine table entry
+# 5M+1S + 4/15 of 1/64 of an inversion (256S+45M) = 580, Jacobian+Jacobian addition 11M+5S = 1260, normalisation of
+# one point 6M+1S + 1/64 inversion = 870
+MADS = {"madd": 882, "dbl": 594, "aff": 580, "jac": 1260, "norm": 870}
 
 
 # ---- distributed helpers (backend-agnostic: RCCL on GPUs, gloo in the CPU tests) -----------------------------
@@ -248,8 +252,23 @@ def main():
     # per-launch figures: one launch covers Bs = B / streams proofs; summed over the launches of the timed region
     dom_bytes = alg_bytes_per_proof(dom_name) * B * args.steps
     achieved_gbs = dom_bytes / (dom_ms * 1e-3) / 1e9
-    point_ops = (census["prove_point_ops"] + census["verify_point_ops"]) * B * args.steps
-    mads = point_ops * MADS_PER_POINT_OP
+    # exact multiply-add count of one prove+verify from the static plan (stats) and the instruction counts above
+    vw, fw = stats["var_windows"], stats["fixed_windows"]
+    mads_per_proof = 0
+    for side in ("prove", "verify"):
+        st_ = stats[side]
+        fixed_madds = st_["fixed_terms"] * fw
+        if side == "prove":
+            fixed_madds -= N * (fw - 1)               # c_A commits pi(i)+1 <= N: one non-zero window per term
+            fixed_madds += 2 * N * (fw + 1)           # re-encryption: 2N fixed-base scalar-muls + one addition each
+            norm_points = 2 * N + 11 * m + 7          # shuffled deck + proof points
+        else:
+            norm_points = 0
+        mads_per_proof += (fixed_madds + st_["var_terms"] * vw) * MADS["madd"]
+        mads_per_proof += st_["var_jobs"] * (vw - 1) * 5 * MADS["dbl"]
+        mads_per_proof += st_["table_bases"] * 15 * MADS["aff"]
+        mads_per_proof += st_["combine_terms"] * MADS["jac"] + norm_points * MADS["norm"]
+    mads = mads_per_proof * B * args.steps
     whole_path_bytes = 45 * 1024 if (m, n) == (2, 26) else None
     # HBM traffic of the dominant kernel from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
     # --pmc WRITE_SIZE in separate runs, gfx950 x2 correction applied to FETCH_SIZE), scaled to this batch
@@ -268,7 +287,9 @@ def main():
         "note": "path is integer-ALU bound (SURVEY 8d3): see int_mul",
         "int_mul": {"bound": "v_mad_u64_u32 issue", "achieved": round(mads / (kernel_ms_total * 1e-3) / 1e9, 1),
                     "peak": INT_MAD_PEAK_G, "unit": "Gmad/s",
-                    "frac": mads / (kernel_ms_total * 1e-3) / 1e9 / INT_MAD_PEAK_G},
+                    "frac": mads / (kernel_ms_total * 1e-3) / 1e9 / INT_MAD_PEAK_G,
+                    "mads_per_proof": mads_per_proof,
+                    "note": "exact v_mad_u64_u32 count of the compiled group law x static plan; peak = 256 CU x 4 SIMD x 8 lanes/clk x 2.4 GHz = 19.7 T/s theoretical, 18 T/s measured (tools/microbench/intrate.hip)"},
         "whole_path_hbm_frac": (value * whole_path_bytes / 1e9 / HBM_PEAK_GBS) if whole_path_bytes else None,
         "kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
     }

@@ -75,7 +75,7 @@ struct Table : mp_table {
 
   ProvePlan pplan;
   VerifyPlan vplan;
-  PhaseDev pph[4], vph;
+  PhaseDev pph[5], vph;
   DevBuf<uint32_t> draws;
   DevBuf<ProofElem> pwire, vwire;
   DevBuf<uint32_t> fbpts;    // (n+5) affine base points
@@ -134,7 +134,7 @@ struct Table : mp_table {
 
     pplan = make_prove_plan(m, n, FCHUNK, VCHUNK);
     vplan = make_verify_plan(m, n, FCHUNK, VCHUNK);
-    for (int i = 0; i < 4; ++i) pph[i].upload(pplan.ph[i], s);
+    for (int i = 0; i < 5; ++i) pph[i].upload(pplan.ph[i], s);
     vph.upload(vplan.ph, s);
     draws.upload(pplan.draws, s);
     pwire.upload(pplan.wire, s);
@@ -204,7 +204,7 @@ struct Table : mp_table {
   void reserve(size_t B) override {
     uint32_t nS = std::max(pplan.lay.nS, vplan.lay.nS), nP = std::max(pplan.lay.nP, vplan.lay.nP);
     uint32_t nJ = std::max(pplan.nJ, vplan.nJ), nD = vph.n_dslots, nT = vph.n_tslots;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 5; ++i) {
       nD = std::max(nD, pph[i].n_dslots);
       nT = std::max(nT, pph[i].n_tslots);
     }
@@ -270,6 +270,7 @@ struct Table : mp_table {
       MP_RUN(k_remask, C, B, 2 * N, ra);
     }
     run_phase(pph[0], w, B);
+    if (l.toom) run_phase(pph[4], w, B);
     {
       FsStatementArgs a = statement_args(w, l.deck, l.shuf, l.cA, l.x);
       MP_RUN(k_fs_round1, C, B, 1, a);
@@ -470,7 +471,7 @@ struct Table : mp_table {
       o[0] += ph.fterms.size(); o[1] += ph.vterms.size(); o[2] += ph.fjobs.size(); o[3] += ph.vjobs.size();
       o[4] += ph.tables.size(); o[5] += ph.cterms.size();
     };
-    for (int i = 0; i < 4; ++i) add(pplan.ph[i], out);
+    for (int i = 0; i < 5; ++i) add(pplan.ph[i], out);
     add(vplan.ph, out + 6);
     out[12] = nwin; out[13] = fbg.windows; out[14] = N;
   }
@@ -556,7 +557,7 @@ struct Table : mp_table {
       ops += ph.cterms.size();                                              // combines
     };
     uint64_t t = 0, o = 0;
-    for (int i = 0; i < 4; ++i) count(pplan.ph[i], t, o);
+    for (int i = 0; i < 5; ++i) count(pplan.ph[i], t, o);
     t += 2 * N;
     o += (uint64_t)2 * N * (fbg.windows + 1);  // remask
     *pt = t; *po = o;

@@ -350,6 +350,25 @@ template <class P>
 MP_HD Fe<P> fe_dbl(const Fe<P>& a) {
   return fe_add<P>(a, a);
 }
+// a / 2 (8x32 representation only: the scalar fields).  Works on the Montgomery residue: (a + (a odd ? p : 0)) >> 1
+template <class P>
+MP_HD Fe<P> fe_half(const Fe<P>& a) {
+  static_assert(!P::L29, "fe_half is only provided for the 8x32 representation");
+  const uint32_t mask = (uint32_t)0 - (a.v[0] & 1u);
+  uint32_t s[9];
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    c += (uint64_t)a.v[i] + (P::MOD[i] & mask);
+    s[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  s[8] = (uint32_t)c;
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = (s[i] >> 1) | (s[i + 1] << 31);
+  return r;
+}
 template <class P>
 MP_HD bool fe_eq(const Fe<P>& a, const Fe<P>& b) {
   if constexpr (P::L29) {

@@ -324,10 +324,15 @@ MP_HD void body_combine(const CombineArgs& a, uint32_t b, uint32_t y) {
   Jac<C> acc = jac_inf<C>();
   for (uint32_t t = 0; t < job.count; ++t) {
     const uint32_t s = a.terms[job.begin + t].s;
-    if (s & AFF_FLAG)
-      jac_madd_ip<C>(acc, ld_aff<C>(a.P + p_off(s & ~AFF_FLAG, a.Bpad, b)));
-    else
-      jac_add_ip<C>(acc, ld_jac<C>(a.J + j_off(s, a.Bpad, b)));
+    if (s & AFF_FLAG) {
+      Aff<C> q = ld_aff<C>(a.P + p_off(s & SLOT_MASK, a.Bpad, b));
+      if (s & NEG_FLAG) q = aff_neg<C>(q);
+      jac_madd_ip<C>(acc, q);
+    } else {
+      Jac<C> q = ld_jac<C>(a.J + j_off(s & SLOT_MASK, a.Bpad, b));
+      if (s & NEG_FLAG) q.Y = fe_neg<typename C::FqP>(q.Y);
+      jac_add_ip<C>(acc, q);
+    }
   }
   st_jac<C>(a.J + j_off(job.out, a.Bpad, b), acc);
 }

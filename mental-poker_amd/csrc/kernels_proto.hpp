@@ -362,6 +362,14 @@ MP_HD void body_prove_scal1(const ProveScalArgs& a, uint32_t b, uint32_t y) {
     rho_hat = fe_sub<R>(rho_hat, fe_mul<R>(MP_LD(l.rho + i), bi));
   }
   MP_ST(l.metau + l.m, rho_hat);
+  if (l.toom) {   // m = 2: halved evaluation scalars of the Toom-Cook diagonals (layout.hpp)
+    for (uint32_t j = 0; j < l.n; ++j) {
+      const Fe<R> a0 = MP_LD(l.mea0 + j), a1 = MP_LD(l.b + j), a2 = MP_LD(l.b + l.n + j);
+      const Fe<R> e = fe_add<R>(a0, a2);
+      MP_ST(l.tsp + j, fe_half<R>(fe_add<R>(e, a1)));
+      MP_ST(l.tsm + j, fe_half<R>(fe_sub<R>(e, a1)));
+    }
+  }
 }
 MP_KERNEL(k_prove_scal1, ProveScalArgs, body_prove_scal1)
 

@@ -29,7 +29,9 @@ struct Term {
   uint32_t s;  // fixed: S slot of the scalar        | var: digit slot        | combine: J slot or (AFF_FLAG | P slot)
   uint32_t b;  // fixed: index of the fixed base     | var: table slot        | combine: unused
 };
-static const uint32_t AFF_FLAG = 0x80000000u;
+static const uint32_t AFF_FLAG = 0x80000000u;   // combine term: P (affine) slot instead of J slot
+static const uint32_t NEG_FLAG = 0x40000000u;   // combine term: subtract instead of add
+static const uint32_t SLOT_MASK = 0x3FFFFFFFu;
 static const uint32_t NO_SLOT = 0xFFFFFFFFu;
 
 // fixed bases of one table context: ck_0..ck_{n-1}, H, G, pk, gen, gsum
@@ -77,7 +79,11 @@ class PhaseBuilder {
     uint32_t d = dslot(sslot), t = tslot(pslot);
     v_.push_back(Term{d, t});
   }
-  void addend(uint32_t pslot) { a_.push_back(pslot); }
+  void addend(uint32_t pslot, bool negate = false) { a_.push_back(AFF_FLAG | (negate ? NEG_FLAG : 0u) | pslot); }
+  // add (or subtract) a Jacobian result computed by an EARLIER kernel class of the same phase (a direct var / fixed
+  // job), never the output of another combine job of this phase
+  void addend_j(uint32_t jslot, bool negate = false) { a_.push_back((negate ? NEG_FLAG : 0u) | jslot); }
+  uint32_t new_partial() { return next_partial_++; }
   void end() {
     size_t nf = (f_.size() + fchunk_ - 1) / fchunk_, nv = (v_.size() + vchunk_ - 1) / vchunk_;
     size_t pieces = nf + nv + a_.size();
@@ -101,7 +107,7 @@ class PhaseBuilder {
     if (!direct) {
       ph_.cjobs.push_back(Job{out_, (uint32_t)ph_.cterms.size(), (uint32_t)(parts.size() + a_.size())});
       for (uint32_t p : parts) ph_.cterms.push_back(Term{p, 0});
-      for (uint32_t p : a_) ph_.cterms.push_back(Term{AFF_FLAG | p, 0});
+      for (uint32_t p : a_) ph_.cterms.push_back(Term{p, 0});
     }
   }
   void normalize(uint32_t first, uint32_t count) {
@@ -141,13 +147,16 @@ struct ProveLay {
   uint32_t rho, a, b, tmp, r, s, sb, hs, dz, t, bp, zB, zs, za0, zbm, zr0, zsm, zt, zd;
   uint32_t svbp, svd, svrd, svdelta, svs1, svsx, svv1, svv2;
   uint32_t mea0, mer0, meb, mes, metau;
+  uint32_t tsp, tsm;          // Toom-Cook (m = 2): halved scalar vectors (a0+a1+a2)/2, (a0-a1+a2)/2
   uint32_t x, y, z, hx, hy, zx, svx, mx;
   uint32_t zabar, zbbar, zrbar, zsbar, ztbar, svat, svbt, svrt, svst, meabar, merbar, mebbar, mesbar, metaubar;
   uint32_t nS, tmp_len;
   // P arena (J arena mirrors [0, nP))
   uint32_t deck, shuf, cA, cB, cb, hB, zcA0, zcBm, zcD, svcd, svcdelta, svcDelta, mecA0, mecB, meE;
+  uint32_t tDp, tDm;          // Toom-Cook (m = 2): C'_1 + C'_2 and C'_2 - C'_1 (2n points each)
   uint32_t nP;
   uint32_t n_draws;
+  uint32_t toom;              // 1: the multi-exponentiation diagonals use 4 evaluation points instead of 6 row products
 };
 
 struct VerifyLay {
@@ -215,6 +224,7 @@ static inline ProveLay make_prove_lay(uint32_t m, uint32_t n) {
   l.za0 = A(n); l.zbm = A(n); l.zr0 = A(1); l.zsm = A(1); l.zt = A(2 * m + 1); l.zd = A(2 * m + 1);
   l.svbp = A(n); l.svd = A(n); l.svrd = A(1); l.svdelta = A(n); l.svs1 = A(1); l.svsx = A(1); l.svv1 = A(n); l.svv2 = A(n);
   l.mea0 = A(n); l.mer0 = A(1); l.meb = A(2 * m); l.mes = A(2 * m); l.metau = A(2 * m);
+  l.tsp = A(n); l.tsm = A(n);
   l.x = A(1); l.y = A(1); l.z = A(1); l.hx = A(1); l.hy = A(1); l.zx = A(1); l.svx = A(1); l.mx = A(1);
   l.zabar = A(n); l.zbbar = A(n); l.zrbar = A(1); l.zsbar = A(1); l.ztbar = A(1);
   l.svat = A(n); l.svbt = A(n); l.svrt = A(1); l.svst = A(1);
@@ -225,6 +235,7 @@ static inline ProveLay make_prove_lay(uint32_t m, uint32_t n) {
   l.deck = Pn(2 * N); l.shuf = Pn(2 * N); l.cA = Pn(m); l.cB = Pn(m); l.cb = Pn(1); l.hB = Pn(m);
   l.zcA0 = Pn(1); l.zcBm = Pn(1); l.zcD = Pn(2 * m + 1); l.svcd = Pn(1); l.svcdelta = Pn(1); l.svcDelta = Pn(1);
   l.mecA0 = Pn(1); l.mecB = Pn(2 * m); l.meE = Pn(4 * m);
+  l.tDp = Pn(2 * n); l.tDm = Pn(2 * n);
   l.nP = p;
   return l;
 }
@@ -249,7 +260,8 @@ static inline std::vector<uint32_t> prove_draw_slots(const ProveLay& l) {
 
 struct ProvePlan {
   ProveLay lay;
-  Phase ph[4];          // A (cA), B (cB + multi-exp first message), C (product first messages), D (zero argument)
+  Phase ph[5];          // A (cA), B (cB + multi-exp first message), C (product first messages), D (zero argument),
+                        // [4] = A2: Toom-Cook base sums, run between A and B
   uint32_t nJ;          // J arena slots (nP + partial sums)
   std::vector<uint32_t> draws;
   std::vector<ProofElem> wire;
@@ -258,6 +270,7 @@ struct ProvePlan {
 static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk) {
   ProvePlan pl;
   pl.lay = make_prove_lay(m, n);
+  pl.lay.toom = (m == 2 && n <= vchunk) ? 1u : 0u;     // the V jobs must be single (un-chunked) var jobs
   const ProveLay& l = pl.lay;
   FixedBases fb{n};
   uint32_t next_partial = l.nP;
@@ -273,11 +286,61 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
     B.normalize(l.shuf, 2 * l.N);
     B.normalize(l.cA, m);
   }
+  if (pl.lay.toom) {  // phase A2 (m = 2): D+ = C'_1 + C'_2, D- = C'_2 - C'_1 (affine + affine, then normalised)
+    PhaseBuilder B(pl.ph[4], next_partial, fchunk, vchunk);
+    for (uint32_t t = 0; t < n; ++t)
+      for (uint32_t c = 0; c < 2; ++c) {
+        B.begin(l.tDp + 2 * t + c);
+        B.addend(l.shuf + 2 * t + c);
+        B.addend(l.shuf + 2 * (n + t) + c);
+        B.end();
+        B.begin(l.tDm + 2 * t + c);
+        B.addend(l.shuf + 2 * (n + t) + c);
+        B.addend(l.shuf + 2 * t + c, true);
+        B.end();
+      }
+    B.normalize(l.tDp, 4 * n);
+  }
   {  // phase B: c_B, multi-exponentiation first message
     PhaseBuilder B(pl.ph[1], next_partial, fchunk, vchunk);
     for (uint32_t k = 0; k < m; ++k) commit(B, l.cB + k, l.b + k * n, n, l.s + k);
     commit(B, l.mecA0, l.mea0, n, l.mer0);
     for (uint32_t k = 0; k < 2 * m; ++k) commit(B, l.mecB + k, l.meb + k, 1, l.mes + k);
+    const bool toom = pl.lay.toom != 0;
+    if (toom) {
+      // m = 2.  E(X) = (a0 + a1 X + a2 X^2)(C'_2 + C'_1 X): evaluate at 0, inf, 1, -1 with the scalars of the last two
+      // already halved (kernel scal1), then E_0 = V0, E_3 = Vinf, E_1 = V1h - Vm1h - Vinf, E_2 = V1h + Vm1h - V0:
+      // 4 row products of n terms per component instead of 6, same group elements.
+      for (uint32_t c = 0; c < 2; ++c) {
+        const uint32_t v0 = B.new_partial(), vinf = B.new_partial(), v1 = B.new_partial(), vm1 = B.new_partial();
+        B.begin(v0);
+        for (uint32_t t = 0; t < n; ++t) B.var(l.mea0 + t, l.shuf + 2 * (n + t) + c);          // a0 . C'_2
+        B.end();
+        B.begin(vinf);
+        for (uint32_t t = 0; t < n; ++t) B.var(l.b + n + t, l.shuf + 2 * t + c);               // a2 . C'_1
+        B.end();
+        B.begin(v1);
+        for (uint32_t t = 0; t < n; ++t) B.var(l.tsp + t, l.tDp + 2 * t + c);                  // (a0+a1+a2)/2 . (C'_1+C'_2)
+        B.end();
+        B.begin(vm1);
+        for (uint32_t t = 0; t < n; ++t) B.var(l.tsm + t, l.tDm + 2 * t + c);                  // (a0-a1+a2)/2 . (C'_2-C'_1)
+        B.end();
+        for (uint32_t k = 0; k < 4; ++k) {
+          B.begin(l.meE + 2 * k + c);
+          if (c == 0) {
+            B.fixed(l.metau + k, fb.G());
+          } else {
+            B.fixed(l.meb + k, fb.gen());
+            B.fixed(l.metau + k, fb.pk());
+          }
+          if (k == 0) B.addend_j(v0);
+          if (k == 3) B.addend_j(vinf);
+          if (k == 1) { B.addend_j(v1); B.addend_j(vm1, true); B.addend_j(vinf, true); }
+          if (k == 2) { B.addend_j(v1); B.addend_j(vm1); B.addend_j(v0, true); }
+          B.end();
+        }
+      }
+    } else {
     for (uint32_t k = 0; k < 2 * m; ++k) {
       for (uint32_t c = 0; c < 2; ++c) {
         B.begin(l.meE + 2 * k + c);
@@ -295,6 +358,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
         }
         B.end();
       }
+    }
     }
     B.normalize(l.cB, m);
     B.normalize(l.mecA0, 1 + 2 * m + 4 * m);

@@ -102,18 +102,66 @@ __device__ __forceinline__ void mul_l29(uint32_t r[9], const uint32_t a[9], cons
   r[8] = (uint32_t)c[17];
 }
 
+// l29 with the sparse-modulus reduction products done as shifts (no mads): m*P6 = (m<<22)+(m<<18), m*P8 = m<<19
+__device__ __forceinline__ void mul_l29s(uint32_t r[9], const uint32_t a[9], const uint32_t b[9]) {
+  const uint32_t MASK = (1u << 29) - 1;
+  uint64_t c[18];
+  #pragma unroll
+  for (int k = 0; k < 18; ++k) c[k] = 0;
+  #pragma unroll
+  for (int i = 0; i < 9; ++i)
+    #pragma unroll
+    for (int j = 0; j < 9; ++j) c[i + j] += (uint64_t)a[i] * b[j];
+  #pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    uint32_t m = (0u - (uint32_t)c[k]) & MASK;
+    uint64_t m64 = m;
+    asm volatile("" : "+v"(m64));     // keep the compiler from re-folding the shifts into a multiply
+    c[k] += m64;
+    c[k + 6] += (m64 << 22) + (m64 << 18);
+    c[k + 8] += m64 << 19;
+    c[k + 1] += c[k] >> 29;
+  }
+  #pragma unroll
+  for (int k = 9; k < 17; ++k) { r[k - 9] = (uint32_t)c[k] & MASK; c[k + 1] += c[k] >> 29; }
+  r[8] = (uint32_t)c[17];
+}
+// sqr with 45 products
+__device__ __forceinline__ void sqr_l29(uint32_t r[9], const uint32_t a[9]) {
+  const uint32_t MASK = (1u << 29) - 1, P6 = 17u << 18, P8 = 1u << 19;
+  uint64_t c[18]; uint32_t a2[9];
+  #pragma unroll
+  for (int i = 0; i < 9; ++i) a2[i] = a[i] << 1;
+  #pragma unroll
+  for (int k = 0; k < 18; ++k) c[k] = 0;
+  #pragma unroll
+  for (int i = 0; i < 9; ++i) { c[2*i] += (uint64_t)a[i]*a[i];
+    #pragma unroll
+    for (int j = i + 1; j < 9; ++j) c[i + j] += (uint64_t)a2[i] * a[j]; }
+  #pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    uint32_t m = (0u - (uint32_t)c[k]) & MASK;
+    c[k] += m; c[k + 6] += (uint64_t)m * P6; c[k + 8] += (uint64_t)m * P8; c[k + 1] += c[k] >> 29;
+  }
+  #pragma unroll
+  for (int k = 9; k < 17; ++k) { r[k - 9] = (uint32_t)c[k] & MASK; c[k + 1] += c[k] >> 29; }
+  r[8] = (uint32_t)c[17];
+}
+
 template<int V> __global__ void __launch_bounds__(256) k(const uint32_t* in, uint32_t* out, int iters) {
   uint32_t a[9], b[9];
   size_t tid = blockIdx.x * 256 + threadIdx.x;
   for (int i=0;i<9;i++){a[i]=in[(tid%1024)*18+i]; b[i]=in[(tid%1024)*18+9+i];}
-  if (V == 3) { for (int i=0;i<9;i++){a[i]&=(1u<<29)-1; b[i]&=(1u<<29)-1;} } else { a[7]&=0x07ffffff; b[7]&=0x07ffffff; }
+  if (V >= 3) { for (int i=0;i<9;i++){a[i]&=(1u<<29)-1; b[i]&=(1u<<29)-1;} } else { a[7]&=0x07ffffff; b[7]&=0x07ffffff; }
   #pragma unroll 1
   for (int it=0; it<iters; ++it) {
     uint32_t r[9];
     if (V==0) { Fe<StarkFq> x,y; for(int i=0;i<8;i++){x.v[i]=a[i];y.v[i]=b[i];} Fe<StarkFq> z=fe_mul<StarkFq>(x,y); for(int i=0;i<8;i++) r[i]=z.v[i]; }
     else if (V==1) mul_comba_asm(r,a,b);
     else if (V==2) mul_comba_grp(r,a,b);
-    else mul_l29(r,a,b);
+    else if (V==3) mul_l29(r,a,b);
+    else if (V==4) mul_l29s(r,a,b);
+    else { sqr_l29(r,a); for(int i=0;i<9;i++) r[i]^=b[i]&1; }
     for(int i=0;i<9;i++){a[i]=b[i]; b[i]=r[i];}
   }
   for (int i=0;i<9;i++) out[tid*9+i]=b[i];
@@ -133,7 +181,7 @@ int main(){
   CK(hipMemcpy(din,h,sizeof(h),hipMemcpyHostToDevice));
   uint32_t hout[36];
   for (int blocks : {1024, 4096}) {
-    run<0>("cios",din,dout,blocks,2000,hout); run<1>("comba_asm",din,dout,blocks,2000,hout); run<2>("comba_grp",din,dout,blocks,2000,hout); run<3>("l29",din,dout,blocks,2000,hout);
+    run<0>("cios",din,dout,blocks,2000,hout); run<1>("comba_asm",din,dout,blocks,2000,hout); run<2>("comba_grp",din,dout,blocks,2000,hout); run<3>("l29",din,dout,blocks,2000,hout); run<4>("l29_shift",din,dout,blocks,2000,hout); run<5>("l29_sqr",din,dout,blocks,2000,hout);
   }
   return 0;
 }
