@@ -98,8 +98,8 @@ struct Table : mp_table {
 
   int init(mp_ctx* c, uint32_t m_, uint32_t n_, const uint8_t* params, const uint8_t* pk, uint32_t fb_bits) {
     ctx = c;
-    if (fb_bits != 8 && fb_bits != 16) return fail(MP_ERR_BAD_ARGUMENT, "fixed-base window width must be 8 or 16 bits");
-    fbg = FbGeom{fb_bits, 256u / fb_bits, (1u << fb_bits) - 1u};
+    if (fb_bits != 8 && fb_bits != 16 && fb_bits != 20) return fail(MP_ERR_BAD_ARGUMENT, "fixed-base window width must be 8, 16 or 20 bits");
+    fbg = FbGeom{fb_bits, (256u + fb_bits - 1u) / fb_bits, (1u << fb_bits) - 1u};
     m = m_; n = n_; N = m * n;
     nwin = (uint32_t)vb_windows(R::BITS);
     FixedBases fb{n};
@@ -160,37 +160,42 @@ struct Table : mp_table {
 
   void build_fixed_tables(uint32_t nb) {
     rt::Stream s = ctx->stream;
-    DevBuf<uint32_t> WJ, W, EJ, scratch;
-    const size_t nwinpts = (size_t)nb * FB_WINDOWS, nent = nwinpts * FB_ENTRIES;
+    // narrow table first (h-bit windows: h = 8 for 8- and 16-bit tables, 10 for 20-bit tables), built by chains
+    const uint32_t h = fbg.bits == 8 ? 8u : fbg.bits / 2u;
+    const FbGeom gh{h, (256u + h - 1u) / h, (1u << h) - 1u};
+    DevBuf<uint32_t> WJ, W, EJ, scratch, Th;
+    const size_t nwinpts = (size_t)nb * gh.windows, nent = nwinpts * gh.entries;
     WJ.alloc(nwinpts * 24, s);
     W.alloc(nwinpts * 16, s);
     EJ.alloc(nent * 24, s);
     scratch.alloc(nent * 8, s);
-    FB.alloc(nent * 16, s);
-    FbWinArgs wa{fbpts.p, WJ.p};
+    Th.alloc(nent * 16, s);
+    FbWinArgs wa{fbpts.p, WJ.p, gh};
     MP_RUN(k_fb_windows, C, nb, 1, wa);
     normalize_flat(WJ.p, W.p, scratch.p, nwinpts);
-    FbFillArgs fa{W.p, EJ.p};
+    FbFillArgs fa{W.p, EJ.p, gh};
     MP_RUN(k_fb_fill, C, (uint32_t)nwinpts, 1, fa);
-    normalize_flat(EJ.p, FB.p, scratch.p, nent);
-    if (fbg.bits == 16) {
-      // widen: 16 windows x 65535 entries per base (2 GB at n = 26); the 8-bit table is only a stepping stone
-      rt::stream_sync(s);
-      const size_t nent16 = (size_t)nb * 16 * 65535;
-      DevBuf<uint32_t> EJ16, FB16, scratch16;
-      EJ16.alloc(nent16 * 24, s, false);
-      scratch16.alloc(nent16 * 8, s, false);
-      FB16.alloc(nent16 * 16, s, false);
-      FbWidenArgs wa16{FB.p, EJ16.p};
-      const size_t per = (size_t)1 << 26;                     // normalise in slices of 64 M points
-      MP_RUN(k_fb_widen, C, (uint32_t)nent16, 1, wa16);      // nb * 16 * 65535 < 2^32 threads for nb <= 4096
-      for (size_t off = 0; off < nent16; off += per) {
-        const size_t cnt = std::min(per, nent16 - off);
-        normalize_flat(EJ16.p + off * 24, FB16.p + off * 16, scratch16.p + off * 8, cnt);
-      }
-      rt::stream_sync(s);
-      std::swap(FB.p, FB16.p);
-      std::swap(FB.n, FB16.n);
+    normalize_flat(EJ.p, Th.p, scratch.p, nent);
+    rt::stream_sync(s);
+    if (fbg.bits == h) {
+      std::swap(FB.p, Th.p);
+      std::swap(FB.n, Th.n);
+      return;
+    }
+    // widen: windows of 2h bits; every entry is one affine + affine addition of two narrow entries
+    // (16-bit: 2 GB at n = 26; 20-bit: 27 GB -- sized for a 288 GB part)
+    const size_t nentw = (size_t)nb * fbg.windows * fbg.entries;
+    if (nentw >= ((size_t)1 << 32)) throw std::runtime_error("fixed-base table too large for one launch: use narrower windows");
+    DevBuf<uint32_t> EJw, scratchw;
+    EJw.alloc(nentw * 24, s, false);
+    scratchw.alloc(nentw * 8, s, false);
+    FB.alloc(nentw * 16, s, false);
+    FbWidenArgs ww{Th.p, EJw.p, gh, fbg};
+    MP_RUN(k_fb_widen, C, (uint32_t)nentw, 1, ww);
+    const size_t per = (size_t)1 << 26;                     // normalise in slices of 64 M points
+    for (size_t off = 0; off < nentw; off += per) {
+      const size_t cnt = std::min(per, nentw - off);
+      normalize_flat(EJw.p + off * 24, FB.p + off * 16, scratchw.p + off * 8, cnt);
     }
     rt::stream_sync(s);
   }

@@ -78,9 +78,9 @@ MP_HD size_t p_off(uint32_t slot, uint32_t Bpad, uint32_t b) { return ((size_t)s
 MP_HD size_t j_off(uint32_t slot, uint32_t Bpad, uint32_t b) { return ((size_t)slot * Bpad + b) * 24; }
 
 // ---- fixed-base MSM ---------------------------------------------------------------------------------
-// geometry of the fixed-base tables of a table context: `bits`-wide unsigned windows (8 or 16)
+// geometry of the fixed-base tables of a table context: `bits`-wide unsigned windows (8, 16 or 20)
 struct FbGeom {
-  uint32_t bits, windows, entries;   // windows = 256 / bits, entries = 2^bits - 1
+  uint32_t bits, windows, entries;   // windows = ceil(256 / bits), entries = 2^bits - 1
 };
 struct FixedArgs {
   const uint32_t* S;
@@ -94,10 +94,12 @@ struct FixedArgs {
 MP_HD const uint32_t* fb_entry(const uint32_t* FB, const FbGeom& g, uint32_t base, uint32_t w, uint32_t d) {
   return FB + (((size_t)base * g.windows + w) * g.entries + (d - 1)) * 16;
 }
-// window w of the canonical scalar k (bits divides 32)
+// window w of the canonical scalar k (bits <= 24; a window may straddle two words)
 MP_HD uint32_t fb_digit(const uint32_t k[8], const FbGeom& g, uint32_t w) {
-  const uint32_t bit = w * g.bits;
-  return (k[bit >> 5] >> (bit & 31)) & ((1u << g.bits) - 1u);
+  const uint32_t bit = w * g.bits, word = bit >> 5, off = bit & 31;
+  uint32_t v = k[word] >> off;
+  if (off + g.bits > 32 && word < 7) v |= k[word + 1] << (32 - off);
+  return v & ((1u << g.bits) - 1u);
 }
 template <class C>
 MP_HD void body_fixed_msm(const FixedArgs& a, uint32_t b, uint32_t y) {
@@ -382,51 +384,55 @@ MP_KERNEL(k_normalize, NormArgs, body_normalize)
 struct FbWinArgs {
   const uint32_t* bases;   // [nbases] affine
   uint32_t* WJ;            // [base][window] Jacobian
+  FbGeom g;
 };
 template <class C>
 MP_HD void body_fb_windows(const FbWinArgs& a, uint32_t x, uint32_t y) {
   Jac<C> acc = jac_from_aff<C>(ld_aff<C>(a.bases + (size_t)x * 16));
-  for (uint32_t w = 0; w < (uint32_t)FB_WINDOWS; ++w) {
-    st_jac<C>(a.WJ + ((size_t)x * FB_WINDOWS + w) * 24, acc);
-    for (int q = 0; q < FB_WINDOW_BITS; ++q) acc = jac_dbl<C>(acc);
+  for (uint32_t w = 0; w < a.g.windows; ++w) {
+    st_jac<C>(a.WJ + ((size_t)x * a.g.windows + w) * 24, acc);
+    for (uint32_t q = 0; q < a.g.bits; ++q) jac_dbl_ip<C>(acc);
   }
 }
 MP_KERNEL(k_fb_windows, FbWinArgs, body_fb_windows)
 // pass 2: entries e * W_w, e = 1..255 (thread = (base, window)), Jacobian out -> normalise
 struct FbFillArgs {
   const uint32_t* W;       // [base*window] affine
-  uint32_t* EJ;            // [base*window][255] Jacobian
+  uint32_t* EJ;            // [base*window][entries] Jacobian
+  FbGeom g;
 };
 template <class C>
 MP_HD void body_fb_fill(const FbFillArgs& a, uint32_t x, uint32_t y) {
   const Aff<C> w = ld_aff<C>(a.W + (size_t)x * 16);
   Jac<C> acc = jac_from_aff<C>(w);
-  uint32_t* out = a.EJ + (size_t)x * FB_ENTRIES * 24;
+  uint32_t* out = a.EJ + (size_t)x * a.g.entries * 24;
   st_jac<C>(out, acc);
-  acc = jac_dbl<C>(acc);
+  jac_dbl_ip<C>(acc);
   st_jac<C>(out + 24, acc);
-  for (uint32_t e = 2; e < (uint32_t)FB_ENTRIES; ++e) {
-    acc = jac_madd<C>(acc, w);
+  for (uint32_t e = 2; e < a.g.entries; ++e) {
+    jac_madd_ip<C>(acc, w);
     st_jac<C>(out + (size_t)e * 24, acc);
   }
 }
 MP_KERNEL(k_fb_fill, FbFillArgs, body_fb_fill)
 
-// pass 3 (16-bit windows only): entry d = hi * 256 + lo of 16-bit window w is T8[2w+1][hi] + T8[2w][lo]
-// (thread = (base * 16 + w) * 65535 + d - 1), Jacobian out -> normalise
+// pass 3 (wide windows): entry d = hi * 2^h + lo of the 2h-bit window w is Th[2w+1][hi] + Th[2w][lo], Th = the table
+// with h-bit windows (thread = (base * windows + w) * entries + d - 1), Jacobian out -> normalise
 struct FbWidenArgs {
-  const uint32_t* T8;      // [base][32][255] affine
-  uint32_t* EJ;            // [base][16][65535] Jacobian
+  const uint32_t* Th;      // [base][gh.windows][gh.entries] affine
+  uint32_t* EJ;            // [base][g.windows][g.entries] Jacobian
+  FbGeom gh, g;
 };
 template <class C>
 MP_HD void body_fb_widen(const FbWidenArgs& a, uint32_t x, uint32_t y) {
-  const uint32_t d = x % 65535u + 1u;
-  const uint32_t bw = x / 65535u;            // base * 16 + w
-  const uint32_t hi = d >> 8, lo = d & 255u;
-  const uint32_t* t8 = a.T8 + (size_t)bw * 2 * FB_ENTRIES * 16;   // window 2w of this base
+  const uint32_t d = x % a.g.entries + 1u;
+  const uint32_t bw = x / a.g.entries;           // base * g.windows + w
+  const uint32_t base = bw / a.g.windows, w = bw % a.g.windows;
+  const uint32_t hi = d >> a.gh.bits, lo = d & a.gh.entries;
+  const uint32_t* tlo = a.Th + ((size_t)base * a.gh.windows + 2 * w) * a.gh.entries * 16;
   Jac<C> acc = jac_inf<C>();
-  if (lo) acc = jac_from_aff<C>(ld_aff<C>(t8 + (size_t)(lo - 1) * 16));
-  if (hi) acc = jac_madd<C>(acc, ld_aff<C>(t8 + ((size_t)FB_ENTRIES + hi - 1) * 16));
+  if (lo) acc = jac_from_aff<C>(ld_aff<C>(tlo + (size_t)(lo - 1) * 16));
+  if (hi && 2 * w + 1 < a.gh.windows) jac_madd_ip<C>(acc, ld_aff<C>(tlo + ((size_t)a.gh.entries + hi - 1) * 16));
   st_jac<C>(a.EJ + (size_t)x * 24, acc);
 }
 MP_KERNEL(k_fb_widen, FbWidenArgs, body_fb_widen)

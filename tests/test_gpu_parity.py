@@ -88,10 +88,12 @@ def test_batch_matches_oracle(mp, engines, coracle, curve, m, n, B):
     assert all(o == mp.CryptoError("Hadamard Product (5.1)") for o in out)
 
 
-def test_wide_fixed_base_windows_match_oracle(mp, coracle):
-    """the throughput configuration of bench.py (16-bit fixed-base windows, 2 GB of tables) is bit-identical too"""
+@pytest.mark.parametrize("fb_bits", [16, 20])
+def test_wide_fixed_base_windows_match_oracle(mp, coracle, fb_bits):
+    """the throughput configurations (16-bit fixed-base windows: 2 GB of tables; 20-bit: 27 GB, what bench.py uses) are
+    bit-identical too"""
     cv, m, n, B = "stark", 2, 26, 4
-    cards = mp.DLCards(cv, device=0, fb_bits=16)
+    cards = mp.DLCards(cv, device=0, fb_bits=fb_bits)
     g0 = coracle.gen_inputs(cv, m, n, 100)
     pp = mp.Parameters(m, n, g0["params"])
     ins = [coracle.gen_inputs(cv, m, n, 700 + b) for b in range(B)]
