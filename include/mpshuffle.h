@@ -100,6 +100,10 @@ int mp_verify_shuffle_batch_dev(mp_table* t, size_t B, const void* d_decks, cons
                                 const void* d_proofs, void* d_status);
 int mp_sync(mp_ctx* ctx);
 int mp_reserve(mp_table* t, size_t B);           /* pre-allocate the batch workspace for B proofs */
+/* Every table holds two static work splits with identical results: a throughput plan (large sub-jobs, fewest operations)
+ * and a latency plan (small sub-jobs: ~16x more lanes per proof).  Batches of at most `B` proofs use the latency plan
+ * (default 512; 0 = always throughput). */
+int mp_set_latency_batch(mp_table* t, size_t B);
 
 /* ---- building blocks (host buffers) ------------------------------------------------------------------------
  * mp_remask_batch: out[i] = in[i] + (rho_i * G, rho_i * pk)        [REF remasking.rs:16-18]

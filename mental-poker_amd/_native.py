@@ -18,7 +18,7 @@ SYMBOLS = [
     "mp_ctx_create", "mp_ctx_destroy", "mp_last_error", "mp_check_name", "mp_proof_size", "mp_params_size",
     "mp_setup", "mp_table_create", "mp_table_create_ex", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
     "mp_shuffle_and_remask_batch", "mp_verify_shuffle_batch", "mp_shuffle_and_remask_batch_dev",
-    "mp_verify_shuffle_batch_dev", "mp_sync", "mp_reserve", "mp_remask_batch", "mp_msm", "mp_commit_batch",
+    "mp_verify_shuffle_batch_dev", "mp_sync", "mp_reserve", "mp_set_latency_batch", "mp_remask_batch", "mp_msm", "mp_commit_batch",
     "mp_profile_enable", "mp_profile_report", "mp_work_census", "mp_plan_stats", "mp_sigma_prove_batch",
     "mp_sigma_verify_batch", "mp_blake2s",
 ]
@@ -99,6 +99,7 @@ def bind(cdll):
     cdll.mp_verify_shuffle_batch_dev.argtypes = [c.c_void_p, c.c_size_t] + [c.c_void_p] * 4
     cdll.mp_sync.argtypes = [c.c_void_p]
     cdll.mp_reserve.argtypes = [c.c_void_p, c.c_size_t]
+    cdll.mp_set_latency_batch.argtypes = [c.c_void_p, c.c_size_t]
     cdll.mp_remask_batch.argtypes = [c.c_void_p, c.c_size_t, u8p, u8p, u8p]
     cdll.mp_msm.argtypes = [c.c_void_p, c.c_size_t, c.c_size_t, u8p, u8p, u8p]
     cdll.mp_commit_batch.argtypes = [c.c_void_p, c.c_size_t, c.c_size_t, u8p, u8p, u8p]
@@ -270,6 +271,9 @@ class Table:
         return bytes(out)
 
     # ---- device-pointer API (ints = HBM addresses, e.g. torch tensor .data_ptr())
+    def set_latency_batch(self, B):
+        self.eng._chk(self.lib.mp_set_latency_batch(self.h, B))
+
     def reserve(self, B):
         self.eng._chk(self.lib.mp_reserve(self.h, B))
 

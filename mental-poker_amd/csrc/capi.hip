@@ -103,6 +103,11 @@ int mp_table_create_ex(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* param
 }
 void mp_table_destroy(mp_table* t) { delete t; }
 
+int mp_set_latency_batch(mp_table* t, size_t B) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_latency_batch: null table");
+  t->set_latency_batch(B);
+  return MP_OK;
+}
 int mp_reserve(mp_table* t, size_t B) {
   if (!t || !B) return fail(MP_ERR_BAD_ARGUMENT, "mp_reserve: bad argument");
   MP_TRY

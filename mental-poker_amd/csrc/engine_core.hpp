@@ -73,11 +73,22 @@ struct Table : mp_table {
   typedef typename C::FqP F;
   typedef typename C::FrP R;
 
-  ProvePlan pplan;
-  VerifyPlan vplan;
-  PhaseDev pph[5], vph;
-  DevBuf<uint32_t> draws;
-  DevBuf<ProofElem> pwire, vwire;
+  // Two static plans per table: [0] throughput (large sub-jobs: fewest operations, one lane per job is fine when
+  // there are thousands of proofs) and [1] latency (small sub-jobs and table groups: ~16x more lanes per proof, used
+  // when the batch is too small to fill the chip otherwise).  Same results, different work split.
+  struct PlanSet {
+    ProvePlan pplan;
+    VerifyPlan vplan;
+    PhaseDev pph[5], vph;
+    DevBuf<uint32_t> draws;
+    DevBuf<ProofElem> pwire, vwire;
+    uint32_t table_group = TABLE_GROUP;
+  };
+  PlanSet ps[2];
+  uint32_t latency_batch = 512;                  // batches up to this size use the latency plan (mp_set_latency_batch)
+  PlanSet& pick(uint32_t B) { return ps[B <= latency_batch ? 1 : 0]; }
+  void set_latency_batch(size_t b) override { latency_batch = (uint32_t)std::min<size_t>(b, 0xFFFFFFFFu); }
+  uint32_t cur_table_group = TABLE_GROUP;
   DevBuf<uint32_t> fbpts;    // (n+5) affine base points
   DevBuf<uint32_t> FB;       // fixed-base window tables
   Workspace ws;
@@ -132,13 +143,17 @@ struct Table : mp_table {
     fbpts.upload(flat, s);
     build_fixed_tables(fb.count());
 
-    pplan = make_prove_plan(m, n, FCHUNK, VCHUNK);
-    vplan = make_verify_plan(m, n, FCHUNK, VCHUNK);
-    for (int i = 0; i < 5; ++i) pph[i].upload(pplan.ph[i], s);
-    vph.upload(vplan.ph, s);
-    draws.upload(pplan.draws, s);
-    pwire.upload(pplan.wire, s);
-    vwire.upload(vplan.wire, s);
+    for (int k = 0; k < 2; ++k) {
+      PlanSet& q = ps[k];
+      q.pplan = make_prove_plan(m, n, k ? 2u : FCHUNK, k ? 4u : VCHUNK);
+      q.vplan = make_verify_plan(m, n, k ? 2u : FCHUNK, k ? 4u : VCHUNK);
+      q.table_group = k ? 8u : TABLE_GROUP;
+      for (int i = 0; i < 5; ++i) q.pph[i].upload(q.pplan.ph[i], s);
+      q.vph.upload(q.vplan.ph, s);
+      q.draws.upload(q.pplan.draws, s);
+      q.pwire.upload(q.pplan.wire, s);
+      q.vwire.upload(q.vplan.wire, s);
+    }
     // Blake2s("Shuffle Proof")  [REF mod.rs:84]
     {
       Blake2sState st;
@@ -207,11 +222,12 @@ struct Table : mp_table {
   }
 
   void reserve(size_t B) override {
-    uint32_t nS = std::max(pplan.lay.nS, vplan.lay.nS), nP = std::max(pplan.lay.nP, vplan.lay.nP);
-    uint32_t nJ = std::max(pplan.nJ, vplan.nJ), nD = vph.n_dslots, nT = vph.n_tslots;
+    PlanSet& q = pick((uint32_t)B);
+    uint32_t nS = std::max(q.pplan.lay.nS, q.vplan.lay.nS), nP = std::max(q.pplan.lay.nP, q.vplan.lay.nP);
+    uint32_t nJ = std::max(q.pplan.nJ, q.vplan.nJ), nD = q.vph.n_dslots, nT = q.vph.n_tslots;
     for (int i = 0; i < 5; ++i) {
-      nD = std::max(nD, pph[i].n_dslots);
-      nT = std::max(nT, pph[i].n_tslots);
+      nD = std::max(nD, q.pph[i].n_dslots);
+      nT = std::max(nT, q.pph[i].n_tslots);
     }
     ws.ensure((uint32_t)B, nS, nP, nJ, nD, nT, nwin, stage_words_needed(), ctx->stream);
   }
@@ -223,8 +239,8 @@ struct Table : mp_table {
       MP_RUN(k_recode, C, B, ph.n_recode, a);
     }
     if (ph.n_tables) {
-      TableArgs a{w.P.p, w.T.p, w.NS.p, ph.tables.p, w.Bpad, ph.n_tables};
-      MP_RUN(k_table, C, B, (ph.n_tables + TABLE_GROUP - 1) / TABLE_GROUP, a);
+      TableArgs a{w.P.p, w.T.p, w.NS.p, ph.tables.p, w.Bpad, ph.n_tables, cur_table_group};
+      MP_RUN(k_table, C, B, (ph.n_tables + cur_table_group - 1) / cur_table_group, a);
     }
     if (ph.n_f) {
       FixedArgs a{w.S.p, w.J.p, FB.p, ph.fjobs.p, ph.fterms.p, w.Bpad, fbg};
@@ -260,7 +276,10 @@ struct Table : mp_table {
     const uint32_t B = (uint32_t)B_;
     reserve(B);
     Workspace& w = ws;
-    const ProveLay& l = pplan.lay;
+    PlanSet& q = pick(B);
+    cur_table_group = q.table_group;
+    const ProveLay& l = q.pplan.lay;
+    PhaseDev* pph = q.pph;
     rt::Stream s = ctx->stream;
     FixedBases fb{n};
     rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
@@ -269,7 +288,7 @@ struct Table : mp_table {
       MP_RUN(k_load_points, C, B, 2 * N, a);
       LoadScalarsArgs sa{rho, w.S.p, w.status.p, w.Bpad, N, l.rho};
       MP_RUN(k_load_scalars, C, B, N, sa);
-      ProveInitArgs ia{w.S.p, w.status.p, perm, seeds, draws.p, l, w.Bpad};
+      ProveInitArgs ia{w.S.p, w.status.p, perm, seeds, q.draws.p, l, w.Bpad};
       MP_RUN(k_prove_init, C, B, 1, ia);
       RemaskArgs ra{w.S.p, w.P.p, w.J.p, FB.p, perm, w.Bpad, N, l.rho, l.deck, l.shuf, fb.G(), fb.pk(), fbg};
       MP_RUN(k_remask, C, B, 2 * N, ra);
@@ -319,8 +338,8 @@ struct Table : mp_table {
     {
       StorePointsArgs a{out_decks, w.P.p, w.Bpad, 2 * N, l.shuf};
       MP_RUN(k_store_points, C, B, 2 * N, a);
-      ProofIoArgs pa{out_proofs, w.S.p, w.P.p, w.status.p, pwire.p, w.Bpad, (uint32_t)proof_size_bytes(m, n)};
-      MP_RUN(k_store_proof, C, B, (uint32_t)pplan.wire.size(), pa);
+      ProofIoArgs pa{out_proofs, w.S.p, w.P.p, w.status.p, q.pwire.p, w.Bpad, (uint32_t)proof_size_bytes(m, n)};
+      MP_RUN(k_store_proof, C, B, (uint32_t)q.pplan.wire.size(), pa);
     }
     rt::d2d(status, w.status.p, (size_t)B * 4, s);
   }
@@ -330,7 +349,9 @@ struct Table : mp_table {
     const uint32_t B = (uint32_t)B_;
     reserve(B);
     Workspace& w = ws;
-    const VerifyLay& l = vplan.lay;
+    PlanSet& q = pick(B);
+    cur_table_group = q.table_group;
+    const VerifyLay& l = q.vplan.lay;
     rt::Stream s = ctx->stream;
     rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
     {
@@ -338,18 +359,18 @@ struct Table : mp_table {
       MP_RUN(k_load_points, C, B, 2 * N, a);
       LoadPointsArgs b{shuf, w.P.p, w.status.p, w.Bpad, 2 * N, l.shuf};
       MP_RUN(k_load_points, C, B, 2 * N, b);
-      ProofIoArgs pa{const_cast<uint8_t*>(proofs), w.S.p, w.P.p, w.status.p, vwire.p, w.Bpad, (uint32_t)proof_size_bytes(m, n)};
-      MP_RUN(k_load_proof, C, B, (uint32_t)vplan.wire.size(), pa);
+      ProofIoArgs pa{const_cast<uint8_t*>(proofs), w.S.p, w.P.p, w.status.p, q.vwire.p, w.Bpad, (uint32_t)proof_size_bytes(m, n)};
+      MP_RUN(k_load_proof, C, B, (uint32_t)q.vplan.wire.size(), pa);
     }
     {
       VerifyFsArgs a{};
       a.st = statement_args(w, l.deck, l.shuf, l.cA, l.x);
       a.l = l;
       MP_RUN(k_verify_fs, C, B, 1, a);
-      VerifyScalArgs sa{w.S.p, w.P.p, w.direct.p, l, vplan.cm, w.Bpad};
+      VerifyScalArgs sa{w.S.p, w.P.p, w.direct.p, l, q.vplan.cm, w.Bpad};
       MP_RUN(k_verify_scal, C, B, 1, sa);
     }
-    run_phase(vph, w, B);
+    run_phase(q.vph, w, B);
     {
       VerdictArgs a{w.J.p, w.direct.p, w.status.p, w.Bpad, l.chk_first};
       MP_RUN(k_verdict, C, B, 1, a);
@@ -476,8 +497,8 @@ struct Table : mp_table {
       o[0] += ph.fterms.size(); o[1] += ph.vterms.size(); o[2] += ph.fjobs.size(); o[3] += ph.vjobs.size();
       o[4] += ph.tables.size(); o[5] += ph.cterms.size();
     };
-    for (int i = 0; i < 5; ++i) add(pplan.ph[i], out);
-    add(vplan.ph, out + 6);
+    for (int i = 0; i < 5; ++i) add(ps[0].pplan.ph[i], out);
+    add(ps[0].vplan.ph, out + 6);
     out[12] = nwin; out[13] = fbg.windows; out[14] = N;
   }
   // ---------------------------------------------------------------- sigma protocols
@@ -562,12 +583,12 @@ struct Table : mp_table {
       ops += ph.cterms.size();                                              // combines
     };
     uint64_t t = 0, o = 0;
-    for (int i = 0; i < 5; ++i) count(pplan.ph[i], t, o);
+    for (int i = 0; i < 5; ++i) count(ps[0].pplan.ph[i], t, o);
     t += 2 * N;
     o += (uint64_t)2 * N * (fbg.windows + 1);  // remask
     *pt = t; *po = o;
     t = 0; o = 0;
-    count(vplan.ph, t, o);
+    count(ps[0].vplan.ph, t, o);
     *vt = t; *vo = o;
   }
 };

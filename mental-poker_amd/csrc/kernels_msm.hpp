@@ -195,7 +195,7 @@ struct TableArgs {
   uint32_t* T;           // [tslot][entry][Bpad] affine
   uint32_t* scratch;     // [tslot][8][Bpad] field elements (prefix products)
   const Term* list;      // {P slot, table slot}; table slots are 0..n_tables-1 in list order
-  uint32_t Bpad, n_tables;
+  uint32_t Bpad, n_tables, group;   // group = bases per lane (<= TABLE_GROUP)
 };
 // operands of target multiple t (entry index t-1) in the round that starts at multiple e0+1 (e0 = 1, 2, 4, 8)
 MP_HD void table_operands(uint32_t t, uint32_t e0, uint32_t& ia, uint32_t& ib, bool& dbl) {
@@ -210,8 +210,8 @@ MP_HD void table_operands(uint32_t t, uint32_t e0, uint32_t& ia, uint32_t& ib, b
 template <class C>
 MP_HD void body_table(const TableArgs& a, uint32_t b, uint32_t y) {
   typedef typename C::FqP F;
-  const uint32_t g0 = y * TABLE_GROUP;
-  const uint32_t g1 = g0 + TABLE_GROUP < a.n_tables ? g0 + TABLE_GROUP : a.n_tables;
+  const uint32_t g0 = y * a.group;
+  const uint32_t g1 = g0 + a.group < a.n_tables ? g0 + a.group : a.n_tables;
   for (uint32_t g = g0; g < g1; ++g) {   // entry 0 = P
     const Term t = a.list[g];
     st_aff<C>(a.T + p_off(t.b * VB_ENTRIES, a.Bpad, b), ld_aff<C>(a.P + p_off(t.s, a.Bpad, b)));

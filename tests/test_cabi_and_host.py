@@ -74,10 +74,12 @@ def test_kernel_bodies_under_emulation_match_golden(emu, name):
     eng = emu(g["curve"])
     m, n = g["m"], g["n"]
     t = eng.table(m, n, bytes.fromhex(g["params"]), bytes.fromhex(g["pk"]))
-    deck, proof = t.shuffle_and_remask(bytes.fromhex(g["deck"]), bytes.fromhex(g["rho"]), g["perm"], bytes.fromhex(g["prover_seed"]))
-    assert deck.hex() == g["shuffled"]
-    assert proof.hex() == g["proof"]
-    assert t.verify_shuffle(bytes.fromhex(g["deck"]), deck, proof) == 0
+    for latency_batch in (512, 0):      # latency plan (small sub-jobs), then throughput plan (large sub-jobs, Toom-Cook for m = 2)
+        t.set_latency_batch(latency_batch)
+        deck, proof = t.shuffle_and_remask(bytes.fromhex(g["deck"]), bytes.fromhex(g["rho"]), g["perm"], bytes.fromhex(g["prover_seed"]))
+        assert deck.hex() == g["shuffled"]
+        assert proof.hex() == g["proof"]
+        assert t.verify_shuffle(bytes.fromhex(g["deck"]), deck, proof) == 0
     bad = bytearray(proof)
     bad[-1] ^= 0          # unchanged copy still verifies
     swapped = deck[128:256] + deck[0:128] + deck[256:]

@@ -60,11 +60,13 @@ def test_golden_vectors(mp, engines, path):
 
 @pytest.mark.parametrize("curve,m,n,B", [("stark", 2, 26, 6), ("stark", 4, 13, 5), ("stark", 6, 5, 3),
                                          ("bn254", 3, 5, 3), ("secp256k1", 2, 7, 3)])
-def test_batch_matches_oracle(mp, engines, coracle, curve, m, n, B):
+@pytest.mark.parametrize("plan", ["latency", "throughput"])
+def test_batch_matches_oracle(mp, engines, coracle, curve, m, n, B, plan):
     cards = engines(curve)
     g0 = coracle.gen_inputs(curve, m, n, 100)
     pp = mp.Parameters(m, n, g0["params"])
     pk = g0["pk"]
+    cards.table(pp, pk).set_latency_batch(512 if plan == "latency" else 0)
     ins = []
     for b in range(B):
         g = coracle.gen_inputs(curve, m, n, 200 + b)     # same draw order => same params? no: own params per seed
@@ -86,6 +88,7 @@ def test_batch_matches_oracle(mp, engines, coracle, curve, m, n, B):
     rot = shufs[1:] + shufs[:1]
     out = cards.verify_shuffle_batch(pp, pk, decks, rot, proofs)
     assert all(o == mp.CryptoError("Hadamard Product (5.1)") for o in out)
+    cards.table(pp, pk).set_latency_batch(512)
 
 
 @pytest.mark.parametrize("fb_bits", [16, 20])
@@ -296,7 +299,7 @@ def test_full_size_properties(mp, engines, coracle):
     """BASELINE size (52 cards, m=2, n=26), a few hundred proofs: every honest proof verifies, outputs do not
     depend on the position in the batch, a chain of dependent shuffles (deck_{j+1} = output_j) verifies, and
     spot proofs equal the oracle's."""
-    cv, m, n, B = "stark", 2, 26, 192
+    cv, m, n, B = "stark", 2, 26, 640      # > 512: the throughput plan
     N = m * n
     g = coracle.gen_inputs(cv, m, n, 31337)
     cards = engines(cv)
