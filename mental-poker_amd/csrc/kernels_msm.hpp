@@ -19,9 +19,6 @@
 namespace mp {
 
 // ---- arena access (16-byte vector loads/stores; arenas are 256-byte aligned, elements 32/64/96 B) ----
-struct U4 {
-  uint32_t a, b, c, d;
-};
 MP_HD void ld_words8(const uint32_t* p, uint32_t v[8]) {
   const uint4* q = reinterpret_cast<const uint4*>(p);
   uint4 lo = q[0], hi = q[1];

@@ -46,9 +46,7 @@ struct FixedBases {
   MP_HD uint32_t count() const { return n + 5; }
 };
 
-static const int FB_WINDOW_BITS = 8;     // fixed-base tables: 32 windows x 255 entries per base
-static const int FB_WINDOWS = 32;
-static const int FB_ENTRIES = 255;
+// fixed-base tables: window width is a property of the table context (FbGeom in kernels_msm.hpp: 8, 16 or 20 bits)
 static const int VB_WINDOW_BITS = 5;     // variable-base (Straus) signed windows: digits in [-15, 16]
 static const int VB_ENTRIES = 16;
 static inline int vb_windows(int scalar_bits) { return (scalar_bits + 1 + VB_WINDOW_BITS - 1) / VB_WINDOW_BITS; }
