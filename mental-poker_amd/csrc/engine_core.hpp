@@ -11,9 +11,9 @@ static const uint32_t VCHUNK = 64;    // variable-base terms per sub-job: the te
 static const uint32_t NORM_CHUNK = 64;   // points per Fermat inversion in k_normalize
 
 struct PhaseDev {
-  DevBuf<Term> recode, tables, fterms, vterms, cterms;
-  DevBuf<Job> fjobs, vjobs, cjobs;
-  uint32_t n_recode = 0, n_tables = 0, n_f = 0, n_v = 0, n_c = 0, n_tslots = 0, n_dslots = 0;
+  DevBuf<Term> recode, tables, fterms, vterms, cterms, cterms2;
+  DevBuf<Job> fjobs, vjobs, cjobs, cjobs2;
+  uint32_t n_recode = 0, n_tables = 0, n_f = 0, n_v = 0, n_c = 0, n_c2 = 0, n_tslots = 0, n_dslots = 0;
   std::vector<std::pair<uint32_t, uint32_t>> normalize;
   void upload(const Phase& ph, rt::Stream s) {
     recode.upload(ph.recode, s);
@@ -24,6 +24,9 @@ struct PhaseDev {
     fjobs.upload(ph.fjobs, s);
     vjobs.upload(ph.vjobs, s);
     cjobs.upload(ph.cjobs, s);
+    cterms2.upload(ph.cterms2, s);
+    cjobs2.upload(ph.cjobs2, s);
+    n_c2 = (uint32_t)ph.cjobs2.size();
     n_recode = (uint32_t)ph.recode.size();
     n_tables = (uint32_t)ph.tables.size();
     n_f = (uint32_t)ph.fjobs.size();
@@ -80,7 +83,8 @@ struct Table : mp_table {
     ProvePlan pplan;
     VerifyPlan vplan;
     PhaseDev pph[5], vph;
-    DevBuf<uint32_t> draws;
+    DevBuf<uint32_t> draws, lin_src;
+    DevBuf<LinJob> lin;
     DevBuf<ProofElem> pwire, vwire;
     uint32_t table_group = TABLE_GROUP;
   };
@@ -151,6 +155,8 @@ struct Table : mp_table {
       for (int i = 0; i < 5; ++i) q.pph[i].upload(q.pplan.ph[i], s);
       q.vph.upload(q.vplan.ph, s);
       q.draws.upload(q.pplan.draws, s);
+      q.lin.upload(q.pplan.lin, s);
+      q.lin_src.upload(q.pplan.lin_src, s);
       q.pwire.upload(q.pplan.wire, s);
       q.vwire.upload(q.vplan.wire, s);
     }
@@ -254,6 +260,10 @@ struct Table : mp_table {
       CombineArgs a{w.J.p, w.P.p, ph.cjobs.p, ph.cterms.p, w.Bpad};
       MP_RUN(k_combine, C, B, ph.n_c, a);
     }
+    if (ph.n_c2) {   // second stage: consumers of first-stage combine outputs
+      CombineArgs a{w.J.p, w.P.p, ph.cjobs2.p, ph.cterms2.p, w.Bpad};
+      MP_RUN(k_combine, C, B, ph.n_c2, a);
+    }
     for (auto& r : ph.normalize)
       normalize_flat(w.J.p + j_off(r.first, w.Bpad, 0), w.P.p + p_off(r.first, w.Bpad, 0), w.NS.p, (size_t)r.second * w.Bpad);
   }
@@ -294,12 +304,12 @@ struct Table : mp_table {
       MP_RUN(k_remask, C, B, 2 * N, ra);
     }
     run_phase(pph[0], w, B);
-    if (l.toom) run_phase(pph[4], w, B);
+    run_phase(pph[4], w, B);      // Toom-Cook / Karatsuba operand sums (empty when unused)
     {
       FsStatementArgs a = statement_args(w, l.deck, l.shuf, l.cA, l.x);
       MP_RUN(k_fs_round1, C, B, 1, a);
     }
-    ProveScalArgs sc{w.S.p, perm, l, w.Bpad};
+    ProveScalArgs sc{w.S.p, perm, l, w.Bpad, q.lin.p, q.lin_src.p, (uint32_t)q.pplan.lin.size()};
     MP_RUN(k_prove_scal1, C, B, 1, sc);
     run_phase(pph[1], w, B);
     const FsDev f{w.stage.p, w.seed.p, w.Bpad};
@@ -495,7 +505,7 @@ struct Table : mp_table {
     for (int i = 0; i < 16; ++i) out[i] = 0;
     auto add = [&](const Phase& ph, uint64_t* o) {
       o[0] += ph.fterms.size(); o[1] += ph.vterms.size(); o[2] += ph.fjobs.size(); o[3] += ph.vjobs.size();
-      o[4] += ph.tables.size(); o[5] += ph.cterms.size();
+      o[4] += ph.tables.size(); o[5] += ph.cterms.size() + ph.cterms2.size();
     };
     for (int i = 0; i < 5; ++i) add(ps[0].pplan.ph[i], out);
     add(ps[0].vplan.ph, out + 6);
@@ -580,7 +590,7 @@ struct Table : mp_table {
       ops += (uint64_t)ph.vterms.size() * nwin;                             // mixed additions
       ops += (uint64_t)ph.vjobs.size() * (nwin - 1) * VB_WINDOW_BITS;       // doublings
       ops += (uint64_t)ph.tables.size() * (VB_ENTRIES - 1);                 // table construction (affine additions)
-      ops += ph.cterms.size();                                              // combines
+      ops += ph.cterms.size() + ph.cterms2.size();                          // combines
     };
     uint64_t t = 0, o = 0;
     for (int i = 0; i < 5; ++i) count(ps[0].pplan.ph[i], t, o);

@@ -337,6 +337,9 @@ struct ProveScalArgs {
   const uint32_t* perm;
   ProveLay l;
   uint32_t Bpad;
+  const LinJob* lin;          // scalar-row sums of the Karatsuba plan (layout.hpp), evaluated at the end of scal1
+  const uint32_t* lin_src;
+  uint32_t n_lin;
 };
 #define MP_LD(slot) ld_fe<R>(a.S + s_off((slot), a.Bpad, b))
 #define MP_ST(slot, val) st_fe<R>(a.S + s_off((slot), a.Bpad, b), (val))
@@ -368,6 +371,14 @@ MP_HD void body_prove_scal1(const ProveScalArgs& a, uint32_t b, uint32_t y) {
       const Fe<R> e = fe_add<R>(a0, a2);
       MP_ST(l.tsp + j, fe_half<R>(fe_add<R>(e, a1)));
       MP_ST(l.tsm + j, fe_half<R>(fe_sub<R>(e, a1)));
+    }
+  }
+  for (uint32_t q = 0; q < a.n_lin; ++q) {   // m >= 3: sums of scalar rows (Karatsuba operands)
+    const LinJob lj = a.lin[q];
+    for (uint32_t j = 0; j < l.n; ++j) {
+      Fe<R> acc = MP_LD(a.lin_src[lj.begin] + j);
+      for (uint32_t i = 1; i < lj.count; ++i) acc = fe_add<R>(acc, MP_LD(a.lin_src[lj.begin + i] + j));
+      MP_ST(lj.dst + j, acc);
     }
   }
 }

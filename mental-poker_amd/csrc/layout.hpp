@@ -10,6 +10,7 @@
 // [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:409-415, 437-442]; naming follows
 // oracle/py/mp_oracle.py (transcript v1).
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <map>
 #include <stdexcept>
@@ -55,8 +56,8 @@ static inline int vb_windows(int scalar_bits) { return (scalar_bits + 1 + VB_WIN
 struct Phase {
   std::vector<Term> recode;   // {S slot, digit slot}
   std::vector<Term> tables;   // {P slot, table slot}
-  std::vector<Job> fjobs, vjobs, cjobs;
-  std::vector<Term> fterms, vterms, cterms;
+  std::vector<Job> fjobs, vjobs, cjobs, cjobs2;     // cjobs2: combine jobs that consume outputs of cjobs (run after them)
+  std::vector<Term> fterms, vterms, cterms, cterms2;
   std::vector<std::pair<uint32_t, uint32_t>> normalize;  // [first slot, count) J -> P
   uint32_t n_dslots = 0, n_tslots = 0;
 };
@@ -78,11 +79,11 @@ class PhaseBuilder {
     v_.push_back(Term{d, t});
   }
   void addend(uint32_t pslot, bool negate = false) { a_.push_back(AFF_FLAG | (negate ? NEG_FLAG : 0u) | pslot); }
-  // add (or subtract) a Jacobian result computed by an EARLIER kernel class of the same phase (a direct var / fixed
-  // job), never the output of another combine job of this phase
+  // add (or subtract) a Jacobian result of this phase: the output of a fixed / var job, or -- when the consuming msm is
+  // closed with end(late = true) -- the output of a first-stage combine job
   void addend_j(uint32_t jslot, bool negate = false) { a_.push_back((negate ? NEG_FLAG : 0u) | jslot); }
   uint32_t new_partial() { return next_partial_++; }
-  void end() {
+  void end(bool late = false) {
     size_t nf = (f_.size() + fchunk_ - 1) / fchunk_, nv = (v_.size() + vchunk_ - 1) / vchunk_;
     size_t pieces = nf + nv + a_.size();
     if (pieces == 0) throw std::logic_error("empty msm");
@@ -103,9 +104,11 @@ class PhaseBuilder {
       parts.push_back(out);
     }
     if (!direct) {
-      ph_.cjobs.push_back(Job{out_, (uint32_t)ph_.cterms.size(), (uint32_t)(parts.size() + a_.size())});
-      for (uint32_t p : parts) ph_.cterms.push_back(Term{p, 0});
-      for (uint32_t p : a_) ph_.cterms.push_back(Term{p, 0});
+      std::vector<Job>& cj = late ? ph_.cjobs2 : ph_.cjobs;
+      std::vector<Term>& ct = late ? ph_.cterms2 : ph_.cterms;
+      cj.push_back(Job{out_, (uint32_t)ct.size(), (uint32_t)(parts.size() + a_.size())});
+      for (uint32_t p : parts) ct.push_back(Term{p, 0});
+      for (uint32_t p : a_) ct.push_back(Term{p, 0});
     }
   }
   void normalize(uint32_t first, uint32_t count) {
@@ -256,8 +259,16 @@ static inline std::vector<uint32_t> prove_draw_slots(const ProveLay& l) {
   return d;
 }
 
+// scalar-vector sums needed by the Karatsuba evaluation of the multi-exponentiation diagonals (kernel scal1):
+// S[dst + t] = sum_{i < count} S[src[begin + i] + t], t < n
+struct LinJob {
+  uint32_t dst, begin, count;
+};
+
 struct ProvePlan {
   ProveLay lay;
+  std::vector<LinJob> lin;
+  std::vector<uint32_t> lin_src;
   Phase ph[5];          // A (cA), B (cB + multi-exp first message), C (product first messages), D (zero argument),
                         // [4] = A2: Toom-Cook base sums, run between A and B
   uint32_t nJ;          // J arena slots (nP + partial sums)
@@ -265,10 +276,124 @@ struct ProvePlan {
   std::vector<ProofElem> wire;
 };
 
+// ---- Karatsuba evaluation of E(X) = (sum_j a_j X^j) (sum_t c_t X^t), c_t = row (m - t) of the shuffled deck, whose
+// coefficients are the 2m diagonals E_k of the multi-exponentiation argument (Bayer-Groth section 4; the reference's
+// dependency uses the schoolbook m(m+1) row products, examples/parameter_selection.rs:3-5).  A "product" is a row MSM
+// <scalar vector, ciphertext vector>; Karatsuba only needs sums of scalar rows, sums of ciphertext rows and +-
+// combinations of the products, so the E_k come out as the same group elements with 13 products instead of 20 at m = 4,
+// 35 instead of 72 at m = 8.  Handles are sorted lists of original row indices (sums of disjoint row sets).
+struct KLeaf {
+  std::vector<uint32_t> a, c;
+  std::map<uint32_t, int> contrib;   // coefficient k -> +-1
+};
+typedef std::vector<std::vector<uint32_t>> KPoly;
+static inline std::vector<uint32_t> k_union(const std::vector<uint32_t>& x, const std::vector<uint32_t>& y) {
+  std::vector<uint32_t> r(x);
+  r.insert(r.end(), y.begin(), y.end());
+  std::sort(r.begin(), r.end());
+  return r;
+}
+static inline void k_append(std::vector<KLeaf>& dst, const std::vector<KLeaf>& src, uint32_t shift, int sign) {
+  for (const KLeaf& s : src) {
+    KLeaf t;
+    t.a = s.a;
+    t.c = s.c;
+    for (auto& kv : s.contrib) t.contrib[kv.first + shift] = sign * kv.second;
+    dst.push_back(t);
+  }
+}
+static inline std::vector<KLeaf> k_mul(const KPoly& A, const KPoly& C) {
+  std::vector<KLeaf> out;
+  if (A.empty() || C.empty()) return out;
+  if (A.size() == 1 || C.size() == 1) {
+    for (uint32_t j = 0; j < A.size(); ++j)
+      for (uint32_t t = 0; t < C.size(); ++t) {
+        KLeaf lf;
+        lf.a = A[j];
+        lf.c = C[t];
+        lf.contrib[j + t] = 1;
+        out.push_back(lf);
+      }
+    return out;
+  }
+  const uint32_t h = (uint32_t)(std::max(A.size(), C.size()) + 1) / 2;
+  const KPoly A0(A.begin(), A.begin() + std::min<size_t>(h, A.size())), A1(A.begin() + std::min<size_t>(h, A.size()), A.end());
+  const KPoly C0(C.begin(), C.begin() + std::min<size_t>(h, C.size())), C1(C.begin() + std::min<size_t>(h, C.size()), C.end());
+  if (A1.empty() || C1.empty()) {
+    k_append(out, k_mul(A0, C0), 0, 1);
+    if (!C1.empty()) k_append(out, k_mul(A0, C1), h, 1);
+    if (!A1.empty()) k_append(out, k_mul(A1, C0), h, 1);
+    return out;
+  }
+  KPoly As(A0), Cs(C0);
+  for (size_t i = 0; i < A1.size(); ++i) As[i] = k_union(A0[i], A1[i]);
+  for (size_t i = 0; i < C1.size(); ++i) Cs[i] = k_union(C0[i], C1[i]);
+  const std::vector<KLeaf> P0 = k_mul(A0, C0), P2 = k_mul(A1, C1), P1 = k_mul(As, Cs);
+  k_append(out, P0, 0, 1);
+  k_append(out, P2, 2 * h, 1);
+  k_append(out, P1, h, 1);
+  k_append(out, P0, h, -1);
+  k_append(out, P2, h, -1);
+  return out;
+}
+// merge leaves with identical operands
+static inline std::vector<KLeaf> k_merge(const std::vector<KLeaf>& in) {
+  std::map<std::pair<std::vector<uint32_t>, std::vector<uint32_t>>, std::map<uint32_t, int>> acc;
+  std::vector<std::pair<std::vector<uint32_t>, std::vector<uint32_t>>> order;
+  for (const KLeaf& lf : in) {
+    auto key = std::make_pair(lf.a, lf.c);
+    if (!acc.count(key)) order.push_back(key);
+    for (auto& kv : lf.contrib) acc[key][kv.first] += kv.second;
+  }
+  std::vector<KLeaf> out;
+  for (auto& key : order) {
+    KLeaf lf;
+    lf.a = key.first;
+    lf.c = key.second;
+    for (auto& kv : acc[key])
+      if (kv.second != 0) lf.contrib[kv.first] = kv.second;
+    if (!lf.contrib.empty()) out.push_back(lf);
+  }
+  return out;
+}
+
 static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk) {
   ProvePlan pl;
   pl.lay = make_prove_lay(m, n);
-  pl.lay.toom = (m == 2 && n <= vchunk) ? 1u : 0u;     // the V jobs must be single (un-chunked) var jobs
+  pl.lay.toom = m == 2 ? 1u : 0u;
+  const bool karatsuba = m >= 3;
+  // Karatsuba plan: leaves, operand vectors (new S / P slots appended to the layout)
+  std::vector<KLeaf> leaves;
+  std::map<std::vector<uint32_t>, uint32_t> svec, cvec;     // handle -> first S slot / first P slot
+  uint32_t kP0 = pl.lay.nP;
+  if (karatsuba) {
+    KPoly A, Cc;
+    for (uint32_t j = 0; j <= m; ++j) A.push_back({j});
+    for (uint32_t t = 0; t < m; ++t) Cc.push_back({m - t - 1});    // X^t <-> row m - t (0-based m - t - 1)
+    leaves = k_merge(k_mul(A, Cc));
+    for (const KLeaf& lf : leaves) {
+      for (auto& kv : lf.contrib)
+        if (kv.second > 8 || kv.second < -8) throw std::logic_error("Karatsuba: coefficient out of range");
+      if (!svec.count(lf.a)) {
+        if (lf.a.size() == 1) {
+          svec[lf.a] = lf.a[0] == 0 ? pl.lay.mea0 : pl.lay.b + (lf.a[0] - 1) * n;
+        } else {
+          svec[lf.a] = pl.lay.nS;
+          pl.lin.push_back(LinJob{pl.lay.nS, (uint32_t)pl.lin_src.size(), (uint32_t)lf.a.size()});
+          for (uint32_t j : lf.a) pl.lin_src.push_back(j == 0 ? pl.lay.mea0 : pl.lay.b + (j - 1) * n);
+          pl.lay.nS += n;
+        }
+      }
+      if (!cvec.count(lf.c)) {
+        if (lf.c.size() == 1) {
+          cvec[lf.c] = pl.lay.shuf + 2 * lf.c[0] * n;
+        } else {
+          cvec[lf.c] = pl.lay.nP;
+          pl.lay.nP += 2 * n;
+        }
+      }
+    }
+  }
   const ProveLay& l = pl.lay;
   FixedBases fb{n};
   uint32_t next_partial = l.nP;
@@ -298,6 +423,19 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
         B.end();
       }
     B.normalize(l.tDp, 4 * n);
+  }
+  if (karatsuba && l.nP > kP0) {  // phase A2 (m >= 3): sums of ciphertext rows used as Karatsuba operands
+    PhaseBuilder B(pl.ph[4], next_partial, fchunk, vchunk);
+    for (auto& kv : cvec) {
+      if (kv.first.size() == 1) continue;
+      for (uint32_t t = 0; t < n; ++t)
+        for (uint32_t c = 0; c < 2; ++c) {
+          B.begin(kv.second + 2 * t + c);
+          for (uint32_t r : kv.first) B.addend(l.shuf + 2 * (r * n + t) + c);
+          B.end();
+        }
+    }
+    B.normalize(kP0, l.nP - kP0);
   }
   {  // phase B: c_B, multi-exponentiation first message
     PhaseBuilder B(pl.ph[1], next_partial, fchunk, vchunk);
@@ -335,7 +473,34 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
           if (k == 3) B.addend_j(vinf);
           if (k == 1) { B.addend_j(v1); B.addend_j(vm1, true); B.addend_j(vinf, true); }
           if (k == 2) { B.addend_j(v1); B.addend_j(vm1); B.addend_j(v0, true); }
+          B.end(true);
+        }
+      }
+    } else if (karatsuba) {
+      for (uint32_t c = 0; c < 2; ++c) {
+        std::vector<uint32_t> part(leaves.size());
+        for (size_t i = 0; i < leaves.size(); ++i) {
+          part[i] = B.new_partial();
+          const uint32_t sv = svec[leaves[i].a], cv = cvec[leaves[i].c];
+          B.begin(part[i]);
+          for (uint32_t t = 0; t < n; ++t) B.var(sv + t, cv + 2 * t + c);
           B.end();
+        }
+        for (uint32_t k = 0; k < 2 * m; ++k) {
+          B.begin(l.meE + 2 * k + c);
+          if (c == 0) {
+            B.fixed(l.metau + k, fb.G());
+          } else {
+            B.fixed(l.meb + k, fb.gen());
+            B.fixed(l.metau + k, fb.pk());
+          }
+          for (size_t i = 0; i < leaves.size(); ++i) {
+            auto it = leaves[i].contrib.find(k);
+            if (it == leaves[i].contrib.end()) continue;
+            // merged leaves can carry a small integer coefficient: add the product that many times
+            for (int rep = 0; rep < (it->second < 0 ? -it->second : it->second); ++rep) B.addend_j(part[i], it->second < 0);
+          }
+          B.end(true);
         }
       }
     } else {
