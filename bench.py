@@ -100,11 +100,19 @@ def main():
     rank, world, local = dist_info()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    # test hooks (used to dry-run the N > 1 path on a single-GPU box): MP_BENCH_FORCE_DEVICE puts every rank on one GPU,
+    # MP_BENCH_BACKEND=gloo runs the (tiny, once-per-session) collectives on CPU tensors instead of RCCL
+    local = int(os.environ.get("MP_BENCH_FORCE_DEVICE", local))
+    backend = os.environ.get("MP_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    gpu = torch.device("cuda", local)
+    dev = gpu if backend == "nccl" else torch.device("cpu")      # device of the collective payloads
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=gpu)
+        else:
+            dist.init_process_group(backend)
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
@@ -135,11 +143,11 @@ def main():
     proof_bytes = table.proof_bytes
 
     # ---- synthetic inputs, resident in HBM
-    gen = torch.Generator(device=dev)
+    gen = torch.Generator(device=gpu)
     gen.manual_seed(1234 + rank)
 
     def rand_bytes(*shape):
-        return torch.randint(0, 256, shape, dtype=torch.uint8, device=dev, generator=gen)
+        return torch.randint(0, 256, shape, dtype=torch.uint8, device=gpu, generator=gen)
 
     def rand_factors():
         f = rand_bytes(B, N, 32)
@@ -147,15 +155,15 @@ def main():
         return f.contiguous()
 
     def rand_perms():
-        return torch.argsort(torch.rand(B, N, device=dev, generator=gen), dim=1).to(torch.int32).contiguous()
+        return torch.argsort(torch.rand(B, N, device=gpu, generator=gen), dim=1).to(torch.int32).contiguous()
 
-    base = torch.frombuffer(bytearray(base_deck), dtype=torch.uint8).to(dev)
+    base = torch.frombuffer(bytearray(base_deck), dtype=torch.uint8).to(gpu)
     decks0 = base.repeat(B, 1).contiguous()
-    decks = torch.empty(B, N * 128, dtype=torch.uint8, device=dev)
-    out_decks = torch.empty(B, N * 128, dtype=torch.uint8, device=dev)
-    out_proofs = torch.empty(B, proof_bytes, dtype=torch.uint8, device=dev)
-    st_p = torch.empty(B, dtype=torch.int32, device=dev)
-    st_v = torch.empty(B, dtype=torch.int32, device=dev)
+    decks = torch.empty(B, N * 128, dtype=torch.uint8, device=gpu)
+    out_decks = torch.empty(B, N * 128, dtype=torch.uint8, device=gpu)
+    out_proofs = torch.empty(B, proof_bytes, dtype=torch.uint8, device=gpu)
+    st_p = torch.empty(B, dtype=torch.int32, device=gpu)
+    st_v = torch.empty(B, dtype=torch.int32, device=gpu)
     torch.cuda.synchronize()
 
     def sl(t, i):
