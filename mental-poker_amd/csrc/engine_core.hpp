@@ -6,7 +6,7 @@
 
 namespace mp {
 
-static const uint32_t FCHUNK = 8;     // fixed-base terms per sub-job   (8 x 32 mixed additions)
+static const uint32_t FCHUNK = 8;     // fixed-base terms per sub-job (8 x 13..32 mixed additions, by window width)
 static const uint32_t VCHUNK = 64;    // variable-base terms per sub-job: the terms of a job share one 250-doubling chain
 static const uint32_t NORM_CHUNK = 64;   // points per Fermat inversion in k_normalize
 
@@ -333,6 +333,7 @@ struct Table : mp_table {
       MP_RUN(k_fs_round, C, B, 1, a);
     }
     MP_RUN(k_prove_scal3, C, B, 1, sc);
+    MP_RUN(k_prove_scal3d, C, B, 2 * m + 1, sc);
     run_phase(pph[3], w, B);
     {
       FsRoundArgs a{};

@@ -3,12 +3,12 @@
 // digits differ per lane) and every arena access is a contiguous run (slot-major arenas, layout.hpp).
 //
 //   body_fixed_msm   sum_t k_t * B_t over bases shared by the whole batch (commit key, G, pk, gen):
-//                    8-bit windows over precomputed tables -> 32 mixed additions per term, no doublings.
+//                    8/16/20-bit windows over precomputed tables -> 32/16/13 mixed additions per term, no doublings.
 //                    Replaces the Pedersen commits / ElGamal encrypt scalar-muls inside the reference's
 //                    prover and verifier [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:409-415,437-442]
 //   body_remask      out[i] = deck[pi(i)] + rho_i * (G, pk)          [REF mod.rs:388-395, remasking.rs:16-18]
 //   body_var_msm     sum_t k_t * P_t over per-proof bases (the decks, proof elements): Straus interleaving
-//                    with signed 5-bit windows over per-proof 16-entry affine tables (ark-ec's
+//                    with signed 5-bit windows over per-proof 16-entry affine tables (body_table; ark-ec's
 //                    VariableBaseMSM bucket method is hopeless at 26..52 terms on a SIMT machine:
 //                    SURVEY.md App. D), doubling chain shared by the terms of a job.
 //   body_table / body_recode / body_combine / body_normalize: their supporting passes.
