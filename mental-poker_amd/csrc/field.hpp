@@ -198,59 +198,76 @@ MP_HD void unpack29(const uint32_t w[8], uint32_t l[9]) {
     l[i] = i < 8 ? (x & M29) : x;
   }
 }
-// Montgomery product (R = 2^261): inputs with limbs < 2^29 and value < 4p, output < 2p with limbs < 2^29
+// Montgomery product (R = 2^261): inputs with limbs < 2^29 and value < 4p, output in (0, 2p) with limbs < 2^29.
+// Product scanning with ONE rolling accumulator and the subtractive reduction T - M p (M = T p^-1 mod R) + R p:
+//   column k:  acc += sum_{i+j=k} a_i b_j - sum_{i+j=k, j>=1} m_i p_j ;  m_k = acc p^-1 mod 2^29 ;  acc = (acc - m_k p_0) >> 29
+// The accumulator is signed (two's complement in a uint64_t; |acc| < 9 * 2^58 + 2^59 < 2^62).  For p = 1 (mod 2^29)
+// (STARK) m_k is just the low limb and the subtraction of m_k p_0 is the shift itself, so a column costs its mads, one
+// 64-bit shift and one mask: 99 mads + 38 other VALU instructions per product on gfx950 (was 90 + 94 with independent
+// column sums, a negation and a 64-bit add per column).  The kernels are bound by VALU issue slots, not by the mads alone
+// (DESIGN.md "instruction mix"), so the instruction count is what matters.  MP_CHAIN pins the association order
+// (mad addend = running accumulator); without it LLVM rebuilds independent column sums and adds the carries separately.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MP_CHAIN(x) asm("" : "+v"(x))
+MP_HD void mont_sub_step(uint64_t& acc, uint32_t m, uint32_t pj) {
+  uint32_t negp = 0u - pj;
+  asm("" : "+s"(negp));   // keeps it a v_mad_i64_i32 (one instruction) instead of a multiply/shift and a 64-bit subtract
+  acc = (uint64_t)((int64_t)acc + (int64_t)(int32_t)m * (int64_t)(int32_t)negp);
+}
+#else
+#define MP_CHAIN(x) ((void)0)
+MP_HD void mont_sub_step(uint64_t& acc, uint32_t m, uint32_t pj) { acc -= (uint64_t)m * pj; }
+#endif
+template <class P, bool SQR>
+MP_HD void mont29(uint32_t r[9], const uint32_t a[9], const uint32_t b[9]) {
+  constexpr uint32_t PINV = (0u - P::INV29) & M29;   // +p^-1 mod 2^29
+  uint32_t m[9], a2[9];
+  if (SQR) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a2[i] = a[i] << 1;
+  }
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 17; ++k) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int j = k - i;
+      if (j < 0 || j > 8) continue;
+      if (SQR) {
+        if (j < i) continue;
+        acc += (uint64_t)(i == j ? a[i] : a2[i]) * a[j];
+      } else {
+        acc += (uint64_t)a[i] * b[j];
+      }
+      MP_CHAIN(acc);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int j = k - i;
+      if (j < 1 || j > 8 || i >= k) continue;
+      if (P::MOD29[j] != 0) {
+        mont_sub_step(acc, m[i], P::MOD29[j]);
+        MP_CHAIN(acc);
+      }
+    }
+    if (k >= 9 && P::MOD29[k - 9] != 0) acc += P::MOD29[k - 9];   // + R p (limbs 0..7; limb 8 below)
+    if (k < 9) {
+      m[k] = ((uint32_t)acc * PINV) & M29;
+      if (P::MOD29[0] != 1) acc -= (uint64_t)m[k] * P::MOD29[0];
+    } else {
+      r[k - 9] = (uint32_t)acc & M29;
+    }
+    acc = (uint64_t)((int64_t)acc >> 29);
+  }
+  r[8] = (uint32_t)acc + P::MOD29[8];
+}
 template <class P>
 MP_HD void mul29(uint32_t r[9], const uint32_t a[9], const uint32_t b[9]) {
-  uint64_t c[18];
-#pragma unroll
-  for (int k = 0; k < 18; ++k) c[k] = 0;
-#pragma unroll
-  for (int i = 0; i < 9; ++i)
-#pragma unroll
-    for (int j = 0; j < 9; ++j) c[i + j] += (uint64_t)a[i] * b[j];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    const uint32_t m = ((uint32_t)c[k] * P::INV29) & M29;
-#pragma unroll
-    for (int i = 0; i < 9; ++i)
-      if (P::MOD29[i] != 0) c[k + i] += (uint64_t)m * P::MOD29[i];
-    c[k + 1] += c[k] >> 29;
-  }
-#pragma unroll
-  for (int k = 9; k < 17; ++k) {
-    r[k - 9] = (uint32_t)c[k] & M29;
-    c[k + 1] += c[k] >> 29;
-  }
-  r[8] = (uint32_t)c[17];
+  mont29<P, false>(r, a, b);
 }
 template <class P>
 MP_HD void sqr29(uint32_t r[9], const uint32_t a[9]) {
-  uint64_t c[18];
-  uint32_t a2[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) a2[i] = a[i] << 1;
-#pragma unroll
-  for (int k = 0; k < 18; ++k) c[k] = 0;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    c[2 * i] += (uint64_t)a[i] * a[i];
-#pragma unroll
-    for (int j = i + 1; j < 9; ++j) c[i + j] += (uint64_t)a2[i] * a[j];
-  }
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    const uint32_t m = ((uint32_t)c[k] * P::INV29) & M29;
-#pragma unroll
-    for (int i = 0; i < 9; ++i)
-      if (P::MOD29[i] != 0) c[k + i] += (uint64_t)m * P::MOD29[i];
-    c[k + 1] += c[k] >> 29;
-  }
-#pragma unroll
-  for (int k = 9; k < 17; ++k) {
-    r[k - 9] = (uint32_t)c[k] & M29;
-    c[k + 1] += c[k] >> 29;
-  }
-  r[8] = (uint32_t)c[17];
+  mont29<P, true>(r, a, a);
 }
 
 // =====================================================================================================

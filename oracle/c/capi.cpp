@@ -207,6 +207,38 @@ struct Api {
     return p.on_curve() ? 1 : 0;
   }
 
+  static int sigma_prove(uint32_t nb, const uint8_t* bases, const uint8_t* publics, const uint8_t* x, const uint8_t* fs_init,
+                         size_t fs_len, const uint8_t* seed, uint8_t* out) {
+    std::vector<Pt> g(nb), a(nb);
+    bool ok = true;
+    for (uint32_t i = 0; i < nb; ++i) {
+      ok &= S::pt_from_wire(bases + 64 * i, g[i]);
+      ok &= S::pt_from_wire(publics + 64 * i, a[i]);
+    }
+    Fr xs;
+    ok &= Fr::from_bytes(x, xs);
+    if (!ok) return -1;
+    auto pf = S::sigma_prove(g, a, xs, fs_init, fs_len, seed);
+    for (uint32_t i = 0; i < nb; ++i) S::pt_wire(pf.A[i], out + 64 * i);
+    pf.z.to_bytes(out + 64 * nb);
+    return 0;
+  }
+  static int sigma_verify(uint32_t nb, const uint8_t* bases, const uint8_t* publics, const uint8_t* proof, const uint8_t* fs_init,
+                          size_t fs_len) {
+    std::vector<Pt> g(nb), a(nb);
+    typename S::SigmaProof pf;
+    pf.A.resize(nb);
+    bool ok = true;
+    for (uint32_t i = 0; i < nb; ++i) {
+      ok &= S::pt_from_wire(bases + 64 * i, g[i]);
+      ok &= S::pt_from_wire(publics + 64 * i, a[i]);
+      ok &= S::pt_from_wire(proof + 64 * i, pf.A[i]);
+    }
+    ok &= Fr::from_bytes(proof + 64 * nb, pf.z);
+    if (!ok) return -1;
+    return S::sigma_verify(g, a, pf, fs_init, fs_len) ? 0 : (nb == 1 ? 5 : 6);
+  }
+
   // timed CPU baseline: `iters` prove+verify pairs on inputs gen_inputs(seed + it)
   static int bench(uint32_t m, uint32_t n, uint64_t seed, int iters, double* prove_s, double* verify_s) {
     const size_t N = (size_t)m * n;
@@ -275,6 +307,14 @@ int mpo_fs_challenges(int curve, const uint8_t* init, size_t init_len, const uin
 int mpo_on_curve(int curve, const uint8_t* pt) { DISPATCH(curve, on_curve(pt)); }
 int mpo_bench(int curve, uint32_t m, uint32_t n, uint64_t seed, int iters, double* prove_s, double* verify_s) {
   DISPATCH(curve, bench(m, n, seed, iters, prove_s, verify_s));
+}
+int mpo_sigma_prove(int curve, uint32_t nb, const uint8_t* bases, const uint8_t* publics, const uint8_t* x,
+                    const uint8_t* fs_init, size_t fs_len, const uint8_t* seed, uint8_t* out) {
+  DISPATCH(curve, sigma_prove(nb, bases, publics, x, fs_init, fs_len, seed, out));
+}
+int mpo_sigma_verify(int curve, uint32_t nb, const uint8_t* bases, const uint8_t* publics, const uint8_t* proof,
+                     const uint8_t* fs_init, size_t fs_len) {
+  DISPATCH(curve, sigma_verify(nb, bases, publics, proof, fs_init, fs_len));
 }
 void mpo_blake2s(const uint8_t* in, size_t len, uint8_t out[32]) { Blake2s::digest(in, len, out); }
 void mpo_chacha20_block(const uint8_t key[32], uint64_t counter, uint32_t out[16]) {

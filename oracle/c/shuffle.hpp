@@ -666,6 +666,46 @@ struct Shuffle {
     proof = prove(pp, pk, deck, out, perm, rho, prng);
   }
 
+  // ---------------------------------------------------------------- sigma protocols
+  // Schnorr identification (1 base) / Chaum-Pedersen DL equality (2 bases) behind
+  // DLCards::{prove,verify}_key_ownership, mask, remask, compute_reveal_token and their verifiers
+  // [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:132-357]; "sigma transcript v1" as frozen in
+  // oracle/py/mp_oracle.py: A_i = r g_i ; absorb(g.., a.., A..) ; c ; z = r + c x ; check z g_i == A_i + c a_i.
+  struct SigmaProof {
+    PtVec A;
+    Fr z;
+  };
+  static SigmaProof sigma_prove(const PtVec& bases, const PtVec& publics, const Fr& x, const uint8_t* fs_init,
+                                size_t fs_init_len, const uint8_t prover_seed[32]) {
+    ChaChaRng prng(prover_seed);
+    Fr r = field_rand<Fr>(prng);
+    SigmaProof pf;
+    for (auto& g : bases) pf.A.push_back(mul(r, g));
+    FsRng fs(fs_init, fs_init_len);
+    std::vector<uint8_t> buf;
+    pts_tobytes(bases, buf);
+    pts_tobytes(publics, buf);
+    pts_tobytes(pf.A, buf);
+    fs.absorb(buf);
+    Fr c = field_rand<Fr>(fs);
+    pf.z = r + c * x;
+    return pf;
+  }
+  static bool sigma_verify(const PtVec& bases, const PtVec& publics, const SigmaProof& pf, const uint8_t* fs_init,
+                           size_t fs_init_len) {
+    if (pf.A.size() != bases.size() || publics.size() != bases.size()) return false;
+    FsRng fs(fs_init, fs_init_len);
+    std::vector<uint8_t> buf;
+    pts_tobytes(bases, buf);
+    pts_tobytes(publics, buf);
+    pts_tobytes(pf.A, buf);
+    fs.absorb(buf);
+    Fr c = field_rand<Fr>(fs);
+    for (size_t i = 0; i < bases.size(); ++i)
+      if (mul(pf.z, bases[i]) != add(pf.A[i], mul(c, publics[i]))) return false;
+    return true;
+  }
+
   // ---------------------------------------------------------------- synthetic inputs
   static Params setup(uint32_t m, uint32_t n, ChaChaRng& rng) {
     Params pp;

@@ -9,6 +9,7 @@ _LIB = os.path.join(_HERE, "libmporacle.so")
 CURVE_IDS = {"stark": 0, "bn254": 1, "secp256k1": 2}
 CHECK_NAMES = {0: "Ok", 1: "Hadamard Product (5.1)", 2: "Zero Argument (5.2)",
                3: "Single Value Product (5.3)", 4: "Multi-Exponentiation Argument (4)"}
+CHECK_NAMES_ALL = {**CHECK_NAMES, 5: "Schnorr Identification", 6: "Chaum-Pedersen"}
 
 
 def build():
@@ -108,6 +109,20 @@ def fs_challenges(curve, init, absorb, count):
 
 def on_curve(curve, pt):
     return lib().mpo_on_curve(CURVE_IDS[curve], _in(pt))
+
+
+def sigma_prove(curve, nbases, bases, publics, x, fs_init, seed):
+    """Schnorr (1 base) / Chaum-Pedersen (2 bases) proof; fs_init = the bytes the FiatShamirRng is seeded from"""
+    out = _buf(64 * nbases + 32)
+    rc = lib().mpo_sigma_prove(CURVE_IDS[curve], nbases, _in(bases), _in(publics), _in(x), _in(fs_init),
+                               ctypes.c_size_t(len(fs_init)), _in(seed), out)
+    assert rc == 0, rc
+    return bytes(out)
+
+
+def sigma_verify(curve, nbases, bases, publics, proof, fs_init):
+    return lib().mpo_sigma_verify(CURVE_IDS[curve], nbases, _in(bases), _in(publics), _in(proof), _in(fs_init),
+                                  ctypes.c_size_t(len(fs_init)))
 
 
 def blake2s(data):

@@ -176,3 +176,24 @@ def test_c_oracle_rejects_bad_usage(coracle):
     pf = bytearray(bytes.fromhex(g["proof"]))
     pf[-32:] = b"\xff" * 32
     assert coracle.verify_shuffle("stark", 2, 3, gi["params"], gi["pk"], gi["deck"], bytes.fromhex(g["shuffled"]), bytes(pf)) < 0
+
+
+def test_sigma_oracles_agree(coracle):
+    """the C++ and the Python restatements of the sigma protocols agree byte for byte, on all curves"""
+    for cvn in ("stark", "bn254", "secp256k1"):
+        cv = po.CURVES[cvn]
+        rng = po.ChaCha20Rng(bytes(range(32)))
+        for nb, fs_init in ((1, po.KEY_OWN_RNG_SEED + b"player"), (2, po.REVEAL_RNG_SEED)):
+            x = po.fr_rand(cv, rng)
+            g = [po.pt_mul(cv, po.fr_rand(cv, rng), cv.G) for _ in range(nb)]
+            a = [po.pt_mul(cv, x, gi) for gi in g]
+            seed = bytes([nb]) * 32
+            exp = po.sigma_proof_bytes(po.sigma_prove(cv, g, a, x, fs_init, seed))
+            gb, ab = b"".join(po.pt_wire(p) for p in g), b"".join(po.pt_wire(p) for p in a)
+            got = coracle.sigma_prove(cvn, nb, gb, ab, po.fe_bytes(x), fs_init, seed)
+            assert got == exp
+            assert coracle.sigma_verify(cvn, nb, gb, ab, got, fs_init) == 0
+            bad = bytearray(got)
+            bad[-1] ^= 1
+            assert coracle.CHECK_NAMES_ALL[coracle.sigma_verify(cvn, nb, gb, ab, bytes(bad), fs_init)] == po.SIGMA_NAMES[nb]
+            assert coracle.sigma_verify(cvn, nb, gb, ab, got, fs_init + b"x") != 0
