@@ -29,11 +29,12 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "py")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 INT_MAD_PEAK_G = 18000.0       # v_mad_u64_u32 issue rate measured with tools/microbench/intrate.hip (Gmad/s)
-# exact v_mad_u64_u32 counts of the compiled STARK group law (llvm -S of jac_madd_ip / jac_dbl_ip / fe_mul / fe_sqr,
-# 9x29-bit limbs): product 90, square 54; mixed addition 8M+3S = 882, doubling 3M+6S = 594, batched-affine table entry
-# 5M+1S + 4/15 of 1/64 of an inversion (256S+45M) = 580, Jacobian+Jacobian addition 11M+5S = 1260, normalisation of
-# one point 6M+1S + 1/64 inversion = 870
-MADS = {"madd": 882, "dbl": 594, "aff": 580, "jac": 1260, "norm": 870}
+# exact 32x32+64 multiply-add counts (v_mad_u64_u32 + v_mad_i64_i32, the same quarter-rate pipe) of the compiled STARK
+# group law (llvm -S of jac_madd_ip / jac_dbl_ip / fe_mul / fe_sqr, 9x29-bit limbs, subtractive Montgomery reduction):
+# product 81 + 18 = 99, square 45 + 18 = 63; mixed addition 8M+3S = 981, doubling 3M+6S = 675, batched-affine table
+# entry 5M+1S + 4/15 of 1/64 of an inversion (256S+45M) = 644, Jacobian+Jacobian addition 11M+5S = 1404, normalisation
+# of one point 6M+1S + 1/64 inversion = 979
+MADS = {"madd": 981, "dbl": 675, "aff": 644, "jac": 1404, "norm": 979}
 
 
 # ---- distributed helpers (backend-agnostic: RCCL on GPUs, gloo in the CPU tests) -----------------------------
@@ -176,9 +177,16 @@ def main():
     # prime: B different random decks = re-encryptions of the base deck (untimed input generation)
     f0, p0, s0 = rand_factors(), rand_perms(), rand_bytes(B, 32)
     torch.cuda.synchronize()
+    for e in engines:
+        e.profile_enable(True)
     for i, t in enumerate(tables):
         t.shuffle_and_remask_batch_dev(Bs, sl(decks0, i), sl(f0, i), sl(p0, i), sl(s0, i), sl(decks, i), sl(out_proofs, i), sl(st_p, i))
     sync_all()
+    priming_launches = {}       # per-kernel launches of the untimed priming prove (tools/pmc_summary.py skips them)
+    for e in engines:
+        for k, (cnt, _) in e.profile_report().items():
+            priming_launches[k] = priming_launches.get(k, 0) + cnt
+        e.profile_enable(False)
     assert int(st_p.abs().sum().item()) == 0, "priming pass failed"
     factors, perms, seeds = rand_factors(), rand_perms(), rand_bytes(B, 32)
     torch.cuda.synchronize()
@@ -282,7 +290,7 @@ def main():
     # --pmc WRITE_SIZE in separate runs, gfx950 x2 correction applied to FETCH_SIZE), scaled to this batch
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["kernels"].get(dom_name)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01d_pmc_summary.json")))["kernels"].get(dom_name)
         if pmc and (m, n) == (2, 26):
             traffic = pmc["hbm_bytes_per_proof_per_step_corrected"] * B * args.steps / dom_count
     except (OSError, ValueError, KeyError):
@@ -297,9 +305,10 @@ def main():
                     "peak": INT_MAD_PEAK_G, "unit": "Gmad/s",
                     "frac": mads / (kernel_ms_total * 1e-3) / 1e9 / INT_MAD_PEAK_G,
                     "mads_per_proof": mads_per_proof,
-                    "note": "exact v_mad_u64_u32 count of the compiled group law x static plan; peak = 256 CU x 4 SIMD x 8 lanes/clk x 2.4 GHz = 19.7 T/s theoretical, 18 T/s measured (tools/microbench/intrate.hip)"},
+                    "note": "exact 32x32+64 mad count (v_mad_u64_u32 + v_mad_i64_i32) of the compiled group law x static plan; peak = 256 CU x 4 SIMD x 8 lanes/clk x 2.4 GHz = 19.7 T/s theoretical, 18 T/s measured (tools/microbench/intrate.hip)"},
         "whole_path_hbm_frac": (value * whole_path_bytes / 1e9 / HBM_PEAK_GBS) if whole_path_bytes else None,
         "kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
+        "kernel_launches": {k: v[0] for k, v in prof.items()}, "priming_launches": priming_launches,
     }
 
     # ---- CPU baseline: the oracle's C++ restatement (port), single thread, bounded sample
@@ -312,6 +321,25 @@ def main():
                "sample": "%d prove+verify pairs, %d-card deck (m=%d,n=%d), %s, single thread; prove %.1f ms verify %.1f ms each"
                          % (it, N, m, n, curve, 1e3 * t_p / it, 1e3 * t_v / it),
                "host_cores_available": os.cpu_count()}
+        # the same port on every host core, one independent proof stream per thread (the reference itself is
+        # single-threaded: BASELINE.md section 2); ctypes releases the GIL for the duration of the C call
+        from concurrent.futures import ThreadPoolExecutor
+        T = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        quota = None
+        try:                                   # cgroup v2 CPU quota of the container, if any ("max" = none)
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            quota = None if q == "max" else float(q) / float(per)
+        except (OSError, ValueError):
+            pass
+        T = max(1, min(T, 64, int(quota + 0.5) if quota else T))    # bounded: the leg must stay within seconds
+        it_mt = 8
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(T) as ex:
+            list(ex.map(lambda i: co.bench(curve, m, n, 1000 + i, it_mt), range(T)))
+        wall = time.perf_counter() - t0
+        cpu["all_cores"] = {"value": T * it_mt / wall, "unit": "proofs/s", "cores": T,
+                            "cgroup_cpu_quota": quota,
+                            "sample": "%d threads x %d prove+verify pairs, one proof stream per thread, %.1f s wall" % (T, it_mt, wall)}
 
     out = {
         "metric": "shuffle proofs/sec (prove+verify)", "value": value, "unit": "proofs/s",

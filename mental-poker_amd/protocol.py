@@ -85,6 +85,20 @@ class Parameters:
     def generator(self):           # el_gamal::Generator
         return self.raw[64 * (self.n + 2):]
 
+    # CanonicalSerialize / CanonicalDeserialize [REF src/lib.rs:52]; format: canonical.py
+    def serialize(self, curve):
+        from . import canonical
+        return canonical.parameters_serialize(curve, self.m, self.n, self.raw)
+
+    @classmethod
+    def deserialize(cls, curve, data):
+        from . import canonical
+        try:
+            m, n, raw = canonical.parameters_deserialize(curve, data)
+        except canonical.SerializationError as e:
+            raise CardProtocolError.io(str(e))
+        return cls(m, n, raw)
+
 
 def _scalar_bytes(vals):
     try:
@@ -108,6 +122,22 @@ class DLCards:
         try:
             return Parameters(m, n, self.engine.setup(m, n, rng_seed))
         except _native.NativeError as e:
+            raise CardProtocolError.io(str(e))
+
+    # -- proof.serialized_size() / serialize() of ZKProofShuffle [REF examples/parameter_selection.rs:95; src/lib.rs:71]
+    def proof_serialized_size(self, pp):
+        from . import canonical
+        return canonical.shuffle_proof_serialized_size(self.curve, pp.m, pp.n)
+
+    def serialize_proof(self, pp, proof):
+        from . import canonical
+        return canonical.shuffle_proof_serialize(self.curve, pp.m, pp.n, proof)
+
+    def deserialize_proof(self, pp, data):
+        from . import canonical
+        try:
+            return canonical.shuffle_proof_deserialize(self.curve, pp.m, pp.n, data)
+        except canonical.SerializationError as e:
             raise CardProtocolError.io(str(e))
 
     def table(self, pp, shared_key):

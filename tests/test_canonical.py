@@ -1,0 +1,86 @@
+"""arkworks-canonical (compressed) serialisation of the trait's associated types
+[REF barnett-smart-card-protocol/src/lib.rs:45-71] and serialized_size() [REF examples/parameter_selection.rs:95]."""
+import glob
+import importlib
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+can = importlib.import_module("mental-poker_amd.canonical")
+
+
+def test_survey_kat_stark_point():
+    # SURVEY.md Appendix B/C [CHECKED-HERE]: k*G on the STARK curve and its compressed encoding
+    x = 0x56a347111c423fb2deff8678925ded9c8ba03b0f577a589cef9f3d3936877c1
+    y = 0x2d58166ea0e2c7447739de2ba33a84aa8729176f2ee470c3c5b6526e8cae8c1
+    wire = x.to_bytes(32, "little") + y.to_bytes(32, "little")
+    enc = can.point_compress("stark", wire)
+    assert enc.hex() == "c1776893d3f3f9ce89a577f5b003bac8d9de258967f8ef2dfb23c41171346a05"
+    assert can.point_decompress("stark", enc) == wire
+    p = can.CURVE_FIELDS["stark"][0]
+    neg = x.to_bytes(32, "little") + (p - y).to_bytes(32, "little")
+    enc_neg = can.point_compress("stark", neg)
+    assert enc_neg[:-1] == enc[:-1] and enc_neg[-1] == enc[-1] | 0x80
+    assert can.point_decompress("stark", enc_neg) == neg
+
+
+def test_sizes():
+    assert [can.point_bytes(c) for c in ("stark", "bn254", "secp256k1")] == [32, 32, 33]
+    # (11m+8) points + (5n+9) scalars + one u64 per vector-valued element (11 of them)
+    assert can.shuffle_proof_serialized_size("stark", 2, 26) == 30 * 32 + 139 * 32 + 11 * 8
+    assert can.shuffle_proof_serialized_size("secp256k1", 3, 3) == 41 * 33 + 24 * 32 + 11 * 8
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "shuffle_*.json"))), ids=os.path.basename)
+def test_roundtrip_golden(path):
+    g = json.load(open(path))
+    cv, m, n = g["curve"], g["m"], g["n"]
+    params, deck, proof = bytes.fromhex(g["params"]), bytes.fromhex(g["shuffled"]), bytes.fromhex(g["proof"])
+    sp = can.parameters_serialize(cv, m, n, params)
+    assert len(sp) == 16 + 8 + (n + 3) * can.point_bytes(cv)
+    assert can.parameters_deserialize(cv, sp) == (m, n, params)
+    sd = can.deck_serialize(cv, deck)
+    assert len(sd) == 8 + 2 * m * n * can.point_bytes(cv)
+    assert can.deck_deserialize(cv, sd) == deck
+    assert can.masked_card_deserialize(cv, can.masked_card_serialize(cv, deck[:128])) == deck[:128]
+    sf = can.shuffle_proof_serialize(cv, m, n, proof)
+    assert len(sf) == can.shuffle_proof_serialized_size(cv, m, n)
+    assert can.shuffle_proof_deserialize(cv, m, n, sf) == proof
+    pk = bytes.fromhex(g["pk"])
+    assert can.point_decompress(cv, can.point_compress(cv, pk)) == pk
+
+
+def test_infinity_and_errors():
+    for cv in ("stark", "secp256k1"):
+        nb = can.point_bytes(cv)
+        inf = can.point_compress(cv, bytes(64))
+        assert inf == bytes(nb - 1) + b"\x40"
+        assert can.point_decompress(cv, inf) == bytes(64)
+        with pytest.raises(can.SerializationError):
+            can.point_decompress(cv, bytes(nb - 1) + b"\xc0")       # infinity with the sign flag
+        with pytest.raises(can.SerializationError):
+            can.point_decompress(cv, bytes(nb - 1))                 # short
+    # x = 5 is not on the STARK curve unless 5^3 + 5 + b is a square: find a non-residue x
+    p, a, b, _ = can.CURVE_FIELDS["stark"]
+    x = next(x for x in range(2, 50) if pow((x ** 3 + a * x + b) % p, (p - 1) // 2, p) != 1)
+    with pytest.raises(can.SerializationError):
+        can.point_decompress("stark", x.to_bytes(32, "little"))
+    with pytest.raises(can.SerializationError):
+        can.point_decompress("stark", p.to_bytes(32, "little"))     # x >= p
+    with pytest.raises(can.SerializationError):
+        can.deck_deserialize("stark", (3).to_bytes(8, "little") + bytes(64))
+    with pytest.raises(can.SerializationError):
+        can.shuffle_proof_serialize("stark", 2, 26, bytes(10))
+
+
+def test_parameters_mirror_roundtrip():
+    mp = importlib.import_module("mental-poker_amd")
+    g = json.load(open(os.path.join(GOLDEN, "shuffle_stark_m2_n3_s1.json")))
+    pp = mp.Parameters(g["m"], g["n"], bytes.fromhex(g["params"]))
+    back = mp.Parameters.deserialize("stark", pp.serialize("stark"))
+    assert (back.m, back.n, back.raw) == (pp.m, pp.n, pp.raw)
+    with pytest.raises(mp.CardProtocolError):
+        mp.Parameters.deserialize("stark", pp.serialize("stark")[:-1])
