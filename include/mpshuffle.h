@@ -19,8 +19,9 @@
  *     (MP_ERR_*; text via mp_last_error);
  *   - wire encodings ("mpshuffle wire v1"):
  *       scalar (Fr)      32 B little-endian canonical integer, must be < group order
- *       point            64 B: x LE || y LE (canonical, affine); point at infinity = 64 zero bytes
- *       ciphertext/card  128 B: c0 || c1                                  (el_gamal::Ciphertext(pub Affine, pub Affine))
+ *       point            mp_point_size(curve) B: x LE || y LE (canonical, affine), 8 bytes per ark-ff limb of the base
+ *                        field: 64 B on the 256-bit curves, 96 B on BLS12-377; point at infinity = all-zero bytes
+ *       ciphertext/card  two points: c0 || c1                             (el_gamal::Ciphertext(pub Affine, pub Affine))
  *       deck             N ciphertexts back to back, N = m*n
  *       parameters       (n+3) points: G | ck_0 .. ck_{n-1} | H | gen     (enc generator, Pedersen key, extra generator)
  *       permutation      N uint32, out[i] = in[perm[i]]                   (Permutation::permute_array)
@@ -43,6 +44,7 @@ extern "C" {
 #define MP_CURVE_STARK 0      /* starknet_curve::Projective: every reference test + examples/round.rs */
 #define MP_CURVE_BN254 1
 #define MP_CURVE_SECP256K1 2
+#define MP_CURVE_BLS12_377 3  /* ark_bls12_377::G1Projective: examples/parameter_selection.rs [REF :25] (377-bit base field) */
 
 #define MP_OK 0
 #define MP_ERR_BAD_ENCODING (-1)     /* non-canonical scalar / coordinate, point not on the curve */
@@ -59,8 +61,11 @@ int mp_ctx_create(int curve_id, int device, mp_ctx** out);
 void mp_ctx_destroy(mp_ctx* ctx);
 const char* mp_last_error(void);                 /* thread-local text of the last error */
 const char* mp_check_name(int code);             /* "Ok", "Hadamard Product (5.1)", ... */
-size_t mp_proof_size(uint32_t m, uint32_t n);    /* (11m+8) points + (5n+9) scalars */
+size_t mp_proof_size(uint32_t m, uint32_t n);    /* (11m+8) points + (5n+9) scalars, 64-byte points (the 256-bit curves) */
 size_t mp_params_size(uint32_t n);               /* (n+3) * 64 */
+size_t mp_point_size(int curve_id);                              /* wire bytes of one point: 64, or 96 on MP_CURVE_BLS12_377 */
+size_t mp_proof_size_curve(int curve_id, uint32_t m, uint32_t n); /* same counts with mp_point_size(curve_id) per point */
+size_t mp_params_size_curve(int curve_id, uint32_t n);            /* (n+3) * mp_point_size(curve_id) */
 
 /* ---- DLCards::setup -----------------------------------------------------------------------------------
  * Derives G, ck_0..ck_{n-1}, H, gen = k * G_std with k = Fr::rand(ChaCha20Rng::from_seed(seed)) in that order. */

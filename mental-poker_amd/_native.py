@@ -11,11 +11,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmpshuffle.so")
 ROOT = os.path.dirname(HERE)
 
-CURVE_IDS = {"stark": 0, "bn254": 1, "secp256k1": 2}
+CURVE_IDS = {"stark": 0, "bn254": 1, "secp256k1": 2, "bls12_377": 3}
 MP_ERR_BAD_ENCODING, MP_ERR_BAD_PERMUTATION, MP_ERR_BAD_ARGUMENT, MP_ERR_NO_DEVICE, MP_ERR_INTERNAL = -1, -2, -3, -4, -5
 
 SYMBOLS = [
     "mp_ctx_create", "mp_ctx_destroy", "mp_last_error", "mp_check_name", "mp_proof_size", "mp_params_size",
+    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve",
     "mp_setup", "mp_table_create", "mp_table_create_ex", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
     "mp_shuffle_and_remask_batch", "mp_verify_shuffle_batch", "mp_shuffle_and_remask_batch_dev",
     "mp_verify_shuffle_batch_dev", "mp_sync", "mp_reserve", "mp_set_latency_batch", "mp_remask_batch", "mp_msm", "mp_commit_batch",
@@ -34,7 +35,7 @@ class NoDeviceError(NativeError):
     pass
 
 
-SOURCES = ["capi.hip", "curve_stark.hip", "curve_bn254.hip", "curve_secp256k1.hip"]
+SOURCES = ["capi.hip", "curve_stark.hip", "curve_bn254.hip", "curve_secp256k1.hip", "curve_bls12_377.hip"]
 
 
 def build(verbose=False):
@@ -86,6 +87,12 @@ def bind(cdll):
     cdll.mp_proof_size.restype = c.c_size_t
     cdll.mp_params_size.argtypes = [c.c_uint32]
     cdll.mp_params_size.restype = c.c_size_t
+    cdll.mp_point_size.argtypes = [c.c_int]
+    cdll.mp_point_size.restype = c.c_size_t
+    cdll.mp_proof_size_curve.argtypes = [c.c_int, c.c_uint32, c.c_uint32]
+    cdll.mp_proof_size_curve.restype = c.c_size_t
+    cdll.mp_params_size_curve.argtypes = [c.c_int, c.c_uint32]
+    cdll.mp_params_size_curve.restype = c.c_size_t
     cdll.mp_setup.argtypes = [c.c_void_p, c.c_uint32, c.c_uint32, u8p, u8p]
     cdll.mp_table_create.argtypes = [c.c_void_p, c.c_uint32, c.c_uint32, u8p, u8p, c.POINTER(c.c_void_p)]
     cdll.mp_table_create_ex.argtypes = [c.c_void_p, c.c_uint32, c.c_uint32, u8p, u8p, c.c_uint32, c.POINTER(c.c_void_p)]
@@ -144,6 +151,7 @@ class Engine:
             text = self.lib.mp_last_error().decode()
             raise (NoDeviceError if rc == MP_ERR_NO_DEVICE else NativeError)(rc, text)
         self.h = h
+        self.point_bytes = self.lib.mp_point_size(CURVE_IDS[curve])     # 64; 96 on bls12_377
 
     def close(self):
         if getattr(self, "h", None):
@@ -165,7 +173,7 @@ class Engine:
         return self.lib.mp_check_name(code).decode()
 
     def proof_size(self, m, n):
-        return self.lib.mp_proof_size(m, n)
+        return self.lib.mp_proof_size_curve(CURVE_IDS[self.curve], m, n)
 
     def blake2s(self, data):
         out = (ctypes.c_uint8 * 32)()
@@ -173,7 +181,7 @@ class Engine:
         return bytes(out)
 
     def setup(self, m, n, seed):
-        out = (ctypes.c_uint8 * self.lib.mp_params_size(n))()
+        out = (ctypes.c_uint8 * self.lib.mp_params_size_curve(CURVE_IDS[self.curve], n))()
         self._chk(self.lib.mp_setup(self.h, m, n, _in(seed), out))
         return bytes(out)
 
@@ -203,12 +211,14 @@ class Table:
         self.eng, self.lib, self.m, self.n, self.N = eng, eng.lib, m, n, m * n
         self.fb_bits = fb_bits
         self.params, self.shared_key = bytes(params), bytes(shared_key)
-        if len(self.params) != 64 * (n + 3) or len(self.shared_key) != 64:
+        self.pb = eng.point_bytes
+        self.cb = 2 * eng.point_bytes       # bytes of one card (ciphertext)
+        if len(self.params) != self.pb * (n + 3) or len(self.shared_key) != self.pb:
             raise NativeError(MP_ERR_BAD_ARGUMENT, "parameters / shared key have the wrong length")
         h = ctypes.c_void_p()
         eng._chk(self.lib.mp_table_create_ex(eng.h, m, n, _in(self.params), _in(self.shared_key), fb_bits, ctypes.byref(h)))
         self.h = h
-        self.proof_bytes = self.lib.mp_proof_size(m, n)
+        self.proof_bytes = eng.proof_size(m, n)
 
     def close(self):
         if getattr(self, "h", None):
@@ -226,8 +236,8 @@ class Table:
         """B proofs; decks: B*N*128 bytes, factors: B*N*32, perms: list of B*N ints, seeds: B*32 -> (decks, proofs, status)"""
         B = len(seeds) // 32
         N = self.N
-        assert len(decks) == B * N * 128 and len(factors) == B * N * 32 and len(perms) == B * N
-        out_d = (ctypes.c_uint8 * (B * N * 128))()
+        assert len(decks) == B * N * self.cb and len(factors) == B * N * 32 and len(perms) == B * N
+        out_d = (ctypes.c_uint8 * (B * N * self.cb))()
         out_p = (ctypes.c_uint8 * (B * self.proof_bytes))()
         st = (ctypes.c_int32 * B)()
         pm = (ctypes.c_uint32 * (B * N))(*perms)
@@ -236,14 +246,14 @@ class Table:
 
     def verify_shuffle_batch(self, decks, shuffled, proofs):
         N = self.N
-        B = len(decks) // (N * 128)
+        B = len(decks) // (N * self.cb)
         assert len(shuffled) == len(decks) and len(proofs) == B * self.proof_bytes
         st = (ctypes.c_int32 * B)()
         self.eng._chk(self.lib.mp_verify_shuffle_batch(self.h, B, _in(decks), _in(shuffled), _in(proofs), st))
         return list(st)
 
     def shuffle_and_remask(self, deck, factors, perm, seed):
-        out_d = (ctypes.c_uint8 * (self.N * 128))()
+        out_d = (ctypes.c_uint8 * (self.N * self.cb))()
         out_p = (ctypes.c_uint8 * self.proof_bytes)()
         pm = (ctypes.c_uint32 * self.N)(*perm)
         rc = self.lib.mp_shuffle_and_remask(self.h, _in(deck), _in(factors), pm, _in(seed), out_d, out_p)
@@ -255,18 +265,18 @@ class Table:
         return self.eng._chk(rc)
 
     def remask_batch(self, cards, factors):
-        count = len(cards) // 128
-        out = (ctypes.c_uint8 * (count * 128))()
+        count = len(cards) // self.cb
+        out = (ctypes.c_uint8 * (count * self.cb))()
         self.eng._chk(self.lib.mp_remask_batch(self.h, count, _in(cards), _in(factors), out))
         return bytes(out)
 
     def msm(self, n_msm, k, scalars, points):
-        out = (ctypes.c_uint8 * (n_msm * 64))()
+        out = (ctypes.c_uint8 * (n_msm * self.pb))()
         self.eng._chk(self.lib.mp_msm(self.h, n_msm, k, _in(scalars), _in(points), out))
         return bytes(out)
 
     def commit_batch(self, count, length, values, r):
-        out = (ctypes.c_uint8 * (count * 64))()
+        out = (ctypes.c_uint8 * (count * self.pb))()
         self.eng._chk(self.lib.mp_commit_batch(self.h, count, length, _in(values), _in(r), out))
         return bytes(out)
 
@@ -285,14 +295,14 @@ class Table:
 
     def sigma_prove_batch(self, nbases, bases, publics, witness, fs_init, seeds):
         B = len(witness) // 32
-        out = (ctypes.c_uint8 * (B * (nbases * 64 + 32)))()
+        out = (ctypes.c_uint8 * (B * (nbases * self.pb + 32)))()
         st = (ctypes.c_int32 * B)()
         self.eng._chk(self.lib.mp_sigma_prove_batch(self.h, B, nbases, _in(bases), _in(publics), _in(witness), _in(fs_init),
                                                     _in(seeds), out, st))
         return bytes(out), list(st)
 
     def sigma_verify_batch(self, nbases, bases, publics, proofs, fs_init):
-        B = len(proofs) // (nbases * 64 + 32)
+        B = len(proofs) // (nbases * self.pb + 32)
         st = (ctypes.c_int32 * B)()
         self.eng._chk(self.lib.mp_sigma_verify_batch(self.h, B, nbases, _in(bases), _in(publics), _in(proofs), _in(fs_init), st))
         return list(st)

@@ -5,7 +5,7 @@ engine's own boundary stays the fixed-width "wire v1" of include/mpshuffle.h (x 
 
 Rules (ark-serialize 0.3, short-Weierstrass affine, compressed):
   * Fr            -> 32 bytes little-endian canonical integer
-  * affine point  -> x little-endian in ceil((modulus_bits + 2) / 8) bytes; the two top bits of the last byte are flags:
+  * affine point  -> x little-endian in ceil((modulus_bits + 2) / 8) bytes (48 B on BLS12-377 G1); the two top bits of the last byte are flags:
                      bit 7 = (y > -y as canonical integers), bit 6 = point at infinity (then x = 0)
                      => 32 B for STARK (252-bit) and bn254 (254-bit), 33 B for secp256k1 (256-bit)
   * Vec<T>        -> u64 little-endian length, then the elements;  usize -> u64 little-endian
@@ -26,6 +26,7 @@ CURVE_FIELDS = {
     "stark": (2**251 + 17 * 2**192 + 1, 1, 0x06f21413efbe40de150e596d72f7a8c5609ad26c15c915c1f4cdfcb99cee9e89, 252),
     "bn254": (0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47, 0, 3, 254),
     "secp256k1": (2**256 - 2**32 - 977, 0, 7, 256),
+    "bls12_377": (0x01ae3a4617c510eac63b05c06ca1493b1a22d9f300f5138f1ef3622fba094800170b5d44300000008508c00000000001, 0, 1, 377),
 }
 SCALAR_BYTES = 32
 
@@ -35,7 +36,17 @@ class SerializationError(ValueError):
 
 
 def point_bytes(curve):
+    """compressed size of a point"""
     return (CURVE_FIELDS[curve][3] + 2 + 7) // 8
+
+
+def coord_bytes(curve):
+    """width of one coordinate in wire v1 (8 bytes per ark-ff limb): 32, or 48 on BLS12-377"""
+    return 8 * ((CURVE_FIELDS[curve][3] + 63) // 64)
+
+
+def wire_point_bytes(curve):
+    return 2 * coord_bytes(curve)
 
 
 def _sqrt(a, p):
@@ -72,16 +83,16 @@ def scalar_serialize(wire32):
 
 
 def point_compress(curve, wire64):
-    """wire v1 (x || y little-endian, 64 zero bytes = infinity) -> compressed canonical bytes"""
+    """wire v1 (x || y little-endian, all-zero bytes = infinity) -> compressed canonical bytes"""
     p, _, _, _ = CURVE_FIELDS[curve]
-    nb = point_bytes(curve)
-    if len(wire64) != 64:
-        raise SerializationError("point: 64 bytes expected")
-    if wire64 == bytes(64):
+    nb, cb = point_bytes(curve), coord_bytes(curve)
+    if len(wire64) != 2 * cb:
+        raise SerializationError("point: %d bytes expected" % (2 * cb))
+    if wire64 == bytes(2 * cb):
         out = bytearray(nb)
         out[-1] |= 0x40
         return bytes(out)
-    x, y = int.from_bytes(wire64[:32], "little"), int.from_bytes(wire64[32:], "little")
+    x, y = int.from_bytes(wire64[:cb], "little"), int.from_bytes(wire64[cb:], "little")
     if x >= p or y >= p:
         raise SerializationError("point: coordinate out of range")
     out = bytearray(x.to_bytes(nb, "little"))
@@ -93,7 +104,7 @@ def point_compress(curve, wire64):
 def point_decompress(curve, data):
     """compressed canonical bytes -> wire v1; rejects x that is not on the curve and non-canonical encodings"""
     p, a, b, _ = CURVE_FIELDS[curve]
-    nb = point_bytes(curve)
+    nb, cb = point_bytes(curve), coord_bytes(curve)
     if len(data) != nb:
         raise SerializationError("point: %d bytes expected" % nb)
     raw = bytearray(data)
@@ -103,7 +114,7 @@ def point_decompress(curve, data):
     if flags & 0x40:
         if x != 0 or flags & 0x80:
             raise SerializationError("point: bad infinity encoding")
-        return bytes(64)
+        return bytes(2 * cb)
     if x >= p:
         raise SerializationError("point: x out of range")
     y = _sqrt((x * x * x + a * x + b) % p, p)
@@ -111,7 +122,7 @@ def point_decompress(curve, data):
         raise SerializationError("point: x is not on the curve")
     if (y > p - y) != bool(flags & 0x80):
         y = p - y
-    return x.to_bytes(32, "little") + y.to_bytes(32, "little")
+    return x.to_bytes(cb, "little") + y.to_bytes(cb, "little")
 
 
 def _usize(v):
@@ -138,7 +149,10 @@ class _Reader:
 
 
 def _points_ser(curve, wire):
-    return b"".join(point_compress(curve, wire[i:i + 64]) for i in range(0, len(wire), 64))
+    w = wire_point_bytes(curve)
+    if len(wire) % w:
+        raise SerializationError("points: whole points expected")
+    return b"".join(point_compress(curve, wire[i:i + w]) for i in range(0, len(wire), w))
 
 
 def _points_de(curve, r, k):
@@ -160,9 +174,10 @@ def masked_card_deserialize(curve, data):
 
 def deck_serialize(curve, wire):
     """Vec<MaskedCard>"""
-    if len(wire) % 128:
+    w = 2 * wire_point_bytes(curve)
+    if len(wire) % w:
         raise SerializationError("deck: whole ciphertexts expected")
-    return _usize(len(wire) // 128) + _points_ser(curve, wire)
+    return _usize(len(wire) // w) + _points_ser(curve, wire)
 
 
 def deck_deserialize(curve, data):
@@ -175,10 +190,11 @@ def deck_deserialize(curve, data):
 
 # ---- Parameters { m, n, enc_parameters { generator }, commit_parameters { g: Vec, h }, generator } ---------------
 def parameters_serialize(curve, m, n, raw):
-    """`raw` = the engine's parameter block: G, ck_0..ck_{n-1}, H, gen (64 B each)"""
-    if len(raw) != 64 * (n + 3):
-        raise SerializationError("parameters: %d bytes expected" % (64 * (n + 3)))
-    G, ck, H, gen = raw[:64], raw[64:64 * (n + 1)], raw[64 * (n + 1):64 * (n + 2)], raw[64 * (n + 2):]
+    """`raw` = the engine's parameter block: G, ck_0..ck_{n-1}, H, gen (one wire point each)"""
+    w = wire_point_bytes(curve)
+    if len(raw) != w * (n + 3):
+        raise SerializationError("parameters: %d bytes expected" % (w * (n + 3)))
+    G, ck, H, gen = raw[:w], raw[w:w * (n + 1)], raw[w * (n + 1):w * (n + 2)], raw[w * (n + 2):]
     return (_usize(m) + _usize(n) + point_compress(curve, G) + _usize(n) + _points_ser(curve, ck)
             + point_compress(curve, H) + point_compress(curve, gen))
 
@@ -200,9 +216,10 @@ def parameters_deserialize(curve, data):
 
 # ---- sigma proofs: Schnorr (1 commitment) / Chaum-Pedersen (2 commitments) + response ---------------------------
 def sigma_proof_serialize(curve, nbases, wire):
-    if len(wire) != 64 * nbases + 32:
+    w = wire_point_bytes(curve)
+    if len(wire) != w * nbases + 32:
         raise SerializationError("sigma proof: bad length")
-    return _points_ser(curve, wire[:64 * nbases]) + wire[64 * nbases:]
+    return _points_ser(curve, wire[:w * nbases]) + wire[w * nbases:]
 
 
 def sigma_proof_deserialize(curve, nbases, data):
@@ -232,15 +249,16 @@ def shuffle_proof_schema(m, n):
 
 
 def shuffle_proof_serialize(curve, m, n, wire):
-    if len(wire) != (11 * m + 8) * 64 + (5 * n + 9) * 32:
+    w = wire_point_bytes(curve)
+    if len(wire) != (11 * m + 8) * w + (5 * n + 9) * 32:
         raise SerializationError("shuffle proof: bad length")
     out, pos = [], 0
     for name, kind, cnt, is_vec in shuffle_proof_schema(m, n):
         if is_vec:
             out.append(_usize(cnt // 2 if name == "mexp.E" else cnt))
         if kind == "G":
-            out.append(_points_ser(curve, wire[pos:pos + 64 * cnt]))
-            pos += 64 * cnt
+            out.append(_points_ser(curve, wire[pos:pos + w * cnt]))
+            pos += w * cnt
         else:
             out.append(wire[pos:pos + 32 * cnt])
             pos += 32 * cnt

@@ -42,10 +42,13 @@ const char* mp_check_name(int code) {
 }
 size_t mp_proof_size(uint32_t m, uint32_t n) { return proof_size_bytes(m, n); }
 size_t mp_params_size(uint32_t n) { return (size_t)(n + 3) * 64; }
+size_t mp_point_size(int curve_id) { return curve_id == MP_CURVE_BLS12_377 ? 96 : 64; }
+size_t mp_proof_size_curve(int curve_id, uint32_t m, uint32_t n) { return proof_size_bytes(m, n, (uint32_t)mp_point_size(curve_id)); }
+size_t mp_params_size_curve(int curve_id, uint32_t n) { return (size_t)(n + 3) * mp_point_size(curve_id); }
 
 int mp_ctx_create(int curve_id, int device, mp_ctx** out) {
   if (!out) return fail(MP_ERR_BAD_ARGUMENT, "null out pointer");
-  if (curve_id < 0 || curve_id > 2) return fail(MP_ERR_BAD_ARGUMENT, "unknown curve id");
+  if (curve_id < 0 || curve_id > 3) return fail(MP_ERR_BAD_ARGUMENT, "unknown curve id");
   MP_TRY
   int ndev = rt::device_count();
   if (ndev <= 0 || device < 0 || device >= ndev)
@@ -72,6 +75,7 @@ int mp_setup(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_
   switch (ctx->curve) {
     case 0: return setup_Stark(ctx, m, n, seed, out_params);
     case 1: return setup_Bn254(ctx, m, n, seed, out_params);
+    case 3: return setup_Bls12_377(ctx, m, n, seed, out_params);
     default: return setup_Secp256k1(ctx, m, n, seed, out_params);
   }
   MP_CATCH
@@ -91,6 +95,7 @@ int mp_table_create_ex(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* param
   switch (ctx->curve) {
     case 0: t = make_table_Stark(ctx, m, n, params, shared_key, fb_window_bits, &rc); break;
     case 1: t = make_table_Bn254(ctx, m, n, params, shared_key, fb_window_bits, &rc); break;
+    case 3: t = make_table_Bls12_377(ctx, m, n, params, shared_key, fb_window_bits, &rc); break;
     default: t = make_table_Secp256k1(ctx, m, n, params, shared_key, fb_window_bits, &rc); break;
   }
   if (rc != MP_OK) {
@@ -156,18 +161,18 @@ int mp_shuffle_and_remask_batch(mp_table* t, size_t B, const uint8_t* decks, con
   MP_TRY
   rt::set_device(t->ctx->device);
   rt::Stream s = t->ctx->stream;
-  const size_t N = t->N, psz = proof_size_bytes(t->m, t->n);
+  const size_t N = t->N, psz = proof_size_bytes(t->m, t->n, t->point_bytes);
   DevBuf<uint8_t> dd, dr, ds, dod, dop;
   DevBuf<uint32_t> dp;
   DevBuf<int32_t> dst;
-  dd.alloc(B * N * 128, s, false); dr.alloc(B * N * 32, s, false); dp.alloc(B * N, s, false); ds.alloc(B * 32, s, false);
-  dod.alloc(B * N * 128, s, false); dop.alloc(B * psz, s, false); dst.alloc(B, s, false);
-  rt::h2d(dd.p, decks, B * N * 128, s);
+  dd.alloc(B * N * 2 * t->point_bytes, s, false); dr.alloc(B * N * 32, s, false); dp.alloc(B * N, s, false); ds.alloc(B * 32, s, false);
+  dod.alloc(B * N * 2 * t->point_bytes, s, false); dop.alloc(B * psz, s, false); dst.alloc(B, s, false);
+  rt::h2d(dd.p, decks, B * N * 2 * t->point_bytes, s);
   rt::h2d(dr.p, masking_factors, B * N * 32, s);
   rt::h2d(dp.p, permutations, B * N * 4, s);
   rt::h2d(ds.p, prover_seeds, B * 32, s);
   t->prove_dev(B, dd.p, dr.p, dp.p, ds.p, dod.p, dop.p, dst.p);
-  rt::d2h(out_decks, dod.p, B * N * 128, s);
+  rt::d2h(out_decks, dod.p, B * N * 2 * t->point_bytes, s);
   rt::d2h(out_proofs, dop.p, B * psz, s);
   rt::d2h(status, dst.p, B * 4, s);
   rt::stream_sync(s);
@@ -180,12 +185,12 @@ int mp_verify_shuffle_batch(mp_table* t, size_t B, const uint8_t* decks, const u
   MP_TRY
   rt::set_device(t->ctx->device);
   rt::Stream s = t->ctx->stream;
-  const size_t N = t->N, psz = proof_size_bytes(t->m, t->n);
+  const size_t N = t->N, psz = proof_size_bytes(t->m, t->n, t->point_bytes);
   DevBuf<uint8_t> dd, dsh, dpf;
   DevBuf<int32_t> dst;
-  dd.alloc(B * N * 128, s, false); dsh.alloc(B * N * 128, s, false); dpf.alloc(B * psz, s, false); dst.alloc(B, s, false);
-  rt::h2d(dd.p, decks, B * N * 128, s);
-  rt::h2d(dsh.p, shuffled_decks, B * N * 128, s);
+  dd.alloc(B * N * 2 * t->point_bytes, s, false); dsh.alloc(B * N * 2 * t->point_bytes, s, false); dpf.alloc(B * psz, s, false); dst.alloc(B, s, false);
+  rt::h2d(dd.p, decks, B * N * 2 * t->point_bytes, s);
+  rt::h2d(dsh.p, shuffled_decks, B * N * 2 * t->point_bytes, s);
   rt::h2d(dpf.p, proofs, B * psz, s);
   t->verify_dev(B, dd.p, dsh.p, dpf.p, dst.p);
   rt::d2h(status, dst.p, B * 4, s);
@@ -204,7 +209,7 @@ int mp_shuffle_and_remask(mp_table* t, const uint8_t* deck, const uint8_t* maski
 }
 int mp_verify_shuffle(mp_table* t, const uint8_t* deck, const uint8_t* shuffled_deck, const uint8_t* proof, size_t proof_len) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle: null table");
-  if (proof_len != proof_size_bytes(t->m, t->n)) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle: wrong proof length");
+  if (proof_len != proof_size_bytes(t->m, t->n, t->point_bytes)) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle: wrong proof length");
   int32_t st = 0;
   int rc = mp_verify_shuffle_batch(t, 1, deck, shuffled_deck, proof, &st);
   if (rc != MP_OK) return rc;

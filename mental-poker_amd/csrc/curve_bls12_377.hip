@@ -1,0 +1,3 @@
+// curve_bls12_377.hip -- instantiates the engine for one curve (separate TU: the curves compile in parallel)
+#include "engine_core.hpp"
+MP_DEFINE_CURVE(Bls12_377)

@@ -126,6 +126,7 @@ struct mp_ctx {
 struct mp_table {
   mp_ctx* ctx = nullptr;
   uint32_t m = 0, n = 0, N = 0;
+  uint32_t point_bytes = 64;   // wire size of a point on this table's curve (Geo<C>::PB)
   virtual ~mp_table() {}
   virtual void reserve(size_t B) = 0;
   virtual void set_latency_batch(size_t B) = 0;
@@ -151,4 +152,5 @@ namespace mp {
 MP_DECLARE_CURVE(Stark)
 MP_DECLARE_CURVE(Bn254)
 MP_DECLARE_CURVE(Secp256k1)
+MP_DECLARE_CURVE(Bls12_377)
 }  // namespace mp

@@ -40,6 +40,7 @@ struct PhaseDev {
 
 // per-batch arenas
 struct Workspace {
+  uint32_t fw = 8;      // words of a base-field element (Geo<C>::FW of the owning table: 8, or 12 on BLS12-377)
   uint32_t Bpad = 0;
   uint32_t nS = 0, nP = 0, nJ = 0, nD = 0, nT = 0, nwin = 0, stage_words = 0;
   DevBuf<uint32_t> S, P, J, T, NS, stage, seed, direct;
@@ -58,12 +59,12 @@ struct Workspace {
     D.n = 0;
     status.n = 0;
     S.alloc((size_t)nS * Bpad * 8, s);
-    P.alloc((size_t)nP * Bpad * 16, s);
-    J.alloc((size_t)nJ * Bpad * 24, s);
+    P.alloc((size_t)nP * Bpad * 2 * fw, s);
+    J.alloc((size_t)nJ * Bpad * 3 * fw, s);
     D.alloc((size_t)std::max(nD, 1u) * nwin * Bpad, s);
-    T.alloc((size_t)std::max(nT, 1u) * VB_ENTRIES * Bpad * 16, s);
+    T.alloc((size_t)std::max(nT, 1u) * VB_ENTRIES * Bpad * 2 * fw, s);
     size_t norm_max = std::max((size_t)nT * 8, (size_t)nJ) * Bpad;   // k_table prefix products (8 per base), k_normalize ranges
-    NS.alloc(norm_max * 8, s);
+    NS.alloc(norm_max * fw, s);
     stage.alloc((size_t)stage_words * Bpad, s);
     seed.alloc((size_t)8 * Bpad, s);
     direct.alloc(Bpad, s);
@@ -75,6 +76,7 @@ template <class C>
 struct Table : mp_table {
   typedef typename C::FqP F;
   typedef typename C::FrP R;
+  typedef Geo<C> G_;      // element sizes of this curve (words in the arenas, bytes on the wire)
 
   // Two static plans per table: [0] throughput (large sub-jobs: fewest operations, one lane per job is fine when
   // there are thousands of proofs) and [1] latency (small sub-jobs and table groups: ~16x more lanes per proof, used
@@ -106,8 +108,8 @@ struct Table : mp_table {
   // ---------------------------------------------------------------- construction
   static bool wire_point_host(const uint8_t* p, Aff<C>& out) {
     // host-side use of the same MP_HD conversion (alignment: copy to an aligned temp)
-    alignas(8) uint8_t tmp[64];
-    memcpy(tmp, p, 64);
+    alignas(8) uint8_t tmp[G_::PB];
+    memcpy(tmp, p, G_::PB);
     return wire_to_aff<C>(tmp, out);
   }
 
@@ -116,15 +118,16 @@ struct Table : mp_table {
     if (fb_bits != 8 && fb_bits != 16 && fb_bits != 20) return fail(MP_ERR_BAD_ARGUMENT, "fixed-base window width must be 8, 16 or 20 bits");
     fbg = FbGeom{fb_bits, (256u + fb_bits - 1u) / fb_bits, (1u << fb_bits) - 1u};
     m = m_; n = n_; N = m * n;
+    point_bytes = G_::PB;
     nwin = (uint32_t)vb_windows(R::BITS);
     FixedBases fb{n};
     std::vector<Aff<C>> bases(fb.count());
     bool ok = true;
     Aff<C> G, H, gen, pkp;
     ok &= wire_point_host(params, G);
-    for (uint32_t j = 0; j < n; ++j) ok &= wire_point_host(params + 64 * (1 + j), bases[fb.ck(j)]);
-    ok &= wire_point_host(params + 64 * (1 + n), H);
-    ok &= wire_point_host(params + 64 * (2 + n), gen);
+    for (uint32_t j = 0; j < n; ++j) ok &= wire_point_host(params + G_::PB * (1 + j), bases[fb.ck(j)]);
+    ok &= wire_point_host(params + G_::PB * (1 + n), H);
+    ok &= wire_point_host(params + G_::PB * (2 + n), gen);
     ok &= wire_point_host(pk, pkp);
     if (!ok) return fail(MP_ERR_BAD_ENCODING, "parameters / shared key: bad point encoding");
     bases[fb.H()] = H; bases[fb.G()] = G; bases[fb.pk()] = pkp; bases[fb.gen()] = gen;
@@ -139,18 +142,18 @@ struct Table : mp_table {
       if (i != fb.gsum() && aff_is_inf<C>(bases[i])) return fail(MP_ERR_BAD_ENCODING, "parameters: a base is the point at infinity");
 
     rt::Stream s = ctx->stream;
-    std::vector<uint32_t> flat(fb.count() * 16);
+    std::vector<uint32_t> flat(fb.count() * G_::PW);
     for (uint32_t i = 0; i < fb.count(); ++i) {
-      fe_pack<F>(bases[i].x, &flat[i * 16]);
-      fe_pack<F>(bases[i].y, &flat[i * 16 + 8]);
+      fe_pack<F>(bases[i].x, &flat[i * G_::PW]);
+      fe_pack<F>(bases[i].y, &flat[i * G_::PW + G_::FW]);
     }
     fbpts.upload(flat, s);
     build_fixed_tables(fb.count());
 
     for (int k = 0; k < 2; ++k) {
       PlanSet& q = ps[k];
-      q.pplan = make_prove_plan(m, n, k ? 2u : FCHUNK, k ? 4u : VCHUNK);
-      q.vplan = make_verify_plan(m, n, k ? 2u : FCHUNK, k ? 4u : VCHUNK);
+      q.pplan = make_prove_plan(m, n, k ? 2u : FCHUNK, k ? 4u : VCHUNK, G_::PB);
+      q.vplan = make_verify_plan(m, n, k ? 2u : FCHUNK, k ? 4u : VCHUNK, G_::PB);
       q.table_group = k ? 8u : TABLE_GROUP;
       for (int i = 0; i < 5; ++i) q.pph[i].upload(q.pplan.ph[i], s);
       q.vph.upload(q.vplan.ph, s);
@@ -186,11 +189,11 @@ struct Table : mp_table {
     const FbGeom gh{h, (256u + h - 1u) / h, (1u << h) - 1u};
     DevBuf<uint32_t> WJ, W, EJ, scratch, Th;
     const size_t nwinpts = (size_t)nb * gh.windows, nent = nwinpts * gh.entries;
-    WJ.alloc(nwinpts * 24, s);
-    W.alloc(nwinpts * 16, s);
-    EJ.alloc(nent * 24, s);
-    scratch.alloc(nent * 8, s);
-    Th.alloc(nent * 16, s);
+    WJ.alloc(nwinpts * G_::JW, s);
+    W.alloc(nwinpts * G_::PW, s);
+    EJ.alloc(nent * G_::JW, s);
+    scratch.alloc(nent * G_::FW, s);
+    Th.alloc(nent * G_::PW, s);
     FbWinArgs wa{fbpts.p, WJ.p, gh};
     MP_RUN(k_fb_windows, C, nb, 1, wa);
     normalize_flat(WJ.p, W.p, scratch.p, nwinpts);
@@ -208,22 +211,23 @@ struct Table : mp_table {
     const size_t nentw = (size_t)nb * fbg.windows * fbg.entries;
     if (nentw >= ((size_t)1 << 32)) throw std::runtime_error("fixed-base table too large for one launch: use narrower windows");
     DevBuf<uint32_t> EJw, scratchw;
-    EJw.alloc(nentw * 24, s, false);
-    scratchw.alloc(nentw * 8, s, false);
-    FB.alloc(nentw * 16, s, false);
+    EJw.alloc(nentw * G_::JW, s, false);
+    scratchw.alloc(nentw * G_::FW, s, false);
+    FB.alloc(nentw * G_::PW, s, false);
     FbWidenArgs ww{Th.p, EJw.p, gh, fbg};
     MP_RUN(k_fb_widen, C, (uint32_t)nentw, 1, ww);
     const size_t per = (size_t)1 << 26;                     // normalise in slices of 64 M points
     for (size_t off = 0; off < nentw; off += per) {
       const size_t cnt = std::min(per, nentw - off);
-      normalize_flat(EJw.p + off * 24, FB.p + off * 16, scratchw.p + off * 8, cnt);
+      normalize_flat(EJw.p + off * G_::JW, FB.p + off * G_::PW, scratchw.p + off * G_::FW, cnt);
     }
     rt::stream_sync(s);
   }
 
   uint32_t stage_words_needed() const {
-    size_t bytes = (size_t)(3 + n + 1 + 4 * N) * 65 + 16 + 32;
-    bytes = std::max(bytes, (size_t)(1 + 6 * m) * 65 + 32);
+    const size_t tb = G_::PB + 1;     // ark ToBytes of a point: x || y || flag
+    size_t bytes = (size_t)(3 + n + 1 + 4 * N) * tb + 16 + 32;
+    bytes = std::max(bytes, (size_t)(1 + 6 * m) * tb + 32);
     return (uint32_t)(bytes / 4 + 4);
   }
 
@@ -235,6 +239,7 @@ struct Table : mp_table {
       nD = std::max(nD, q.pph[i].n_dslots);
       nT = std::max(nT, q.pph[i].n_tslots);
     }
+    ws.fw = G_::FW;
     ws.ensure((uint32_t)B, nS, nP, nJ, nD, nT, nwin, stage_words_needed(), ctx->stream);
   }
 
@@ -265,7 +270,7 @@ struct Table : mp_table {
       MP_RUN(k_combine, C, B, ph.n_c2, a);
     }
     for (auto& r : ph.normalize)
-      normalize_flat(w.J.p + j_off(r.first, w.Bpad, 0), w.P.p + p_off(r.first, w.Bpad, 0), w.NS.p, (size_t)r.second * w.Bpad);
+      normalize_flat(w.J.p + j_off<C>(r.first, w.Bpad, 0), w.P.p + p_off<C>(r.first, w.Bpad, 0), w.NS.p, (size_t)r.second * w.Bpad);
   }
 
   FsStatementArgs statement_args(Workspace& w, uint32_t p_deck, uint32_t p_shuf, uint32_t p_cA, uint32_t s_x) {
@@ -349,7 +354,7 @@ struct Table : mp_table {
     {
       StorePointsArgs a{out_decks, w.P.p, w.Bpad, 2 * N, l.shuf};
       MP_RUN(k_store_points, C, B, 2 * N, a);
-      ProofIoArgs pa{out_proofs, w.S.p, w.P.p, w.status.p, q.pwire.p, w.Bpad, (uint32_t)proof_size_bytes(m, n)};
+      ProofIoArgs pa{out_proofs, w.S.p, w.P.p, w.status.p, q.pwire.p, w.Bpad, (uint32_t)proof_size_bytes(m, n, G_::PB)};
       MP_RUN(k_store_proof, C, B, (uint32_t)q.pplan.wire.size(), pa);
     }
     rt::d2d(status, w.status.p, (size_t)B * 4, s);
@@ -370,7 +375,7 @@ struct Table : mp_table {
       MP_RUN(k_load_points, C, B, 2 * N, a);
       LoadPointsArgs b{shuf, w.P.p, w.status.p, w.Bpad, 2 * N, l.shuf};
       MP_RUN(k_load_points, C, B, 2 * N, b);
-      ProofIoArgs pa{const_cast<uint8_t*>(proofs), w.S.p, w.P.p, w.status.p, q.vwire.p, w.Bpad, (uint32_t)proof_size_bytes(m, n)};
+      ProofIoArgs pa{const_cast<uint8_t*>(proofs), w.S.p, w.P.p, w.status.p, q.vwire.p, w.Bpad, (uint32_t)proof_size_bytes(m, n, G_::PB)};
       MP_RUN(k_load_proof, C, B, (uint32_t)q.vplan.wire.size(), pa);
     }
     {
@@ -397,6 +402,7 @@ struct Table : mp_table {
   };
   void run_adhoc(Adhoc& ad, uint32_t B, uint32_t nS, uint32_t nP, uint32_t nJ) {
     ad.dev.upload(ad.ph, ctx->stream);
+    ad.w.fw = G_::FW;
     ad.w.ensure(B, nS, nP, nJ, ad.ph.n_dslots, ad.ph.n_tslots, nwin, 4, ctx->stream);
   }
 
@@ -408,8 +414,8 @@ struct Table : mp_table {
     run_adhoc(ad, B, 1, 4, 4);
     Workspace& w = ad.w;
     DevBuf<uint8_t> din, drho, dout;
-    din.alloc(count * 128, s, false); drho.alloc(count * 32, s, false); dout.alloc(count * 128, s, false);
-    rt::h2d(din.p, cards, count * 128, s);
+    din.alloc(count * 2 * G_::PB, s, false); drho.alloc(count * 32, s, false); dout.alloc(count * 2 * G_::PB, s, false);
+    rt::h2d(din.p, cards, count * 2 * G_::PB, s);
     rt::h2d(drho.p, rho, count * 32, s);
     rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
     FixedBases fb{n};
@@ -419,11 +425,11 @@ struct Table : mp_table {
     MP_RUN(k_load_scalars, C, B, 1, sa);
     RemaskArgs ra{w.S.p, w.P.p, w.J.p, FB.p, nullptr, w.Bpad, 1, 0, 0, 2, fb.G(), fb.pk(), fbg};
     MP_RUN(k_remask, C, B, 2, ra);
-    normalize_flat(w.J.p + j_off(2, w.Bpad, 0), w.P.p + p_off(2, w.Bpad, 0), w.NS.p, (size_t)2 * w.Bpad);
+    normalize_flat(w.J.p + j_off<C>(2, w.Bpad, 0), w.P.p + p_off<C>(2, w.Bpad, 0), w.NS.p, (size_t)2 * w.Bpad);
     StorePointsArgs st{dout.p, w.P.p, w.Bpad, 2, 2};
     MP_RUN(k_store_points, C, B, 2, st);
     std::vector<int32_t> hs(B);
-    rt::d2h(out, dout.p, count * 128, s);
+    rt::d2h(out, dout.p, count * 2 * G_::PB, s);
     rt::d2h(hs.data(), w.status.p, (size_t)B * 4, s);
     rt::stream_sync(s);
     for (auto v : hs)
@@ -445,9 +451,9 @@ struct Table : mp_table {
     run_adhoc(ad, B, K, K + 1, next_partial);
     Workspace& w = ad.w;
     DevBuf<uint8_t> dsc, dpt, dout;
-    dsc.alloc(n_msm * k * 32, s, false); dpt.alloc(n_msm * k * 64, s, false); dout.alloc(n_msm * 64, s, false);
+    dsc.alloc(n_msm * k * 32, s, false); dpt.alloc(n_msm * k * G_::PB, s, false); dout.alloc(n_msm * G_::PB, s, false);
     rt::h2d(dsc.p, scalars, n_msm * k * 32, s);
-    rt::h2d(dpt.p, points, n_msm * k * 64, s);
+    rt::h2d(dpt.p, points, n_msm * k * G_::PB, s);
     rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
     LoadPointsArgs la{dpt.p, w.P.p, w.status.p, w.Bpad, K, 0};
     MP_RUN(k_load_points, C, B, K, la);
@@ -457,7 +463,7 @@ struct Table : mp_table {
     StorePointsArgs so{dout.p, w.P.p, w.Bpad, 1, K};
     MP_RUN(k_store_points, C, B, 1, so);
     std::vector<int32_t> hs(B);
-    rt::d2h(out, dout.p, n_msm * 64, s);
+    rt::d2h(out, dout.p, n_msm * G_::PB, s);
     rt::d2h(hs.data(), w.status.p, (size_t)B * 4, s);
     rt::stream_sync(s);
     for (auto v : hs)
@@ -481,7 +487,7 @@ struct Table : mp_table {
     run_adhoc(ad, B, L + 1, 1, next_partial);
     Workspace& w = ad.w;
     DevBuf<uint8_t> dv, dr, dout;
-    dv.alloc(std::max<size_t>(count * len * 32, 4), s, false); dr.alloc(count * 32, s, false); dout.alloc(count * 64, s, false);
+    dv.alloc(std::max<size_t>(count * len * 32, 4), s, false); dr.alloc(count * 32, s, false); dout.alloc(count * G_::PB, s, false);
     if (len) rt::h2d(dv.p, values, count * len * 32, s);
     rt::h2d(dr.p, r, count * 32, s);
     rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
@@ -495,7 +501,7 @@ struct Table : mp_table {
     StorePointsArgs so{dout.p, w.P.p, w.Bpad, 1, 0};
     MP_RUN(k_store_points, C, B, 1, so);
     std::vector<int32_t> hs(B);
-    rt::d2h(out, dout.p, count * 64, s);
+    rt::d2h(out, dout.p, count * G_::PB, s);
     rt::d2h(hs.data(), w.status.p, (size_t)B * 4, s);
     rt::stream_sync(s);
     for (auto v : hs)
@@ -518,7 +524,7 @@ struct Table : mp_table {
     rt::Stream s = ctx->stream;
     const uint32_t B = (uint32_t)B_;
     const SigmaLay l = make_sigma_lay(nb);
-    const size_t psz = (size_t)nb * 64 + 32;
+    const size_t psz = (size_t)nb * G_::PB + 32;
     Adhoc ad;
     uint32_t next_partial = l.chk + nb;
     {
@@ -541,14 +547,15 @@ struct Table : mp_table {
       }
     }
     ad.dev.upload(ad.ph, s);
-    ad.w.ensure(B, 6, 3 * nb, next_partial, ad.ph.n_dslots, ad.ph.n_tslots, nwin, (3 * nb * 65 + 32) / 4 + 4, s);
+    ad.w.fw = G_::FW;
+    ad.w.ensure(B, 6, 3 * nb, next_partial, ad.ph.n_dslots, ad.ph.n_tslots, nwin, (3 * nb * (G_::PB + 1) + 32) / 4 + 4, s);
     Workspace& w = ad.w;
     DevBuf<uint8_t> dg, da, dx, dfs, dseed, dpf;
     DevBuf<int32_t> dst;
-    dg.alloc((size_t)B * nb * 64, s, false); da.alloc((size_t)B * nb * 64, s, false); dfs.alloc((size_t)B * 32, s, false);
+    dg.alloc((size_t)B * nb * G_::PB, s, false); da.alloc((size_t)B * nb * G_::PB, s, false); dfs.alloc((size_t)B * 32, s, false);
     dpf.alloc((size_t)B * psz, s, false);
-    rt::h2d(dg.p, bases, (size_t)B * nb * 64, s);
-    rt::h2d(da.p, publics, (size_t)B * nb * 64, s);
+    rt::h2d(dg.p, bases, (size_t)B * nb * G_::PB, s);
+    rt::h2d(da.p, publics, (size_t)B * nb * G_::PB, s);
     rt::h2d(dfs.p, fs_init, (size_t)B * 32, s);
     rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
     LoadPointsArgs lg{dg.p, w.P.p, w.status.p, w.Bpad, nb, l.g};
@@ -618,19 +625,20 @@ static int setup_device(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[
   Aff<C> g;
   g.x = fe_unpack<F>(C::GX_MONT);
   g.y = fe_unpack<F>(C::GY_MONT);
-  alignas(8) uint8_t gw[64];
+  alignas(8) uint8_t gw[Geo<C>::PB];
   aff_to_wire<C>(g, gw);
-  std::vector<uint8_t> scalars((size_t)cnt * 32), points((size_t)cnt * 64);
+  std::vector<uint8_t> scalars((size_t)cnt * 32), points((size_t)cnt * Geo<C>::PB);
   for (uint32_t i = 0; i < cnt; ++i) {
     Fe<R> kf = frstream_next<R>(st);
     uint32_t k[8];
     fe_to_canonical<R>(kf, k);
     memcpy(&scalars[(size_t)i * 32], k, 32);
-    memcpy(&points[(size_t)i * 64], gw, 64);
+    memcpy(&points[(size_t)i * Geo<C>::PB], gw, Geo<C>::PB);
   }
   Table<C> t;
   t.ctx = ctx;
   t.m = m; t.n = n; t.N = m * n;
+  t.point_bytes = Geo<C>::PB;
   t.nwin = (uint32_t)vb_windows(R::BITS);
   t.msm_host(cnt, 1, scalars.data(), points.data(), out);
   return MP_OK;

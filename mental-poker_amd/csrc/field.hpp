@@ -28,7 +28,7 @@ namespace mp {
 
 template <class P>
 struct Fe {
-  uint32_t v[P::L29 ? 9 : 8];
+  uint32_t v[P::L29 ? 9 : P::NW];   // NW = 8 packed words (256-bit fields) or 12 (BLS12-377 Fq)
 };
 
 static constexpr uint32_t M29 = (1u << 29) - 1;
@@ -38,53 +38,55 @@ static constexpr uint32_t M29 = (1u << 29) - 1;
 // =====================================================================================================
 // r = a - MOD if a >= MOD (a given with an extra top carry word `hi`), branch-free
 template <class P>
-MP_HD void fe_cond_sub(uint32_t r[8], const uint32_t a[8], uint32_t hi) {
-  uint32_t d[8];
+MP_HD void fe_cond_sub(uint32_t* r, const uint32_t* a, uint32_t hi) {
+  constexpr int N = P::NW;
+  uint32_t d[N];
   uint64_t br = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < N; ++i) {
     uint64_t t = (uint64_t)a[i] - P::MOD[i] - br;
     d[i] = (uint32_t)t;
     br = (t >> 32) & 1;
   }
   bool ge = (br == 0) || (hi != 0);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) r[i] = ge ? d[i] : a[i];
+  for (int i = 0; i < N; ++i) r[i] = ge ? d[i] : a[i];
 }
 
 // Montgomery product on 8x32 limbs, CIOS in plain C (host / development emulator form)
 template <class P>
-MP_HD void mul32_cios(uint32_t r[8], const uint32_t a[8], const uint32_t b[8]) {
-  uint32_t t[9];
+MP_HD void mul32_cios(uint32_t* r, const uint32_t* a, const uint32_t* b) {
+  constexpr int N = P::NW;
+  uint32_t t[N + 1];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) t[i] = 0;
+  for (int i = 0; i < N + 1; ++i) t[i] = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < N; ++i) {
     uint64_t c = 0;
     const uint32_t bi = b[i];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < N; ++j) {
       c += (uint64_t)a[j] * bi + t[j];
       t[j] = (uint32_t)c;
       c >>= 32;
     }
-    c += t[8];
-    t[8] = (uint32_t)c;
+    c += t[N];
+    t[N] = (uint32_t)c;
     uint32_t t9 = (uint32_t)(c >> 32);
     const uint32_t m = t[0] * P::INV;
     c = (uint64_t)m * P::MOD[0] + t[0];
     c >>= 32;
 #pragma unroll
-    for (int j = 1; j < 8; ++j) {
+    for (int j = 1; j < N; ++j) {
       c += (uint64_t)m * P::MOD[j] + t[j];
       t[j - 1] = (uint32_t)c;
       c >>= 32;
     }
-    c += t[8];
-    t[7] = (uint32_t)c;
-    t[8] = t9 + (uint32_t)(c >> 32);
+    c += t[N];
+    t[N - 1] = (uint32_t)c;
+    t[N] = t9 + (uint32_t)(c >> 32);
   }
-  fe_cond_sub<P>(r, t, t[8]);
+  fe_cond_sub<P>(r, t, t[N]);
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -93,19 +95,20 @@ MP_HD void fe_mac96(uint64_t& acc, uint32_t& acc2, uint32_t x, uint32_t y) {
 }
 // gfx950 form of the 8x32 product (see header comment)
 template <class P>
-MP_HD void mul32(uint32_t r[8], const uint32_t a[8], const uint32_t b[8]) {
+MP_HD void mul32(uint32_t* r, const uint32_t* a, const uint32_t* b) {
+  constexpr int N = P::NW;
   uint64_t acc = 0;
   uint32_t acc2 = 0;
-  uint32_t t[8], m[8];
+  uint32_t t[N], m[N];
 #pragma unroll
-  for (int k = 0; k < 15; ++k) {
+  for (int k = 0; k < 2 * N - 1; ++k) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < N; ++i) {
       const int j = k - i;
-      if (j < 0 || j > 7) continue;
+      if (j < 0 || j > N - 1) continue;
       fe_mac96(acc, acc2, a[i], b[j]);
     }
-    if (k < 8) {
+    if (k < N) {
 #pragma unroll
       for (int i = 0; i < k; ++i) {
         if (P::MOD[k - i] == 0) continue;
@@ -123,21 +126,21 @@ MP_HD void mul32(uint32_t r[8], const uint32_t a[8], const uint32_t b[8]) {
       acc2 = 0;
     } else {
 #pragma unroll
-      for (int i = k - 7; i < 8; ++i) {
+      for (int i = k - (N - 1); i < N; ++i) {
         if (P::MOD[k - i] == 0) continue;
         fe_mac96(acc, acc2, m[i], P::MOD[k - i]);
       }
-      t[k - 8] = (uint32_t)acc;
+      t[k - N] = (uint32_t)acc;
       acc = (acc >> 32) | ((uint64_t)acc2 << 32);
       acc2 = 0;
     }
   }
-  t[7] = (uint32_t)acc;
+  t[N - 1] = (uint32_t)acc;
   fe_cond_sub<P>(r, t, (uint32_t)(acc >> 32));
 }
 #else
 template <class P>
-MP_HD void mul32(uint32_t r[8], const uint32_t a[8], const uint32_t b[8]) {
+MP_HD void mul32(uint32_t* r, const uint32_t* a, const uint32_t* b) {
   mul32_cios<P>(r, a, b);
 }
 #endif
@@ -277,7 +280,7 @@ template <class P>
 MP_HD Fe<P> fe_zero() {
   Fe<P> r;
 #pragma unroll
-  for (int i = 0; i < (P::L29 ? 9 : 8); ++i) r.v[i] = 0;
+  for (int i = 0; i < (P::L29 ? 9 : P::NW); ++i) r.v[i] = 0;
   return r;
 }
 template <class P>
@@ -288,7 +291,7 @@ MP_HD Fe<P> fe_one() {
     for (int i = 0; i < 9; ++i) r.v[i] = P::R1_29[i];
   } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.v[i] = P::R1[i];
+    for (int i = 0; i < P::NW; ++i) r.v[i] = P::R1[i];
   }
   return r;
 }
@@ -305,7 +308,7 @@ MP_HD bool fe_is_zero(const Fe<P>& a) {
   } else {
     uint32_t o = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o |= a.v[i];
+    for (int i = 0; i < P::NW; ++i) o |= a.v[i];
     return o == 0;
   }
 }
@@ -318,10 +321,10 @@ MP_HD Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
     for (int i = 0; i < 9; ++i) s[i] = (int32_t)(a.v[i] + b.v[i]);
     reduce_carry29<P>(s, r.v);
   } else {
-    uint32_t s[8];
+    uint32_t s[P::NW];
     uint64_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < P::NW; ++i) {
       c += (uint64_t)a.v[i] + b.v[i];
       s[i] = (uint32_t)c;
       c >>= 32;
@@ -340,10 +343,10 @@ MP_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
     for (int i = 0; i < 9; ++i) s[i] = (int32_t)a.v[i] - (int32_t)b.v[i] + 4 * (int32_t)P::MOD29[i];
     reduce_carry29<P>(s, r.v);
   } else {
-    uint32_t d[8];
+    uint32_t d[P::NW];
     uint64_t br = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < P::NW; ++i) {
       uint64_t t = (uint64_t)a.v[i] - b.v[i] - br;
       d[i] = (uint32_t)t;
       br = (t >> 32) & 1;
@@ -351,7 +354,7 @@ MP_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
     uint32_t mask = (uint32_t)0 - (uint32_t)br;
     uint64_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < P::NW; ++i) {
       c += (uint64_t)d[i] + (P::MOD[i] & mask);
       r.v[i] = (uint32_t)c;
       c >>= 32;
@@ -370,7 +373,7 @@ MP_HD Fe<P> fe_dbl(const Fe<P>& a) {
 // a / 2 (8x32 representation only: the scalar fields).  Works on the Montgomery residue: (a + (a odd ? p : 0)) >> 1
 template <class P>
 MP_HD Fe<P> fe_half(const Fe<P>& a) {
-  static_assert(!P::L29, "fe_half is only provided for the 8x32 representation");
+  static_assert(!P::L29 && P::NW == 8, "fe_half is only provided for the 8x32 representation");
   const uint32_t mask = (uint32_t)0 - (a.v[0] & 1u);
   uint32_t s[9];
   uint64_t c = 0;
@@ -393,7 +396,7 @@ MP_HD bool fe_eq(const Fe<P>& a, const Fe<P>& b) {
   } else {
     uint32_t o = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o |= a.v[i] ^ b.v[i];
+    for (int i = 0; i < P::NW; ++i) o |= a.v[i] ^ b.v[i];
     return o == 0;
   }
 }
@@ -416,60 +419,60 @@ MP_HD Fe<P> fe_sqr(const Fe<P>& a) {
   return r;
 }
 
-// ---- memory format: 8 packed words, canonical Montgomery residue -------------------------------------------
+// ---- memory format: P::NW packed words, canonical Montgomery residue ---------------------------------------
 template <class P>
-MP_HD Fe<P> fe_unpack(const uint32_t w[8]) {
+MP_HD Fe<P> fe_unpack(const uint32_t* w) {
   Fe<P> r;
   if constexpr (P::L29) {
     unpack29(w, r.v);
   } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.v[i] = w[i];
+    for (int i = 0; i < P::NW; ++i) r.v[i] = w[i];
   }
   return r;
 }
 template <class P>
-MP_HD void fe_pack(const Fe<P>& a, uint32_t w[8]) {
+MP_HD void fe_pack(const Fe<P>& a, uint32_t* w) {
   if constexpr (P::L29) {
     uint32_t c[9];
     canonical29<P>(a.v, c);
     pack29(c, w);
   } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) w[i] = a.v[i];
+    for (int i = 0; i < P::NW; ++i) w[i] = a.v[i];
   }
 }
 
 // ---- canonical integer (8 x u32, little-endian) <-> Montgomery form ---------------------------------------------
 template <class P>
-MP_HD Fe<P> fe_from_canonical(const uint32_t a[8]) {
+MP_HD Fe<P> fe_from_canonical(const uint32_t* a) {
   Fe<P> t = fe_unpack<P>(a), r2;
   if constexpr (P::L29) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) r2.v[i] = P::R2_29[i];
   } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r2.v[i] = P::R2[i];
+    for (int i = 0; i < P::NW; ++i) r2.v[i] = P::R2[i];
   }
   return fe_mul<P>(t, r2);
 }
 template <class P>
-MP_HD void fe_to_canonical(const Fe<P>& a, uint32_t out[8]) {
+MP_HD void fe_to_canonical(const Fe<P>& a, uint32_t* out) {
   Fe<P> one = fe_zero<P>();
   one.v[0] = 1u;
   fe_pack<P>(fe_mul<P>(a, one), out);
 }
 template <class P>
 MP_HD Fe<P> fe_from_u32(uint32_t x) {
-  uint32_t a[8] = {x, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t a[P::NW] = {x};
   return fe_from_canonical<P>(a);
 }
 // is the canonical integer a < MOD ?
 template <class P>
-MP_HD bool fe_canonical_in_range(const uint32_t a[8]) {
+MP_HD bool fe_canonical_in_range(const uint32_t* a) {
   uint64_t br = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < P::NW; ++i) {
     uint64_t t = (uint64_t)a[i] - P::MOD[i] - br;
     br = (t >> 32) & 1;
   }

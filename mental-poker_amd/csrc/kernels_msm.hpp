@@ -18,61 +18,80 @@
 
 namespace mp {
 
-// ---- arena access (16-byte vector loads/stores; arenas are 256-byte aligned, elements 32/64/96 B) ----
-MP_HD void ld_words8(const uint32_t* p, uint32_t v[8]) {
+// ---- arena access (16-byte vector loads/stores; arenas are 256-byte aligned) ----------------------------------
+// Sizes in 32-bit words of the arena elements of curve C: a base-field element is FW packed words (8; 12 on BLS12-377),
+// an affine point 2 FW, a Jacobian point 3 FW; a scalar (Fr) is 8 words on every supported curve.
+template <class C>
+struct Geo {
+  static constexpr uint32_t FW = C::FqP::NW;
+  static constexpr uint32_t PW = 2 * FW;
+  static constexpr uint32_t JW = 3 * FW;
+  static constexpr uint32_t FB = 4 * FW;   // wire bytes of a coordinate
+  static constexpr uint32_t PB = 8 * FW;   // wire bytes of a point (x || y)
+};
+template <int N>
+MP_HD void ld_words(const uint32_t* p, uint32_t* v) {
+  static_assert(N % 4 == 0, "elements are whole 16-byte vectors");
   const uint4* q = reinterpret_cast<const uint4*>(p);
-  uint4 lo = q[0], hi = q[1];
-  v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
-  v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+#pragma unroll
+  for (int i = 0; i < N / 4; ++i) {
+    const uint4 t = q[i];
+    v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+  }
 }
-MP_HD void st_words8(uint32_t* p, const uint32_t v[8]) {
+template <int N>
+MP_HD void st_words(uint32_t* p, const uint32_t* v) {
   uint4* q = reinterpret_cast<uint4*>(p);
-  q[0] = make_uint4(v[0], v[1], v[2], v[3]);
-  q[1] = make_uint4(v[4], v[5], v[6], v[7]);
+#pragma unroll
+  for (int i = 0; i < N / 4; ++i) q[i] = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
 }
-// memory format of a field element = 8 packed words (canonical Montgomery residue, field.hpp)
+// memory format of a field element = F::NW packed words (canonical Montgomery residue, field.hpp)
 template <class F>
 MP_HD Fe<F> ld_fe(const uint32_t* p) {
-  uint32_t w[8];
-  ld_words8(p, w);
+  uint32_t w[F::NW];
+  ld_words<F::NW>(p, w);
   return fe_unpack<F>(w);
 }
 template <class F>
 MP_HD void st_fe(uint32_t* p, const Fe<F>& a) {
-  uint32_t w[8];
+  uint32_t w[F::NW];
   fe_pack<F>(a, w);
-  st_words8(p, w);
+  st_words<F::NW>(p, w);
 }
 template <class C>
 MP_HD Aff<C> ld_aff(const uint32_t* p) {
   Aff<C> a;
   a.x = ld_fe<typename C::FqP>(p);
-  a.y = ld_fe<typename C::FqP>(p + 8);
+  a.y = ld_fe<typename C::FqP>(p + Geo<C>::FW);
   return a;
 }
 template <class C>
 MP_HD void st_aff(uint32_t* p, const Aff<C>& a) {
   st_fe<typename C::FqP>(p, a.x);
-  st_fe<typename C::FqP>(p + 8, a.y);
+  st_fe<typename C::FqP>(p + Geo<C>::FW, a.y);
 }
 template <class C>
 MP_HD Jac<C> ld_jac(const uint32_t* p) {
   Jac<C> j;
   j.X = ld_fe<typename C::FqP>(p);
-  j.Y = ld_fe<typename C::FqP>(p + 8);
-  j.Z = ld_fe<typename C::FqP>(p + 16);
+  j.Y = ld_fe<typename C::FqP>(p + Geo<C>::FW);
+  j.Z = ld_fe<typename C::FqP>(p + 2 * Geo<C>::FW);
   return j;
 }
 template <class C>
 MP_HD void st_jac(uint32_t* p, const Jac<C>& j) {
   st_fe<typename C::FqP>(p, j.X);
-  st_fe<typename C::FqP>(p + 8, j.Y);
-  st_fe<typename C::FqP>(p + 16, j.Z);
+  st_fe<typename C::FqP>(p + Geo<C>::FW, j.Y);
+  st_fe<typename C::FqP>(p + 2 * Geo<C>::FW, j.Z);
 }
 
 MP_HD size_t s_off(uint32_t slot, uint32_t Bpad, uint32_t b) { return ((size_t)slot * Bpad + b) * 8; }
-MP_HD size_t p_off(uint32_t slot, uint32_t Bpad, uint32_t b) { return ((size_t)slot * Bpad + b) * 16; }
-MP_HD size_t j_off(uint32_t slot, uint32_t Bpad, uint32_t b) { return ((size_t)slot * Bpad + b) * 24; }
+template <class C>   // scratch arenas of base-field elements (prefix products of the batched inversions)
+MP_HD size_t f_off(uint32_t slot, uint32_t Bpad, uint32_t b) { return ((size_t)slot * Bpad + b) * Geo<C>::FW; }
+template <class C>
+MP_HD size_t p_off(uint32_t slot, uint32_t Bpad, uint32_t b) { return ((size_t)slot * Bpad + b) * Geo<C>::PW; }
+template <class C>
+MP_HD size_t j_off(uint32_t slot, uint32_t Bpad, uint32_t b) { return ((size_t)slot * Bpad + b) * Geo<C>::JW; }
 
 // ---- fixed-base MSM ---------------------------------------------------------------------------------
 // geometry of the fixed-base tables of a table context: `bits`-wide unsigned windows (8, 16 or 20)
@@ -82,14 +101,15 @@ struct FbGeom {
 struct FixedArgs {
   const uint32_t* S;
   uint32_t* J;
-  const uint32_t* FB;   // [base][window][entry(1..entries)] affine, 16 words each
+  const uint32_t* FB;   // [base][window][entry(1..entries)] affine, Geo<C>::PW words each
   const Job* jobs;
   const Term* terms;
   uint32_t Bpad;
   FbGeom g;
 };
+template <class C>
 MP_HD const uint32_t* fb_entry(const uint32_t* FB, const FbGeom& g, uint32_t base, uint32_t w, uint32_t d) {
-  return FB + (((size_t)base * g.windows + w) * g.entries + (d - 1)) * 16;
+  return FB + (((size_t)base * g.windows + w) * g.entries + (d - 1)) * Geo<C>::PW;
 }
 // window w of the canonical scalar k (bits <= 24; a window may straddle two words)
 MP_HD uint32_t fb_digit(const uint32_t k[8], const FbGeom& g, uint32_t w) {
@@ -110,10 +130,10 @@ MP_HD void body_fixed_msm(const FixedArgs& a, uint32_t b, uint32_t y) {
 #pragma unroll 1
     for (uint32_t w = 0; w < a.g.windows; ++w) {
       const uint32_t d = fb_digit(k, a.g, w);
-      if (d) jac_madd_ip<C>(acc, ld_aff<C>(fb_entry(a.FB, a.g, term.b, w, d)));
+      if (d) jac_madd_ip<C>(acc, ld_aff<C>(fb_entry<C>(a.FB, a.g, term.b, w, d)));
     }
   }
-  st_jac<C>(a.J + j_off(job.out, a.Bpad, b), acc);
+  st_jac<C>(a.J + j_off<C>(job.out, a.Bpad, b), acc);
 }
 MP_KERNEL_OCC(k_fixed_msm, FixedArgs, body_fixed_msm, 4)
 
@@ -143,10 +163,10 @@ MP_HD void body_remask(const RemaskArgs& a, uint32_t b, uint32_t y) {
 #pragma unroll 1
   for (uint32_t w = 0; w < a.g.windows; ++w) {
     const uint32_t d = fb_digit(k, a.g, w);
-    if (d) jac_madd_ip<C>(acc, ld_aff<C>(fb_entry(a.FB, a.g, base, w, d)));
+    if (d) jac_madd_ip<C>(acc, ld_aff<C>(fb_entry<C>(a.FB, a.g, base, w, d)));
   }
-  jac_madd_ip<C>(acc, ld_aff<C>(a.P + p_off(a.p_deck + 2 * src + comp, a.Bpad, b)));
-  st_jac<C>(a.J + j_off(a.j_out + y, a.Bpad, b), acc);
+  jac_madd_ip<C>(acc, ld_aff<C>(a.P + p_off<C>(a.p_deck + 2 * src + comp, a.Bpad, b)));
+  st_jac<C>(a.J + j_off<C>(a.j_out + y, a.Bpad, b), acc);
 }
 MP_KERNEL_OCC(k_remask, RemaskArgs, body_remask, 4)
 
@@ -211,7 +231,7 @@ MP_HD void body_table(const TableArgs& a, uint32_t b, uint32_t y) {
   const uint32_t g1 = g0 + a.group < a.n_tables ? g0 + a.group : a.n_tables;
   for (uint32_t g = g0; g < g1; ++g) {   // entry 0 = P
     const Term t = a.list[g];
-    st_aff<C>(a.T + p_off(t.b * VB_ENTRIES, a.Bpad, b), ld_aff<C>(a.P + p_off(t.s, a.Bpad, b)));
+    st_aff<C>(a.T + p_off<C>(t.b * VB_ENTRIES, a.Bpad, b), ld_aff<C>(a.P + p_off<C>(t.s, a.Bpad, b)));
   }
 #pragma unroll 1
   for (uint32_t e0 = 1; e0 < (uint32_t)VB_ENTRIES; e0 *= 2) {   // targets: entries e0 .. 2*e0-1
@@ -226,10 +246,10 @@ MP_HD void body_table(const TableArgs& a, uint32_t b, uint32_t y) {
         table_operands(e0 + i + 1, e0, ia, ib, dbl);
         Fe<F> den;
         if (dbl)
-          den = fe_dbl<F>(ld_fe<F>(a.T + p_off(ts * VB_ENTRIES + ia, a.Bpad, b) + 8));
+          den = fe_dbl<F>(ld_fe<F>(a.T + p_off<C>(ts * VB_ENTRIES + ia, a.Bpad, b) + Geo<C>::FW));
         else
-          den = fe_sub<F>(ld_fe<F>(a.T + p_off(ts * VB_ENTRIES + ib, a.Bpad, b)), ld_fe<F>(a.T + p_off(ts * VB_ENTRIES + ia, a.Bpad, b)));
-        st_fe<F>(a.scratch + s_off(ts * 8 + i, a.Bpad, b), prod);
+          den = fe_sub<F>(ld_fe<F>(a.T + p_off<C>(ts * VB_ENTRIES + ib, a.Bpad, b)), ld_fe<F>(a.T + p_off<C>(ts * VB_ENTRIES + ia, a.Bpad, b)));
+        st_fe<F>(a.scratch + f_off<C>(ts * 8 + i, a.Bpad, b), prod);
         if (!fe_is_zero(den)) prod = fe_mul<F>(prod, den);   // zero only for P = infinity (prime-order group)
       }
     }
@@ -242,18 +262,18 @@ MP_HD void body_table(const TableArgs& a, uint32_t b, uint32_t y) {
         uint32_t ia, ib;
         bool dbl;
         table_operands(e0 + i + 1, e0, ia, ib, dbl);
-        const Aff<C> pa = ld_aff<C>(a.T + p_off(ts * VB_ENTRIES + ia, a.Bpad, b));
+        const Aff<C> pa = ld_aff<C>(a.T + p_off<C>(ts * VB_ENTRIES + ia, a.Bpad, b));
         Aff<C> pb = pa;
         Fe<F> den;
         if (dbl) {
           den = fe_dbl<F>(pa.y);
         } else {
-          pb = ld_aff<C>(a.T + p_off(ts * VB_ENTRIES + ib, a.Bpad, b));
+          pb = ld_aff<C>(a.T + p_off<C>(ts * VB_ENTRIES + ib, a.Bpad, b));
           den = fe_sub<F>(pb.x, pa.x);
         }
         Aff<C> out = aff_inf<C>();
         if (!fe_is_zero(den)) {
-          const Fe<F> dinv = fe_mul<F>(inv, ld_fe<F>(a.scratch + s_off(ts * 8 + i, a.Bpad, b)));
+          const Fe<F> dinv = fe_mul<F>(inv, ld_fe<F>(a.scratch + f_off<C>(ts * 8 + i, a.Bpad, b)));
           inv = fe_mul<F>(inv, den);
           Fe<F> num;
           if (dbl) {
@@ -267,7 +287,7 @@ MP_HD void body_table(const TableArgs& a, uint32_t b, uint32_t y) {
           out.x = fe_sub<F>(fe_sub<F>(fe_sqr<F>(lam), pa.x), pb.x);
           out.y = fe_sub<F>(fe_mul<F>(lam, fe_sub<F>(pa.x, out.x)), pa.y);
         }
-        st_aff<C>(a.T + p_off(ts * VB_ENTRIES + e0 + i, a.Bpad, b), out);
+        st_aff<C>(a.T + p_off<C>(ts * VB_ENTRIES + e0 + i, a.Bpad, b), out);
       }
     }
   }
@@ -299,13 +319,13 @@ MP_HD void body_var_msm(const VarArgs& a, uint32_t b, uint32_t y) {
       const int d = a.D[((size_t)term.s * a.nwin + w) * a.Bpad + b];
       if (d != 0) {
         const uint32_t e = (uint32_t)(d < 0 ? -d : d) - 1;
-        Aff<C> q = ld_aff<C>(a.T + p_off(term.b * VB_ENTRIES + e, a.Bpad, b));
+        Aff<C> q = ld_aff<C>(a.T + p_off<C>(term.b * VB_ENTRIES + e, a.Bpad, b));
         if (d < 0) q = aff_neg<C>(q);
         jac_madd_ip<C>(acc, q);
       }
     }
   }
-  st_jac<C>(a.J + j_off(job.out, a.Bpad, b), acc);
+  st_jac<C>(a.J + j_off<C>(job.out, a.Bpad, b), acc);
 }
 MP_KERNEL_OCC(k_var_msm, VarArgs, body_var_msm, 4)
 
@@ -324,16 +344,16 @@ MP_HD void body_combine(const CombineArgs& a, uint32_t b, uint32_t y) {
   for (uint32_t t = 0; t < job.count; ++t) {
     const uint32_t s = a.terms[job.begin + t].s;
     if (s & AFF_FLAG) {
-      Aff<C> q = ld_aff<C>(a.P + p_off(s & SLOT_MASK, a.Bpad, b));
+      Aff<C> q = ld_aff<C>(a.P + p_off<C>(s & SLOT_MASK, a.Bpad, b));
       if (s & NEG_FLAG) q = aff_neg<C>(q);
       jac_madd_ip<C>(acc, q);
     } else {
-      Jac<C> q = ld_jac<C>(a.J + j_off(s & SLOT_MASK, a.Bpad, b));
+      Jac<C> q = ld_jac<C>(a.J + j_off<C>(s & SLOT_MASK, a.Bpad, b));
       if (s & NEG_FLAG) q.Y = fe_neg<typename C::FqP>(q.Y);
       jac_add_ip<C>(acc, q);
     }
   }
-  st_jac<C>(a.J + j_off(job.out, a.Bpad, b), acc);
+  st_jac<C>(a.J + j_off<C>(job.out, a.Bpad, b), acc);
 }
 MP_KERNEL_OCC(k_combine, CombineArgs, body_combine, 4)
 
@@ -355,23 +375,23 @@ MP_HD void body_normalize(const NormArgs& a, uint32_t x, uint32_t y) {
   for (uint32_t i = 0; i < a.chunk; ++i) {
     const size_t e = (size_t)x + (size_t)i * a.nthreads;
     if (e >= a.count) break;
-    st_fe<F>(a.scratch + e * 8, prod);               // product of the Z's before this element
-    Fe<F> z = ld_fe<F>(a.src + e * 24 + 16);
+    st_fe<F>(a.scratch + e * Geo<C>::FW, prod);               // product of the Z's before this element
+    Fe<F> z = ld_fe<F>(a.src + e * Geo<C>::JW + 2 * Geo<C>::FW);
     if (!fe_is_zero(z)) prod = fe_mul<F>(prod, z);
     nmine = i + 1;
   }
   Fe<F> inv = fe_inv<F>(prod);
   for (uint32_t i = nmine; i-- > 0;) {
     const size_t e = (size_t)x + (size_t)i * a.nthreads;
-    Jac<C> j = ld_jac<C>(a.src + e * 24);
+    Jac<C> j = ld_jac<C>(a.src + e * Geo<C>::JW);
     Aff<C> out = aff_inf<C>();
     if (!fe_is_zero(j.Z)) {
-      Fe<F> before = ld_fe<F>(a.scratch + e * 8);
+      Fe<F> before = ld_fe<F>(a.scratch + e * Geo<C>::FW);
       Fe<F> zinv = fe_mul<F>(inv, before);
       inv = fe_mul<F>(inv, j.Z);
       out = jac_to_aff_with_zinv<C>(j, zinv);
     }
-    st_aff<C>(a.dst + e * 16, out);
+    st_aff<C>(a.dst + e * Geo<C>::PW, out);
   }
 }
 MP_KERNEL(k_normalize, NormArgs, body_normalize)
@@ -385,9 +405,9 @@ struct FbWinArgs {
 };
 template <class C>
 MP_HD void body_fb_windows(const FbWinArgs& a, uint32_t x, uint32_t y) {
-  Jac<C> acc = jac_from_aff<C>(ld_aff<C>(a.bases + (size_t)x * 16));
+  Jac<C> acc = jac_from_aff<C>(ld_aff<C>(a.bases + (size_t)x * Geo<C>::PW));
   for (uint32_t w = 0; w < a.g.windows; ++w) {
-    st_jac<C>(a.WJ + ((size_t)x * a.g.windows + w) * 24, acc);
+    st_jac<C>(a.WJ + ((size_t)x * a.g.windows + w) * Geo<C>::JW, acc);
     for (uint32_t q = 0; q < a.g.bits; ++q) jac_dbl_ip<C>(acc);
   }
 }
@@ -400,15 +420,15 @@ struct FbFillArgs {
 };
 template <class C>
 MP_HD void body_fb_fill(const FbFillArgs& a, uint32_t x, uint32_t y) {
-  const Aff<C> w = ld_aff<C>(a.W + (size_t)x * 16);
+  const Aff<C> w = ld_aff<C>(a.W + (size_t)x * Geo<C>::PW);
   Jac<C> acc = jac_from_aff<C>(w);
-  uint32_t* out = a.EJ + (size_t)x * a.g.entries * 24;
+  uint32_t* out = a.EJ + (size_t)x * a.g.entries * Geo<C>::JW;
   st_jac<C>(out, acc);
   jac_dbl_ip<C>(acc);
-  st_jac<C>(out + 24, acc);
+  st_jac<C>(out + Geo<C>::JW, acc);
   for (uint32_t e = 2; e < a.g.entries; ++e) {
     jac_madd_ip<C>(acc, w);
-    st_jac<C>(out + (size_t)e * 24, acc);
+    st_jac<C>(out + (size_t)e * Geo<C>::JW, acc);
   }
 }
 MP_KERNEL(k_fb_fill, FbFillArgs, body_fb_fill)
@@ -426,11 +446,11 @@ MP_HD void body_fb_widen(const FbWidenArgs& a, uint32_t x, uint32_t y) {
   const uint32_t bw = x / a.g.entries;           // base * g.windows + w
   const uint32_t base = bw / a.g.windows, w = bw % a.g.windows;
   const uint32_t hi = d >> a.gh.bits, lo = d & a.gh.entries;
-  const uint32_t* tlo = a.Th + ((size_t)base * a.gh.windows + 2 * w) * a.gh.entries * 16;
+  const uint32_t* tlo = a.Th + ((size_t)base * a.gh.windows + 2 * w) * a.gh.entries * Geo<C>::PW;
   Jac<C> acc = jac_inf<C>();
-  if (lo) acc = jac_from_aff<C>(ld_aff<C>(tlo + (size_t)(lo - 1) * 16));
-  if (hi && 2 * w + 1 < a.gh.windows) jac_madd_ip<C>(acc, ld_aff<C>(tlo + ((size_t)a.gh.entries + hi - 1) * 16));
-  st_jac<C>(a.EJ + (size_t)x * 24, acc);
+  if (lo) acc = jac_from_aff<C>(ld_aff<C>(tlo + (size_t)(lo - 1) * Geo<C>::PW));
+  if (hi && 2 * w + 1 < a.gh.windows) jac_madd_ip<C>(acc, ld_aff<C>(tlo + ((size_t)a.gh.entries + hi - 1) * Geo<C>::PW));
+  st_jac<C>(a.EJ + (size_t)x * Geo<C>::JW, acc);
 }
 MP_KERNEL(k_fb_widen, FbWidenArgs, body_fb_widen)
 

@@ -21,32 +21,32 @@ MP_HD void status_fail(int32_t* status, uint32_t b, int32_t code) {
   status[b] = code;
 }
 
-// wire field element (32 B little-endian canonical) -> Montgomery; false if >= modulus
+// wire field element (4 F::NW bytes little-endian canonical: 32, or 48 for BLS12-377 Fq) -> Montgomery; false if >= modulus
 template <class F>
 MP_HD bool wire_to_fe(const uint8_t* p, Fe<F>& out) {
-  uint32_t k[8];
+  uint32_t k[F::NW];
   const uint32_t* q = reinterpret_cast<const uint32_t*>(p);   // wire buffers are 4-byte aligned (API contract)
 #pragma unroll
-  for (int i = 0; i < 8; ++i) k[i] = q[i];
+  for (int i = 0; i < F::NW; ++i) k[i] = q[i];
   const bool ok = fe_canonical_in_range<F>(k);
   out = fe_from_canonical<F>(k);
   return ok;
 }
 template <class F>
 MP_HD void fe_to_wire(const Fe<F>& a, uint8_t* p) {
-  uint32_t k[8];
+  uint32_t k[F::NW];
   fe_to_canonical<F>(a, k);
   uint32_t* q = reinterpret_cast<uint32_t*>(p);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) q[i] = k[i];
+  for (int i = 0; i < F::NW; ++i) q[i] = k[i];
 }
-// wire point: x || y (64 B); infinity = 64 zero bytes.  false if a coordinate is out of range or the point
+// wire point: x || y (Geo<C>::PB = 64 B; 96 B on BLS12-377); infinity = all-zero bytes.  false if a coordinate is out of range or the point
 // is not on the curve.
 template <class C>
 MP_HD bool wire_to_aff(const uint8_t* p, Aff<C>& out) {
   typedef typename C::FqP F;
   bool ok = wire_to_fe<F>(p, out.x);
-  ok &= wire_to_fe<F>(p + 32, out.y);
+  ok &= wire_to_fe<F>(p + Geo<C>::FB, out.y);
   if (aff_is_inf<C>(out)) return ok;
   return ok && aff_on_curve<C>(out);
 }
@@ -54,12 +54,12 @@ template <class C>
 MP_HD void aff_to_wire(const Aff<C>& a, uint8_t* p) {
   typedef typename C::FqP F;
   fe_to_wire<F>(a.x, p);       // (0,0) Montgomery = (0,0) canonical = the infinity encoding
-  fe_to_wire<F>(a.y, p + 32);
+  fe_to_wire<F>(a.y, p + Geo<C>::FB);
 }
 
 // ---- load / store -------------------------------------------------------------------------------------
 struct LoadPointsArgs {
-  const uint8_t* src;    // [B][count][64]
+  const uint8_t* src;    // [B][count][point bytes]
   uint32_t* P;
   int32_t* status;
   uint32_t Bpad, count, p_slot;
@@ -68,12 +68,12 @@ struct LoadPointsArgs {
 template <class C>
 MP_HD void body_load_points(const LoadPointsArgs& a, uint32_t b, uint32_t y) {
   Aff<C> pt;
-  const bool ok = wire_to_aff<C>(a.src + ((size_t)b * a.count + y) * 64, pt);
+  const bool ok = wire_to_aff<C>(a.src + ((size_t)b * a.count + y) * Geo<C>::PB, pt);
   if (!ok) {
     status_fail(a.status, b, ST_BAD_ENCODING);
     pt = aff_inf<C>();
   }
-  st_aff<C>(a.P + p_off(a.p_slot + y, a.Bpad, b), pt);
+  st_aff<C>(a.P + p_off<C>(a.p_slot + y, a.Bpad, b), pt);
 }
 MP_KERNEL(k_load_points, LoadPointsArgs, body_load_points)
 
@@ -114,7 +114,7 @@ MP_HD void body_load_proof(const ProofIoArgs& a, uint32_t b, uint32_t y) {
       status_fail(a.status, b, ST_BAD_ENCODING);
       pt = aff_inf<C>();
     }
-    st_aff<C>(a.P + p_off(e.slot, a.Bpad, b), pt);
+    st_aff<C>(a.P + p_off<C>(e.slot, a.Bpad, b), pt);
   } else {
     Fe<R> v;
     if (!wire_to_fe<R>(src, v)) {
@@ -131,20 +131,20 @@ MP_HD void body_store_proof(const ProofIoArgs& a, uint32_t b, uint32_t y) {
   const ProofElem e = a.map[y];
   uint8_t* dst = a.proof + (size_t)b * a.proof_bytes + e.offset;
   if (e.is_point)
-    aff_to_wire<C>(ld_aff<C>(a.P + p_off(e.slot, a.Bpad, b)), dst);
+    aff_to_wire<C>(ld_aff<C>(a.P + p_off<C>(e.slot, a.Bpad, b)), dst);
   else
     fe_to_wire<R>(ld_fe<R>(a.S + s_off(e.slot, a.Bpad, b)), dst);
 }
 MP_KERNEL(k_store_proof, ProofIoArgs, body_store_proof)
 
 struct StorePointsArgs {
-  uint8_t* dst;          // [B][count][64]
+  uint8_t* dst;          // [B][count][point bytes]
   const uint32_t* P;
   uint32_t Bpad, count, p_slot;
 };
 template <class C>
 MP_HD void body_store_points(const StorePointsArgs& a, uint32_t b, uint32_t y) {
-  aff_to_wire<C>(ld_aff<C>(a.P + p_off(a.p_slot + y, a.Bpad, b)), a.dst + ((size_t)b * a.count + y) * 64);
+  aff_to_wire<C>(ld_aff<C>(a.P + p_off<C>(a.p_slot + y, a.Bpad, b)), a.dst + ((size_t)b * a.count + y) * Geo<C>::PB);
 }
 MP_KERNEL(k_store_points, StorePointsArgs, body_store_points)
 
@@ -211,22 +211,23 @@ struct FsDev {
   uint32_t Bpad;
 };
 template <class C>
-MP_HD void fs_put_point(StageWriter& w, const Aff<C>& p) {
+MP_HD void fs_put_point(StageWriter& w, const Aff<C>& p) {   // ark ToBytes: x || y (8 bytes per limb) || infinity flag
   typedef typename C::FqP F;
-  uint32_t k[8];
+  constexpr int FW = F::NW;
+  uint32_t k[FW];
   if (aff_is_inf<C>(p)) {   // GroupAffine::zero() = (0, 1, infinity = true)
-    for (int i = 0; i < 8; ++i) stage_word(w, 0);
+    for (int i = 0; i < FW; ++i) stage_word(w, 0);
     stage_word(w, 1);
-    for (int i = 1; i < 8; ++i) stage_word(w, 0);
+    for (int i = 1; i < FW; ++i) stage_word(w, 0);
     stage_byte(w, 1);
     return;
   }
   fe_to_canonical<F>(p.x, k);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) stage_word(w, k[i]);
+  for (int i = 0; i < FW; ++i) stage_word(w, k[i]);
   fe_to_canonical<F>(p.y, k);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) stage_word(w, k[i]);
+  for (int i = 0; i < FW; ++i) stage_word(w, k[i]);
   stage_byte(w, 0);
 }
 MP_HD void fs_load_seed(const FsDev& f, uint32_t b, uint32_t seed[8]) {
@@ -247,7 +248,7 @@ MP_HD void fs_finish_absorb(StageWriter& w, uint32_t seed[8]) {
 template <class C>
 MP_HD void fs_absorb_points(const FsDev& f, const uint32_t* P, uint32_t b, uint32_t seed[8], uint32_t first, uint32_t count) {
   StageWriter w = stage_begin(f.stage, f.Bpad, b);
-  for (uint32_t i = 0; i < count; ++i) fs_put_point<C>(w, ld_aff<C>(P + p_off(first + i, f.Bpad, b)));
+  for (uint32_t i = 0; i < count; ++i) fs_put_point<C>(w, ld_aff<C>(P + p_off<C>(first + i, f.Bpad, b)));
   fs_finish_absorb(w, seed);
 }
 template <class C>
@@ -275,13 +276,13 @@ MP_HD void fs_statement_and_x(const FsStatementArgs& a, uint32_t b, uint32_t see
 #pragma unroll
   for (int i = 0; i < 8; ++i) seed[i] = a.init_seed[i];
   StageWriter w = stage_begin(a.f.stage, a.f.Bpad, b);
-  fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.G() * 16));
-  fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.pk() * 16));
-  fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.gen() * 16));
-  for (uint32_t j = 0; j < a.n; ++j) fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.ck(j) * 16));
-  fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.H() * 16));
-  for (uint32_t i = 0; i < 2 * a.N; ++i) fs_put_point<C>(w, ld_aff<C>(a.P + p_off(a.p_deck + i, a.f.Bpad, b)));
-  for (uint32_t i = 0; i < 2 * a.N; ++i) fs_put_point<C>(w, ld_aff<C>(a.P + p_off(a.p_shuf + i, a.f.Bpad, b)));
+  fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.G() * Geo<C>::PW));
+  fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.pk() * Geo<C>::PW));
+  fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.gen() * Geo<C>::PW));
+  for (uint32_t j = 0; j < a.n; ++j) fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.ck(j) * Geo<C>::PW));
+  fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.H() * Geo<C>::PW));
+  for (uint32_t i = 0; i < 2 * a.N; ++i) fs_put_point<C>(w, ld_aff<C>(a.P + p_off<C>(a.p_deck + i, a.f.Bpad, b)));
+  for (uint32_t i = 0; i < 2 * a.N; ++i) fs_put_point<C>(w, ld_aff<C>(a.P + p_off<C>(a.p_shuf + i, a.f.Bpad, b)));
   stage_word(w, a.m); stage_word(w, 0); stage_word(w, a.n); stage_word(w, 0);   // u64 m, u64 n
   fs_finish_absorb(w, seed);
   fs_absorb_points<C>(a.f, a.P, b, seed, a.p_cA, a.m);
@@ -314,8 +315,8 @@ MP_HD void fs_run_steps(const FsRoundArgs& a, uint32_t b, uint32_t seed[8]) {
   for (uint32_t s = 0; s < a.nsteps; ++s) {
     const FsStep st = a.step[s];
     StageWriter w = stage_begin(a.f.stage, a.f.Bpad, b);
-    for (uint32_t i = 0; i < st.count; ++i) fs_put_point<C>(w, ld_aff<C>(a.P + p_off(st.first + i, a.f.Bpad, b)));
-    for (uint32_t i = 0; i < st.count2; ++i) fs_put_point<C>(w, ld_aff<C>(a.P + p_off(st.first2 + i, a.f.Bpad, b)));
+    for (uint32_t i = 0; i < st.count; ++i) fs_put_point<C>(w, ld_aff<C>(a.P + p_off<C>(st.first + i, a.f.Bpad, b)));
+    for (uint32_t i = 0; i < st.count2; ++i) fs_put_point<C>(w, ld_aff<C>(a.P + p_off<C>(st.first2 + i, a.f.Bpad, b)));
     fs_finish_absorb(w, seed);
     if (st.slot0 != NO_SLOT) fs_challenges<C>(seed, a.S, a.f.Bpad, b, st.slot0, st.slot1);
   }
@@ -323,7 +324,7 @@ MP_HD void fs_run_steps(const FsRoundArgs& a, uint32_t b, uint32_t seed[8]) {
 template <class C>
 MP_HD void body_fs_round(const FsRoundArgs& a, uint32_t b, uint32_t y) {
   if (a.copy_from != NO_SLOT)
-    st_aff<C>(a.P + p_off(a.copy_to, a.f.Bpad, b), ld_aff<C>(a.P + p_off(a.copy_from, a.f.Bpad, b)));
+    st_aff<C>(a.P + p_off<C>(a.copy_to, a.f.Bpad, b), ld_aff<C>(a.P + p_off<C>(a.copy_from, a.f.Bpad, b)));
   uint32_t seed[8];
   fs_load_seed(a.f, b, seed);
   fs_run_steps<C>(a, b, seed);
@@ -625,11 +626,11 @@ MP_HD void body_verify_scal(const VerifyScalArgs& a, uint32_t b, uint32_t y_) {
   // --- Hadamard: first commitment, last commitment
   MP_ST(c.had_y, y);
   MP_ST(c.had_mz, fe_neg<R>(z));
-  if (!aff_eq<C>(ld_aff<C>(a.P + p_off(l.hB + m - 1, a.Bpad, b)), ld_aff<C>(a.P + p_off(l.cb, a.Bpad, b)))) fail |= 1u << VC_HAD_BM;
+  if (!aff_eq<C>(ld_aff<C>(a.P + p_off<C>(l.hB + m - 1, a.Bpad, b)), ld_aff<C>(a.P + p_off<C>(l.cb, a.Bpad, b)))) fail |= 1u << VC_HAD_BM;
   // --- zero argument
   {
     const Fe<R> hx = MP_LD(l.hx), hy = MP_LD(l.hy), zx = MP_LD(l.zx);
-    if (!aff_is_inf<C>(ld_aff<C>(a.P + p_off(l.zcD + m + 1, a.Bpad, b)))) fail |= 1u << VC_ZERO_DM1;
+    if (!aff_is_inf<C>(ld_aff<C>(a.P + p_off<C>(l.zcD + m + 1, a.Bpad, b)))) fail |= 1u << VC_ZERO_DM1;
     const uint32_t t_zx = l.tmp, t_hx = l.tmp + 2 * m + 1;     // zx^0..zx^2m ; hx^0..hx^m
     Fe<R> acc = one;
     for (uint32_t i = 0; i <= 2 * m; ++i) {
@@ -697,7 +698,7 @@ MP_HD void body_verify_scal(const VerifyScalArgs& a, uint32_t b, uint32_t y_) {
   // --- multi-exponentiation
   {
     const Fe<R> mx = MP_LD(l.mx);
-    if (!aff_is_inf<C>(ld_aff<C>(a.P + p_off(l.mecB + m, a.Bpad, b)))) fail |= 1u << VC_ME_BM;
+    if (!aff_is_inf<C>(ld_aff<C>(a.P + p_off<C>(l.mecB + m, a.Bpad, b)))) fail |= 1u << VC_ME_BM;
     const uint32_t t_mx = l.tmp;    // mx^0 .. mx^(2m-1)
     Fe<R> acc = one;
     for (uint32_t k = 0; k < 2 * m; ++k) {
@@ -738,7 +739,7 @@ MP_HD void body_verdict(const VerdictArgs& a, uint32_t b, uint32_t y) {
   for (int cidx = 0; cidx < (int)VC_COUNT && code == 0; ++cidx) {
     bool failed;
     if (vcheck_is_msm(cidx))
-      failed = !fe_is_zero(ld_fe<typename C::FqP>(a.J + j_off(a.chk_first + cidx, a.Bpad, b) + 16));
+      failed = !fe_is_zero(ld_fe<typename C::FqP>(a.J + j_off<C>(a.chk_first + cidx, a.Bpad, b) + 2 * Geo<C>::FW));
     else
       failed = (direct >> cidx) & 1u;
     if (failed) code = vcheck_code(cidx);

@@ -72,7 +72,7 @@ MP_HD void body_sigma_fs(const SigmaFsArgs& a, uint32_t b, uint32_t y) {
 MP_KERNEL(k_sigma_fs, SigmaFsArgs, body_sigma_fs)
 
 struct SigmaIoArgs {
-  uint8_t* proofs;          // [B][nb*64 + 32]
+  uint8_t* proofs;          // [B][nb * point bytes + 32]
   uint32_t* S;
   uint32_t* P;
   int32_t* status;
@@ -83,27 +83,27 @@ struct SigmaIoArgs {
 template <class C>
 MP_HD void body_sigma_store(const SigmaIoArgs& a, uint32_t b, uint32_t y) {
   typedef typename C::FrP R;
-  uint8_t* dst = a.proofs + (size_t)b * (a.l.nb * 64 + 32);
+  uint8_t* dst = a.proofs + (size_t)b * (a.l.nb * Geo<C>::PB + 32);
   if (y < a.l.nb)
-    aff_to_wire<C>(ld_aff<C>(a.P + p_off(a.l.A + y, a.Bpad, b)), dst + 64 * y);
+    aff_to_wire<C>(ld_aff<C>(a.P + p_off<C>(a.l.A + y, a.Bpad, b)), dst + Geo<C>::PB * y);
   else
-    fe_to_wire<R>(ld_fe<R>(a.S + s_off(a.l.z, a.Bpad, b)), dst + 64 * a.l.nb);
+    fe_to_wire<R>(ld_fe<R>(a.S + s_off(a.l.z, a.Bpad, b)), dst + Geo<C>::PB * a.l.nb);
 }
 MP_KERNEL(k_sigma_store, SigmaIoArgs, body_sigma_store)
 template <class C>
 MP_HD void body_sigma_load(const SigmaIoArgs& a, uint32_t b, uint32_t y) {
   typedef typename C::FrP R;
-  const uint8_t* src = a.proofs + (size_t)b * (a.l.nb * 64 + 32);
+  const uint8_t* src = a.proofs + (size_t)b * (a.l.nb * Geo<C>::PB + 32);
   if (y < a.l.nb) {
     Aff<C> pt;
-    if (!wire_to_aff<C>(src + 64 * y, pt)) {
+    if (!wire_to_aff<C>(src + Geo<C>::PB * y, pt)) {
       status_fail(a.status, b, ST_BAD_ENCODING);
       pt = aff_inf<C>();
     }
-    st_aff<C>(a.P + p_off(a.l.A + y, a.Bpad, b), pt);
+    st_aff<C>(a.P + p_off<C>(a.l.A + y, a.Bpad, b), pt);
   } else {
     Fe<R> v;
-    if (!wire_to_fe<R>(src + 64 * a.l.nb, v)) {
+    if (!wire_to_fe<R>(src + Geo<C>::PB * a.l.nb, v)) {
       status_fail(a.status, b, ST_BAD_ENCODING);
       v = fe_zero<R>();
     }
@@ -123,7 +123,7 @@ template <class C>
 MP_HD void body_sigma_verdict(const SigmaVerdictArgs& a, uint32_t b, uint32_t y) {
   if (a.status[b] < 0) return;
   bool ok = true;
-  for (uint32_t i = 0; i < a.l.nb; ++i) ok &= fe_is_zero(ld_fe<typename C::FqP>(a.J + j_off(a.l.chk + i, a.Bpad, b) + 16));
+  for (uint32_t i = 0; i < a.l.nb; ++i) ok &= fe_is_zero(ld_fe<typename C::FqP>(a.J + j_off<C>(a.l.chk + i, a.Bpad, b) + 2 * Geo<C>::FW));
   a.status[b] = ok ? 0 : a.fail_code;
 }
 MP_KERNEL(k_sigma_verdict, SigmaVerdictArgs, body_sigma_verdict)

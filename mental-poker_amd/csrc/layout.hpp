@@ -182,10 +182,10 @@ struct ProofElem {
 };
 
 template <class L>
-static inline std::vector<ProofElem> proof_wire_map(const L& l) {
+static inline std::vector<ProofElem> proof_wire_map(const L& l, uint32_t point_bytes) {
   std::vector<ProofElem> v;
   uint32_t off = 0;
-  auto P = [&](uint32_t s) { v.push_back(ProofElem{1, s, off}); off += 64; };
+  auto P = [&](uint32_t s) { v.push_back(ProofElem{1, s, off}); off += point_bytes; };
   auto S = [&](uint32_t s) { v.push_back(ProofElem{0, s, off}); off += 32; };
   const uint32_t m = l.m, n = l.n;
   for (uint32_t k = 0; k < m; ++k) P(l.cA + k);
@@ -209,7 +209,10 @@ static inline std::vector<ProofElem> proof_wire_map(const L& l) {
   return v;
 }
 
-static inline size_t proof_size_bytes(uint32_t m, uint32_t n) { return (size_t)(11 * m + 8) * 64 + (size_t)(5 * n + 9) * 32; }
+// point_bytes: 64 for the 256-bit curves, 96 for BLS12-377 (Geo<C>::PB)
+static inline size_t proof_size_bytes(uint32_t m, uint32_t n, uint32_t point_bytes = 64) {
+  return (size_t)(11 * m + 8) * point_bytes + (size_t)(5 * n + 9) * 32;
+}
 
 static inline ProveLay make_prove_lay(uint32_t m, uint32_t n) {
   ProveLay l{};
@@ -357,7 +360,7 @@ static inline std::vector<KLeaf> k_merge(const std::vector<KLeaf>& in) {
   return out;
 }
 
-static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk) {
+static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk, uint32_t point_bytes = 64) {
   ProvePlan pl;
   pl.lay = make_prove_lay(m, n);
   pl.lay.toom = m == 2 ? 1u : 0u;
@@ -548,7 +551,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
   pl.nJ = next_partial;
   pl.draws = prove_draw_slots(l);
   pl.lay.n_draws = (uint32_t)pl.draws.size();
-  pl.wire = proof_wire_map(l);
+  pl.wire = proof_wire_map(l, point_bytes);
   return pl;
 }
 
@@ -665,7 +668,7 @@ struct VerifyPlan {
   std::vector<ProofElem> wire;
 };
 
-static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk) {
+static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk, uint32_t point_bytes = 64) {
   VerifyPlan pl;
   pl.lay = make_verify_lay(m, n);
   const VerifyLay& l = pl.lay;
@@ -745,7 +748,7 @@ static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchun
     B.end();
   }
   pl.nJ = next_partial;
-  pl.wire = proof_wire_map(l);
+  pl.wire = proof_wire_map(l, point_bytes);
   return pl;
 }
 

@@ -69,21 +69,22 @@ class Parameters:
     """discrete_log_cards::Parameters { m, n, enc_parameters, commit_parameters, generator } [REF mod.rs:37-61]"""
 
     def __init__(self, m, n, raw):
-        if len(raw) != 64 * (n + 3):
+        if len(raw) not in (64 * (n + 3), 96 * (n + 3)):     # 64-byte points; 96 on BLS12-377
             raise CardProtocolError.io("parameters: expected %d bytes" % (64 * (n + 3)))
         self.m, self.n, self.raw = m, n, bytes(raw)
+        self.pb = len(self.raw) // (n + 3)
 
     @property
     def enc_parameters(self):      # el_gamal::Parameters { generator }
-        return self.raw[:64]
+        return self.raw[:self.pb]
 
     @property
     def commit_parameters(self):   # pedersen::CommitKey: n generators + h
-        return self.raw[64:64 * (self.n + 2)]
+        return self.raw[self.pb:self.pb * (self.n + 2)]
 
     @property
     def generator(self):           # el_gamal::Generator
-        return self.raw[64 * (self.n + 2):]
+        return self.raw[self.pb * (self.n + 2):]
 
     # CanonicalSerialize / CanonicalDeserialize [REF src/lib.rs:52]; format: canonical.py
     def serialize(self, curve):
@@ -165,7 +166,8 @@ class DLCards:
                                                    permutation.mapping, rng_seed)
         except _native.NativeError as e:
             raise CardProtocolError.io(str(e))
-        return [out_deck[i * 128:(i + 1) * 128] for i in range(N)], proof
+        cb = 2 * self.engine.point_bytes
+        return [out_deck[i * cb:(i + 1) * cb] for i in range(N)], proof
 
     # -- fn verify_shuffle(pp, shared_key, original_deck, shuffled_deck, proof) -> Result<(), CryptoError>
     #                                                                                    [REF mod.rs:420-443]
@@ -242,31 +244,31 @@ class DLCards:
     # -- fn verify_mask(pp, shared_key, card, masked_card, proof) -> Result<(), CryptoError>  [REF mod.rs:213-240]
     def verify_mask(self, pp, shared_key, card, masked_card, proof):
         t = self._t(pp, shared_key)
-        stmt = masked_card[:64] + self._mul(t, [(1, masked_card[64:]), (-1, card)])
+        stmt = masked_card[:self.engine.point_bytes] + self._mul(t, [(1, masked_card[self.engine.point_bytes:]), (-1, card)])
         self._sigma_verify(t, 2, pp.enc_parameters + shared_key, stmt, proof, MASKING_RNG_SEED)
 
     # -- fn remask(rng, pp, shared_key, original_card, alpha) -> (MaskedCard, ZKProofRemasking)  [REF mod.rs:242-272]
     def remask(self, rng_seed, pp, shared_key, original_card, alpha):
         t = self._t(pp, shared_key)
         remasked = t.remask_batch(original_card, _scalar_bytes([alpha]))
-        stmt = self._mul(t, [(1, remasked[:64]), (-1, original_card[:64])]) + self._mul(t, [(1, remasked[64:]), (-1, original_card[64:])])
+        stmt = self._mul(t, [(1, remasked[:self.engine.point_bytes]), (-1, original_card[:self.engine.point_bytes])]) + self._mul(t, [(1, remasked[self.engine.point_bytes:]), (-1, original_card[self.engine.point_bytes:])])
         return remasked, self._sigma_prove(t, 2, pp.enc_parameters + shared_key, stmt, alpha, REMASKING_RNG_SEED, rng_seed)
 
     # -- fn verify_remask(pp, shared_key, original_masked, remasked, proof) -> Result<(), CryptoError>  [REF mod.rs:274-298]
     def verify_remask(self, pp, shared_key, original_masked, remasked, proof):
         t = self._t(pp, shared_key)
-        stmt = self._mul(t, [(1, remasked[:64]), (-1, original_masked[:64])]) + self._mul(t, [(1, remasked[64:]), (-1, original_masked[64:])])
+        stmt = self._mul(t, [(1, remasked[:self.engine.point_bytes]), (-1, original_masked[:self.engine.point_bytes])]) + self._mul(t, [(1, remasked[self.engine.point_bytes:]), (-1, original_masked[self.engine.point_bytes:])])
         self._sigma_verify(t, 2, pp.enc_parameters + shared_key, stmt, proof, REMASKING_RNG_SEED)
 
     # -- fn compute_reveal_token(rng, pp, sk, pk, masked_card) -> (RevealToken, ZKProofReveal)  [REF mod.rs:300-330]
     def compute_reveal_token(self, rng_seed, pp, sk, pk, masked_card):
         t = self._t(pp)
-        token = self._mul(t, [(sk, masked_card[:64])])
-        return token, self._sigma_prove(t, 2, masked_card[:64] + pp.enc_parameters, token + pk, sk, REVEAL_RNG_SEED, rng_seed)
+        token = self._mul(t, [(sk, masked_card[:self.engine.point_bytes])])
+        return token, self._sigma_prove(t, 2, masked_card[:self.engine.point_bytes] + pp.enc_parameters, token + pk, sk, REVEAL_RNG_SEED, rng_seed)
 
     # -- fn verify_reveal(pp, pk, reveal_token, masked_card, proof) -> Result<(), CryptoError>  [REF mod.rs:332-357]
     def verify_reveal(self, pp, pk, reveal_token, masked_card, proof):
-        self._sigma_verify(self._t(pp), 2, masked_card[:64] + pp.enc_parameters, reveal_token + pk, proof, REVEAL_RNG_SEED)
+        self._sigma_verify(self._t(pp), 2, masked_card[:self.engine.point_bytes] + pp.enc_parameters, reveal_token + pk, proof, REVEAL_RNG_SEED)
 
     # -- fn unmask(pp, decryption_key, masked_card) -> Result<Card, CardProtocolError>     [REF mod.rs:359-378; reveal.rs:14-16]
     def unmask(self, pp, decryption_key, masked_card):
@@ -275,7 +277,7 @@ class DLCards:
                 self.verify_reveal(pp, pk, token, masked_card, proof)
             except CryptoError as e:
                 raise CardProtocolError("ProofVerificationError", e)
-        return self._mul(self._t(pp), [(1, masked_card[64:])] + [(-1, tok) for tok, _, _ in decryption_key])
+        return self._mul(self._t(pp), [(1, masked_card[self.engine.point_bytes:])] + [(-1, tok) for tok, _, _ in decryption_key])
 
     # -- batched forms (the data-parallel axis: independent proofs of one table)
     def shuffle_and_remask_batch(self, rng_seeds, pp, shared_key, decks, masking_factors, permutations):
@@ -287,13 +289,13 @@ class DLCards:
                                                   b"".join(rng_seeds))
         except _native.NativeError as e:
             raise CardProtocolError.io(str(e))
-        N, ps = pp.m * pp.n, t.proof_bytes
+        N, ps, cb = pp.m * pp.n, t.proof_bytes, 2 * self.engine.point_bytes
         out = []
         for b, s in enumerate(st):
             if s < 0:
                 out.append(CardProtocolError.io(self.engine.check_name(s)))
             else:
-                out.append(([d[(b * N + i) * 128:(b * N + i + 1) * 128] for i in range(N)], p[b * ps:(b + 1) * ps]))
+                out.append(([d[(b * N + i) * cb:(b * N + i + 1) * cb] for i in range(N)], p[b * ps:(b + 1) * ps]))
         return out
 
     def verify_shuffle_batch(self, pp, shared_key, original_decks, shuffled_decks, proofs):
@@ -319,6 +321,7 @@ CURVE_ORDERS = {
     "stark": 0x0800000000000010ffffffffffffffffb781126dcae7b2321e66a241adc64d2f,
     "bn254": 21888242871839275222246405745257275088548364400416034343698204186575808495617,
     "secp256k1": 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141,
+    "bls12_377": 0x12ab655e9a2ca55660b44d1e5c37b00159aa76fed00000010a11800000000001,
 }
 KEY_OWN_RNG_SEED = b"Key Ownership Proof"   # [REF mod.rs:80-83]
 MASKING_RNG_SEED = b"Masking Proof"

@@ -26,6 +26,11 @@ const u64 SecpFr::MOD[4] = {0xbfd25e8cd0364141ULL, 0xbaaedce6af48a03bULL, 0xffff
 const u64 Secp256k1::B[4] = {7, 0, 0, 0};
 const u64 Secp256k1::GX[4] = {0x59f2815b16f81798ULL, 0x029bfcdb2dce28d9ULL, 0x55a06295ce870b07ULL, 0x79be667ef9dcbbacULL};
 const u64 Secp256k1::GY[4] = {0x9c47d08ffb10d4b8ULL, 0xfd17b448a6855419ULL, 0x5da4fbfc0e1108a8ULL, 0x483ada7726a3c465ULL};
+const u64 Bls377Fq::MOD[6] = {0x8508c00000000001ULL, 0x170b5d4430000000ULL, 0x1ef3622fba094800ULL, 0x1a22d9f300f5138fULL, 0xc63b05c06ca1493bULL, 0x01ae3a4617c510eaULL};
+const u64 Bls377Fr::MOD[4] = {0x0a11800000000001ULL, 0x59aa76fed0000001ULL, 0x60b44d1e5c37b001ULL, 0x12ab655e9a2ca556ULL};
+const u64 Bls12_377::B[6] = {1, 0, 0, 0, 0, 0};
+const u64 Bls12_377::GX[6] = {0xeab9b16eb21be9efULL, 0xd5481512ffcd394eULL, 0x188282c8bd37cb5cULL, 0x85951e2caa9d41bbULL, 0xc8fc6225bf87ff54ULL, 0x008848defe740a67ULL};
+const u64 Bls12_377::GY[6] = {0xfd82de55559c8ea6ULL, 0xc2fe3d3634a9591aULL, 0x6d182ad44fb82305ULL, 0xbd7fb348ca3e52d9ULL, 0x1f674f5d30afeec4ULL, 0x01914a69c5102effULL};
 }  // namespace mpo
 
 using namespace mpo;
@@ -40,37 +45,38 @@ struct Api {
   typedef typename S::Ct Ct;
   typedef typename S::Deck Deck;
   typedef typename S::Params Params;
+  static const size_t PW = S::PW;   // wire bytes of a point (64; 96 on BLS12-377)
 
   static bool load_params(uint32_t m, uint32_t n, const uint8_t* p, Params& pp) {
     pp.m = m;
     pp.n = n;
     bool ok = S::pt_from_wire(p, pp.G);
     pp.ck.resize(n);
-    for (uint32_t i = 0; i < n; ++i) ok &= S::pt_from_wire(p + 64 * (1 + i), pp.ck[i]);
-    ok &= S::pt_from_wire(p + 64 * (1 + n), pp.H);
-    ok &= S::pt_from_wire(p + 64 * (2 + n), pp.gen);
+    for (uint32_t i = 0; i < n; ++i) ok &= S::pt_from_wire(p + PW * (1 + i), pp.ck[i]);
+    ok &= S::pt_from_wire(p + PW * (1 + n), pp.H);
+    ok &= S::pt_from_wire(p + PW * (2 + n), pp.gen);
     pp.gsum = S::compute_gsum(pp.ck);
     return ok;
   }
   static void store_params(const Params& pp, uint8_t* p) {
     S::pt_wire(pp.G, p);
-    for (uint32_t i = 0; i < pp.n; ++i) S::pt_wire(pp.ck[i], p + 64 * (1 + i));
-    S::pt_wire(pp.H, p + 64 * (1 + pp.n));
-    S::pt_wire(pp.gen, p + 64 * (2 + pp.n));
+    for (uint32_t i = 0; i < pp.n; ++i) S::pt_wire(pp.ck[i], p + PW * (1 + i));
+    S::pt_wire(pp.H, p + PW * (1 + pp.n));
+    S::pt_wire(pp.gen, p + PW * (2 + pp.n));
   }
   static bool load_deck(const uint8_t* p, size_t N, Deck& d) {
     d.resize(N);
     bool ok = true;
     for (size_t i = 0; i < N; ++i) {
-      ok &= S::pt_from_wire(p + 128 * i, d[i].c0);
-      ok &= S::pt_from_wire(p + 128 * i + 64, d[i].c1);
+      ok &= S::pt_from_wire(p + 2 * PW * i, d[i].c0);
+      ok &= S::pt_from_wire(p + 2 * PW * i + PW, d[i].c1);
     }
     return ok;
   }
   static void store_deck(const Deck& d, uint8_t* p) {
     for (size_t i = 0; i < d.size(); ++i) {
-      S::pt_wire(d[i].c0, p + 128 * i);
-      S::pt_wire(d[i].c1, p + 128 * i + 64);
+      S::pt_wire(d[i].c0, p + 2 * PW * i);
+      S::pt_wire(d[i].c1, p + 2 * PW * i + PW);
     }
   }
   static bool load_scalars(const uint8_t* p, size_t k, std::vector<Fr>& v) {
@@ -173,7 +179,7 @@ struct Api {
     std::vector<Fr> s;
     std::vector<Pt> p(n);
     bool ok = load_scalars(scalars, n, s);
-    for (size_t i = 0; i < n; ++i) ok &= S::pt_from_wire(points + 64 * i, p[i]);
+    for (size_t i = 0; i < n; ++i) ok &= S::pt_from_wire(points + PW * i, p[i]);
     if (!ok) return -1;
     Jac<Cv> acc = Jac<Cv>::infinity();
     if (algo == 0) {
@@ -212,15 +218,15 @@ struct Api {
     std::vector<Pt> g(nb), a(nb);
     bool ok = true;
     for (uint32_t i = 0; i < nb; ++i) {
-      ok &= S::pt_from_wire(bases + 64 * i, g[i]);
-      ok &= S::pt_from_wire(publics + 64 * i, a[i]);
+      ok &= S::pt_from_wire(bases + PW * i, g[i]);
+      ok &= S::pt_from_wire(publics + PW * i, a[i]);
     }
     Fr xs;
     ok &= Fr::from_bytes(x, xs);
     if (!ok) return -1;
     auto pf = S::sigma_prove(g, a, xs, fs_init, fs_len, seed);
-    for (uint32_t i = 0; i < nb; ++i) S::pt_wire(pf.A[i], out + 64 * i);
-    pf.z.to_bytes(out + 64 * nb);
+    for (uint32_t i = 0; i < nb; ++i) S::pt_wire(pf.A[i], out + PW * i);
+    pf.z.to_bytes(out + PW * nb);
     return 0;
   }
   static int sigma_verify(uint32_t nb, const uint8_t* bases, const uint8_t* publics, const uint8_t* proof, const uint8_t* fs_init,
@@ -230,11 +236,11 @@ struct Api {
     pf.A.resize(nb);
     bool ok = true;
     for (uint32_t i = 0; i < nb; ++i) {
-      ok &= S::pt_from_wire(bases + 64 * i, g[i]);
-      ok &= S::pt_from_wire(publics + 64 * i, a[i]);
-      ok &= S::pt_from_wire(proof + 64 * i, pf.A[i]);
+      ok &= S::pt_from_wire(bases + PW * i, g[i]);
+      ok &= S::pt_from_wire(publics + PW * i, a[i]);
+      ok &= S::pt_from_wire(proof + PW * i, pf.A[i]);
     }
-    ok &= Fr::from_bytes(proof + 64 * nb, pf.z);
+    ok &= Fr::from_bytes(proof + PW * nb, pf.z);
     if (!ok) return -1;
     return S::sigma_verify(g, a, pf, fs_init, fs_len) ? 0 : (nb == 1 ? 5 : 6);
   }
@@ -242,7 +248,7 @@ struct Api {
   // timed CPU baseline: `iters` prove+verify pairs on inputs gen_inputs(seed + it)
   static int bench(uint32_t m, uint32_t n, uint64_t seed, int iters, double* prove_s, double* verify_s) {
     const size_t N = (size_t)m * n;
-    std::vector<uint8_t> params(64 * (n + 3)), pk(64), deck(128 * N), rho(32 * N), pseed(32), outd(128 * N),
+    std::vector<uint8_t> params(PW * (n + 3)), pk(PW), deck(2 * PW * N), rho(32 * N), pseed(32), outd(2 * PW * N),
         proof(S::proof_size(m, n));
     std::vector<uint32_t> perm(N);
     *prove_s = *verify_s = 0;
@@ -269,12 +275,17 @@ struct Api {
     case 0: return Api<Stark>::call;            \
     case 1: return Api<Bn254>::call;            \
     case 2: return Api<Secp256k1>::call;        \
+    case 3: return Api<Bls12_377>::call;        \
     default: return -100;                       \
   }
 
 extern "C" {
 
-size_t mpo_proof_size(uint32_t m, uint32_t n) { return Shuffle<Stark>::proof_size(m, n); }
+size_t mpo_proof_size(uint32_t m, uint32_t n) { return Shuffle<Stark>::proof_size(m, n); }   // the 256-bit curves
+size_t mpo_point_size(int curve) { return curve == 3 ? Shuffle<Bls12_377>::PW : Shuffle<Stark>::PW; }
+size_t mpo_proof_size_curve(int curve, uint32_t m, uint32_t n) {
+  return curve == 3 ? Shuffle<Bls12_377>::proof_size(m, n) : Shuffle<Stark>::proof_size(m, n);
+}
 
 int mpo_gen_inputs(int curve, uint32_t m, uint32_t n, uint64_t seed, uint8_t* params, uint8_t* pk, uint8_t* deck,
                    uint8_t* rho, uint32_t* perm, uint8_t* prover_seed) {

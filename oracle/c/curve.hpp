@@ -11,12 +11,14 @@
 
 namespace mpo {
 
-struct StarkFq { static const u64 MOD[4]; };
-struct StarkFr { static const u64 MOD[4]; };
-struct Bn254Fq { static const u64 MOD[4]; };
-struct Bn254Fr { static const u64 MOD[4]; };
-struct SecpFq { static const u64 MOD[4]; };
-struct SecpFr { static const u64 MOD[4]; };
+struct StarkFq { static const int NL = 4; static const u64 MOD[4]; };
+struct StarkFr { static const int NL = 4; static const u64 MOD[4]; };
+struct Bn254Fq { static const int NL = 4; static const u64 MOD[4]; };
+struct Bn254Fr { static const int NL = 4; static const u64 MOD[4]; };
+struct SecpFq { static const int NL = 4; static const u64 MOD[4]; };
+struct SecpFr { static const int NL = 4; static const u64 MOD[4]; };
+struct Bls377Fq { static const int NL = 6; static const u64 MOD[6]; };   // 377-bit base field: ark-ff Fp384
+struct Bls377Fr { static const int NL = 4; static const u64 MOD[4]; };
 
 struct Stark {
   typedef Fp<StarkFq> Fq;
@@ -38,6 +40,16 @@ struct Secp256k1 {
   static const int A = 0;
   static const u64 B[4], GX[4], GY[4];
   static const int ID = 2;
+};
+
+// BLS12-377 G1 [REF barnett-smart-card-protocol/examples/parameter_selection.rs:25]; cofactor != 1 -- the protocol only
+// ever sees multiples of the generator (prime-order subgroup)
+struct Bls12_377 {
+  typedef Fp<Bls377Fq> Fq;
+  typedef Fp<Bls377Fr> Fr;
+  static const int A = 0;
+  static const u64 B[6], GX[6], GY[6];
+  static const int ID = 3;
 };
 
 template <class Cv>
@@ -200,7 +212,7 @@ Jac<Cv> msm_pippenger(const typename Cv::Fr* scalars, const Affine<Cv>* bases, s
     for (size_t i = 0; i < size; ++i) {
       const u64* k = ks[i].l;
       if ((k[0] | k[1] | k[2] | k[3]) == 0) continue;
-      if (cmp256(k, one) == 0) {
+      if (cmpN(k, one, 4) == 0) {
         if (w_start == 0) res = res.add_mixed(bases[i]);
         continue;
       }

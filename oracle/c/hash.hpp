@@ -168,7 +168,7 @@ F field_rand(Rng& rng) {
     F f;
     for (int i = 0; i < 4; ++i) f.v[i] = rng.next_u64();
     if (shave) f.v[3] &= (~(uint64_t)0) >> shave;
-    if (cmp256(f.v, F::modulus()) < 0) return f;
+    if (cmpN(f.v, F::modulus(), 4) < 0) return f;   // scalar fields only (4 limbs)
   }
 }
 

@@ -45,39 +45,41 @@ struct Shuffle {
   };
 
   // ---------------------------------------------------------------- encodings
+  static const size_t FQB = Fq::BYTES;   // bytes of a base-field coordinate (32; 48 on BLS12-377)
+  static const size_t PW = 2 * FQB;      // wire size of a point
   static void pt_tobytes(const Pt& P, std::vector<uint8_t>& out) {  // ark ToBytes: x || y || inf
-    uint8_t b[65];
+    uint8_t b[2 * Fq::BYTES + 1];
     if (P.inf) {
-      memset(b, 0, 65);
-      b[32] = 1;
-      b[64] = 1;
+      memset(b, 0, PW + 1);
+      b[FQB] = 1;
+      b[PW] = 1;
     } else {
       P.x.to_bytes(b);
-      P.y.to_bytes(b + 32);
-      b[64] = 0;
+      P.y.to_bytes(b + FQB);
+      b[PW] = 0;
     }
-    out.insert(out.end(), b, b + 65);
+    out.insert(out.end(), b, b + PW + 1);
   }
   static void pts_tobytes(const PtVec& v, std::vector<uint8_t>& out) {
     for (auto& P : v) pt_tobytes(P, out);
   }
   static void pt_wire(const Pt& P, uint8_t* out) {
     if (P.inf) {
-      memset(out, 0, 64);  // infinity = (0, 0): on none of the curves (b != 0)
+      memset(out, 0, PW);  // infinity = (0, 0): on none of the curves (b != 0)
     } else {
       P.x.to_bytes(out);
-      P.y.to_bytes(out + 32);
+      P.y.to_bytes(out + FQB);
     }
   }
   static bool pt_from_wire(const uint8_t* in, Pt& P) {
     bool allzero = true;
-    for (int i = 0; i < 64; ++i) allzero &= in[i] == 0;
+    for (size_t i = 0; i < PW; ++i) allzero &= in[i] == 0;
     if (allzero) {
       P = Pt::infinity();
       return true;
     }
     P.inf = false;
-    return Fq::from_bytes(in, P.x) && Fq::from_bytes(in + 32, P.y);
+    return Fq::from_bytes(in, P.x) && Fq::from_bytes(in + FQB, P.y);
   }
 
   // ---------------------------------------------------------------- group helpers
@@ -174,11 +176,11 @@ struct Shuffle {
     MexpProof mexp;
   };
 
-  static size_t proof_size(uint32_t m, uint32_t n) { return (size_t)(11 * m + 8) * 64 + (size_t)(5 * n + 9) * 32; }
+  static size_t proof_size(uint32_t m, uint32_t n) { return (size_t)(11 * m + 8) * PW + (size_t)(5 * n + 9) * 32; }
 
   static void proof_to_bytes(const Proof& pf, uint8_t* out) {
     uint8_t* o = out;
-    auto P = [&](const Pt& p) { pt_wire(p, o); o += 64; };
+    auto P = [&](const Pt& p) { pt_wire(p, o); o += PW; };
     auto S = [&](const Fr& s) { s.to_bytes(o); o += 32; };
     for (auto& p : pf.cA) P(p);
     for (auto& p : pf.cB) P(p);
@@ -206,7 +208,7 @@ struct Shuffle {
   static bool proof_from_bytes(const uint8_t* in, uint32_t m, uint32_t n, Proof& pf) {
     const uint8_t* o = in;
     bool ok = true;
-    auto P = [&](Pt& p) { ok &= pt_from_wire(o, p); o += 64; };
+    auto P = [&](Pt& p) { ok &= pt_from_wire(o, p); o += PW; };
     auto S = [&](Fr& s) { ok &= Fr::from_bytes(o, s); o += 32; };
     pf.cA.resize(m); pf.cB.resize(m);
     for (auto& p : pf.cA) P(p);

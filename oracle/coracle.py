@@ -6,7 +6,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libmporacle.so")
-CURVE_IDS = {"stark": 0, "bn254": 1, "secp256k1": 2}
+CURVE_IDS = {"stark": 0, "bn254": 1, "secp256k1": 2, "bls12_377": 3}
 CHECK_NAMES = {0: "Ok", 1: "Hadamard Product (5.1)", 2: "Zero Argument (5.2)",
                3: "Single Value Product (5.3)", 4: "Multi-Exponentiation Argument (4)"}
 CHECK_NAMES_ALL = {**CHECK_NAMES, 5: "Schnorr Identification", 6: "Chaum-Pedersen"}
@@ -22,6 +22,10 @@ def _load():
     lib = ctypes.CDLL(_LIB)
     lib.mpo_proof_size.restype = ctypes.c_size_t
     lib.mpo_proof_size.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    lib.mpo_proof_size_curve.restype = ctypes.c_size_t
+    lib.mpo_proof_size_curve.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
+    lib.mpo_point_size.restype = ctypes.c_size_t
+    lib.mpo_point_size.argtypes = [ctypes.c_int]
     return lib
 
 
@@ -43,14 +47,20 @@ def _in(b):
     return (ctypes.c_uint8 * len(b)).from_buffer_copy(bytes(b)) if len(b) else (ctypes.c_uint8 * 1)()
 
 
-def proof_size(m, n):
-    return lib().mpo_proof_size(m, n)
+def proof_size(m, n, curve="stark"):
+    return lib().mpo_proof_size_curve(CURVE_IDS[curve], m, n)
+
+
+def point_size(curve):
+    """wire bytes of one affine point: 64, or 96 on BLS12-377"""
+    return lib().mpo_point_size(CURVE_IDS[curve])
 
 
 def gen_inputs(curve, m, n, seed):
     """-> dict(params, pk, deck, rho, perm, prover_seed) in boundary (wire) bytes"""
     N = m * n
-    params, pk, deck, rho, ps = _buf(64 * (n + 3)), _buf(64), _buf(128 * N), _buf(32 * N), _buf(32)
+    pw = point_size(curve)
+    params, pk, deck, rho, ps = _buf(pw * (n + 3)), _buf(pw), _buf(2 * pw * N), _buf(32 * N), _buf(32)
     perm = (ctypes.c_uint32 * N)()
     rc = lib().mpo_gen_inputs(CURVE_IDS[curve], m, n, ctypes.c_uint64(seed), params, pk, deck, rho, perm, ps)
     assert rc == 0, rc
@@ -60,7 +70,7 @@ def gen_inputs(curve, m, n, seed):
 
 def shuffle_and_remask(curve, m, n, params, pk, deck, rho, perm, prover_seed):
     N = m * n
-    out_deck, out_proof = _buf(128 * N), _buf(proof_size(m, n))
+    out_deck, out_proof = _buf(2 * point_size(curve) * N), _buf(proof_size(m, n, curve))
     p = (ctypes.c_uint32 * N)(*perm)
     rc = lib().mpo_shuffle_and_remask(CURVE_IDS[curve], m, n, _in(params), _in(pk), _in(deck), _in(rho), p,
                                       _in(prover_seed), out_deck, out_proof)
@@ -70,13 +80,13 @@ def shuffle_and_remask(curve, m, n, params, pk, deck, rho, perm, prover_seed):
 
 
 def verify_shuffle(curve, m, n, params, pk, deck, shuffled, proof):
-    assert len(proof) == proof_size(m, n)
+    assert len(proof) == proof_size(m, n, curve)
     return lib().mpo_verify_shuffle(CURVE_IDS[curve], m, n, _in(params), _in(pk), _in(deck), _in(shuffled), _in(proof))
 
 
 def remask_deck(curve, G, pk, deck, rho, perm=None):
-    N = len(deck) // 128
-    out = _buf(128 * N)
+    N = len(deck) // (2 * point_size(curve))
+    out = _buf(2 * point_size(curve) * N)
     p = (ctypes.c_uint32 * N)(*perm) if perm is not None else None
     rc = lib().mpo_remask_deck(CURVE_IDS[curve], _in(G), _in(pk), _in(deck), ctypes.c_size_t(N), _in(rho), p, out)
     assert rc == 0, rc
@@ -85,14 +95,14 @@ def remask_deck(curve, G, pk, deck, rho, perm=None):
 
 def msm(curve, scalars, points, algo=0):
     n = len(scalars) // 32
-    out = _buf(64)
+    out = _buf(point_size(curve))
     rc = lib().mpo_msm(CURVE_IDS[curve], _in(scalars), _in(points), ctypes.c_size_t(n), algo, out)
     assert rc == 0, rc
     return bytes(out)
 
 
 def commit(curve, n, params, v, r):
-    out = _buf(64)
+    out = _buf(point_size(curve))
     rc = lib().mpo_commit(CURVE_IDS[curve], n, _in(params), _in(v), ctypes.c_size_t(len(v) // 32), _in(r), out)
     assert rc == 0, rc
     return bytes(out)
@@ -113,7 +123,7 @@ def on_curve(curve, pt):
 
 def sigma_prove(curve, nbases, bases, publics, x, fs_init, seed):
     """Schnorr (1 base) / Chaum-Pedersen (2 bases) proof; fs_init = the bytes the FiatShamirRng is seeded from"""
-    out = _buf(64 * nbases + 32)
+    out = _buf(point_size(curve) * nbases + 32)
     rc = lib().mpo_sigma_prove(CURVE_IDS[curve], nbases, _in(bases), _in(publics), _in(x), _in(fs_init),
                                ctypes.c_size_t(len(fs_init)), _in(seed), out)
     assert rc == 0, rc

@@ -44,6 +44,7 @@ class Curve:
         self.name, self.cid, self.p, self.a, self.b, self.q = name, cid, p, a, b, q
         self.G = (gx, gy)
         self.fq_bits = q.bit_length()
+        self.fq_bytes = 8 * ((p.bit_length() + 63) // 64)     # ark-ff limbs: 32 B for <= 256-bit p, 48 B for BLS12-377
         # arkworks REPR_SHAVE_BITS for a 4x64-limb field: 256 - modulus bits
         self.fr_shave = 256 - self.fq_bits
         self.R = 1 << 256
@@ -80,7 +81,17 @@ SECP256K1 = Curve(
     0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798,
     0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8,
 )
-CURVES = {c.name: c for c in (STARK, BN254, SECP256K1)}
+# BLS12-377 G1 (examples/parameter_selection.rs [REF barnett-smart-card-protocol/examples/parameter_selection.rs:25]);
+# constants: SURVEY.md App. C.  Cofactor != 1: every point the protocol touches is a multiple of G (prime-order subgroup).
+BLS12_377 = Curve(
+    "bls12_377", 3,
+    0x01ae3a4617c510eac63b05c06ca1493b1a22d9f300f5138f1ef3622fba094800170b5d44300000008508c00000000001,
+    0, 1,
+    0x12ab655e9a2ca55660b44d1e5c37b00159aa76fed00000010a11800000000001,
+    0x008848defe740a67c8fc6225bf87ff5485951e2caa9d41bb188282c8bd37cb5cd5481512ffcd394eeab9b16eb21be9ef,
+    0x01914a69c5102eff1f674f5d30afeec4bd7fb348ca3e52d96d182ad44fb82305c2fe3d3634a9591afd82de55559c8ea6,
+)
+CURVES = {c.name: c for c in (STARK, BN254, SECP256K1, BLS12_377)}
 
 # ----------------------------------------------------------------------------------------------
 # Group law (Jacobian internally, affine tuples / None = infinity at the interface)
@@ -266,29 +277,67 @@ class FiatShamirRng:
 
 
 def fe_bytes(v):
+    """scalar (Fr): 32 B little-endian"""
     return int(v).to_bytes(32, "little")
+
+
+# Width of a base-field coordinate in bytes (ark-ff limbs * 8): 32 for the 256-bit curves, 48 for BLS12-377.  The
+# encoders below have no curve argument (points are plain tuples), so the width is ambient: every entry point that takes
+# a curve or a Params sets it for the duration of the call (`_with_curve`), tests use `with curve_ctx(cv):`.
+_FQB = 32
+
+
+class curve_ctx:
+    def __init__(self, cv):
+        self.nb = cv.fq_bytes
+
+    def __enter__(self):
+        global _FQB
+        self.old, _FQB = _FQB, self.nb
+
+    def __exit__(self, *a):
+        global _FQB
+        _FQB = self.old
+
+
+def _with_curve(f):
+    import functools
+
+    @functools.wraps(f)
+    def g(cv_or_pp, *a, **k):
+        with curve_ctx(getattr(cv_or_pp, "cv", cv_or_pp)):
+            return f(cv_or_pp, *a, **k)
+    return g
+
+
+def point_bytes():
+    return 2 * _FQB
+
+
+def fq_bytes(v):
+    return int(v).to_bytes(_FQB, "little")
 
 
 def pt_tobytes(P):
     """ark `ToBytes` of an affine point: x || y || infinity flag (GroupAffine::zero() = (0, 1, true))."""
     if P is None:
-        return fe_bytes(0) + fe_bytes(1) + b"\x01"
-    return fe_bytes(P[0]) + fe_bytes(P[1]) + b"\x00"
+        return fq_bytes(0) + fq_bytes(1) + b"\x01"
+    return fq_bytes(P[0]) + fq_bytes(P[1]) + b"\x00"
 
 
 def pt_wire(P):
-    """boundary ("wire") encoding: x LE || y LE, 64 B; infinity = 64 zero bytes ((0,0) is on none of
-    the curves since b != 0; a flag bit would collide with y on the 256-bit secp256k1 field)."""
+    """boundary ("wire") encoding: x LE || y LE (64 B; 96 B on BLS12-377); infinity = all-zero bytes ((0,0) is on none
+    of the curves since b != 0; a flag bit would collide with y on the 256-bit secp256k1 field)."""
     if P is None:
-        return bytes(64)
-    return fe_bytes(P[0]) + fe_bytes(P[1])
+        return bytes(2 * _FQB)
+    return fq_bytes(P[0]) + fq_bytes(P[1])
 
 
 def pt_from_wire(b):
-    assert len(b) == 64
-    if b == bytes(64):
+    assert len(b) == 2 * _FQB
+    if b == bytes(2 * _FQB):
         return None
-    return (int.from_bytes(b[:32], "little"), int.from_bytes(b[32:], "little"))
+    return (int.from_bytes(b[:_FQB], "little"), int.from_bytes(b[_FQB:], "little"))
 
 
 def ct_tobytes(ct):
@@ -576,6 +625,7 @@ def mexp_verify(pp, pk, fs, Crows, C, cA, pf):
         raise VerifyError(4)
 
 
+@_with_curve
 def statement_bytes(pp, pk, deck, shuffled):
     out = pt_tobytes(pp.G) + pt_tobytes(pk) + pt_tobytes(pp.gen)
     out += _pts_bytes(pp.ck) + pt_tobytes(pp.H)
@@ -588,6 +638,7 @@ def statement_bytes(pp, pk, deck, shuffled):
 SHUFFLE_RNG_SEED = b"Shuffle Proof"  # [REF mod.rs:84]
 
 
+@_with_curve
 def shuffle_prove(pp, pk, deck, shuffled, perm, rho, prng):
     """ShuffleArgument::prove  [REF mod.rs:409-415].  shuffled[i] = deck[perm[i]] + E(0; rho[i])."""
     cv, q, m, n = pp.cv, pp.cv.q, pp.m, pp.n
@@ -622,6 +673,7 @@ def shuffle_prove(pp, pk, deck, shuffled, perm, rho, prng):
     return dict(cA=cA, cB=cB, product=product, mexp=mexp)
 
 
+@_with_curve
 def shuffle_verify(pp, pk, deck, shuffled, proof):
     """ShuffleArgument::verify  [REF mod.rs:437-442]; raises VerifyError(code) on the first failing check."""
     cv, q, m, n = pp.cv, pp.cv.q, pp.m, pp.n
@@ -651,6 +703,7 @@ def shuffle_verify(pp, pk, deck, shuffled, proof):
 # ----------------------------------------------------------------------------------------------
 
 
+@_with_curve
 def shuffle_and_remask(pp, pk, deck, masking_factors, perm, prover_seed):
     """DLCards::shuffle_and_remask [REF mod.rs:380-418]; `permute_array(v)[i] = v[mapping[i]]`."""
     permuted = [deck[perm[i]] for i in range(len(deck))]
@@ -660,6 +713,7 @@ def shuffle_and_remask(pp, pk, deck, masking_factors, perm, prover_seed):
     return shuffled, proof
 
 
+@_with_curve
 def verify_shuffle(pp, pk, deck, shuffled, proof):
     """DLCards::verify_shuffle [REF mod.rs:420-443] -> 0 or the code of the first failing check."""
     try:
@@ -674,7 +728,7 @@ def verify_shuffle(pp, pk, deck, shuffled, proof):
 
 
 def proof_size(m, n):
-    return (11 * m + 8) * 64 + (5 * n + 9) * 32
+    return (11 * m + 8) * 2 * _FQB + (5 * n + 9) * 32
 
 
 def proof_to_bytes(pf):
@@ -702,7 +756,7 @@ def proof_from_bytes(buf, m, n):
     pos = [0]
 
     def P():
-        v = pt_from_wire(buf[pos[0]:pos[0] + 64]); pos[0] += 64; return v
+        v = pt_from_wire(buf[pos[0]:pos[0] + 2 * _FQB]); pos[0] += 2 * _FQB; return v
 
     def S():
         v = int.from_bytes(buf[pos[0]:pos[0] + 32], "little"); pos[0] += 32; return v
@@ -742,6 +796,7 @@ def setup(cv, m, n, rng):
     return Params(cv, m, n, G, ck, H, gen)
 
 
+@_with_curve
 def gen_inputs(cv, m, n, seed_u64):
     """seed -> (pp, pk, deck, rho, perm, prover_seed).  Draw order: setup scalars; sk; per card
     (k1, k2) -> deck[i] = (k1*G_std, k2*G_std) [random ciphertext pairs, REF tests.rs:187]; rho_i;
@@ -765,6 +820,7 @@ def gen_inputs(cv, m, n, seed_u64):
     return pp, pk, deck, rho, perm, prover_seed
 
 
+@_with_curve
 def params_to_bytes(pp):
     """boundary layout of the shared parameters: G | ck_0..ck_{n-1} | H | gen   (wire points)"""
     return pt_wire(pp.G) + b"".join(pt_wire(P) for P in pp.ck) + pt_wire(pp.H) + pt_wire(pp.gen)
@@ -775,7 +831,8 @@ def deck_to_bytes(deck):
 
 
 def deck_from_bytes(buf):
-    return [(pt_from_wire(buf[i:i + 64]), pt_from_wire(buf[i + 64:i + 128])) for i in range(0, len(buf), 128)]
+    w = 2 * _FQB
+    return [(pt_from_wire(buf[i:i + w]), pt_from_wire(buf[i + w:i + 2 * w])) for i in range(0, len(buf), 2 * w)]
 
 
 # ----------------------------------------------------------------------------------------------
@@ -799,6 +856,7 @@ SIGMA_NAMES = {1: "Schnorr Identification", 2: "Chaum-Pedersen"}
 CHECK_NAMES.update({5: "Schnorr Identification", 6: "Chaum-Pedersen"})
 
 
+@_with_curve
 def sigma_prove(cv, bases, publics, x, fs_init, prover_seed):
     """-> (commitments, z).  `fs_init` = bytes the FiatShamirRng is seeded from; r = first Fr::rand of
     ChaCha20Rng::from_seed(prover_seed)."""
@@ -810,6 +868,7 @@ def sigma_prove(cv, bases, publics, x, fs_init, prover_seed):
     return A, (r + c * x) % cv.q
 
 
+@_with_curve
 def sigma_verify(cv, bases, publics, proof, fs_init):
     A, z = proof
     fs = FiatShamirRng(fs_init)
@@ -827,8 +886,9 @@ def sigma_proof_bytes(proof):
 
 
 def sigma_proof_from_bytes(buf, nbases):
-    A = [pt_from_wire(buf[64 * i:64 * i + 64]) for i in range(nbases)]
-    return A, int.from_bytes(buf[64 * nbases:64 * nbases + 32], "little")
+    w = 2 * _FQB
+    A = [pt_from_wire(buf[w * i:w * i + w]) for i in range(nbases)]
+    return A, int.from_bytes(buf[w * nbases:w * nbases + 32], "little")
 
 
 def player_keygen(pp, rng):

@@ -24,6 +24,7 @@ def hx(b):
 def curve_kats():
     out = {}
     for name, cv in po.CURVES.items():
+      with po.curve_ctx(cv):          # coordinate width of the encoders (32 B; 48 B on BLS12-377)
         G = cv.G
         pp = po.Params(cv, 1, 1, G, [G], G, G)
         pk = po.pt_mul(cv, 7, G)
@@ -56,6 +57,11 @@ def shuffle_case(curve, m, n, seed):
     pp, pk, deck, rho, perm, ps = po.gen_inputs(cv, m, n, seed)
     sh, pf = po.shuffle_and_remask(pp, pk, deck, rho, perm, ps)
     assert po.verify_shuffle(pp, pk, deck, sh, pf) == 0
+    with po.curve_ctx(cv):
+        return _case_dict(curve, m, n, seed, pp, pk, deck, rho, perm, ps, sh, pf)
+
+
+def _case_dict(curve, m, n, seed, pp, pk, deck, rho, perm, ps, sh, pf):
     return dict(curve=curve, m=m, n=n, seed=seed, params=hx(po.params_to_bytes(pp)), pk=hx(po.pt_wire(pk)),
                 deck=hx(po.deck_to_bytes(deck)), rho=hx(b"".join(po.fe_bytes(r) for r in rho)), perm=perm,
                 prover_seed=hx(ps), shuffled=hx(po.deck_to_bytes(sh)), proof=hx(po.proof_to_bytes(pf)))
@@ -67,7 +73,7 @@ def main():
     with open(os.path.join(HERE, "fs_kats.json"), "w") as f:
         json.dump(fs_kats(), f, indent=1)
     cases = [("stark", 2, 26, 7), ("stark", 4, 13, 9), ("stark", 2, 3, 1), ("stark", 3, 4, 11),
-             ("bn254", 2, 4, 3), ("secp256k1", 3, 3, 5)]
+             ("bn254", 2, 4, 3), ("secp256k1", 3, 3, 5), ("bls12_377", 2, 3, 13)]
     for c in cases:
         with open(os.path.join(HERE, "shuffle_%s_m%d_n%d_s%d.json" % c), "w") as f:
             json.dump(shuffle_case(*c), f, indent=1)

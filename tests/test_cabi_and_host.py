@@ -68,7 +68,8 @@ def emu(native):
 
 
 @pytest.mark.parametrize("name", ["shuffle_stark_m2_n3_s1.json", "shuffle_stark_m3_n4_s11.json", "shuffle_bn254_m2_n4_s3.json",
-                                  "shuffle_secp256k1_m3_n3_s5.json", "shuffle_stark_m4_n13_s9.json"])
+                                  "shuffle_secp256k1_m3_n3_s5.json", "shuffle_stark_m4_n13_s9.json",
+                                  "shuffle_bls12_377_m2_n3_s13.json"])
 def test_kernel_bodies_under_emulation_match_golden(emu, name):
     g = load_json(os.path.join(GOLDEN, name))
     eng = emu(g["curve"])
@@ -82,7 +83,8 @@ def test_kernel_bodies_under_emulation_match_golden(emu, name):
         assert t.verify_shuffle(bytes.fromhex(g["deck"]), deck, proof) == 0
     bad = bytearray(proof)
     bad[-1] ^= 0          # unchanged copy still verifies
-    swapped = deck[128:256] + deck[0:128] + deck[256:]
+    cb = 2 * eng.point_bytes          # one card = two points
+    swapped = deck[cb:2 * cb] + deck[0:cb] + deck[2 * cb:]
     assert eng.check_name(t.verify_shuffle(bytes.fromhex(g["deck"]), swapped, proof)) == "Hadamard Product (5.1)"
     t.close()
 

@@ -28,7 +28,7 @@ def test_survey_kat_stark_point():
 
 
 def test_sizes():
-    assert [can.point_bytes(c) for c in ("stark", "bn254", "secp256k1")] == [32, 32, 33]
+    assert [can.point_bytes(c) for c in ("stark", "bn254", "secp256k1", "bls12_377")] == [32, 32, 33, 48]
     # (11m+8) points + (5n+9) scalars + one u64 per vector-valued element (11 of them)
     assert can.shuffle_proof_serialized_size("stark", 2, 26) == 30 * 32 + 139 * 32 + 11 * 8
     assert can.shuffle_proof_serialized_size("secp256k1", 3, 3) == 41 * 33 + 24 * 32 + 11 * 8
@@ -45,7 +45,8 @@ def test_roundtrip_golden(path):
     sd = can.deck_serialize(cv, deck)
     assert len(sd) == 8 + 2 * m * n * can.point_bytes(cv)
     assert can.deck_deserialize(cv, sd) == deck
-    assert can.masked_card_deserialize(cv, can.masked_card_serialize(cv, deck[:128])) == deck[:128]
+    w = 2 * can.wire_point_bytes(cv)
+    assert can.masked_card_deserialize(cv, can.masked_card_serialize(cv, deck[:w])) == deck[:w]
     sf = can.shuffle_proof_serialize(cv, m, n, proof)
     assert len(sf) == can.shuffle_proof_serialized_size(cv, m, n)
     assert can.shuffle_proof_deserialize(cv, m, n, sf) == proof
@@ -54,11 +55,11 @@ def test_roundtrip_golden(path):
 
 
 def test_infinity_and_errors():
-    for cv in ("stark", "secp256k1"):
+    for cv in ("stark", "secp256k1", "bls12_377"):
         nb = can.point_bytes(cv)
-        inf = can.point_compress(cv, bytes(64))
+        inf = can.point_compress(cv, bytes(can.wire_point_bytes(cv)))
         assert inf == bytes(nb - 1) + b"\x40"
-        assert can.point_decompress(cv, inf) == bytes(64)
+        assert can.point_decompress(cv, inf) == bytes(can.wire_point_bytes(cv))
         with pytest.raises(can.SerializationError):
             can.point_decompress(cv, bytes(nb - 1) + b"\xc0")       # infinity with the sign flag
         with pytest.raises(can.SerializationError):

@@ -46,20 +46,22 @@ def test_golden_vectors(mp, engines, path):
     cards = engines(cv)
     pp = mp.Parameters(m, n, bytes.fromhex(g["params"]))
     pk = bytes.fromhex(g["pk"])
-    deck = _split(bytes.fromhex(g["deck"]), 128)
+    cb = 2 * cards.engine.point_bytes          # one card = two points (128 B; 192 B on BLS12-377)
+    deck = _split(bytes.fromhex(g["deck"]), cb)
     rho = [int.from_bytes(x, "little") for x in _split(bytes.fromhex(g["rho"]), 32)]
     shuffled, proof = cards.shuffle_and_remask(bytes.fromhex(g["prover_seed"]), pp, pk, deck, rho, mp.Permutation(g["perm"]))
     assert b"".join(shuffled).hex() == g["shuffled"]
     assert proof.hex() == g["proof"]
     assert cards.verify_shuffle(pp, pk, deck, shuffled, proof) is None
-    wrong = _split(po.deck_to_bytes(po.gen_inputs(po.CURVES[cv], m, n, g["seed"] + 1000)[2]), 128)
+    with po.curve_ctx(po.CURVES[cv]):
+        wrong = _split(po.deck_to_bytes(po.gen_inputs(po.CURVES[cv], m, n, g["seed"] + 1000)[2]), cb)
     with pytest.raises(mp.CryptoError) as ei:
         cards.verify_shuffle(pp, pk, deck, wrong, proof)
     assert ei.value == mp.CryptoError("Hadamard Product (5.1)")
 
 
 @pytest.mark.parametrize("curve,m,n,B", [("stark", 2, 26, 6), ("stark", 4, 13, 5), ("stark", 6, 5, 3),
-                                         ("bn254", 3, 5, 3), ("secp256k1", 2, 7, 3)])
+                                         ("bn254", 3, 5, 3), ("secp256k1", 2, 7, 3), ("bls12_377", 2, 5, 3)])
 @pytest.mark.parametrize("plan", ["latency", "throughput"])
 def test_batch_matches_oracle(mp, engines, coracle, curve, m, n, B, plan):
     cards = engines(curve)
@@ -73,7 +75,7 @@ def test_batch_matches_oracle(mp, engines, coracle, curve, m, n, B, plan):
         ins.append(g)
     # all proofs of a batch share the table's (params, pk): take decks / rho / perm / seeds from each input set
     res = cards.shuffle_and_remask_batch([g["prover_seed"] for g in ins], pp, pk,
-                                         [_split(g["deck"], 128) for g in ins],
+                                         [_split(g["deck"], 2 * cards.engine.point_bytes) for g in ins],
                                          [[int.from_bytes(x, "little") for x in _split(g["rho"], 32)] for g in ins],
                                          [mp.Permutation(g["perm"]) for g in ins])
     decks, shufs, proofs = [], [], []
@@ -82,7 +84,7 @@ def test_batch_matches_oracle(mp, engines, coracle, curve, m, n, B, plan):
         exp_deck, exp_proof = coracle.shuffle_and_remask(curve, m, n, g0["params"], pk, g["deck"], g["rho"], g["perm"], g["prover_seed"])
         assert b"".join(r[0]) == exp_deck
         assert r[1] == exp_proof
-        decks.append(_split(g["deck"], 128)); shufs.append(r[0]); proofs.append(r[1])
+        decks.append(_split(g["deck"], 2 * cards.engine.point_bytes)); shufs.append(r[0]); proofs.append(r[1])
     assert cards.verify_shuffle_batch(pp, pk, decks, shufs, proofs) == [None] * B
     # mixed batch: proof b checked against the deck of proof b+1 must fail by name, the others pass
     rot = shufs[1:] + shufs[:1]
@@ -100,34 +102,37 @@ def test_wide_fixed_base_windows_match_oracle(mp, coracle, fb_bits):
     g0 = coracle.gen_inputs(cv, m, n, 100)
     pp = mp.Parameters(m, n, g0["params"])
     ins = [coracle.gen_inputs(cv, m, n, 700 + b) for b in range(B)]
-    res = cards.shuffle_and_remask_batch([g["prover_seed"] for g in ins], pp, g0["pk"], [_split(g["deck"], 128) for g in ins],
+    res = cards.shuffle_and_remask_batch([g["prover_seed"] for g in ins], pp, g0["pk"], [_split(g["deck"], 2 * cards.engine.point_bytes) for g in ins],
                                          [[int.from_bytes(x, "little") for x in _split(g["rho"], 32)] for g in ins],
                                          [mp.Permutation(g["perm"]) for g in ins])
     for g, r in zip(ins, res):
         exp_deck, exp_proof = coracle.shuffle_and_remask(cv, m, n, g0["params"], g0["pk"], g["deck"], g["rho"], g["perm"], g["prover_seed"])
         assert b"".join(r[0]) == exp_deck and r[1] == exp_proof
-    assert cards.verify_shuffle_batch(pp, g0["pk"], [_split(g["deck"], 128) for g in ins], [r[0] for r in res], [r[1] for r in res]) == [None] * B
+    assert cards.verify_shuffle_batch(pp, g0["pk"], [_split(g["deck"], 2 * cards.engine.point_bytes) for g in ins], [r[0] for r in res], [r[1] for r in res]) == [None] * B
     wrong = [res[(b + 1) % B][0] for b in range(B)]
-    out = cards.verify_shuffle_batch(pp, g0["pk"], [_split(g["deck"], 128) for g in ins], wrong, [r[1] for r in res])
+    out = cards.verify_shuffle_batch(pp, g0["pk"], [_split(g["deck"], 2 * cards.engine.point_bytes) for g in ins], wrong, [r[1] for r in res])
     assert all(o == mp.CryptoError("Hadamard Product (5.1)") for o in out)
 
 
 @pytest.mark.parametrize("curve,m,n,B", [("stark", 8, 128, 2), ("stark", 16, 64, 1), ("stark", 32, 32, 1),
-                                         ("secp256k1", 2, 26, 3), ("bn254", 2, 26, 2), ("stark", 10, 30, 1)])
+                                         ("secp256k1", 2, 26, 3), ("bn254", 2, 26, 2), ("stark", 10, 30, 1),
+                                         ("bls12_377", 2, 150, 1), ("bls12_377", 6, 50, 1), ("bls12_377", 10, 30, 1),
+                                         ("bls12_377", 12, 25, 1), ("bls12_377", 30, 10, 1)])
 def test_baseline_config_shapes(mp, engines, coracle, curve, m, n, B):
     """the other shapes BASELINE.json / the reference name: 1024-card decks as (8,128), (16,64), (32,32); secp256k1 and
-    bn254 at 52 cards; (10,30) from examples/parameter_selection.rs:41-42 -- bit-exact against the oracle"""
+    bn254 at 52 cards; the five (m,n) pairs of the 300-card sweep on BLS12-377 G1 [REF examples/parameter_selection.rs:25-57]
+    -- bit-exact against the oracle"""
     cards = engines(curve)
     g0 = coracle.gen_inputs(curve, m, n, 900)
     pp = mp.Parameters(m, n, g0["params"])
     ins = [g0] + [coracle.gen_inputs(curve, m, n, 901 + b) for b in range(B - 1)]
-    res = cards.shuffle_and_remask_batch([g["prover_seed"] for g in ins], pp, g0["pk"], [_split(g["deck"], 128) for g in ins],
+    res = cards.shuffle_and_remask_batch([g["prover_seed"] for g in ins], pp, g0["pk"], [_split(g["deck"], 2 * cards.engine.point_bytes) for g in ins],
                                          [[int.from_bytes(x, "little") for x in _split(g["rho"], 32)] for g in ins],
                                          [mp.Permutation(g["perm"]) for g in ins])
     for g, r in zip(ins, res):
         exp_deck, exp_proof = coracle.shuffle_and_remask(curve, m, n, g0["params"], g0["pk"], g["deck"], g["rho"], g["perm"], g["prover_seed"])
         assert b"".join(r[0]) == exp_deck and r[1] == exp_proof
-    decks = [_split(g["deck"], 128) for g in ins]
+    decks = [_split(g["deck"], 2 * cards.engine.point_bytes) for g in ins]
     assert cards.verify_shuffle_batch(pp, g0["pk"], decks, [r[0] for r in res], [r[1] for r in res]) == [None] * B
     bad = list(res[0][0])
     bad[0], bad[1] = bad[1], bad[0]
@@ -237,7 +242,7 @@ def test_usage_errors_are_io_errors(mp, engines, coracle):
     g = coracle.gen_inputs(cv, m, n, 5)
     cards = engines(cv)
     pp = mp.Parameters(m, n, g["params"])
-    deck = _split(g["deck"], 128)
+    deck = _split(g["deck"], 2 * cards.engine.point_bytes)
     rho = [int.from_bytes(x, "little") for x in _split(g["rho"], 32)]
     good = cards.shuffle_and_remask(g["prover_seed"], pp, g["pk"], deck, rho, mp.Permutation(g["perm"]))
     with pytest.raises(mp.CardProtocolError) as e:
@@ -304,7 +309,7 @@ def test_full_size_properties(mp, engines, coracle):
     g = coracle.gen_inputs(cv, m, n, 31337)
     cards = engines(cv)
     pp = mp.Parameters(m, n, g["params"])
-    deck = _split(g["deck"], 128)
+    deck = _split(g["deck"], 2 * cards.engine.point_bytes)
     rng = mp.ChaCha20Rng(b"\x05" * 32)
     q = po.STARK.q
     seeds, rhos, perms = [], [], []
