@@ -109,6 +109,12 @@ int mp_reserve(mp_table* t, size_t B);           /* pre-allocate the batch works
  * and a latency plan (small sub-jobs: ~16x more lanes per proof).  Batches of at most `B` proofs use the latency plan
  * (default 512; 0 = always throughput). */
 int mp_set_latency_batch(mp_table* t, size_t B);
+/* Verification strategy.  on (default): the verifier first evaluates ALL group equations of a proof merged into one
+ * multi-scalar multiplication with random weights derived from the whole proof (soundness loss ~2^-250); a batch in which
+ * every proof passes ends there.  Only if some proof fails is the batch re-evaluated equation by equation, so that the
+ * FIRST failing check is reported by name exactly as the reference does [REF tests.rs:223-225].  off: always evaluate
+ * the equations one by one.  Results (status words) are identical in both modes. */
+int mp_set_merged_verify(mp_table* t, int on);
 
 /* ---- building blocks (host buffers) ------------------------------------------------------------------------
  * mp_remask_batch: out[i] = in[i] + (rho_i * G, rho_i * pk)        [REF remasking.rs:16-18]

@@ -113,6 +113,11 @@ int mp_set_latency_batch(mp_table* t, size_t B) {
   t->set_latency_batch(B);
   return MP_OK;
 }
+int mp_set_merged_verify(mp_table* t, int on) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_merged_verify: null table");
+  t->set_merged_verify(on != 0);
+  return MP_OK;
+}
 int mp_reserve(mp_table* t, size_t B) {
   if (!t || !B) return fail(MP_ERR_BAD_ARGUMENT, "mp_reserve: bad argument");
   MP_TRY

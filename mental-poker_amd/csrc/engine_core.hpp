@@ -84,7 +84,9 @@ struct Table : mp_table {
   struct PlanSet {
     ProvePlan pplan;
     VerifyPlan vplan;
-    PhaseDev pph[5], vph;
+    PhaseDev pph[5], vph, vmph;      // vmph: the merged verification plan (one MSM for all equations)
+    DevBuf<MergeJob> mjobs;
+    DevBuf<MergePair> mpairs;
     DevBuf<uint32_t> draws, lin_src;
     DevBuf<LinJob> lin;
     DevBuf<ProofElem> pwire, vwire;
@@ -98,6 +100,9 @@ struct Table : mp_table {
   DevBuf<uint32_t> fbpts;    // (n+5) affine base points
   DevBuf<uint32_t> FB;       // fixed-base window tables
   Workspace ws;
+  bool merged_verify = true;   // verify_dev screens the batch with the merged equation first (mp_set_merged_verify)
+  void set_merged_verify(bool on) override { merged_verify = on; }
+  DevBuf<uint32_t> vflag;      // [1] "some proof of the batch needs the per-equation pass"
   uint32_t nwin = 0;
   FbGeom fbg{8, 32, 255};
   uint32_t init_seed[8];
@@ -157,6 +162,9 @@ struct Table : mp_table {
       q.table_group = k ? 8u : TABLE_GROUP;
       for (int i = 0; i < 5; ++i) q.pph[i].upload(q.pplan.ph[i], s);
       q.vph.upload(q.vplan.ph, s);
+      q.vmph.upload(q.vplan.mph, s);
+      q.mjobs.upload(q.vplan.mjobs, s);
+      q.mpairs.upload(q.vplan.mpairs, s);
       q.draws.upload(q.pplan.draws, s);
       q.lin.upload(q.pplan.lin, s);
       q.lin_src.upload(q.pplan.lin_src, s);
@@ -234,7 +242,8 @@ struct Table : mp_table {
   void reserve(size_t B) override {
     PlanSet& q = pick((uint32_t)B);
     uint32_t nS = std::max(q.pplan.lay.nS, q.vplan.lay.nS), nP = std::max(q.pplan.lay.nP, q.vplan.lay.nP);
-    uint32_t nJ = std::max(q.pplan.nJ, q.vplan.nJ), nD = q.vph.n_dslots, nT = q.vph.n_tslots;
+    uint32_t nJ = std::max(q.pplan.nJ, q.vplan.nJ), nD = std::max(q.vph.n_dslots, q.vmph.n_dslots),
+             nT = std::max(q.vph.n_tslots, q.vmph.n_tslots);
     for (int i = 0; i < 5; ++i) {
       nD = std::max(nD, q.pph[i].n_dslots);
       nT = std::max(nT, q.pph[i].n_tslots);
@@ -361,6 +370,11 @@ struct Table : mp_table {
   }
 
   // ---------------------------------------------------------------- verify
+  // Two passes.  (1) Screening: all group equations merged with random weights into ONE multi-scalar multiplication
+  // (n + 5 fixed-base terms instead of one per equation and base, a quarter of the doubling chains) -- every honest batch
+  // ends here.  (2) Only if some proof failed the screen: the equations one by one, to report the FIRST failing check by
+  // name as the reference does [REF tests.rs:223-225].  A proof that passes (1) satisfies every equation except with
+  // probability ~2^-250 over weights that depend on the whole proof.
   void verify_dev(size_t B_, const uint8_t* decks, const uint8_t* shuf, const uint8_t* proofs, int32_t* status) override {
     const uint32_t B = (uint32_t)B_;
     reserve(B);
@@ -369,27 +383,43 @@ struct Table : mp_table {
     cur_table_group = q.table_group;
     const VerifyLay& l = q.vplan.lay;
     rt::Stream s = ctx->stream;
-    rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
-    {
-      LoadPointsArgs a{decks, w.P.p, w.status.p, w.Bpad, 2 * N, l.deck};
-      MP_RUN(k_load_points, C, B, 2 * N, a);
-      LoadPointsArgs b{shuf, w.P.p, w.status.p, w.Bpad, 2 * N, l.shuf};
-      MP_RUN(k_load_points, C, B, 2 * N, b);
-      ProofIoArgs pa{const_cast<uint8_t*>(proofs), w.S.p, w.P.p, w.status.p, q.vwire.p, w.Bpad, (uint32_t)proof_size_bytes(m, n, G_::PB)};
-      MP_RUN(k_load_proof, C, B, (uint32_t)q.vplan.wire.size(), pa);
-    }
-    {
-      VerifyFsArgs a{};
-      a.st = statement_args(w, l.deck, l.shuf, l.cA, l.x);
-      a.l = l;
-      MP_RUN(k_verify_fs, C, B, 1, a);
-      VerifyScalArgs sa{w.S.p, w.P.p, w.direct.p, l, q.vplan.cm, w.Bpad};
-      MP_RUN(k_verify_scal, C, B, 1, sa);
-    }
-    run_phase(q.vph, w, B);
-    {
-      VerdictArgs a{w.J.p, w.direct.p, w.status.p, w.Bpad, l.chk_first};
-      MP_RUN(k_verdict, C, B, 1, a);
+    for (int pass = merged_verify ? 0 : 1; pass < 2; ++pass) {
+      const bool merged = pass == 0;
+      rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
+      {
+        LoadPointsArgs a{decks, w.P.p, w.status.p, w.Bpad, 2 * N, l.deck};
+        MP_RUN(k_load_points, C, B, 2 * N, a);
+        LoadPointsArgs b{shuf, w.P.p, w.status.p, w.Bpad, 2 * N, l.shuf};
+        MP_RUN(k_load_points, C, B, 2 * N, b);
+        ProofIoArgs pa{const_cast<uint8_t*>(proofs), w.S.p, w.P.p, w.status.p, q.vwire.p, w.Bpad, (uint32_t)proof_size_bytes(m, n, G_::PB)};
+        MP_RUN(k_load_proof, C, B, (uint32_t)q.vplan.wire.size(), pa);
+      }
+      {
+        VerifyFsArgs a{};
+        a.st = statement_args(w, l.deck, l.shuf, l.cA, l.x);
+        a.l = l;
+        a.merge = merged ? 1u : 0u;
+        MP_RUN(k_verify_fs, C, B, 1, a);
+        VerifyScalArgs sa{w.S.p, w.P.p, w.direct.p, l, q.vplan.cm, w.Bpad};
+        MP_RUN(k_verify_scal, C, B, 1, sa);
+      }
+      if (merged) {
+        VerifyMergeArgs ma{w.S.p, q.mjobs.p, q.mpairs.p, w.Bpad};
+        MP_RUN(k_verify_merge, C, B, (uint32_t)q.vplan.mjobs.size(), ma);
+        run_phase(q.vmph, w, B);
+        if (!vflag.n) vflag.alloc(1, s);
+        rt::dzero(vflag.p, 4, s);
+        VerdictMergedArgs a{w.J.p, w.direct.p, w.status.p, vflag.p, w.Bpad, l.chk_merged};
+        MP_RUN(k_verdict_merged, C, B, 1, a);
+        uint32_t flag = 0;
+        rt::d2h(&flag, vflag.p, 4, s);
+        rt::stream_sync(s);
+        if (!flag) break;       // nobody needs a closer look
+      } else {
+        run_phase(q.vph, w, B);
+        VerdictArgs a{w.J.p, w.direct.p, w.status.p, w.Bpad, l.chk_first};
+        MP_RUN(k_verdict, C, B, 1, a);
+      }
     }
     rt::d2d(status, w.status.p, (size_t)B * 4, s);
   }
@@ -515,7 +545,7 @@ struct Table : mp_table {
       o[4] += ph.tables.size(); o[5] += ph.cterms.size() + ph.cterms2.size();
     };
     for (int i = 0; i < 5; ++i) add(ps[0].pplan.ph[i], out);
-    add(ps[0].vplan.ph, out + 6);
+    add(merged_verify ? ps[0].vplan.mph : ps[0].vplan.ph, out + 6);    // what an honest batch executes
     out[12] = nwin; out[13] = fbg.windows; out[14] = N;
   }
   // ---------------------------------------------------------------- sigma protocols
@@ -606,7 +636,7 @@ struct Table : mp_table {
     o += (uint64_t)2 * N * (fbg.windows + 1);  // remask
     *pt = t; *po = o;
     t = 0; o = 0;
-    count(ps[0].vplan.ph, t, o);
+    count(merged_verify ? ps[0].vplan.mph : ps[0].vplan.ph, t, o);
     *vt = t; *vo = o;
   }
 };

@@ -580,6 +580,7 @@ MP_KERNEL(k_prove_scal4, ProveScalArgs, body_prove_scal4)
 struct VerifyFsArgs {
   FsStatementArgs st;
   VerifyLay l;
+  uint32_t merge;      // 1: also derive the weights r_k of the merged equation (verifier-only randomness)
 };
 template <class C>
 MP_HD void body_verify_fs(const VerifyFsArgs& a, uint32_t b, uint32_t y) {
@@ -601,8 +602,45 @@ MP_HD void body_verify_fs(const VerifyFsArgs& a, uint32_t b, uint32_t y) {
   fs_challenges<C>(seed, S, f.Bpad, b, l.svx, NO_SLOT);
   fs_absorb_points<C>(f, P, b, seed, l.mecA0, 1 + 2 * m + 4 * m);  // mecA0, mecB[2m], meE[4m] consecutive
   fs_challenges<C>(seed, S, f.Bpad, b, l.mx, NO_SLOT);
+  if (a.merge) {
+    // Weights of the merged equation: they must depend on EVERY proof element, including the final responses that the
+    // transcript itself never absorbs (a prover who knew r could trade errors between equations through them): absorb
+    // the 5n+9 response scalars (slots 0 .. 5n+8, wire order) and squeeze one weight per check id.
+    typedef typename C::FrP R;
+    StageWriter w = stage_begin(f.stage, f.Bpad, b);
+    for (uint32_t i = 0; i < 5 * l.n + 9; ++i) {
+      uint32_t k[8];
+      fe_to_canonical<R>(ld_fe<R>(S + s_off(l.zabar + i, f.Bpad, b)), k);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) stage_word(w, k[t]);
+    }
+    fs_finish_absorb(w, seed);
+    FrStream st;
+    frstream_init(st, seed);
+    for (uint32_t k = 0; k < (uint32_t)VC_COUNT; ++k) st_fe<R>(S + s_off(l.mr + k, f.Bpad, b), frstream_next<R>(st));
+  }
 }
 MP_KERNEL(k_verify_fs, VerifyFsArgs, body_verify_fs)
+
+// merged scalars: S[dst] = sum_{pairs} S[r] * S[coef]      (lane = (proof, merge job))
+struct VerifyMergeArgs {
+  uint32_t* S;
+  const MergeJob* jobs;
+  const MergePair* pairs;
+  uint32_t Bpad;
+};
+template <class C>
+MP_HD void body_verify_merge(const VerifyMergeArgs& a, uint32_t b, uint32_t y) {
+  typedef typename C::FrP R;
+  const MergeJob job = a.jobs[y];
+  Fe<R> acc = fe_zero<R>();
+  for (uint32_t i = 0; i < job.count; ++i) {
+    const MergePair pr = a.pairs[job.begin + i];
+    acc = fe_add<R>(acc, fe_mul<R>(ld_fe<R>(a.S + s_off(pr.r, a.Bpad, b)), ld_fe<R>(a.S + s_off(pr.coef, a.Bpad, b))));
+  }
+  st_fe<R>(a.S + s_off(job.dst, a.Bpad, b), acc);
+}
+MP_KERNEL(k_verify_merge, VerifyMergeArgs, body_verify_merge)
 
 struct VerifyScalArgs {
   uint32_t* S;
@@ -747,6 +785,26 @@ MP_HD void body_verdict(const VerdictArgs& a, uint32_t b, uint32_t y) {
   a.status[b] = code;
 }
 MP_KERNEL(k_verdict, VerdictArgs, body_verdict)
+
+// merged verification: 0 = every equation holds (up to the 2^-250 chance that random weights hide an error) and every
+// direct check passed; otherwise the proof is marked 1 and the batch flag is raised -- the engine then evaluates the
+// equations one by one to name the first failing check [REF tests.rs:223-225 expects the name]
+struct VerdictMergedArgs {
+  const uint32_t* J;
+  const uint32_t* direct;
+  int32_t* status;
+  uint32_t* flag;        // [1] raised when any proof of the batch needs the per-equation pass
+  uint32_t Bpad, chk_merged;
+};
+template <class C>
+MP_HD void body_verdict_merged(const VerdictMergedArgs& a, uint32_t b, uint32_t y) {
+  if (a.status[b] < 0) return;   // usage error already recorded
+  const bool bad = a.direct[b] != 0 ||
+                   !fe_is_zero(ld_fe<typename C::FqP>(a.J + j_off<C>(a.chk_merged, a.Bpad, b) + 2 * Geo<C>::FW));
+  a.status[b] = bad ? 1 : 0;
+  if (bad) a.flag[0] = 1u;       // same value from every failing lane: no atomic needed
+}
+MP_KERNEL(k_verdict_merged, VerdictMergedArgs, body_verdict_merged)
 
 #undef MP_LD
 #undef MP_ST

@@ -172,6 +172,9 @@ struct VerifyLay {
   uint32_t nP;
   // result slots of the "== O" checks (J arena, >= nP) and their codes
   uint32_t chk_first, n_chk;
+  // merged ("screening") verification: random weights r_k of the MSM checks, the merged scalar of every P slot and of
+  // every fixed base, the J slot of the single merged check
+  uint32_t mr, mvar, mfix, chk_merged;
 };
 
 // wire order of the proof: element = (is_point, slot); identical for prover (source) and verifier (destination)
@@ -602,6 +605,9 @@ static inline VerifyLay make_verify_lay(uint32_t m, uint32_t n) {
   // coefficient block: sized generously; exact use is fixed by make_verify_plan / body_verify_scalars
   l.n_coef = 2 * N + 6 * n + 16 * m + 32;
   l.coef = A(l.n_coef);
+  l.mr = A(VC_COUNT);
+  l.mvar = A(4 * N + 11 * m + 8);      // one per P slot (= nP below)
+  l.mfix = A(n + 5);                   // one per fixed base (FixedBases::count())
   l.nS = s;
   uint32_t p = 0;
   auto Pn = [&](uint32_t cnt) { uint32_t r = p; p += cnt; return r; };
@@ -609,8 +615,10 @@ static inline VerifyLay make_verify_lay(uint32_t m, uint32_t n) {
   l.zcA0 = Pn(1); l.zcBm = Pn(1); l.zcD = Pn(2 * m + 1); l.svcd = Pn(1); l.svcdelta = Pn(1); l.svcDelta = Pn(1);
   l.mecA0 = Pn(1); l.mecB = Pn(2 * m); l.meE = Pn(4 * m);
   l.nP = p;
+  if (l.nP != 4 * N + 11 * m + 8) throw std::logic_error("verify layout: P slot count");
   l.chk_first = l.nP;
-  l.n_chk = VC_COUNT;
+  l.n_chk = VC_COUNT + 1;
+  l.chk_merged = l.chk_first + VC_COUNT;
   return l;
 }
 
@@ -660,31 +668,36 @@ static inline VCoefMap make_vcoef_map(const VerifyLay& l) {
   return c;
 }
 
+// merged scalar dst = sum over pairs S[r] * S[coef]   (kernel k_verify_merge)
+struct MergeJob {
+  uint32_t dst, begin, count;
+};
+struct MergePair {
+  uint32_t r, coef;
+};
 struct VerifyPlan {
   VerifyLay lay;
   VCoefMap cm;
-  Phase ph;
+  Phase ph;             // one MSM per equation: names the first failing check
+  Phase mph;            // all equations merged with random weights into ONE MSM: accept / "look closer"
+  std::vector<MergeJob> mjobs;
+  std::vector<MergePair> mpairs;
   uint32_t nJ;
   std::vector<ProofElem> wire;
 };
 
-static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk, uint32_t point_bytes = 64) {
-  VerifyPlan pl;
-  pl.lay = make_verify_lay(m, n);
-  const VerifyLay& l = pl.lay;
-  pl.cm = make_vcoef_map(l);
-  const VCoefMap& c = pl.cm;
-  const uint32_t N = l.N;
+// The verifier's group equations, each "sum of scalar * point == O" (one description, two consumers: the per-equation plan
+// and the merged plan).  Sink: begin(check id) / var(coef slot, P slot) / fixed(coef slot, base) / end().
+template <class Sink>
+static inline void describe_verify(const VerifyLay& l, const VCoefMap& c, Sink& B) {
+  const uint32_t m = l.m, n = l.n, N = l.N;
   FixedBases fb{n};
-  uint32_t next_partial = l.chk_first + l.n_chk;
-  PhaseBuilder B(pl.ph, next_partial, fchunk, vchunk);
-  auto chk = [&](int id) { return l.chk_first + (uint32_t)id; };
   // VC_HAD_B1
-  B.begin(chk(VC_HAD_B1));
+  B.begin(VC_HAD_B1);
   B.var(c.had_y, l.cA + 0); B.var(l.one, l.cB + 0); B.var(c.minus_one, l.hB + 0); B.fixed(c.had_mz, fb.gsum());
   B.end();
   // VC_ZERO_A
-  B.begin(chk(VC_ZERO_A));
+  B.begin(VC_ZERO_A);
   B.var(l.one, l.zcA0);
   for (uint32_t i = 1; i < m; ++i) { B.var(c.za_cA + i, l.cA + i); B.var(c.za_cB + i, l.cB + i); }
   B.fixed(c.za_gsum, fb.gsum());
@@ -692,51 +705,51 @@ static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchun
   B.fixed(c.za_H, fb.H());
   B.end();
   // VC_ZERO_B
-  B.begin(chk(VC_ZERO_B));
+  B.begin(VC_ZERO_B);
   for (uint32_t j = 0; j < m; ++j) B.var(c.zb_hB + j, l.hB + j);
   B.var(l.one, l.zcBm);
   for (uint32_t j = 0; j < n; ++j) B.fixed(c.zb_ck + j, fb.ck(j));
   B.fixed(c.zb_H, fb.H());
   B.end();
   // VC_ZERO_D
-  B.begin(chk(VC_ZERO_D));
+  B.begin(VC_ZERO_D);
   for (uint32_t k = 0; k < 2 * m + 1; ++k) B.var(c.zd_cD + k, l.zcD + k);
   B.fixed(c.zd_ck0, fb.ck(0)); B.fixed(c.zd_H, fb.H());
   B.end();
   // VC_SVP_A
-  B.begin(chk(VC_SVP_A));
+  B.begin(VC_SVP_A);
   B.var(c.sa_x, l.cb); B.var(l.one, l.svcd);
   for (uint32_t j = 0; j < n; ++j) B.fixed(c.sa_ck + j, fb.ck(j));
   B.fixed(c.sa_H, fb.H());
   B.end();
   // VC_SVP_D
-  B.begin(chk(VC_SVP_D));
+  B.begin(VC_SVP_D);
   B.var(c.sd_x, l.svcDelta); B.var(l.one, l.svcdelta);
   for (uint32_t j = 0; j + 1 < n; ++j) B.fixed(c.sd_ck + j, fb.ck(j));
   B.fixed(c.sd_H, fb.H());
   B.end();
   // VC_ME_EM0/1 : sum x^{i+1} deck_i - E[m] == O
   for (uint32_t comp = 0; comp < 2; ++comp) {
-    B.begin(chk(VC_ME_EM0 + comp));
+    B.begin(VC_ME_EM0 + comp);
     for (uint32_t i = 0; i < N; ++i) B.var(c.em_x + i, l.deck + 2 * i + comp);
     B.var(c.minus_one, l.meE + 2 * m + comp);
     B.end();
   }
   // VC_ME_A
-  B.begin(chk(VC_ME_A));
+  B.begin(VC_ME_A);
   B.var(l.one, l.mecA0);
   for (uint32_t j = 1; j <= m; ++j) B.var(c.ma_x + j, l.cB + (j - 1));
   for (uint32_t j = 0; j < n; ++j) B.fixed(c.ma_ck + j, fb.ck(j));
   B.fixed(c.ma_H, fb.H());
   B.end();
   // VC_ME_B
-  B.begin(chk(VC_ME_B));
+  B.begin(VC_ME_B);
   for (uint32_t k = 0; k < 2 * m; ++k) B.var(c.mb_x + k, l.mecB + k);
   B.fixed(c.mb_ck0, fb.ck(0)); B.fixed(c.mb_H, fb.H());
   B.end();
   // VC_ME_E0/1
   for (uint32_t comp = 0; comp < 2; ++comp) {
-    B.begin(chk(VC_ME_E0 + comp));
+    B.begin(VC_ME_E0 + comp);
     for (uint32_t k = 0; k < 2 * m; ++k) B.var(c.me_x + k, l.meE + 2 * k + comp);
     for (uint32_t i = 0; i < N; ++i) B.var(c.me_c + i, l.shuf + 2 * i + comp);
     if (comp == 0) {
@@ -747,7 +760,65 @@ static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchun
     }
     B.end();
   }
-  pl.nJ = next_partial;
+}
+
+// Sink 1: one MSM per equation, result in the equation's check slot
+struct PerCheckSink {
+  PhaseBuilder& B;
+  uint32_t chk_first;
+  void begin(int id) { B.begin(chk_first + (uint32_t)id); }
+  void var(uint32_t coef, uint32_t pslot) { B.var(coef, pslot); }
+  void fixed(uint32_t coef, uint32_t base) { B.fixed(coef, base); }
+  void end() { B.end(); }
+};
+// Sink 2: records (check, coefficient) per point / base for the merged equation sum_k r_k * (equation k) == O
+struct MergeSink {
+  uint32_t mr;
+  int cur = 0;
+  std::map<uint32_t, std::vector<MergePair>> by_p, by_base;
+  void begin(int id) { cur = id; }
+  void var(uint32_t coef, uint32_t pslot) { by_p[pslot].push_back(MergePair{mr + (uint32_t)cur, coef}); }
+  void fixed(uint32_t coef, uint32_t base) { by_base[base].push_back(MergePair{mr + (uint32_t)cur, coef}); }
+  void end() {}
+};
+
+static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk, uint32_t point_bytes = 64) {
+  VerifyPlan pl;
+  pl.lay = make_verify_lay(m, n);
+  const VerifyLay& l = pl.lay;
+  pl.cm = make_vcoef_map(l);
+  const VCoefMap& c = pl.cm;
+  {
+    uint32_t next_partial = l.chk_first + l.n_chk;
+    PhaseBuilder B(pl.ph, next_partial, fchunk, vchunk);
+    PerCheckSink sink{B, l.chk_first};
+    describe_verify(l, c, sink);
+    pl.nJ = next_partial;
+  }
+  {
+    // merged plan: every distinct point / base once, with the scalar sum_k r_k * coef_k (k_verify_merge).  Fewer
+    // fixed-base terms (n + 5 instead of one per equation and base) and fewer doubling chains (the variable-base terms
+    // fill whole sub-jobs) -- and a single result to test.
+    MergeSink ms{l.mr};
+    describe_verify(l, c, ms);
+    uint32_t next_partial = l.chk_first + l.n_chk;
+    PhaseBuilder B(pl.mph, next_partial, fchunk, vchunk);
+    B.begin(l.chk_merged);
+    auto job = [&](uint32_t dst, const std::vector<MergePair>& v) {
+      pl.mjobs.push_back(MergeJob{dst, (uint32_t)pl.mpairs.size(), (uint32_t)v.size()});
+      pl.mpairs.insert(pl.mpairs.end(), v.begin(), v.end());
+    };
+    for (auto& kv : ms.by_p) {
+      job(l.mvar + kv.first, kv.second);
+      B.var(l.mvar + kv.first, kv.first);
+    }
+    for (auto& kv : ms.by_base) {
+      job(l.mfix + kv.first, kv.second);
+      B.fixed(l.mfix + kv.first, kv.first);
+    }
+    B.end();
+    pl.nJ = std::max(pl.nJ, next_partial);
+  }
   pl.wire = proof_wire_map(l, point_bytes);
   return pl;
 }
