@@ -212,6 +212,47 @@ def test_tampering_names_the_failing_check(mp, engines):
         assert name(mut) == exp
 
 
+def test_merged_and_per_equation_verification_agree(mp, engines):
+    """mp_set_merged_verify: the merged screening pass and the equation-by-equation pass give the same status words on a
+    mixed batch (honest proofs, one tampering per sub-argument, a bad encoding), and an all-honest batch passes in both"""
+    g = load_json(os.path.join(GOLDEN, "shuffle_stark_m3_n4_s11.json"))
+    m, n = g["m"], g["n"]
+    cards = engines("stark")
+    pp = mp.Parameters(m, n, bytes.fromhex(g["params"]))
+    pk = bytes.fromhex(g["pk"])
+    deck, shuf = bytes.fromhex(g["deck"]), bytes.fromhex(g["shuffled"])
+    pf = po.proof_from_bytes(bytes.fromhex(g["proof"]), m, n)
+    q = po.STARK.q
+
+    def tampered(path, key, idx=None):
+        p2 = copy.deepcopy(pf)
+        d = p2
+        for k in path:
+            d = d[k]
+        if idx is None:
+            d[key] = (d[key] + 1) % q
+        else:
+            d[key][idx] = (d[key][idx] + 1) % q
+        return po.proof_to_bytes(p2)
+
+    good = bytes.fromhex(g["proof"])
+    proofs = [good, tampered(["product", "had", "zero"], "tbar"), good, tampered(["product", "svp"], "rt"),
+              tampered(["mexp"], "taubar"), tampered(["mexp"], "abar", 1), good]
+    garbage = bytearray(good)
+    garbage[0:32] = b"\xff" * 32                       # x coordinate >= p: bad encoding, reported as a usage error
+    proofs.append(bytes(garbage))
+    B = len(proofs)
+    t = cards.table(pp, pk)
+    out = {}
+    for mode in (True, False):
+        t.set_merged_verify(mode)
+        out[mode] = t.verify_shuffle_batch(deck * B, shuf * B, b"".join(proofs))
+        assert t.verify_shuffle_batch(deck * 3, shuf * 3, good * 3) == [0, 0, 0]
+    t.set_merged_verify(True)
+    assert out[True] == out[False]
+    assert out[True] == [0, 2, 0, 3, 4, 4, 0, -1]
+
+
 def _po_args(g):
     cv = po.CURVES[g["curve"]]
     pp, pk, deck, rho, perm, ps = po.gen_inputs(cv, g["m"], g["n"], g["seed"])
