@@ -235,10 +235,12 @@ MP_HD void body_table(const TableArgs& a, uint32_t b, uint32_t y) {
   }
 #pragma unroll 1
   for (uint32_t e0 = 1; e0 < (uint32_t)VB_ENTRIES; e0 *= 2) {   // targets: entries e0 .. 2*e0-1
-    // pass 1: denominators (2y for a doubling, x_b - x_a for an addition) and their running product
+    // pass 1: denominators (2y for a doubling, x_b - x_a for an addition) and their running product.  Every addition of
+    // the round has the same first operand (2^k P, entry e0 - 1): loaded once per base, not once per target.
     Fe<F> prod = fe_one<F>();
     for (uint32_t g = g0; g < g1; ++g) {
       const uint32_t ts = a.list[g].b;
+      const Fe<F> xa = ld_fe<F>(a.T + p_off<C>(ts * VB_ENTRIES + e0 - 1, a.Bpad, b));
 #pragma unroll 1
       for (uint32_t i = 0; i < e0; ++i) {
         uint32_t ia, ib;
@@ -248,7 +250,7 @@ MP_HD void body_table(const TableArgs& a, uint32_t b, uint32_t y) {
         if (dbl)
           den = fe_dbl<F>(ld_fe<F>(a.T + p_off<C>(ts * VB_ENTRIES + ia, a.Bpad, b) + Geo<C>::FW));
         else
-          den = fe_sub<F>(ld_fe<F>(a.T + p_off<C>(ts * VB_ENTRIES + ib, a.Bpad, b)), ld_fe<F>(a.T + p_off<C>(ts * VB_ENTRIES + ia, a.Bpad, b)));
+          den = fe_sub<F>(ld_fe<F>(a.T + p_off<C>(ts * VB_ENTRIES + ib, a.Bpad, b)), xa);
         st_fe<F>(a.scratch + f_off<C>(ts * 8 + i, a.Bpad, b), prod);
         if (!fe_is_zero(den)) prod = fe_mul<F>(prod, den);   // zero only for P = infinity (prime-order group)
       }
@@ -257,15 +259,17 @@ MP_HD void body_table(const TableArgs& a, uint32_t b, uint32_t y) {
     // pass 2 (exact reverse order): slope, new point
     for (uint32_t g = g1; g-- > g0;) {
       const uint32_t ts = a.list[g].b;
+      const Aff<C> pe = ld_aff<C>(a.T + p_off<C>(ts * VB_ENTRIES + e0 - 1, a.Bpad, b));   // 2^k P
 #pragma unroll 1
       for (uint32_t i = e0; i-- > 0;) {
         uint32_t ia, ib;
         bool dbl;
         table_operands(e0 + i + 1, e0, ia, ib, dbl);
-        const Aff<C> pa = ld_aff<C>(a.T + p_off<C>(ts * VB_ENTRIES + ia, a.Bpad, b));
-        Aff<C> pb = pa;
+        Aff<C> pa = pe, pb;
         Fe<F> den;
         if (dbl) {
+          if (ia != e0 - 1) pa = ld_aff<C>(a.T + p_off<C>(ts * VB_ENTRIES + ia, a.Bpad, b));
+          pb = pa;
           den = fe_dbl<F>(pa.y);
         } else {
           pb = ld_aff<C>(a.T + p_off<C>(ts * VB_ENTRIES + ib, a.Bpad, b));
