@@ -383,7 +383,9 @@ struct Table : mp_table {
     cur_table_group = q.table_group;
     const VerifyLay& l = q.vplan.lay;
     rt::Stream s = ctx->stream;
-    for (int pass = merged_verify ? 0 : 1; pass < 2; ++pass) {
+    // small batches (latency plan) go straight to the per-equation pass: with an idle chip the merged MSM is one long
+    // dependency chain and its flag read-back a round trip -- it only pays when lanes are scarce
+    for (int pass = (merged_verify && B > latency_batch) ? 0 : 1; pass < 2; ++pass) {
       const bool merged = pass == 0;
       rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
       {
