@@ -27,8 +27,6 @@ struct CardProtocolError : std::runtime_error {
 };
 
 typedef std::array<uint8_t, 32> Scalar;        // C::ScalarField, little-endian canonical
-typedef std::array<uint8_t, 64> PublicKey;     // el_gamal::PublicKey (affine point)
-typedef std::array<uint8_t, 128> MaskedCard;   // el_gamal::Ciphertext(pub Affine, pub Affine)
 typedef std::vector<uint8_t> ZKProofShuffle;   // shuffle::proof::Proof
 
 struct Permutation {                            // utils::permutation::Permutation
@@ -40,24 +38,30 @@ struct Parameters {                             // discrete_log_cards::Parameter
   std::vector<uint8_t> raw;                     // G | ck_0..ck_{n-1} | H | gen
 };
 
-class DLCards {
+// PB = wire bytes of an affine point on the curve: 64 for the 256-bit curves, 96 for BLS12-377 (mp_point_size)
+template <size_t PB>
+class DLCardsT {
  public:
-  explicit DLCards(int curve_id = MP_CURVE_STARK, int device = 0) {
+  typedef std::array<uint8_t, PB> PublicKey;        // el_gamal::PublicKey (affine point)
+  typedef std::array<uint8_t, 2 * PB> MaskedCard;   // el_gamal::Ciphertext(pub Affine, pub Affine)
+
+  explicit DLCardsT(int curve_id = MP_CURVE_STARK, int device = 0) : curve_(curve_id) {
+    if (mp_point_size(curve_id) != PB) throw CardProtocolError("curve / point size mismatch");
     if (mp_ctx_create(curve_id, device, &ctx_) != MP_OK) throw CardProtocolError(mp_last_error());
   }
-  ~DLCards() {
+  ~DLCardsT() {
     if (table_) mp_table_destroy(table_);
     mp_ctx_destroy(ctx_);
   }
-  DLCards(const DLCards&) = delete;
-  DLCards& operator=(const DLCards&) = delete;
+  DLCardsT(const DLCardsT&) = delete;
+  DLCardsT& operator=(const DLCardsT&) = delete;
 
   // fn setup<R: Rng>(rng, m, n) -> Result<Parameters, CardProtocolError>
   Parameters setup(const std::array<uint8_t, 32>& rng_seed, uint32_t m, uint32_t n) {
     Parameters pp;
     pp.m = m;
     pp.n = n;
-    pp.raw.resize(mp_params_size(n));
+    pp.raw.resize(mp_params_size_curve(curve_, n));
     if (mp_setup(ctx_, m, n, rng_seed.data(), pp.raw.data()) != MP_OK) throw CardProtocolError(mp_last_error());
     return pp;
   }
@@ -73,7 +77,7 @@ class DLCards {
       throw CardProtocolError("deck, masking factors and permutation must have m*n entries");
     bind(pp, shared_key);
     std::vector<MaskedCard> out(N);
-    ZKProofShuffle proof(mp_proof_size(pp.m, pp.n));
+    ZKProofShuffle proof(mp_proof_size_curve(curve_, pp.m, pp.n));
     int rc = mp_shuffle_and_remask(table_, deck[0].data(), masking_factors[0].data(), permutation.mapping.data(), rng_seed.data(),
                                    out[0].data(), proof.data());
     if (rc != MP_OK) throw CardProtocolError(mp_last_error());
@@ -103,11 +107,16 @@ class DLCards {
     bound_pk_ = pk;
     bound_m_ = pp.m;
   }
+  int curve_;
   mp_ctx* ctx_ = nullptr;
   mp_table* table_ = nullptr;
   std::vector<uint8_t> bound_params_;
   PublicKey bound_pk_{};
   uint32_t bound_m_ = 0;
 };
+typedef DLCardsT<64> DLCards;              // DLCards<starknet_curve / bn254 / secp256k1>
+typedef DLCardsT<96> DLCardsBls12_377;     // DLCards<ark_bls12_377::G1Projective> [REF examples/parameter_selection.rs:25-29]
+typedef DLCards::PublicKey PublicKey;
+typedef DLCards::MaskedCard MaskedCard;
 
 }  // namespace barnett_smart
