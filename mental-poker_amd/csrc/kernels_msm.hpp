@@ -202,10 +202,20 @@ MP_KERNEL(k_recode, RecodeArgs, body_recode)
 
 // ---- per-proof window tables: multiples 1P..16P of every variable base, AFFINE, built with batched affine
 // additions.  One lane owns a group of up to TABLE_GROUP bases of one proof.  The multiples are produced in four
-// rounds -- {2P}, {3P,4P}, {5P..8P}, {9P..16P}: tP = 2*(t/2)P for even t, tP = 2^k P + (t-2^k)P for odd t, so
-// every operand comes from an earlier round -- and ALL slopes of a round (up to 8 x TABLE_GROUP) share ONE
-// Fermat inversion (Montgomery's trick; prefix products through HBM scratch).
-// ~5M + 1S per entry plus 4/15 of 1/64 of an inversion, against 7M+4S (Jacobian chain) + ~13M (normalisation).
+// rounds -- {2P}, {3P,4P}, {5P..8P}, {9P..16P} -- from the PREVIOUS round's outputs only:
+//      even t:  tP = 2 * (t/2)P                      odd t:  tP = aP + (a+1)P,  a = (t-1)/2
+// and ALL slopes of a round (up to 8 x TABLE_GROUP) share ONE Fermat inversion (Montgomery's trick; prefix products
+// through HBM scratch).  ~5M + 1S per entry plus 4/15 of 1/64 of an inversion, against 7M+4S (Jacobian chain) + ~13M
+// (normalisation).
+// The kernel is HBM-bound, so the passes are arranged to touch memory as little as possible:
+//   * the denominators of round r+1 (2 y_s, x_{s+1} - x_s) are functions of round r's outputs: their running product is
+//     accumulated WHILE round r writes those outputs (no separate pass that re-reads them);
+//   * a round's operands are consecutive entries of the previous round, consumed in order: each is loaded once and slides
+//     through two registers (lo, hi) instead of being re-read per target;
+//   * Montgomery's trick needs the second pass in the exact reverse order of the products, so the rounds alternate
+//     direction (bases and targets descending, then ascending, ...) -- which is also the order the sliding window wants.
+// Per base: 128 B copy + 15 x (32 + 32) B prefix products + ~15 x 64 B operand reads + 15 x 64 B results
+// = ~3.0 KB instead of 4.2 KB with a separate denominator pass and per-target operand loads.
 static const uint32_t TABLE_GROUP = 64;
 struct TableArgs {
   const uint32_t* P;
@@ -214,89 +224,125 @@ struct TableArgs {
   const Term* list;      // {P slot, table slot}; table slots are 0..n_tables-1 in list order
   uint32_t Bpad, n_tables, group;   // group = bases per lane (<= TABLE_GROUP)
 };
-// operands of target multiple t (entry index t-1) in the round that starts at multiple e0+1 (e0 = 1, 2, 4, 8)
-MP_HD void table_operands(uint32_t t, uint32_t e0, uint32_t& ia, uint32_t& ib, bool& dbl) {
-  dbl = (t & 1u) == 0;
-  if (dbl) {
-    ia = ib = t / 2 - 1;
-  } else {
-    ia = e0 - 1;          // (2^k) P
-    ib = t - e0 - 1;      // (t - 2^k) P
+// Scratch slot (of the 8 per table) of the prefix product for target t of the round with base e0.  A round reads its own
+// slots while it writes the next round's: with this placement (round 2 in the upper half) every slot is read before the
+// next round overwrites it, in both directions -- no second buffer.
+MP_HD uint32_t table_key(uint32_t e0, uint32_t t) { return (e0 == 2 ? 4u : 0u) + (t - e0 - 1); }
+// one prefix-product step of the NEXT round's batch: remember the product so far for target t (multiple t of table ts,
+// round base e0n: targets e0n+1 .. 2 e0n), then fold its denominator in (a zero denominator -- P = infinity on a
+// prime-order group -- is skipped here and in the consuming pass alike)
+template <class C>
+MP_HD void table_emit(const TableArgs& a, uint32_t b, uint32_t ts, uint32_t e0n, uint32_t t, Fe<typename C::FqP>& prod,
+                      const Fe<typename C::FqP>& den) {
+  typedef typename C::FqP F;
+  st_fe<F>(a.scratch + f_off<C>(ts * 8 + table_key(e0n, t), a.Bpad, b), prod);
+  if (!fe_is_zero(den)) prod = fe_mul<F>(prod, den);
+}
+// target t of the current round from its operands (doubling of lo, or lo + hi); consumes one step of the running inverse
+template <class C>
+MP_HD Aff<C> table_step(const TableArgs& a, uint32_t b, uint32_t ts, uint32_t e0, uint32_t t, Fe<typename C::FqP>& inv,
+                        const Aff<C>& lo, const Aff<C>& hi, bool dbl) {
+  typedef typename C::FqP F;
+  const Fe<F> den = dbl ? fe_dbl<F>(lo.y) : fe_sub<F>(hi.x, lo.x);
+  Aff<C> out = aff_inf<C>();
+  if (!fe_is_zero(den)) {
+    const Fe<F> dinv = fe_mul<F>(inv, ld_fe<F>(a.scratch + f_off<C>(ts * 8 + table_key(e0, t), a.Bpad, b)));
+    inv = fe_mul<F>(inv, den);
+    Fe<F> num;
+    if (dbl) {
+      const Fe<F> xx = fe_sqr<F>(lo.x);
+      num = fe_add<F>(fe_dbl<F>(xx), xx);
+      if (C::A == 1) num = fe_add<F>(num, fe_one<F>());
+    } else {
+      num = fe_sub<F>(hi.y, lo.y);
+    }
+    const Fe<F> lam = fe_mul<F>(num, dinv);
+    const Fe<F>& x2 = dbl ? lo.x : hi.x;
+    out.x = fe_sub<F>(fe_sub<F>(fe_sqr<F>(lam), lo.x), x2);
+    out.y = fe_sub<F>(fe_mul<F>(lam, fe_sub<F>(lo.x, out.x)), lo.y);
   }
+  st_aff<C>(a.T + p_off<C>(ts * VB_ENTRIES + t - 1, a.Bpad, b), out);
+  return out;
 }
 template <class C>
 MP_HD void body_table(const TableArgs& a, uint32_t b, uint32_t y) {
   typedef typename C::FqP F;
   const uint32_t g0 = y * a.group;
   const uint32_t g1 = g0 + a.group < a.n_tables ? g0 + a.group : a.n_tables;
-  for (uint32_t g = g0; g < g1; ++g) {   // entry 0 = P
+  // entry 1 = P; denominators of round 1 (target 2 = 2P): bases ascending
+  Fe<F> prod = fe_one<F>();
+  for (uint32_t g = g0; g < g1; ++g) {
     const Term t = a.list[g];
-    st_aff<C>(a.T + p_off<C>(t.b * VB_ENTRIES, a.Bpad, b), ld_aff<C>(a.P + p_off<C>(t.s, a.Bpad, b)));
+    const Aff<C> p1 = ld_aff<C>(a.P + p_off<C>(t.s, a.Bpad, b));
+    st_aff<C>(a.T + p_off<C>(t.b * VB_ENTRIES, a.Bpad, b), p1);
+    table_emit<C>(a, b, t.b, 1, 2, prod, fe_dbl<F>(p1.y));
   }
+  bool desc = true;     // direction of this round = reverse of the order its denominators were multiplied in
 #pragma unroll 1
-  for (uint32_t e0 = 1; e0 < (uint32_t)VB_ENTRIES; e0 *= 2) {   // targets: entries e0 .. 2*e0-1
-    // pass 1: denominators (2y for a doubling, x_b - x_a for an addition) and their running product.  Every addition of
-    // the round has the same first operand (2^k P, entry e0 - 1): loaded once per base, not once per target.
-    Fe<F> prod = fe_one<F>();
-    for (uint32_t g = g0; g < g1; ++g) {
-      const uint32_t ts = a.list[g].b;
-      const Fe<F> xa = ld_fe<F>(a.T + p_off<C>(ts * VB_ENTRIES + e0 - 1, a.Bpad, b));
-#pragma unroll 1
-      for (uint32_t i = 0; i < e0; ++i) {
-        uint32_t ia, ib;
-        bool dbl;
-        table_operands(e0 + i + 1, e0, ia, ib, dbl);
-        Fe<F> den;
-        if (dbl)
-          den = fe_dbl<F>(ld_fe<F>(a.T + p_off<C>(ts * VB_ENTRIES + ia, a.Bpad, b) + Geo<C>::FW));
-        else
-          den = fe_sub<F>(ld_fe<F>(a.T + p_off<C>(ts * VB_ENTRIES + ib, a.Bpad, b)), xa);
-        st_fe<F>(a.scratch + f_off<C>(ts * 8 + i, a.Bpad, b), prod);
-        if (!fe_is_zero(den)) prod = fe_mul<F>(prod, den);   // zero only for P = infinity (prime-order group)
-      }
-    }
+  for (uint32_t e0 = 1; e0 < (uint32_t)VB_ENTRIES; e0 *= 2, desc = !desc) {   // targets: multiples e0+1 .. 2 e0
     Fe<F> inv = fe_inv<F>(prod);
-    // pass 2 (exact reverse order): slope, new point
-    for (uint32_t g = g1; g-- > g0;) {
+    prod = fe_one<F>();
+    const bool emit = 2 * e0 < (uint32_t)VB_ENTRIES;
+    const uint32_t e0n = 2 * e0;
+    for (uint32_t gi = 0; gi < g1 - g0; ++gi) {
+      const uint32_t g = desc ? g1 - 1 - gi : g0 + gi;
       const uint32_t ts = a.list[g].b;
-      const Aff<C> pe = ld_aff<C>(a.T + p_off<C>(ts * VB_ENTRIES + e0 - 1, a.Bpad, b));   // 2^k P
+      const uint32_t* tb = a.T + p_off<C>(ts * VB_ENTRIES, a.Bpad, b);
+      const size_t estride = (size_t)a.Bpad * Geo<C>::PW;          // words between consecutive entries of a table
+      if (e0 == 1) {            // single target 2 = 2 * 1; next round: 4 = 2*2, 3 = 1 + 2 (descending emission)
+        const Aff<C> lo = ld_aff<C>(tb);
+        const Aff<C> o2 = table_step<C>(a, b, ts, 1, 2, inv, lo, lo, true);
+        table_emit<C>(a, b, ts, e0n, 4, prod, fe_dbl<F>(o2.y));
+        table_emit<C>(a, b, ts, e0n, 3, prod, fe_sub<F>(o2.x, lo.x));
+        continue;
+      }
+      const uint32_t h = e0 / 2;                                    // operands: multiples h .. e0 (entries h-1 .. e0-1)
+      if (desc) {
+        // t = 2e0, 2e0-1, ..., e0+1 : dbl(e0), add(e0-1,e0), dbl(e0-1), ..., add(h, h+1)
+        Aff<C> lo = ld_aff<C>(tb + (size_t)(e0 - 1) * estride), hi = lo;
+        Fe<F> prevx = lo.x;                                         // x of the previous output (t + 1)
 #pragma unroll 1
-      for (uint32_t i = e0; i-- > 0;) {
-        uint32_t ia, ib;
-        bool dbl;
-        table_operands(e0 + i + 1, e0, ia, ib, dbl);
-        Aff<C> pa = pe, pb;
-        Fe<F> den;
-        if (dbl) {
-          if (ia != e0 - 1) pa = ld_aff<C>(a.T + p_off<C>(ts * VB_ENTRIES + ia, a.Bpad, b));
-          pb = pa;
-          den = fe_dbl<F>(pa.y);
-        } else {
-          pb = ld_aff<C>(a.T + p_off<C>(ts * VB_ENTRIES + ib, a.Bpad, b));
-          den = fe_sub<F>(pb.x, pa.x);
-        }
-        Aff<C> out = aff_inf<C>();
-        if (!fe_is_zero(den)) {
-          const Fe<F> dinv = fe_mul<F>(inv, ld_fe<F>(a.scratch + f_off<C>(ts * 8 + i, a.Bpad, b)));
-          inv = fe_mul<F>(inv, den);
-          Fe<F> num;
-          if (dbl) {
-            const Fe<F> xx = fe_sqr<F>(pa.x);
-            num = fe_add<F>(fe_dbl<F>(xx), xx);
-            if (C::A == 1) num = fe_add<F>(num, fe_one<F>());
-          } else {
-            num = fe_sub<F>(pb.y, pa.y);
+        for (uint32_t t = 2 * e0; t > e0; --t) {
+          const bool dbl = (t & 1u) == 0;
+          if (!dbl) {                                               // operands (t-1)/2, (t+1)/2: slide down by one
+            hi = lo;
+            lo = ld_aff<C>(tb + (size_t)((t - 1) / 2 - 1) * estride);
           }
-          const Fe<F> lam = fe_mul<F>(num, dinv);
-          out.x = fe_sub<F>(fe_sub<F>(fe_sqr<F>(lam), pa.x), pb.x);
-          out.y = fe_sub<F>(fe_mul<F>(lam, fe_sub<F>(pa.x, out.x)), pa.y);
+          const Aff<C> out = table_step<C>(a, b, ts, e0, t, inv, lo, hi, dbl);
+          if (emit) {
+            if (t < 2 * e0) table_emit<C>(a, b, ts, e0n, 2 * t + 1, prod, fe_sub<F>(prevx, out.x));   // (t) + (t+1)
+            table_emit<C>(a, b, ts, e0n, 2 * t, prod, fe_dbl<F>(out.y));
+            prevx = out.x;
+          }
         }
-        st_aff<C>(a.T + p_off<C>(ts * VB_ENTRIES + e0 + i, a.Bpad, b), out);
+        if (emit)                                                   // (e0) + (e0+1); x of multiple e0 is re-read (32 B)
+          table_emit<C>(a, b, ts, e0n, 2 * e0 + 1, prod, fe_sub<F>(prevx, ld_fe<F>(tb + (size_t)(e0 - 1) * estride)));
+      } else {
+        // t = e0+1, ..., 2e0 : add(h, h+1), dbl(h+1), add(h+1, h+2), ..., dbl(e0)
+        Aff<C> lo = ld_aff<C>(tb + (size_t)(h - 1) * estride), hi = lo;
+        Fe<F> prevx = lo.x;
+        if (emit) prevx = ld_fe<F>(tb + (size_t)(e0 - 1) * estride);    // x of multiple e0: first operand of (e0)+(e0+1)
+#pragma unroll 1
+        for (uint32_t t = e0 + 1; t <= 2 * e0; ++t) {
+          const bool dbl = (t & 1u) == 0;
+          if (!dbl) {                                               // operands a = (t-1)/2 (current hi) and a+1 (loaded)
+            if (t != e0 + 1) lo = hi;
+            hi = ld_aff<C>(tb + (size_t)((t + 1) / 2 - 1) * estride);
+          } else {
+            lo = hi;                                                // 2 * (t/2): the operand loaded last
+          }
+          const Aff<C> out = table_step<C>(a, b, ts, e0, t, inv, lo, hi, dbl);
+          if (emit) {
+            table_emit<C>(a, b, ts, e0n, 2 * t - 1, prod, fe_sub<F>(out.x, prevx));                    // (t-1) + (t)
+            table_emit<C>(a, b, ts, e0n, 2 * t, prod, fe_dbl<F>(out.y));
+            prevx = out.x;
+          }
+        }
       }
     }
   }
 }
-MP_KERNEL_OCC(k_table, TableArgs, body_table, 4)
+MP_KERNEL_OCC(k_table, TableArgs, body_table, 3)
 
 // ---- variable-base MSM (Straus) -----------------------------------------------------------------------
 struct VarArgs {
