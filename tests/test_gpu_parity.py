@@ -241,6 +241,12 @@ def test_merged_and_per_equation_verification_agree(mp, engines):
     garbage = bytearray(good)
     garbage[0:32] = b"\xff" * 32                       # x coordinate >= p: bad encoding, reported as a usage error
     proofs.append(bytes(garbage))
+    # errors that cancel under EQUAL weights: +1 on the H-coefficient of one equation, -1 on the H-coefficient of another
+    # (zero argument, equations A and B) -- the merged equation must still see them (its weights are random)
+    p3 = copy.deepcopy(pf)
+    z = p3["product"]["had"]["zero"]
+    z["rbar"], z["sbar"] = (z["rbar"] + 1) % q, (z["sbar"] - 1) % q
+    proofs.append(po.proof_to_bytes(p3))
     B = len(proofs)
     t = cards.table(pp, pk)
     t.set_latency_batch(0)          # small batches skip the screening pass unless the throughput plan is forced
@@ -252,7 +258,7 @@ def test_merged_and_per_equation_verification_agree(mp, engines):
     t.set_merged_verify(True)
     t.set_latency_batch(512)
     assert out[True] == out[False]
-    assert out[True] == [0, 2, 0, 3, 4, 4, 0, -1]
+    assert out[True] == [0, 2, 0, 3, 4, 4, 0, -1, 2]
 
 
 def _po_args(g):
