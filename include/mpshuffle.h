@@ -67,6 +67,12 @@ size_t mp_point_size(int curve_id);                              /* wire bytes o
 size_t mp_proof_size_curve(int curve_id, uint32_t m, uint32_t n); /* same counts with mp_point_size(curve_id) per point */
 size_t mp_params_size_curve(int curve_id, uint32_t n);            /* (n+3) * mp_point_size(curve_id) */
 
+/* Page-locked host memory for the host-buffer entry points (mp_*_batch): with buffers from mp_host_alloc every transfer is
+ * an asynchronous DMA that overlaps the kernels of the neighbouring chunks; ordinary (pageable) buffers work too, at the
+ * runtime's staging speed.  NULL on failure (mp_last_error). */
+void* mp_host_alloc(size_t bytes);
+void mp_host_free(void* p);
+
 /* ---- DLCards::setup -----------------------------------------------------------------------------------
  * Derives G, ck_0..ck_{n-1}, H, gen = k * G_std with k = Fr::rand(ChaCha20Rng::from_seed(seed)) in that order. */
 int mp_setup(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out_params);

@@ -16,7 +16,7 @@ MP_ERR_BAD_ENCODING, MP_ERR_BAD_PERMUTATION, MP_ERR_BAD_ARGUMENT, MP_ERR_NO_DEVI
 
 SYMBOLS = [
     "mp_ctx_create", "mp_ctx_destroy", "mp_last_error", "mp_check_name", "mp_proof_size", "mp_params_size",
-    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify",
+    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_host_alloc", "mp_host_free",
     "mp_setup", "mp_table_create", "mp_table_create_ex", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
     "mp_shuffle_and_remask_batch", "mp_verify_shuffle_batch", "mp_shuffle_and_remask_batch_dev",
     "mp_verify_shuffle_batch_dev", "mp_sync", "mp_reserve", "mp_set_latency_batch", "mp_remask_batch", "mp_msm", "mp_commit_batch",
@@ -88,6 +88,10 @@ def bind(cdll):
     cdll.mp_params_size.argtypes = [c.c_uint32]
     cdll.mp_params_size.restype = c.c_size_t
     cdll.mp_set_merged_verify.argtypes = [c.c_void_p, c.c_int]
+    cdll.mp_host_alloc.argtypes = [c.c_size_t]
+    cdll.mp_host_alloc.restype = c.c_void_p
+    cdll.mp_host_free.argtypes = [c.c_void_p]
+    cdll.mp_host_free.restype = None
     cdll.mp_point_size.argtypes = [c.c_int]
     cdll.mp_point_size.restype = c.c_size_t
     cdll.mp_proof_size_curve.argtypes = [c.c_int, c.c_uint32, c.c_uint32]

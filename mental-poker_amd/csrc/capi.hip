@@ -1,6 +1,7 @@
 // capi.hip -- the C ABI of libmpshuffle.so (include/mpshuffle.h): argument checking, error mapping and
 // dispatch to the per-curve engines (curve_*.hip).  Mirrors DLCards::{setup, shuffle_and_remask, verify_shuffle}
 // [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:105-121, 380-418, 420-443].
+#include <algorithm>
 #include <cstring>
 
 #include "engine_base.hpp"
@@ -58,6 +59,8 @@ int mp_ctx_create(int curve_id, int device, mp_ctx** out) {
   c->curve = curve_id;
   c->device = device;
   c->stream = rt::stream_create();
+  c->h2d = rt::stream_create();
+  c->d2h = rt::stream_create();
   *out = c;
   return MP_OK;
   MP_CATCH
@@ -65,6 +68,8 @@ int mp_ctx_create(int curve_id, int device, mp_ctx** out) {
 void mp_ctx_destroy(mp_ctx* ctx) {
   if (!ctx) return;
   rt::stream_destroy(ctx->stream);
+  rt::stream_destroy(ctx->h2d);
+  rt::stream_destroy(ctx->d2h);
   delete ctx;
 }
 
@@ -106,7 +111,24 @@ int mp_table_create_ex(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* param
   return MP_OK;
   MP_CATCH
 }
-void mp_table_destroy(mp_table* t) { delete t; }
+void mp_table_destroy(mp_table* t) {
+  if (!t) return;
+  for (auto& st : t->io) {
+    if (st.up) rt::event_destroy(st.up);
+    if (st.done) rt::event_destroy(st.done);
+    if (st.down) rt::event_destroy(st.down);
+  }
+  delete t;
+}
+void* mp_host_alloc(size_t bytes) {
+  try {
+    return rt::host_alloc(bytes);
+  } catch (const std::exception& e) {
+    fail(MP_ERR_INTERNAL, e.what());
+    return nullptr;
+  }
+}
+void mp_host_free(void* p) { rt::host_free(p); }
 
 int mp_set_latency_batch(mp_table* t, size_t B) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_latency_batch: null table");
@@ -158,6 +180,19 @@ int mp_sync(mp_ctx* ctx) {
   MP_CATCH
 }
 
+// ---- host-buffer entry points: the batch is cut into chunks and pipelined -- while the kernels of chunk k run on the
+// context's stream, chunk k+1 is uploaded on a second stream and the results of chunk k-1 are downloaded on a third
+// (PCIe is full duplex).  Staging buffers are persistent (two chunks in flight).  With page-locked caller buffers
+// (mp_host_alloc) every copy is an asynchronous DMA; with pageable buffers the runtime stages them and the overlap is partial.
+static const size_t IO_CHUNK = 65536;   // proofs per chunk: the kernels need ~64 k lanes to run at full rate
+static void io_events(mp_io_stage& st) {
+  if (!st.up) {
+    st.up = rt::event_create();
+    st.done = rt::event_create();
+    st.down = rt::event_create();
+  }
+}
+
 int mp_shuffle_and_remask_batch(mp_table* t, size_t B, const uint8_t* decks, const uint8_t* masking_factors,
                                 const uint32_t* permutations, const uint8_t* prover_seeds, uint8_t* out_decks,
                                 uint8_t* out_proofs, int32_t* status) {
@@ -165,21 +200,43 @@ int mp_shuffle_and_remask_batch(mp_table* t, size_t B, const uint8_t* decks, con
     return fail(MP_ERR_BAD_ARGUMENT, "mp_shuffle_and_remask_batch: bad argument");
   MP_TRY
   rt::set_device(t->ctx->device);
-  rt::Stream s = t->ctx->stream;
-  const size_t N = t->N, psz = proof_size_bytes(t->m, t->n, t->point_bytes);
-  DevBuf<uint8_t> dd, dr, ds, dod, dop;
-  DevBuf<uint32_t> dp;
-  DevBuf<int32_t> dst;
-  dd.alloc(B * N * 2 * t->point_bytes, s, false); dr.alloc(B * N * 32, s, false); dp.alloc(B * N, s, false); ds.alloc(B * 32, s, false);
-  dod.alloc(B * N * 2 * t->point_bytes, s, false); dop.alloc(B * psz, s, false); dst.alloc(B, s, false);
-  rt::h2d(dd.p, decks, B * N * 2 * t->point_bytes, s);
-  rt::h2d(dr.p, masking_factors, B * N * 32, s);
-  rt::h2d(dp.p, permutations, B * N * 4, s);
-  rt::h2d(ds.p, prover_seeds, B * 32, s);
-  t->prove_dev(B, dd.p, dr.p, dp.p, ds.p, dod.p, dop.p, dst.p);
-  rt::d2h(out_decks, dod.p, B * N * 2 * t->point_bytes, s);
-  rt::d2h(out_proofs, dop.p, B * psz, s);
-  rt::d2h(status, dst.p, B * 4, s);
+  rt::Stream s = t->ctx->stream, up = t->ctx->h2d, down = t->ctx->d2h;
+  const size_t N = t->N, psz = proof_size_bytes(t->m, t->n, t->point_bytes), dsz = N * 2 * t->point_bytes;
+  const size_t chunk = std::min(B, IO_CHUNK), nchunks = (B + chunk - 1) / chunk;
+  for (auto& st : t->io) {
+    io_events(st);
+    st.used = false;
+    st.in0.alloc(chunk * dsz, s, false); st.in1.alloc(chunk * N * 32, s, false); st.perm.alloc(chunk * N, s, false);
+    st.in2.alloc(chunk * 32, s, false); st.out0.alloc(chunk * dsz, s, false); st.out1.alloc(chunk * psz, s, false);
+    st.status.alloc(chunk, s, false);
+  }
+  auto upload = [&](size_t k) {
+    mp_io_stage& st = t->io[k & 1];
+    const size_t o = k * chunk, c = std::min(chunk, B - o);
+    if (st.used) rt::stream_wait(up, st.done);          // the kernels of chunk k-2 have consumed these buffers
+    rt::h2d(st.in0.p, decks + o * dsz, c * dsz, up);
+    rt::h2d(st.in1.p, masking_factors + o * N * 32, c * N * 32, up);
+    rt::h2d(st.perm.p, permutations + o * N, c * N * 4, up);
+    rt::h2d(st.in2.p, prover_seeds + o * 32, c * 32, up);
+    rt::event_record(st.up, up);
+  };
+  upload(0);
+  for (size_t k = 0; k < nchunks; ++k) {
+    mp_io_stage& st = t->io[k & 1];
+    const size_t o = k * chunk, c = std::min(chunk, B - o);
+    rt::stream_wait(s, st.up);
+    if (st.used) rt::stream_wait(s, st.down);            // results of chunk k-2 have left the output buffers
+    t->prove_dev(c, st.in0.p, st.in1.p, st.perm.p, st.in2.p, st.out0.p, st.out1.p, st.status.p);
+    rt::event_record(st.done, s);
+    if (k + 1 < nchunks) upload(k + 1);
+    rt::stream_wait(down, st.done);
+    rt::d2h(out_decks + o * dsz, st.out0.p, c * dsz, down);
+    rt::d2h(out_proofs + o * psz, st.out1.p, c * psz, down);
+    rt::d2h(status + o, st.status.p, c * 4, down);
+    rt::event_record(st.down, down);
+    st.used = true;
+  }
+  rt::stream_sync(down);
   rt::stream_sync(s);
   return MP_OK;
   MP_CATCH
@@ -189,16 +246,39 @@ int mp_verify_shuffle_batch(mp_table* t, size_t B, const uint8_t* decks, const u
   if (!t || !B || !decks || !shuffled_decks || !proofs || !status) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_batch: bad argument");
   MP_TRY
   rt::set_device(t->ctx->device);
-  rt::Stream s = t->ctx->stream;
-  const size_t N = t->N, psz = proof_size_bytes(t->m, t->n, t->point_bytes);
-  DevBuf<uint8_t> dd, dsh, dpf;
-  DevBuf<int32_t> dst;
-  dd.alloc(B * N * 2 * t->point_bytes, s, false); dsh.alloc(B * N * 2 * t->point_bytes, s, false); dpf.alloc(B * psz, s, false); dst.alloc(B, s, false);
-  rt::h2d(dd.p, decks, B * N * 2 * t->point_bytes, s);
-  rt::h2d(dsh.p, shuffled_decks, B * N * 2 * t->point_bytes, s);
-  rt::h2d(dpf.p, proofs, B * psz, s);
-  t->verify_dev(B, dd.p, dsh.p, dpf.p, dst.p);
-  rt::d2h(status, dst.p, B * 4, s);
+  rt::Stream s = t->ctx->stream, up = t->ctx->h2d, down = t->ctx->d2h;
+  const size_t N = t->N, psz = proof_size_bytes(t->m, t->n, t->point_bytes), dsz = N * 2 * t->point_bytes;
+  const size_t chunk = std::min(B, IO_CHUNK), nchunks = (B + chunk - 1) / chunk;
+  for (auto& st : t->io) {
+    io_events(st);
+    st.used = false;
+    st.in0.alloc(chunk * dsz, s, false); st.in3.alloc(chunk * dsz, s, false); st.out1.alloc(chunk * psz, s, false);
+    st.status.alloc(chunk, s, false);
+  }
+  auto upload = [&](size_t k) {
+    mp_io_stage& st = t->io[k & 1];
+    const size_t o = k * chunk, c = std::min(chunk, B - o);
+    if (st.used) rt::stream_wait(up, st.done);
+    rt::h2d(st.in0.p, decks + o * dsz, c * dsz, up);
+    rt::h2d(st.in3.p, shuffled_decks + o * dsz, c * dsz, up);
+    rt::h2d(st.out1.p, proofs + o * psz, c * psz, up);
+    rt::event_record(st.up, up);
+  };
+  upload(0);
+  for (size_t k = 0; k < nchunks; ++k) {
+    mp_io_stage& st = t->io[k & 1];
+    const size_t o = k * chunk, c = std::min(chunk, B - o);
+    if (k + 1 < nchunks) upload(k + 1);                  // before verify_dev: it ends with a read-back of the screening flag
+    rt::stream_wait(s, st.up);
+    if (st.used) rt::stream_wait(s, st.down);
+    t->verify_dev(c, st.in0.p, st.in3.p, st.out1.p, st.status.p);
+    rt::event_record(st.done, s);
+    rt::stream_wait(down, st.done);
+    rt::d2h(status + o, st.status.p, c * 4, down);
+    rt::event_record(st.down, down);
+    st.used = true;
+  }
+  rt::stream_sync(down);
   rt::stream_sync(s);
   return MP_OK;
   MP_CATCH

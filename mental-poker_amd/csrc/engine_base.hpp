@@ -112,7 +112,8 @@ struct Profiler {
 struct mp_ctx {
   int curve = 0;
   int device = 0;
-  mp::rt::Stream stream{};
+  mp::rt::Stream stream{};      // all kernels
+  mp::rt::Stream h2d{}, d2h{};  // host-buffer API: uploads and downloads of neighbouring chunks overlap the kernels
   mp::Profiler prof;
 };
 
@@ -123,8 +124,17 @@ struct mp_ctx {
     ctx->prof.end(ctx->stream);                            \
   } while (0)
 
+// device staging of the host-buffer entry points (mp_*_batch): two chunks in flight
+struct mp_io_stage {
+  mp::DevBuf<uint8_t> in0, in1, in2, in3, out0, out1;
+  mp::DevBuf<uint32_t> perm;
+  mp::DevBuf<int32_t> status;
+  mp::rt::Event up = nullptr, done = nullptr, down = nullptr;   // upload finished / kernels finished / download finished
+  bool used = false;
+};
 struct mp_table {
   mp_ctx* ctx = nullptr;
+  mp_io_stage io[2];
   uint32_t m = 0, n = 0, N = 0;
   uint32_t point_bytes = 64;   // wire size of a point on this table's curve (Geo<C>::PB)
   virtual ~mp_table() {}

@@ -65,6 +65,18 @@ inline float event_ms(Event a, Event b) {
   return ms;
 }
 inline void launch_check(const char* name) { check(hipGetLastError(), name); }
+inline void stream_wait(Stream s, Event e) { check(hipStreamWaitEvent(s, e, 0), "stream wait event"); }
+inline void event_sync(Event e) { check(hipEventSynchronize(e), "event sync"); }
+// page-locked host memory: DMA at PCIe speed and truly asynchronous copies (pageable buffers go through the runtime's
+// bounce buffers at ~9 GB/s and block the calling thread)
+inline void* host_alloc(size_t bytes) {
+  void* p = nullptr;
+  check(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault), "hipHostMalloc");
+  return p;
+}
+inline void host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
 
 }  // namespace rt
 }  // namespace mp

@@ -49,6 +49,10 @@ inline void event_record(Event e, Stream) {
 }
 inline float event_ms(Event a, Event b) { return (float)(*b - *a); }
 inline void launch_check(const char*) {}
+inline void stream_wait(Stream, Event) {}
+inline void event_sync(Event) {}
+inline void* host_alloc(size_t bytes) { return dmalloc(bytes); }
+inline void host_free(void* p) { free(p); }
 }  // namespace rt
 }  // namespace mp
 
