@@ -109,6 +109,22 @@ int mp_shuffle_and_remask_batch_dev(mp_table* t, size_t B, const void* d_decks, 
                                     void* d_out_proofs, void* d_status);
 int mp_verify_shuffle_batch_dev(mp_table* t, size_t B, const void* d_decks, const void* d_shuffled_decks,
                                 const void* d_proofs, void* d_status);
+/* ---- keyed batches: one aggregate public key PER PROOF ----------------------------------------------------------------
+ * A card server runs many tables at once; the tables share the public parameters (one mp_table) and differ only in their
+ * aggregate key, which the reference passes per call (`shared_key`, [REF mod.rs:380-386, 420-426]).  shared_keys /
+ * d_keys: B wire points.  The key's terms become per-proof work: the verifier gains one variable-base term, the prover
+ * builds the key's own window tables (2^(5w) pk, w < 51) for the N re-encryptions rho_i * pk -- about 9 % more work per
+ * prove+verify than under the table's fixed key.  Results are byte-identical to a table created with that key. */
+int mp_shuffle_and_remask_batch_keys(mp_table* t, size_t B, const uint8_t* shared_keys, const uint8_t* decks,
+                                     const uint8_t* masking_factors, const uint32_t* permutations, const uint8_t* prover_seeds,
+                                     uint8_t* out_decks, uint8_t* out_proofs, int32_t* status);
+int mp_verify_shuffle_batch_keys(mp_table* t, size_t B, const uint8_t* shared_keys, const uint8_t* decks,
+                                 const uint8_t* shuffled_decks, const uint8_t* proofs, int32_t* status);
+int mp_shuffle_and_remask_batch_keys_dev(mp_table* t, size_t B, const void* d_keys, const void* d_decks,
+                                         const void* d_masking_factors, const void* d_permutations, const void* d_prover_seeds,
+                                         void* d_out_decks, void* d_out_proofs, void* d_status);
+int mp_verify_shuffle_batch_keys_dev(mp_table* t, size_t B, const void* d_keys, const void* d_decks, const void* d_shuffled_decks,
+                                     const void* d_proofs, void* d_status);
 int mp_sync(mp_ctx* ctx);
 int mp_reserve(mp_table* t, size_t B);           /* pre-allocate the batch workspace for B proofs */
 /* Every table holds two static work splits with identical results: a throughput plan (large sub-jobs, fewest operations)

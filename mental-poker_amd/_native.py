@@ -16,7 +16,8 @@ MP_ERR_BAD_ENCODING, MP_ERR_BAD_PERMUTATION, MP_ERR_BAD_ARGUMENT, MP_ERR_NO_DEVI
 
 SYMBOLS = [
     "mp_ctx_create", "mp_ctx_destroy", "mp_last_error", "mp_check_name", "mp_proof_size", "mp_params_size",
-    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_host_alloc", "mp_host_free",
+    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_host_alloc", "mp_host_free", "mp_shuffle_and_remask_batch_keys",
+    "mp_verify_shuffle_batch_keys", "mp_shuffle_and_remask_batch_keys_dev", "mp_verify_shuffle_batch_keys_dev",
     "mp_setup", "mp_table_create", "mp_table_create_ex", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
     "mp_shuffle_and_remask_batch", "mp_verify_shuffle_batch", "mp_shuffle_and_remask_batch_dev",
     "mp_verify_shuffle_batch_dev", "mp_sync", "mp_reserve", "mp_set_latency_batch", "mp_remask_batch", "mp_msm", "mp_commit_batch",
@@ -109,6 +110,10 @@ def bind(cdll):
     cdll.mp_verify_shuffle_batch.argtypes = [c.c_void_p, c.c_size_t, u8p, u8p, u8p, i32p]
     cdll.mp_shuffle_and_remask_batch_dev.argtypes = [c.c_void_p, c.c_size_t] + [c.c_void_p] * 7
     cdll.mp_verify_shuffle_batch_dev.argtypes = [c.c_void_p, c.c_size_t] + [c.c_void_p] * 4
+    cdll.mp_shuffle_and_remask_batch_keys.argtypes = [c.c_void_p, c.c_size_t, u8p, u8p, u8p, u32p, u8p, u8p, u8p, i32p]
+    cdll.mp_verify_shuffle_batch_keys.argtypes = [c.c_void_p, c.c_size_t, u8p, u8p, u8p, u8p, i32p]
+    cdll.mp_shuffle_and_remask_batch_keys_dev.argtypes = [c.c_void_p, c.c_size_t] + [c.c_void_p] * 8
+    cdll.mp_verify_shuffle_batch_keys_dev.argtypes = [c.c_void_p, c.c_size_t] + [c.c_void_p] * 5
     cdll.mp_sync.argtypes = [c.c_void_p]
     cdll.mp_reserve.argtypes = [c.c_void_p, c.c_size_t]
     cdll.mp_set_latency_batch.argtypes = [c.c_void_p, c.c_size_t]
@@ -248,6 +253,33 @@ class Table:
         pm = (ctypes.c_uint32 * (B * N))(*perms)
         self.eng._chk(self.lib.mp_shuffle_and_remask_batch(self.h, B, _in(decks), _in(factors), pm, _in(seeds), out_d, out_p, st))
         return bytes(out_d), bytes(out_p), list(st)
+
+    # ---- keyed batches: one aggregate key per proof (keys: B wire points)
+    def shuffle_and_remask_batch_keys(self, keys, decks, factors, perms, seeds):
+        B = len(seeds) // 32
+        N = self.N
+        assert len(keys) == B * self.pb and len(decks) == B * N * self.cb and len(factors) == B * N * 32 and len(perms) == B * N
+        out_d = (ctypes.c_uint8 * (B * N * self.cb))()
+        out_p = (ctypes.c_uint8 * (B * self.proof_bytes))()
+        st = (ctypes.c_int32 * B)()
+        pm = (ctypes.c_uint32 * (B * N))(*perms)
+        self.eng._chk(self.lib.mp_shuffle_and_remask_batch_keys(self.h, B, _in(keys), _in(decks), _in(factors), pm, _in(seeds), out_d, out_p, st))
+        return bytes(out_d), bytes(out_p), list(st)
+
+    def verify_shuffle_batch_keys(self, keys, decks, shuffled, proofs):
+        N = self.N
+        B = len(decks) // (N * self.cb)
+        assert len(keys) == B * self.pb and len(shuffled) == len(decks) and len(proofs) == B * self.proof_bytes
+        st = (ctypes.c_int32 * B)()
+        self.eng._chk(self.lib.mp_verify_shuffle_batch_keys(self.h, B, _in(keys), _in(decks), _in(shuffled), _in(proofs), st))
+        return list(st)
+
+    def shuffle_and_remask_batch_keys_dev(self, B, d_keys, d_decks, d_factors, d_perms, d_seeds, d_out_decks, d_out_proofs, d_status):
+        self.eng._chk(self.lib.mp_shuffle_and_remask_batch_keys_dev(self.h, B, d_keys, d_decks, d_factors, d_perms, d_seeds,
+                                                                    d_out_decks, d_out_proofs, d_status))
+
+    def verify_shuffle_batch_keys_dev(self, B, d_keys, d_decks, d_shuffled, d_proofs, d_status):
+        self.eng._chk(self.lib.mp_verify_shuffle_batch_keys_dev(self.h, B, d_keys, d_decks, d_shuffled, d_proofs, d_status))
 
     def verify_shuffle_batch(self, decks, shuffled, proofs):
         N = self.N

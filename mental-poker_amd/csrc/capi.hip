@@ -172,6 +172,29 @@ int mp_verify_shuffle_batch_dev(mp_table* t, size_t B, const void* d_decks, cons
   return MP_OK;
   MP_CATCH
 }
+int mp_shuffle_and_remask_batch_keys_dev(mp_table* t, size_t B, const void* d_keys, const void* d_decks, const void* d_masking_factors,
+                                         const void* d_permutations, const void* d_prover_seeds, void* d_out_decks,
+                                         void* d_out_proofs, void* d_status) {
+  if (!t || !B || !d_keys || !d_decks || !d_masking_factors || !d_permutations || !d_prover_seeds || !d_out_decks || !d_out_proofs || !d_status)
+    return fail(MP_ERR_BAD_ARGUMENT, "mp_shuffle_and_remask_batch_keys_dev: bad argument");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  t->prove_dev(B, (const uint8_t*)d_decks, (const uint8_t*)d_masking_factors, (const uint32_t*)d_permutations,
+               (const uint8_t*)d_prover_seeds, (uint8_t*)d_out_decks, (uint8_t*)d_out_proofs, (int32_t*)d_status, (const uint8_t*)d_keys);
+  return MP_OK;
+  MP_CATCH
+}
+int mp_verify_shuffle_batch_keys_dev(mp_table* t, size_t B, const void* d_keys, const void* d_decks, const void* d_shuffled_decks,
+                                     const void* d_proofs, void* d_status) {
+  if (!t || !B || !d_keys || !d_decks || !d_shuffled_decks || !d_proofs || !d_status)
+    return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_batch_keys_dev: bad argument");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  t->verify_dev(B, (const uint8_t*)d_decks, (const uint8_t*)d_shuffled_decks, (const uint8_t*)d_proofs, (int32_t*)d_status,
+                (const uint8_t*)d_keys);
+  return MP_OK;
+  MP_CATCH
+}
 int mp_sync(mp_ctx* ctx) {
   if (!ctx) return fail(MP_ERR_BAD_ARGUMENT, "mp_sync: null");
   MP_TRY
@@ -193,9 +216,9 @@ static void io_events(mp_io_stage& st) {
   }
 }
 
-int mp_shuffle_and_remask_batch(mp_table* t, size_t B, const uint8_t* decks, const uint8_t* masking_factors,
-                                const uint32_t* permutations, const uint8_t* prover_seeds, uint8_t* out_decks,
-                                uint8_t* out_proofs, int32_t* status) {
+static int prove_batch_host(mp_table* t, size_t B, const uint8_t* keys, const uint8_t* decks, const uint8_t* masking_factors,
+                            const uint32_t* permutations, const uint8_t* prover_seeds, uint8_t* out_decks,
+                            uint8_t* out_proofs, int32_t* status) {
   if (!t || !B || !decks || !masking_factors || !permutations || !prover_seeds || !out_decks || !out_proofs || !status)
     return fail(MP_ERR_BAD_ARGUMENT, "mp_shuffle_and_remask_batch: bad argument");
   MP_TRY
@@ -209,6 +232,7 @@ int mp_shuffle_and_remask_batch(mp_table* t, size_t B, const uint8_t* decks, con
     st.in0.alloc(chunk * dsz, s, false); st.in1.alloc(chunk * N * 32, s, false); st.perm.alloc(chunk * N, s, false);
     st.in2.alloc(chunk * 32, s, false); st.out0.alloc(chunk * dsz, s, false); st.out1.alloc(chunk * psz, s, false);
     st.status.alloc(chunk, s, false);
+    if (keys) st.keys.alloc(chunk * t->point_bytes, s, false);
   }
   auto upload = [&](size_t k) {
     mp_io_stage& st = t->io[k & 1];
@@ -218,6 +242,7 @@ int mp_shuffle_and_remask_batch(mp_table* t, size_t B, const uint8_t* decks, con
     rt::h2d(st.in1.p, masking_factors + o * N * 32, c * N * 32, up);
     rt::h2d(st.perm.p, permutations + o * N, c * N * 4, up);
     rt::h2d(st.in2.p, prover_seeds + o * 32, c * 32, up);
+    if (keys) rt::h2d(st.keys.p, keys + o * t->point_bytes, c * t->point_bytes, up);
     rt::event_record(st.up, up);
   };
   upload(0);
@@ -226,7 +251,7 @@ int mp_shuffle_and_remask_batch(mp_table* t, size_t B, const uint8_t* decks, con
     const size_t o = k * chunk, c = std::min(chunk, B - o);
     rt::stream_wait(s, st.up);
     if (st.used) rt::stream_wait(s, st.down);            // results of chunk k-2 have left the output buffers
-    t->prove_dev(c, st.in0.p, st.in1.p, st.perm.p, st.in2.p, st.out0.p, st.out1.p, st.status.p);
+    t->prove_dev(c, st.in0.p, st.in1.p, st.perm.p, st.in2.p, st.out0.p, st.out1.p, st.status.p, keys ? st.keys.p : nullptr);
     rt::event_record(st.done, s);
     if (k + 1 < nchunks) upload(k + 1);
     rt::stream_wait(down, st.done);
@@ -241,8 +266,8 @@ int mp_shuffle_and_remask_batch(mp_table* t, size_t B, const uint8_t* decks, con
   return MP_OK;
   MP_CATCH
 }
-int mp_verify_shuffle_batch(mp_table* t, size_t B, const uint8_t* decks, const uint8_t* shuffled_decks,
-                            const uint8_t* proofs, int32_t* status) {
+static int verify_batch_host(mp_table* t, size_t B, const uint8_t* keys, const uint8_t* decks, const uint8_t* shuffled_decks,
+                             const uint8_t* proofs, int32_t* status) {
   if (!t || !B || !decks || !shuffled_decks || !proofs || !status) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_batch: bad argument");
   MP_TRY
   rt::set_device(t->ctx->device);
@@ -254,6 +279,7 @@ int mp_verify_shuffle_batch(mp_table* t, size_t B, const uint8_t* decks, const u
     st.used = false;
     st.in0.alloc(chunk * dsz, s, false); st.in3.alloc(chunk * dsz, s, false); st.out1.alloc(chunk * psz, s, false);
     st.status.alloc(chunk, s, false);
+    if (keys) st.keys.alloc(chunk * t->point_bytes, s, false);
   }
   auto upload = [&](size_t k) {
     mp_io_stage& st = t->io[k & 1];
@@ -262,6 +288,7 @@ int mp_verify_shuffle_batch(mp_table* t, size_t B, const uint8_t* decks, const u
     rt::h2d(st.in0.p, decks + o * dsz, c * dsz, up);
     rt::h2d(st.in3.p, shuffled_decks + o * dsz, c * dsz, up);
     rt::h2d(st.out1.p, proofs + o * psz, c * psz, up);
+    if (keys) rt::h2d(st.keys.p, keys + o * t->point_bytes, c * t->point_bytes, up);
     rt::event_record(st.up, up);
   };
   upload(0);
@@ -271,7 +298,7 @@ int mp_verify_shuffle_batch(mp_table* t, size_t B, const uint8_t* decks, const u
     if (k + 1 < nchunks) upload(k + 1);                  // before verify_dev: it ends with a read-back of the screening flag
     rt::stream_wait(s, st.up);
     if (st.used) rt::stream_wait(s, st.down);
-    t->verify_dev(c, st.in0.p, st.in3.p, st.out1.p, st.status.p);
+    t->verify_dev(c, st.in0.p, st.in3.p, st.out1.p, st.status.p, keys ? st.keys.p : nullptr);
     rt::event_record(st.done, s);
     rt::stream_wait(down, st.done);
     rt::d2h(status + o, st.status.p, c * 4, down);
@@ -284,6 +311,26 @@ int mp_verify_shuffle_batch(mp_table* t, size_t B, const uint8_t* decks, const u
   MP_CATCH
 }
 
+int mp_shuffle_and_remask_batch(mp_table* t, size_t B, const uint8_t* decks, const uint8_t* masking_factors,
+                                const uint32_t* permutations, const uint8_t* prover_seeds, uint8_t* out_decks,
+                                uint8_t* out_proofs, int32_t* status) {
+  return prove_batch_host(t, B, nullptr, decks, masking_factors, permutations, prover_seeds, out_decks, out_proofs, status);
+}
+int mp_verify_shuffle_batch(mp_table* t, size_t B, const uint8_t* decks, const uint8_t* shuffled_decks,
+                            const uint8_t* proofs, int32_t* status) {
+  return verify_batch_host(t, B, nullptr, decks, shuffled_decks, proofs, status);
+}
+int mp_shuffle_and_remask_batch_keys(mp_table* t, size_t B, const uint8_t* shared_keys, const uint8_t* decks,
+                                     const uint8_t* masking_factors, const uint32_t* permutations, const uint8_t* prover_seeds,
+                                     uint8_t* out_decks, uint8_t* out_proofs, int32_t* status) {
+  if (!shared_keys) return fail(MP_ERR_BAD_ARGUMENT, "mp_shuffle_and_remask_batch_keys: null keys");
+  return prove_batch_host(t, B, shared_keys, decks, masking_factors, permutations, prover_seeds, out_decks, out_proofs, status);
+}
+int mp_verify_shuffle_batch_keys(mp_table* t, size_t B, const uint8_t* shared_keys, const uint8_t* decks,
+                                 const uint8_t* shuffled_decks, const uint8_t* proofs, int32_t* status) {
+  if (!shared_keys) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_batch_keys: null keys");
+  return verify_batch_host(t, B, shared_keys, decks, shuffled_decks, proofs, status);
+}
 int mp_shuffle_and_remask(mp_table* t, const uint8_t* deck, const uint8_t* masking_factors, const uint32_t* permutation,
                           const uint8_t prover_seed[32], uint8_t* out_deck, uint8_t* out_proof) {
   int32_t st = 0;

@@ -126,7 +126,7 @@ struct mp_ctx {
 
 // device staging of the host-buffer entry points (mp_*_batch): two chunks in flight
 struct mp_io_stage {
-  mp::DevBuf<uint8_t> in0, in1, in2, in3, out0, out1;
+  mp::DevBuf<uint8_t> in0, in1, in2, in3, out0, out1, keys;
   mp::DevBuf<uint32_t> perm;
   mp::DevBuf<int32_t> status;
   mp::rt::Event up = nullptr, done = nullptr, down = nullptr;   // upload finished / kernels finished / download finished
@@ -141,9 +141,11 @@ struct mp_table {
   virtual void reserve(size_t B) = 0;
   virtual void set_latency_batch(size_t B) = 0;
   virtual void set_merged_verify(bool on) = 0;
+  // keys: nullptr = the table's own aggregate key; otherwise one wire point per proof (device memory)
   virtual void prove_dev(size_t B, const uint8_t* decks, const uint8_t* rho, const uint32_t* perm, const uint8_t* seeds,
-                         uint8_t* out_decks, uint8_t* out_proofs, int32_t* status) = 0;
-  virtual void verify_dev(size_t B, const uint8_t* decks, const uint8_t* shuf, const uint8_t* proofs, int32_t* status) = 0;
+                         uint8_t* out_decks, uint8_t* out_proofs, int32_t* status, const uint8_t* keys = nullptr) = 0;
+  virtual void verify_dev(size_t B, const uint8_t* decks, const uint8_t* shuf, const uint8_t* proofs, int32_t* status,
+                          const uint8_t* keys = nullptr) = 0;
   virtual void remask_host(size_t count, const uint8_t* cards, const uint8_t* rho, uint8_t* out) = 0;
   virtual void msm_host(size_t n_msm, size_t k, const uint8_t* scalars, const uint8_t* points, uint8_t* out) = 0;
   virtual void commit_host(size_t count, size_t len, const uint8_t* values, const uint8_t* r, uint8_t* out) = 0;

@@ -92,9 +92,13 @@ struct Table : mp_table {
     DevBuf<ProofElem> pwire, vwire;
     uint32_t table_group = TABLE_GROUP;
   };
-  PlanSet ps[2];
+  PlanSet ps[2];        // plans with the table's own aggregate key as a fixed base
+  PlanSet psk[2];       // plans for keyed batches (per-proof aggregate key): built on first use
+  bool psk_ready = false;
+  DevBuf<Term> key_recode, key_tables;          // static job lists of the per-proof key tables
+  uint32_t key_d_first = 0, key_t_first = 0;     // first digit slot (rho_0) / table slot (window 0) of the key machinery
   uint32_t latency_batch = 512;                  // batches up to this size use the latency plan (mp_set_latency_batch)
-  PlanSet& pick(uint32_t B) { return ps[B <= latency_batch ? 1 : 0]; }
+  PlanSet& pick(uint32_t B, bool keyed = false) { return (keyed ? psk : ps)[B <= latency_batch ? 1 : 0]; }
   void set_latency_batch(size_t b) override { latency_batch = (uint32_t)std::min<size_t>(b, 0xFFFFFFFFu); }
   uint32_t cur_table_group = TABLE_GROUP;
   DevBuf<uint32_t> fbpts;    // (n+5) affine base points
@@ -116,6 +120,45 @@ struct Table : mp_table {
     alignas(8) uint8_t tmp[G_::PB];
     memcpy(tmp, p, G_::PB);
     return wire_to_aff<C>(tmp, out);
+  }
+
+  void build_plans(PlanSet* set, bool keyed) {
+    rt::Stream s = ctx->stream;
+    for (int k = 0; k < 2; ++k) {
+      PlanSet& q = set[k];
+      q.pplan = make_prove_plan(m, n, k ? 2u : FCHUNK, k ? 4u : VCHUNK, G_::PB, keyed);
+      q.vplan = make_verify_plan(m, n, k ? 2u : FCHUNK, k ? 4u : VCHUNK, G_::PB, keyed);
+      q.table_group = k ? 8u : TABLE_GROUP;
+      for (int i = 0; i < 5; ++i) q.pph[i].upload(q.pplan.ph[i], s);
+      q.vph.upload(q.vplan.ph, s);
+      q.vmph.upload(q.vplan.mph, s);
+      q.mjobs.upload(q.vplan.mjobs, s);
+      q.mpairs.upload(q.vplan.mpairs, s);
+      q.draws.upload(q.pplan.draws, s);
+      q.lin.upload(q.pplan.lin, s);
+      q.lin_src.upload(q.pplan.lin_src, s);
+      q.pwire.upload(q.pplan.wire, s);
+      q.vwire.upload(q.vplan.wire, s);
+    }
+  }
+  // keyed batches: plans + the static lists that turn a proof's key into window tables (recode rho, tables of 2^(5w) pk)
+  void ensure_keyed() {
+    if (psk_ready) return;
+    build_plans(psk, true);
+    const ProveLay& l = psk[0].pplan.lay;
+    // the key's digit / table slots live behind those of every phase of either plan
+    key_d_first = key_t_first = 0;
+    for (int k = 0; k < 2; ++k)
+      for (int i = 0; i < 5; ++i) {
+        key_d_first = std::max(key_d_first, psk[k].pplan.ph[i].n_dslots);
+        key_t_first = std::max(key_t_first, psk[k].pplan.ph[i].n_tslots);
+      }
+    std::vector<Term> rec, tab;
+    for (uint32_t i = 0; i < N; ++i) rec.push_back(Term{l.rho + i, key_d_first + i});
+    for (uint32_t w = 0; w < nwin; ++w) tab.push_back(Term{l.kw + w, key_t_first + w});
+    key_recode.upload(rec, ctx->stream);
+    key_tables.upload(tab, ctx->stream);
+    psk_ready = true;
   }
 
   int init(mp_ctx* c, uint32_t m_, uint32_t n_, const uint8_t* params, const uint8_t* pk, uint32_t fb_bits) {
@@ -155,22 +198,7 @@ struct Table : mp_table {
     fbpts.upload(flat, s);
     build_fixed_tables(fb.count());
 
-    for (int k = 0; k < 2; ++k) {
-      PlanSet& q = ps[k];
-      q.pplan = make_prove_plan(m, n, k ? 2u : FCHUNK, k ? 4u : VCHUNK, G_::PB);
-      q.vplan = make_verify_plan(m, n, k ? 2u : FCHUNK, k ? 4u : VCHUNK, G_::PB);
-      q.table_group = k ? 8u : TABLE_GROUP;
-      for (int i = 0; i < 5; ++i) q.pph[i].upload(q.pplan.ph[i], s);
-      q.vph.upload(q.vplan.ph, s);
-      q.vmph.upload(q.vplan.mph, s);
-      q.mjobs.upload(q.vplan.mjobs, s);
-      q.mpairs.upload(q.vplan.mpairs, s);
-      q.draws.upload(q.pplan.draws, s);
-      q.lin.upload(q.pplan.lin, s);
-      q.lin_src.upload(q.pplan.lin_src, s);
-      q.pwire.upload(q.pplan.wire, s);
-      q.vwire.upload(q.vplan.wire, s);
-    }
+    build_plans(ps, false);
     // Blake2s("Shuffle Proof")  [REF mod.rs:84]
     {
       Blake2sState st;
@@ -239,14 +267,20 @@ struct Table : mp_table {
     return (uint32_t)(bytes / 4 + 4);
   }
 
-  void reserve(size_t B) override {
-    PlanSet& q = pick((uint32_t)B);
+  void reserve(size_t B) override { reserve_for(B, false); }
+  void reserve_for(size_t B, bool keyed) {
+    if (keyed) ensure_keyed();
+    PlanSet& q = pick((uint32_t)B, keyed);
     uint32_t nS = std::max(q.pplan.lay.nS, q.vplan.lay.nS), nP = std::max(q.pplan.lay.nP, q.vplan.lay.nP);
     uint32_t nJ = std::max(q.pplan.nJ, q.vplan.nJ), nD = std::max(q.vph.n_dslots, q.vmph.n_dslots),
              nT = std::max(q.vph.n_tslots, q.vmph.n_tslots);
     for (int i = 0; i < 5; ++i) {
       nD = std::max(nD, q.pph[i].n_dslots);
       nT = std::max(nT, q.pph[i].n_tslots);
+    }
+    if (keyed) {
+      nD = std::max(nD, key_d_first + N);
+      nT = std::max(nT, key_t_first + nwin);
     }
     ws.fw = G_::FW;
     ws.ensure((uint32_t)B, nS, nP, nJ, nD, nT, nwin, stage_words_needed(), ctx->stream);
@@ -282,7 +316,7 @@ struct Table : mp_table {
       normalize_flat(w.J.p + j_off<C>(r.first, w.Bpad, 0), w.P.p + p_off<C>(r.first, w.Bpad, 0), w.NS.p, (size_t)r.second * w.Bpad);
   }
 
-  FsStatementArgs statement_args(Workspace& w, uint32_t p_deck, uint32_t p_shuf, uint32_t p_cA, uint32_t s_x) {
+  FsStatementArgs statement_args(Workspace& w, uint32_t p_deck, uint32_t p_shuf, uint32_t p_cA, uint32_t s_x, uint32_t p_pk = NO_SLOT) {
     FsStatementArgs a{};
     a.f = FsDev{w.stage.p, w.seed.p, w.Bpad};
     a.S = w.S.p;
@@ -291,16 +325,20 @@ struct Table : mp_table {
     memcpy(a.init_seed, init_seed, 32);
     a.m = m; a.n = n; a.N = N;
     a.p_deck = p_deck; a.p_shuf = p_shuf; a.p_cA = p_cA; a.s_x = s_x;
+    a.p_pk = p_pk;
     return a;
   }
 
   // ---------------------------------------------------------------- prove
+  // keys != nullptr: keyed batch -- proof b is made under the aggregate key keys[b] (one wire point each) instead of the
+  // table's own key [REF mod.rs:380-418 takes shared_key per call; tables of different card tables differ in nothing else]
   void prove_dev(size_t B_, const uint8_t* decks, const uint8_t* rho, const uint32_t* perm, const uint8_t* seeds,
-                 uint8_t* out_decks, uint8_t* out_proofs, int32_t* status) override {
+                 uint8_t* out_decks, uint8_t* out_proofs, int32_t* status, const uint8_t* keys) override {
     const uint32_t B = (uint32_t)B_;
-    reserve(B);
+    const bool keyed = keys != nullptr;
+    reserve_for(B, keyed);
     Workspace& w = ws;
-    PlanSet& q = pick(B);
+    PlanSet& q = pick(B, keyed);
     cur_table_group = q.table_group;
     const ProveLay& l = q.pplan.lay;
     PhaseDev* pph = q.pph;
@@ -314,13 +352,27 @@ struct Table : mp_table {
       MP_RUN(k_load_scalars, C, B, N, sa);
       ProveInitArgs ia{w.S.p, w.status.p, perm, seeds, q.draws.p, l, w.Bpad};
       MP_RUN(k_prove_init, C, B, 1, ia);
-      RemaskArgs ra{w.S.p, w.P.p, w.J.p, FB.p, perm, w.Bpad, N, l.rho, l.deck, l.shuf, fb.G(), fb.pk(), fbg};
+      RemaskArgs ra{w.S.p, w.P.p, w.J.p, FB.p, perm, w.Bpad, N, l.rho, l.deck, l.shuf, fb.G(), fb.pk(), fbg,
+                    0, w.D.p, w.T.p, key_d_first, key_t_first, nwin};
+      if (keyed) {
+        // the proof's key -> window bases 2^(5w) pk -> their 16-entry tables; signed digits of the masking factors
+        LoadPointsArgs ka{keys, w.P.p, w.status.p, w.Bpad, 1, l.pk};
+        MP_RUN(k_load_points, C, B, 1, ka);
+        KeyWinArgs kw{w.P.p, w.J.p, w.Bpad, l.pk, l.kw, nwin};
+        MP_RUN(k_key_windows, C, B, 1, kw);
+        normalize_flat(w.J.p + j_off<C>(l.kw, w.Bpad, 0), w.P.p + p_off<C>(l.kw, w.Bpad, 0), w.NS.p, (size_t)nwin * w.Bpad);
+        RecodeArgs rc{w.S.p, w.D.p, key_recode.p, w.Bpad, nwin};
+        MP_RUN(k_recode, C, B, N, rc);
+        TableArgs ta{w.P.p, w.T.p, w.NS.p, key_tables.p, w.Bpad, nwin, cur_table_group};
+        MP_RUN(k_table, C, B, (nwin + cur_table_group - 1) / cur_table_group, ta);
+        ra.keyed = 1;
+      }
       MP_RUN(k_remask, C, B, 2 * N, ra);
     }
     run_phase(pph[0], w, B);
     run_phase(pph[4], w, B);      // Toom-Cook / Karatsuba operand sums (empty when unused)
     {
-      FsStatementArgs a = statement_args(w, l.deck, l.shuf, l.cA, l.x);
+      FsStatementArgs a = statement_args(w, l.deck, l.shuf, l.cA, l.x, keyed ? l.pk : NO_SLOT);
       MP_RUN(k_fs_round1, C, B, 1, a);
     }
     ProveScalArgs sc{w.S.p, perm, l, w.Bpad, q.lin.p, q.lin_src.p, (uint32_t)q.pplan.lin.size()};
@@ -375,11 +427,13 @@ struct Table : mp_table {
   // ends here.  (2) Only if some proof failed the screen: the equations one by one, to report the FIRST failing check by
   // name as the reference does [REF tests.rs:223-225].  A proof that passes (1) satisfies every equation except with
   // probability ~2^-250 over weights that depend on the whole proof.
-  void verify_dev(size_t B_, const uint8_t* decks, const uint8_t* shuf, const uint8_t* proofs, int32_t* status) override {
+  void verify_dev(size_t B_, const uint8_t* decks, const uint8_t* shuf, const uint8_t* proofs, int32_t* status,
+                  const uint8_t* keys) override {
     const uint32_t B = (uint32_t)B_;
-    reserve(B);
+    const bool keyed = keys != nullptr;
+    reserve_for(B, keyed);
     Workspace& w = ws;
-    PlanSet& q = pick(B);
+    PlanSet& q = pick(B, keyed);
     cur_table_group = q.table_group;
     const VerifyLay& l = q.vplan.lay;
     rt::Stream s = ctx->stream;
@@ -395,10 +449,14 @@ struct Table : mp_table {
         MP_RUN(k_load_points, C, B, 2 * N, b);
         ProofIoArgs pa{const_cast<uint8_t*>(proofs), w.S.p, w.P.p, w.status.p, q.vwire.p, w.Bpad, (uint32_t)proof_size_bytes(m, n, G_::PB)};
         MP_RUN(k_load_proof, C, B, (uint32_t)q.vplan.wire.size(), pa);
+        if (keyed) {
+          LoadPointsArgs ka{keys, w.P.p, w.status.p, w.Bpad, 1, l.pk};
+          MP_RUN(k_load_points, C, B, 1, ka);
+        }
       }
       {
         VerifyFsArgs a{};
-        a.st = statement_args(w, l.deck, l.shuf, l.cA, l.x);
+        a.st = statement_args(w, l.deck, l.shuf, l.cA, l.x, keyed ? l.pk : NO_SLOT);
         a.l = l;
         a.merge = merged ? 1u : 0u;
         MP_RUN(k_verify_fs, C, B, 1, a);
@@ -455,7 +513,7 @@ struct Table : mp_table {
     MP_RUN(k_load_points, C, B, 2, a);
     LoadScalarsArgs sa{drho.p, w.S.p, w.status.p, w.Bpad, 1, 0};
     MP_RUN(k_load_scalars, C, B, 1, sa);
-    RemaskArgs ra{w.S.p, w.P.p, w.J.p, FB.p, nullptr, w.Bpad, 1, 0, 0, 2, fb.G(), fb.pk(), fbg};
+    RemaskArgs ra{w.S.p, w.P.p, w.J.p, FB.p, nullptr, w.Bpad, 1, 0, 0, 2, fb.G(), fb.pk(), fbg, 0, nullptr, nullptr, 0, 0, 0};
     MP_RUN(k_remask, C, B, 2, ra);
     normalize_flat(w.J.p + j_off<C>(2, w.Bpad, 0), w.P.p + p_off<C>(2, w.Bpad, 0), w.NS.p, (size_t)2 * w.Bpad);
     StorePointsArgs st{dout.p, w.P.p, w.Bpad, 2, 2};

@@ -148,6 +148,12 @@ struct RemaskArgs {
   uint32_t s_rho, p_deck, j_out;
   uint32_t base_G, base_pk;
   FbGeom g;
+  // keyed batches: the aggregate key is per proof -- its multiples come from the proof's own window tables
+  // (entries 1..16 of 2^(5w) pk, built by k_key_windows + k_table) and the signed digits of rho
+  uint32_t keyed;
+  const int8_t* D;      // [dslot][window][Bpad]
+  const uint32_t* T;    // [tslot][entry][Bpad]
+  uint32_t d_first, t_first, nwin;   // digit slot of rho_0, table slot of window 0
 };
 // y = 2*i + component
 template <class C>
@@ -160,6 +166,21 @@ MP_HD void body_remask(const RemaskArgs& a, uint32_t b, uint32_t y) {
   fe_to_canonical<R>(ld_fe<R>(a.S + s_off(a.s_rho + i, a.Bpad, b)), k);
   const uint32_t base = comp ? a.base_pk : a.base_G;
   Jac<C> acc = jac_inf<C>();
+  if (a.keyed && comp) {
+#pragma unroll 1
+    for (uint32_t w = 0; w < a.nwin; ++w) {
+      const int d = a.D[((size_t)(a.d_first + i) * a.nwin + w) * a.Bpad + b];
+      if (d != 0) {
+        const uint32_t e = (uint32_t)(d < 0 ? -d : d) - 1;
+        Aff<C> q = ld_aff<C>(a.T + p_off<C>((a.t_first + w) * VB_ENTRIES + e, a.Bpad, b));
+        if (d < 0) q = aff_neg<C>(q);
+        jac_madd_ip<C>(acc, q);
+      }
+    }
+    jac_madd_ip<C>(acc, ld_aff<C>(a.P + p_off<C>(a.p_deck + 2 * src + comp, a.Bpad, b)));
+    st_jac<C>(a.J + j_off<C>(a.j_out + y, a.Bpad, b), acc);
+    return;
+  }
 #pragma unroll 1
   for (uint32_t w = 0; w < a.g.windows; ++w) {
     const uint32_t d = fb_digit(k, a.g, w);
@@ -169,6 +190,25 @@ MP_HD void body_remask(const RemaskArgs& a, uint32_t b, uint32_t y) {
   st_jac<C>(a.J + j_off<C>(a.j_out + y, a.Bpad, b), acc);
 }
 MP_KERNEL_OCC(k_remask, RemaskArgs, body_remask, 4)
+
+// ---- window bases of a per-proof key: W_w = 2^(5w) * pk, w < nwin (lane = proof; Jacobian out -> normalise -> k_table)
+struct KeyWinArgs {
+  const uint32_t* P;
+  uint32_t* J;
+  uint32_t Bpad, p_pk, j_first, nwin;
+};
+template <class C>
+MP_HD void body_key_windows(const KeyWinArgs& a, uint32_t b, uint32_t y) {
+  Jac<C> acc = jac_from_aff<C>(ld_aff<C>(a.P + p_off<C>(a.p_pk, a.Bpad, b)));
+  st_jac<C>(a.J + j_off<C>(a.j_first, a.Bpad, b), acc);
+#pragma unroll 1
+  for (uint32_t w = 1; w < a.nwin; ++w) {
+#pragma unroll 1
+    for (int q = 0; q < VB_WINDOW_BITS; ++q) jac_dbl_ip<C>(acc);
+    st_jac<C>(a.J + j_off<C>(a.j_first + w, a.Bpad, b), acc);
+  }
+}
+MP_KERNEL(k_key_windows, KeyWinArgs, body_key_windows)
 
 // ---- signed-window recoding of the variable-base scalars -------------------------------------------
 struct RecodeArgs {

@@ -269,6 +269,7 @@ struct FsStatementArgs {
   uint32_t init_seed[8];       // Blake2s("Shuffle Proof")
   uint32_t m, n, N;
   uint32_t p_deck, p_shuf, p_cA, s_x;
+  uint32_t p_pk;               // keyed batches: P slot of the per-proof aggregate key (NO_SLOT: the table's fixed base)
 };
 template <class C>
 MP_HD void fs_statement_and_x(const FsStatementArgs& a, uint32_t b, uint32_t seed[8]) {
@@ -277,7 +278,10 @@ MP_HD void fs_statement_and_x(const FsStatementArgs& a, uint32_t b, uint32_t see
   for (int i = 0; i < 8; ++i) seed[i] = a.init_seed[i];
   StageWriter w = stage_begin(a.f.stage, a.f.Bpad, b);
   fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.G() * Geo<C>::PW));
-  fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.pk() * Geo<C>::PW));
+  if (a.p_pk != NO_SLOT)
+    fs_put_point<C>(w, ld_aff<C>(a.P + p_off<C>(a.p_pk, a.f.Bpad, b)));
+  else
+    fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.pk() * Geo<C>::PW));
   fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.gen() * Geo<C>::PW));
   for (uint32_t j = 0; j < a.n; ++j) fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.ck(j) * Geo<C>::PW));
   fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.H() * Geo<C>::PW));

@@ -50,6 +50,7 @@ struct FixedBases {
 // fixed-base tables: window width is a property of the table context (FbGeom in kernels_msm.hpp: 8, 16 or 20 bits)
 static const int VB_WINDOW_BITS = 5;     // variable-base (Straus) signed windows: digits in [-15, 16]
 static const int VB_ENTRIES = 16;
+static const uint32_t KEY_WINDOWS = 52;  // >= vb_windows(scalar bits) of every curve: window bases of a per-proof key
 static inline int vb_windows(int scalar_bits) { return (scalar_bits + 1 + VB_WINDOW_BITS - 1) / VB_WINDOW_BITS; }
 
 // One phase = everything that can run between two Fiat-Shamir squeeze points.
@@ -155,6 +156,7 @@ struct ProveLay {
   // P arena (J arena mirrors [0, nP))
   uint32_t deck, shuf, cA, cB, cb, hB, zcA0, zcBm, zcD, svcd, svcdelta, svcDelta, mecA0, mecB, meE;
   uint32_t tDp, tDm;          // Toom-Cook (m = 2): C'_1 + C'_2 and C'_2 - C'_1 (2n points each)
+  uint32_t pk, kw;            // per-proof aggregate key (keyed batches) and its window bases 2^(5w) pk, w < KEY_WINDOWS
   uint32_t nP;
   uint32_t n_draws;
   uint32_t toom;              // 1: the multi-exponentiation diagonals use 4 evaluation points instead of 6 row products
@@ -169,6 +171,7 @@ struct VerifyLay {
   uint32_t nS, tmp_len, n_coef;
   // points
   uint32_t deck, shuf, cA, cB, cb, hB, zcA0, zcBm, zcD, svcd, svcdelta, svcDelta, mecA0, mecB, meE;
+  uint32_t pk;                // per-proof aggregate key (keyed batches)
   uint32_t nP;
   // result slots of the "== O" checks (J arena, >= nP) and their codes
   uint32_t chk_first, n_chk;
@@ -243,6 +246,7 @@ static inline ProveLay make_prove_lay(uint32_t m, uint32_t n) {
   l.zcA0 = Pn(1); l.zcBm = Pn(1); l.zcD = Pn(2 * m + 1); l.svcd = Pn(1); l.svcdelta = Pn(1); l.svcDelta = Pn(1);
   l.mecA0 = Pn(1); l.mecB = Pn(2 * m); l.meE = Pn(4 * m);
   l.tDp = Pn(2 * n); l.tDm = Pn(2 * n);
+  l.pk = Pn(1); l.kw = Pn(KEY_WINDOWS);
   l.nP = p;
   return l;
 }
@@ -363,7 +367,10 @@ static inline std::vector<KLeaf> k_merge(const std::vector<KLeaf>& in) {
   return out;
 }
 
-static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk, uint32_t point_bytes = 64) {
+// keyed: the aggregate key is a per-proof point (P slot lay.pk) instead of the table's fixed base: its terms become
+// variable-base terms (the re-encryption uses the key's own window tables, kernels_msm.hpp body_remask)
+static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk, uint32_t point_bytes = 64,
+                                        bool keyed = false) {
   ProvePlan pl;
   pl.lay = make_prove_lay(m, n);
   pl.lay.toom = m == 2 ? 1u : 0u;
@@ -473,7 +480,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
             B.fixed(l.metau + k, fb.G());
           } else {
             B.fixed(l.meb + k, fb.gen());
-            B.fixed(l.metau + k, fb.pk());
+            if (keyed) B.var(l.metau + k, l.pk); else B.fixed(l.metau + k, fb.pk());
           }
           if (k == 0) B.addend_j(v0);
           if (k == 3) B.addend_j(vinf);
@@ -498,7 +505,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
             B.fixed(l.metau + k, fb.G());
           } else {
             B.fixed(l.meb + k, fb.gen());
-            B.fixed(l.metau + k, fb.pk());
+            if (keyed) B.var(l.metau + k, l.pk); else B.fixed(l.metau + k, fb.pk());
           }
           for (size_t i = 0; i < leaves.size(); ++i) {
             auto it = leaves[i].contrib.find(k);
@@ -517,7 +524,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
           B.fixed(l.metau + k, fb.G());
         } else {
           B.fixed(l.meb + k, fb.gen());
-          B.fixed(l.metau + k, fb.pk());
+          if (keyed) B.var(l.metau + k, l.pk); else B.fixed(l.metau + k, fb.pk());
         }
         for (uint32_t i = 1; i <= m; ++i) {
           int64_t j = (int64_t)k - (int64_t)m + (int64_t)i;
@@ -606,7 +613,7 @@ static inline VerifyLay make_verify_lay(uint32_t m, uint32_t n) {
   l.n_coef = 2 * N + 6 * n + 16 * m + 32;
   l.coef = A(l.n_coef);
   l.mr = A(VC_COUNT);
-  l.mvar = A(4 * N + 11 * m + 8);      // one per P slot (= nP below)
+  l.mvar = A(4 * N + 11 * m + 9);      // one per P slot (= nP below)
   l.mfix = A(n + 5);                   // one per fixed base (FixedBases::count())
   l.nS = s;
   uint32_t p = 0;
@@ -614,8 +621,9 @@ static inline VerifyLay make_verify_lay(uint32_t m, uint32_t n) {
   l.deck = Pn(2 * N); l.shuf = Pn(2 * N); l.cA = Pn(m); l.cB = Pn(m); l.cb = Pn(1); l.hB = Pn(m);
   l.zcA0 = Pn(1); l.zcBm = Pn(1); l.zcD = Pn(2 * m + 1); l.svcd = Pn(1); l.svcdelta = Pn(1); l.svcDelta = Pn(1);
   l.mecA0 = Pn(1); l.mecB = Pn(2 * m); l.meE = Pn(4 * m);
+  l.pk = Pn(1);
   l.nP = p;
-  if (l.nP != 4 * N + 11 * m + 8) throw std::logic_error("verify layout: P slot count");
+  if (l.nP != 4 * N + 11 * m + 9) throw std::logic_error("verify layout: P slot count");
   l.chk_first = l.nP;
   l.n_chk = VC_COUNT + 1;
   l.chk_merged = l.chk_first + VC_COUNT;
@@ -689,7 +697,7 @@ struct VerifyPlan {
 // The verifier's group equations, each "sum of scalar * point == O" (one description, two consumers: the per-equation plan
 // and the merged plan).  Sink: begin(check id) / var(coef slot, P slot) / fixed(coef slot, base) / end().
 template <class Sink>
-static inline void describe_verify(const VerifyLay& l, const VCoefMap& c, Sink& B) {
+static inline void describe_verify(const VerifyLay& l, const VCoefMap& c, Sink& B, bool keyed) {
   const uint32_t m = l.m, n = l.n, N = l.N;
   FixedBases fb{n};
   // VC_HAD_B1
@@ -756,7 +764,7 @@ static inline void describe_verify(const VerifyLay& l, const VCoefMap& c, Sink& 
       B.fixed(c.me_tauG, fb.G());
     } else {
       B.fixed(c.me_bgen, fb.gen());
-      B.fixed(c.me_taupk, fb.pk());
+      if (keyed) B.var(c.me_taupk, l.pk); else B.fixed(c.me_taupk, fb.pk());
     }
     B.end();
   }
@@ -782,7 +790,8 @@ struct MergeSink {
   void end() {}
 };
 
-static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk, uint32_t point_bytes = 64) {
+static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk, uint32_t point_bytes = 64,
+                                          bool keyed = false) {
   VerifyPlan pl;
   pl.lay = make_verify_lay(m, n);
   const VerifyLay& l = pl.lay;
@@ -792,7 +801,7 @@ static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchun
     uint32_t next_partial = l.chk_first + l.n_chk;
     PhaseBuilder B(pl.ph, next_partial, fchunk, vchunk);
     PerCheckSink sink{B, l.chk_first};
-    describe_verify(l, c, sink);
+    describe_verify(l, c, sink, keyed);
     pl.nJ = next_partial;
   }
   {
@@ -800,7 +809,7 @@ static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchun
     // fixed-base terms (n + 5 instead of one per equation and base) and fewer doubling chains (the variable-base terms
     // fill whole sub-jobs) -- and a single result to test.
     MergeSink ms{l.mr};
-    describe_verify(l, c, ms);
+    describe_verify(l, c, ms, keyed);
     uint32_t next_partial = l.chk_first + l.n_chk;
     PhaseBuilder B(pl.mph, next_partial, fchunk, vchunk);
     B.begin(l.chk_merged);

@@ -89,6 +89,30 @@ def test_kernel_bodies_under_emulation_match_golden(emu, name):
     t.close()
 
 
+def test_emulated_keyed_batch(emu, coracle):
+    """keyed batches (one aggregate key per proof, mp_*_batch_keys): byte-identical to the oracle run under each proof's key"""
+    for cv, m, n in (("stark", 2, 3), ("bls12_377", 2, 3)):
+        eng = emu(cv)
+        ins = [coracle.gen_inputs(cv, m, n, 500 + b) for b in range(3)]
+        g0 = ins[0]
+        t = eng.table(m, n, g0["params"], g0["pk"])
+        keys = b"".join(g["pk"] for g in ins)
+        decks = b"".join(g["deck"] for g in ins)
+        for lb in (512, 0):
+            t.set_latency_batch(lb)
+            d, p, st = t.shuffle_and_remask_batch_keys(keys, decks, b"".join(g["rho"] for g in ins), [v for g in ins for v in g["perm"]],
+                                                       b"".join(g["prover_seed"] for g in ins))
+            assert st == [0, 0, 0]
+            cb, ps = len(g0["deck"]), t.proof_bytes
+            for b, g in enumerate(ins):
+                ed, ep = coracle.shuffle_and_remask(cv, m, n, g0["params"], g["pk"], g["deck"], g["rho"], g["perm"], g["prover_seed"])
+                assert d[b * cb:(b + 1) * cb] == ed and p[b * ps:(b + 1) * ps] == ep
+            assert t.verify_shuffle_batch_keys(keys, decks, d, p) == [0, 0, 0]
+            wrong = ins[0]["pk"] + ins[0]["pk"] + ins[2]["pk"]          # proof 1 checked under another table's key
+            assert t.verify_shuffle_batch_keys(wrong, decks, d, p) == [0, 1, 0]
+        t.close()
+
+
 def test_emulated_batch_and_status(emu, coracle):
     cv, m, n = "stark", 2, 3
     eng = emu(cv)

@@ -212,6 +212,32 @@ def test_tampering_names_the_failing_check(mp, engines):
         assert name(mut) == exp
 
 
+@pytest.mark.parametrize("curve,m,n,B", [("stark", 2, 26, 5), ("stark", 4, 13, 3), ("secp256k1", 2, 7, 3), ("bls12_377", 2, 5, 2)])
+@pytest.mark.parametrize("plan", ["latency", "throughput"])
+def test_keyed_batches_match_oracle(mp, engines, coracle, curve, m, n, B, plan):
+    """mp_*_batch_keys: every proof of the batch under its own aggregate key (tables of a card server share the parameters
+    and differ in the key [REF mod.rs:380-386]) -- byte-identical to the oracle run with that key; a proof checked under
+    another table's key is rejected"""
+    cards = engines(curve)
+    g0 = coracle.gen_inputs(curve, m, n, 700)
+    pp = mp.Parameters(m, n, g0["params"])
+    t = cards.table(pp, g0["pk"])
+    t.set_latency_batch(512 if plan == "latency" else 0)
+    ins = [coracle.gen_inputs(curve, m, n, 701 + b) for b in range(B)]
+    keys, decks = b"".join(g["pk"] for g in ins), b"".join(g["deck"] for g in ins)
+    d, p, st = t.shuffle_and_remask_batch_keys(keys, decks, b"".join(g["rho"] for g in ins), [v for g in ins for v in g["perm"]],
+                                               b"".join(g["prover_seed"] for g in ins))
+    assert st == [0] * B
+    cb, ps = len(g0["deck"]), t.proof_bytes
+    for b, g in enumerate(ins):
+        ed, ep = coracle.shuffle_and_remask(curve, m, n, g0["params"], g["pk"], g["deck"], g["rho"], g["perm"], g["prover_seed"])
+        assert d[b * cb:(b + 1) * cb] == ed and p[b * ps:(b + 1) * ps] == ep
+    assert t.verify_shuffle_batch_keys(keys, decks, d, p) == [0] * B
+    rot = b"".join(g["pk"] for g in ins[1:] + ins[:1])
+    assert all(v > 0 for v in t.verify_shuffle_batch_keys(rot, decks, d, p))
+    t.set_latency_batch(512)
+
+
 def test_merged_and_per_equation_verification_agree(mp, engines):
     """mp_set_merged_verify: the merged screening pass and the equation-by-equation pass give the same status words on a
     mixed batch (honest proofs, one tampering per sub-argument, a bad encoding), and an all-honest batch passes in both"""
