@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--fb-bits", type=int, default=20, help="fixed-base window width (8, 16 or 20 bits; 20 = 27 GB of tables at n=26)")
     ap.add_argument("--cpu-iters", type=int, default=96, help="prove+verify pairs timed for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--keyed", type=int, default=0, metavar="K",
+                    help="keyed batches: K distinct aggregate keys (card tables) spread over the batch, one key per proof "
+                         "(mp_*_batch_keys_dev); 0 = every proof under the table's own key")
     args = ap.parse_args()
 
     import torch
@@ -174,6 +177,12 @@ def main():
         for e in engines:
             e.sync()
 
+    # keyed batches: K aggregate keys (random group elements from the engine's own setup), key b % K for proof b
+    keys = None
+    if args.keyed > 0:
+        kpts = eng.setup(m, max(args.keyed, 2), bytes([4] * 32))
+        kt = torch.frombuffer(bytearray(kpts[:64 * args.keyed]), dtype=torch.uint8).to(gpu).view(args.keyed, 64)
+        keys = kt[torch.arange(B, device=gpu) % args.keyed].contiguous()
     # prime: B different random decks = re-encryptions of the base deck (untimed input generation)
     f0, p0, s0 = rand_factors(), rand_perms(), rand_bytes(B, 32)
     torch.cuda.synchronize()
@@ -193,6 +202,11 @@ def main():
 
     def step():
         for i, t in enumerate(tables):
+            if keys is not None:
+                t.shuffle_and_remask_batch_keys_dev(Bs, sl(keys, i), sl(decks, i), sl(factors, i), sl(perms, i), sl(seeds, i),
+                                                    sl(out_decks, i), sl(out_proofs, i), sl(st_p, i))
+                t.verify_shuffle_batch_keys_dev(Bs, sl(keys, i), sl(decks, i), sl(out_decks, i), sl(out_proofs, i), sl(st_v, i))
+                continue
             t.shuffle_and_remask_batch_dev(Bs, sl(decks, i), sl(factors, i), sl(perms, i), sl(seeds, i), sl(out_decks, i),
                                            sl(out_proofs, i), sl(st_p, i))
             t.verify_shuffle_batch_dev(Bs, sl(decks, i), sl(out_decks, i), sl(out_proofs, i), sl(st_v, i))
@@ -229,7 +243,8 @@ def main():
         import coracle as co
         co.build()
         b = B // 2
-        exp_deck, exp_proof = co.shuffle_and_remask(curve, m, n, params, pk, bytes(decks[b].cpu().numpy().tobytes()),
+        pk_b = pk if keys is None else bytes(keys[b].cpu().numpy().tobytes())
+        exp_deck, exp_proof = co.shuffle_and_remask(curve, m, n, params, pk_b, bytes(decks[b].cpu().numpy().tobytes()),
                                                     bytes(factors[b].cpu().numpy().tobytes()),
                                                     [int(v) for v in perms[b].cpu().tolist()],
                                                     bytes(seeds[b].cpu().numpy().tobytes()))
@@ -348,6 +363,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%d-card deck, m=%d n=%d, %s curve, shuffle_and_remask + verify_shuffle" % (N, m, n, curve),
                    "proofs_per_gpu_per_step": B, "streams": S, "fixed_base_window_bits": args.fb_bits,
+                   "aggregate_keys": args.keyed if args.keyed else 1,
                    "parity_vs_oracle": parity},
         "roofline": roofline, "cpu_baseline": cpu,
     }

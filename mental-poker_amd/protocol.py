@@ -298,6 +298,35 @@ class DLCards:
                 out.append(([d[(b * N + i) * cb:(b * N + i + 1) * cb] for i in range(N)], p[b * ps:(b + 1) * ps]))
         return out
 
+    # -- keyed batches: proof b under shared_keys[b] (many card tables with common parameters in one launch); results are
+    #    those of shuffle_and_remask / verify_shuffle called with that key [REF mod.rs:380-386, 420-426]
+    def shuffle_and_remask_batch_keys(self, rng_seeds, pp, shared_keys, decks, masking_factors, permutations):
+        t = self.table(pp, shared_keys[0])
+        perms = [v for p in permutations for v in p.mapping]
+        try:
+            d, p, st = t.shuffle_and_remask_batch_keys(b"".join(shared_keys), b"".join(b"".join(dk) for dk in decks),
+                                                       b"".join(_scalar_bytes(f) for f in masking_factors), perms, b"".join(rng_seeds))
+        except _native.NativeError as e:
+            raise CardProtocolError.io(str(e))
+        N, ps, cb = pp.m * pp.n, t.proof_bytes, 2 * self.engine.point_bytes
+        out = []
+        for b, s in enumerate(st):
+            if s < 0:
+                out.append(CardProtocolError.io(self.engine.check_name(s)))
+            else:
+                out.append(([d[(b * N + i) * cb:(b * N + i + 1) * cb] for i in range(N)], p[b * ps:(b + 1) * ps]))
+        return out
+
+    def verify_shuffle_batch_keys(self, pp, shared_keys, original_decks, shuffled_decks, proofs):
+        t = self.table(pp, shared_keys[0])
+        try:
+            st = t.verify_shuffle_batch_keys(b"".join(shared_keys), b"".join(b"".join(d) for d in original_decks),
+                                             b"".join(b"".join(d) for d in shuffled_decks), b"".join(proofs))
+        except _native.NativeError as e:
+            raise CardProtocolError.io(str(e))
+        return [None if s == 0 else (CryptoError(self.engine.check_name(s)) if s > 0 else CardProtocolError.io(self.engine.check_name(s)))
+                for s in st]
+
     def verify_shuffle_batch(self, pp, shared_key, original_decks, shuffled_decks, proofs):
         t = self.table(pp, shared_key)
         try:
