@@ -238,6 +238,71 @@ def test_keyed_batches_match_oracle(mp, engines, coracle, curve, m, n, B, plan):
     t.set_latency_batch(512)
 
 
+def test_verifier_fuzz_against_oracle(mp, engines, coracle):
+    """~200 random single-element corruptions of an honest proof (a scalar replaced by a random scalar, a point by
+    another valid point, or two elements swapped), verified in ONE batch: every status word -- accept, or the code of the first failing
+    check -- equals the C++ oracle's verdict, under both verification strategies"""
+    g = load_json(os.path.join(GOLDEN, "shuffle_stark_m4_n13_s9.json"))
+    m, n = g["m"], g["n"]
+    cards = engines("stark")
+    pp = mp.Parameters(m, n, bytes.fromhex(g["params"]))
+    pk, deck, shuf = bytes.fromhex(g["pk"]), bytes.fromhex(g["deck"]), bytes.fromhex(g["shuffled"])
+    good = bytes.fromhex(g["proof"])
+    npts, nsc = 11 * m + 8, 5 * n + 9
+    # element boundaries of wire v1: (offset, size) of every element
+    with po.curve_ctx(po.STARK):
+        pf = po.proof_from_bytes(good, m, n)
+    sizes = []
+
+    def walk(x):
+        if isinstance(x, dict):
+            for k in x:
+                walk(x[k])
+        elif isinstance(x, list):
+            for v in x:
+                walk(v)
+        elif x is None:
+            sizes.append(64)                                    # point at infinity (c_D[m+1], c_B[m] of the honest proof)
+        elif isinstance(x, tuple):
+            if len(x) == 2 and all(isinstance(v, int) for v in x):
+                sizes.append(64)
+            else:
+                for v in x:
+                    walk(v)
+        else:
+            sizes.append(32)
+    walk(pf)            # dict order of proof_from_bytes == wire order (asserted below)
+    assert sum(sizes) == len(good) and sizes.count(64) == npts and sizes.count(32) == nsc
+    offs = [sum(sizes[:i]) for i in range(len(sizes))]
+    rng = mp.ChaCha20Rng(bytes([9] * 32))
+    q = po.STARK.q
+    pts = [deck[64 * i:64 * i + 64] for i in range(8)]
+    proofs = [good]
+    for trial in range(199):
+        b = bytearray(good)
+        e = rng.next_u64() % len(sizes)
+        kind = rng.next_u64() % 3
+        if kind == 2:                                           # swap two elements of the same size
+            f = next(i for i in range(e + 1, e + len(sizes)) if sizes[i % len(sizes)] == sizes[e]) % len(sizes)
+            o1, o2, sz = offs[e], offs[f], sizes[e]
+            b[o1:o1 + sz], b[o2:o2 + sz] = b[o2:o2 + sz], b[o1:o1 + sz]
+        elif sizes[e] == 32:
+            b[offs[e]:offs[e] + 32] = (mp.fr_rand("stark", rng) if kind else (int.from_bytes(b[offs[e]:offs[e] + 32], "little") + 1) % q).to_bytes(32, "little")
+        else:
+            b[offs[e]:offs[e] + 64] = pts[rng.next_u64() % len(pts)]
+        proofs.append(bytes(b))
+    B = len(proofs)
+    exp = [coracle.verify_shuffle("stark", m, n, bytes.fromhex(g["params"]), pk, deck, shuf, p) for p in proofs]
+    assert exp[0] == 0 and sum(1 for v in exp if v) > 150 and len(set(exp)) == 5      # every check code occurs
+    t = cards.table(pp, pk)
+    t.set_latency_batch(0)
+    for mode in (True, False):
+        t.set_merged_verify(mode)
+        assert t.verify_shuffle_batch(deck * B, shuf * B, b"".join(proofs)) == exp
+    t.set_merged_verify(True)
+    t.set_latency_batch(512)
+
+
 def test_merged_and_per_equation_verification_agree(mp, engines):
     """mp_set_merged_verify: the merged screening pass and the equation-by-equation pass give the same status words on a
     mixed batch (honest proofs, one tampering per sub-argument, a bad encoding), and an all-honest batch passes in both"""
