@@ -177,6 +177,87 @@ MP_HD Jac<C> jac_add(const Jac<C>& p, const Jac<C>& q) {
   return r;
 }
 
+// ---- XYZZ accumulator (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; infinity: ZZ = 0): mixed addition 8M+2S instead of the
+// Jacobian 8M+3S, doubling 6M+4S instead of 3M+6S -- pays where mixed additions outnumber doublings 5:1 or more
+// (the Straus loop of k_var_msm).  Same completeness rules as the Jacobian law above.
+template <class C>
+struct Xyzz {
+  Fe<typename C::FqP> X, Y, ZZ, ZZZ;
+};
+template <class C>
+MP_HD Xyzz<C> xyzz_inf() {
+  Xyzz<C> p;
+  p.X = fe_one<typename C::FqP>();
+  p.Y = fe_one<typename C::FqP>();
+  p.ZZ = fe_zero<typename C::FqP>();
+  p.ZZZ = fe_zero<typename C::FqP>();
+  return p;
+}
+template <class C>
+MP_HD void xyzz_dbl_ip(Xyzz<C>& p) {
+  typedef typename C::FqP F;
+  if (fe_is_zero(p.ZZ)) return;
+  if (fe_is_zero(p.Y)) {
+    p.ZZ = fe_zero<F>();
+    p.ZZZ = fe_zero<F>();
+    return;
+  }
+  const Fe<F> U = fe_dbl<F>(p.Y);
+  const Fe<F> V = fe_sqr<F>(U);
+  const Fe<F> W = fe_mul<F>(U, V);
+  const Fe<F> S = fe_mul<F>(p.X, V);
+  const Fe<F> XX = fe_sqr<F>(p.X);
+  Fe<F> M = fe_add<F>(fe_dbl<F>(XX), XX);
+  if (C::A == 1) M = fe_add<F>(M, fe_sqr<F>(p.ZZ));
+  const Fe<F> X3 = fe_sub<F>(fe_sqr<F>(M), fe_dbl<F>(S));
+  p.Y = fe_sub<F>(fe_mul<F>(M, fe_sub<F>(S, X3)), fe_mul<F>(W, p.Y));
+  p.X = X3;
+  p.ZZ = fe_mul<F>(V, p.ZZ);
+  p.ZZZ = fe_mul<F>(W, p.ZZZ);
+}
+template <class C>
+MP_HD void xyzz_madd_ip(Xyzz<C>& p, const Aff<C>& q) {
+  typedef typename C::FqP F;
+  if (aff_is_inf<C>(q)) return;
+  if (fe_is_zero(p.ZZ)) {
+    p.X = q.x;
+    p.Y = q.y;
+    p.ZZ = fe_one<F>();
+    p.ZZZ = fe_one<F>();
+    return;
+  }
+  const Fe<F> Pd = fe_sub<F>(fe_mul<F>(q.x, p.ZZ), p.X);
+  const Fe<F> Rr = fe_sub<F>(fe_mul<F>(q.y, p.ZZZ), p.Y);
+  if (fe_is_zero(Pd)) {
+    if (fe_is_zero(Rr)) {
+      xyzz_dbl_ip<C>(p);         // P + P
+    } else {
+      p.ZZ = fe_zero<F>();       // P + (-P)
+      p.ZZZ = fe_zero<F>();
+    }
+    return;
+  }
+  const Fe<F> PP = fe_sqr<F>(Pd);
+  const Fe<F> PPP = fe_mul<F>(Pd, PP);
+  const Fe<F> Q = fe_mul<F>(p.X, PP);
+  const Fe<F> X3 = fe_sub<F>(fe_sub<F>(fe_sqr<F>(Rr), PPP), fe_dbl<F>(Q));
+  p.Y = fe_sub<F>(fe_mul<F>(Rr, fe_sub<F>(Q, X3)), fe_mul<F>(p.Y, PPP));
+  p.X = X3;
+  p.ZZ = fe_mul<F>(p.ZZ, PP);
+  p.ZZZ = fe_mul<F>(p.ZZZ, PPP);
+}
+// the same point in Jacobian coordinates with Z = ZZ: (X ZZ, Y ZZZ, ZZ)
+template <class C>
+MP_HD Jac<C> xyzz_to_jac(const Xyzz<C>& p) {
+  typedef typename C::FqP F;
+  Jac<C> j;
+  if (fe_is_zero(p.ZZ)) return jac_inf<C>();
+  j.X = fe_mul<F>(p.X, p.ZZ);
+  j.Y = fe_mul<F>(p.Y, p.ZZZ);
+  j.Z = p.ZZ;
+  return j;
+}
+
 // affine from Jacobian given zinv = 1/Z
 template <class C>
 MP_HD Aff<C> jac_to_aff_with_zinv(const Jac<C>& j, const Fe<typename C::FqP>& zinv) {

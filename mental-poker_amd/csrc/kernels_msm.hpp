@@ -122,7 +122,7 @@ template <class C>
 MP_HD void body_fixed_msm(const FixedArgs& a, uint32_t b, uint32_t y) {
   typedef typename C::FrP R;
   const Job job = a.jobs[y];
-  Jac<C> acc = jac_inf<C>();
+  Xyzz<C> acc = xyzz_inf<C>();     // no doublings here: every operation is the 8M+2S mixed addition
   for (uint32_t t = 0; t < job.count; ++t) {
     const Term term = a.terms[job.begin + t];
     uint32_t k[8];
@@ -130,10 +130,10 @@ MP_HD void body_fixed_msm(const FixedArgs& a, uint32_t b, uint32_t y) {
 #pragma unroll 1
     for (uint32_t w = 0; w < a.g.windows; ++w) {
       const uint32_t d = fb_digit(k, a.g, w);
-      if (d) jac_madd_ip<C>(acc, ld_aff<C>(fb_entry<C>(a.FB, a.g, term.b, w, d)));
+      if (d) xyzz_madd_ip<C>(acc, ld_aff<C>(fb_entry<C>(a.FB, a.g, term.b, w, d)));
     }
   }
-  st_jac<C>(a.J + j_off<C>(job.out, a.Bpad, b), acc);
+  st_jac<C>(a.J + j_off<C>(job.out, a.Bpad, b), xyzz_to_jac<C>(acc));
 }
 MP_KERNEL_OCC(k_fixed_msm, FixedArgs, body_fixed_msm, 4)
 
@@ -165,7 +165,7 @@ MP_HD void body_remask(const RemaskArgs& a, uint32_t b, uint32_t y) {
   uint32_t k[8];
   fe_to_canonical<R>(ld_fe<R>(a.S + s_off(a.s_rho + i, a.Bpad, b)), k);
   const uint32_t base = comp ? a.base_pk : a.base_G;
-  Jac<C> acc = jac_inf<C>();
+  Xyzz<C> acc = xyzz_inf<C>();
   if (a.keyed && comp) {
 #pragma unroll 1
     for (uint32_t w = 0; w < a.nwin; ++w) {
@@ -174,20 +174,20 @@ MP_HD void body_remask(const RemaskArgs& a, uint32_t b, uint32_t y) {
         const uint32_t e = (uint32_t)(d < 0 ? -d : d) - 1;
         Aff<C> q = ld_aff<C>(a.T + p_off<C>((a.t_first + w) * VB_ENTRIES + e, a.Bpad, b));
         if (d < 0) q = aff_neg<C>(q);
-        jac_madd_ip<C>(acc, q);
+        xyzz_madd_ip<C>(acc, q);
       }
     }
-    jac_madd_ip<C>(acc, ld_aff<C>(a.P + p_off<C>(a.p_deck + 2 * src + comp, a.Bpad, b)));
-    st_jac<C>(a.J + j_off<C>(a.j_out + y, a.Bpad, b), acc);
+    xyzz_madd_ip<C>(acc, ld_aff<C>(a.P + p_off<C>(a.p_deck + 2 * src + comp, a.Bpad, b)));
+    st_jac<C>(a.J + j_off<C>(a.j_out + y, a.Bpad, b), xyzz_to_jac<C>(acc));
     return;
   }
 #pragma unroll 1
   for (uint32_t w = 0; w < a.g.windows; ++w) {
     const uint32_t d = fb_digit(k, a.g, w);
-    if (d) jac_madd_ip<C>(acc, ld_aff<C>(fb_entry<C>(a.FB, a.g, base, w, d)));
+    if (d) xyzz_madd_ip<C>(acc, ld_aff<C>(fb_entry<C>(a.FB, a.g, base, w, d)));
   }
-  jac_madd_ip<C>(acc, ld_aff<C>(a.P + p_off<C>(a.p_deck + 2 * src + comp, a.Bpad, b)));
-  st_jac<C>(a.J + j_off<C>(a.j_out + y, a.Bpad, b), acc);
+  xyzz_madd_ip<C>(acc, ld_aff<C>(a.P + p_off<C>(a.p_deck + 2 * src + comp, a.Bpad, b)));
+  st_jac<C>(a.J + j_off<C>(a.j_out + y, a.Bpad, b), xyzz_to_jac<C>(acc));
 }
 MP_KERNEL_OCC(k_remask, RemaskArgs, body_remask, 4)
 
@@ -396,12 +396,12 @@ struct VarArgs {
 template <class C>
 MP_HD void body_var_msm(const VarArgs& a, uint32_t b, uint32_t y) {
   const Job job = a.jobs[y];
-  Jac<C> acc = jac_inf<C>();
+  Xyzz<C> acc = xyzz_inf<C>();     // XYZZ accumulator: a job is ~25..60 mixed additions per 5 doublings
 #pragma unroll 1
   for (int w = (int)a.nwin - 1; w >= 0; --w) {
     if (w != (int)a.nwin - 1) {
 #pragma unroll 1
-      for (int q = 0; q < VB_WINDOW_BITS; ++q) jac_dbl_ip<C>(acc);
+      for (int q = 0; q < VB_WINDOW_BITS; ++q) xyzz_dbl_ip<C>(acc);
     }
 #pragma unroll 1
     for (uint32_t t = 0; t < job.count; ++t) {
@@ -411,11 +411,11 @@ MP_HD void body_var_msm(const VarArgs& a, uint32_t b, uint32_t y) {
         const uint32_t e = (uint32_t)(d < 0 ? -d : d) - 1;
         Aff<C> q = ld_aff<C>(a.T + p_off<C>(term.b * VB_ENTRIES + e, a.Bpad, b));
         if (d < 0) q = aff_neg<C>(q);
-        jac_madd_ip<C>(acc, q);
+        xyzz_madd_ip<C>(acc, q);
       }
     }
   }
-  st_jac<C>(a.J + j_off<C>(job.out, a.Bpad, b), acc);
+  st_jac<C>(a.J + j_off<C>(job.out, a.Bpad, b), xyzz_to_jac<C>(acc));
 }
 MP_KERNEL_OCC(k_var_msm, VarArgs, body_var_msm, 4)
 
