@@ -305,7 +305,7 @@ def main():
     # --pmc WRITE_SIZE in separate runs, gfx950 x2 correction applied to FETCH_SIZE), scaled to this batch
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_summary.json")))["kernels"].get(dom_name)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01i_pmc_summary.json")))["kernels"].get(dom_name)
         if pmc and (m, n) == (2, 26):
             traffic = pmc["hbm_bytes_per_proof_per_step_corrected"] * B * args.steps / dom_count
     except (OSError, ValueError, KeyError):
