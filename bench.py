@@ -31,10 +31,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 INT_MAD_PEAK_G = 18000.0       # v_mad_u64_u32 issue rate measured with tools/microbench/intrate.hip (Gmad/s)
 # exact 32x32+64 multiply-add counts (v_mad_u64_u32 + v_mad_i64_i32, the same quarter-rate pipe) of the compiled STARK
 # group law (llvm -S of xyzz_madd_ip / xyzz_dbl_ip / fe_mul / fe_sqr, 9x29-bit limbs, subtractive Montgomery reduction):
-# product 81 + 18 = 99, square 45 + 18 = 63; XYZZ mixed addition 8M+2S = 918, XYZZ doubling 6M+4S = 846 (the MSM loops);
+# product 81 + 18 = 99, square 45 + 18 = 63, a b - c d with one reduction 162 + 18 = 180; XYZZ mixed addition 8M+2S = 900,
+# XYZZ doubling 6M+4S = 828 (the MSM loops; each contains one fused product pair);
 # batched-affine table entry 5M+1S + 4/15 of 1/64 of an inversion (256S+45M) = 644, Jacobian+Jacobian addition 11M+5S =
 # 1404 (combines), normalisation of one point 6M+1S + 1/64 inversion = 979
-MADS = {"madd": 918, "dbl": 846, "aff": 644, "jac": 1404, "norm": 979}
+MADS = {"madd": 900, "dbl": 828, "aff": 644, "jac": 1404, "norm": 979}
 
 
 # ---- distributed helpers (backend-agnostic: RCCL on GPUs, gloo in the CPU tests) -----------------------------

@@ -210,7 +210,7 @@ MP_HD void xyzz_dbl_ip(Xyzz<C>& p) {
   Fe<F> M = fe_add<F>(fe_dbl<F>(XX), XX);
   if (C::A == 1) M = fe_add<F>(M, fe_sqr<F>(p.ZZ));
   const Fe<F> X3 = fe_sub<F>(fe_sqr<F>(M), fe_dbl<F>(S));
-  p.Y = fe_sub<F>(fe_mul<F>(M, fe_sub<F>(S, X3)), fe_mul<F>(W, p.Y));
+  p.Y = fe_mulsub<F>(M, fe_sub<F>(S, X3), W, p.Y);
   p.X = X3;
   p.ZZ = fe_mul<F>(V, p.ZZ);
   p.ZZZ = fe_mul<F>(W, p.ZZZ);
@@ -241,7 +241,7 @@ MP_HD void xyzz_madd_ip(Xyzz<C>& p, const Aff<C>& q) {
   const Fe<F> PPP = fe_mul<F>(Pd, PP);
   const Fe<F> Q = fe_mul<F>(p.X, PP);
   const Fe<F> X3 = fe_sub<F>(fe_sub<F>(fe_sqr<F>(Rr), PPP), fe_dbl<F>(Q));
-  p.Y = fe_sub<F>(fe_mul<F>(Rr, fe_sub<F>(Q, X3)), fe_mul<F>(p.Y, PPP));
+  p.Y = fe_mulsub<F>(Rr, fe_sub<F>(Q, X3), p.Y, PPP);     // one reduction for the two products
   p.X = X3;
   p.ZZ = fe_mul<F>(p.ZZ, PP);
   p.ZZZ = fe_mul<F>(p.ZZZ, PPP);
