@@ -1,5 +1,6 @@
-// Short-Weierstrass group law for the gfx950 engine: Jacobian accumulators, affine operands
-// (mixed addition 7M+4S, doubling 1M+8S for a = 1 / 2M+5S-style for a = 0, full addition 11M+5S).
+// Short-Weierstrass group law for the gfx950 engine.  Two accumulator forms, affine operands:
+//   * XYZZ (X, Y, ZZ, ZZZ) in the MSM loops: mixed addition 8M+2S, doubling 6M+4S, each with one fused product pair;
+//   * Jacobian for partial sums and their combination: mixed addition 8M+3S, doubling 3M+6S, full addition 11M+5S.
 // Replaces ark-ec 0.3 `GroupProjective` add_assign_mixed / double_in_place / add_assign used by the
 // reference's ElGamal, Pedersen and shuffle-argument calls
 // [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:7, 380-443].

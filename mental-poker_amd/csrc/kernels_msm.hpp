@@ -10,8 +10,9 @@
 //   body_var_msm     sum_t k_t * P_t over per-proof bases (the decks, proof elements): Straus interleaving
 //                    with signed 5-bit windows over per-proof 16-entry affine tables (body_table; ark-ec's
 //                    VariableBaseMSM bucket method is hopeless at 26..52 terms on a SIMT machine:
-//                    SURVEY.md App. D), doubling chain shared by the terms of a job.
+//                    SURVEY.md App. D), doubling chain shared by the terms of a job.  XYZZ accumulators.
 //   body_table / body_recode / body_combine / body_normalize: their supporting passes.
+//   body_key_windows keyed batches: window bases 2^(5w) pk of a per-proof aggregate key (their tables: body_table).
 #pragma once
 #include "curve.hpp"
 #include "layout.hpp"
