@@ -36,7 +36,7 @@ class NoDeviceError(NativeError):
     pass
 
 
-SOURCES = ["capi.hip", "curve_stark.hip", "curve_bn254.hip", "curve_secp256k1.hip", "curve_bls12_377.hip"]
+SOURCES = ["capi.hip"] + [f % c for c in ("stark", "bn254", "secp256k1", "bls12_377") for f in ("curve_%s.hip", "curve_%s_msm.hip")]
 
 
 def build(verbose=False):

@@ -1,0 +1,5 @@
+// curve_bls12_377_msm.hip -- the group-arithmetic kernels of one curve (explicit instantiations; see kernels_msm.hpp)
+#include "kernels_msm.hpp"
+namespace mp {
+MP_MSM_KERNELS(template, Bls12_377)
+}

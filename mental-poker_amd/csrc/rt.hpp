@@ -98,6 +98,8 @@ inline void host_free(void* p) {
     if (x < nx) BODY<C>(a, x, blockIdx.y);                                        \
   }
 
+// explicit instantiation / extern declaration of kernel NAME for curve C (X = `template` or `extern template`)
+#define MP_KERNEL_INST(X, NAME, ARGS, C) X MP_GLOBAL void NAME<C>(ARGS, uint32_t);
 #define MP_LAUNCH(NAME, C, stream, nx, ny, args)                                  \
   do {                                                                            \
     if ((nx) > 0 && (ny) > 0) {                                                   \

@@ -65,6 +65,8 @@ inline void host_free(void* p) { free(p); }
     }                                                       \
   }
 #define MP_KERNEL_OCC(NAME, ARGS, BODY, WAVES) MP_KERNEL(NAME, ARGS, BODY)
+// explicit instantiation / extern declaration of kernel NAME for curve C (X = `template` or `extern template`)
+#define MP_KERNEL_INST(X, NAME, ARGS, C) X void NAME<C>(const ARGS&, uint32_t, uint32_t);
 #define MP_LAUNCH(NAME, C, stream, nx, ny, args) NAME<C>((args), (uint32_t)(nx), (uint32_t)(ny))
 
 #endif  // MP_RT_HPP
