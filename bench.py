@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--curve", default="stark")
     ap.add_argument("--streams", type=int, default=1, help="independent engine contexts (HIP streams) per GPU; the batch is split evenly")
     ap.add_argument("--fb-bits", type=int, default=20, help="fixed-base window width (8, 16 or 20 bits; 20 = 27 GB of tables at n=26)")
-    ap.add_argument("--cpu-iters", type=int, default=96, help="prove+verify pairs timed for cpu_baseline")
+    ap.add_argument("--cpu-iters", type=int, default=160, help="prove+verify pairs timed for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--keyed", type=int, default=0, metavar="K",
                     help="keyed batches: K distinct aggregate keys (card tables) spread over the batch, one key per proof "
