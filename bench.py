@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=131072, help="proofs per GPU per step (~0.9 MB of HBM each)")
+    ap.add_argument("--batch", type=int, default=262144, help="proofs per GPU per step (~0.45 MB of HBM each: 142 GB in use at the default)")
     ap.add_argument("--m", type=int, default=2)
     ap.add_argument("--n", type=int, default=26)
     ap.add_argument("--curve", default="stark")
