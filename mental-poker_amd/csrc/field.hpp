@@ -337,7 +337,13 @@ MP_HD Fe<P> fe_one() {
 template <class P>
 MP_HD bool fe_is_zero(const Fe<P>& a) {
   if constexpr (P::L29) {
-    // lazily reduced: a is one of 0, p, 2p, ... ; the limbs of k*p are k*MOD29[i] (no carries: sparse p)
+    // lazily reduced: a is one of 0, p, 2p, ... ; the limbs of k*p are k*MOD29[i] (no carries: sparse p).
+    // Fast path: where p has a zero limb, so has k*p -- almost every non-zero value is rejected by one OR chain.
+    uint32_t z = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+      if (P::MOD29[i] == 0) z |= a.v[i];
+    if (z != 0) return false;
     const uint32_t k = a.v[8] >> P::TOP29;
     uint32_t o = 0;
 #pragma unroll
