@@ -50,7 +50,8 @@ def build(verbose=False):
     headers.append(os.path.join(ROOT, "include", "mpshuffle.h"))
     hdr_time = max(os.path.getmtime(h) for h in headers)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    # max-ilp scheduling: +0.8 % on the MSM kernels in a back-to-back A/B (interleaves the mad chains with the carry handling)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
