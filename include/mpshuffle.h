@@ -115,6 +115,8 @@ int mp_verify_shuffle_batch_dev(mp_table* t, size_t B, const void* d_decks, cons
  * d_keys: B wire points.  The key's terms become per-proof work: the verifier gains one variable-base term, the prover
  * builds the key's own window tables (2^(5w) pk, w < 51) for the N re-encryptions rho_i * pk -- about 9 % more work per
  * prove+verify than under the table's fixed key.  Results are byte-identical to a table created with that key. */
+/* a table of the shared parameters alone (no aggregate key): accepts only the _keys entry points */
+int mp_table_create_params(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, uint32_t fb_window_bits, mp_table** out);
 int mp_shuffle_and_remask_batch_keys(mp_table* t, size_t B, const uint8_t* shared_keys, const uint8_t* decks,
                                      const uint8_t* masking_factors, const uint32_t* permutations, const uint8_t* prover_seeds,
                                      uint8_t* out_decks, uint8_t* out_proofs, int32_t* status);

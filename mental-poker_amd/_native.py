@@ -16,7 +16,7 @@ MP_ERR_BAD_ENCODING, MP_ERR_BAD_PERMUTATION, MP_ERR_BAD_ARGUMENT, MP_ERR_NO_DEVI
 
 SYMBOLS = [
     "mp_ctx_create", "mp_ctx_destroy", "mp_last_error", "mp_check_name", "mp_proof_size", "mp_params_size",
-    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_host_alloc", "mp_host_free", "mp_shuffle_and_remask_batch_keys",
+    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_host_alloc", "mp_host_free", "mp_shuffle_and_remask_batch_keys", "mp_table_create_params",
     "mp_verify_shuffle_batch_keys", "mp_shuffle_and_remask_batch_keys_dev", "mp_verify_shuffle_batch_keys_dev",
     "mp_setup", "mp_table_create", "mp_table_create_ex", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
     "mp_shuffle_and_remask_batch", "mp_verify_shuffle_batch", "mp_shuffle_and_remask_batch_dev",
@@ -111,6 +111,7 @@ def bind(cdll):
     cdll.mp_verify_shuffle_batch.argtypes = [c.c_void_p, c.c_size_t, u8p, u8p, u8p, i32p]
     cdll.mp_shuffle_and_remask_batch_dev.argtypes = [c.c_void_p, c.c_size_t] + [c.c_void_p] * 7
     cdll.mp_verify_shuffle_batch_dev.argtypes = [c.c_void_p, c.c_size_t] + [c.c_void_p] * 4
+    cdll.mp_table_create_params.argtypes = [c.c_void_p, c.c_uint32, c.c_uint32, u8p, c.c_uint32, c.POINTER(c.c_void_p)]
     cdll.mp_shuffle_and_remask_batch_keys.argtypes = [c.c_void_p, c.c_size_t, u8p, u8p, u8p, u32p, u8p, u8p, u8p, i32p]
     cdll.mp_verify_shuffle_batch_keys.argtypes = [c.c_void_p, c.c_size_t, u8p, u8p, u8p, u8p, i32p]
     cdll.mp_shuffle_and_remask_batch_keys_dev.argtypes = [c.c_void_p, c.c_size_t] + [c.c_void_p] * 8
@@ -221,13 +222,16 @@ class Table:
     def __init__(self, eng, m, n, params, shared_key, fb_bits=8):
         self.eng, self.lib, self.m, self.n, self.N = eng, eng.lib, m, n, m * n
         self.fb_bits = fb_bits
-        self.params, self.shared_key = bytes(params), bytes(shared_key)
+        self.params, self.shared_key = bytes(params), (bytes(shared_key) if shared_key is not None else None)
         self.pb = eng.point_bytes
         self.cb = 2 * eng.point_bytes       # bytes of one card (ciphertext)
-        if len(self.params) != self.pb * (n + 3) or len(self.shared_key) != self.pb:
+        if len(self.params) != self.pb * (n + 3) or (self.shared_key is not None and len(self.shared_key) != self.pb):
             raise NativeError(MP_ERR_BAD_ARGUMENT, "parameters / shared key have the wrong length")
         h = ctypes.c_void_p()
-        eng._chk(self.lib.mp_table_create_ex(eng.h, m, n, _in(self.params), _in(self.shared_key), fb_bits, ctypes.byref(h)))
+        if self.shared_key is None:         # parameters only: a table for keyed batches (one aggregate key per proof)
+            eng._chk(self.lib.mp_table_create_params(eng.h, m, n, _in(self.params), fb_bits, ctypes.byref(h)))
+        else:
+            eng._chk(self.lib.mp_table_create_ex(eng.h, m, n, _in(self.params), _in(self.shared_key), fb_bits, ctypes.byref(h)))
         self.h = h
         self.proof_bytes = eng.proof_size(m, n)
 

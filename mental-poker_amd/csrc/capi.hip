@@ -111,6 +111,12 @@ int mp_table_create_ex(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* param
   return MP_OK;
   MP_CATCH
 }
+int mp_table_create_params(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, uint32_t fb_window_bits, mp_table** out) {
+  // a table of the shared parameters only, for keyed batches: the enc generator G stands in for the (unused) fixed key
+  int rc = mp_table_create_ex(ctx, m, n, params, params, fb_window_bits, out);
+  if (rc == MP_OK) (*out)->keyless = true;
+  return rc;
+}
 void mp_table_destroy(mp_table* t) {
   if (!t) return;
   for (auto& st : t->io) {
@@ -155,6 +161,7 @@ int mp_shuffle_and_remask_batch_dev(mp_table* t, size_t B, const void* d_decks, 
                                     void* d_out_proofs, void* d_status) {
   if (!t || !B || !d_decks || !d_masking_factors || !d_permutations || !d_prover_seeds || !d_out_decks || !d_out_proofs || !d_status)
     return fail(MP_ERR_BAD_ARGUMENT, "mp_shuffle_and_remask_batch_dev: bad argument");
+  if (t->keyless) return fail(MP_ERR_BAD_ARGUMENT, "this table has no aggregate key: use the _keys entry points");
   MP_TRY
   rt::set_device(t->ctx->device);
   t->prove_dev(B, (const uint8_t*)d_decks, (const uint8_t*)d_masking_factors, (const uint32_t*)d_permutations,
@@ -166,6 +173,7 @@ int mp_verify_shuffle_batch_dev(mp_table* t, size_t B, const void* d_decks, cons
                                 const void* d_proofs, void* d_status) {
   if (!t || !B || !d_decks || !d_shuffled_decks || !d_proofs || !d_status)
     return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_batch_dev: bad argument");
+  if (t->keyless) return fail(MP_ERR_BAD_ARGUMENT, "this table has no aggregate key: use the _keys entry points");
   MP_TRY
   rt::set_device(t->ctx->device);
   t->verify_dev(B, (const uint8_t*)d_decks, (const uint8_t*)d_shuffled_decks, (const uint8_t*)d_proofs, (int32_t*)d_status);
@@ -221,6 +229,7 @@ static int prove_batch_host(mp_table* t, size_t B, const uint8_t* keys, const ui
                             uint8_t* out_proofs, int32_t* status) {
   if (!t || !B || !decks || !masking_factors || !permutations || !prover_seeds || !out_decks || !out_proofs || !status)
     return fail(MP_ERR_BAD_ARGUMENT, "mp_shuffle_and_remask_batch: bad argument");
+  if (t->keyless && !keys) return fail(MP_ERR_BAD_ARGUMENT, "this table has no aggregate key: use the _keys entry points");
   MP_TRY
   rt::set_device(t->ctx->device);
   rt::Stream s = t->ctx->stream, up = t->ctx->h2d, down = t->ctx->d2h;
@@ -269,6 +278,7 @@ static int prove_batch_host(mp_table* t, size_t B, const uint8_t* keys, const ui
 static int verify_batch_host(mp_table* t, size_t B, const uint8_t* keys, const uint8_t* decks, const uint8_t* shuffled_decks,
                              const uint8_t* proofs, int32_t* status) {
   if (!t || !B || !decks || !shuffled_decks || !proofs || !status) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_batch: bad argument");
+  if (t->keyless && !keys) return fail(MP_ERR_BAD_ARGUMENT, "this table has no aggregate key: use the _keys entry points");
   MP_TRY
   rt::set_device(t->ctx->device);
   rt::Stream s = t->ctx->stream, up = t->ctx->h2d, down = t->ctx->d2h;

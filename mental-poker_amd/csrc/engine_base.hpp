@@ -137,6 +137,7 @@ struct mp_table {
   mp_io_stage io[2];
   uint32_t m = 0, n = 0, N = 0;
   uint32_t point_bytes = 64;   // wire size of a point on this table's curve (Geo<C>::PB)
+  bool keyless = false;        // created from the parameters alone (mp_table_create_params): keyed entry points only
   virtual ~mp_table() {}
   virtual void reserve(size_t B) = 0;
   virtual void set_latency_batch(size_t B) = 0;

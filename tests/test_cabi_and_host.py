@@ -89,7 +89,7 @@ def test_kernel_bodies_under_emulation_match_golden(emu, name):
     t.close()
 
 
-def test_emulated_keyed_batch(emu, coracle):
+def test_emulated_keyed_batch(emu, coracle, native):
     """keyed batches (one aggregate key per proof, mp_*_batch_keys): byte-identical to the oracle run under each proof's key"""
     for cv, m, n in (("stark", 2, 3), ("bls12_377", 2, 3)):
         eng = emu(cv)
@@ -111,6 +111,16 @@ def test_emulated_keyed_batch(emu, coracle):
             wrong = ins[0]["pk"] + ins[0]["pk"] + ins[2]["pk"]          # proof 1 checked under another table's key
             assert t.verify_shuffle_batch_keys(wrong, decks, d, p) == [0, 1, 0]
         t.close()
+    # a table made from the parameters alone serves keyed batches and refuses the fixed-key entry points
+    eng = emu("stark")
+    g = coracle.gen_inputs("stark", 2, 3, 500)
+    t = eng.table(2, 3, g["params"], None)
+    d, p, st = t.shuffle_and_remask_batch_keys(g["pk"], g["deck"], g["rho"], g["perm"], g["prover_seed"])
+    assert st == [0] and (d, p) == coracle.shuffle_and_remask("stark", 2, 3, g["params"], g["pk"], g["deck"], g["rho"], g["perm"], g["prover_seed"])
+    assert t.verify_shuffle_batch_keys(g["pk"], g["deck"], d, p) == [0]
+    with pytest.raises(native.NativeError):
+        t.verify_shuffle_batch(g["deck"], d, p)
+    t.close()
 
 
 def test_emulated_batch_and_status(emu, coracle):
