@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--fb-bits", type=int, default=20, help="fixed-base window width (8, 16 or 20 bits; 20 = 27 GB of tables at n=26)")
     ap.add_argument("--cpu-iters", type=int, default=160, help="prove+verify pairs timed for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency-batch", type=int, default=None,
+                    help="batches up to this size use the latency plan (engine default 8192): mp_set_latency_batch")
     ap.add_argument("--keyed", type=int, default=0, metavar="K",
                     help="keyed batches: K distinct aggregate keys (card tables) spread over the batch, one key per proof "
                          "(mp_*_batch_keys_dev); 0 = every proof under the table's own key")
@@ -143,6 +145,8 @@ def main():
     engines = [eng] + [mp.Engine(curve, device=local) for _ in range(S - 1)]
     tables = [e.table(m, n, params, pk, fb_bits=args.fb_bits) for e in engines]
     for t in tables:
+        if args.latency_batch is not None:
+            t.set_latency_batch(args.latency_batch)
         t.reserve(Bs)
     table = tables[0]
     proof_bytes = table.proof_bytes

@@ -97,7 +97,8 @@ struct Table : mp_table {
   bool psk_ready = false;
   DevBuf<Term> key_recode, key_tables;          // static job lists of the per-proof key tables
   uint32_t key_d_first = 0, key_t_first = 0;     // first digit slot (rho_0) / table slot (window 0) of the key machinery
-  uint32_t latency_batch = 512;                  // batches up to this size use the latency plan (mp_set_latency_batch)
+  uint32_t latency_batch = 8192;                 // batches up to this size use the latency plan (mp_set_latency_batch);
+                                                 // measured crossover with the throughput plan: ~12 k proofs (52 cards)
   PlanSet& pick(uint32_t B, bool keyed = false) { return (keyed ? psk : ps)[B <= latency_batch ? 1 : 0]; }
   void set_latency_batch(size_t b) override { latency_batch = (uint32_t)std::min<size_t>(b, 0xFFFFFFFFu); }
   uint32_t cur_table_group = TABLE_GROUP;

@@ -68,7 +68,7 @@ def test_batch_matches_oracle(mp, engines, coracle, curve, m, n, B, plan):
     g0 = coracle.gen_inputs(curve, m, n, 100)
     pp = mp.Parameters(m, n, g0["params"])
     pk = g0["pk"]
-    cards.table(pp, pk).set_latency_batch(512 if plan == "latency" else 0)
+    cards.table(pp, pk).set_latency_batch(8192 if plan == "latency" else 0)
     ins = []
     for b in range(B):
         g = coracle.gen_inputs(curve, m, n, 200 + b)     # same draw order => same params? no: own params per seed
@@ -90,7 +90,7 @@ def test_batch_matches_oracle(mp, engines, coracle, curve, m, n, B, plan):
     rot = shufs[1:] + shufs[:1]
     out = cards.verify_shuffle_batch(pp, pk, decks, rot, proofs)
     assert all(o == mp.CryptoError("Hadamard Product (5.1)") for o in out)
-    cards.table(pp, pk).set_latency_batch(512)
+    cards.table(pp, pk).set_latency_batch(8192)
 
 
 @pytest.mark.parametrize("fb_bits", [16, 20])
@@ -222,7 +222,7 @@ def test_keyed_batches_match_oracle(mp, engines, coracle, curve, m, n, B, plan):
     g0 = coracle.gen_inputs(curve, m, n, 700)
     pp = mp.Parameters(m, n, g0["params"])
     t = cards.table(pp, g0["pk"])
-    t.set_latency_batch(512 if plan == "latency" else 0)
+    t.set_latency_batch(8192 if plan == "latency" else 0)
     ins = [coracle.gen_inputs(curve, m, n, 701 + b) for b in range(B)]
     keys, decks = b"".join(g["pk"] for g in ins), b"".join(g["deck"] for g in ins)
     d, p, st = t.shuffle_and_remask_batch_keys(keys, decks, b"".join(g["rho"] for g in ins), [v for g in ins for v in g["perm"]],
@@ -235,7 +235,7 @@ def test_keyed_batches_match_oracle(mp, engines, coracle, curve, m, n, B, plan):
     assert t.verify_shuffle_batch_keys(keys, decks, d, p) == [0] * B
     rot = b"".join(g["pk"] for g in ins[1:] + ins[:1])
     assert all(v > 0 for v in t.verify_shuffle_batch_keys(rot, decks, d, p))
-    t.set_latency_batch(512)
+    t.set_latency_batch(8192)
 
 
 def test_verifier_fuzz_against_oracle(mp, engines, coracle):
@@ -300,7 +300,7 @@ def test_verifier_fuzz_against_oracle(mp, engines, coracle):
         t.set_merged_verify(mode)
         assert t.verify_shuffle_batch(deck * B, shuf * B, b"".join(proofs)) == exp
     t.set_merged_verify(True)
-    t.set_latency_batch(512)
+    t.set_latency_batch(8192)
 
 
 def test_merged_and_per_equation_verification_agree(mp, engines):
@@ -347,7 +347,7 @@ def test_merged_and_per_equation_verification_agree(mp, engines):
         out[mode] = t.verify_shuffle_batch(deck * B, shuf * B, b"".join(proofs))
         assert t.verify_shuffle_batch(deck * 3, shuf * 3, good * 3) == [0, 0, 0]
     t.set_merged_verify(True)
-    t.set_latency_batch(512)
+    t.set_latency_batch(8192)
     assert out[True] == out[False]
     assert out[True] == [0, 2, 0, 3, 4, 4, 0, -1, 2]
 
@@ -444,11 +444,12 @@ def test_full_size_properties(mp, engines, coracle):
     """BASELINE size (52 cards, m=2, n=26), a few hundred proofs: every honest proof verifies, outputs do not
     depend on the position in the batch, a chain of dependent shuffles (deck_{j+1} = output_j) verifies, and
     spot proofs equal the oracle's."""
-    cv, m, n, B = "stark", 2, 26, 640      # > 512: the throughput plan
+    cv, m, n, B = "stark", 2, 26, 640
     N = m * n
     g = coracle.gen_inputs(cv, m, n, 31337)
     cards = engines(cv)
     pp = mp.Parameters(m, n, g["params"])
+    cards.table(pp, g["pk"]).set_latency_batch(0)       # the throughput plan (and the merged verifier), as at full batch sizes
     deck = _split(g["deck"], 2 * cards.engine.point_bytes)
     rng = mp.ChaCha20Rng(b"\x05" * 32)
     q = po.STARK.q
@@ -476,3 +477,4 @@ def test_full_size_properties(mp, engines, coracle):
         with pytest.raises(mp.CryptoError):
             cards.verify_shuffle(pp, g["pk"], deck if j else nxt, nxt if j else cur, proof)
         cur = nxt
+    cards.table(pp, g["pk"]).set_latency_batch(8192)
