@@ -92,15 +92,23 @@ struct Table : mp_table {
     DevBuf<ProofElem> pwire, vwire;
     uint32_t table_group = TABLE_GROUP;
   };
-  PlanSet ps[2];        // plans with the table's own aggregate key as a fixed base
-  PlanSet psk[2];       // plans for keyed batches (per-proof aggregate key): built on first use
+  // Three static work splits per table, identical results: [0] throughput (64 variable-base / 8 fixed-base terms per lane,
+  // 64 bases per table lane: fewest operations), [1] latency (4 / 2 / 8: ~16x more lanes per proof), [2] medium (16 / 4 / 16).
+  // Measured on an MI355X, 52 cards: latency wins up to ~4 k proofs in flight, medium up to ~14 k, throughput beyond.
+  static const int N_PLANS = 3;
+  PlanSet ps[N_PLANS];        // plans with the table's own aggregate key as a fixed base
+  PlanSet psk[N_PLANS];       // plans for keyed batches (per-proof aggregate key): built on first use
   bool psk_ready = false;
   DevBuf<Term> key_recode, key_tables;          // static job lists of the per-proof key tables
   uint32_t key_d_first = 0, key_t_first = 0;     // first digit slot (rho_0) / table slot (window 0) of the key machinery
-  uint32_t latency_batch = 8192;                 // batches up to this size use the latency plan (mp_set_latency_batch);
-                                                 // measured crossover with the throughput plan: ~12 k proofs (52 cards)
-  PlanSet& pick(uint32_t B, bool keyed = false) { return (keyed ? psk : ps)[B <= latency_batch ? 1 : 0]; }
-  void set_latency_batch(size_t b) override { latency_batch = (uint32_t)std::min<size_t>(b, 0xFFFFFFFFu); }
+  uint32_t latency_batch = 4096;                 // batches up to this size use the latency plan (mp_set_latency_batch),
+  uint32_t medium_batch = 14336;                 // up to this size the medium plan (3.5 x latency_batch), larger ones throughput
+  int plan_of(uint32_t B) const { return B <= latency_batch ? 1 : (B <= medium_batch ? 2 : 0); }
+  PlanSet& pick(uint32_t B, bool keyed = false) { return (keyed ? psk : ps)[plan_of(B)]; }
+  void set_latency_batch(size_t b) override {
+    latency_batch = (uint32_t)std::min<size_t>(b, 0x20000000u);
+    medium_batch = latency_batch / 2 * 7;
+  }
   uint32_t cur_table_group = TABLE_GROUP;
   DevBuf<uint32_t> fbpts;    // (n+5) affine base points
   DevBuf<uint32_t> FB;       // fixed-base window tables
@@ -125,11 +133,12 @@ struct Table : mp_table {
 
   void build_plans(PlanSet* set, bool keyed) {
     rt::Stream s = ctx->stream;
-    for (int k = 0; k < 2; ++k) {
+    static const uint32_t fch[N_PLANS] = {FCHUNK, 2, 4}, vch[N_PLANS] = {VCHUNK, 4, 16}, grp[N_PLANS] = {TABLE_GROUP, 8, 16};
+    for (int k = 0; k < N_PLANS; ++k) {
       PlanSet& q = set[k];
-      q.pplan = make_prove_plan(m, n, k ? 2u : FCHUNK, k ? 4u : VCHUNK, G_::PB, keyed);
-      q.vplan = make_verify_plan(m, n, k ? 2u : FCHUNK, k ? 4u : VCHUNK, G_::PB, keyed);
-      q.table_group = k ? 8u : TABLE_GROUP;
+      q.pplan = make_prove_plan(m, n, fch[k], vch[k], G_::PB, keyed);
+      q.vplan = make_verify_plan(m, n, fch[k], vch[k], G_::PB, keyed);
+      q.table_group = grp[k];
       for (int i = 0; i < 5; ++i) q.pph[i].upload(q.pplan.ph[i], s);
       q.vph.upload(q.vplan.ph, s);
       q.vmph.upload(q.vplan.mph, s);
@@ -149,7 +158,7 @@ struct Table : mp_table {
     const ProveLay& l = psk[0].pplan.lay;
     // the key's digit / table slots live behind those of every phase of either plan
     key_d_first = key_t_first = 0;
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < N_PLANS; ++k)
       for (int i = 0; i < 5; ++i) {
         key_d_first = std::max(key_d_first, psk[k].pplan.ph[i].n_dslots);
         key_t_first = std::max(key_t_first, psk[k].pplan.ph[i].n_tslots);
@@ -440,7 +449,7 @@ struct Table : mp_table {
     rt::Stream s = ctx->stream;
     // small batches (latency plan) go straight to the per-equation pass: with an idle chip the merged MSM is one long
     // dependency chain and its flag read-back a round trip -- it only pays when lanes are scarce
-    for (int pass = (merged_verify && B > latency_batch) ? 0 : 1; pass < 2; ++pass) {
+    for (int pass = (merged_verify && plan_of(B) == 0) ? 0 : 1; pass < 2; ++pass) {
       const bool merged = pass == 0;
       rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
       {

@@ -98,7 +98,7 @@ def test_emulated_keyed_batch(emu, coracle, native):
         t = eng.table(m, n, g0["params"], g0["pk"])
         keys = b"".join(g["pk"] for g in ins)
         decks = b"".join(g["deck"] for g in ins)
-        for lb in (8192, 0):
+        for lb in (8192, 2, 0):            # latency, medium (2 < B = 3 <= 7) and throughput plans
             t.set_latency_batch(lb)
             d, p, st = t.shuffle_and_remask_batch_keys(keys, decks, b"".join(g["rho"] for g in ins), [v for g in ins for v in g["perm"]],
                                                        b"".join(g["prover_seed"] for g in ins))

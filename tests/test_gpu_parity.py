@@ -62,13 +62,14 @@ def test_golden_vectors(mp, engines, path):
 
 @pytest.mark.parametrize("curve,m,n,B", [("stark", 2, 26, 6), ("stark", 4, 13, 5), ("stark", 6, 5, 3),
                                          ("bn254", 3, 5, 3), ("secp256k1", 2, 7, 3), ("bls12_377", 2, 5, 3)])
-@pytest.mark.parametrize("plan", ["latency", "throughput"])
+@pytest.mark.parametrize("plan", ["latency", "medium", "throughput"])
 def test_batch_matches_oracle(mp, engines, coracle, curve, m, n, B, plan):
     cards = engines(curve)
     g0 = coracle.gen_inputs(curve, m, n, 100)
     pp = mp.Parameters(m, n, g0["params"])
     pk = g0["pk"]
-    cards.table(pp, pk).set_latency_batch(8192 if plan == "latency" else 0)
+    # latency plan up to L proofs, medium plan up to 3.5 L, throughput beyond (L = 0: always throughput); B is 3..6 here
+    cards.table(pp, pk).set_latency_batch({"latency": 8192, "medium": 2, "throughput": 0}[plan])
     ins = []
     for b in range(B):
         g = coracle.gen_inputs(curve, m, n, 200 + b)     # same draw order => same params? no: own params per seed
