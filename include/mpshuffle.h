@@ -131,8 +131,8 @@ int mp_sync(mp_ctx* ctx);
 int mp_reserve(mp_table* t, size_t B);           /* pre-allocate the batch workspace for B proofs */
 /* Every table holds three static work splits with identical results: a throughput plan (large sub-jobs, fewest operations),
  * a latency plan (small sub-jobs: ~16x more lanes per proof) and a medium plan in between.  Batches of at most `B` proofs
- * use the latency plan, up to 3.5 B the medium plan, larger ones the throughput plan (default B = 4096: measured on an
- * MI355X with 52 cards; 0 = always throughput). */
+ * use the latency plan, up to 3.5 B the medium plan, larger ones the throughput plan (default B = 4096 * 52 / N, at least 64:
+ * measured on an MI355X with 52 and 1024 cards; 0 = always throughput). */
 int mp_set_latency_batch(mp_table* t, size_t B);
 /* Verification strategy.  on (default): the verifier first evaluates ALL group equations of a proof merged into one
  * multi-scalar multiplication with random weights derived from the whole proof (soundness loss ~2^-250); a batch in which

@@ -177,6 +177,8 @@ struct Table : mp_table {
     fbg = FbGeom{fb_bits, (256u + fb_bits - 1u) / fb_bits, (1u << fb_bits) - 1u};
     m = m_; n = n_; N = m * n;
     point_bytes = G_::PB;
+    // plan thresholds count lanes, and a proof of N cards brings ~N/52 times the lanes of a 52-card proof
+    set_latency_batch(std::max<size_t>(64, (size_t)4096 * 52 / N));
     nwin = (uint32_t)vb_windows(R::BITS);
     FixedBases fb{n};
     std::vector<Aff<C>> bases(fb.count());
