@@ -91,6 +91,7 @@ struct Table : mp_table {
     DevBuf<LinJob> lin;
     DevBuf<ProofElem> pwire, vwire;
     uint32_t table_group = TABLE_GROUP;
+    uint32_t norm_chunk = NORM_CHUNK;
   };
   // Three static work splits per table, identical results: [0] throughput (64 variable-base / 8 fixed-base terms per lane,
   // 64 bases per table lane: fewest operations), [1] latency (4 / 2 / 8: ~16x more lanes per proof), [2] medium (16 / 4 / 16).
@@ -110,6 +111,7 @@ struct Table : mp_table {
     medium_batch = latency_batch / 2 * 7;
   }
   uint32_t cur_table_group = TABLE_GROUP;
+  uint32_t cur_norm_chunk = NORM_CHUNK;          // points per inversion in k_normalize: a property of the plan in use
   DevBuf<uint32_t> fbpts;    // (n+5) affine base points
   DevBuf<uint32_t> FB;       // fixed-base window tables
   Workspace ws;
@@ -139,6 +141,7 @@ struct Table : mp_table {
       q.pplan = make_prove_plan(m, n, fch[k], vch[k], G_::PB, keyed);
       q.vplan = make_verify_plan(m, n, fch[k], vch[k], G_::PB, keyed);
       q.table_group = grp[k];
+      q.norm_chunk = k == 1 ? 8u : (k == 2 ? 32u : NORM_CHUNK);   // fewer points per serial inversion chain when lanes are idle
       for (int i = 0; i < 5; ++i) q.pph[i].upload(q.pplan.ph[i], s);
       q.vph.upload(q.vplan.ph, s);
       q.vmph.upload(q.vplan.mph, s);
@@ -226,7 +229,8 @@ struct Table : mp_table {
 
   void normalize_flat(const uint32_t* src, uint32_t* dst, uint32_t* scratch, size_t count) {
     if (!count) return;
-    NormArgs a{src, dst, scratch, (uint32_t)count, (uint32_t)((count + NORM_CHUNK - 1) / NORM_CHUNK), NORM_CHUNK};
+    const uint32_t ch = cur_norm_chunk;
+    NormArgs a{src, dst, scratch, (uint32_t)count, (uint32_t)((count + ch - 1) / ch), ch};
     MP_RUN(k_normalize, C, a.nthreads, 1, a);
   }
 
@@ -352,6 +356,7 @@ struct Table : mp_table {
     Workspace& w = ws;
     PlanSet& q = pick(B, keyed);
     cur_table_group = q.table_group;
+    cur_norm_chunk = q.norm_chunk;
     const ProveLay& l = q.pplan.lay;
     PhaseDev* pph = q.pph;
     rt::Stream s = ctx->stream;
@@ -447,6 +452,7 @@ struct Table : mp_table {
     Workspace& w = ws;
     PlanSet& q = pick(B, keyed);
     cur_table_group = q.table_group;
+    cur_norm_chunk = q.norm_chunk;
     const VerifyLay& l = q.vplan.lay;
     rt::Stream s = ctx->stream;
     // small batches (latency plan) go straight to the per-equation pass: with an idle chip the merged MSM is one long
