@@ -129,9 +129,10 @@ int mp_verify_shuffle_batch_keys_dev(mp_table* t, size_t B, const void* d_keys, 
                                      const void* d_proofs, void* d_status);
 int mp_sync(mp_ctx* ctx);
 int mp_reserve(mp_table* t, size_t B);           /* pre-allocate the batch workspace for B proofs */
-/* Every table holds three static work splits with identical results: a throughput plan (large sub-jobs, fewest operations),
- * a latency plan (small sub-jobs: ~16x more lanes per proof) and a medium plan in between.  Batches of at most `B` proofs
- * use the latency plan, up to 3.5 B the medium plan, larger ones the throughput plan (default B = 4096 * 52 / N, at least 64:
+/* Every table holds four static work splits with identical results: a throughput plan (large sub-jobs, fewest operations),
+ * a latency plan (small sub-jobs: ~16x more lanes per proof), a medium plan in between and a finest split for single proofs.
+ * Batches of at most 3/16 B proofs use the finest split, up to `B` the latency plan, up to 3.5 B the medium plan, larger ones
+ * the throughput plan (default B = 4096 * 52 / N, at least 64:
  * measured on an MI355X with 52 and 1024 cards; 0 = always throughput). */
 int mp_set_latency_batch(mp_table* t, size_t B);
 /* Verification strategy.  on (default): the verifier first evaluates ALL group equations of a proof merged into one

@@ -93,10 +93,11 @@ struct Table : mp_table {
     uint32_t table_group = TABLE_GROUP;
     uint32_t norm_chunk = NORM_CHUNK;
   };
-  // Three static work splits per table, identical results: [0] throughput (64 variable-base / 8 fixed-base terms per lane,
-  // 64 bases per table lane: fewest operations), [1] latency (4 / 2 / 8: ~16x more lanes per proof), [2] medium (16 / 4 / 16).
-  // Measured on an MI355X, 52 cards: latency wins up to ~4 k proofs in flight, medium up to ~14 k, throughput beyond.
-  static const int N_PLANS = 3;
+  // Four static work splits per table, identical results: [0] throughput (64 variable-base / 8 fixed-base terms per lane,
+  // 64 bases per table lane: fewest operations), [1] latency (4 / 2 / 8: ~16x more lanes per proof), [2] medium (16 / 4 / 16),
+  // [3] single proofs and tiny batches (2 / 1 / 4).  Measured on an MI355X, 52 cards: [3] wins up to ~768 proofs in flight,
+  // latency up to ~4 k, medium up to ~14 k, throughput beyond.
+  static const int N_PLANS = 4;
   PlanSet ps[N_PLANS];        // plans with the table's own aggregate key as a fixed base
   PlanSet psk[N_PLANS];       // plans for keyed batches (per-proof aggregate key): built on first use
   bool psk_ready = false;
@@ -104,11 +105,13 @@ struct Table : mp_table {
   uint32_t key_d_first = 0, key_t_first = 0;     // first digit slot (rho_0) / table slot (window 0) of the key machinery
   uint32_t latency_batch = 4096;                 // batches up to this size use the latency plan (mp_set_latency_batch),
   uint32_t medium_batch = 14336;                 // up to this size the medium plan (3.5 x latency_batch), larger ones throughput
-  int plan_of(uint32_t B) const { return B <= latency_batch ? 1 : (B <= medium_batch ? 2 : 0); }
+  uint32_t tiny_batch = 768;                     // up to this size the finest split (3/16 x latency_batch)
+  int plan_of(uint32_t B) const { return B <= tiny_batch ? 3 : (B <= latency_batch ? 1 : (B <= medium_batch ? 2 : 0)); }
   PlanSet& pick(uint32_t B, bool keyed = false) { return (keyed ? psk : ps)[plan_of(B)]; }
   void set_latency_batch(size_t b) override {
     latency_batch = (uint32_t)std::min<size_t>(b, 0x20000000u);
     medium_batch = latency_batch / 2 * 7;
+    tiny_batch = latency_batch / 16 * 3;
   }
   uint32_t cur_table_group = TABLE_GROUP;
   uint32_t cur_norm_chunk = NORM_CHUNK;          // points per inversion in k_normalize: a property of the plan in use
@@ -135,13 +138,14 @@ struct Table : mp_table {
 
   void build_plans(PlanSet* set, bool keyed) {
     rt::Stream s = ctx->stream;
-    static const uint32_t fch[N_PLANS] = {FCHUNK, 2, 4}, vch[N_PLANS] = {VCHUNK, 4, 16}, grp[N_PLANS] = {TABLE_GROUP, 8, 16};
+    static const uint32_t fch[N_PLANS] = {FCHUNK, 2, 4, 1}, vch[N_PLANS] = {VCHUNK, 4, 16, 2}, grp[N_PLANS] = {TABLE_GROUP, 8, 16, 4},
+                          nch[N_PLANS] = {NORM_CHUNK, 8, 32, 4};
     for (int k = 0; k < N_PLANS; ++k) {
       PlanSet& q = set[k];
       q.pplan = make_prove_plan(m, n, fch[k], vch[k], G_::PB, keyed);
       q.vplan = make_verify_plan(m, n, fch[k], vch[k], G_::PB, keyed);
       q.table_group = grp[k];
-      q.norm_chunk = k == 1 ? 8u : (k == 2 ? 32u : NORM_CHUNK);   // fewer points per serial inversion chain when lanes are idle
+      q.norm_chunk = nch[k];       // fewer points per serial inversion chain when lanes are idle
       for (int i = 0; i < 5; ++i) q.pph[i].upload(q.pplan.ph[i], s);
       q.vph.upload(q.vplan.ph, s);
       q.vmph.upload(q.vplan.mph, s);

@@ -75,7 +75,7 @@ def test_kernel_bodies_under_emulation_match_golden(emu, name):
     eng = emu(g["curve"])
     m, n = g["m"], g["n"]
     t = eng.table(m, n, bytes.fromhex(g["params"]), bytes.fromhex(g["pk"]))
-    for latency_batch in (8192, 0):      # latency plan (small sub-jobs), then throughput plan (large sub-jobs, Toom-Cook for m = 2)
+    for latency_batch in (8192, 8, 0):   # finest split, latency plan, throughput plan (large sub-jobs, Toom-Cook for m = 2)
         t.set_latency_batch(latency_batch)
         deck, proof = t.shuffle_and_remask(bytes.fromhex(g["deck"]), bytes.fromhex(g["rho"]), g["perm"], bytes.fromhex(g["prover_seed"]))
         assert deck.hex() == g["shuffled"]
@@ -98,7 +98,7 @@ def test_emulated_keyed_batch(emu, coracle, native):
         t = eng.table(m, n, g0["params"], g0["pk"])
         keys = b"".join(g["pk"] for g in ins)
         decks = b"".join(g["deck"] for g in ins)
-        for lb in (8192, 2, 0):            # latency, medium (2 < B = 3 <= 7) and throughput plans
+        for lb in (8192, 8, 2, 0):         # finest, latency, medium (2 < B = 3 <= 7) and throughput plans
             t.set_latency_batch(lb)
             d, p, st = t.shuffle_and_remask_batch_keys(keys, decks, b"".join(g["rho"] for g in ins), [v for g in ins for v in g["perm"]],
                                                        b"".join(g["prover_seed"] for g in ins))

@@ -62,14 +62,15 @@ def test_golden_vectors(mp, engines, path):
 
 @pytest.mark.parametrize("curve,m,n,B", [("stark", 2, 26, 6), ("stark", 4, 13, 5), ("stark", 6, 5, 3),
                                          ("bn254", 3, 5, 3), ("secp256k1", 2, 7, 3), ("bls12_377", 2, 5, 3)])
-@pytest.mark.parametrize("plan", ["latency", "medium", "throughput"])
+@pytest.mark.parametrize("plan", ["tiny", "latency", "medium", "throughput"])
 def test_batch_matches_oracle(mp, engines, coracle, curve, m, n, B, plan):
     cards = engines(curve)
     g0 = coracle.gen_inputs(curve, m, n, 100)
     pp = mp.Parameters(m, n, g0["params"])
     pk = g0["pk"]
-    # latency plan up to L proofs, medium plan up to 3.5 L, throughput beyond (L = 0: always throughput); B is 3..6 here
-    cards.table(pp, pk).set_latency_batch({"latency": 8192, "medium": 2, "throughput": 0}[plan])
+    # finest split up to 3/16 L proofs, latency plan up to L, medium plan up to 3.5 L, throughput beyond (L = 0: always
+    # throughput); B is 3..6 here
+    cards.table(pp, pk).set_latency_batch({"tiny": 8192, "latency": 8, "medium": 2, "throughput": 0}[plan])
     ins = []
     for b in range(B):
         g = coracle.gen_inputs(curve, m, n, 200 + b)     # same draw order => same params? no: own params per seed
@@ -214,7 +215,7 @@ def test_tampering_names_the_failing_check(mp, engines):
 
 
 @pytest.mark.parametrize("curve,m,n,B", [("stark", 2, 26, 5), ("stark", 4, 13, 3), ("secp256k1", 2, 7, 3), ("bls12_377", 2, 5, 2)])
-@pytest.mark.parametrize("plan", ["latency", "throughput"])
+@pytest.mark.parametrize("plan", ["tiny", "latency", "throughput"])
 def test_keyed_batches_match_oracle(mp, engines, coracle, curve, m, n, B, plan):
     """mp_*_batch_keys: every proof of the batch under its own aggregate key (tables of a card server share the parameters
     and differ in the key [REF mod.rs:380-386]) -- byte-identical to the oracle run with that key; a proof checked under
@@ -223,7 +224,7 @@ def test_keyed_batches_match_oracle(mp, engines, coracle, curve, m, n, B, plan):
     g0 = coracle.gen_inputs(curve, m, n, 700)
     pp = mp.Parameters(m, n, g0["params"])
     t = cards.table(pp, g0["pk"])
-    t.set_latency_batch(8192 if plan == "latency" else 0)
+    t.set_latency_batch({"tiny": 8192, "latency": 8, "throughput": 0}[plan])
     ins = [coracle.gen_inputs(curve, m, n, 701 + b) for b in range(B)]
     keys, decks = b"".join(g["pk"] for g in ins), b"".join(g["deck"] for g in ins)
     d, p, st = t.shuffle_and_remask_batch_keys(keys, decks, b"".join(g["rho"] for g in ins), [v for g in ins for v in g["perm"]],

@@ -10,7 +10,7 @@ m, n = 2, 26
 g = co.gen_inputs("stark", m, n, 7)
 eng = mp.Engine("stark", 0)
 t = eng.table(m, n, g["params"], g["pk"], fb_bits=16)
-for name, lb in (("latency plan", 8192), ("throughput plan", 0)):
+for name, lb in (("finest split", 8192), ("throughput plan", 0)):
     t.set_latency_batch(lb)
     for B in (1, 4, 64):
         decks, rho, perm, seeds = g["deck"] * B, g["rho"] * B, g["perm"] * B, g["prover_seed"] * B
