@@ -459,9 +459,10 @@ struct Table : mp_table {
     cur_norm_chunk = q.norm_chunk;
     const VerifyLay& l = q.vplan.lay;
     rt::Stream s = ctx->stream;
-    // small batches (latency plan) go straight to the per-equation pass: with an idle chip the merged MSM is one long
-    // dependency chain and its flag read-back a round trip -- it only pays when lanes are scarce
-    for (int pass = (merged_verify && plan_of(B) == 0) ? 0 : 1; pass < 2; ++pass) {
+    // small batches (the two finest splits) go straight to the per-equation pass: with an idle chip the merged MSM is one long
+    // dependency chain and its flag read-back a round trip -- it pays from the medium plan on (+3 % there, measured)
+    const int plan = plan_of(B);
+    for (int pass = (merged_verify && (plan == 0 || plan == 2)) ? 0 : 1; pass < 2; ++pass) {
       const bool merged = pass == 0;
       rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
       {
