@@ -72,6 +72,8 @@ size_t mp_params_size_curve(int curve_id, uint32_t n);            /* (n+3) * mp_
  * runtime's staging speed.  NULL on failure (mp_last_error). */
 void* mp_host_alloc(size_t bytes);
 void mp_host_free(void* p);
+/* proofs per pipelined chunk of the host-buffer entry points (default 65536; 0 restores the default) */
+int mp_set_io_chunk(mp_table* t, size_t proofs);
 
 /* ---- DLCards::setup -----------------------------------------------------------------------------------
  * Derives G, ck_0..ck_{n-1}, H, gen = k * G_std with k = Fr::rand(ChaCha20Rng::from_seed(seed)) in that order. */

@@ -16,7 +16,7 @@ MP_ERR_BAD_ENCODING, MP_ERR_BAD_PERMUTATION, MP_ERR_BAD_ARGUMENT, MP_ERR_NO_DEVI
 
 SYMBOLS = [
     "mp_ctx_create", "mp_ctx_destroy", "mp_last_error", "mp_check_name", "mp_proof_size", "mp_params_size",
-    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_host_alloc", "mp_host_free", "mp_shuffle_and_remask_batch_keys", "mp_table_create_params",
+    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_host_alloc", "mp_host_free", "mp_set_io_chunk", "mp_shuffle_and_remask_batch_keys", "mp_table_create_params",
     "mp_verify_shuffle_batch_keys", "mp_shuffle_and_remask_batch_keys_dev", "mp_verify_shuffle_batch_keys_dev",
     "mp_setup", "mp_table_create", "mp_table_create_ex", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
     "mp_shuffle_and_remask_batch", "mp_verify_shuffle_batch", "mp_shuffle_and_remask_batch_dev",
@@ -90,6 +90,7 @@ def bind(cdll):
     cdll.mp_params_size.argtypes = [c.c_uint32]
     cdll.mp_params_size.restype = c.c_size_t
     cdll.mp_set_merged_verify.argtypes = [c.c_void_p, c.c_int]
+    cdll.mp_set_io_chunk.argtypes = [c.c_void_p, c.c_size_t]
     cdll.mp_host_alloc.argtypes = [c.c_size_t]
     cdll.mp_host_alloc.restype = c.c_void_p
     cdll.mp_host_free.argtypes = [c.c_void_p]
@@ -348,6 +349,10 @@ class Table:
         st = (ctypes.c_int32 * B)()
         self.eng._chk(self.lib.mp_sigma_verify_batch(self.h, B, nbases, _in(bases), _in(publics), _in(proofs), _in(fs_init), st))
         return list(st)
+
+    def set_io_chunk(self, proofs):
+        """proofs per pipelined chunk of the host-buffer entry points (0 = default 65536)"""
+        self.eng._chk(self.lib.mp_set_io_chunk(self.h, proofs))
 
     def set_merged_verify(self, on=True):
         """verification strategy: merged screening pass first (default) or always equation by equation"""

@@ -141,6 +141,11 @@ int mp_set_latency_batch(mp_table* t, size_t B) {
   t->set_latency_batch(B);
   return MP_OK;
 }
+int mp_set_io_chunk(mp_table* t, size_t proofs) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_io_chunk: null table");
+  t->io_chunk = proofs;
+  return MP_OK;
+}
 int mp_set_merged_verify(mp_table* t, int on) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_merged_verify: null table");
   t->set_merged_verify(on != 0);
@@ -215,7 +220,7 @@ int mp_sync(mp_ctx* ctx) {
 // context's stream, chunk k+1 is uploaded on a second stream and the results of chunk k-1 are downloaded on a third
 // (PCIe is full duplex).  Staging buffers are persistent (two chunks in flight).  With page-locked caller buffers
 // (mp_host_alloc) every copy is an asynchronous DMA; with pageable buffers the runtime stages them and the overlap is partial.
-static const size_t IO_CHUNK = 65536;   // proofs per chunk: the kernels need ~64 k lanes to run at full rate
+static const size_t IO_CHUNK = 65536;   // default proofs per chunk: the kernels need ~64 k lanes to run at full rate
 static void io_events(mp_io_stage& st) {
   if (!st.up) {
     st.up = rt::event_create();
@@ -234,7 +239,7 @@ static int prove_batch_host(mp_table* t, size_t B, const uint8_t* keys, const ui
   rt::set_device(t->ctx->device);
   rt::Stream s = t->ctx->stream, up = t->ctx->h2d, down = t->ctx->d2h;
   const size_t N = t->N, psz = proof_size_bytes(t->m, t->n, t->point_bytes), dsz = N * 2 * t->point_bytes;
-  const size_t chunk = std::min(B, IO_CHUNK), nchunks = (B + chunk - 1) / chunk;
+  const size_t chunk = std::min(B, t->io_chunk ? t->io_chunk : IO_CHUNK), nchunks = (B + chunk - 1) / chunk;
   for (auto& st : t->io) {
     io_events(st);
     st.used = false;
@@ -283,7 +288,7 @@ static int verify_batch_host(mp_table* t, size_t B, const uint8_t* keys, const u
   rt::set_device(t->ctx->device);
   rt::Stream s = t->ctx->stream, up = t->ctx->h2d, down = t->ctx->d2h;
   const size_t N = t->N, psz = proof_size_bytes(t->m, t->n, t->point_bytes), dsz = N * 2 * t->point_bytes;
-  const size_t chunk = std::min(B, IO_CHUNK), nchunks = (B + chunk - 1) / chunk;
+  const size_t chunk = std::min(B, t->io_chunk ? t->io_chunk : IO_CHUNK), nchunks = (B + chunk - 1) / chunk;
   for (auto& st : t->io) {
     io_events(st);
     st.used = false;

@@ -135,6 +135,7 @@ struct mp_io_stage {
 struct mp_table {
   mp_ctx* ctx = nullptr;
   mp_io_stage io[2];
+  size_t io_chunk = 0;         // proofs per pipelined chunk of the host-buffer entry points (0 = default, mp_set_io_chunk)
   uint32_t m = 0, n = 0, N = 0;
   uint32_t point_bytes = 64;   // wire size of a point on this table's curve (Geo<C>::PB)
   bool keyless = false;        // created from the parameters alone (mp_table_create_params): keyed entry points only

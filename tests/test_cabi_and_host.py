@@ -89,6 +89,32 @@ def test_kernel_bodies_under_emulation_match_golden(emu, name):
     t.close()
 
 
+def test_emulated_chunked_host_pipeline(emu, coracle):
+    """the host-buffer entry points cut a batch into chunks (upload / kernels / download pipelined): 5 proofs in chunks of 2
+    give the same bytes as one chunk, with and without per-proof keys"""
+    cv, m, n = "stark", 2, 3
+    eng = emu(cv)
+    ins = [coracle.gen_inputs(cv, m, n, 800 + b) for b in range(5)]
+    g0 = ins[0]
+    t = eng.table(m, n, g0["params"], g0["pk"])
+    args = (b"".join(g["deck"] for g in ins), b"".join(g["rho"] for g in ins), [v for g in ins for v in g["perm"]],
+            b"".join(g["prover_seed"] for g in ins))
+    keys = b"".join(g["pk"] for g in ins)
+    ref = t.shuffle_and_remask_batch(*args)
+    refk = t.shuffle_and_remask_batch_keys(keys, *args)
+    t.set_io_chunk(2)
+    assert t.shuffle_and_remask_batch(*args) == ref
+    assert t.shuffle_and_remask_batch_keys(keys, *args) == refk
+    assert t.verify_shuffle_batch(args[0], ref[0], ref[1]) == [0] * 5
+    assert t.verify_shuffle_batch_keys(keys, args[0], refk[0], refk[1]) == [0] * 5
+    ps = t.proof_bytes
+    swapped = ref[1][ps:2 * ps] + ref[1][:ps] + ref[1][2 * ps:]     # proofs 0 and 1 exchanged: both fail, the other chunks pass
+    st = t.verify_shuffle_batch(args[0], ref[0], swapped)
+    assert st[0] > 0 and st[1] > 0 and st[2:] == [0] * 3
+    t.set_io_chunk(0)
+    t.close()
+
+
 def test_emulated_keyed_batch(emu, coracle, native):
     """keyed batches (one aggregate key per proof, mp_*_batch_keys): byte-identical to the oracle run under each proof's key"""
     for cv, m, n in (("stark", 2, 3), ("bls12_377", 2, 3)):

@@ -240,6 +240,32 @@ def test_keyed_batches_match_oracle(mp, engines, coracle, curve, m, n, B, plan):
     t.set_latency_batch(8192)
 
 
+def test_chunked_host_pipeline(mp, engines, coracle):
+    """mp_*_batch with a batch cut into several pipelined chunks (upload, kernels and download on three streams): 11 proofs in
+    chunks of 4 equal the single-chunk result and the oracle"""
+    cv, m, n, B = "stark", 2, 26, 11
+    cards = engines(cv)
+    ins = [coracle.gen_inputs(cv, m, n, 900 + b) for b in range(B)]
+    g0 = ins[0]
+    t = cards.table(mp.Parameters(m, n, g0["params"]), g0["pk"])
+    args = (b"".join(g["deck"] for g in ins), b"".join(g["rho"] for g in ins), [v for g in ins for v in g["perm"]],
+            b"".join(g["prover_seed"] for g in ins))
+    ref = t.shuffle_and_remask_batch(*args)
+    t.set_io_chunk(4)
+    got = t.shuffle_and_remask_batch(*args)
+    assert got == ref and got[2] == [0] * B
+    cb, ps = len(g0["deck"]), t.proof_bytes
+    for b in (0, 3, 4, 10):
+        g = ins[b]
+        ed, ep = coracle.shuffle_and_remask(cv, m, n, g0["params"], g0["pk"], g["deck"], g["rho"], g["perm"], g["prover_seed"])
+        assert got[0][b * cb:(b + 1) * cb] == ed and got[1][b * ps:(b + 1) * ps] == ep
+    assert t.verify_shuffle_batch(args[0], got[0], got[1]) == [0] * B
+    swapped = got[1][ps:2 * ps] + got[1][:ps] + got[1][2 * ps:]
+    st = t.verify_shuffle_batch(args[0], got[0], swapped)
+    assert st[0] > 0 and st[1] > 0 and st[2:] == [0] * (B - 2)
+    t.set_io_chunk(0)
+
+
 def test_verifier_fuzz_against_oracle(mp, engines, coracle):
     """~200 random single-element corruptions of an honest proof (a scalar replaced by a random scalar, a point by
     another valid point, or two elements swapped), verified in ONE batch: every status word -- accept, or the code of the first failing
