@@ -85,6 +85,13 @@ class PhaseBuilder {
   void addend_j(uint32_t jslot, bool negate = false) { a_.push_back((negate ? NEG_FLAG : 0u) | jslot); }
   uint32_t new_partial() { return next_partial_++; }
   void end(bool late = false) {
+    // One lane adds up the partial sums of an MSM one after the other (k_combine): with the fine splits a long MSM
+    // (n = 150 commitments, 4N-term verifier equations) would turn into hundreds of partials and a serial chain longer than
+    // the one the split was meant to shorten -- cap the partials per MSM and kind.
+    const size_t MAXP = 128;
+    size_t fchunk_ = this->fchunk_, vchunk_ = this->vchunk_;
+    if ((f_.size() + fchunk_ - 1) / fchunk_ > MAXP) fchunk_ = (f_.size() + MAXP - 1) / MAXP;
+    if ((v_.size() + vchunk_ - 1) / vchunk_ > MAXP) vchunk_ = (v_.size() + MAXP - 1) / MAXP;
     size_t nf = (f_.size() + fchunk_ - 1) / fchunk_, nv = (v_.size() + vchunk_ - 1) / vchunk_;
     size_t pieces = nf + nv + a_.size();
     if (pieces == 0) throw std::logic_error("empty msm");
