@@ -7,18 +7,33 @@ re-encryption + Bayer-Groth prover) and `verify_shuffle`, with every input alrea
 Synthetic data: random ciphertext decks [REF src/discrete_log_cards/tests.rs:187] obtained by re-encrypting one
 random base deck on the GPU; masking factors uniform below 2^251; uniform permutations; random prover seeds.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
 
-Proofs are independent, so ranks shard the batch with no data-path collective (weak scaling: B proofs per GPU
-per step); the shared parameters are produced on rank 0 and broadcast once over RCCL.  Rank 0 prints one JSON
-line.  `roofline` is measured live with HIP events on the engine's own stream around every kernel launch of the
-timed region; `cpu_baseline` times the oracle's single-threaded C++ restatement (arkworks-style algorithms) on a
-bounded sample of the same workload on this box's host cores.
+N > 1: one rank per GPU.  Started from a plain shell, bench.py launches the N ranks ITSELF (it re-executes under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`); started by the driver under
+torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.  Proofs are independent, so ranks
+shard the batch with no data-path collective (weak scaling: B proofs per GPU per step); the shared parameters are
+produced on rank 0 and broadcast once over RCCL; per-rank proof counts, verdict sums and times are all-gathered and
+rank 0 prints ONE JSON line.
+
+Workloads (`--workload`, BASELINE.json's configs):
+  pairs    (default; configs 2 and 4) B independent prove + verify pairs per step
+  chain32  (config 3) T card tables x 32 players: 32 DEPENDENT shuffles per table (deck_{j+1} = output_j), each table under its
+           own aggregate key (keyed batches); every link proved (T proofs per launch) and verified [REF examples/round.rs:268-350]
+  mixed    (config 5) a stream of independent jobs, 50 % prove jobs / 50 % verify jobs (the proofs of the previous step)
+
+`roofline` is measured live with HIP events on the engine's own stream around every kernel launch of the timed region;
+`cpu_baseline` times the oracle's single-threaded C++ restatement (arkworks-style algorithms) on a bounded sample of
+the same workload on this box's host cores.
 """
 import argparse
+import glob
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,13 +44,6 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "py")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 INT_MAD_PEAK_G = 18000.0       # v_mad_u64_u32 issue rate measured with tools/microbench/intrate.hip (Gmad/s)
-# exact 32x32+64 multiply-add counts (v_mad_u64_u32 + v_mad_i64_i32, the same quarter-rate pipe) of the compiled STARK
-# group law (llvm -S of xyzz_madd_ip / xyzz_dbl_ip / fe_mul / fe_sqr, 9x29-bit limbs, subtractive Montgomery reduction):
-# product 81 + 18 = 99, square 45 + 18 = 63, a b - c d with one reduction 162 + 18 = 180; XYZZ mixed addition 8M+2S = 900,
-# XYZZ doubling 6M+4S = 828 (the MSM loops; each contains one fused product pair);
-# batched-affine table entry 5M+1S + 4/15 of 1/64 of an inversion (256S+45M) = 644, Jacobian+Jacobian addition 11M+5S =
-# 1404 (combines), normalisation of one point 6M+1S + 1/64 inversion = 979
-MADS = {"madd": 900, "dbl": 828, "aff": 644, "jac": 1404, "norm": 979}
 
 
 # ---- distributed helpers (backend-agnostic: RCCL on GPUs, gloo in the CPU tests) -----------------------------
@@ -74,11 +82,99 @@ def reduce_sum(x, device):
     return float(t.item())
 
 
+def gather_rows(row, device):
+    """all-gather one row of float64 per rank (proof counts, verdict sums, seconds) -> list of rows, rank order"""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(v) for v in row], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, t)
+        return [[float(v) for v in o.cpu().tolist()] for o in out]
+    return [[float(v) for v in t.cpu().tolist()]]
+
+
+def gather_objects(obj):
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, obj)
+        return out
+    return [obj]
+
+
 def shard_range(total, rank, world):
     """static contiguous block partition of proof indices"""
     base, rem = divmod(total, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n_ranks, argv):
+    """plain-shell start with --gpus N > 1: run N ranks of this script under torch.distributed.run (one per GPU)"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+# ---- reproducible measurement metadata ------------------------------------------------------------------------------
+def engine_source_hash():
+    """sha256 over the engine's sources: ties a PMC summary under profiles/ to the build it was taken from"""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "mental-poker_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hpp", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "mpshuffle.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def find_pmc_summary(src_hash, curve, m, n, batch, workload):
+    """the PMC summary (tools/pmc_summary.py) taken from THIS build at THIS configuration, or None"""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if (d.get("engine_src") == src_hash and d.get("batch") == batch and d.get("curve") == curve and
+                d.get("m") == m and d.get("n") == n and d.get("workload", "pairs") == workload):
+            return os.path.relpath(path, ROOT), d
+    return None, None
+
+
+def load_mad_counts(curve):
+    """multiply-add instructions (v_mad_u64_u32 + v_mad_i64_i32) per field product / square / fused product pair of this
+    curve's base field, counted in the gfx950 assembly of the build (tools/gen_mad_counts.py -> mad_counts.json)"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "mental-poker_amd", "mad_counts.json")))
+    except (OSError, ValueError):
+        return None
+    c = d.get("curves", {}).get(curve)
+    if not c:
+        return None
+    M, S, MS, inv = c["mul"], c["sqr"], c["mulsub"], c["inv_sqr"] * c["sqr"] + c["inv_mul"] * c["mul"]
+    a1 = 1 if c["a_is_one"] else 0
+    return {
+        "field": {"mul": M, "sqr": S, "mulsub": MS, "inv": inv},
+        "madd": 6 * M + 2 * S + MS,                      # XYZZ += affine   (curve.hpp xyzz_madd_ip, main path)
+        "dbl": 4 * M + (3 + a1) * S + MS,                # XYZZ doubling    (xyzz_dbl_ip)
+        "aff": 5 * M + (1 + 8.0 / 15.0) * S + (4.0 / 15.0) * inv / 64.0,   # batched-affine table entry (k_table): 2 prefix-product steps, lam,
+                                                         # lam^2, y3 (+ x^2 for the 8 doublings of 15); 4 inversions per 64 bases
+        "jac": 11 * M + 5 * S,                           # Jacobian + Jacobian (k_combine)
+        "norm": 6 * M + S + inv / 64.0,                  # Jacobian -> affine with a 64-point batched inversion
+    }
 
 
 # ---- the benchmark -----------------------------------------------------------------------------------------
@@ -87,20 +183,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=262144, help="proofs per GPU per step (~0.45 MB of HBM each: 142 GB in use at the default)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="proofs per GPU per step (default 262144 = ~0.45 MB of HBM each: 142 GB in use; chain32: card tables per GPU)")
+    ap.add_argument("--workload", default="pairs", choices=["pairs", "chain32", "mixed"])
     ap.add_argument("--m", type=int, default=2)
     ap.add_argument("--n", type=int, default=26)
-    ap.add_argument("--curve", default="stark")
+    ap.add_argument("--curve", default=None, help="stark (default; mixed: secp256k1), bn254, secp256k1, bls12_377")
     ap.add_argument("--streams", type=int, default=1, help="independent engine contexts (HIP streams) per GPU; the batch is split evenly")
     ap.add_argument("--fb-bits", type=int, default=20, help="fixed-base window width (8, 16 or 20 bits; 20 = 27 GB of tables at n=26)")
     ap.add_argument("--cpu-iters", type=int, default=160, help="prove+verify pairs timed for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the two extra one-step measurements (keyed batch, per-equation verification) reported in config")
     ap.add_argument("--latency-batch", type=int, default=None,
                     help="batches up to this size use the latency plan (engine default 8192): mp_set_latency_batch")
     ap.add_argument("--keyed", type=int, default=0, metavar="K",
                     help="keyed batches: K distinct aggregate keys (card tables) spread over the batch, one key per proof "
                          "(mp_*_batch_keys_dev); 0 = every proof under the table's own key")
+    ap.add_argument("--per-equation", action="store_true", help="verify equation by equation (mp_set_merged_verify off)")
+    ap.add_argument("--players", type=int, default=32, help="chain32: shuffles per table")
+    ap.add_argument("--digest", action="store_true",
+                    help="test hook: sha256 of every rank's outputs of the last step in config.digests (inputs are seeded per "
+                         "block of --seed-block proofs, so a sharded run and an unsharded run of the same blocks must agree)")
+    ap.add_argument("--seed-block", type=int, default=None)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -111,6 +220,8 @@ def main():
     # MP_BENCH_BACKEND=gloo runs the (tiny, once-per-session) collectives on CPU tensors instead of RCCL
     local = int(os.environ.get("MP_BENCH_FORCE_DEVICE", local))
     backend = os.environ.get("MP_BENCH_BACKEND", "nccl")
+    if local >= torch.cuda.device_count():
+        raise SystemExit("rank %d: no GPU %d on this node (%d visible)" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     gpu = torch.device("cuda", local)
     dev = gpu if backend == "nccl" else torch.device("cpu")      # device of the collective payloads
@@ -124,22 +235,27 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
     mp = importlib.import_module("mental-poker_amd")
-    m, n, curve, B = args.m, args.n, args.curve, args.batch
+    workload = args.workload
+    curve = args.curve or ("secp256k1" if workload == "mixed" else "stark")
+    m, n = args.m, args.n
     N = m * n
+    B = args.batch if args.batch is not None else (65536 if workload == "chain32" else 262144)
     eng = mp.Engine(curve, device=local)
+    PB = eng.point_bytes
+    CB = 2 * PB
 
     # ---- shared parameters: rank 0 runs `setup`, everyone receives them over RCCL (once)
-    psz = 64 * (n + 3)
+    psz = PB * (n + 3)
     blob = None
     if rank == 0:
         params = eng.setup(m, n, bytes([1] * 32))
-        pk = eng.setup(m, 2, bytes([2] * 32))[:64]                  # aggregate key: a random group element
+        pk = eng.setup(m, 2, bytes([2] * 32))[:PB]                  # aggregate key: a random group element
         base_deck = eng.setup(m, 2 * N - 3, bytes([3] * 32))        # 2N random points = N random ciphertexts
         blob = params + pk + base_deck
-    blob = bcast_bytes(blob, psz + 64 + 128 * N, 0, dev)
-    params, pk, base_deck = blob[:psz], blob[psz:psz + 64], blob[psz + 64:]
+    blob = bcast_bytes(blob, psz + PB + CB * N, 0, dev)
+    params, pk, base_deck = blob[:psz], blob[psz:psz + PB], blob[psz + PB:]
     # ---- S independent contexts (one HIP stream each); each owns 1/S of the batch
-    S = max(1, args.streams)
+    S = max(1, args.streams) if workload == "pairs" else 1
     Bs = B // S
     assert Bs * S == B, "--batch must be a multiple of --streams"
     engines = [eng] + [mp.Engine(curve, device=local) for _ in range(S - 1)]
@@ -147,74 +263,43 @@ def main():
     for t in tables:
         if args.latency_batch is not None:
             t.set_latency_batch(args.latency_batch)
-        t.reserve(Bs)
+        if args.per_equation:
+            t.set_merged_verify(False)
     table = tables[0]
     proof_bytes = table.proof_bytes
 
-    # ---- synthetic inputs, resident in HBM
+    # ---- synthetic inputs, resident in HBM; seeded per block of `seed_block` proofs of the GLOBAL batch (rank r owns the
+    # proofs [r B, (r+1) B) of the world x B proofs of one step), so the data do not depend on how the batch is sharded
+    seed_block = args.seed_block or B
+    assert B % seed_block == 0
     gen = torch.Generator(device=gpu)
-    gen.manual_seed(1234 + rank)
 
-    def rand_bytes(*shape):
-        return torch.randint(0, 256, shape, dtype=torch.uint8, device=gpu, generator=gen)
+    def per_block(fn, salt):
+        outs = []
+        for k in range(B // seed_block):
+            gen.manual_seed(1234 + 7919 * salt + (rank * B) // seed_block + k)
+            outs.append(fn(seed_block))
+        return torch.cat(outs).contiguous() if len(outs) > 1 else outs[0].contiguous()
 
-    def rand_factors():
-        f = rand_bytes(B, N, 32)
-        f[:, :, 31] &= 0x07            # < 2^251 < group order
-        return f.contiguous()
+    def rand_bytes(cnt, *shape):
+        return torch.randint(0, 256, (cnt,) + shape, dtype=torch.uint8, device=gpu, generator=gen)
 
-    def rand_perms():
-        return torch.argsort(torch.rand(B, N, device=gpu, generator=gen), dim=1).to(torch.int32).contiguous()
+    def rand_factors(salt):
+        def f(cnt):
+            x = rand_bytes(cnt, N, 32)
+            x[:, :, 31] &= 0x07            # < 2^251 < group order
+            return x
+        return per_block(f, salt)
 
-    base = torch.frombuffer(bytearray(base_deck), dtype=torch.uint8).to(gpu)
-    decks0 = base.repeat(B, 1).contiguous()
-    decks = torch.empty(B, N * 128, dtype=torch.uint8, device=gpu)
-    out_decks = torch.empty(B, N * 128, dtype=torch.uint8, device=gpu)
-    out_proofs = torch.empty(B, proof_bytes, dtype=torch.uint8, device=gpu)
-    st_p = torch.empty(B, dtype=torch.int32, device=gpu)
-    st_v = torch.empty(B, dtype=torch.int32, device=gpu)
-    torch.cuda.synchronize()
+    def rand_perms(salt):
+        return per_block(lambda cnt: torch.argsort(torch.rand(cnt, N, device=gpu, generator=gen), dim=1).to(torch.int32), salt)
 
-    def sl(t, i):
-        return t[i * Bs:(i + 1) * Bs].data_ptr()
+    def rand_seeds(salt):
+        return per_block(lambda cnt: rand_bytes(cnt, 32), salt)
 
     def sync_all():
         for e in engines:
             e.sync()
-
-    # keyed batches: K aggregate keys (random group elements from the engine's own setup), key b % K for proof b
-    keys = None
-    if args.keyed > 0:
-        kpts = eng.setup(m, max(args.keyed, 2), bytes([4] * 32))
-        kt = torch.frombuffer(bytearray(kpts[:64 * args.keyed]), dtype=torch.uint8).to(gpu).view(args.keyed, 64)
-        keys = kt[torch.arange(B, device=gpu) % args.keyed].contiguous()
-    # prime: B different random decks = re-encryptions of the base deck (untimed input generation)
-    f0, p0, s0 = rand_factors(), rand_perms(), rand_bytes(B, 32)
-    torch.cuda.synchronize()
-    for e in engines:
-        e.profile_enable(True)
-    for i, t in enumerate(tables):
-        t.shuffle_and_remask_batch_dev(Bs, sl(decks0, i), sl(f0, i), sl(p0, i), sl(s0, i), sl(decks, i), sl(out_proofs, i), sl(st_p, i))
-    sync_all()
-    priming_launches = {}       # per-kernel launches of the untimed priming prove (tools/pmc_summary.py skips them)
-    for e in engines:
-        for k, (cnt, _) in e.profile_report().items():
-            priming_launches[k] = priming_launches.get(k, 0) + cnt
-        e.profile_enable(False)
-    assert int(st_p.abs().sum().item()) == 0, "priming pass failed"
-    factors, perms, seeds = rand_factors(), rand_perms(), rand_bytes(B, 32)
-    torch.cuda.synchronize()
-
-    def step():
-        for i, t in enumerate(tables):
-            if keys is not None:
-                t.shuffle_and_remask_batch_keys_dev(Bs, sl(keys, i), sl(decks, i), sl(factors, i), sl(perms, i), sl(seeds, i),
-                                                    sl(out_decks, i), sl(out_proofs, i), sl(st_p, i))
-                t.verify_shuffle_batch_keys_dev(Bs, sl(keys, i), sl(decks, i), sl(out_decks, i), sl(out_proofs, i), sl(st_v, i))
-                continue
-            t.shuffle_and_remask_batch_dev(Bs, sl(decks, i), sl(factors, i), sl(perms, i), sl(seeds, i), sl(out_decks, i),
-                                           sl(out_proofs, i), sl(st_p, i))
-            t.verify_shuffle_batch_dev(Bs, sl(decks, i), sl(out_decks, i), sl(out_proofs, i), sl(st_v, i))
 
     def barrier():
         if world > 1:
@@ -222,6 +307,179 @@ def main():
         torch.cuda.synchronize()
         sync_all()
 
+    # keyed batches: K aggregate keys (random group elements from the engine's own setup), key b % K for proof b
+    def make_keys(K, count):
+        kpts = eng.setup(m, max(K, 2), bytes([4] * 32))
+        kt = torch.frombuffer(bytearray(kpts[:PB * K]), dtype=torch.uint8).to(gpu).view(K, PB)
+        return kt[torch.arange(count, device=gpu) % K].contiguous()
+
+    base = torch.frombuffer(bytearray(base_deck), dtype=torch.uint8).to(gpu)
+
+    def prime_decks(count, keys=None):
+        """`count` different random decks = re-encryptions of the base deck (untimed input generation)"""
+        d0 = base.repeat(count, 1).contiguous()
+        out = torch.empty(count, N * CB, dtype=torch.uint8, device=gpu)
+        pr = torch.empty(count, proof_bytes, dtype=torch.uint8, device=gpu)
+        st = torch.empty(count, dtype=torch.int32, device=gpu)
+        f0, p0, s0 = rand_factors(101), rand_perms(102), rand_seeds(103)
+        torch.cuda.synchronize()
+        table.shuffle_and_remask_batch_dev(count, d0.data_ptr(), f0[:count].data_ptr(), p0[:count].data_ptr(),
+                                           s0[:count].data_ptr(), out.data_ptr(), pr.data_ptr(), st.data_ptr())
+        eng.sync()
+        assert int(st.abs().sum().item()) == 0, "priming pass failed"
+        return out
+
+    digests = None
+    extras = {}
+    # =============================================================================================== workload: pairs
+    if workload == "pairs":
+        for t in tables:
+            t.reserve(Bs)
+        keys = make_keys(args.keyed, B) if args.keyed > 0 else None
+        for e in engines:
+            e.profile_enable(True)
+        decks = prime_decks(B)
+        priming_launches = {}       # per-kernel launches of the untimed priming prove (tools/pmc_summary.py skips them)
+        for e in engines:
+            for k, (cnt, _) in e.profile_report().items():
+                priming_launches[k] = priming_launches.get(k, 0) + cnt
+            e.profile_enable(False)
+        out_decks = torch.empty(B, N * CB, dtype=torch.uint8, device=gpu)
+        out_proofs = torch.empty(B, proof_bytes, dtype=torch.uint8, device=gpu)
+        st_p = torch.empty(B, dtype=torch.int32, device=gpu)
+        st_v = torch.empty(B, dtype=torch.int32, device=gpu)
+        factors, perms, seeds = rand_factors(1), rand_perms(2), rand_seeds(3)
+        torch.cuda.synchronize()
+
+        def sl(t, i):
+            return t[i * Bs:(i + 1) * Bs].data_ptr()
+
+        def step(kk=keys):
+            for i, t in enumerate(tables):
+                if kk is not None:
+                    t.shuffle_and_remask_batch_keys_dev(Bs, sl(kk, i), sl(decks, i), sl(factors, i), sl(perms, i), sl(seeds, i),
+                                                        sl(out_decks, i), sl(out_proofs, i), sl(st_p, i))
+                    t.verify_shuffle_batch_keys_dev(Bs, sl(kk, i), sl(decks, i), sl(out_decks, i), sl(out_proofs, i), sl(st_v, i))
+                    continue
+                t.shuffle_and_remask_batch_dev(Bs, sl(decks, i), sl(factors, i), sl(perms, i), sl(seeds, i), sl(out_decks, i),
+                                               sl(out_proofs, i), sl(st_p, i))
+                t.verify_shuffle_batch_dev(Bs, sl(decks, i), sl(out_decks, i), sl(out_proofs, i), sl(st_v, i))
+
+        proofs_per_step = B
+        units = "prove+verify pairs"
+
+        def check():
+            return int((st_p != 0).sum().item()) + int((st_v != 0).sum().item())
+
+        def parity_inputs():
+            b = B // 2
+            pk_b = pk if keys is None else bytes(keys[b].cpu().numpy().tobytes())
+            return (pk_b, decks[b], factors[b], perms[b], seeds[b], out_decks[b], out_proofs[b])
+
+        def digest():
+            h = []
+            for k in range(B // seed_block):
+                s_ = slice(k * seed_block, (k + 1) * seed_block)
+                hh = hashlib.sha256()
+                hh.update(out_decks[s_].cpu().numpy().tobytes())
+                hh.update(out_proofs[s_].cpu().numpy().tobytes())
+                h.append(hh.hexdigest())
+            return h
+    # =============================================================================================== workload: chain32
+    elif workload == "chain32":
+        # T tables per GPU, `players` dependent shuffles each; table t has its own aggregate key (keyed batches); link j of
+        # every table is proved in ONE launch of T proofs (the data-parallel axis runs across tables), all decks stay in HBM.
+        T, L = B, args.players
+        keyless = eng.table(m, n, params, None, fb_bits=args.fb_bits)
+        if args.latency_batch is not None:
+            keyless.set_latency_batch(args.latency_batch)
+        keys = make_keys(T, T)                 # one key per table
+        deck0 = prime_decks(T)
+        table.close()
+        chain = torch.empty(L + 1, T, N * CB, dtype=torch.uint8, device=gpu)
+        chain[0] = deck0
+        del deck0
+        proofs = torch.empty(L, T, proof_bytes, dtype=torch.uint8, device=gpu)
+        st_p = torch.empty(L, T, dtype=torch.int32, device=gpu)
+        st_v = torch.empty(L, T, dtype=torch.int32, device=gpu)
+        fac = [rand_factors(10 + j) for j in range(2)]      # two sets of witnesses, alternated along the chain
+        prm = [rand_perms(20 + j) for j in range(2)]
+        sds = rand_seeds(30)
+        # verification is independent per link: batches of G links (G T proofs per launch, as many as fit the workspace)
+        G = max(1, min(L, 262144 // T))
+        while L % G:
+            G -= 1
+        kk = keys.repeat(G, 1).contiguous()
+        keyless.reserve(max(T, G * T))
+        priming_launches = {}
+        torch.cuda.synchronize()
+
+        def step():
+            for j in range(L):
+                keyless.shuffle_and_remask_batch_keys_dev(T, keys.data_ptr(), chain[j].data_ptr(), fac[j & 1].data_ptr(),
+                                                          prm[j & 1].data_ptr(), sds.data_ptr(), chain[j + 1].data_ptr(),
+                                                          proofs[j].data_ptr(), st_p[j].data_ptr())
+            for j in range(0, L, G):
+                keyless.verify_shuffle_batch_keys_dev(G * T, kk.data_ptr(), chain[j].data_ptr(), chain[j + 1].data_ptr(),
+                                                      proofs[j].data_ptr(), st_v[j].data_ptr())
+
+        proofs_per_step = T * L
+        units = "prove+verify pairs (%d tables x %d dependent shuffles, %d proofs per prove launch, %d per verify launch)" % (T, L, T, G * T)
+
+        def check():
+            return int((st_p != 0).sum().item()) + int((st_v != 0).sum().item())
+
+        def parity_inputs():
+            t_, j = T // 2, L - 1
+            return (bytes(keys[t_].cpu().numpy().tobytes()), chain[j][t_], fac[j & 1][t_], prm[j & 1][t_], sds[t_],
+                    chain[j + 1][t_], proofs[j][t_])
+
+        def digest():
+            hh = hashlib.sha256()
+            hh.update(chain[L].cpu().numpy().tobytes())
+            return [hh.hexdigest()]
+        table = keyless
+        tables = [keyless]
+    # =============================================================================================== workload: mixed
+    else:
+        # a stream of B independent jobs per step: B/2 prove jobs (fresh decks) and B/2 verify jobs (the proofs made by the
+        # previous step's prove jobs) -- BASELINE config 5
+        H = B // 2
+        table.reserve(H)
+        decks = prime_decks(H)
+        out_decks = [torch.empty(H, N * CB, dtype=torch.uint8, device=gpu) for _ in range(2)]
+        out_proofs = [torch.empty(H, proof_bytes, dtype=torch.uint8, device=gpu) for _ in range(2)]
+        st_p = torch.empty(H, dtype=torch.int32, device=gpu)
+        st_v = torch.zeros(H, dtype=torch.int32, device=gpu)
+        factors, perms, seeds = rand_factors(1)[:H], rand_perms(2)[:H], rand_seeds(3)[:H]
+        priming_launches = {}
+        state = {"cur": 0, "have_prev": False}
+        torch.cuda.synchronize()
+
+        def step():
+            c = state["cur"]
+            table.shuffle_and_remask_batch_dev(H, decks.data_ptr(), factors.data_ptr(), perms.data_ptr(), seeds.data_ptr(),
+                                               out_decks[c].data_ptr(), out_proofs[c].data_ptr(), st_p.data_ptr())
+            p = c if not state["have_prev"] else 1 - c       # very first step: verify what was just proved
+            table.verify_shuffle_batch_dev(H, decks.data_ptr(), out_decks[p].data_ptr(), out_proofs[p].data_ptr(), st_v.data_ptr())
+            state["cur"], state["have_prev"] = 1 - c, True
+
+        proofs_per_step = H
+        units = "pair equivalents: %d prove jobs + %d verify jobs per step" % (H, H)
+
+        def check():
+            return int((st_p != 0).sum().item()) + int((st_v != 0).sum().item())
+
+        def parity_inputs():
+            b, c = H // 2, 1 - state["cur"]
+            return (pk, decks[b], factors[b], perms[b], seeds[b], out_decks[c][b], out_proofs[c][b])
+
+        def digest():
+            hh = hashlib.sha256()
+            hh.update(out_proofs[1 - state["cur"]].cpu().numpy().tobytes())
+            return [hh.hexdigest()]
+
+    # ---- timed region: W warm-up steps, barrier + synchronize, K steps, barrier + synchronize
     for _ in range(args.warmup):
         step()
     barrier()
@@ -231,34 +489,54 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = time.perf_counter() - t0
+    my_elapsed = time.perf_counter() - t0
     prof = {}
     for e in engines:
         for k, (cnt, ms) in e.profile_report().items():
             c0, m0 = prof.get(k, (0, 0.0))
             prof[k] = (c0 + cnt, m0 + ms)
         e.profile_enable(False)
-    elapsed = reduce_max(elapsed, dev)
+    elapsed = reduce_max(my_elapsed, dev)
 
-    # ---- correctness of what was timed (outside the timed region)
-    bad = int((st_p != 0).sum().item()) + int((st_v != 0).sum().item())
-    assert bad == 0, "%d proofs failed on rank %d" % (bad, rank)
+    # ---- correctness of what was timed (outside the timed region); verdicts gathered from every rank
+    bad = check()
+    rows = gather_rows([proofs_per_step * args.steps, bad, my_elapsed], dev)
+    total_proofs = sum(r[0] for r in rows)
+    total_bad = int(sum(r[1] for r in rows))
+    assert total_bad == 0, "%d proofs failed (per rank: %s)" % (total_bad, [int(r[1]) for r in rows])
+    if args.digest:
+        digests = gather_objects(digest())
     parity = None
     if rank == 0:
         import coracle as co
         co.build()
-        b = B // 2
-        pk_b = pk if keys is None else bytes(keys[b].cpu().numpy().tobytes())
-        exp_deck, exp_proof = co.shuffle_and_remask(curve, m, n, params, pk_b, bytes(decks[b].cpu().numpy().tobytes()),
-                                                    bytes(factors[b].cpu().numpy().tobytes()),
-                                                    [int(v) for v in perms[b].cpu().tolist()],
-                                                    bytes(seeds[b].cpu().numpy().tobytes()))
-        parity = (bytes(out_decks[b].cpu().numpy().tobytes()) == exp_deck and
-                  bytes(out_proofs[b].cpu().numpy().tobytes()) == exp_proof)
+        pk_b, d_in, f_in, p_in, s_in, d_out, pr_out = parity_inputs()
+        tb = lambda t: bytes(t.cpu().numpy().tobytes())
+        exp_deck, exp_proof = co.shuffle_and_remask(curve, m, n, params, pk_b, tb(d_in), tb(f_in), [int(v) for v in p_in.cpu().tolist()], tb(s_in))
+        parity = tb(d_out) == exp_deck and tb(pr_out) == exp_proof
         assert parity, "timed output differs from the oracle"
-
-    total_proofs = reduce_sum(B * args.steps, dev)
     value = total_proofs / elapsed
+
+    # ---- the conditions of the headline, measured beside it (pairs workload, N = 1): one step each, same batch
+    if workload == "pairs" and world == 1 and not args.no_extras and args.keyed == 0 and not args.per_equation and S == 1:
+        def timed_step(fn):
+            fn()
+            barrier()
+            t1 = time.perf_counter()
+            fn()
+            barrier()
+            return B / (time.perf_counter() - t1)
+        table.set_merged_verify(False)
+        extras["per_equation_value"] = timed_step(step)          # every equation its own MSM, as the reference evaluates them
+        table.set_merged_verify(True)
+        free_b, _ = torch.cuda.mem_get_info()
+        if free_b > 40e9:
+            k1000 = make_keys(1000, B)
+            extras["keyed_value"] = timed_step(lambda: step(k1000))   # one aggregate key per proof (1000 distinct), as the reference passes it per call
+            extras["keyed_distinct_keys"] = 1000
+        else:
+            extras["keyed_value"] = None
+        assert check() == 0
 
     if rank != 0:
         if world > 1:
@@ -267,75 +545,85 @@ def main():
 
     # ---- roofline of the dominant kernel (live HIP-event timings of the timed region)
     stats = table.plan_stats()
-    census = table.work_census()
     dom = max(prof.items(), key=lambda kv: kv[1][1])
     dom_name, (dom_count, dom_ms) = dom
     kernel_ms_total = sum(v[1] for v in prof.values())
 
     def alg_bytes_per_proof(kernel):
         """ALGORITHMIC bytes one proof needs from this kernel class in one step (prove + verify launches):
-        scalars 32 B, points 64 B, Jacobian results 96 B ("algorithmic bytes")."""
+        scalars 32 B, points PB, Jacobian results 1.5 PB ("algorithmic bytes")."""
         pv = [stats["prove"], stats["verify"]]
         if kernel == "k_var_msm":
-            return sum(s["var_terms"] * (32 + 64) + s["var_jobs"] * 96 for s in pv)
+            return sum(s["var_terms"] * (32 + PB) + s["var_jobs"] * 3 * PB // 2 for s in pv)
+        if kernel == "k_bucket_msm":
+            return sum(s.get("bucket_terms", 0) * (32 + PB) + s.get("bucket_jobs", 0) * 3 * PB // 2 for s in pv)
         if kernel == "k_fixed_msm":
-            return sum(s["fixed_terms"] * 32 + s["fixed_jobs"] * 96 for s in pv)
+            return sum(s["fixed_terms"] * 32 + s["fixed_jobs"] * 3 * PB // 2 for s in pv)
         if kernel == "k_table":
-            return sum(s["table_bases"] * (64 + 16 * 96) for s in pv)
+            return sum(s["table_bases"] * (PB + 16 * PB) for s in pv)
         if kernel == "k_normalize":
-            return sum(s["table_bases"] * 16 * (96 + 64) for s in pv)
-        return 45 * 1024
-    # per-launch figures: one launch covers Bs = B / streams proofs; summed over the launches of the timed region
-    dom_bytes = alg_bytes_per_proof(dom_name) * B * args.steps
+            return sum(s["table_bases"] * 16 * (3 * PB // 2 + PB) for s in pv)
+        return None
+    whole_path_bytes = (2 * N * PB + N * 32 + 4 * N + (n + 4) * PB) + (2 * N * PB + proof_bytes) + (4 * N * PB + proof_bytes + (n + 4) * PB)   # SURVEY 8d4
+    per_proof = alg_bytes_per_proof(dom_name) or whole_path_bytes
+    # per-launch figures: summed over the launches of the timed region
+    dom_bytes = per_proof * total_proofs / world
     achieved_gbs = dom_bytes / (dom_ms * 1e-3) / 1e9
-    # exact multiply-add count of one prove+verify from the static plan (stats) and the instruction counts above
-    vw, fw = stats["var_windows"], stats["fixed_windows"]
-    mads_per_proof = 0
-    for side in ("prove", "verify"):
-        st_ = stats[side]
-        fixed_madds = st_["fixed_terms"] * fw
-        if side == "prove":
-            fixed_madds -= N * (fw - 1)               # c_A commits pi(i)+1 <= N: one non-zero window per term
-            fixed_madds += 2 * N * (fw + 1)           # re-encryption: 2N fixed-base scalar-muls + one addition each
-            norm_points = 2 * N + 11 * m + 7          # shuffled deck + proof points
-        else:
-            norm_points = 0
-        mads_per_proof += (fixed_madds + st_["var_terms"] * vw) * MADS["madd"]
-        mads_per_proof += st_["var_jobs"] * (vw - 1) * 5 * MADS["dbl"]
-        mads_per_proof += st_["table_bases"] * 15 * MADS["aff"]
-        mads_per_proof += st_["combine_terms"] * MADS["jac"] + norm_points * MADS["norm"]
-    mads = mads_per_proof * B * args.steps
-    whole_path_bytes = 45 * 1024 if (m, n) == (2, 26) else None      # SURVEY 8d4
-    # HBM traffic of the dominant kernel from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
-    # --pmc WRITE_SIZE in separate runs, gfx950 x2 correction applied to FETCH_SIZE), scaled to this batch
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01i_pmc_summary.json")))["kernels"].get(dom_name)
-        if pmc and (m, n) == (2, 26):
-            traffic = pmc["hbm_bytes_per_proof_per_step_corrected"] * B * args.steps / dom_count
-    except (OSError, ValueError, KeyError):
-        traffic = None
+    # multiply-add count of one prove+verify: static plan (stats) x instruction counts of the compiled group law
+    mc = load_mad_counts(curve)
+    int_mul = None
+    if mc:
+        vw, fw = stats["var_windows"], stats["fixed_windows"]
+        mads_per_proof = 0
+        for side in ("prove", "verify"):
+            st_ = stats[side]
+            fixed_madds = st_["fixed_terms"] * fw
+            if side == "prove":
+                fixed_madds -= N * (fw - 1)               # c_A commits pi(i)+1 <= N: one non-zero window per term
+                fixed_madds += 2 * N * (fw + 1)           # re-encryption: 2N fixed-base scalar-muls + one addition each
+                norm_points = 2 * N + 11 * m + 7          # shuffled deck + proof points
+            else:
+                norm_points = 0
+            mads_per_proof += (fixed_madds + st_["var_terms"] * vw) * mc["madd"]
+            mads_per_proof += st_["var_jobs"] * (vw - 1) * 5 * mc["dbl"]
+            mads_per_proof += st_["table_bases"] * 15 * mc["aff"]
+            mads_per_proof += st_["combine_terms"] * mc["jac"] + norm_points * mc["norm"]
+            mads_per_proof += st_.get("bucket_madds", 0) * mc["madd"] + st_.get("bucket_adds", 0) * mc["jac"]
+        mads = mads_per_proof * total_proofs / world
+        int_mul = {"bound": "v_mad_u64_u32 issue", "achieved": round(mads / (kernel_ms_total * 1e-3) / 1e9, 1),
+                   "peak": INT_MAD_PEAK_G, "unit": "Gmad/s",
+                   "frac": mads / (kernel_ms_total * 1e-3) / 1e9 / INT_MAD_PEAK_G,
+                   "mads_per_proof": int(mads_per_proof), "mads_per_op": {k: v for k, v in mc.items() if k != "field"},
+                   "mads_per_field_op": mc["field"],
+                   "note": "32x32+64 multiply-adds (v_mad_u64_u32 + v_mad_i64_i32) counted in the gfx950 assembly of THIS build "
+                           "(mental-poker_amd/mad_counts.json, tools/gen_mad_counts.py) x static plan; peak = 256 CU x 4 SIMD x 8 lanes/clk x "
+                           "2.4 GHz = 19.7 T/s theoretical, 18 T/s measured (tools/microbench/intrate.hip)"}
+    # HBM traffic of the dominant kernel: PMC pass (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, gfx950 x2
+    # correction applied to FETCH_SIZE) of THIS build at THIS configuration, if one is committed under profiles/
+    src_hash = engine_source_hash()
+    traffic, traffic_src = None, None
+    pmc_path, pmc = find_pmc_summary(src_hash, curve, m, n, B, workload)
+    if pmc and dom_name in pmc.get("kernels", {}):
+        traffic = pmc["kernels"][dom_name]["hbm_bytes_per_proof_per_step_corrected"] * (total_proofs / world) / dom_count
+        traffic_src = pmc_path
     roofline = {
         "bound": "hbm", "kernel": dom_name, "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+        "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
         "avg_launch_ms": dom_ms / dom_count, "launches": dom_count,
-        "alg_bytes_per_launch": dom_bytes / dom_count,
+        "alg_bytes_per_launch": dom_bytes / dom_count, "alg_bytes_per_proof": per_proof,
         "note": "path is integer-ALU bound (SURVEY 8d3): see int_mul",
-        "int_mul": {"bound": "v_mad_u64_u32 issue", "achieved": round(mads / (kernel_ms_total * 1e-3) / 1e9, 1),
-                    "peak": INT_MAD_PEAK_G, "unit": "Gmad/s",
-                    "frac": mads / (kernel_ms_total * 1e-3) / 1e9 / INT_MAD_PEAK_G,
-                    "mads_per_proof": mads_per_proof,
-                    "note": "exact 32x32+64 mad count (v_mad_u64_u32 + v_mad_i64_i32) of the compiled group law x static plan; peak = 256 CU x 4 SIMD x 8 lanes/clk x 2.4 GHz = 19.7 T/s theoretical, 18 T/s measured (tools/microbench/intrate.hip)"},
-        "whole_path_hbm_frac": (value * whole_path_bytes / 1e9 / HBM_PEAK_GBS) if whole_path_bytes else None,
+        "int_mul": int_mul,
+        "whole_path_hbm_frac": value / world * whole_path_bytes / 1e9 / HBM_PEAK_GBS,
         "kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
         "kernel_launches": {k: v[0] for k, v in prof.items()}, "priming_launches": priming_launches,
+        "engine_src": src_hash,
     }
 
     # ---- CPU baseline: the oracle's C++ restatement (port), single thread, bounded sample
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         import coracle as co
-        it = args.cpu_iters
+        it = args.cpu_iters if N <= 64 else max(2, args.cpu_iters * 52 // (N * max(1, m // 2)))
         t_p, t_v = co.bench(curve, m, n, 99, it)
         cpu = {"value": it / (t_p + t_v), "unit": "proofs/s", "cores": 1, "kind": "port",
                "sample": "%d prove+verify pairs, %d-card deck (m=%d,n=%d), %s, single thread; prove %.1f ms verify %.1f ms each"
@@ -352,7 +640,7 @@ def main():
         except (OSError, ValueError):
             pass
         T = max(1, min(T, 64, int(quota + 0.5) if quota else T))    # bounded: the leg must stay within seconds
-        it_mt = 8
+        it_mt = max(1, min(8, it // 4))
         t0 = time.perf_counter()
         with ThreadPoolExecutor(T) as ex:
             list(ex.map(lambda i: co.bench(curve, m, n, 1000 + i, it_mt), range(T)))
@@ -361,15 +649,26 @@ def main():
                             "cgroup_cpu_quota": quota,
                             "sample": "%d threads x %d prove+verify pairs, one proof stream per thread, %.1f s wall" % (T, it_mt, wall)}
 
+    limbs = {"stark": "9x29-bit lazy base field", "bls12_377": "12x32 base field"}.get(curve, "8x32 base field")
+    config = {"workload": "%s: %d-card deck, m=%d n=%d, %s curve, shuffle_and_remask + verify_shuffle" % (workload, N, m, n, curve),
+              "unit_counted": units,
+              "proofs_per_gpu_per_step": proofs_per_step, "streams": S, "fixed_base_window_bits": args.fb_bits,
+              "aggregate_keys": (B if workload == "chain32" else (args.keyed if args.keyed else 1)),
+              "verification": "per equation" if args.per_equation else "merged screening pass (per-equation pass only to name a failure)",
+              "parallelism": "%d rank(s), proofs sharded, no data-path collective; parameters broadcast once (%s)" % (world, backend),
+              "per_rank_proofs": [int(r[0]) for r in rows], "per_rank_failed": [int(r[1]) for r in rows],
+              "per_rank_seconds": [round(r[2], 4) for r in rows],
+              "parity_vs_oracle": parity}
+    config.update(extras)
+    if digests is not None:
+        config["digests"] = digests
     out = {
         "metric": "shuffle proofs/sec (prove+verify)", "value": value, "unit": "proofs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery: 9x29-bit lazy base field, 8x32 scalar field)",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32 limbs (256-bit Montgomery: %s, 8x32 scalar field)" % limbs,
         "data": "synthetic",
-        "config": {"workload": "%d-card deck, m=%d n=%d, %s curve, shuffle_and_remask + verify_shuffle" % (N, m, n, curve),
-                   "proofs_per_gpu_per_step": B, "streams": S, "fixed_base_window_bits": args.fb_bits,
-                   "aggregate_keys": args.keyed if args.keyed else 1,
-                   "parity_vs_oracle": parity},
+        "config": config,
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(out))

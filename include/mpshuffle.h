@@ -143,6 +143,11 @@ int mp_set_latency_batch(mp_table* t, size_t B);
  * FIRST failing check is reported by name exactly as the reference does [REF tests.rs:223-225].  off: always evaluate
  * the equations one by one.  Results (status words) are identical in both modes. */
 int mp_set_merged_verify(mp_table* t, int on);
+/* Curves with a cofactor (MP_CURVE_BLS12_377): every wire point of a call -- decks, keys, proof elements -- is tested for
+ * membership in the prime-order subgroup ([q]P == O), as ark-ec's validating deserialiser does; failures give
+ * MP_ERR_BAD_ENCODING for that proof.  on by default; a caller whose points were already validated (e.g. deserialised by
+ * arkworks with checks) may switch it off -- it costs about three verifications per proof.  No effect on prime-order curves. */
+int mp_set_subgroup_check(mp_table* t, int on);
 
 /* ---- building blocks (host buffers) ------------------------------------------------------------------------
  * mp_remask_batch: out[i] = in[i] + (rho_i * G, rho_i * pk)        [REF remasking.rs:16-18]

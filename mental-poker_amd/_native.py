@@ -16,7 +16,7 @@ MP_ERR_BAD_ENCODING, MP_ERR_BAD_PERMUTATION, MP_ERR_BAD_ARGUMENT, MP_ERR_NO_DEVI
 
 SYMBOLS = [
     "mp_ctx_create", "mp_ctx_destroy", "mp_last_error", "mp_check_name", "mp_proof_size", "mp_params_size",
-    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_host_alloc", "mp_host_free", "mp_set_io_chunk", "mp_shuffle_and_remask_batch_keys", "mp_table_create_params",
+    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_set_subgroup_check", "mp_host_alloc", "mp_host_free", "mp_set_io_chunk", "mp_shuffle_and_remask_batch_keys", "mp_table_create_params",
     "mp_verify_shuffle_batch_keys", "mp_shuffle_and_remask_batch_keys_dev", "mp_verify_shuffle_batch_keys_dev",
     "mp_setup", "mp_table_create", "mp_table_create_ex", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
     "mp_shuffle_and_remask_batch", "mp_verify_shuffle_batch", "mp_shuffle_and_remask_batch_dev",
@@ -72,6 +72,15 @@ def build(verbose=False):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    # multiply-add counts of the compiled field arithmetic (bench.py's int_mul roofline): regenerated with the library
+    mc = os.path.join(HERE, "mad_counts.json")
+    gen = os.path.join(ROOT, "tools", "gen_mad_counts.py")
+    if os.path.exists(gen) and (not os.path.exists(mc) or os.path.getmtime(mc) < max(hdr_time, os.path.getmtime(gen))):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("gen_mad_counts", gen)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.main([f for f in flags if f != "-fPIC"])
     return LIB_PATH
 
 
@@ -90,6 +99,7 @@ def bind(cdll):
     cdll.mp_params_size.argtypes = [c.c_uint32]
     cdll.mp_params_size.restype = c.c_size_t
     cdll.mp_set_merged_verify.argtypes = [c.c_void_p, c.c_int]
+    cdll.mp_set_subgroup_check.argtypes = [c.c_void_p, c.c_int]
     cdll.mp_set_io_chunk.argtypes = [c.c_void_p, c.c_size_t]
     cdll.mp_host_alloc.argtypes = [c.c_size_t]
     cdll.mp_host_alloc.restype = c.c_void_p
@@ -252,7 +262,10 @@ class Table:
         """B proofs; decks: B*N*128 bytes, factors: B*N*32, perms: list of B*N ints, seeds: B*32 -> (decks, proofs, status)"""
         B = len(seeds) // 32
         N = self.N
-        assert len(decks) == B * N * self.cb and len(factors) == B * N * 32 and len(perms) == B * N
+        self._need("prover seeds", len(seeds), B * 32)
+        self._need("decks", len(decks), B * N * self.cb)
+        self._need("masking factors", len(factors), B * N * 32)
+        self._need("permutations", len(perms), B * N)
         out_d = (ctypes.c_uint8 * (B * N * self.cb))()
         out_p = (ctypes.c_uint8 * (B * self.proof_bytes))()
         st = (ctypes.c_int32 * B)()
@@ -264,7 +277,11 @@ class Table:
     def shuffle_and_remask_batch_keys(self, keys, decks, factors, perms, seeds):
         B = len(seeds) // 32
         N = self.N
-        assert len(keys) == B * self.pb and len(decks) == B * N * self.cb and len(factors) == B * N * 32 and len(perms) == B * N
+        self._need("prover seeds", len(seeds), B * 32)
+        self._need("keys", len(keys), B * self.pb)
+        self._need("decks", len(decks), B * N * self.cb)
+        self._need("masking factors", len(factors), B * N * 32)
+        self._need("permutations", len(perms), B * N)
         out_d = (ctypes.c_uint8 * (B * N * self.cb))()
         out_p = (ctypes.c_uint8 * (B * self.proof_bytes))()
         st = (ctypes.c_int32 * B)()
@@ -275,7 +292,10 @@ class Table:
     def verify_shuffle_batch_keys(self, keys, decks, shuffled, proofs):
         N = self.N
         B = len(decks) // (N * self.cb)
-        assert len(keys) == B * self.pb and len(shuffled) == len(decks) and len(proofs) == B * self.proof_bytes
+        self._need("decks", len(decks), B * N * self.cb)
+        self._need("keys", len(keys), B * self.pb)
+        self._need("shuffled decks", len(shuffled), len(decks))
+        self._need("proofs", len(proofs), B * self.proof_bytes)
         st = (ctypes.c_int32 * B)()
         self.eng._chk(self.lib.mp_verify_shuffle_batch_keys(self.h, B, _in(keys), _in(decks), _in(shuffled), _in(proofs), st))
         return list(st)
@@ -290,12 +310,22 @@ class Table:
     def verify_shuffle_batch(self, decks, shuffled, proofs):
         N = self.N
         B = len(decks) // (N * self.cb)
-        assert len(shuffled) == len(decks) and len(proofs) == B * self.proof_bytes
+        self._need("decks", len(decks), B * N * self.cb)
+        self._need("shuffled decks", len(shuffled), len(decks))
+        self._need("proofs", len(proofs), B * self.proof_bytes)
         st = (ctypes.c_int32 * B)()
         self.eng._chk(self.lib.mp_verify_shuffle_batch(self.h, B, _in(decks), _in(shuffled), _in(proofs), st))
         return list(st)
 
+    def _need(self, what, got, want):
+        if got != want:
+            raise NativeError(MP_ERR_BAD_ARGUMENT, "%s: %d bytes/entries given, %d expected" % (what, got, want))
+
     def shuffle_and_remask(self, deck, factors, perm, seed):
+        self._need("deck", len(deck), self.N * self.cb)
+        self._need("masking factors", len(factors), self.N * 32)
+        self._need("permutation", len(perm), self.N)
+        self._need("prover seed", len(seed), 32)
         out_d = (ctypes.c_uint8 * (self.N * self.cb))()
         out_p = (ctypes.c_uint8 * self.proof_bytes)()
         pm = (ctypes.c_uint32 * self.N)(*perm)
@@ -304,6 +334,9 @@ class Table:
         return bytes(out_d), bytes(out_p)
 
     def verify_shuffle(self, deck, shuffled, proof):
+        self._need("deck", len(deck), self.N * self.cb)
+        self._need("shuffled deck", len(shuffled), self.N * self.cb)
+        self._need("proof", len(proof), self.proof_bytes)
         rc = self.lib.mp_verify_shuffle(self.h, _in(deck), _in(shuffled), _in(proof), len(proof))
         return self.eng._chk(rc)
 
@@ -357,6 +390,10 @@ class Table:
     def set_merged_verify(self, on=True):
         """verification strategy: merged screening pass first (default) or always equation by equation"""
         self.eng._chk(self.lib.mp_set_merged_verify(self.h, 1 if on else 0))
+
+    def set_subgroup_check(self, on=True):
+        """curves with a cofactor: test every wire point for membership in the prime-order subgroup (default on)"""
+        self.eng._chk(self.lib.mp_set_subgroup_check(self.h, 1 if on else 0))
 
     def plan_stats(self):
         v = (ctypes.c_uint64 * 16)()

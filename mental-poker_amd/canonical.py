@@ -122,7 +122,38 @@ def point_decompress(curve, data):
         raise SerializationError("point: x is not on the curve")
     if (y > p - y) != bool(flags & 0x80):
         y = p - y
+    if curve in SUBGROUP_ORDER and not _in_subgroup(curve, x, y):
+        raise SerializationError("point: not in the prime-order subgroup")     # ark-ec 0.3 deserialize checks this too
     return x.to_bytes(cb, "little") + y.to_bytes(cb, "little")
+
+
+# curves with a cofactor: group order q of the prime-order subgroup ([q]P == O is what ark-ec's deserialiser verifies)
+SUBGROUP_ORDER = {"bls12_377": 0x12ab655e9a2ca55660b44d1e5c37b00159aa76fed00000010a11800000000001}
+
+
+def _in_subgroup(curve, x, y):
+    p, a, _, _ = CURVE_FIELDS[curve]
+
+    def add(P, Q):
+        if P is None:
+            return Q
+        if Q is None:
+            return P
+        if P[0] == Q[0]:
+            if (P[1] + Q[1]) % p == 0:
+                return None
+            lam = (3 * P[0] * P[0] + a) * pow(2 * P[1], -1, p) % p
+        else:
+            lam = (Q[1] - P[1]) * pow(Q[0] - P[0], -1, p) % p
+        x3 = (lam * lam - P[0] - Q[0]) % p
+        return (x3, (lam * (P[0] - x3) - P[1]) % p)
+    acc, base, k = None, (x, y), SUBGROUP_ORDER[curve]
+    while k:
+        if k & 1:
+            acc = add(acc, base)
+        base = add(base, base)
+        k >>= 1
+    return acc is None
 
 
 def _usize(v):

@@ -151,6 +151,11 @@ int mp_set_merged_verify(mp_table* t, int on) {
   t->set_merged_verify(on != 0);
   return MP_OK;
 }
+int mp_set_subgroup_check(mp_table* t, int on) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_subgroup_check: null table");
+  t->set_subgroup_check(on != 0);
+  return MP_OK;
+}
 int mp_reserve(mp_table* t, size_t B) {
   if (!t || !B) return fail(MP_ERR_BAD_ARGUMENT, "mp_reserve: bad argument");
   MP_TRY

@@ -21,6 +21,13 @@ struct Jac {
   Fe<typename C::FqP> X, Y, Z;
 };
 
+// cofactor of the curve's group (ONE = prime order): BLS12-377 G1 has h = 0x170b5d44300000000000000000000000
+template <class C>
+struct Cofactor {
+  static constexpr bool ONE = C::ID != 3;
+  static constexpr uint32_t H[4] = {0x00000000u, 0x00000000u, 0x30000000u, 0x170b5d44u};
+};
+
 template <class C>
 MP_HD bool aff_is_inf(const Aff<C>& a) {
   return fe_is_zero(a.x) && fe_is_zero(a.y);

@@ -3,6 +3,7 @@
 #pragma once
 #include "engine_base.hpp"
 #include "kernels_sigma.hpp"
+#include "setup_host.hpp"
 
 namespace mp {
 
@@ -120,6 +121,14 @@ struct Table : mp_table {
   Workspace ws;
   bool merged_verify = true;   // verify_dev screens the batch with the merged equation first (mp_set_merged_verify)
   void set_merged_verify(bool on) override { merged_verify = on; }
+  // curves with a cofactor: every wire point of a call is tested for [q]P == O (kernels_msm.hpp k_subgroup_check)
+  bool subgroup_check = !Cofactor<C>::ONE;
+  void set_subgroup_check(bool on) override { subgroup_check = on && !Cofactor<C>::ONE; }
+  void check_subgroup(Workspace& w, uint32_t B, uint32_t first, uint32_t count) {
+    if (!subgroup_check || !count) return;
+    SubgroupArgs a{w.P.p, w.status.p, w.Bpad, first};
+    MP_RUN(k_subgroup_check, C, B, count, a);
+  }
   DevBuf<uint32_t> vflag;      // [1] "some proof of the batch needs the per-equation pass"
   uint32_t nwin = 0;
   FbGeom fbg{8, 32, 255};
@@ -197,6 +206,9 @@ struct Table : mp_table {
     ok &= wire_point_host(params + G_::PB * (2 + n), gen);
     ok &= wire_point_host(pk, pkp);
     if (!ok) return fail(MP_ERR_BAD_ENCODING, "parameters / shared key: bad point encoding");
+    ok = aff_in_subgroup_host<C>(G) && aff_in_subgroup_host<C>(H) && aff_in_subgroup_host<C>(gen) && aff_in_subgroup_host<C>(pkp);
+    for (uint32_t j = 0; j < n; ++j) ok = ok && aff_in_subgroup_host<C>(bases[fb.ck(j)]);
+    if (!ok) return fail(MP_ERR_BAD_ENCODING, "parameters / shared key: a point is not in the prime-order subgroup");
     bases[fb.H()] = H; bases[fb.G()] = G; bases[fb.pk()] = pkp; bases[fb.gen()] = gen;
     Jac<C> gs = jac_inf<C>();
     for (uint32_t j = 0; j < n; ++j) gs = jac_madd<C>(gs, bases[fb.ck(j)]);
@@ -375,10 +387,12 @@ struct Table : mp_table {
       MP_RUN(k_prove_init, C, B, 1, ia);
       RemaskArgs ra{w.S.p, w.P.p, w.J.p, FB.p, perm, w.Bpad, N, l.rho, l.deck, l.shuf, fb.G(), fb.pk(), fbg,
                     0, w.D.p, w.T.p, key_d_first, key_t_first, nwin};
+      check_subgroup(w, B, l.deck, 2 * N);
       if (keyed) {
         // the proof's key -> window bases 2^(5w) pk -> their 16-entry tables; signed digits of the masking factors
         LoadPointsArgs ka{keys, w.P.p, w.status.p, w.Bpad, 1, l.pk};
         MP_RUN(k_load_points, C, B, 1, ka);
+        check_subgroup(w, B, l.pk, 1);
         KeyWinArgs kw{w.P.p, w.J.p, w.Bpad, l.pk, l.kw, nwin};
         MP_RUN(k_key_windows, C, B, 1, kw);
         normalize_flat(w.J.p + j_off<C>(l.kw, w.Bpad, 0), w.P.p + p_off<C>(l.kw, w.Bpad, 0), w.NS.p, (size_t)nwin * w.Bpad);
@@ -476,6 +490,8 @@ struct Table : mp_table {
           LoadPointsArgs ka{keys, w.P.p, w.status.p, w.Bpad, 1, l.pk};
           MP_RUN(k_load_points, C, B, 1, ka);
         }
+        // decks and proof points are the P slots [0, pk); the key follows
+        check_subgroup(w, B, 0, l.pk + (keyed ? 1u : 0u));
       }
       {
         VerifyFsArgs a{};
@@ -724,36 +740,18 @@ struct Table : mp_table {
   }
 };
 
-// DLCards::setup: the scalars come from ChaCha20Rng(seed) on the host (stream logic only); the n+3 scalar
-// multiplications k_i * G_std run on the GPU as n+3 one-term variable-base MSMs (same kernels as mp_msm).
+// DLCards::setup [REF mod.rs:105-121]: n + 3 independent `C::rand` points (setup_host.hpp) -- host work, once per table
+template <class C>
+static void aff_to_wire_host(const Aff<C>& a, uint8_t* out) {
+  alignas(8) uint8_t tmp[Geo<C>::PB];
+  aff_to_wire<C>(a, tmp);
+  memcpy(out, tmp, Geo<C>::PB);
+}
 template <class C>
 static int setup_device(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out) {
-  typedef typename C::FqP F;
-  typedef typename C::FrP R;
-  uint32_t key[8];
-  memcpy(key, seed, 32);
-  FrStream st;
-  frstream_init(st, key);
-  const uint32_t cnt = n + 3;
-  Aff<C> g;
-  g.x = fe_unpack<F>(C::GX_MONT);
-  g.y = fe_unpack<F>(C::GY_MONT);
-  alignas(8) uint8_t gw[Geo<C>::PB];
-  aff_to_wire<C>(g, gw);
-  std::vector<uint8_t> scalars((size_t)cnt * 32), points((size_t)cnt * Geo<C>::PB);
-  for (uint32_t i = 0; i < cnt; ++i) {
-    Fe<R> kf = frstream_next<R>(st);
-    uint32_t k[8];
-    fe_to_canonical<R>(kf, k);
-    memcpy(&scalars[(size_t)i * 32], k, 32);
-    memcpy(&points[(size_t)i * Geo<C>::PB], gw, Geo<C>::PB);
-  }
-  Table<C> t;
-  t.ctx = ctx;
-  t.m = m; t.n = n; t.N = m * n;
-  t.point_bytes = Geo<C>::PB;
-  t.nwin = (uint32_t)vb_windows(R::BITS);
-  t.msm_host(cnt, 1, scalars.data(), points.data(), out);
+  (void)ctx;
+  (void)m;
+  setup_points_host<C>(n, seed, out, &aff_to_wire_host<C>, Geo<C>::PB);
   return MP_OK;
 }
 

@@ -487,6 +487,32 @@ MP_HD void body_normalize(const NormArgs& a, uint32_t x, uint32_t y) {
 }
 MP_KERNEL(k_normalize, NormArgs, body_normalize)
 
+// ---- subgroup membership of wire points on a curve with a cofactor (BLS12-377 G1): [q]P == O, q = the prime group order.
+// wire_to_aff only proves "on the curve"; the batched-affine tables and the completeness rules of the group law assume the
+// prime-order subgroup, and an off-subgroup component of small order would pass an equation with probability ~1/order.  This is
+// the check ark-ec 0.3 performs when it deserialises a point.  253 doublings + ~126 additions per point: dearer than the
+// verifier's own work per point, so it only exists on curves that need it and can be switched off by callers whose points come
+// from a validating deserialiser (mp_set_subgroup_check).
+struct SubgroupArgs {
+  const uint32_t* P;
+  int32_t* status;
+  uint32_t Bpad, p_first;
+};
+template <class C>
+MP_HD void body_subgroup_check(const SubgroupArgs& a, uint32_t b, uint32_t y) {
+  typedef typename C::FrP R;
+  const Aff<C> p = ld_aff<C>(a.P + p_off<C>(a.p_first + y, a.Bpad, b));
+  if (aff_is_inf<C>(p)) return;
+  Jac<C> acc = jac_from_aff<C>(p);
+#pragma unroll 1
+  for (int i = R::BITS - 2; i >= 0; --i) {
+    jac_dbl_ip<C>(acc);
+    if ((R::MOD[i >> 5] >> (i & 31)) & 1u) jac_madd_ip<C>(acc, p);
+  }
+  if (!jac_is_inf<C>(acc)) a.status[b] = -1;      // ST_BAD_ENCODING (kernels_proto.hpp)
+}
+MP_KERNEL_OCC(k_subgroup_check, SubgroupArgs, body_subgroup_check, 2)
+
 // ---- construction of the fixed-base tables (setup time, once per table context) -------------------------
 // pass 1: window bases W_w = 2^(8w) * B for every base (thread = base), Jacobian out -> normalise
 struct FbWinArgs {
@@ -558,6 +584,7 @@ MP_KERNEL(k_fb_widen, FbWidenArgs, body_fb_widen)
   MP_KERNEL_INST(X, k_normalize, NormArgs, C) \
   MP_KERNEL_INST(X, k_fb_windows, FbWinArgs, C) \
   MP_KERNEL_INST(X, k_fb_fill, FbFillArgs, C) \
-  MP_KERNEL_INST(X, k_fb_widen, FbWidenArgs, C)
+  MP_KERNEL_INST(X, k_fb_widen, FbWidenArgs, C) \
+  MP_KERNEL_INST(X, k_subgroup_check, SubgroupArgs, C)
 
 }  // namespace mp

@@ -160,6 +160,11 @@ class DLCards:
         N = pp.m * pp.n
         if len(deck) != N or len(masking_factors) != N or len(permutation.mapping) != N:
             raise CardProtocolError.io("deck, masking factors and permutation must have m*n entries")
+        cb = 2 * self.engine.point_bytes
+        if any(len(c) != cb for c in deck) or len(bytes(shared_key)) != self.engine.point_bytes:
+            raise CardProtocolError.io("a card is %d bytes, the shared key %d" % (cb, self.engine.point_bytes))
+        if len(bytes(rng_seed)) != 32:
+            raise CardProtocolError.io("the prover seed is 32 bytes")
         t = self.table(pp, shared_key)
         try:
             out_deck, proof = t.shuffle_and_remask(b"".join(deck), _scalar_bytes(masking_factors),
@@ -172,6 +177,15 @@ class DLCards:
     # -- fn verify_shuffle(pp, shared_key, original_deck, shuffled_deck, proof) -> Result<(), CryptoError>
     #                                                                                    [REF mod.rs:420-443]
     def verify_shuffle(self, pp, shared_key, original_deck, shuffled_deck, proof):
+        # peer-supplied data: every length is checked HERE, before raw pointers reach the C ABI (the reference returns an
+        # error for a statement of the wrong size)
+        N, cb = pp.m * pp.n, 2 * self.engine.point_bytes
+        if len(original_deck) != N or len(shuffled_deck) != N:
+            raise CardProtocolError.io("both decks must have m*n cards")
+        if any(len(c) != cb for c in original_deck) or any(len(c) != cb for c in shuffled_deck):
+            raise CardProtocolError.io("a card is %d bytes" % cb)
+        if len(bytes(shared_key)) != self.engine.point_bytes or len(proof) != self.engine.proof_size(pp.m, pp.n):
+            raise CardProtocolError.io("shared key / proof have the wrong length")
         t = self.table(pp, shared_key)
         try:
             rc = t.verify_shuffle(b"".join(original_deck), b"".join(shuffled_deck), proof)

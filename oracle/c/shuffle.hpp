@@ -709,15 +709,93 @@ struct Shuffle {
   }
 
   // ---------------------------------------------------------------- synthetic inputs
+  // ---- `C::rand(rng)` of ark-ec 0.3 [UPSTREAM-RECALL]: x = Fq::rand, greatest = rng.gen::<bool>(), lift, scale by the cofactor.
+  // No discrete logarithm of the result is known to anybody ("setup v2": round 1 used k*G_std, a commitment trapdoor).
+  static Fq fq_rand(ChaChaRng& rng) {
+    const int NL = Fq::N, shave = 64 * NL - Fq::C().bits;
+    for (;;) {
+      u64 a[Fq::N];
+      for (int i = 0; i < NL; ++i) a[i] = rng.next_u64();
+      if (shave) a[NL - 1] &= (~(u64)0) >> shave;
+      if (cmpN(a, Fq::modulus(), NL) >= 0) continue;
+      Fq f;                                   // the accepted limbs ARE the Montgomery representation
+      memcpy(f.v, a, 8 * NL);
+      return f;
+    }
+  }
+  // Tonelli-Shanks; false if `a` is not a square
+  static bool fq_sqrt(const Fq& a, Fq& out) {
+    const int NL = Fq::N;
+    if (a.is_zero()) { out = a; return true; }
+    u64 pm1[Fq::N], half[Fq::N], t[Fq::N], t1h[Fq::N], one[Fq::N] = {1};
+    subN(pm1, Fq::modulus(), one, NL);
+    auto shr1 = [&](u64* r, const u64* x) { for (int i = 0; i < NL; ++i) r[i] = (x[i] >> 1) | (i + 1 < NL ? x[i + 1] << 63 : 0); };
+    shr1(half, pm1);
+    const Fq minus_one = Fq::one().neg();
+    if (a.pow(half) != Fq::one()) return false;
+    int s = 0;
+    memcpy(t, pm1, 8 * NL);
+    while (!(t[0] & 1)) { shr1(t, t); ++s; }
+    addN(t1h, t, one, NL);
+    shr1(t1h, t1h);
+    Fq z = Fq::from_u64(2);
+    for (u64 k = 2; z.pow(half) != minus_one; ) z = Fq::from_u64(++k);
+    Fq c = z.pow(t), r = a.pow(t1h), tt = a.pow(t);
+    int M = s;
+    while (tt != Fq::one()) {
+      int i = 0;
+      Fq u = tt;
+      while (u != Fq::one()) { u = u.sqr(); ++i; }
+      Fq b = c;
+      for (int k = 0; k < M - i - 1; ++k) b = b.sqr();
+      r = r * b;
+      c = b.sqr();
+      tt = tt * c;
+      M = i;
+    }
+    out = r;
+    return true;
+  }
+  static Pt point_rand(ChaChaRng& rng) {
+    for (;;) {
+      Fq x = fq_rand(rng);
+      const bool greatest = (rng.next_u32() >> 31) & 1;
+      Fq rhs = x.sqr() * x + Fq::from_u256(Cv::B);
+      if (Cv::A == 1) rhs = rhs + x;
+      Fq y;
+      if (!fq_sqrt(rhs, y)) continue;
+      Fq ny = y.neg();
+      u64 yi[Fq::N], nyi[Fq::N];
+      y.to_u256(yi);
+      ny.to_u256(nyi);
+      const bool y_is_larger = cmpN(yi, nyi, Fq::N) > 0;
+      Pt p;
+      p.x = x;
+      p.y = (y_is_larger == greatest) ? y : ny;
+      p.inf = false;
+      if (Cv::ID == 3) {                       // BLS12-377 G1: scale by the cofactor 0x170b5d44300000000000000000000000
+        const u64 h[2] = {0x0000000000000000ull, 0x170b5d4430000000ull};
+        Jac<Cv> acc = Jac<Cv>::infinity();
+        for (int i = 127; i >= 0; --i) {
+          acc = acc.dbl();
+          if ((h[i / 64] >> (i % 64)) & 1) acc = acc.add_mixed(p);
+        }
+        p = acc.to_affine();
+      }
+      return p;
+    }
+  }
+
+  // ---------------------------------------------------------------- synthetic inputs
+  // DLCards::setup [REF mod.rs:105-121]: G, ck_0..ck_{n-1}, H, gen -- independent `C::rand` points in that order
   static Params setup(uint32_t m, uint32_t n, ChaChaRng& rng) {
     Params pp;
     pp.m = m;
     pp.n = n;
-    Pt g = Pt::generator();
-    pp.G = mul(field_rand<Fr>(rng), g);
-    for (uint32_t i = 0; i < n; ++i) pp.ck.push_back(mul(field_rand<Fr>(rng), g));
-    pp.H = mul(field_rand<Fr>(rng), g);
-    pp.gen = mul(field_rand<Fr>(rng), g);
+    pp.G = point_rand(rng);
+    for (uint32_t i = 0; i < n; ++i) pp.ck.push_back(point_rand(rng));
+    pp.H = point_rand(rng);
+    pp.gen = point_rand(rng);
     pp.gsum = compute_gsum(pp.ck);
     return pp;
   }

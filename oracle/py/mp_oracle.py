@@ -180,6 +180,17 @@ def pt_mul(cv, k, P):
     return to_affine(cv, jac_mul(cv, k, P))
 
 
+def pt_mul_raw(cv, k, P):
+    """[k]P for an integer k >= 0 that is NOT reduced modulo the group order (cofactor clearing, subgroup tests)"""
+    acc = (1, 1, 0)
+    J = to_jac(P)
+    for bit in bin(k)[2:] if k else "":
+        acc = jac_double(cv, acc)
+        if bit == "1":
+            acc = jac_add(cv, acc, J)
+    return to_affine(cv, acc)
+
+
 def msm(cv, scalars, points):
     """sum k_i * P_i (plain per-term double-and-add; the result is a canonical group element)."""
     acc = (1, 1, 0)
@@ -786,13 +797,74 @@ def proof_from_bytes(buf, m, n):
 # ----------------------------------------------------------------------------------------------
 
 
+COFACTOR = {"bls12_377": 0x170b5d44300000000000000000000000}      # G1 cofactor of BLS12-377; the other curves have prime order
+
+
+def fq_rand(cv, rng):
+    """arkworks-0.3 `Fp::rand` on the BASE field: fq_bytes/8 u64 limbs (limb 0 first), top REPR_SHAVE_BITS of the last limb
+    cleared, accepted if < p; the accepted limbs ARE the Montgomery representation (value = limbs / R mod p, R = 2^(64 limbs))."""
+    nl = cv.fq_bytes // 8
+    shave = 64 * nl - cv.p.bit_length()
+    while True:
+        limbs = [rng.next_u64() for _ in range(nl)]
+        if shave:
+            limbs[-1] &= (1 << (64 - shave)) - 1
+        v = sum(l << (64 * i) for i, l in enumerate(limbs))
+        if v < cv.p:
+            return v * pow(1 << (64 * nl), -1, cv.p) % cv.p
+
+
+def fq_sqrt(cv, a):
+    """a square root of a mod p (Tonelli-Shanks), or None if a is not a square"""
+    p = cv.p
+    a %= p
+    if a == 0:
+        return 0
+    if pow(a, (p - 1) // 2, p) != 1:
+        return None
+    s, t = 0, p - 1
+    while t % 2 == 0:
+        s, t = s + 1, t // 2
+    z = 2
+    while pow(z, (p - 1) // 2, p) != p - 1:
+        z += 1
+    c, r, tt, M = pow(z, t, p), pow(a, (t + 1) // 2, p), pow(a, t, p), s
+    while tt != 1:
+        i, u = 0, tt
+        while u != 1:
+            u, i = u * u % p, i + 1
+        b = pow(c, 1 << (M - i - 1), p)
+        r, c = r * b % p, b * b % p
+        tt, M = tt * c % p, i
+    return r
+
+
+def point_rand(cv, rng):
+    """`C::rand(rng)` of ark-ec 0.3 (`GroupAffine::rand` -> `get_point_from_x` -> `scale_by_cofactor`) [UPSTREAM-RECALL]:
+    loop { x = Fq::rand; greatest = rng.gen::<bool>() (= top bit of next_u32); y = sqrt(x^3 + a x + b) or retry;
+    y = the larger of (y, -y) as canonical integers iff greatest }; multiply by the cofactor.  Nobody learns a discrete
+    logarithm of the result with respect to anything."""
+    while True:
+        x = fq_rand(cv, rng)
+        greatest = (rng.next_u32() >> 31) & 1
+        y = fq_sqrt(cv, (x * x * x + cv.a * x + cv.b) % cv.p)
+        if y is None:
+            continue
+        ny = (cv.p - y) % cv.p
+        lo, hi = min(y, ny), max(y, ny)
+        P = (x, hi if greatest else lo)
+        h = COFACTOR.get(cv.name, 1)
+        return pt_mul_raw(cv, h, P) if h != 1 else P
+
+
 def setup(cv, m, n, rng):
-    """DLCards::setup [REF mod.rs:105-121]: G, ck (n generators + H), extra generator -- here k*G_std
-    with k = Fr::rand(rng) in the order G, ck_0..ck_{n-1}, H, gen."""
-    G = pt_mul(cv, fr_rand(cv, rng), cv.G)
-    ck = [pt_mul(cv, fr_rand(cv, rng), cv.G) for _ in range(n)]
-    H = pt_mul(cv, fr_rand(cv, rng), cv.G)
-    gen = pt_mul(cv, fr_rand(cv, rng), cv.G)
+    """DLCards::setup [REF mod.rs:105-121]: G (`Enc::setup`), ck = n generators + H (`Comm::setup`), extra generator
+    (`Enc::generator`) -- each an independent `C::rand(rng)` point, in the order G, ck_0..ck_{n-1}, H, gen ("setup v2":
+    round 1 derived them as k*G_std, which made the seed a commitment trapdoor)."""
+    G = point_rand(cv, rng)
+    ck = [point_rand(cv, rng) for _ in range(n)]
+    H = point_rand(cv, rng)
+    gen = point_rand(cv, rng)
     return Params(cv, m, n, G, ck, H, gen)
 
 

@@ -230,3 +230,76 @@ def test_emulated_sigma_engine_matches_oracle(emu):
     assert t.sigma_verify_batch(2, bases, pubs, bytes(bad), fsi) == [0, 0, 6]
     assert eng.check_name(5) == "Schnorr Identification" and eng.check_name(6) == "Chaum-Pedersen"
     t.close()
+
+
+@pytest.mark.parametrize("cvn", ["stark", "bn254", "secp256k1", "bls12_377"])
+def test_setup_has_no_trapdoor_and_matches_oracle(emu, cvn):
+    """mp_setup ("setup v2"): n + 3 independent `C::rand` points (x from the stream, lifted, cofactor-cleared) -- the same bytes as
+    the oracle, on the curve, in the prime-order subgroup, and NOT the round-1 construction k * G_std"""
+    import mp_oracle as po
+    cv = po.CURVES[cvn]
+    seed = bytes(range(7, 39))
+    raw = emu(cvn).setup(2, 4, seed)
+    with po.curve_ctx(cv):
+        pp = po.setup(cv, 2, 4, po.ChaCha20Rng(seed))
+        pts = [pp.G] + pp.ck + [pp.H, pp.gen]
+        assert raw == b"".join(po.pt_wire(P) for P in pts)
+        for P in pts:
+            assert cv.is_on_curve(P) and po.pt_mul_raw(cv, cv.q, P) is None and po.pt_mul_raw(cv, cv.q - 1, P) == po.pt_neg(cv, P)
+        old = po.pt_mul(cv, po.fr_rand(cv, po.ChaCha20Rng(seed)), cv.G)
+        assert pts[0] != old
+
+
+def test_single_shot_entry_points_validate_lengths(emu, native):
+    """peer-supplied buffers of the wrong size are refused in the binding (never handed to the C ABI as short buffers)"""
+    g = load_json(os.path.join(GOLDEN, "shuffle_stark_m2_n3_s1.json"))
+    eng = emu("stark")
+    t = eng.table(2, 3, bytes.fromhex(g["params"]), bytes.fromhex(g["pk"]))
+    deck, shuf, proof = bytes.fromhex(g["deck"]), bytes.fromhex(g["shuffled"]), bytes.fromhex(g["proof"])
+    assert t.verify_shuffle(deck, shuf, proof) == 0
+    for bad in ((deck[:-128], shuf, proof), (deck, shuf[:-1], proof), (deck, shuf, proof[:-32]), (deck + deck, shuf, proof)):
+        with pytest.raises(native.NativeError):
+            t.verify_shuffle(*bad)
+    rho, perm, seed = bytes.fromhex(g["rho"]), g["perm"], bytes.fromhex(g["prover_seed"])
+    for bad in ((deck[:-64], rho, perm, seed), (deck, rho[:-32], perm, seed), (deck, rho, perm[:-1], seed), (deck, rho, perm, seed[:16])):
+        with pytest.raises(native.NativeError):
+            t.shuffle_and_remask(*bad)
+    with pytest.raises(native.NativeError):
+        t.verify_shuffle_batch(deck, shuf[:-1], proof)
+
+
+def test_points_outside_the_prime_order_subgroup_are_rejected(emu, native):
+    """BLS12-377 G1 has a cofactor: a point ON the curve but outside the prime-order subgroup must be refused as a key, as a
+    deck component (status MP_ERR_BAD_ENCODING) and by the canonical decoder -- what ark-ec's validating deserialiser does"""
+    import mp_oracle as po
+    cv = po.CURVES["bls12_377"]
+    g = load_json(os.path.join(GOLDEN, "shuffle_bls12_377_m2_n3_s13.json"))
+    with po.curve_ctx(cv):
+        x = 5
+        while True:                      # a curve point that was NOT multiplied by the cofactor ...
+            y = po.fq_sqrt(cv, (x ** 3 + cv.b) % cv.p)
+            if y is not None and po.pt_mul_raw(cv, cv.q, (x, y)) is not None:
+                break
+            x += 1
+        low = po.pt_mul_raw(cv, cv.q, (x, y))      # ... times q: non-trivial, of order dividing the cofactor
+        assert cv.is_on_curve(low) and po.pt_mul_raw(cv, po.COFACTOR["bls12_377"], low) is None
+        bad = po.pt_wire(low)
+    eng = emu("bls12_377")
+    params, pk = bytes.fromhex(g["params"]), bytes.fromhex(g["pk"])
+    with pytest.raises(native.NativeError):
+        eng.table(2, 3, params, bad)
+    with pytest.raises(native.NativeError):
+        eng.table(2, 3, bad + params[96:], pk)
+    t = eng.table(2, 3, params, pk)
+    deck, shuf, proof = bytes.fromhex(g["deck"]), bytes.fromhex(g["shuffled"]), bytes.fromhex(g["proof"])
+    assert t.verify_shuffle_batch(deck, shuf, proof) == [0]
+    tampered = bad + deck[96:]
+    assert t.verify_shuffle_batch(tampered, shuf, proof) == [native._native.MP_ERR_BAD_ENCODING]
+    _, _, st = t.shuffle_and_remask_batch(tampered, bytes.fromhex(g["rho"]), g["perm"], bytes.fromhex(g["prover_seed"]))
+    assert st == [native._native.MP_ERR_BAD_ENCODING]
+    t.set_subgroup_check(False)                     # the caller vouches for its points: the same input is now merely a wrong statement
+    assert t.verify_shuffle_batch(tampered, shuf, proof)[0] > 0
+    comp = native.canonical.point_compress("bls12_377", bad)
+    with pytest.raises(native.canonical.SerializationError):
+        native.canonical.point_decompress("bls12_377", comp)
+    assert native.canonical.point_decompress("bls12_377", native.canonical.point_compress("bls12_377", pk)) == pk

@@ -32,6 +32,9 @@ def _worker(rank, world, port, q):
     t = bench.reduce_max(1.0 + rank, dev)
     s = bench.reduce_sum(hi - lo, dev)
     assert bench.dist_info() == (rank, world, rank)
+    rows = bench.gather_rows([hi - lo, rank, 0.5], dev)
+    assert rows == [[501.0, 0.0, 0.5], [500.0, 1.0, 0.5]]
+    assert bench.gather_objects({"r": rank}) == [{"r": 0}, {"r": 1}]
     q.put((rank, got == bytes(range(256)) * 7, (lo, hi), t, s))
     dist.barrier()
     dist.destroy_process_group()
@@ -62,3 +65,72 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+# ---- the sharded data path itself: every rank proves and verifies its block of the batch with an ENGINE (the development
+# emulator -- kernel bodies as CPU loops, tools/hostemu -- since this container has no GPU), parameters travel through the
+# same broadcast bench.py uses, and the concatenated per-rank outputs must equal the unsharded run byte for byte
+def _inputs(co, curve, m, n, total):
+    g = co.gen_inputs(curve, m, n, 77)
+    N = m * n
+    decks, rho, perms, seeds = b"", b"", [], b""
+    for i in range(total):
+        gi = co.gen_inputs(curve, m, n, 1000 + i)
+        decks += g["deck"]
+        rho += gi["rho"]
+        perms += gi["perm"]
+        seeds += gi["prover_seed"]
+    return g, decks, rho, perms, seeds
+
+
+def _engine_worker(rank, world, port, q, total):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import ctypes
+    import importlib
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import bench
+    import coracle as co
+    pkg = importlib.import_module("mental-poker_amd")
+    lib = pkg._native.bind(ctypes.CDLL(os.path.join(ROOT, "tools", "hostemu", "libmpemu.so")))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    curve, m, n = "stark", 2, 3
+    N = m * n
+    g, decks, rho, perms, seeds = _inputs(co, curve, m, n, total)
+    eng = pkg._native.Engine(curve, 0, lib=lib)
+    blob = (g["params"] + g["pk"]) if rank == 0 else None            # rank 0 owns the session's parameters
+    blob = bench.bcast_bytes(blob, 64 * (n + 3) + 64, 0, dev)
+    table = eng.table(m, n, blob[:64 * (n + 3)], blob[64 * (n + 3):])
+    lo, hi = bench.shard_range(total, rank, world)
+    sl = lambda b, w: b[lo * w:hi * w]
+    out_d, out_p, st = table.shuffle_and_remask_batch(sl(decks, 128 * N), sl(rho, 32 * N), perms[lo * N:hi * N], sl(seeds, 32))
+    sv = table.verify_shuffle_batch(sl(decks, 128 * N), out_d, out_p)
+    rows = bench.gather_rows([hi - lo, sum(1 for v in st + sv if v != 0)], dev)
+    parts = bench.gather_objects((out_d, out_p))
+    if rank == 0:
+        full_d, full_p, st_all = table.shuffle_and_remask_batch(decks, rho, perms, seeds)      # the unsharded run
+        ok = b"".join(p[0] for p in parts) == full_d and b"".join(p[1] for p in parts) == full_p and not any(st_all)
+        exp_d, exp_p = co.shuffle_and_remask(curve, m, n, g["params"], g["pk"], decks[:128 * N], rho[:32 * N], perms[:N], seeds[:32])
+        ok = ok and full_d[:128 * N] == exp_d and full_p[:len(exp_p)] == exp_p
+        q.put((ok, rows))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_engine_output_equals_unsharded():
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools", "hostemu")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    total = 5
+    procs = [ctx.Process(target=_engine_worker, args=(r, 2, port, q, total)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, rows = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
+    assert rows == [[3.0, 0.0], [2.0, 0.0]]

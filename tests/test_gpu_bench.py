@@ -1,0 +1,63 @@
+"""GPU tests of bench.py itself (run on the MI355X box): `--gpus N` started from a plain shell launches N ranks on its own,
+the sharded run produces byte-identical outputs to an unsharded run of the same proofs, and the JSON line carries what the
+driver reads.  The box has one GPU: MP_BENCH_FORCE_DEVICE / MP_BENCH_BACKEND=gloo put both ranks on it and run the
+once-per-session collectives over gloo (on an 8-GPU node the same code path uses RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), env=e, cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE json line"
+    return json.loads(lines[0])
+
+
+COMMON = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--fb-bits", "8", "--digest", "--seed-block", "192"]
+
+
+def test_self_launch_two_ranks_equals_unsharded():
+    sharded = run_bench("--gpus", "2", "--batch", "192", *COMMON, env={"MP_BENCH_FORCE_DEVICE": "0", "MP_BENCH_BACKEND": "gloo"})
+    assert sharded["n_gpus"] == 2
+    assert sharded["config"]["per_rank_proofs"] == [192, 192] and sharded["config"]["per_rank_failed"] == [0, 0]
+    assert len(sharded["config"]["per_rank_seconds"]) == 2
+    assert abs(sharded["value"] - 384 / (sharded["ms_per_step"] * 1e-3)) < 1e-6 * sharded["value"]
+    single = run_bench("--gpus", "1", "--batch", "384", *COMMON)
+    assert single["n_gpus"] == 1
+    flat = [d for per_rank in sharded["config"]["digests"] for d in per_rank]
+    assert flat == single["config"]["digests"][0] and len(flat) == 2 and flat[0] != flat[1]
+    assert single["config"]["parity_vs_oracle"] is True and sharded["config"]["parity_vs_oracle"] is True
+
+
+def test_json_line_contract_and_extras():
+    d = run_bench("--batch", "4096", "--steps", "2", "--warmup", "1", "--fb-bits", "8", "--cpu-iters", "2")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6
+    assert r["traffic"] is None or r["traffic_source"].startswith("profiles/")      # only from a PMC pass of THIS build and batch
+    assert r["int_mul"]["mads_per_op"]["madd"] == 900 and r["int_mul"]["mads_per_op"]["dbl"] == 828   # STARK, counted in the assembly
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
+    assert d["config"]["per_equation_value"] > 0 and d["config"]["keyed_value"] > 0
+
+
+@pytest.mark.parametrize("workload,extra", [("chain32", ["--batch", "256", "--players", "4"]),
+                                            ("mixed", ["--batch", "512"])])
+def test_workload_modes(workload, extra):
+    d = run_bench("--workload", workload, "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--fb-bits", "8", *extra)
+    assert d["config"]["workload"].startswith(workload) and d["config"]["parity_vs_oracle"] is True and d["value"] > 0
+    if workload == "mixed":
+        assert "secp256k1" in d["config"]["workload"]
