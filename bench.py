@@ -200,6 +200,8 @@ def main():
     ap.add_argument("--keyed", type=int, default=0, metavar="K",
                     help="keyed batches: K distinct aggregate keys (card tables) spread over the batch, one key per proof "
                          "(mp_*_batch_keys_dev); 0 = every proof under the table's own key")
+    ap.add_argument("--bucket-min", type=int, default=None,
+                    help="variable-base MSMs of at least this many terms run on the bucket-method kernel (engine default 2048; 0 = never)")
     ap.add_argument("--per-equation", action="store_true", help="verify equation by equation (mp_set_merged_verify off)")
     ap.add_argument("--players", type=int, default=32, help="chain32: shuffles per table")
     ap.add_argument("--digest", action="store_true",
@@ -265,6 +267,8 @@ def main():
             t.set_latency_batch(args.latency_batch)
         if args.per_equation:
             t.set_merged_verify(False)
+        if args.bucket_min is not None:
+            t.set_bucket_min(args.bucket_min)
     table = tables[0]
     proof_bytes = table.proof_bytes
 

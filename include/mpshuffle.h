@@ -143,6 +143,11 @@ int mp_set_latency_batch(mp_table* t, size_t B);
  * FIRST failing check is reported by name exactly as the reference does [REF tests.rs:223-225].  off: always evaluate
  * the equations one by one.  Results (status words) are identical in both modes. */
 int mp_set_merged_verify(mp_table* t, int on);
+/* Variable-base MSMs with at least `terms` terms (default 2048: the verifier's products over a 1024-card deck) run on the
+ * wave-cooperative bucket-method kernel (LDS-staged digits, counting sort by wavefront prefix sum, wave-wide bucket reduction),
+ * smaller ones on the Straus kernel with per-proof window tables; 0 = never.  Results are identical; the split is a property of
+ * the table's static plans, which this call rebuilds. */
+int mp_set_bucket_min(mp_table* t, size_t terms);
 /* Curves with a cofactor (MP_CURVE_BLS12_377): every wire point of a call -- decks, keys, proof elements -- is tested for
  * membership in the prime-order subgroup ([q]P == O), as ark-ec's validating deserialiser does; failures give
  * MP_ERR_BAD_ENCODING for that proof.  on by default; a caller whose points were already validated (e.g. deserialised by

@@ -151,6 +151,14 @@ int mp_set_merged_verify(mp_table* t, int on) {
   t->set_merged_verify(on != 0);
   return MP_OK;
 }
+int mp_set_bucket_min(mp_table* t, size_t terms) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_min: null table");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  t->set_bucket_min((uint32_t)std::min<size_t>(terms, 0x7FFFFFFFu));
+  return MP_OK;
+  MP_CATCH
+}
 int mp_set_subgroup_check(mp_table* t, int on) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_subgroup_check: null table");
   t->set_subgroup_check(on != 0);

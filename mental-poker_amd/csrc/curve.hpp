@@ -254,6 +254,37 @@ MP_HD void xyzz_madd_ip(Xyzz<C>& p, const Aff<C>& q) {
   p.ZZ = fe_mul<F>(p.ZZ, PP);
   p.ZZZ = fe_mul<F>(p.ZZZ, PPP);
 }
+// p <- p + q, both XYZZ (12M + 2S): partial sums of the bucket method (kernels_bucket.hpp)
+template <class C>
+MP_HD void xyzz_add_ip(Xyzz<C>& p, const Xyzz<C>& q) {
+  typedef typename C::FqP F;
+  if (fe_is_zero(q.ZZ)) return;
+  if (fe_is_zero(p.ZZ)) {
+    p = q;
+    return;
+  }
+  const Fe<F> U1 = fe_mul<F>(p.X, q.ZZ), U2 = fe_mul<F>(q.X, p.ZZ);
+  const Fe<F> S1 = fe_mul<F>(p.Y, q.ZZZ), S2 = fe_mul<F>(q.Y, p.ZZZ);
+  const Fe<F> Pd = fe_sub<F>(U2, U1);
+  const Fe<F> Rr = fe_sub<F>(S2, S1);
+  if (fe_is_zero(Pd)) {
+    if (fe_is_zero(Rr)) {
+      xyzz_dbl_ip<C>(p);         // P + P
+    } else {
+      p.ZZ = fe_zero<F>();       // P + (-P)
+      p.ZZZ = fe_zero<F>();
+    }
+    return;
+  }
+  const Fe<F> PP = fe_sqr<F>(Pd);
+  const Fe<F> PPP = fe_mul<F>(Pd, PP);
+  const Fe<F> Q = fe_mul<F>(U1, PP);
+  const Fe<F> X3 = fe_sub<F>(fe_sub<F>(fe_sqr<F>(Rr), PPP), fe_dbl<F>(Q));
+  p.Y = fe_mulsub<F>(Rr, fe_sub<F>(Q, X3), S1, PPP);
+  p.X = X3;
+  p.ZZ = fe_mul<F>(fe_mul<F>(p.ZZ, q.ZZ), PP);
+  p.ZZZ = fe_mul<F>(fe_mul<F>(p.ZZZ, q.ZZZ), PPP);
+}
 // the same point in Jacobian coordinates with Z = ZZ: (X ZZ, Y ZZZ, ZZ)
 template <class C>
 MP_HD Jac<C> xyzz_to_jac(const Xyzz<C>& p) {

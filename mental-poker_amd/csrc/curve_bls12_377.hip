@@ -2,5 +2,6 @@
 #include "engine_core.hpp"
 namespace mp {
 MP_MSM_KERNELS(extern template, Bls12_377)
+MP_BUCKET_KERNELS(extern template, Bls12_377)
 }
 MP_DEFINE_CURVE(Bls12_377)

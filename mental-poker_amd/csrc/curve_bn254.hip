@@ -2,5 +2,6 @@
 #include "engine_core.hpp"
 namespace mp {
 MP_MSM_KERNELS(extern template, Bn254)
+MP_BUCKET_KERNELS(extern template, Bn254)
 }
 MP_DEFINE_CURVE(Bn254)

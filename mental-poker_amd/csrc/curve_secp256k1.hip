@@ -2,5 +2,6 @@
 #include "engine_core.hpp"
 namespace mp {
 MP_MSM_KERNELS(extern template, Secp256k1)
+MP_BUCKET_KERNELS(extern template, Secp256k1)
 }
 MP_DEFINE_CURVE(Secp256k1)

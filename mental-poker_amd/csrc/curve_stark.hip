@@ -2,5 +2,6 @@
 #include "engine_core.hpp"
 namespace mp {
 MP_MSM_KERNELS(extern template, Stark)
+MP_BUCKET_KERNELS(extern template, Stark)
 }
 MP_DEFINE_CURVE(Stark)

@@ -2,6 +2,7 @@
 // Included by one translation unit per curve (curve_*.hip).
 #pragma once
 #include "engine_base.hpp"
+#include "kernels_bucket.hpp"
 #include "kernels_sigma.hpp"
 #include "setup_host.hpp"
 
@@ -10,10 +11,15 @@ namespace mp {
 static const uint32_t FCHUNK = 8;     // fixed-base terms per sub-job (8 x 13..32 mixed additions, by window width)
 static const uint32_t VCHUNK = 64;    // variable-base terms per sub-job: the terms of a job share one 250-doubling chain
 static const uint32_t NORM_CHUNK = 64;   // points per Fermat inversion in k_normalize
+static const uint32_t BUCKET_MIN = 2048; // variable-base terms from which an MSM runs on the bucket kernel (kernels_bucket.hpp)
 
 struct PhaseDev {
   DevBuf<Term> recode, tables, fterms, vterms, cterms, cterms2;
   DevBuf<Job> fjobs, vjobs, cjobs, cjobs2;
+  DevBuf<BJob> bjobs;
+  DevBuf<Term> bterms;
+  DevBuf<BTermPos> bpos;
+  uint32_t n_b = 0, n_bterms = 0, b_dig_bytes = 0, b_kpad_max = 0;
   uint32_t n_recode = 0, n_tables = 0, n_f = 0, n_v = 0, n_c = 0, n_c2 = 0, n_tslots = 0, n_dslots = 0;
   std::vector<std::pair<uint32_t, uint32_t>> normalize;
   void upload(const Phase& ph, rt::Stream s) {
@@ -28,6 +34,13 @@ struct PhaseDev {
     cterms2.upload(ph.cterms2, s);
     cjobs2.upload(ph.cjobs2, s);
     n_c2 = (uint32_t)ph.cjobs2.size();
+    bjobs.upload(ph.bjobs, s);
+    bterms.upload(ph.bterms, s);
+    bpos.upload(ph.bpos, s);
+    n_b = (uint32_t)ph.bjobs.size();
+    n_bterms = (uint32_t)ph.bterms.size();
+    b_dig_bytes = ph.b_dig_bytes;
+    b_kpad_max = ph.b_kpad_max;
     n_recode = (uint32_t)ph.recode.size();
     n_tables = (uint32_t)ph.tables.size();
     n_f = (uint32_t)ph.fjobs.size();
@@ -46,11 +59,15 @@ struct Workspace {
   uint32_t nS = 0, nP = 0, nJ = 0, nD = 0, nT = 0, nwin = 0, stage_words = 0;
   DevBuf<uint32_t> S, P, J, T, NS, stage, seed, direct;
   DevBuf<int8_t> D;
+  DevBuf<int8_t> D8;        // bucket-method digits, proof-major: [b][d8_bytes]
+  uint32_t d8_bytes = 0;
   DevBuf<int32_t> status;
   void ensure(uint32_t B, uint32_t nS_, uint32_t nP_, uint32_t nJ_, uint32_t nD_, uint32_t nT_, uint32_t nwin_,
-              uint32_t stage_words_, rt::Stream s) {
+              uint32_t stage_words_, rt::Stream s, uint32_t d8_bytes_ = 0) {
     uint32_t need = (B + 63u) & ~63u;
-    if (need <= Bpad && nS_ <= nS && nP_ <= nP && nJ_ <= nJ && nD_ <= nD && nT_ <= nT && stage_words_ <= stage_words) return;
+    if (need <= Bpad && nS_ <= nS && nP_ <= nP && nJ_ <= nJ && nD_ <= nD && nT_ <= nT && stage_words_ <= stage_words &&
+        d8_bytes_ <= d8_bytes)
+      return;
     Bpad = std::max(Bpad, need);
     nS = std::max(nS, nS_); nP = std::max(nP, nP_); nJ = std::max(nJ, nJ_); nD = std::max(nD, nD_); nT = std::max(nT, nT_);
     nwin = nwin_;
@@ -58,6 +75,9 @@ struct Workspace {
     // re-allocate everything (capacity grows monotonically); zero-filled so padding lanes hold valid data
     S.n = P.n = J.n = T.n = NS.n = stage.n = seed.n = direct.n = 0;
     D.n = 0;
+    D8.n = 0;
+    d8_bytes = std::max(d8_bytes, d8_bytes_);
+    D8.alloc((size_t)std::max(d8_bytes, 4u) * Bpad, s);      // zero-filled: the padding digits of an MSM stay zero
     status.n = 0;
     S.alloc((size_t)nS * Bpad * 8, s);
     P.alloc((size_t)nP * Bpad * 2 * fw, s);
@@ -114,6 +134,15 @@ struct Table : mp_table {
     medium_batch = latency_batch / 2 * 7;
     tiny_batch = latency_batch / 16 * 3;
   }
+  uint32_t bucket_min = BUCKET_MIN;              // MSMs of at least this many variable-base terms use the bucket kernel (0 = never)
+  void set_bucket_min(uint32_t terms) override {
+    if (terms == bucket_min) return;
+    bucket_min = terms;
+    rt::stream_sync(ctx->stream);
+    build_plans(ps, false);          // the split between Straus sub-jobs and bucket jobs is part of the static plans
+    psk_ready = false;
+    rt::stream_sync(ctx->stream);
+  }
   uint32_t cur_table_group = TABLE_GROUP;
   uint32_t cur_norm_chunk = NORM_CHUNK;          // points per inversion in k_normalize: a property of the plan in use
   DevBuf<uint32_t> fbpts;    // (n+5) affine base points
@@ -151,8 +180,8 @@ struct Table : mp_table {
                           nch[N_PLANS] = {NORM_CHUNK, 8, 32, 4};
     for (int k = 0; k < N_PLANS; ++k) {
       PlanSet& q = set[k];
-      q.pplan = make_prove_plan(m, n, fch[k], vch[k], G_::PB, keyed);
-      q.vplan = make_verify_plan(m, n, fch[k], vch[k], G_::PB, keyed);
+      q.pplan = make_prove_plan(m, n, fch[k], vch[k], G_::PB, keyed, bucket_min, bk_windows(R::BITS));
+      q.vplan = make_verify_plan(m, n, fch[k], vch[k], G_::PB, keyed, bucket_min, bk_windows(R::BITS));
       q.table_group = grp[k];
       q.norm_chunk = nch[k];       // fewer points per serial inversion chain when lanes are idle
       for (int i = 0; i < 5; ++i) q.pph[i].upload(q.pplan.ph[i], s);
@@ -306,16 +335,18 @@ struct Table : mp_table {
     uint32_t nS = std::max(q.pplan.lay.nS, q.vplan.lay.nS), nP = std::max(q.pplan.lay.nP, q.vplan.lay.nP);
     uint32_t nJ = std::max(q.pplan.nJ, q.vplan.nJ), nD = std::max(q.vph.n_dslots, q.vmph.n_dslots),
              nT = std::max(q.vph.n_tslots, q.vmph.n_tslots);
+    uint32_t d8 = std::max(q.vph.b_dig_bytes, q.vmph.b_dig_bytes);
     for (int i = 0; i < 5; ++i) {
       nD = std::max(nD, q.pph[i].n_dslots);
       nT = std::max(nT, q.pph[i].n_tslots);
+      d8 = std::max(d8, q.pph[i].b_dig_bytes);
     }
     if (keyed) {
       nD = std::max(nD, key_d_first + N);
       nT = std::max(nT, key_t_first + nwin);
     }
     ws.fw = G_::FW;
-    ws.ensure((uint32_t)B, nS, nP, nJ, nD, nT, nwin, stage_words_needed(), ctx->stream);
+    ws.ensure((uint32_t)B, nS, nP, nJ, nD, nT, nwin, stage_words_needed(), ctx->stream, d8);
   }
 
   // ---------------------------------------------------------------- one dependency level of group work
@@ -335,6 +366,18 @@ struct Table : mp_table {
     if (ph.n_v) {
       VarArgs a{w.D.p, w.T.p, w.J.p, ph.vjobs.p, ph.vterms.p, w.Bpad, nwin};
       MP_RUN(k_var_msm, C, B, ph.n_v, a);
+    }
+    if (ph.n_b) {   // large MSMs: bucket method, one wave per (proof, MSM, window)
+      const uint32_t bw = bk_windows(R::BITS);
+      if ((uint64_t)B * ph.n_bterms >= ((uint64_t)1 << 32)) throw std::runtime_error("bucket recode: batch too large for one launch");
+      BRecodeArgs ra{w.S.p, w.D8.p, ph.bterms.p, ph.bpos.p, w.Bpad, bw, ph.n_bterms, (size_t)w.d8_bytes};
+      MP_RUN(k_bucket_recode, C, B * ph.n_bterms, 1, ra);
+      BucketArgs ba{w.D8.p, w.P.p, w.J.p, ph.bjobs.p, ph.bterms.p, w.Bpad, bw, ph.n_b, (size_t)w.d8_bytes};
+      ctx->prof.begin("k_bucket_msm", ctx->stream);
+      MP_WAVE_LAUNCH(k_bucket_msm, C, ctx->stream, B * ph.n_b * bw, bk_lds_words(ph.b_kpad_max, XyzzWords<C>::N), ba);
+      ctx->prof.end(ctx->stream);
+      BFoldArgs fa{w.J.p, ph.bjobs.p, w.Bpad, bw};
+      MP_RUN(k_bucket_fold, C, B, ph.n_b, fa);
     }
     if (ph.n_c) {
       CombineArgs a{w.J.p, w.P.p, ph.cjobs.p, ph.cterms.p, w.Bpad};
@@ -532,7 +575,7 @@ struct Table : mp_table {
   void run_adhoc(Adhoc& ad, uint32_t B, uint32_t nS, uint32_t nP, uint32_t nJ) {
     ad.dev.upload(ad.ph, ctx->stream);
     ad.w.fw = G_::FW;
-    ad.w.ensure(B, nS, nP, nJ, ad.ph.n_dslots, ad.ph.n_tslots, nwin, 4, ctx->stream);
+    ad.w.ensure(B, nS, nP, nJ, ad.ph.n_dslots, ad.ph.n_tslots, nwin, 4, ctx->stream, ad.ph.b_dig_bytes);
   }
 
   void remask_host(size_t count, const uint8_t* cards, const uint8_t* rho, uint8_t* out) override {
@@ -571,7 +614,7 @@ struct Table : mp_table {
     Adhoc ad;
     uint32_t next_partial = K + 1;
     {
-      PhaseBuilder pb(ad.ph, next_partial, FCHUNK, VCHUNK);
+      PhaseBuilder pb(ad.ph, next_partial, FCHUNK, VCHUNK, bucket_min, bk_windows(R::BITS));
       pb.begin(K);
       for (uint32_t t = 0; t < K; ++t) pb.var(t, t);
       pb.end();
@@ -639,13 +682,17 @@ struct Table : mp_table {
 
   void plan_stats(uint64_t out[16]) override {
     for (int i = 0; i < 16; ++i) out[i] = 0;
+    uint64_t bucket_terms = 0, bucket_jobs = 0;
     auto add = [&](const Phase& ph, uint64_t* o) {
       o[0] += ph.fterms.size(); o[1] += ph.vterms.size(); o[2] += ph.fjobs.size(); o[3] += ph.vjobs.size();
       o[4] += ph.tables.size(); o[5] += ph.cterms.size() + ph.cterms2.size();
+      bucket_terms += ph.bterms.size();
+      bucket_jobs += ph.bjobs.size();
     };
     for (int i = 0; i < 5; ++i) add(ps[0].pplan.ph[i], out);
     add(merged_verify ? ps[0].vplan.mph : ps[0].vplan.ph, out + 6);    // what an honest batch executes
     out[12] = nwin; out[13] = fbg.windows; out[14] = N;
+    out[15] = bucket_terms | (bucket_jobs << 32);      // variable-base terms / MSMs on the bucket kernel (prove + verify)
   }
   // ---------------------------------------------------------------- sigma protocols
   void sigma_host(bool prove, size_t B_, uint32_t nb, const uint8_t* bases, const uint8_t* publics, const uint8_t* witness,
@@ -728,6 +775,9 @@ struct Table : mp_table {
       ops += (uint64_t)ph.vjobs.size() * (nwin - 1) * VB_WINDOW_BITS;       // doublings
       ops += (uint64_t)ph.tables.size() * (VB_ENTRIES - 1);                 // table construction (affine additions)
       ops += ph.cterms.size() + ph.cterms2.size();                          // combines
+      terms += ph.bterms.size();
+      ops += (uint64_t)ph.bterms.size() * bk_windows(R::BITS);              // bucket method: one mixed addition per term and window
+      ops += (uint64_t)ph.bjobs.size() * bk_windows(R::BITS) * (14 + BK_BITS + 1);   // wave-wide reduction + fold
     };
     uint64_t t = 0, o = 0;
     for (int i = 0; i < 5; ++i) count(ps[0].pplan.ph[i], t, o);

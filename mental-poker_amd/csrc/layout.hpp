@@ -30,6 +30,19 @@ struct Term {
   uint32_t s;  // fixed: S slot of the scalar        | var: digit slot        | combine: J slot or (AFF_FLAG | P slot)
   uint32_t b;  // fixed: index of the fixed base     | var: table slot        | combine: unused
 };
+// bucket-method MSM (kernels_bucket.hpp): one job = one large MSM; its terms are {S slot, P slot} in Phase::bterms
+struct BJob {
+  uint32_t out;        // J slot of the folded result
+  uint32_t win_first;  // J slots [win_first, win_first + windows): per-window results
+  uint32_t begin;      // first term
+  uint32_t count;      // number of terms K
+  uint32_t kpad;       // K rounded up to a multiple of 64
+  uint32_t dig_off;    // byte offset of the job's digits inside a proof's digit block (window w at + w * kpad)
+};
+struct BTermPos {
+  uint32_t pos;        // dig_off of the job + index of the term in the job
+  uint32_t kpad;
+};
 static const uint32_t AFF_FLAG = 0x80000000u;   // combine term: P (affine) slot instead of J slot
 static const uint32_t NEG_FLAG = 0x40000000u;   // combine term: subtract instead of add
 static const uint32_t SLOT_MASK = 0x3FFFFFFFu;
@@ -61,13 +74,19 @@ struct Phase {
   std::vector<Term> fterms, vterms, cterms, cterms2;
   std::vector<std::pair<uint32_t, uint32_t>> normalize;  // [first slot, count) J -> P
   uint32_t n_dslots = 0, n_tslots = 0;
+  std::vector<BJob> bjobs;    // MSMs large enough for the bucket method
+  std::vector<Term> bterms;   // {S slot, P slot}
+  std::vector<BTermPos> bpos;
+  uint32_t b_dig_bytes = 0;   // bytes of bucket digits per proof
+  uint32_t b_kpad_max = 0;
 };
 
 // Host-side builder: msm(out) { fixed(..) var(..) addend(..) } -> chunked sub-jobs + one combine job.
 class PhaseBuilder {
  public:
-  PhaseBuilder(Phase& ph, uint32_t& next_partial, uint32_t fchunk, uint32_t vchunk)
-      : ph_(ph), next_partial_(next_partial), fchunk_(fchunk), vchunk_(vchunk) {}
+  // bucket_min: MSMs with at least this many variable-base terms go to the bucket kernel (0 = never); bwin = its windows
+  PhaseBuilder(Phase& ph, uint32_t& next_partial, uint32_t fchunk, uint32_t vchunk, uint32_t bucket_min = 0, uint32_t bwin = 0)
+      : ph_(ph), next_partial_(next_partial), fchunk_(fchunk), vchunk_(vchunk), bucket_min_(bucket_min), bwin_(bwin) {}
   void begin(uint32_t out_slot) {
     out_ = out_slot;
     f_.clear();
@@ -75,10 +94,8 @@ class PhaseBuilder {
     a_.clear();
   }
   void fixed(uint32_t sslot, uint32_t base) { f_.push_back(Term{sslot, base}); }
-  void var(uint32_t sslot, uint32_t pslot) {
-    uint32_t d = dslot(sslot), t = tslot(pslot);
-    v_.push_back(Term{d, t});
-  }
+  // (digit / table slots are only created when the MSM is closed as a Straus job: a bucket job needs neither)
+  void var(uint32_t sslot, uint32_t pslot) { v_.push_back(Term{sslot, pslot}); }
   void addend(uint32_t pslot, bool negate = false) { a_.push_back(AFF_FLAG | (negate ? NEG_FLAG : 0u) | pslot); }
   // add (or subtract) a Jacobian result of this phase: the output of a fixed / var job, or -- when the consuming msm is
   // closed with end(late = true) -- the output of a first-stage combine job
@@ -90,9 +107,12 @@ class PhaseBuilder {
     // the one the split was meant to shorten -- cap the partials per MSM and kind.
     const size_t MAXP = 128;
     size_t fchunk_ = this->fchunk_, vchunk_ = this->vchunk_;
+    const bool bucket = bucket_min_ && v_.size() >= bucket_min_ && v_.size() < 32768;
+    if (!bucket)
+      for (Term& t : v_) t = Term{dslot(t.s), tslot(t.b)};
     if ((f_.size() + fchunk_ - 1) / fchunk_ > MAXP) fchunk_ = (f_.size() + MAXP - 1) / MAXP;
     if ((v_.size() + vchunk_ - 1) / vchunk_ > MAXP) vchunk_ = (v_.size() + MAXP - 1) / MAXP;
-    size_t nf = (f_.size() + fchunk_ - 1) / fchunk_, nv = (v_.size() + vchunk_ - 1) / vchunk_;
+    size_t nf = (f_.size() + fchunk_ - 1) / fchunk_, nv = bucket ? 1 : (v_.size() + vchunk_ - 1) / vchunk_;
     size_t pieces = nf + nv + a_.size();
     if (pieces == 0) throw std::logic_error("empty msm");
     bool direct = pieces == 1 && a_.empty();
@@ -104,7 +124,19 @@ class PhaseBuilder {
       ph_.fterms.insert(ph_.fterms.end(), f_.begin() + b, f_.begin() + e);
       parts.push_back(out);
     }
-    for (size_t c = 0; c < nv; ++c) {
+    if (bucket) {
+      const uint32_t out = direct ? out_ : next_partial_++;
+      const uint32_t kpad = (uint32_t)((v_.size() + 63) / 64 * 64);
+      BJob bj{out, next_partial_, (uint32_t)ph_.bterms.size(), (uint32_t)v_.size(), kpad, ph_.b_dig_bytes};
+      next_partial_ += bwin_;
+      for (size_t i = 0; i < v_.size(); ++i) ph_.bpos.push_back(BTermPos{ph_.b_dig_bytes + (uint32_t)i, kpad});
+      ph_.bterms.insert(ph_.bterms.end(), v_.begin(), v_.end());
+      ph_.b_dig_bytes += bwin_ * kpad;
+      ph_.b_kpad_max = std::max(ph_.b_kpad_max, kpad);
+      ph_.bjobs.push_back(bj);
+      parts.push_back(out);
+    }
+    for (size_t c = 0; !bucket && c < nv; ++c) {
       uint32_t out = direct ? out_ : next_partial_++;
       size_t b = c * vchunk_, e = std::min(v_.size(), b + vchunk_);
       ph_.vjobs.push_back(Job{out, (uint32_t)ph_.vterms.size(), (uint32_t)(e - b)});
@@ -142,7 +174,7 @@ class PhaseBuilder {
   }
   Phase& ph_;
   uint32_t& next_partial_;
-  uint32_t fchunk_, vchunk_;
+  uint32_t fchunk_, vchunk_, bucket_min_, bwin_;
   uint32_t out_ = 0;
   std::vector<Term> f_, v_;
   std::vector<uint32_t> a_;
@@ -377,7 +409,7 @@ static inline std::vector<KLeaf> k_merge(const std::vector<KLeaf>& in) {
 // keyed: the aggregate key is a per-proof point (P slot lay.pk) instead of the table's fixed base: its terms become
 // variable-base terms (the re-encryption uses the key's own window tables, kernels_msm.hpp body_remask)
 static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk, uint32_t point_bytes = 64,
-                                        bool keyed = false) {
+                                        bool keyed = false, uint32_t bucket_min = 0, uint32_t bwin = 0) {
   ProvePlan pl;
   pl.lay = make_prove_lay(m, n);
   pl.lay.toom = m == 2 ? 1u : 0u;
@@ -424,13 +456,13 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
     B.end();
   };
   {  // phase A: c_A (the re-encryption itself is the dedicated remask kernel)
-    PhaseBuilder B(pl.ph[0], next_partial, fchunk, vchunk);
+    PhaseBuilder B(pl.ph[0], next_partial, fchunk, vchunk, bucket_min, bwin);
     for (uint32_t k = 0; k < m; ++k) commit(B, l.cA + k, l.a + k * n, n, l.r + k);
     B.normalize(l.shuf, 2 * l.N);
     B.normalize(l.cA, m);
   }
   if (pl.lay.toom) {  // phase A2 (m = 2): D+ = C'_1 + C'_2, D- = C'_2 - C'_1 (affine + affine, then normalised)
-    PhaseBuilder B(pl.ph[4], next_partial, fchunk, vchunk);
+    PhaseBuilder B(pl.ph[4], next_partial, fchunk, vchunk, bucket_min, bwin);
     for (uint32_t t = 0; t < n; ++t)
       for (uint32_t c = 0; c < 2; ++c) {
         B.begin(l.tDp + 2 * t + c);
@@ -445,7 +477,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
     B.normalize(l.tDp, 4 * n);
   }
   if (karatsuba && l.nP > kP0) {  // phase A2 (m >= 3): sums of ciphertext rows used as Karatsuba operands
-    PhaseBuilder B(pl.ph[4], next_partial, fchunk, vchunk);
+    PhaseBuilder B(pl.ph[4], next_partial, fchunk, vchunk, bucket_min, bwin);
     for (auto& kv : cvec) {
       if (kv.first.size() == 1) continue;
       for (uint32_t t = 0; t < n; ++t)
@@ -458,7 +490,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
     B.normalize(kP0, l.nP - kP0);
   }
   {  // phase B: c_B, multi-exponentiation first message
-    PhaseBuilder B(pl.ph[1], next_partial, fchunk, vchunk);
+    PhaseBuilder B(pl.ph[1], next_partial, fchunk, vchunk, bucket_min, bwin);
     for (uint32_t k = 0; k < m; ++k) commit(B, l.cB + k, l.b + k * n, n, l.s + k);
     commit(B, l.mecA0, l.mea0, n, l.mer0);
     for (uint32_t k = 0; k < 2 * m; ++k) commit(B, l.mecB + k, l.meb + k, 1, l.mes + k);
@@ -547,7 +579,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
     B.normalize(l.mecA0, 1 + 2 * m + 4 * m);
   }
   {  // phase C: product-argument first messages that do not depend on later challenges
-    PhaseBuilder B(pl.ph[2], next_partial, fchunk, vchunk);
+    PhaseBuilder B(pl.ph[2], next_partial, fchunk, vchunk, bucket_min, bwin);
     commit(B, l.cb, l.bp + (m - 1) * n, n, l.sb);
     commit(B, l.hB + 0, l.dz, n, l.t);                       // = c_A[0] of the product statement (c_D0 + c_{-z})
     for (uint32_t i = 1; i + 1 < m; ++i) commit(B, l.hB + i, l.bp + i * n, n, l.hs + i);
@@ -559,7 +591,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
     B.normalize(l.svcd, 3);
   }
   {  // phase D: zero-argument first message
-    PhaseBuilder B(pl.ph[3], next_partial, fchunk, vchunk);
+    PhaseBuilder B(pl.ph[3], next_partial, fchunk, vchunk, bucket_min, bwin);
     commit(B, l.zcA0, l.za0, n, l.zr0);
     commit(B, l.zcBm, l.zbm, n, l.zsm);
     for (uint32_t k = 0; k < 2 * m + 1; ++k) commit(B, l.zcD + k, l.zd + k, 1, l.zt + k);
@@ -798,7 +830,7 @@ struct MergeSink {
 };
 
 static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk, uint32_t point_bytes = 64,
-                                          bool keyed = false) {
+                                          bool keyed = false, uint32_t bucket_min = 0, uint32_t bwin = 0) {
   VerifyPlan pl;
   pl.lay = make_verify_lay(m, n);
   const VerifyLay& l = pl.lay;
@@ -806,7 +838,7 @@ static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchun
   const VCoefMap& c = pl.cm;
   {
     uint32_t next_partial = l.chk_first + l.n_chk;
-    PhaseBuilder B(pl.ph, next_partial, fchunk, vchunk);
+    PhaseBuilder B(pl.ph, next_partial, fchunk, vchunk, bucket_min, bwin);
     PerCheckSink sink{B, l.chk_first};
     describe_verify(l, c, sink, keyed);
     pl.nJ = next_partial;
@@ -818,7 +850,7 @@ static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchun
     MergeSink ms{l.mr};
     describe_verify(l, c, ms, keyed);
     uint32_t next_partial = l.chk_first + l.n_chk;
-    PhaseBuilder B(pl.mph, next_partial, fchunk, vchunk);
+    PhaseBuilder B(pl.mph, next_partial, fchunk, vchunk, bucket_min, bwin);
     B.begin(l.chk_merged);
     auto job = [&](uint32_t dst, const std::vector<MergePair>& v) {
       pl.mjobs.push_back(MergeJob{dst, (uint32_t)pl.mpairs.size(), (uint32_t)v.size()});

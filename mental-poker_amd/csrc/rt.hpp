@@ -80,7 +80,6 @@ inline void host_free(void* p) {
 
 }  // namespace rt
 }  // namespace mp
-
 // A kernel is a body `void body(const Args&, uint32_t x, uint32_t y)` run once per (x, y) of a
 // (nx, ny) index space; x is the fast (lane) axis.  256-thread workgroups = 4 wave64.
 #define MP_KERNEL(NAME, ARGS, BODY)                                               \
@@ -97,6 +96,84 @@ inline void host_free(void* p) {
     uint32_t x = blockIdx.x * 256u + threadIdx.x;                                 \
     if (x < nx) BODY<C>(a, x, blockIdx.y);                                        \
   }
+
+// ---- wave-cooperative kernels: one 64-lane wave = one work item (kernels_bucket.hpp) ---------------------------------------
+// The body is written against a tiny execution interface so that the SAME source runs on the GPU (each lane executes the
+// lambda once, lanes talk through LDS and cross-lane shuffles) and in the development emulator (tools/hostemu: the lambda
+// runs for lane = 0..63 in turn between two sync points):
+//   wv.lanes([&](uint32_t lane) { ... })    per-lane code; state that lives across sections is a PerLane<T> indexed by lane
+//   wv.sync()                               LDS written before is visible to every lane of the wave afterwards
+//   wv.lds                                  this wave's slice of LDS (32-bit words)
+//   wv.atomic_add(p, v)                     LDS atomic, returns the old value
+//   wv.excl_scan(x) / wv.max(x)             wave-level exclusive prefix sum / maximum over a PerLane<uint32_t>
+namespace mp {
+template <class T>
+struct PerLane {
+  T v;
+  __device__ __forceinline__ T& operator[](uint32_t) { return v; }
+  __device__ __forceinline__ const T& operator[](uint32_t) const { return v; }
+};
+struct WaveCtx {
+  uint32_t lane;
+  uint32_t* lds;
+  template <class Fn>
+  __device__ __forceinline__ void lanes(Fn f) { f(lane); }
+  __device__ __forceinline__ void sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  __device__ __forceinline__ uint32_t atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+  // exclusive prefix sum across the 64 lanes (Hillis-Steele over DPP / ds_bpermute shuffles)
+  __device__ __forceinline__ void excl_scan(PerLane<uint32_t>& x) {
+    uint32_t incl = x.v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const uint32_t up = __shfl_up(incl, s, 64);
+      if (lane >= (uint32_t)s) incl += up;
+    }
+    x.v = incl - x.v;
+  }
+  __device__ __forceinline__ uint32_t max(const PerLane<uint32_t>& x) {
+    uint32_t m = x.v;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+      const uint32_t o = __shfl_xor(m, s, 64);
+      m = o > m ? o : m;
+    }
+    return m;
+  }
+  // does any lane of the wave hold a non-zero flag?  (wavefront ballot)
+  __device__ __forceinline__ bool any(const PerLane<uint32_t>& x) { return __ballot(x.v != 0) != 0; }
+};
+}  // namespace mp
+// a workgroup holds up to 4 waves (= 4 independent work items); `lds_words` 32-bit words of dynamic LDS per wave
+#define MP_WAVE_KERNEL(NAME, ARGS, BODY)                                                       \
+  template <class C>                                                                           \
+  MP_GLOBAL void __launch_bounds__(256, 2) NAME(ARGS a, uint32_t nwaves, uint32_t lds_words) { \
+    extern __shared__ uint32_t mp_dyn_lds[];                                                   \
+    const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                  \
+    if (wid >= nwaves) return;                                                                 \
+    mp::WaveCtx wv{threadIdx.x & 63u, mp_dyn_lds + (size_t)(threadIdx.x >> 6) * lds_words};    \
+    BODY<C>(a, wid, wv);                                                                       \
+  }
+#define MP_WAVE_KERNEL_INST(X, NAME, ARGS, C) X MP_GLOBAL void NAME<C>(ARGS, uint32_t, uint32_t);
+// waves per workgroup: as many (<= 4) as fit twice into the CU's 160 KB of LDS
+#define MP_WAVE_LAUNCH(NAME, C, stream, nwaves, lds_words, args)                                                              \
+  do {                                                                                                                        \
+    if ((nwaves) > 0) {                                                                                                       \
+      const size_t bytes_ = (size_t)(lds_words) * 4;                                                                          \
+      uint32_t wpb_ = 4;                                                                                                      \
+      while (wpb_ > 1 && wpb_ * bytes_ > 80u * 1024u) wpb_ >>= 1;                                                             \
+      if (wpb_ * bytes_ > 160u * 1024u) throw std::runtime_error(#NAME ": work item does not fit the LDS");                    \
+      if (wpb_ * bytes_ > 64u * 1024u)                                                                                        \
+        mp::rt::check(hipFuncSetAttribute(reinterpret_cast<const void*>(&NAME<C>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          (int)(wpb_ * bytes_)), "LDS size attribute");                                       \
+      hipLaunchKernelGGL((NAME<C>), dim3(((nwaves) + wpb_ - 1) / wpb_), dim3(64 * wpb_), wpb_ * bytes_, (stream), (args),      \
+                         (uint32_t)(nwaves), (uint32_t)(lds_words));                                                          \
+      mp::rt::launch_check(#NAME);                                                                                            \
+    }                                                                                                                         \
+  } while (0)
 
 // explicit instantiation / extern declaration of kernel NAME for curve C (X = `template` or `extern template`)
 #define MP_KERNEL_INST(X, NAME, ARGS, C) X MP_GLOBAL void NAME<C>(ARGS, uint32_t);

@@ -303,3 +303,55 @@ def test_points_outside_the_prime_order_subgroup_are_rejected(emu, native):
     with pytest.raises(native.canonical.SerializationError):
         native.canonical.point_decompress("bls12_377", comp)
     assert native.canonical.point_decompress("bls12_377", native.canonical.point_compress("bls12_377", pk)) == pk
+
+
+@pytest.mark.parametrize("name", ["shuffle_stark_m2_n26_s7.json", "shuffle_stark_m3_n4_s11.json", "shuffle_secp256k1_m3_n3_s5.json",
+                                  "shuffle_bls12_377_m2_n3_s13.json"])
+def test_bucket_method_kernel_under_emulation_matches_golden(emu, name):
+    """mp_set_bucket_min forces every variable-base MSM of >= 4 terms through the wave-cooperative bucket kernel
+    (kernels_bucket.hpp: LDS-staged digits, counting sort, two buckets per lane, wave-wide reduction): same bytes, same verdicts"""
+    g = load_json(os.path.join(GOLDEN, name))
+    eng = emu(g["curve"])
+    m, n = g["m"], g["n"]
+    t = eng.table(m, n, bytes.fromhex(g["params"]), bytes.fromhex(g["pk"]))
+    t.set_bucket_min(4)
+    for latency_batch, merged in (((0, True),) if n > 8 else ((0, True), (0, False), (8192, True))):
+        t.set_latency_batch(latency_batch)
+        t.set_merged_verify(merged)
+        eng.profile_enable(True)
+        deck, proof = t.shuffle_and_remask(bytes.fromhex(g["deck"]), bytes.fromhex(g["rho"]), g["perm"], bytes.fromhex(g["prover_seed"]))
+        assert deck.hex() == g["shuffled"] and proof.hex() == g["proof"]
+        assert t.verify_shuffle(bytes.fromhex(g["deck"]), deck, proof) == 0
+        bad = bytearray(proof)
+        bad[-1] ^= 1
+        assert t.verify_shuffle(bytes.fromhex(g["deck"]), deck, bytes(bad)) != 0
+        rep = eng.profile_report()
+        eng.profile_enable(False)
+        assert rep["k_bucket_msm"][0] >= 2 and "k_bucket_fold" in rep and "k_bucket_recode" in rep
+        if m == 2 and latency_batch == 0 and merged:
+            assert "k_var_msm" not in rep or rep["k_var_msm"][0] < rep["k_bucket_msm"][0] + 3
+
+
+def test_bucket_msm_edge_scalars_under_emulation(emu, coracle):
+    """0, 1, q - 1, +-128 boundaries of the signed 8-bit recoding, repeated and opposite points, the point at infinity"""
+    import random
+    cvn = "stark"
+    q = 0x0800000000000010ffffffffffffffffb781126dcae7b2321e66a241adc64d2f
+    eng = emu(cvn)
+    gi = coracle.gen_inputs(cvn, 2, 3, 5)
+    t = eng.table(2, 3, gi["params"], gi["pk"])
+    t.set_bucket_min(16)
+    random.seed(4)
+    K = 150
+    pts = bytearray(eng.setup(2, K - 3, bytes([9] * 32)))
+    pts[64 * 7:64 * 8] = pts[64 * 6:64 * 7]            # the same point twice
+    pts[64 * 9:64 * 10] = bytes(64)                    # infinity
+    sc = [random.randrange(q) for _ in range(K)]
+    sc[0:12] = [0, 1, q - 1, 128, 127, 129, 2 ** 248, 2 ** 251, 255, 256 * 128, q - 128, q - 129]
+    sc[6], sc[7] = 5, q - 5                            # P and -P cancel inside one bucket
+    scb = b"".join(s.to_bytes(32, "little") for s in sc)
+    assert t.msm(1, K, scb, bytes(pts)) == coracle.msm(cvn, scb, bytes(pts))
+    same = b"".join((77).to_bytes(32, "little") for _ in range(K))      # every term in ONE bucket of one window
+    assert t.msm(1, K, same, bytes(pts)) == coracle.msm(cvn, same, bytes(pts))
+    zero = bytes(32 * K)
+    assert t.msm(1, K, zero, bytes(pts)) == bytes(64)

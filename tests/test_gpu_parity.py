@@ -7,6 +7,7 @@ fixed vectors, edge inputs, tamper cases per check, usage errors, batch-position
 full-size round trips."""
 import copy
 import os
+import random
 
 import pytest
 
@@ -506,3 +507,60 @@ def test_full_size_properties(mp, engines, coracle):
             cards.verify_shuffle(pp, g["pk"], deck if j else nxt, nxt if j else cur, proof)
         cur = nxt
     cards.table(pp, g["pk"]).set_latency_batch(8192)
+
+
+# ---- the bucket-method kernel (kernels_bucket.hpp): large MSMs run on it by default (>= 2048 terms: the merged verifier
+# equation of the 1024-card shapes in test_baseline_config_shapes); here it is forced onto small shapes and exercised directly
+@pytest.mark.parametrize("curve,m,n,B", [("stark", 2, 26, 70), ("stark", 4, 13, 5), ("secp256k1", 2, 7, 3), ("bls12_377", 2, 5, 3)])
+def test_bucket_kernel_matches_oracle(mp, coracle, curve, m, n, B):
+    cards = mp.DLCards(curve, device=0)
+    g0 = coracle.gen_inputs(curve, m, n, 100)
+    pp, pk = mp.Parameters(m, n, g0["params"]), g0["pk"]
+    t = cards.table(pp, pk)
+    t.set_bucket_min(4)
+    t.set_latency_batch(0)
+    cards.engine.profile_enable(True)
+    ins = [coracle.gen_inputs(curve, m, n, 900 + b) for b in range(B)]
+    cb = 2 * cards.engine.point_bytes
+    res = cards.shuffle_and_remask_batch([g["prover_seed"] for g in ins], pp, pk, [_split(g["deck"], cb) for g in ins],
+                                         [[int.from_bytes(x, "little") for x in _split(g["rho"], 32)] for g in ins],
+                                         [mp.Permutation(g["perm"]) for g in ins])
+    decks, shufs, proofs = [], [], []
+    for i, (g, r) in enumerate(zip(ins, res)):
+        assert not isinstance(r, Exception), r
+        if i < 4:
+            exp_deck, exp_proof = coracle.shuffle_and_remask(curve, m, n, g0["params"], pk, g["deck"], g["rho"], g["perm"], g["prover_seed"])
+            assert b"".join(r[0]) == exp_deck and r[1] == exp_proof
+        decks.append(_split(g["deck"], cb)); shufs.append(r[0]); proofs.append(r[1])
+    for merged in (True, False):
+        t.set_merged_verify(merged)
+        assert cards.verify_shuffle_batch(pp, pk, decks, shufs, proofs) == [None] * B
+        out = cards.verify_shuffle_batch(pp, pk, decks, shufs[1:] + shufs[:1], proofs)
+        assert all(o == mp.CryptoError("Hadamard Product (5.1)") for o in out)
+    rep = cards.engine.profile_report()
+    assert rep["k_bucket_msm"][0] >= 3
+
+
+def test_bucket_msm_large_and_edge_scalars(mp, coracle):
+    cv = "stark"
+    q = 0x0800000000000010ffffffffffffffffb781126dcae7b2321e66a241adc64d2f
+    eng = mp.Engine(cv, device=0)
+    gi = coracle.gen_inputs(cv, 2, 3, 5)
+    t = eng.table(2, 3, gi["params"], gi["pk"])
+    rnd = random.Random(11)
+    for K, n_msm in ((2500, 3), (4193, 2), (150, 5)):
+        t.set_bucket_min(2048 if K > 2048 else 16)
+        pts = bytearray(eng.setup(2, K - 3, bytes([9] * 32)))
+        pts[64 * 7:64 * 8] = pts[64 * 6:64 * 7]
+        pts[64 * 9:64 * 10] = bytes(64)
+        sc, allp = b"", b""
+        for j in range(n_msm):
+            s = [rnd.randrange(q) for _ in range(K)]
+            s[0:12] = [0, 1, q - 1, 128, 127, 129, 2 ** 248, 2 ** 251, 255, 256 * 128, q - 128, q - 129]
+            if j == 1:
+                s = [77] * K                      # every term of every window in one bucket
+            sc += b"".join(v.to_bytes(32, "little") for v in s)
+            allp += bytes(pts)
+        got = t.msm(n_msm, K, sc, allp)
+        for j in range(n_msm):
+            assert got[64 * j:64 * j + 64] == coracle.msm(cv, sc[32 * K * j:32 * K * (j + 1)], bytes(pts)), (K, j)

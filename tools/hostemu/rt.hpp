@@ -65,6 +65,60 @@ inline void host_free(void* p) { free(p); }
     }                                                       \
   }
 #define MP_KERNEL_OCC(NAME, ARGS, BODY, WAVES) MP_KERNEL(NAME, ARGS, BODY)
+
+// wave-cooperative kernels (see the product rt.hpp): the 64 lanes of a wave run one after the other between sync points
+#include <vector>
+namespace mp {
+template <class T>
+struct PerLane {
+  T v[64];
+  T& operator[](uint32_t l) { return v[l]; }
+  const T& operator[](uint32_t l) const { return v[l]; }
+};
+struct WaveCtx {
+  uint32_t* lds;
+  template <class Fn>
+  void lanes(Fn f) {
+    for (uint32_t l = 0; l < 64; ++l) f(l);
+  }
+  void sync() {}
+  uint32_t atomic_add(uint32_t* p, uint32_t v) {
+    const uint32_t old = *p;
+    *p = old + v;
+    return old;
+  }
+  void excl_scan(PerLane<uint32_t>& x) {
+    uint32_t run = 0;
+    for (uint32_t l = 0; l < 64; ++l) {
+      const uint32_t t = x.v[l];
+      x.v[l] = run;
+      run += t;
+    }
+  }
+  uint32_t max(const PerLane<uint32_t>& x) {
+    uint32_t m = 0;
+    for (uint32_t l = 0; l < 64; ++l) m = x.v[l] > m ? x.v[l] : m;
+    return m;
+  }
+  bool any(const PerLane<uint32_t>& x) {
+    for (uint32_t l = 0; l < 64; ++l)
+      if (x.v[l]) return true;
+    return false;
+  }
+};
+}  // namespace mp
+#define MP_WAVE_KERNEL(NAME, ARGS, BODY)                                   \
+  template <class C>                                                       \
+  void NAME(const ARGS& a, uint32_t nwaves, uint32_t lds_words) {          \
+    _Pragma("omp parallel for schedule(dynamic, 1)")                       \
+    for (uint32_t wid = 0; wid < nwaves; ++wid) {                          \
+      std::vector<uint32_t> lds(lds_words);                                \
+      mp::WaveCtx wv{lds.data()};                                          \
+      BODY<C>(a, wid, wv);                                                 \
+    }                                                                      \
+  }
+#define MP_WAVE_KERNEL_INST(X, NAME, ARGS, C) X void NAME<C>(const ARGS&, uint32_t, uint32_t);
+#define MP_WAVE_LAUNCH(NAME, C, stream, nwaves, lds_words, args) NAME<C>((args), (uint32_t)(nwaves), (uint32_t)(lds_words))
 // explicit instantiation / extern declaration of kernel NAME for curve C (X = `template` or `extern template`)
 #define MP_KERNEL_INST(X, NAME, ARGS, C) X void NAME<C>(const ARGS&, uint32_t, uint32_t);
 #define MP_LAUNCH(NAME, C, stream, nx, ny, args) NAME<C>((args), (uint32_t)(nx), (uint32_t)(ny))
