@@ -167,7 +167,7 @@ MP_HD void reduce_carry29(int32_t s[9], uint32_t out[9]) {
   q = q < 0 ? 0 : q;
 #pragma unroll
   for (int i = 0; i < 9; ++i)
-    if (P::MOD29[i] != 0) s[i] -= q * (int32_t)P::MOD29[i];
+    if (P::SMOD29[i] != 0) s[i] -= q * P::SMOD29[i];
   carry29(s, out);
 }
 // bring a lazily reduced value (< 8p, normalised limbs) to the canonical residue in [0, p)
@@ -176,14 +176,27 @@ MP_HD void canonical29(const uint32_t a[9], uint32_t out[9]) {
   int32_t s[9];
   const int32_t q = (int32_t)(a[8] >> P::TOP29);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) s[i] = (int32_t)a[i] - (P::MOD29[i] != 0 ? q * (int32_t)P::MOD29[i] : 0);
+  for (int i = 0; i < 9; ++i) s[i] = (int32_t)a[i] - (P::SMOD29[i] != 0 ? q * P::SMOD29[i] : 0);
   uint32_t t[9];
   carry29(s, t);
-  // now in (-p, p): add p back if negative
+  // now in (-p, p) (pseudo-Mersenne p = 2^256 - c: in [0, p + 8c)): add p back if negative
   const int32_t neg = (int32_t)t[8] < 0 ? 1 : 0;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) s[i] = (int32_t)t[i] + (P::MOD29[i] != 0 ? neg * (int32_t)P::MOD29[i] : 0);
+  for (int i = 0; i < 9; ++i) s[i] = (int32_t)t[i] + (P::SMOD29[i] != 0 ? neg * P::SMOD29[i] : 0);
   carry29(s, out);
+  if constexpr (P::PM29) {
+    // 2^256 > p: the remainder below 2^256 may still be >= p.  t >= p  <=>  t + c >= 2^256
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s[i] = (int32_t)out[i];
+    s[0] += (int32_t)P::G0;
+    s[1] += (int32_t)P::G1;
+    uint32_t u[9];
+    carry29(s, u);
+    const bool ge = (u[8] >> 24) != 0;
+    u[8] &= 0x00FFFFFFu;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out[i] = ge ? u[i] : out[i];
+  }
 }
 MP_HD void pack29(const uint32_t l[9], uint32_t w[8]) {
 #pragma unroll
@@ -212,6 +225,7 @@ MP_HD void unpack29(const uint32_t w[8], uint32_t l[9]) {
 // (mad addend = running accumulator); without it LLVM rebuilds independent column sums and adds the carries separately.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MP_CHAIN(x) asm("" : "+v"(x))
+#define MP_OPAQUE(x) asm("" : "+v"(x))      // stops LLVM from re-deriving x's shifted copies with further multiplies
 MP_HD void mont_sub_step(uint64_t& acc, uint32_t m, uint32_t pj) {
   uint32_t negp = 0u - pj;
   asm("" : "+s"(negp));   // keeps it a v_mad_i64_i32 (one instruction) instead of a multiply/shift and a 64-bit subtract
@@ -219,8 +233,22 @@ MP_HD void mont_sub_step(uint64_t& acc, uint32_t m, uint32_t pj) {
 }
 #else
 #define MP_CHAIN(x) ((void)0)
-MP_HD void mont_sub_step(uint64_t& acc, uint32_t m, uint32_t pj) { acc -= (uint64_t)m * pj; }
+#define MP_OPAQUE(x) ((void)0)
+MP_HD void mont_sub_step(uint64_t& acc, uint32_t m, uint32_t pj) { acc -= (uint64_t)((int64_t)m * (int64_t)(int32_t)pj); }
 #endif
+// acc -= m * pj for a limb pj of the (signed sparse) modulus.  Pseudo-Mersenne primes have pj = +-2^s there: a 64-bit shift
+// and add / subtract instead of a multiply-add keeps the product at the 99 multiply-adds of the sparse STARK prime
+// (81 limb products + m_k = acc p^-1 + m_k p_0 per column).
+template <class P>
+MP_HD void mont_sub_limb(uint64_t& acc, uint32_t m, int32_t pj) {
+  if (P::PM29 && pj > 0 && (pj & (pj - 1)) == 0) {
+    acc -= (uint64_t)m << __builtin_ctz((unsigned)pj);
+  } else if (P::PM29 && pj < 0 && ((-pj) & (-pj - 1)) == 0) {
+    acc += (uint64_t)m << __builtin_ctz((unsigned)(-pj));
+  } else {
+    mont_sub_step(acc, m, (uint32_t)pj);      // one v_mad_i64_i32 with the constant -pj (either sign)
+  }
+}
 template <class P, bool SQR>
 MP_HD void mont29(uint32_t r[9], const uint32_t a[9], const uint32_t b[9]) {
   constexpr uint32_t PINV = (0u - P::INV29) & M29;   // +p^-1 mod 2^29
@@ -248,21 +276,22 @@ MP_HD void mont29(uint32_t r[9], const uint32_t a[9], const uint32_t b[9]) {
     for (int i = 0; i < 9; ++i) {
       const int j = k - i;
       if (j < 1 || j > 8 || i >= k) continue;
-      if (P::MOD29[j] != 0) {
-        mont_sub_step(acc, m[i], P::MOD29[j]);
+      if (P::SMOD29[j] != 0) {
+        mont_sub_limb<P>(acc, m[i], P::SMOD29[j]);
         MP_CHAIN(acc);
       }
     }
-    if (k >= 9 && P::MOD29[k - 9] != 0) acc += P::MOD29[k - 9];   // + R p (limbs 0..7; limb 8 below)
+    if (k >= 9 && P::SMOD29[k - 9] != 0) acc += (uint64_t)(int64_t)P::SMOD29[k - 9];   // + R p (limbs 0..7; limb 8 below)
     if (k < 9) {
       m[k] = ((uint32_t)acc * PINV) & M29;
-      if (P::MOD29[0] != 1) acc -= (uint64_t)m[k] * P::MOD29[0];
+      if (P::PM29) MP_OPAQUE(m[k]);
+      if (P::SMOD29[0] != 1) mont_sub_limb<P>(acc, m[k], P::SMOD29[0]);
     } else {
       r[k - 9] = (uint32_t)acc & M29;
     }
     acc = (uint64_t)((int64_t)acc >> 29);
   }
-  r[8] = (uint32_t)acc + P::MOD29[8];
+  r[8] = (uint32_t)acc + (uint32_t)P::SMOD29[8];
 }
 template <class P>
 MP_HD void mul29(uint32_t r[9], const uint32_t a[9], const uint32_t b[9]) {
@@ -290,21 +319,22 @@ MP_HD void muladd29(uint32_t r[9], const uint32_t a[9], const uint32_t b[9], con
     for (int i = 0; i < 9; ++i) {
       const int j = k - i;
       if (j < 1 || j > 8 || i >= k) continue;
-      if (P::MOD29[j] != 0) {
-        mont_sub_step(acc, m[i], P::MOD29[j]);
+      if (P::SMOD29[j] != 0) {
+        mont_sub_limb<P>(acc, m[i], P::SMOD29[j]);
         MP_CHAIN(acc);
       }
     }
-    if (k >= 9 && P::MOD29[k - 9] != 0) acc += P::MOD29[k - 9];
+    if (k >= 9 && P::SMOD29[k - 9] != 0) acc += (uint64_t)(int64_t)P::SMOD29[k - 9];
     if (k < 9) {
       m[k] = ((uint32_t)acc * PINV) & M29;
-      if (P::MOD29[0] != 1) acc -= (uint64_t)m[k] * P::MOD29[0];
+      if (P::PM29) MP_OPAQUE(m[k]);
+      if (P::SMOD29[0] != 1) mont_sub_limb<P>(acc, m[k], P::SMOD29[0]);
     } else {
       r[k - 9] = (uint32_t)acc & M29;
     }
     acc = (uint64_t)((int64_t)acc >> 29);
   }
-  r[8] = (uint32_t)acc + P::MOD29[8];
+  r[8] = (uint32_t)acc + (uint32_t)P::SMOD29[8];
 }
 template <class P>
 MP_HD void sqr29(uint32_t r[9], const uint32_t a[9]) {
@@ -336,7 +366,20 @@ MP_HD Fe<P> fe_one() {
 // a == 0 (mod p)
 template <class P>
 MP_HD bool fe_is_zero(const Fe<P>& a) {
-  if constexpr (P::L29) {
+  if constexpr (P::PM29) {
+    // a is one of 0, p, 2p, 3p; k p = k 2^256 - k c has the limbs (2^29 - k G0, 2^29 - 1 - k G1, 2^29 - 1, ..., k 2^24 - 1)
+    const uint32_t k = (a.v[8] + 1u) >> 24;
+    if (k == 0) {
+      uint32_t o = 0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) o |= a.v[i];
+      return o == 0;
+    }
+    uint32_t o = (a.v[0] ^ ((1u << 29) - k * P::G0)) | (a.v[1] ^ (M29 - k * P::G1)) | (a.v[8] ^ ((k << 24) - 1u));
+#pragma unroll
+    for (int i = 2; i < 8; ++i) o |= a.v[i] ^ M29;
+    return o == 0;
+  } else if constexpr (P::L29) {
     // lazily reduced: a is one of 0, p, 2p, ... ; the limbs of k*p are k*MOD29[i] (no carries: sparse p).
     // Fast path: where p has a zero limb, so has k*p -- almost every non-zero value is rejected by one OR chain.
     uint32_t z = 0;
@@ -384,7 +427,7 @@ MP_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
     // a - b + 4p in (0, 8p)
     int32_t s[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) s[i] = (int32_t)a.v[i] - (int32_t)b.v[i] + 4 * (int32_t)P::MOD29[i];
+    for (int i = 0; i < 9; ++i) s[i] = (int32_t)a.v[i] - (int32_t)b.v[i] + 4 * P::SMOD29[i];
     reduce_carry29<P>(s, r.v);
   } else {
     uint32_t d[P::NW];

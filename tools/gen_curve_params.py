@@ -47,20 +47,49 @@ def is_l29(p):
     return top & (top - 1) == 0 and l[7] == 0 and all(x * 64 < (1 << 29) for x in l[:8])
 
 
+def is_pm29(p):
+    """pseudo-Mersenne prime 2^256 - c with a small c (secp256k1: c = 2^32 + 977 = G0 + G1 2^29): 9x29-bit lazy Montgomery limbs
+    like the sparse primes, with p written in SIGNED sparse limbs (-G0, -G1, 0, ..., 0, 2^24) (field.hpp)"""
+    return p.bit_length() == 256 and (1 << 256) - p < (1 << 40)
+
+
+def field_R(p):
+    """the Montgomery constant R of the in-memory residue a R mod p"""
+    return 1 << (261 if (is_l29(p) or is_pm29(p)) else 32 * nwords(p))
+
+
+def slimbs29(v):
+    return "{" + ", ".join(str(x) for x in v) + "}"
+
+
 def field(name, p):
     inv = (-pow(p, -1, 1 << 32)) % (1 << 32)
     l29 = is_l29(p)
+    pm = is_pm29(p)
     nw = nwords(p)
-    R = 1 << (261 if l29 else 32 * nw)
+    R = field_R(p)
     s = "struct %s {\n" % name
     s += "  static constexpr int NW = %d;                 // packed 32-bit words of an element in memory (and limbs of the 32-bit form)\n" % nw
-    s += "  static constexpr bool L29 = %s;             // 9x29-bit lazy limbs (R = 2^261) instead of 8x32 (R = 2^256)\n" % ("true" if l29 else "false")
+    s += "  static constexpr bool L29 = %s;             // 9x29-bit lazy limbs (R = 2^261) instead of 8x32 (R = 2^256)\n" % ("true" if (l29 or pm) else "false")
+    s += "  static constexpr bool PM29 = %s;            // ... for a pseudo-Mersenne prime 2^256 - c: signed sparse limbs of p (SMOD29)\n" % ("true" if pm else "false")
+    if pm:
+        c = (1 << 256) - p
+        l29 = True
+        s += "  static constexpr uint32_t G0 = %du, G1 = %du;     // c = G0 + G1 2^29: p = 2^256 - c\n" % (c & ((1 << 29) - 1), c >> 29)
+        assert (c >> 29) < 16
     if l29:
         s += "  static constexpr uint32_t MOD29[9] = %s;\n" % limbs29(p)
+        if pm:
+            c = (1 << 256) - p
+            sm = [-(c & ((1 << 29) - 1)), -(c >> 29), 0, 0, 0, 0, 0, 0, 1 << 24]
+        else:
+            sm = [(p >> (29 * i)) & ((1 << 29) - 1 if i < 8 else 0xFFFFFFFF) for i in range(9)]
+        assert sum(x << (29 * i) for i, x in enumerate(sm)) == p
+        s += "  static constexpr int32_t SMOD29[9] = %s;   // p as signed sparse 29-bit limbs: sum SMOD29[i] 2^(29 i) = p\n" % slimbs29(sm)
         s += "  static constexpr uint32_t R1_29[9] = %s;   // R mod p, 29-bit limbs\n" % limbs29(R % p)
         s += "  static constexpr uint32_t R2_29[9] = %s;   // R^2 mod p, 29-bit limbs\n" % limbs29(R * R % p)
         s += "  static constexpr uint32_t INV29 = 0x%08xu;   // -p^{-1} mod 2^29\n" % ((-pow(p, -1, 1 << 29)) % (1 << 29))
-        s += "  static constexpr int TOP29 = %d;             // p's top limb is 2^TOP29\n" % (((p >> 232)).bit_length() - 1)
+        s += "  static constexpr int TOP29 = %d;             // p's top (signed) limb is 2^TOP29\n" % (24 if pm else ((p >> 232)).bit_length() - 1)
     s += "  static constexpr uint32_t MOD[%d] = %s;\n" % (nw, limbs(p, nw))
     s += "  static constexpr uint32_t R1[%d] = %s;   // R mod p\n" % (nw, limbs(R % p, nw))
     s += "  static constexpr uint32_t R2[%d] = %s;   // R^2 mod p\n" % (nw, limbs(R * R % p, nw))
@@ -75,7 +104,7 @@ def field(name, p):
 out = ["// GENERATED by tools/gen_curve_params.py -- do not edit.  Constants: SURVEY.md App. C.",
        "#pragma once", "#include <cstdint>", "namespace mp {", ""]
 for (nm, cid, p, a, b, q, gx, gy) in CURVES:
-    RQ = 1 << (261 if is_l29(p) else 32 * nwords(p))
+    RQ = field_R(p)
     nw = nwords(p)
     out.append(field(nm + "Fq", p))
     out.append(field(nm + "Fr", q))
