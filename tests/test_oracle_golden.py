@@ -199,3 +199,44 @@ def test_sigma_oracles_agree(coracle):
             bad[-1] ^= 1
             assert coracle.CHECK_NAMES_ALL[coracle.sigma_verify(cvn, nb, gb, ab, bytes(bad), fs_init)] == po.SIGMA_NAMES[nb]
             assert coracle.sigma_verify(cvn, nb, gb, ab, got, fs_init + b"x") != 0
+
+
+# ---- published vectors for the two primitives under the transcript (RFC 7693 BLAKE2s, RFC 7539 / rand_chacha ChaCha20) -----------
+RFC7693_ABC = "508c5e8c327c14e2e1a72ba34eeb452f37458b209ed63a294d999b4c86675982"        # RFC 7693 Appendix B: BLAKE2s-256("abc")
+BLAKE2S_EMPTY = "69217a3079908094e11121d042354a7c1f55b6482ca1a51e1b250dfd1ed0eef9"      # BLAKE2s-256("")
+# rand_chacha `test_chacha_true_values_a` (ChaCha20Rng::from_seed([0; 32]), the first 32 next_u32 results) = RFC 7539 A.1 vectors
+# #1 and #2: the zero-key keystream blocks 0 and 1
+CHACHA20_ZERO_SEED_U32 = [
+    0xade0b876, 0x903df1a0, 0xe56a5d40, 0x28bd8653, 0xb819d2bd, 0x1aed8da0, 0xccef36a8, 0xc70d778b,
+    0x7c5941da, 0x8d485751, 0x3fe02477, 0x374ad8b8, 0xf4b8436a, 0x1ca11815, 0x69b687c3, 0x8665eeb2,
+    0xbee7079f, 0x7a385155, 0x7c97ba98, 0x0d082d73, 0xa0290fcb, 0x6965e348, 0x3e53c612, 0xed7aee32,
+    0x7621b729, 0x434ee69c, 0xb03371d5, 0xd539d874, 0x281fed31, 0x45fb0a51, 0x1f0ae1ac, 0x6f4d794b]
+
+
+def test_published_blake2s_vectors(coracle, mp):
+    for msg, exp in ((b"abc", RFC7693_ABC), (b"", BLAKE2S_EMPTY)):
+        assert po.blake2s(msg).hex() == exp
+        assert coracle.blake2s(msg).hex() == exp
+    # multi-block input: both restatements against hashlib (which carries the reference implementation of RFC 7693)
+    import hashlib
+    for n in (63, 64, 65, 127, 128, 129, 1000):
+        msg = bytes((7 * i + 3) & 0xFF for i in range(n))
+        assert coracle.blake2s(msg) == hashlib.blake2s(msg).digest() == po.blake2s(msg)
+    # the engine's own host helper (include/mpshuffle.h mp_blake2s): callable without a device
+    import ctypes
+    lib = mp.load()
+    for msg, exp in ((b"abc", RFC7693_ABC), (b"Shuffle Proof", "99df86eeefd21867b5ea2a0194c5e8dd819aa01221dcdcbc5ff6b16f9303b656")):
+        out = (ctypes.c_uint8 * 32)()
+        assert lib.mp_blake2s((ctypes.c_uint8 * len(msg)).from_buffer_copy(msg), len(msg), out) == 0
+        assert bytes(out).hex() == exp
+
+
+def test_published_chacha20rng_vectors(coracle, mp):
+    r = po.ChaCha20Rng(bytes(32))
+    assert [r.next_u32() for _ in range(32)] == CHACHA20_ZERO_SEED_U32
+    r = po.ChaCha20Rng(bytes(32))
+    w = CHACHA20_ZERO_SEED_U32
+    assert [r.next_u64() for _ in range(16)] == [w[2 * i] | (w[2 * i + 1] << 32) for i in range(16)]   # BlockRng: low word first
+    assert coracle.chacha20_block(bytes(32), 0) == w[:16] and coracle.chacha20_block(bytes(32), 1) == w[16:]
+    m = mp.ChaCha20Rng(bytes(32))                    # the host mirror used by protocol.py
+    assert [m.next_u64() for _ in range(16)] == [w[2 * i] | (w[2 * i + 1] << 32) for i in range(16)]
