@@ -95,6 +95,21 @@ class DLCardsT {
     if (rc < 0) throw CardProtocolError(mp_last_error());
   }
 
+  // CanonicalSerialize / CanonicalDeserialize of ZKProofShuffle and `proof.serialized_size()`
+  // [REF src/lib.rs:71; examples/parameter_selection.rs:95]
+  size_t serialized_size(const Parameters& pp) const { return mp_serialized_proof_size(curve_, pp.m, pp.n); }
+  std::vector<uint8_t> serialize(const Parameters& pp, const ZKProofShuffle& proof) const {
+    std::vector<uint8_t> out(serialized_size(pp));
+    if (proof.size() != mp_proof_size_curve(curve_, pp.m, pp.n) || mp_proof_serialize(curve_, pp.m, pp.n, proof.data(), out.data()) != MP_OK)
+      throw CardProtocolError(mp_last_error());
+    return out;
+  }
+  ZKProofShuffle deserialize_proof(const Parameters& pp, const std::vector<uint8_t>& bytes) const {
+    ZKProofShuffle proof(mp_proof_size_curve(curve_, pp.m, pp.n));
+    if (mp_proof_deserialize(curve_, pp.m, pp.n, bytes.data(), bytes.size(), proof.data()) != MP_OK) throw CardProtocolError(mp_last_error());
+    return proof;
+  }
+
   mp_table* table() const { return table_; }   // for the batched / device-resident entry points of mpshuffle.h
 
  private:

@@ -175,6 +175,29 @@ int mp_sigma_verify_batch(mp_table* t, size_t B, uint32_t nbases, const uint8_t*
                           const uint8_t* proofs, const uint8_t* fs_init, int32_t* status);
 int mp_blake2s(const uint8_t* in, size_t len, uint8_t out[32]);   /* host helper: BLAKE2s-256 */
 
+/* ---- canonical serialisation (arkworks-0.3 `CanonicalSerialize` / `CanonicalDeserialize`, compressed) ----------------------
+ * Every associated type of the trait is CanonicalSerialize + CanonicalDeserialize [REF src/lib.rs:45-71], and the reference's
+ * harness measures `proof.serialized_size()` [REF examples/parameter_selection.rs:95]: these are the conversions between those
+ * byte strings and the engine's wire v1.  Host work (no context, no GPU); deserialisation validates like ark-ec (canonical x, x on
+ * the curve, prime-order subgroup on curves with a cofactor, scalars < q) and costs one square root per point.
+ *   Fr 32 B LE | point: x LE in ceil((bits+2)/8) bytes, bit 7 of the last byte = (y > -y), bit 6 = infinity | Vec<T>: u64 LE length
+ *   MaskedCard = 2 points; deck = Vec<MaskedCard>; Parameters { m, n, enc { G }, commit { Vec ck, H }, gen } [REF mod.rs:37-43];
+ *   proof: elements in wire-v1 order, one Vec per vector-valued element (upstream's struct lives in the un-vendored dependency,
+ *   so sizes are exact for this grouping; byte-compatibility with upstream's layout is not claimed).
+ * Sizes: caller allocates; errors: MP_ERR_BAD_ENCODING (invalid data) / MP_ERR_BAD_ARGUMENT. */
+size_t mp_serialized_point_size(int curve_id);                               /* 32 (STARK, bn254), 33 (secp256k1), 48 (BLS12-377) */
+size_t mp_serialized_deck_size(int curve_id, size_t cards);
+size_t mp_serialized_params_size(int curve_id, uint32_t n);
+size_t mp_serialized_proof_size(int curve_id, uint32_t m, uint32_t n);      /* = ZKProofShuffle::serialized_size() */
+int mp_points_serialize(int curve_id, size_t count, const uint8_t* wire_points, uint8_t* out);
+int mp_points_deserialize(int curve_id, size_t count, const uint8_t* data, uint8_t* out_wire_points);
+int mp_deck_serialize(int curve_id, size_t cards, const uint8_t* wire_deck, uint8_t* out);
+int mp_deck_deserialize(int curve_id, const uint8_t* data, size_t len, size_t max_cards, uint8_t* out_wire_deck, size_t* out_cards);
+int mp_params_serialize(int curve_id, uint32_t m, uint32_t n, const uint8_t* raw_params, uint8_t* out);
+int mp_params_deserialize(int curve_id, const uint8_t* data, size_t len, size_t max_n, uint32_t* m, uint32_t* n, uint8_t* out_raw_params);
+int mp_proof_serialize(int curve_id, uint32_t m, uint32_t n, const uint8_t* proof_wire, uint8_t* out);
+int mp_proof_deserialize(int curve_id, uint32_t m, uint32_t n, const uint8_t* data, size_t len, uint8_t* out_proof_wire);
+
 /* ---- measurement hooks ---------------------------------------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by HIP events on the context's stream;
  * mp_profile_report writes "name count total_ms\n" lines (and resets) -- bench.py's roofline source. */

@@ -5,8 +5,8 @@ identifier: import it with `importlib.import_module("mental-poker_amd")`.
 Everything is computed by libmpshuffle.so (hand-written HIP for gfx950); importing works without a GPU,
 creating an engine does not (no CPU fallback)."""
 from . import _native, canonical
-from ._native import Engine, NativeError, NoDeviceError, build, load
+from ._native import Engine, NativeError, NoDeviceError, Serializer, build, load
 from .protocol import (CardProtocolError, ChaCha20Rng, CryptoError, DLCards, Parameters, Permutation, fr_rand)
 
-__all__ = ["Engine", "NativeError", "NoDeviceError", "build", "load", "DLCards", "Parameters", "Permutation",
+__all__ = ["Engine", "Serializer", "NativeError", "NoDeviceError", "build", "load", "DLCards", "Parameters", "Permutation",
            "CryptoError", "CardProtocolError", "ChaCha20Rng", "fr_rand", "_native", "canonical"]

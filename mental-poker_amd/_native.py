@@ -23,6 +23,9 @@ SYMBOLS = [
     "mp_verify_shuffle_batch_dev", "mp_sync", "mp_reserve", "mp_set_latency_batch", "mp_remask_batch", "mp_msm", "mp_commit_batch",
     "mp_profile_enable", "mp_profile_report", "mp_work_census", "mp_plan_stats", "mp_sigma_prove_batch",
     "mp_sigma_verify_batch", "mp_blake2s",
+    "mp_serialized_point_size", "mp_serialized_deck_size", "mp_serialized_params_size", "mp_serialized_proof_size",
+    "mp_points_serialize", "mp_points_deserialize", "mp_deck_serialize", "mp_deck_deserialize", "mp_params_serialize",
+    "mp_params_deserialize", "mp_proof_serialize", "mp_proof_deserialize",
 ]
 
 
@@ -141,6 +144,18 @@ def bind(cdll):
     cdll.mp_sigma_prove_batch.argtypes = [c.c_void_p, c.c_size_t, c.c_uint32, u8p, u8p, u8p, u8p, u8p, u8p, i32p]
     cdll.mp_sigma_verify_batch.argtypes = [c.c_void_p, c.c_size_t, c.c_uint32, u8p, u8p, u8p, u8p, i32p]
     cdll.mp_blake2s.argtypes = [u8p, c.c_size_t, u8p]
+    for fn, at in (("mp_serialized_point_size", [c.c_int]), ("mp_serialized_deck_size", [c.c_int, c.c_size_t]),
+                   ("mp_serialized_params_size", [c.c_int, c.c_uint32]), ("mp_serialized_proof_size", [c.c_int, c.c_uint32, c.c_uint32])):
+        getattr(cdll, fn).argtypes = at
+        getattr(cdll, fn).restype = c.c_size_t
+    cdll.mp_points_serialize.argtypes = [c.c_int, c.c_size_t, u8p, u8p]
+    cdll.mp_points_deserialize.argtypes = [c.c_int, c.c_size_t, u8p, u8p]
+    cdll.mp_deck_serialize.argtypes = [c.c_int, c.c_size_t, u8p, u8p]
+    cdll.mp_deck_deserialize.argtypes = [c.c_int, u8p, c.c_size_t, c.c_size_t, u8p, c.POINTER(c.c_size_t)]
+    cdll.mp_params_serialize.argtypes = [c.c_int, c.c_uint32, c.c_uint32, u8p, u8p]
+    cdll.mp_params_deserialize.argtypes = [c.c_int, u8p, c.c_size_t, c.c_size_t, c.POINTER(c.c_uint32), c.POINTER(c.c_uint32), u8p]
+    cdll.mp_proof_serialize.argtypes = [c.c_int, c.c_uint32, c.c_uint32, u8p, u8p]
+    cdll.mp_proof_deserialize.argtypes = [c.c_int, c.c_uint32, c.c_uint32, u8p, c.c_size_t, u8p]
     return cdll
 
 
@@ -161,6 +176,80 @@ def load():
 def _in(b):
     b = bytes(b)
     return (ctypes.c_uint8 * max(len(b), 1)).from_buffer_copy(b if b else b"\0")
+
+
+class Serializer:
+    """include/mpshuffle.h "canonical serialisation": arkworks-0.3 compressed bytes <-> wire v1.  Host work in libmpshuffle.so;
+    needs no GPU and no context."""
+
+    def __init__(self, curve, lib=None):
+        self.lib, self.cid, self.curve = (lib if lib is not None else load()), CURVE_IDS[curve], curve
+        self.pb = self.lib.mp_point_size(self.cid)
+        self.cb = self.lib.mp_serialized_point_size(self.cid)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise NativeError(rc, self.lib.mp_last_error().decode())
+
+    def proof_serialized_size(self, m, n):
+        return self.lib.mp_serialized_proof_size(self.cid, m, n)
+
+    def points_serialize(self, wire):
+        k = len(wire) // self.pb
+        if k * self.pb != len(wire):
+            raise NativeError(MP_ERR_BAD_ARGUMENT, "whole wire points expected")
+        out = (ctypes.c_uint8 * max(k * self.cb, 1))()
+        self._chk(self.lib.mp_points_serialize(self.cid, k, _in(wire), out))
+        return bytes(out)[:k * self.cb]
+
+    def points_deserialize(self, data):
+        k = len(data) // self.cb
+        if k * self.cb != len(data):
+            raise NativeError(MP_ERR_BAD_ENCODING, "whole compressed points expected")
+        out = (ctypes.c_uint8 * max(k * self.pb, 1))()
+        self._chk(self.lib.mp_points_deserialize(self.cid, k, _in(data), out))
+        return bytes(out)[:k * self.pb]
+
+    def deck_serialize(self, wire):
+        k = len(wire) // (2 * self.pb)
+        if 2 * k * self.pb != len(wire):
+            raise NativeError(MP_ERR_BAD_ARGUMENT, "whole cards expected")
+        out = (ctypes.c_uint8 * self.lib.mp_serialized_deck_size(self.cid, k))()
+        self._chk(self.lib.mp_deck_serialize(self.cid, k, _in(wire), out))
+        return bytes(out)
+
+    def deck_deserialize(self, data):
+        cap = max(len(data) // (2 * self.cb), 1)
+        out = (ctypes.c_uint8 * (cap * 2 * self.pb))()
+        k = ctypes.c_size_t()
+        self._chk(self.lib.mp_deck_deserialize(self.cid, _in(data), len(data), cap, out, ctypes.byref(k)))
+        return bytes(out)[:k.value * 2 * self.pb]
+
+    def params_serialize(self, m, n, raw):
+        if len(raw) != self.pb * (n + 3):
+            raise NativeError(MP_ERR_BAD_ARGUMENT, "parameters: wrong length")
+        out = (ctypes.c_uint8 * self.lib.mp_serialized_params_size(self.cid, n))()
+        self._chk(self.lib.mp_params_serialize(self.cid, m, n, _in(raw), out))
+        return bytes(out)
+
+    def params_deserialize(self, data):
+        cap = max(len(data) // self.cb, 1)
+        out = (ctypes.c_uint8 * (self.pb * (cap + 3)))()
+        m, n = ctypes.c_uint32(), ctypes.c_uint32()
+        self._chk(self.lib.mp_params_deserialize(self.cid, _in(data), len(data), cap, ctypes.byref(m), ctypes.byref(n), out))
+        return m.value, n.value, bytes(out)[:self.pb * (n.value + 3)]
+
+    def proof_serialize(self, m, n, wire):
+        if len(wire) != self.lib.mp_proof_size_curve(self.cid, m, n):
+            raise NativeError(MP_ERR_BAD_ARGUMENT, "proof: wrong length")
+        out = (ctypes.c_uint8 * self.proof_serialized_size(m, n))()
+        self._chk(self.lib.mp_proof_serialize(self.cid, m, n, _in(wire), out))
+        return bytes(out)
+
+    def proof_deserialize(self, m, n, data):
+        out = (ctypes.c_uint8 * self.lib.mp_proof_size_curve(self.cid, m, n))()
+        self._chk(self.lib.mp_proof_deserialize(self.cid, m, n, _in(data), len(data), out))
+        return bytes(out)
 
 
 class Engine:

@@ -472,4 +472,163 @@ int mp_plan_stats(mp_table* t, uint64_t out[16]) {
   return MP_OK;
 }
 
-}  // extern "C"
+
+// ---- canonical (arkworks-0.3 compressed) serialisation of the trait's associated types: host work, no context ---------------
+namespace {
+long ser_points(int curve, bool de, size_t count, const uint8_t* in, uint8_t* out) {
+  switch (curve) {
+    case 0: return ser_points_Stark(de, count, in, out);
+    case 1: return ser_points_Bn254(de, count, in, out);
+    case 3: return ser_points_Bls12_377(de, count, in, out);
+    default: return ser_points_Secp256k1(de, count, in, out);
+  }
+}
+bool ser_scalars_ok(int curve, size_t count, const uint8_t* in) {
+  switch (curve) {
+    case 0: return ser_scalars_ok_Stark(count, in);
+    case 1: return ser_scalars_ok_Bn254(count, in);
+    case 3: return ser_scalars_ok_Bls12_377(count, in);
+    default: return ser_scalars_ok_Secp256k1(count, in);
+  }
+}
+const int kCurveBits[4] = {252, 254, 256, 377};
+// element groups of the shuffle proof in wire order: {points?, count, is_vec, vec_len}
+struct Group {
+  bool point;
+  uint32_t count;
+  bool vec;
+  uint32_t vec_len;
+};
+std::vector<Group> proof_schema(uint32_t m, uint32_t n) {
+  return {
+      {true, m, true, m}, {true, m, true, m}, {true, 1, false, 0}, {true, m, true, m},
+      {true, 1, false, 0}, {true, 1, false, 0}, {true, 2 * m + 1, true, 2 * m + 1},
+      {false, n, true, n}, {false, n, true, n}, {false, 1, false, 0}, {false, 1, false, 0}, {false, 1, false, 0},
+      {true, 1, false, 0}, {true, 1, false, 0}, {true, 1, false, 0},
+      {false, n, true, n}, {false, n, true, n}, {false, 1, false, 0}, {false, 1, false, 0},
+      {true, 1, false, 0}, {true, 2 * m, true, 2 * m}, {true, 4 * m, true, 2 * m},      // E: 2m ciphertexts = 4m points
+      {false, n, true, n}, {false, 1, false, 0}, {false, 1, false, 0}, {false, 1, false, 0}, {false, 1, false, 0}};
+}
+void put_u64(uint8_t* p, uint64_t v) { memcpy(p, &v, 8); }
+uint64_t get_u64(const uint8_t* p) {
+  uint64_t v;
+  memcpy(&v, p, 8);
+  return v;
+}
+bool curve_ok(int c) { return c >= 0 && c <= 3; }
+}  // namespace
+
+size_t mp_serialized_point_size(int curve_id) { return curve_ok(curve_id) ? (size_t)(kCurveBits[curve_id] + 2 + 7) / 8 : 0; }
+size_t mp_serialized_deck_size(int curve_id, size_t cards) { return 8 + 2 * cards * mp_serialized_point_size(curve_id); }
+size_t mp_serialized_params_size(int curve_id, uint32_t n) { return 24 + (size_t)(n + 3) * mp_serialized_point_size(curve_id); }
+size_t mp_serialized_proof_size(int curve_id, uint32_t m, uint32_t n) {
+  size_t sz = 0;
+  for (const Group& g : proof_schema(m, n)) sz += (g.vec ? 8 : 0) + (size_t)g.count * (g.point ? mp_serialized_point_size(curve_id) : 32);
+  return sz;
+}
+int mp_points_serialize(int curve_id, size_t count, const uint8_t* wire_points, uint8_t* out) {
+  if (!curve_ok(curve_id) || (count && (!wire_points || !out))) return fail(MP_ERR_BAD_ARGUMENT, "mp_points_serialize: bad argument");
+  MP_TRY
+  if (ser_points(curve_id, false, count, wire_points, out) >= 0) return fail(MP_ERR_BAD_ENCODING, "point: coordinate out of range");
+  return MP_OK;
+  MP_CATCH
+}
+int mp_points_deserialize(int curve_id, size_t count, const uint8_t* data, uint8_t* out_wire_points) {
+  if (!curve_ok(curve_id) || (count && (!data || !out_wire_points))) return fail(MP_ERR_BAD_ARGUMENT, "mp_points_deserialize: bad argument");
+  MP_TRY
+  if (ser_points(curve_id, true, count, data, out_wire_points) >= 0)
+    return fail(MP_ERR_BAD_ENCODING, "point: non-canonical encoding, x not on the curve, or not in the prime-order subgroup");
+  return MP_OK;
+  MP_CATCH
+}
+int mp_deck_serialize(int curve_id, size_t cards, const uint8_t* wire_deck, uint8_t* out) {
+  if (!curve_ok(curve_id) || !out || (cards && !wire_deck)) return fail(MP_ERR_BAD_ARGUMENT, "mp_deck_serialize: bad argument");
+  put_u64(out, cards);
+  return mp_points_serialize(curve_id, 2 * cards, wire_deck, out + 8);
+}
+int mp_deck_deserialize(int curve_id, const uint8_t* data, size_t len, size_t max_cards, uint8_t* out_wire_deck, size_t* out_cards) {
+  if (!curve_ok(curve_id) || !data || !out_cards) return fail(MP_ERR_BAD_ARGUMENT, "mp_deck_deserialize: bad argument");
+  if (len < 8) return fail(MP_ERR_BAD_ENCODING, "deck: not enough data");
+  const uint64_t k = get_u64(data);
+  if (k > max_cards) return fail(MP_ERR_BAD_ARGUMENT, "deck: more cards than the output buffer holds");
+  if (len != mp_serialized_deck_size(curve_id, (size_t)k)) return fail(MP_ERR_BAD_ENCODING, "deck: length does not match the card count");
+  *out_cards = (size_t)k;
+  return mp_points_deserialize(curve_id, 2 * (size_t)k, data + 8, out_wire_deck);
+}
+// Parameters { m, n, enc_parameters { generator }, commit_parameters { g: Vec, h }, generator } [REF mod.rs:37-43]; raw = G | ck | H | gen
+int mp_params_serialize(int curve_id, uint32_t m, uint32_t n, const uint8_t* raw_params, uint8_t* out) {
+  if (!curve_ok(curve_id) || !raw_params || !out) return fail(MP_ERR_BAD_ARGUMENT, "mp_params_serialize: bad argument");
+  const size_t pb = mp_point_size(curve_id), cb = mp_serialized_point_size(curve_id);
+  put_u64(out, m);
+  put_u64(out + 8, n);
+  int rc = mp_points_serialize(curve_id, 1, raw_params, out + 16);
+  if (rc) return rc;
+  put_u64(out + 16 + cb, n);
+  rc = mp_points_serialize(curve_id, n, raw_params + pb, out + 24 + cb);
+  if (rc) return rc;
+  return mp_points_serialize(curve_id, 2, raw_params + pb * (n + 1), out + 24 + cb * (n + 1));
+}
+int mp_params_deserialize(int curve_id, const uint8_t* data, size_t len, size_t max_n, uint32_t* m, uint32_t* n, uint8_t* out_raw_params) {
+  if (!curve_ok(curve_id) || !data || !m || !n || !out_raw_params) return fail(MP_ERR_BAD_ARGUMENT, "mp_params_deserialize: bad argument");
+  if (len < 16) return fail(MP_ERR_BAD_ENCODING, "parameters: not enough data");
+  const uint64_t mm = get_u64(data), nn = get_u64(data + 8);
+  if (nn > max_n || mm > 0xFFFFFFFFull) return fail(MP_ERR_BAD_ARGUMENT, "parameters: n exceeds the output buffer");
+  if (len != mp_serialized_params_size(curve_id, (uint32_t)nn)) return fail(MP_ERR_BAD_ENCODING, "parameters: length does not match n");
+  const size_t pb = mp_point_size(curve_id), cb = mp_serialized_point_size(curve_id);
+  if (get_u64(data + 16 + cb) != nn) return fail(MP_ERR_BAD_ENCODING, "parameters: commit key length != n");
+  int rc = mp_points_deserialize(curve_id, 1, data + 16, out_raw_params);
+  if (rc) return rc;
+  rc = mp_points_deserialize(curve_id, (size_t)nn, data + 24 + cb, out_raw_params + pb);
+  if (rc) return rc;
+  rc = mp_points_deserialize(curve_id, 2, data + 24 + cb * (nn + 1), out_raw_params + pb * (nn + 1));
+  if (rc) return rc;
+  *m = (uint32_t)mm;
+  *n = (uint32_t)nn;
+  return MP_OK;
+}
+int mp_proof_serialize(int curve_id, uint32_t m, uint32_t n, const uint8_t* proof_wire, uint8_t* out) {
+  if (!curve_ok(curve_id) || !proof_wire || !out || m < 2 || n < 2) return fail(MP_ERR_BAD_ARGUMENT, "mp_proof_serialize: bad argument");
+  const size_t pb = mp_point_size(curve_id), cb = mp_serialized_point_size(curve_id);
+  for (const Group& g : proof_schema(m, n)) {
+    if (g.vec) {
+      put_u64(out, g.vec_len);
+      out += 8;
+    }
+    if (g.point) {
+      const int rc = mp_points_serialize(curve_id, g.count, proof_wire, out);
+      if (rc) return rc;
+      proof_wire += pb * g.count;
+      out += cb * g.count;
+    } else {
+      memcpy(out, proof_wire, 32 * (size_t)g.count);
+      proof_wire += 32 * (size_t)g.count;
+      out += 32 * (size_t)g.count;
+    }
+  }
+  return MP_OK;
+}
+int mp_proof_deserialize(int curve_id, uint32_t m, uint32_t n, const uint8_t* data, size_t len, uint8_t* out_proof_wire) {
+  if (!curve_ok(curve_id) || !data || !out_proof_wire || m < 2 || n < 2) return fail(MP_ERR_BAD_ARGUMENT, "mp_proof_deserialize: bad argument");
+  if (len != mp_serialized_proof_size(curve_id, m, n)) return fail(MP_ERR_BAD_ENCODING, "shuffle proof: wrong length");
+  const size_t pb = mp_point_size(curve_id), cb = mp_serialized_point_size(curve_id);
+  for (const Group& g : proof_schema(m, n)) {
+    if (g.vec) {
+      if (get_u64(data) != g.vec_len) return fail(MP_ERR_BAD_ENCODING, "shuffle proof: a vector has the wrong length");
+      data += 8;
+    }
+    if (g.point) {
+      const int rc = mp_points_deserialize(curve_id, g.count, data, out_proof_wire);
+      if (rc) return rc;
+      data += cb * g.count;
+      out_proof_wire += pb * g.count;
+    } else {
+      if (!ser_scalars_ok(curve_id, g.count, data)) return fail(MP_ERR_BAD_ENCODING, "shuffle proof: scalar out of range");
+      memcpy(out_proof_wire, data, 32 * (size_t)g.count);
+      data += 32 * (size_t)g.count;
+      out_proof_wire += 32 * (size_t)g.count;
+    }
+  }
+  return MP_OK;
+}
+
+}

@@ -165,7 +165,9 @@ namespace mp {
 #define MP_DECLARE_CURVE(NAME)                                                                                          \
   mp_table* make_table_##NAME(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, const uint8_t* pk,           \
                               uint32_t fb_bits, int* rc);                                                              \
-  int setup_##NAME(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out);
+  int setup_##NAME(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out);                                   \
+  long ser_points_##NAME(bool de, size_t count, const uint8_t* in, uint8_t* out);                                                \
+  bool ser_scalars_ok_##NAME(size_t count, const uint8_t* in);
 MP_DECLARE_CURVE(Stark)
 MP_DECLARE_CURVE(Bn254)
 MP_DECLARE_CURVE(Secp256k1)

@@ -4,6 +4,7 @@
 #include "engine_base.hpp"
 #include "kernels_bucket.hpp"
 #include "kernels_sigma.hpp"
+#include "serialize_host.hpp"
 #include "setup_host.hpp"
 
 namespace mp {
@@ -818,4 +819,8 @@ static int setup_device(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[
   int setup_##NAME(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out) {                \
     return setup_device<NAME>(ctx, m, n, seed, out);                                                           \
   }                                                                                                            \
+  long ser_points_##NAME(bool de, size_t count, const uint8_t* in, uint8_t* out) {                             \
+    return Ser<NAME>::points(de, count, in, out);                                                              \
+  }                                                                                                            \
+  bool ser_scalars_ok_##NAME(size_t count, const uint8_t* in) { return Ser<NAME>::scalars_ok(count, in); }     \
   }

@@ -126,19 +126,25 @@ class DLCards:
             raise CardProtocolError.io(str(e))
 
     # -- proof.serialized_size() / serialize() of ZKProofShuffle [REF examples/parameter_selection.rs:95; src/lib.rs:71]
+    # (C ABI: mp_serialized_proof_size / mp_proof_serialize / mp_proof_deserialize; canonical.py is the pure-Python cross-check)
+    def _ser(self):
+        if getattr(self, "_serializer", None) is None:
+            self._serializer = _native.Serializer(self.curve, lib=self.engine.lib)
+        return self._serializer
+
     def proof_serialized_size(self, pp):
-        from . import canonical
-        return canonical.shuffle_proof_serialized_size(self.curve, pp.m, pp.n)
+        return self._ser().proof_serialized_size(pp.m, pp.n)
 
     def serialize_proof(self, pp, proof):
-        from . import canonical
-        return canonical.shuffle_proof_serialize(self.curve, pp.m, pp.n, proof)
+        try:
+            return self._ser().proof_serialize(pp.m, pp.n, proof)
+        except _native.NativeError as e:
+            raise CardProtocolError.io(str(e))
 
     def deserialize_proof(self, pp, data):
-        from . import canonical
         try:
-            return canonical.shuffle_proof_deserialize(self.curve, pp.m, pp.n, data)
-        except canonical.SerializationError as e:
+            return self._ser().proof_deserialize(pp.m, pp.n, data)
+        except _native.NativeError as e:
             raise CardProtocolError.io(str(e))
 
     def table(self, pp, shared_key):

@@ -33,6 +33,13 @@ int main(int argc, char** argv) {
   if (memcmp(res.first[0].data(), exp_deck, N * 128) != 0) { printf("FAIL: shuffled deck differs\n"); return 1; }
   if (res.second.size() != psz || memcmp(res.second.data(), exp_proof, psz) != 0) { printf("FAIL: proof differs\n"); return 1; }
   cards.verify_shuffle(pp, pk, deck, res.first, res.second);          // Ok(())
+  {                                                                     // serialise -> deserialise round trip of the proof
+    const std::vector<uint8_t> ser = cards.serialize(pp, res.second);
+    if (ser.size() != cards.serialized_size(pp) || cards.deserialize_proof(pp, ser) != res.second) {
+      std::fprintf(stderr, "serialisation round trip failed\n");
+      return 3;
+    }
+  }
   std::vector<MaskedCard> wrong(res.first.rbegin(), res.first.rend());  // some other deck
   try {
     cards.verify_shuffle(pp, pk, deck, wrong, res.second);

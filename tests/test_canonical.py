@@ -85,3 +85,73 @@ def test_parameters_mirror_roundtrip():
     assert (back.m, back.n, back.raw) == (pp.m, pp.n, pp.raw)
     with pytest.raises(mp.CardProtocolError):
         mp.Parameters.deserialize("stark", pp.serialize("stark")[:-1])
+
+
+# ---- the same conversions through the C ABI (include/mpshuffle.h "canonical serialisation": host code of libmpshuffle.so) -----
+@pytest.fixture(scope="module")
+def native():
+    import importlib
+    mp = importlib.import_module("mental-poker_amd")
+    mp.build()
+    return mp
+
+
+@pytest.mark.parametrize("name", ["shuffle_stark_m2_n26_s7.json", "shuffle_stark_m3_n4_s11.json", "shuffle_bn254_m2_n4_s3.json",
+                                  "shuffle_secp256k1_m3_n3_s5.json", "shuffle_bls12_377_m2_n3_s13.json"])
+def test_c_abi_serialisation_matches_python(native, name):
+    from conftest import GOLDEN, load_json
+    can = native.canonical
+    g = load_json(os.path.join(GOLDEN, name))
+    cv, m, n = g["curve"], g["m"], g["n"]
+    ser = native.Serializer(cv)
+    proof, deck, params = bytes.fromhex(g["proof"]), bytes.fromhex(g["shuffled"]), bytes.fromhex(g["params"])
+    assert ser.cb == can.point_bytes(cv) and ser.proof_serialized_size(m, n) == can.shuffle_proof_serialized_size(cv, m, n)
+    sp = ser.proof_serialize(m, n, proof)
+    assert sp == can.shuffle_proof_serialize(cv, m, n, proof) and len(sp) == ser.proof_serialized_size(m, n)
+    assert ser.proof_deserialize(m, n, sp) == proof
+    sd = ser.deck_serialize(deck)
+    assert sd == can.deck_serialize(cv, deck) and ser.deck_deserialize(sd) == deck
+    spp = ser.params_serialize(m, n, params)
+    assert spp == can.parameters_serialize(cv, m, n, params) and ser.params_deserialize(spp) == (m, n, params)
+    inf = bytes(ser.pb)
+    assert ser.points_deserialize(ser.points_serialize(inf + deck[:ser.pb])) == inf + deck[:ser.pb]
+    # invalid data is refused the way ark-serialize refuses it
+    for bad in (sp[:-1], sp + b"\0", bytes([sp[0] ^ 1]) + sp[1:]):
+        with pytest.raises(native.NativeError):
+            ser.proof_deserialize(m, n, bad)
+    z = bytearray(sp)
+    z[-20:] = b"\xff" * 20               # last scalar >= q on every curve
+    with pytest.raises(native.NativeError):
+        ser.proof_deserialize(m, n, bytes(z))
+    x_off_curve = None
+    for v in range(2, 200):               # an x with no point on the curve
+        c = v.to_bytes(ser.cb, "little")
+        try:
+            can.point_decompress(cv, c)
+        except can.SerializationError:
+            x_off_curve = c
+            break
+    with pytest.raises(native.NativeError):
+        ser.points_deserialize(x_off_curve)
+    both = bytearray(ser.cb)
+    both[-1] = 0xC0                       # infinity with the sign flag set
+    with pytest.raises(native.NativeError):
+        ser.points_deserialize(bytes(both))
+
+
+def test_c_abi_rejects_points_outside_the_subgroup(native):
+    import mp_oracle as po
+    cv = po.CURVES["bls12_377"]
+    ser = native.Serializer("bls12_377")
+    with po.curve_ctx(cv):
+        x = 5
+        while True:
+            y = po.fq_sqrt(cv, (x ** 3 + cv.b) % cv.p)
+            if y is not None and po.pt_mul_raw(cv, cv.q, (x, y)) is not None:
+                break
+            x += 1
+        bad = po.pt_wire((x, y))
+    comp = ser.points_serialize(bad)                       # compression does not judge
+    assert comp == native.canonical.point_compress("bls12_377", bad)
+    with pytest.raises(native.NativeError):
+        ser.points_deserialize(comp)
