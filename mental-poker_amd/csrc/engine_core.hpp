@@ -13,6 +13,7 @@ static const uint32_t FCHUNK = 8;     // fixed-base terms per sub-job (8 x 13..3
 static const uint32_t VCHUNK = 64;    // variable-base terms per sub-job: the terms of a job share one 250-doubling chain
 static const uint32_t NORM_CHUNK = 64;   // points per Fermat inversion in k_normalize
 static const uint32_t BUCKET_MIN = 2048; // variable-base terms from which an MSM runs on the bucket kernel (kernels_bucket.hpp)
+static const uint32_t BUCKET_MIN_SMALL_BATCH = 128;   // ... in the plans for small batches (latency, not throughput)
 
 struct PhaseDev {
   DevBuf<Term> recode, tables, fterms, vterms, cterms, cterms2;
@@ -181,8 +182,12 @@ struct Table : mp_table {
                           nch[N_PLANS] = {NORM_CHUNK, 8, 32, 4};
     for (int k = 0; k < N_PLANS; ++k) {
       PlanSet& q = set[k];
-      q.pplan = make_prove_plan(m, n, fch[k], vch[k], G_::PB, keyed, bucket_min, bk_windows(R::BITS));
-      q.vplan = make_verify_plan(m, n, fch[k], vch[k], G_::PB, keyed, bucket_min, bk_windows(R::BITS));
+      // the two finest splits serve batches too small to fill the chip with one lane per Straus job: there the bucket kernel
+      // (windows x 64 lanes per MSM) already pays from 128 terms on -- the merged verifier equation of a 52-card proof has 239
+      // (one proof: verify 4.4 -> 3.6 ms, profiles/r02_latency.txt)
+      const uint32_t bmin = (bucket_min && (k == 1 || k == 3)) ? std::min(bucket_min, BUCKET_MIN_SMALL_BATCH) : bucket_min;
+      q.pplan = make_prove_plan(m, n, fch[k], vch[k], G_::PB, keyed, bmin, bk_windows(R::BITS));
+      q.vplan = make_verify_plan(m, n, fch[k], vch[k], G_::PB, keyed, bmin, bk_windows(R::BITS));
       q.table_group = grp[k];
       q.norm_chunk = nch[k];       // fewer points per serial inversion chain when lanes are idle
       for (int i = 0; i < 5; ++i) q.pph[i].upload(q.pplan.ph[i], s);
@@ -520,7 +525,8 @@ struct Table : mp_table {
     // small batches (the two finest splits) go straight to the per-equation pass: with an idle chip the merged MSM is one long
     // dependency chain and its flag read-back a round trip -- it pays from the medium plan on (+3 % there, measured)
     const int plan = plan_of(B);
-    for (int pass = (merged_verify && (plan == 0 || plan == 2)) ? 0 : 1; pass < 2; ++pass) {
+    // (unless the merged equation runs on the bucket kernel, which spreads ONE MSM over windows x 64 lanes)
+    for (int pass = (merged_verify && (plan == 0 || plan == 2 || q.vmph.n_b)) ? 0 : 1; pass < 2; ++pass) {
       const bool merged = pass == 0;
       rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
       {
