@@ -560,7 +560,7 @@ def main():
         if kernel == "k_var_msm":
             return sum(s["var_terms"] * (32 + PB) + s["var_jobs"] * 3 * PB // 2 for s in pv)
         if kernel == "k_bucket_msm":
-            return sum(s.get("bucket_terms", 0) * (32 + PB) + s.get("bucket_jobs", 0) * 3 * PB // 2 for s in pv)
+            return stats.get("bucket_terms", 0) * (32 + PB) + stats.get("bucket_jobs", 0) * 3 * PB // 2
         if kernel == "k_fixed_msm":
             return sum(s["fixed_terms"] * 32 + s["fixed_jobs"] * 3 * PB // 2 for s in pv)
         if kernel == "k_table":
@@ -592,7 +592,13 @@ def main():
             mads_per_proof += st_["var_jobs"] * (vw - 1) * 5 * mc["dbl"]
             mads_per_proof += st_["table_bases"] * 15 * mc["aff"]
             mads_per_proof += st_["combine_terms"] * mc["jac"] + norm_points * mc["norm"]
-            mads_per_proof += st_.get("bucket_madds", 0) * mc["madd"] + st_.get("bucket_adds", 0) * mc["jac"]
+        # bucket-method MSMs: one mixed addition per term and window; per (MSM, window) a 14-step wave-wide reduction on 64 lanes
+        # (XYZZ + XYZZ, 12M+2S) and the fold (8 doublings + 1 addition)
+        bw = {"stark": 32, "bn254": 32, "secp256k1": 33, "bls12_377": 32}.get(curve, 32)
+        fm = mc["field"]
+        xyzz_add = 12 * fm["mul"] + 2 * fm["sqr"]
+        mads_per_proof += stats.get("bucket_terms", 0) * bw * mc["madd"]
+        mads_per_proof += stats.get("bucket_jobs", 0) * bw * (14 * 64 * xyzz_add + 8 * mc["dbl"] + mc["jac"])
         mads = mads_per_proof * total_proofs / world
         int_mul = {"bound": "v_mad_u64_u32 issue", "achieved": round(mads / (kernel_ms_total * 1e-3) / 1e9, 1),
                    "peak": INT_MAD_PEAK_G, "unit": "Gmad/s",

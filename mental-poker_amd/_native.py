@@ -16,7 +16,7 @@ MP_ERR_BAD_ENCODING, MP_ERR_BAD_PERMUTATION, MP_ERR_BAD_ARGUMENT, MP_ERR_NO_DEVI
 
 SYMBOLS = [
     "mp_ctx_create", "mp_ctx_destroy", "mp_last_error", "mp_check_name", "mp_proof_size", "mp_params_size",
-    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_set_subgroup_check", "mp_set_bucket_min", "mp_host_alloc", "mp_host_free", "mp_set_io_chunk", "mp_shuffle_and_remask_batch_keys", "mp_table_create_params",
+    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_set_subgroup_check", "mp_set_bucket_min", "mp_set_toom_cook", "mp_host_alloc", "mp_host_free", "mp_set_io_chunk", "mp_shuffle_and_remask_batch_keys", "mp_table_create_params",
     "mp_verify_shuffle_batch_keys", "mp_shuffle_and_remask_batch_keys_dev", "mp_verify_shuffle_batch_keys_dev",
     "mp_setup", "mp_table_create", "mp_table_create_ex", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
     "mp_shuffle_and_remask_batch", "mp_verify_shuffle_batch", "mp_shuffle_and_remask_batch_dev",
@@ -104,6 +104,7 @@ def bind(cdll):
     cdll.mp_set_merged_verify.argtypes = [c.c_void_p, c.c_int]
     cdll.mp_set_subgroup_check.argtypes = [c.c_void_p, c.c_int]
     cdll.mp_set_bucket_min.argtypes = [c.c_void_p, c.c_size_t]
+    cdll.mp_set_toom_cook.argtypes = [c.c_void_p, c.c_int]
     cdll.mp_set_io_chunk.argtypes = [c.c_void_p, c.c_size_t]
     cdll.mp_host_alloc.argtypes = [c.c_size_t]
     cdll.mp_host_alloc.restype = c.c_void_p
@@ -485,6 +486,10 @@ class Table:
         """variable-base MSMs of at least `terms` terms run on the bucket-method kernel (default 2048; 0 = never)"""
         self.eng._chk(self.lib.mp_set_bucket_min(self.h, terms))
 
+    def set_toom_cook(self, on=True):
+        """3 <= m <= 8: Toom-Cook (default) or Karatsuba evaluation of the multi-exponentiation diagonals"""
+        self.eng._chk(self.lib.mp_set_toom_cook(self.h, 1 if on else 0))
+
     def set_subgroup_check(self, on=True):
         """curves with a cofactor: test every wire point for membership in the prime-order subgroup (default on)"""
         self.eng._chk(self.lib.mp_set_subgroup_check(self.h, 1 if on else 0))
@@ -495,6 +500,8 @@ class Table:
         keys = ["fixed_terms", "var_terms", "fixed_jobs", "var_jobs", "table_bases", "combine_terms"]
         out = {"prove": dict(zip(keys, v[0:6])), "verify": dict(zip(keys, v[6:12]))}
         out.update(var_windows=v[12], fixed_windows=v[13], N=v[14])
+        # MSMs on the bucket-method kernel (prove + verify together): terms and jobs; 8-bit windows
+        out.update(bucket_terms=v[15] & 0xFFFFFFFF, bucket_jobs=v[15] >> 32)
         return out
 
     def work_census(self):

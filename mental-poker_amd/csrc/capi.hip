@@ -159,6 +159,14 @@ int mp_set_bucket_min(mp_table* t, size_t terms) {
   return MP_OK;
   MP_CATCH
 }
+int mp_set_toom_cook(mp_table* t, int on) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_toom_cook: null table");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  t->set_toom_cook(on != 0);
+  return MP_OK;
+  MP_CATCH
+}
 int mp_set_subgroup_check(mp_table* t, int on) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_subgroup_check: null table");
   t->set_subgroup_check(on != 0);

@@ -145,6 +145,7 @@ struct mp_table {
   virtual void set_merged_verify(bool on) = 0;
   virtual void set_subgroup_check(bool on) = 0;
   virtual void set_bucket_min(uint32_t terms) = 0;
+  virtual void set_toom_cook(bool on) = 0;
   // keys: nullptr = the table's own aggregate key; otherwise one wire point per proof (device memory)
   virtual void prove_dev(size_t B, const uint8_t* decks, const uint8_t* rho, const uint32_t* perm, const uint8_t* seeds,
                          uint8_t* out_decks, uint8_t* out_proofs, int32_t* status, const uint8_t* keys = nullptr) = 0;

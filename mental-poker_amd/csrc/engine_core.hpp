@@ -107,10 +107,10 @@ struct Table : mp_table {
   struct PlanSet {
     ProvePlan pplan;
     VerifyPlan vplan;
-    PhaseDev pph[5], vph, vmph;      // vmph: the merged verification plan (one MSM for all equations)
+    PhaseDev pph[6], vph, vmph;      // vmph: the merged verification plan (one MSM for all equations)
     DevBuf<MergeJob> mjobs;
     DevBuf<MergePair> mpairs;
-    DevBuf<uint32_t> draws, lin_src;
+    DevBuf<uint32_t> draws, lin_src, lin_coef, consts;      // consts: Fr constants of the Toom-Cook plan (8 words each)
     DevBuf<LinJob> lin;
     DevBuf<ProofElem> pwire, vwire;
     uint32_t table_group = TABLE_GROUP;
@@ -137,6 +137,75 @@ struct Table : mp_table {
     tiny_batch = latency_batch / 16 * 3;
   }
   uint32_t bucket_min = BUCKET_MIN;              // MSMs of at least this many variable-base terms use the bucket kernel (0 = never)
+  bool toom_cook = true;        // 3 <= m <= 8: Toom-Cook instead of Karatsuba for the multi-exponentiation diagonals
+  void set_toom_cook(bool on) override {
+    if (on == toom_cook) return;
+    toom_cook = on;
+    rt::stream_sync(ctx->stream);
+    build_plans(ps, false);
+    psk_ready = false;
+    rt::stream_sync(ctx->stream);
+  }
+  // Fr constants of a Toom-Cook plan: powers x_e^j of the evaluation points and the inverse Vandermonde matrix W (host)
+  std::vector<uint32_t> toom_constants(const ToomPlan& T) {
+    std::vector<uint32_t> out((size_t)std::max<uint32_t>(T.n_consts, 1) * 8, 0u);
+    if (!T.E) return out;
+    const uint32_t E = T.E, mm = E / 2;
+    auto put = [&](uint32_t idx, const Fe<R>& v) { fe_pack<R>(v, &out[(size_t)idx * 8]); };
+    std::vector<Fe<R>> X(E);
+    for (uint32_t e = 0; e < E; ++e) {
+      const int32_t x = T.x_of(e);
+      X[e] = x >= 0 ? fe_from_u32<R>((uint32_t)x) : fe_neg<R>(fe_from_u32<R>((uint32_t)(-x)));
+    }
+    for (uint32_t e = 2; e < E; ++e) {
+      Fe<R> p = fe_one<R>();
+      for (uint32_t j = 0; j <= mm; ++j) {
+        put(e * (mm + 1) + j, p);
+        p = fe_mul<R>(p, X[e]);
+      }
+    }
+    // V[e][k] = x_e^k (e = 0: X = 0 -> (1, 0, ...); e = 1: X = infinity -> (0, ..., 0, 1)); W = V^-1 by Gauss-Jordan
+    std::vector<Fe<R>> V((size_t)E * E, fe_zero<R>()), W((size_t)E * E, fe_zero<R>());
+    for (uint32_t e = 0; e < E; ++e) {
+      W[(size_t)e * E + e] = fe_one<R>();
+      if (e == 1) {
+        V[(size_t)e * E + (E - 1)] = fe_one<R>();
+        continue;
+      }
+      Fe<R> p = fe_one<R>();
+      for (uint32_t k = 0; k < E; ++k) {
+        V[(size_t)e * E + k] = p;
+        p = e == 0 ? fe_zero<R>() : fe_mul<R>(p, X[e]);
+      }
+    }
+    for (uint32_t col = 0; col < E; ++col) {
+      uint32_t piv = col;
+      while (piv < E && fe_is_zero(V[(size_t)piv * E + col])) ++piv;
+      if (piv == E) throw std::logic_error("Toom-Cook: singular Vandermonde matrix");
+      for (uint32_t k = 0; k < E; ++k) {
+        std::swap(V[(size_t)piv * E + k], V[(size_t)col * E + k]);
+        std::swap(W[(size_t)piv * E + k], W[(size_t)col * E + k]);
+      }
+      const Fe<R> inv = fe_inv<R>(V[(size_t)col * E + col]);
+      for (uint32_t k = 0; k < E; ++k) {
+        V[(size_t)col * E + k] = fe_mul<R>(V[(size_t)col * E + k], inv);
+        W[(size_t)col * E + k] = fe_mul<R>(W[(size_t)col * E + k], inv);
+      }
+      for (uint32_t r = 0; r < E; ++r) {
+        if (r == col) continue;
+        const Fe<R> f = V[(size_t)r * E + col];
+        if (fe_is_zero(f)) continue;
+        for (uint32_t k = 0; k < E; ++k) {
+          V[(size_t)r * E + k] = fe_sub<R>(V[(size_t)r * E + k], fe_mul<R>(f, V[(size_t)col * E + k]));
+          W[(size_t)r * E + k] = fe_sub<R>(W[(size_t)r * E + k], fe_mul<R>(f, W[(size_t)col * E + k]));
+        }
+      }
+    }
+    // W now maps the products (index e) to the coefficients (index k): E_k = sum_e W[k][e] P_e
+    for (uint32_t k = 0; k < E; ++k)
+      for (uint32_t e = 0; e < E; ++e) put(T.w_const_first + k * E + e, W[(size_t)k * E + e]);
+    return out;
+  }
   void set_bucket_min(uint32_t terms) override {
     if (terms == bucket_min) return;
     bucket_min = terms;
@@ -186,11 +255,11 @@ struct Table : mp_table {
       // (windows x 64 lanes per MSM) already pays from 128 terms on -- the merged verifier equation of a 52-card proof has 239
       // (one proof: verify 4.4 -> 3.6 ms, profiles/r02_latency.txt)
       const uint32_t bmin = (bucket_min && (k == 1 || k == 3)) ? std::min(bucket_min, BUCKET_MIN_SMALL_BATCH) : bucket_min;
-      q.pplan = make_prove_plan(m, n, fch[k], vch[k], G_::PB, keyed, bmin, bk_windows(R::BITS));
+      q.pplan = make_prove_plan(m, n, fch[k], vch[k], G_::PB, keyed, bmin, bk_windows(R::BITS), toom_cook);
       q.vplan = make_verify_plan(m, n, fch[k], vch[k], G_::PB, keyed, bmin, bk_windows(R::BITS));
       q.table_group = grp[k];
       q.norm_chunk = nch[k];       // fewer points per serial inversion chain when lanes are idle
-      for (int i = 0; i < 5; ++i) q.pph[i].upload(q.pplan.ph[i], s);
+      for (int i = 0; i < 6; ++i) q.pph[i].upload(q.pplan.ph[i], s);
       q.vph.upload(q.vplan.ph, s);
       q.vmph.upload(q.vplan.mph, s);
       q.mjobs.upload(q.vplan.mjobs, s);
@@ -198,6 +267,8 @@ struct Table : mp_table {
       q.draws.upload(q.pplan.draws, s);
       q.lin.upload(q.pplan.lin, s);
       q.lin_src.upload(q.pplan.lin_src, s);
+      q.lin_coef.upload(q.pplan.lin_coef, s);
+      q.consts.upload(toom_constants(q.pplan.toom), s);
       q.pwire.upload(q.pplan.wire, s);
       q.vwire.upload(q.vplan.wire, s);
     }
@@ -210,7 +281,7 @@ struct Table : mp_table {
     // the key's digit / table slots live behind those of every phase of either plan
     key_d_first = key_t_first = 0;
     for (int k = 0; k < N_PLANS; ++k)
-      for (int i = 0; i < 5; ++i) {
+      for (int i = 0; i < 6; ++i) {
         key_d_first = std::max(key_d_first, psk[k].pplan.ph[i].n_dslots);
         key_t_first = std::max(key_t_first, psk[k].pplan.ph[i].n_tslots);
       }
@@ -342,7 +413,7 @@ struct Table : mp_table {
     uint32_t nJ = std::max(q.pplan.nJ, q.vplan.nJ), nD = std::max(q.vph.n_dslots, q.vmph.n_dslots),
              nT = std::max(q.vph.n_tslots, q.vmph.n_tslots);
     uint32_t d8 = std::max(q.vph.b_dig_bytes, q.vmph.b_dig_bytes);
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < 6; ++i) {
       nD = std::max(nD, q.pph[i].n_dslots);
       nT = std::max(nT, q.pph[i].n_tslots);
       d8 = std::max(d8, q.pph[i].b_dig_bytes);
@@ -454,14 +525,28 @@ struct Table : mp_table {
       MP_RUN(k_remask, C, B, 2 * N, ra);
     }
     run_phase(pph[0], w, B);
-    run_phase(pph[4], w, B);      // Toom-Cook / Karatsuba operand sums (empty when unused)
+    run_phase(pph[4], w, B);      // Toom-Cook (m = 2) / Karatsuba operand sums (empty when unused)
+    const ToomPlan& tk = q.pplan.toom;
+    if (tk.E) {                   // Toom-Cook, 3 <= m <= 8: the ciphertext polynomial at +-1 .. +-(m-1)
+      ToomPointsArgs ta{w.P.p, w.J.p, w.Bpad, m, n, l.shuf, tk.cv_first};
+      MP_RUN(k_toom_points, C, B, 2 * n, ta);
+      normalize_flat(w.J.p + j_off<C>(tk.cv_first, w.Bpad, 0), w.P.p + p_off<C>(tk.cv_first, w.Bpad, 0), w.NS.p,
+                     (size_t)(tk.E - 2) * 2 * n * w.Bpad);
+    }
     {
       FsStatementArgs a = statement_args(w, l.deck, l.shuf, l.cA, l.x, keyed ? l.pk : NO_SLOT);
       MP_RUN(k_fs_round1, C, B, 1, a);
     }
-    ProveScalArgs sc{w.S.p, perm, l, w.Bpad, q.lin.p, q.lin_src.p, (uint32_t)q.pplan.lin.size()};
+    ProveScalArgs sc{w.S.p, perm, l, w.Bpad, q.lin.p, q.lin_src.p, tk.E ? 0u : (uint32_t)q.pplan.lin.size()};
     MP_RUN(k_prove_scal1, C, B, 1, sc);
+    if (tk.E) {                   // the scalar polynomial at the same points; the interpolation matrix as MSM scalars
+      LinCombArgs la{w.S.p, q.lin.p, q.lin_src.p, q.lin_coef.p, q.consts.p, w.Bpad, n};
+      MP_RUN(k_lin_comb, C, B, (uint32_t)q.pplan.lin.size() * n, la);
+      FillConstArgs fa{w.S.p, q.consts.p, w.Bpad, tk.w_first, tk.w_const_first};
+      MP_RUN(k_fill_consts, C, B, tk.E * tk.E, fa);
+    }
     run_phase(pph[1], w, B);
+    run_phase(pph[5], w, B);      // Toom-Cook interpolation: the diagonals E_k from the 2m products (empty otherwise)
     const FsDev f{w.stage.p, w.seed.p, w.Bpad};
     {
       FsRoundArgs a{};
@@ -696,7 +781,7 @@ struct Table : mp_table {
       bucket_terms += ph.bterms.size();
       bucket_jobs += ph.bjobs.size();
     };
-    for (int i = 0; i < 5; ++i) add(ps[0].pplan.ph[i], out);
+    for (int i = 0; i < 6; ++i) add(ps[0].pplan.ph[i], out);
     add(merged_verify ? ps[0].vplan.mph : ps[0].vplan.ph, out + 6);    // what an honest batch executes
     out[12] = nwin; out[13] = fbg.windows; out[14] = N;
     out[15] = bucket_terms | (bucket_jobs << 32);      // variable-base terms / MSMs on the bucket kernel (prove + verify)
@@ -787,7 +872,7 @@ struct Table : mp_table {
       ops += (uint64_t)ph.bjobs.size() * bk_windows(R::BITS) * (14 + BK_BITS + 1);   // wave-wide reduction + fold
     };
     uint64_t t = 0, o = 0;
-    for (int i = 0; i < 5; ++i) count(ps[0].pplan.ph[i], t, o);
+    for (int i = 0; i < 6; ++i) count(ps[0].pplan.ph[i], t, o);
     t += 2 * N;
     o += (uint64_t)2 * N * (fbg.windows + 1);  // remask
     *pt = t; *po = o;

@@ -487,6 +487,59 @@ MP_HD void body_normalize(const NormArgs& a, uint32_t x, uint32_t y) {
 }
 MP_KERNEL(k_normalize, NormArgs, body_normalize)
 
+// ---- Toom-Cook, ciphertext side: C(x) = sum_s x^s c_s at x = +-1 .. +-(m-1) for one column point of the shuffled deck
+// (c_s = row m - s; x = proof, y = 2 t + component).  Even / odd split: C(+-x) = Ce(x^2) +- x Co(x^2), Horner in x^2; the small
+// integer multiples are double-and-add chains on Jacobian points (x <= 7: at most 5 doublings + 2 additions per multiple).
+// Jacobian out -> k_normalize -> the operand vectors of the 2m - 2 products.
+struct ToomPointsArgs {
+  const uint32_t* P;
+  uint32_t* J;
+  uint32_t Bpad, m, n, p_shuf, cv_first;
+};
+template <class C>
+MP_HD void jac_mul_small_ip(Jac<C>& p, uint32_t k) {      // p <- k p, 1 <= k < 64
+  if (k == 1) return;
+  const Jac<C> base = p;
+  int top = 5;
+  while (!((k >> top) & 1u)) --top;
+  for (int i = top - 1; i >= 0; --i) {
+    jac_dbl_ip<C>(p);
+    if ((k >> i) & 1u) jac_add_ip<C>(p, base);
+  }
+}
+template <class C>
+MP_HD void body_toom_points(const ToomPointsArgs& a, uint32_t b, uint32_t y) {
+  const uint32_t t = y >> 1, comp = y & 1u, m = a.m;
+  // c_s at P slot p_shuf + 2 ((m - 1 - s) n + t) + comp
+  auto cs = [&](uint32_t s) { return ld_aff<C>(a.P + p_off<C>(a.p_shuf + 2 * ((m - 1 - s) * a.n + t) + comp, a.Bpad, b)); };
+  const uint32_t top_even = (m - 1) & ~1u, top_odd = ((m - 1) & 1u) ? m - 1 : m - 2;      // m >= 3: both exist
+#pragma unroll 1
+  for (uint32_t x = 1; x < m; ++x) {
+    const uint32_t yy = x * x;
+    Jac<C> ce = jac_from_aff<C>(cs(top_even));
+#pragma unroll 1
+    for (int s = (int)top_even - 2; s >= 0; s -= 2) {
+      jac_mul_small_ip<C>(ce, yy);
+      jac_madd_ip<C>(ce, cs((uint32_t)s));
+    }
+    Jac<C> co = jac_from_aff<C>(cs(top_odd));
+#pragma unroll 1
+    for (int s = (int)top_odd - 2; s >= 1; s -= 2) {
+      jac_mul_small_ip<C>(co, yy);
+      jac_madd_ip<C>(co, cs((uint32_t)s));
+    }
+    jac_mul_small_ip<C>(co, x);
+    Jac<C> plus = ce;
+    jac_add_ip<C>(plus, co);
+    co.Y = fe_neg<typename C::FqP>(co.Y);
+    jac_add_ip<C>(ce, co);
+    // e = 2x (+x) and 2x + 1 (-x); vectors of 2n points each, e >= 2
+    st_jac<C>(a.J + j_off<C>(a.cv_first + (2 * x - 2) * 2 * a.n + y, a.Bpad, b), plus);
+    st_jac<C>(a.J + j_off<C>(a.cv_first + (2 * x - 1) * 2 * a.n + y, a.Bpad, b), ce);
+  }
+}
+MP_KERNEL_OCC(k_toom_points, ToomPointsArgs, body_toom_points, 2)
+
 // ---- subgroup membership of wire points on a curve with a cofactor (BLS12-377 G1): [q]P == O, q = the prime group order.
 // wire_to_aff only proves "on the curve"; the batched-affine tables and the completeness rules of the group law assume the
 // prime-order subgroup, and an off-subgroup component of small order would pass an equation with probability ~1/order.  This is
@@ -585,6 +638,7 @@ MP_KERNEL(k_fb_widen, FbWidenArgs, body_fb_widen)
   MP_KERNEL_INST(X, k_fb_windows, FbWinArgs, C) \
   MP_KERNEL_INST(X, k_fb_fill, FbFillArgs, C) \
   MP_KERNEL_INST(X, k_fb_widen, FbWidenArgs, C) \
-  MP_KERNEL_INST(X, k_subgroup_check, SubgroupArgs, C)
+  MP_KERNEL_INST(X, k_subgroup_check, SubgroupArgs, C) \
+  MP_KERNEL_INST(X, k_toom_points, ToomPointsArgs, C)
 
 }  // namespace mp

@@ -389,6 +389,42 @@ MP_HD void body_prove_scal1(const ProveScalArgs& a, uint32_t b, uint32_t y) {
 }
 MP_KERNEL(k_prove_scal1, ProveScalArgs, body_prove_scal1)
 
+// ---- Toom-Cook operands (3 <= m <= 8, layout.hpp ToomPlan) ---------------------------------------------------------------
+// scalar side: S[dst + t] = sum_i consts[coef_i] * S[src_i + t]   (x = proof, y = job * n + t: one lane per output scalar)
+struct LinCombArgs {
+  uint32_t* S;
+  const LinJob* lin;
+  const uint32_t* lin_src;
+  const uint32_t* lin_coef;
+  const uint32_t* consts;     // Fr constants, Montgomery, 8 words each
+  uint32_t Bpad, n;
+};
+template <class C>
+MP_HD void body_lin_comb(const LinCombArgs& a, uint32_t b, uint32_t y) {
+  typedef typename C::FrP R;
+  const LinJob lj = a.lin[y / a.n];
+  const uint32_t t = y % a.n;
+  Fe<R> acc = fe_zero<R>();
+  for (uint32_t i = 0; i < lj.count; ++i) {
+    const Fe<R> c = ld_fe<R>(a.consts + (size_t)a.lin_coef[lj.begin + i] * 8);
+    acc = fe_add<R>(acc, fe_mul<R>(c, ld_fe<R>(a.S + s_off(a.lin_src[lj.begin + i] + t, a.Bpad, b))));
+  }
+  st_fe<R>(a.S + s_off(lj.dst + t, a.Bpad, b), acc);
+}
+MP_KERNEL(k_lin_comb, LinCombArgs, body_lin_comb)
+// constants into S slots (the interpolation matrix as ordinary MSM scalars): x = proof, y = constant
+struct FillConstArgs {
+  uint32_t* S;
+  const uint32_t* consts;
+  uint32_t Bpad, s_first, c_first;
+};
+template <class C>
+MP_HD void body_fill_consts(const FillConstArgs& a, uint32_t b, uint32_t y) {
+  typedef typename C::FrP R;
+  st_fe<R>(a.S + s_off(a.s_first + y, a.Bpad, b), ld_fe<R>(a.consts + (size_t)(a.c_first + y) * 8));
+}
+MP_KERNEL(k_fill_consts, FillConstArgs, body_fill_consts)
+
 // after y, z: d - z, t, Hadamard partial products, single-value-product first-message vectors
 template <class C>
 MP_HD void body_prove_scal2(const ProveScalArgs& a, uint32_t b, uint32_t y_) {

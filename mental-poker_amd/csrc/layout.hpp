@@ -314,12 +314,28 @@ struct LinJob {
   uint32_t dst, begin, count;
 };
 
+// Toom-Cook evaluation of the multi-exponentiation diagonals for 3 <= m <= TOOM_MAX_M (see make_prove_plan): 2m evaluation
+// points x_e -- e = 0: X = 0, e = 1: X = infinity, e = 2x / 2x + 1: X = +x / -x for x = 1 .. m - 1.
+struct ToomPlan {
+  uint32_t E = 0;                 // number of evaluation points (2m), 0 = not used
+  uint32_t sv_first = 0;          // S slots of the evaluated scalar vectors, e >= 2: sv_first + (e - 2) n
+  uint32_t cv_first = 0;          // P slots of the evaluated ciphertext vectors, e >= 2: cv_first + (e - 2) 2n
+  uint32_t pp_first = 0;          // P slots of the 2m products (2 components each): pp_first + 2 e + c
+  uint32_t w_first = 0;           // S slots of the interpolation matrix W[k][e] (constants): w_first + k E + e
+  // constants the engine computes in Fr (layout.hpp has no field arithmetic): index e (m + 1) + j = x_e^j, then W row-major
+  uint32_t n_consts = 0, w_const_first = 0;
+  int32_t x_of(uint32_t e) const { return e < 2 ? 0 : ((e & 1) ? -(int32_t)(e / 2) : (int32_t)(e / 2)); }
+};
+static const uint32_t TOOM_MAX_M = 8;
+// S[dst + t] = sum_i C_i S[src_i + t] with constant coefficients C_i = consts[lin_coef_i] (kernel k_lin_comb)
 struct ProvePlan {
   ProveLay lay;
   std::vector<LinJob> lin;
   std::vector<uint32_t> lin_src;
-  Phase ph[5];          // A (cA), B (cB + multi-exp first message), C (product first messages), D (zero argument),
-                        // [4] = A2: Toom-Cook base sums, run between A and B
+  std::vector<uint32_t> lin_coef;     // per source: index into the constant table (Toom-Cook), empty = plain sums (Karatsuba)
+  ToomPlan toom;
+  Phase ph[6];          // A (cA), B (cB + multi-exp first message), C (product first messages), D (zero argument),
+                        // [4] = A2: Toom-Cook / Karatsuba operand sums, run between A and B; [5] = B2: Toom-Cook interpolation
   uint32_t nJ;          // J arena slots (nP + partial sums)
   std::vector<uint32_t> draws;
   std::vector<ProofElem> wire;
@@ -409,11 +425,37 @@ static inline std::vector<KLeaf> k_merge(const std::vector<KLeaf>& in) {
 // keyed: the aggregate key is a per-proof point (P slot lay.pk) instead of the table's fixed base: its terms become
 // variable-base terms (the re-encryption uses the key's own window tables, kernels_msm.hpp body_remask)
 static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk, uint32_t point_bytes = 64,
-                                        bool keyed = false, uint32_t bucket_min = 0, uint32_t bwin = 0) {
+                                        bool keyed = false, uint32_t bucket_min = 0, uint32_t bwin = 0, bool toom_cook = true) {
   ProvePlan pl;
   pl.lay = make_prove_lay(m, n);
   pl.lay.toom = m == 2 ? 1u : 0u;
-  const bool karatsuba = m >= 3;
+  // 3 <= m <= 8: Toom-Cook with the 2m points 0, inf, +-1 .. +-(m-1): 2m row products instead of Karatsuba's 13 (m = 4) / 35
+  // (m = 8).  The ciphertext polynomial is evaluated with doublings and additions only (small integer points), the scalar
+  // polynomial in Fr, and the coefficients E_k come back through the inverse Vandermonde matrix over Fr (phase B2: one
+  // 2m-term MSM per diagonal over the 2m normalised products) -- the same group elements, so the proof bytes do not change.
+  const bool toomk = toom_cook && m >= 3 && m <= TOOM_MAX_M;
+  const bool karatsuba = m >= 3 && !toomk;
+  if (toomk) {
+    ToomPlan& T = pl.toom;
+    T.E = 2 * m;
+    T.sv_first = pl.lay.nS;
+    pl.lay.nS += (T.E - 2) * n;
+    T.w_first = pl.lay.nS;
+    pl.lay.nS += T.E * T.E;
+    T.cv_first = pl.lay.nP;
+    pl.lay.nP += (T.E - 2) * 2 * n;
+    T.pp_first = pl.lay.nP;
+    pl.lay.nP += 2 * T.E;
+    T.w_const_first = T.E * (m + 1);
+    T.n_consts = T.w_const_first + T.E * T.E;
+    for (uint32_t e = 2; e < T.E; ++e) {          // A(x_e) = sum_j x_e^j a_j
+      pl.lin.push_back(LinJob{T.sv_first + (e - 2) * n, (uint32_t)pl.lin_src.size(), m + 1});
+      for (uint32_t j = 0; j <= m; ++j) {
+        pl.lin_src.push_back(j == 0 ? pl.lay.mea0 : pl.lay.b + (j - 1) * n);
+        pl.lin_coef.push_back(e * (m + 1) + j);
+      }
+    }
+  }
   // Karatsuba plan: leaves, operand vectors (new S / P slots appended to the layout)
   std::vector<KLeaf> leaves;
   std::map<std::vector<uint32_t>, uint32_t> svec, cvec;     // handle -> first S slot / first P slot
@@ -528,6 +570,18 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
           B.end(true);
         }
       }
+    } else if (toomk) {
+      // the 2m products <A(x_e), C(x_e)> (two components each), normalised at the end of this phase; the diagonals: phase B2
+      const ToomPlan& T = pl.toom;
+      for (uint32_t e = 0; e < T.E; ++e)
+        for (uint32_t c = 0; c < 2; ++c) {
+          const uint32_t sv = e == 0 ? l.mea0 : (e == 1 ? l.b + (m - 1) * n : T.sv_first + (e - 2) * n);
+          const uint32_t cv = e == 0 ? l.shuf + 2 * (m - 1) * n : (e == 1 ? l.shuf : T.cv_first + (e - 2) * 2 * n);
+          B.begin(T.pp_first + 2 * e + c);
+          for (uint32_t t = 0; t < n; ++t) B.var(sv + t, cv + 2 * t + c);
+          B.end();
+        }
+      B.normalize(T.pp_first, 2 * T.E);
     } else if (karatsuba) {
       for (uint32_t c = 0; c < 2; ++c) {
         std::vector<uint32_t> part(leaves.size());
@@ -576,7 +630,30 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
     }
     }
     B.normalize(l.cB, m);
-    B.normalize(l.mecA0, 1 + 2 * m + 4 * m);
+    B.normalize(l.mecA0, toomk ? 1 + 2 * m : 1 + 2 * m + 4 * m);
+  }
+  if (toomk) {  // phase B2: E_k = E(b_k gen; tau_k) + sum_e W[k][e] P_e  (E_0 = P_0 and E_{2m-1} = P_inf exactly)
+    const ToomPlan& T = pl.toom;
+    PhaseBuilder B(pl.ph[5], next_partial, fchunk, vchunk, bucket_min, bwin);
+    for (uint32_t k = 0; k < 2 * m; ++k)
+      for (uint32_t c = 0; c < 2; ++c) {
+        B.begin(l.meE + 2 * k + c);
+        if (c == 0) {
+          B.fixed(l.metau + k, fb.G());
+        } else {
+          B.fixed(l.meb + k, fb.gen());
+          if (keyed) B.var(l.metau + k, l.pk); else B.fixed(l.metau + k, fb.pk());
+        }
+        if (k == 0) {
+          B.addend(T.pp_first + c);
+        } else if (k == 2 * m - 1) {
+          B.addend(T.pp_first + 2 + c);
+        } else {
+          for (uint32_t e = 0; e < T.E; ++e) B.var(T.w_first + k * T.E + e, T.pp_first + 2 * e + c);
+        }
+        B.end();
+      }
+    B.normalize(l.meE, 4 * m);
   }
   {  // phase C: product-argument first messages that do not depend on later challenges
     PhaseBuilder B(pl.ph[2], next_partial, fchunk, vchunk, bucket_min, bwin);

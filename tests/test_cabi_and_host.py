@@ -355,3 +355,25 @@ def test_bucket_msm_edge_scalars_under_emulation(emu, coracle):
     assert t.msm(1, K, same, bytes(pts)) == coracle.msm(cvn, same, bytes(pts))
     zero = bytes(32 * K)
     assert t.msm(1, K, zero, bytes(pts)) == bytes(64)
+
+
+@pytest.mark.parametrize("name", ["shuffle_stark_m3_n4_s11.json", "shuffle_stark_m4_n13_s9.json", "shuffle_secp256k1_m3_n3_s5.json"])
+def test_toom_cook_and_karatsuba_give_the_same_proof(emu, name):
+    """3 <= m <= 8: the diagonals of the multi-exponentiation argument through Toom-Cook (2m products, evaluation at small integer
+    points, interpolation over Fr) and through recursive Karatsuba are the same group elements -- identical proof bytes"""
+    g = load_json(os.path.join(GOLDEN, name))
+    eng = emu(g["curve"])
+    m, n = g["m"], g["n"]
+    t = eng.table(m, n, bytes.fromhex(g["params"]), bytes.fromhex(g["pk"]))
+    args = (bytes.fromhex(g["deck"]), bytes.fromhex(g["rho"]), g["perm"], bytes.fromhex(g["prover_seed"]))
+    for on in (True, False):
+        t.set_toom_cook(on)
+        for latency_batch in (0, 8192):
+            t.set_latency_batch(latency_batch)
+            eng.profile_enable(True)
+            deck, proof = t.shuffle_and_remask(*args)
+            rep = eng.profile_report()
+            eng.profile_enable(False)
+            assert deck.hex() == g["shuffled"] and proof.hex() == g["proof"]
+            assert ("k_toom_points" in rep) == on and ("k_lin_comb" in rep) == on
+            assert t.verify_shuffle(args[0], deck, proof) == 0
