@@ -614,7 +614,8 @@ def main():
     traffic, traffic_src = None, None
     pmc_path, pmc = find_pmc_summary(src_hash, curve, m, n, B, workload)
     if pmc and dom_name in pmc.get("kernels", {}):
-        traffic = pmc["kernels"][dom_name]["hbm_bytes_per_proof_per_step_corrected"] * (total_proofs / world) / dom_count
+        e_ = pmc["kernels"][dom_name]
+        traffic = e_.get("hbm_bytes_per_proof_per_step", e_["hbm_bytes_per_proof_per_step_corrected"]) * (total_proofs / world) / dom_count
         traffic_src = pmc_path
     roofline = {
         "bound": "hbm", "kernel": dom_name, "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

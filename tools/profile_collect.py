@@ -20,6 +20,11 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# FETCH_SIZE -> bytes: x2 for wide coalesced streams (MI355X_MICROARCH.md, "HBM"); x1 for the 64-byte gathers of k_var_msm, calibrated
+# on its exactly known table reads (profiles/r02_fetch_calibration.txt: raw / expected = 0.955 on seven launches of three shapes);
+# k_remask likewise (raw 92.8 KB per proof against 104 x 13 entries + 104 deck points = 93.2 KB); k_fixed_msm and k_bucket_msm gather
+# 64-byte entries / points the same way (k_fixed_msm: raw 251 KB against <= 320 KB of table entries, some of them L2 hits)
+FETCH_CAL = {"k_var_msm": 1.0, "k_bucket_msm": 1.0, "k_remask": 1.0, "k_fixed_msm": 1.0}
 
 
 def kname(s):
@@ -94,7 +99,9 @@ def main():
         kernels = {}
         for k in sorted(F, key=lambda k: -(2 * F[k][0] + W.get(k, [0, 0])[0])):
             f, w = F[k][0], W.get(k, [0.0, 0])[0]
-            e = {"dispatches": F[k][1], "fetch_kb_total": f, "write_kb_total": w,
+            cal = FETCH_CAL.get(k, 2.0)
+            e = {"dispatches": F[k][1], "fetch_kb_total": f, "write_kb_total": w, "fetch_calibration": cal,
+                 "hbm_bytes_per_proof_per_step": (cal * f + w) * 1024 / batch / passes,
                  "hbm_bytes_per_proof_per_step_corrected": (2 * f + w) * 1024 / batch / passes,
                  "hbm_bytes_per_proof_per_step_raw": (f + w) * 1024 / batch / passes}
             for c, per in SQ.items():
@@ -104,8 +111,10 @@ def main():
         wl = pb["config"]["workload"]
         mm = re.search(r"m=(\d+) n=(\d+), (\w+) curve", wl)
         meta = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ set in separate passes of `python bench.py --no-cpu-baseline "
-                         "<args> --steps 1 --warmup 0` (tools/profile_round.sh); TCC counters in KB; corrected = (2 FETCH + WRITE) KB "
-                         "(gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x, MI355X_MICROARCH.md); per proof per prove+verify step; "
+                         "--no-extras <args> --steps 1 --warmup 0` (tools/profile_round.sh); TCC counters in KB; hbm_bytes_per_proof_per_step = "
+                         "(fetch_calibration x FETCH + WRITE) KB: x2 for wide coalesced reads (gfx950 FETCH_SIZE under-reports them, "
+                         "MI355X_MICROARCH.md), x1 for the 64-byte gathers of k_var_msm (profiles/r02_fetch_calibration.txt); `_corrected` = x2 "
+                         "for every kernel (round 1's convention); per proof per prove+verify step; "
                          "SQ_* = per-launch averages (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES / SQ_WAIT_* count quad-cycles)",
                 "engine_src": pb["roofline"].get("engine_src") or (sys.argv[2] if len(sys.argv) > 2 else None),
                 "workload": wl.split(":")[0] if ":" in wl else "pairs",
@@ -119,7 +128,7 @@ def main():
                 extra = "  VALU insts/launch %.3g  wave-cycles %.3g  wait_any %.3g  wait_inst %.3g" % (
                     v["SQ_INSTS_VALU_per_launch"], v.get("SQ_WAVE_CYCLES_per_launch", 0), v.get("SQ_WAIT_ANY_per_launch", 0),
                     v.get("SQ_WAIT_INST_ANY_per_launch", 0))
-            print("%-16s %9.1f KB/proof/step (corrected)%s" % (k, v["hbm_bytes_per_proof_per_step_corrected"] / 1024, extra))
+            print("%-16s %9.1f KB/proof/step (FETCH x %.0f + WRITE)%s" % (k, v["hbm_bytes_per_proof_per_step"] / 1024, v["fetch_calibration"], extra))
 
 
 if __name__ == "__main__":
