@@ -27,6 +27,11 @@ def main():
     ap.add_argument("--curve", default="bls12_377")
     ap.add_argument("--batch", type=int, default=256, help="proofs in flight for the throughput column")
     ap.add_argument("--cpu", action="store_true", help="also time the CPU port (oracle) on the same inputs")
+    ap.add_argument("--subgroup-check", action="store_true",
+                    help="keep the engine's per-call subgroup test of every wire point on (BLS12-377 has a cofactor).  The reference times "
+                         "shuffle_and_remask on values that arkworks validated when they were deserialised, i.e. outside its timed region; "
+                         "here the inputs come from the engine's own setup, so the harness switches the test off like a caller with validated points would")
+    ap.add_argument("--karatsuba", action="store_true", help="3 <= m <= 8: recursive Karatsuba also in the throughput plans (the small-batch plans always use it)")
     args = ap.parse_args()
     cards = mp.DLCards(args.curve, device=0)
     can = mp.canonical
@@ -49,7 +54,10 @@ def main():
                                                     "proof (B)", "wire (B)", " | CPU prove (s)" if args.cpu else ""))
     for m, n in PAIRS:
         pp = cards.setup(fresh(), m, n)
-        cards.shuffle_and_remask(fresh(), pp, shared_key, deck, factors, permutation)        # builds the table, warms up
+        t = cards.table(pp, shared_key)                                                      # builds the table
+        t.set_subgroup_check(args.subgroup_check)
+        t.set_toom_cook(not args.karatsuba)
+        cards.shuffle_and_remask(fresh(), pp, shared_key, deck, factors, permutation)        # warms up
         seed = fresh()
         t0 = time.perf_counter()
         shuffled, proof = cards.shuffle_and_remask(seed, pp, shared_key, deck, factors, permutation)

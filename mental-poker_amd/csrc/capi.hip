@@ -22,6 +22,51 @@ using namespace mp;
   catch (const std::invalid_argument& e) { return fail(MP_ERR_BAD_ENCODING, e.what()); } \
   catch (const std::exception& e) { return fail(MP_ERR_INTERNAL, e.what()); }
 
+// ---- canonical (arkworks-0.3 compressed) serialisation of the trait's associated types: host work, no context ---------------
+namespace {
+long ser_points(int curve, bool de, size_t count, const uint8_t* in, uint8_t* out) {
+  switch (curve) {
+    case 0: return ser_points_Stark(de, count, in, out);
+    case 1: return ser_points_Bn254(de, count, in, out);
+    case 3: return ser_points_Bls12_377(de, count, in, out);
+    default: return ser_points_Secp256k1(de, count, in, out);
+  }
+}
+bool ser_scalars_ok(int curve, size_t count, const uint8_t* in) {
+  switch (curve) {
+    case 0: return ser_scalars_ok_Stark(count, in);
+    case 1: return ser_scalars_ok_Bn254(count, in);
+    case 3: return ser_scalars_ok_Bls12_377(count, in);
+    default: return ser_scalars_ok_Secp256k1(count, in);
+  }
+}
+const int kCurveBits[4] = {252, 254, 256, 377};
+// element groups of the shuffle proof in wire order: {points?, count, is_vec, vec_len}
+struct Group {
+  bool point;
+  uint32_t count;
+  bool vec;
+  uint32_t vec_len;
+};
+std::vector<Group> proof_schema(uint32_t m, uint32_t n) {
+  return {
+      {true, m, true, m}, {true, m, true, m}, {true, 1, false, 0}, {true, m, true, m},
+      {true, 1, false, 0}, {true, 1, false, 0}, {true, 2 * m + 1, true, 2 * m + 1},
+      {false, n, true, n}, {false, n, true, n}, {false, 1, false, 0}, {false, 1, false, 0}, {false, 1, false, 0},
+      {true, 1, false, 0}, {true, 1, false, 0}, {true, 1, false, 0},
+      {false, n, true, n}, {false, n, true, n}, {false, 1, false, 0}, {false, 1, false, 0},
+      {true, 1, false, 0}, {true, 2 * m, true, 2 * m}, {true, 4 * m, true, 2 * m},      // E: 2m ciphertexts = 4m points
+      {false, n, true, n}, {false, 1, false, 0}, {false, 1, false, 0}, {false, 1, false, 0}, {false, 1, false, 0}};
+}
+void put_u64(uint8_t* p, uint64_t v) { memcpy(p, &v, 8); }
+uint64_t get_u64(const uint8_t* p) {
+  uint64_t v;
+  memcpy(&v, p, 8);
+  return v;
+}
+bool curve_ok(int c) { return c >= 0 && c <= 3; }
+}  // namespace
+
 extern "C" {
 
 const char* mp_last_error(void) { return mp::last_error().c_str(); }
@@ -481,50 +526,7 @@ int mp_plan_stats(mp_table* t, uint64_t out[16]) {
 }
 
 
-// ---- canonical (arkworks-0.3 compressed) serialisation of the trait's associated types: host work, no context ---------------
-namespace {
-long ser_points(int curve, bool de, size_t count, const uint8_t* in, uint8_t* out) {
-  switch (curve) {
-    case 0: return ser_points_Stark(de, count, in, out);
-    case 1: return ser_points_Bn254(de, count, in, out);
-    case 3: return ser_points_Bls12_377(de, count, in, out);
-    default: return ser_points_Secp256k1(de, count, in, out);
-  }
-}
-bool ser_scalars_ok(int curve, size_t count, const uint8_t* in) {
-  switch (curve) {
-    case 0: return ser_scalars_ok_Stark(count, in);
-    case 1: return ser_scalars_ok_Bn254(count, in);
-    case 3: return ser_scalars_ok_Bls12_377(count, in);
-    default: return ser_scalars_ok_Secp256k1(count, in);
-  }
-}
-const int kCurveBits[4] = {252, 254, 256, 377};
-// element groups of the shuffle proof in wire order: {points?, count, is_vec, vec_len}
-struct Group {
-  bool point;
-  uint32_t count;
-  bool vec;
-  uint32_t vec_len;
-};
-std::vector<Group> proof_schema(uint32_t m, uint32_t n) {
-  return {
-      {true, m, true, m}, {true, m, true, m}, {true, 1, false, 0}, {true, m, true, m},
-      {true, 1, false, 0}, {true, 1, false, 0}, {true, 2 * m + 1, true, 2 * m + 1},
-      {false, n, true, n}, {false, n, true, n}, {false, 1, false, 0}, {false, 1, false, 0}, {false, 1, false, 0},
-      {true, 1, false, 0}, {true, 1, false, 0}, {true, 1, false, 0},
-      {false, n, true, n}, {false, n, true, n}, {false, 1, false, 0}, {false, 1, false, 0},
-      {true, 1, false, 0}, {true, 2 * m, true, 2 * m}, {true, 4 * m, true, 2 * m},      // E: 2m ciphertexts = 4m points
-      {false, n, true, n}, {false, 1, false, 0}, {false, 1, false, 0}, {false, 1, false, 0}, {false, 1, false, 0}};
-}
-void put_u64(uint8_t* p, uint64_t v) { memcpy(p, &v, 8); }
-uint64_t get_u64(const uint8_t* p) {
-  uint64_t v;
-  memcpy(&v, p, 8);
-  return v;
-}
-bool curve_ok(int c) { return c >= 0 && c <= 3; }
-}  // namespace
+// ---- canonical serialisation entry points (helpers: above the extern "C" block)
 
 size_t mp_serialized_point_size(int curve_id) { return curve_ok(curve_id) ? (size_t)(kCurveBits[curve_id] + 2 + 7) / 8 : 0; }
 size_t mp_serialized_deck_size(int curve_id, size_t cards) { return 8 + 2 * cards * mp_serialized_point_size(curve_id); }

@@ -255,7 +255,9 @@ struct Table : mp_table {
       // (windows x 64 lanes per MSM) already pays from 128 terms on -- the merged verifier equation of a 52-card proof has 239
       // (one proof: verify 4.4 -> 3.6 ms, profiles/r02_latency.txt)
       const uint32_t bmin = (bucket_min && (k == 1 || k == 3)) ? std::min(bucket_min, BUCKET_MIN_SMALL_BATCH) : bucket_min;
-      q.pplan = make_prove_plan(m, n, fch[k], vch[k], G_::PB, keyed, bmin, bk_windows(R::BITS), toom_cook);
+      // Toom-Cook adds two dependent stages (operand evaluation, interpolation): a win when the batch fills the chip (throughput and
+      // medium plans), a loss for a handful of proofs, where the small-batch plans keep Karatsuba (BLS12-377 (6,50), one proof: 78 vs 94 ms)
+      q.pplan = make_prove_plan(m, n, fch[k], vch[k], G_::PB, keyed, bmin, bk_windows(R::BITS), toom_cook && (k == 0 || k == 2));
       q.vplan = make_verify_plan(m, n, fch[k], vch[k], G_::PB, keyed, bmin, bk_windows(R::BITS));
       q.table_group = grp[k];
       q.norm_chunk = nch[k];       // fewer points per serial inversion chain when lanes are idle

@@ -281,7 +281,7 @@ MP_HD void body_bucket_fold(const BFoldArgs& a, uint32_t b, uint32_t y) {
   }
   st_jac<C>(a.J + j_off<C>(job.out, a.Bpad, b), acc);
 }
-MP_KERNEL_OCC(k_bucket_fold, BFoldArgs, body_bucket_fold, 4)
+MP_KERNEL_OCC(k_bucket_fold, BFoldArgs, body_bucket_fold, Geo<C>::OCC4)
 
 #define MP_BUCKET_KERNELS(X, C)                          \
   MP_KERNEL_INST(X, k_bucket_recode, BRecodeArgs, C)     \

@@ -24,6 +24,11 @@ namespace mp {
 // an affine point 2 FW, a Jacobian point 3 FW; a scalar (Fr) is 8 words on every supported curve.
 template <class C>
 struct Geo {
+  // waves per SIMD the group-arithmetic kernels are compiled for: 4 (128 VGPRs) on the 256-bit curves; the 12-word base field of
+  // BLS12-377 needs > 200 registers for an XYZZ accumulator plus the temporaries of one addition, i.e. 2 waves -- asking for 4
+  // there only made the compiler spill and warn
+  static constexpr int OCC4 = C::FqP::NW > 8 ? 2 : 4;
+  static constexpr int OCC3 = C::FqP::NW > 8 ? 2 : 3;
   static constexpr uint32_t FW = C::FqP::NW;
   static constexpr uint32_t PW = 2 * FW;
   static constexpr uint32_t JW = 3 * FW;
@@ -136,7 +141,7 @@ MP_HD void body_fixed_msm(const FixedArgs& a, uint32_t b, uint32_t y) {
   }
   st_jac<C>(a.J + j_off<C>(job.out, a.Bpad, b), xyzz_to_jac<C>(acc));
 }
-MP_KERNEL_OCC(k_fixed_msm, FixedArgs, body_fixed_msm, 4)
+MP_KERNEL_OCC(k_fixed_msm, FixedArgs, body_fixed_msm, Geo<C>::OCC4)
 
 // ---- re-encryption (remask) -------------------------------------------------------------------------
 struct RemaskArgs {
@@ -190,7 +195,7 @@ MP_HD void body_remask(const RemaskArgs& a, uint32_t b, uint32_t y) {
   xyzz_madd_ip<C>(acc, ld_aff<C>(a.P + p_off<C>(a.p_deck + 2 * src + comp, a.Bpad, b)));
   st_jac<C>(a.J + j_off<C>(a.j_out + y, a.Bpad, b), xyzz_to_jac<C>(acc));
 }
-MP_KERNEL_OCC(k_remask, RemaskArgs, body_remask, 4)
+MP_KERNEL_OCC(k_remask, RemaskArgs, body_remask, Geo<C>::OCC4)
 
 // ---- window bases of a per-proof key: W_w = 2^(5w) * pk, w < nwin (lane = proof; Jacobian out -> normalise -> k_table)
 struct KeyWinArgs {
@@ -383,7 +388,7 @@ MP_HD void body_table(const TableArgs& a, uint32_t b, uint32_t y) {
     }
   }
 }
-MP_KERNEL_OCC(k_table, TableArgs, body_table, 3)
+MP_KERNEL_OCC(k_table, TableArgs, body_table, Geo<C>::OCC3)
 
 // ---- variable-base MSM (Straus) -----------------------------------------------------------------------
 struct VarArgs {
@@ -418,7 +423,7 @@ MP_HD void body_var_msm(const VarArgs& a, uint32_t b, uint32_t y) {
   }
   st_jac<C>(a.J + j_off<C>(job.out, a.Bpad, b), xyzz_to_jac<C>(acc));
 }
-MP_KERNEL_OCC(k_var_msm, VarArgs, body_var_msm, 4)
+MP_KERNEL_OCC(k_var_msm, VarArgs, body_var_msm, Geo<C>::OCC4)
 
 // ---- combine partial sums ---------------------------------------------------------------------------
 struct CombineArgs {
@@ -446,7 +451,7 @@ MP_HD void body_combine(const CombineArgs& a, uint32_t b, uint32_t y) {
   }
   st_jac<C>(a.J + j_off<C>(job.out, a.Bpad, b), acc);
 }
-MP_KERNEL_OCC(k_combine, CombineArgs, body_combine, 4)
+MP_KERNEL_OCC(k_combine, CombineArgs, body_combine, Geo<C>::OCC4)
 
 // ---- batch normalisation Jacobian -> affine (Montgomery's trick, one inversion per `chunk` points) ----
 // Works on FLAT arrays: element e of the source is 24 words at src + 24 e; a slot range of an arena is

@@ -375,5 +375,6 @@ def test_toom_cook_and_karatsuba_give_the_same_proof(emu, name):
             rep = eng.profile_report()
             eng.profile_enable(False)
             assert deck.hex() == g["shuffled"] and proof.hex() == g["proof"]
-            assert ("k_toom_points" in rep) == on and ("k_lin_comb" in rep) == on
+            uses_toom = on and latency_batch == 0         # the small-batch plans keep Karatsuba (fewer dependent stages)
+            assert ("k_toom_points" in rep) == uses_toom and ("k_lin_comb" in rep) == uses_toom
             assert t.verify_shuffle(args[0], deck, proof) == 0
