@@ -204,6 +204,9 @@ def main():
                     help="variable-base MSMs of at least this many terms run on the bucket-method kernel (engine default 2048; 0 = never)")
     ap.add_argument("--per-equation", action="store_true", help="verify equation by equation (mp_set_merged_verify off)")
     ap.add_argument("--players", type=int, default=32, help="chain32: shuffles per table")
+    ap.add_argument("--per-link-verify", action="store_true",
+                    help="chain32: verify every link on its own (mp_verify_shuffle_batch_keys_dev) instead of one chain equation per table "
+                         "(mp_verify_shuffle_chain_dev)")
     ap.add_argument("--digest", action="store_true",
                     help="test hook: sha256 of every rank's outputs of the last step in config.digests (inputs are seeded per "
                          "block of --seed-block proofs, so a sharded run and an unsharded run of the same blocks must agree)")
@@ -241,7 +244,7 @@ def main():
     curve = args.curve or ("secp256k1" if workload == "mixed" else "stark")
     m, n = args.m, args.n
     N = m * n
-    B = args.batch if args.batch is not None else (65536 if workload == "chain32" else 262144)
+    B = args.batch if args.batch is not None else (49152 if workload == "chain32" else 262144)
     eng = mp.Engine(curve, device=local)
     PB = eng.point_bytes
     CB = 2 * PB
@@ -409,12 +412,13 @@ def main():
         fac = [rand_factors(10 + j) for j in range(2)]      # two sets of witnesses, alternated along the chain
         prm = [rand_perms(20 + j) for j in range(2)]
         sds = rand_seeds(30)
-        # verification is independent per link: batches of G links (G T proofs per launch, as many as fit the workspace)
-        G = max(1, min(L, 262144 // T))
+        # verification: one chain equation per table over all L links (default), or link by link in batches of G links
+        chain_verify = not args.per_link_verify
+        G = L if chain_verify else max(1, min(L, 262144 // T))
         while L % G:
             G -= 1
         kk = keys.repeat(G, 1).contiguous()
-        keyless.reserve(max(T, G * T))
+        keyless.reserve(T if chain_verify else max(T, G * T))
         priming_launches = {}
         torch.cuda.synchronize()
 
@@ -423,12 +427,16 @@ def main():
                 keyless.shuffle_and_remask_batch_keys_dev(T, keys.data_ptr(), chain[j].data_ptr(), fac[j & 1].data_ptr(),
                                                           prm[j & 1].data_ptr(), sds.data_ptr(), chain[j + 1].data_ptr(),
                                                           proofs[j].data_ptr(), st_p[j].data_ptr())
+            if chain_verify:
+                keyless.verify_shuffle_chain_dev(T, L, kk.data_ptr(), chain.data_ptr(), proofs.data_ptr(), st_v.data_ptr())
+                return
             for j in range(0, L, G):
                 keyless.verify_shuffle_batch_keys_dev(G * T, kk.data_ptr(), chain[j].data_ptr(), chain[j + 1].data_ptr(),
                                                       proofs[j].data_ptr(), st_v[j].data_ptr())
 
         proofs_per_step = T * L
-        units = "prove+verify pairs (%d tables x %d dependent shuffles, %d proofs per prove launch, %d per verify launch)" % (T, L, T, G * T)
+        units = ("prove+verify pairs (%d tables x %d dependent shuffles, %d proofs per prove launch; verification: %s)"
+                 % (T, L, T, "one chain equation per table (mp_verify_shuffle_chain_dev)" if chain_verify else "%d proofs per launch, link by link" % (G * T)))
 
         def check():
             return int((st_p != 0).sum().item()) + int((st_v != 0).sum().item())

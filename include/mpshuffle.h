@@ -129,6 +129,17 @@ int mp_shuffle_and_remask_batch_keys_dev(mp_table* t, size_t B, const void* d_ke
                                          void* d_out_decks, void* d_out_proofs, void* d_status);
 int mp_verify_shuffle_batch_keys_dev(mp_table* t, size_t B, const void* d_keys, const void* d_decks, const void* d_shuffled_decks,
                                      const void* d_proofs, void* d_status);
+/* ---- chain verification: the shuffle chain of a card table verified as one equation -------------------------------------------
+ * A table's deck passes through `links` shuffles (deck_{j+1} = output of link j [REF examples/round.rs:268-350]) and every one of
+ * them is verified.  These entry points verify `tables` chains at once; decks: (links + 1) x tables decks, deck j of table t at index
+ * j * tables + t; proofs / status / keys: links x tables, link j of table t at j * tables + t (keys: the table's aggregate key repeated
+ * per link; NULL = the mp_table's own key).  The merged equations of a chain's links are added up with weights that depend on every
+ * proof of the chain, so every inner deck is a base once instead of twice and the n + 5 fixed bases appear once per table; the MSM runs on
+ * the bucket kernel.  A table whose chain fails is re-verified link by link: status words are identical to mp_verify_shuffle_batch*. */
+int mp_verify_shuffle_chain(mp_table* t, size_t tables, uint32_t links, const uint8_t* shared_keys, const uint8_t* decks,
+                            const uint8_t* proofs, int32_t* status);
+int mp_verify_shuffle_chain_dev(mp_table* t, size_t tables, uint32_t links, const void* d_keys, const void* d_decks, const void* d_proofs,
+                                void* d_status);
 int mp_sync(mp_ctx* ctx);
 int mp_reserve(mp_table* t, size_t B);           /* pre-allocate the batch workspace for B proofs */
 /* Every table holds four static work splits with identical results: a throughput plan (large sub-jobs, fewest operations),

@@ -20,7 +20,7 @@ SYMBOLS = [
     "mp_verify_shuffle_batch_keys", "mp_shuffle_and_remask_batch_keys_dev", "mp_verify_shuffle_batch_keys_dev",
     "mp_setup", "mp_table_create", "mp_table_create_ex", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
     "mp_shuffle_and_remask_batch", "mp_verify_shuffle_batch", "mp_shuffle_and_remask_batch_dev",
-    "mp_verify_shuffle_batch_dev", "mp_sync", "mp_reserve", "mp_set_latency_batch", "mp_remask_batch", "mp_msm", "mp_commit_batch",
+    "mp_verify_shuffle_batch_dev", "mp_verify_shuffle_chain", "mp_verify_shuffle_chain_dev", "mp_sync", "mp_reserve", "mp_set_latency_batch", "mp_remask_batch", "mp_msm", "mp_commit_batch",
     "mp_profile_enable", "mp_profile_report", "mp_work_census", "mp_plan_stats", "mp_sigma_prove_batch",
     "mp_sigma_verify_batch", "mp_blake2s",
     "mp_serialized_point_size", "mp_serialized_deck_size", "mp_serialized_params_size", "mp_serialized_proof_size",
@@ -132,6 +132,8 @@ def bind(cdll):
     cdll.mp_verify_shuffle_batch_keys.argtypes = [c.c_void_p, c.c_size_t, u8p, u8p, u8p, u8p, i32p]
     cdll.mp_shuffle_and_remask_batch_keys_dev.argtypes = [c.c_void_p, c.c_size_t] + [c.c_void_p] * 8
     cdll.mp_verify_shuffle_batch_keys_dev.argtypes = [c.c_void_p, c.c_size_t] + [c.c_void_p] * 5
+    cdll.mp_verify_shuffle_chain.argtypes = [c.c_void_p, c.c_size_t, c.c_uint32, u8p, u8p, u8p, i32p]
+    cdll.mp_verify_shuffle_chain_dev.argtypes = [c.c_void_p, c.c_size_t, c.c_uint32] + [c.c_void_p] * 4
     cdll.mp_sync.argtypes = [c.c_void_p]
     cdll.mp_reserve.argtypes = [c.c_void_p, c.c_size_t]
     cdll.mp_set_latency_batch.argtypes = [c.c_void_p, c.c_size_t]
@@ -390,6 +392,20 @@ class Table:
         st = (ctypes.c_int32 * B)()
         self.eng._chk(self.lib.mp_verify_shuffle_batch_keys(self.h, B, _in(keys), _in(decks), _in(shuffled), _in(proofs), st))
         return list(st)
+
+    # ---- chain verification: `tables` chains of `links` shuffles; decks: (links + 1) * tables decks (deck j of table t at j * tables + t)
+    def verify_shuffle_chain(self, tables, links, decks, proofs, keys=None):
+        self._need("decks", len(decks), (links + 1) * tables * self.N * self.cb)
+        self._need("proofs", len(proofs), links * tables * self.proof_bytes)
+        if keys is not None:
+            self._need("keys", len(keys), links * tables * self.pb)
+        st = (ctypes.c_int32 * (links * tables))()
+        self.eng._chk(self.lib.mp_verify_shuffle_chain(self.h, tables, links, _in(keys) if keys is not None else None, _in(decks),
+                                                       _in(proofs), st))
+        return list(st)
+
+    def verify_shuffle_chain_dev(self, tables, links, d_keys, d_decks, d_proofs, d_status):
+        self.eng._chk(self.lib.mp_verify_shuffle_chain_dev(self.h, tables, links, d_keys, d_decks, d_proofs, d_status))
 
     def shuffle_and_remask_batch_keys_dev(self, B, d_keys, d_decks, d_factors, d_perms, d_seeds, d_out_decks, d_out_proofs, d_status):
         self.eng._chk(self.lib.mp_shuffle_and_remask_batch_keys_dev(self.h, B, d_keys, d_decks, d_factors, d_perms, d_seeds,

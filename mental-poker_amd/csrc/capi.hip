@@ -274,6 +274,43 @@ int mp_verify_shuffle_batch_keys_dev(mp_table* t, size_t B, const void* d_keys, 
   return MP_OK;
   MP_CATCH
 }
+int mp_verify_shuffle_chain_dev(mp_table* t, size_t tables, uint32_t links, const void* d_keys, const void* d_decks, const void* d_proofs,
+                                void* d_status) {
+  if (!t || !tables || !links || !d_decks || !d_proofs || !d_status || links > 4095)
+    return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_chain_dev: bad argument");
+  if (t->keyless && !d_keys) return fail(MP_ERR_BAD_ARGUMENT, "this table has no aggregate key: pass one key per link");
+  if ((uint64_t)tables * links >= ((uint64_t)1 << 31)) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_chain_dev: too many proofs for one call");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  t->verify_chain_dev(tables, links, (const uint8_t*)d_decks, (const uint8_t*)d_proofs, (int32_t*)d_status, (const uint8_t*)d_keys);
+  return MP_OK;
+  MP_CATCH
+}
+int mp_verify_shuffle_chain(mp_table* t, size_t tables, uint32_t links, const uint8_t* shared_keys, const uint8_t* decks, const uint8_t* proofs,
+                            int32_t* status) {
+  if (!t || !tables || !links || !decks || !proofs || !status) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_chain: bad argument");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  rt::Stream s = t->ctx->stream;
+  const size_t B = tables * links, pb = t->point_bytes, deck_bytes = (size_t)2 * t->N * pb, psz = proof_size_bytes(t->m, t->n, (uint32_t)pb);
+  DevBuf<uint8_t> dd, dp, dk;
+  DevBuf<int32_t> ds;
+  dd.alloc((B + tables) * deck_bytes, s, false);
+  dp.alloc(B * psz, s, false);
+  ds.alloc(B, s, false);
+  rt::h2d(dd.p, decks, (B + tables) * deck_bytes, s);
+  rt::h2d(dp.p, proofs, B * psz, s);
+  if (shared_keys) {
+    dk.alloc(B * pb, s, false);
+    rt::h2d(dk.p, shared_keys, B * pb, s);
+  }
+  const int rc = mp_verify_shuffle_chain_dev(t, tables, links, shared_keys ? dk.p : nullptr, dd.p, dp.p, ds.p);
+  if (rc != MP_OK) return rc;
+  rt::d2h(status, ds.p, B * 4, s);
+  rt::stream_sync(s);
+  return MP_OK;
+  MP_CATCH
+}
 int mp_sync(mp_ctx* ctx) {
   if (!ctx) return fail(MP_ERR_BAD_ARGUMENT, "mp_sync: null");
   MP_TRY

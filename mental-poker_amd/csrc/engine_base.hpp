@@ -151,6 +151,9 @@ struct mp_table {
                          uint8_t* out_decks, uint8_t* out_proofs, int32_t* status, const uint8_t* keys = nullptr) = 0;
   virtual void verify_dev(size_t B, const uint8_t* decks, const uint8_t* shuf, const uint8_t* proofs, int32_t* status,
                           const uint8_t* keys = nullptr) = 0;
+  // chain verification: T tables x L links, decks [(L + 1)][T], proofs / status / keys [L][T] (device memory)
+  virtual void verify_chain_dev(size_t T, uint32_t L, const uint8_t* decks, const uint8_t* proofs, int32_t* status,
+                                const uint8_t* keys = nullptr) = 0;
   virtual void remask_host(size_t count, const uint8_t* cards, const uint8_t* rho, uint8_t* out) = 0;
   virtual void msm_host(size_t n_msm, size_t k, const uint8_t* scalars, const uint8_t* points, uint8_t* out) = 0;
   virtual void commit_host(size_t count, size_t len, const uint8_t* values, const uint8_t* r, uint8_t* out) = 0;

@@ -439,7 +439,7 @@ struct Table : mp_table {
       MP_RUN(k_table, C, B, (ph.n_tables + cur_table_group - 1) / cur_table_group, a);
     }
     if (ph.n_f) {
-      FixedArgs a{w.S.p, w.J.p, FB.p, ph.fjobs.p, ph.fterms.p, w.Bpad, fbg};
+      FixedArgs a{w.S.p, w.J.p, FB.p, ph.fjobs.p, ph.fterms.p, w.Bpad, fbg, w.Bpad};
       MP_RUN(k_fixed_msm, C, B, ph.n_f, a);
     }
     if (ph.n_v) {
@@ -451,7 +451,7 @@ struct Table : mp_table {
       if ((uint64_t)B * ph.n_bterms >= ((uint64_t)1 << 32)) throw std::runtime_error("bucket recode: batch too large for one launch");
       BRecodeArgs ra{w.S.p, w.D8.p, ph.bterms.p, ph.bpos.p, w.Bpad, bw, ph.n_bterms, (size_t)w.d8_bytes};
       MP_RUN(k_bucket_recode, C, B * ph.n_bterms, 1, ra);
-      BucketArgs ba{w.D8.p, w.P.p, w.J.p, ph.bjobs.p, ph.bterms.p, w.Bpad, bw, ph.n_b, (size_t)w.d8_bytes};
+      BucketArgs ba{w.D8.p, w.P.p, w.J.p, ph.bjobs.p, ph.bterms.p, w.Bpad, bw, ph.n_b, (size_t)w.d8_bytes, 0u};
       ctx->prof.begin("k_bucket_msm", ctx->stream);
       MP_WAVE_LAUNCH(k_bucket_msm, C, ctx->stream, B * ph.n_b * bw, bk_lds_words(ph.b_kpad_max, XyzzWords<C>::N), ba);
       ctx->prof.end(ctx->stream);
@@ -658,6 +658,143 @@ struct Table : mp_table {
       }
     }
     rt::d2d(status, w.status.p, (size_t)B * 4, s);
+  }
+
+
+  // ---------------------------------------------------------------- chain verification
+  // The L shuffles of one card table form a chain (deck_{j+1} = output of link j [REF examples/round.rs:268-350]) and every one of
+  // them is verified.  Checked one by one, each of the L - 1 inner decks is a base in TWO verifier equations (as the shuffled deck
+  // of link j - 1 and as the input deck of link j).  Here the merged equations of all links of a table are added up with weights
+  // rho_j that depend on every proof of the chain: every distinct point appears ONCE -- (L + 1) 2N deck points + L (11m + 8) proof
+  // points instead of L (4N + 11m + 8) -- the n + 5 fixed bases appear once per table instead of once per link, and the resulting
+  // MSM (4 424 terms for 32 links of a 52-card deck) is long enough for the bucket kernel.  A table whose chain fails is re-verified
+  // link by link, so the per-link status words are exactly those of verify_dev.  T tables, lane of (link j, table t) = j T + t.
+  struct ChainPlan {
+    uint32_t L = 0;
+    bool keyed = false;
+    Phase ph;
+    PhaseDev dev;
+    std::vector<ChainTerm> cterms;
+    DevBuf<ChainTerm> dterms;
+    uint32_t K = 0, nfix = 0, nJ = 0;
+  };
+  ChainPlan chain;
+  Workspace cws;                      // lean workspace of chain verification: no window tables, no digit planes
+  DevBuf<uint32_t> chain_cw, chain_cs;
+  DevBuf<int8_t> chain_d8;
+  void build_chain_plan(uint32_t L, bool keyed) {
+    if (chain.L == L && chain.keyed == keyed) return;
+    if (keyed) ensure_keyed();
+    PlanSet& q = (keyed ? psk : ps)[0];
+    const VerifyLay& l = q.vplan.lay;
+    chain.ph = Phase();
+    chain.cterms.clear();
+    chain.L = L;
+    chain.keyed = keyed;
+    uint32_t next_partial = 1;                  // J slot 0 = the chain equation's value
+    PhaseBuilder pb(chain.ph, next_partial, FCHUNK, VCHUNK, 1u, bk_windows(R::BITS));
+    pb.begin(0);
+    auto var = [&](ChainTerm ct, uint32_t pslot, uint32_t link) {
+      pb.var((uint32_t)chain.cterms.size(), pslot | (link << 20));
+      chain.cterms.push_back(ct);
+    };
+    for (uint32_t j = 0; j <= L; ++j)
+      for (uint32_t i = 0; i < 2 * N; ++i) {
+        if (j == 0) var(ChainTerm{l.mvar + l.deck + i, 0, 1, NO_SLOT}, l.deck + i, 0);
+        else if (j < L) var(ChainTerm{l.mvar + l.deck + i, j, 1, l.mvar + l.shuf + i}, l.deck + i, j);
+        else var(ChainTerm{l.mvar + l.shuf + i, L - 1, 1, NO_SLOT}, l.shuf + i, L - 1);
+      }
+    for (uint32_t j = 0; j < L; ++j)
+      for (uint32_t slot = l.cA; slot < l.pk; ++slot) var(ChainTerm{l.mvar + slot, j, 1, NO_SLOT}, slot, j);
+    if (keyed) var(ChainTerm{l.mvar + l.pk, 0, L, NO_SLOT}, l.pk, 0);
+    chain.K = (uint32_t)chain.cterms.size();
+    FixedBases fb{n};
+    for (uint32_t f = 0; f < fb.count(); ++f) {
+      if (keyed && f == fb.pk()) continue;
+      pb.fixed((uint32_t)chain.cterms.size(), f);
+      chain.cterms.push_back(ChainTerm{l.mfix + f, 0, L, NO_SLOT});
+    }
+    chain.nfix = (uint32_t)chain.cterms.size() - chain.K;
+    pb.end();
+    chain.nJ = next_partial;
+    chain.dev.upload(chain.ph, ctx->stream);
+    chain.dterms.upload(chain.cterms, ctx->stream);
+  }
+  void verify_chain_dev(size_t T_, uint32_t L, const uint8_t* decks, const uint8_t* proofs, int32_t* status, const uint8_t* keys) override {
+    const uint32_t T = (uint32_t)T_, B = T * L, Tpad = (T + 63u) & ~63u;
+    const bool keyed = keys != nullptr;
+    build_chain_plan(L, keyed);
+    PlanSet& q = (keyed ? psk : ps)[0];
+    const VerifyLay& l = q.vplan.lay;
+    rt::Stream s = ctx->stream;
+    Workspace& w = cws;
+    w.fw = G_::FW;
+    w.ensure(B, l.nS, l.nP, std::max(chain.nJ, 8u), 0, 0, nwin, stage_words_needed(), s, 0);
+    const size_t deck_bytes = (size_t)2 * N * G_::PB;
+    rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
+    {
+      LoadPointsArgs a{decks, w.P.p, w.status.p, w.Bpad, 2 * N, l.deck};
+      MP_RUN(k_load_points, C, B, 2 * N, a);
+      LoadPointsArgs b{decks + (size_t)T * deck_bytes, w.P.p, w.status.p, w.Bpad, 2 * N, l.shuf};
+      MP_RUN(k_load_points, C, B, 2 * N, b);
+      ProofIoArgs pa{const_cast<uint8_t*>(proofs), w.S.p, w.P.p, w.status.p, q.vwire.p, w.Bpad, (uint32_t)proof_size_bytes(m, n, G_::PB)};
+      MP_RUN(k_load_proof, C, B, (uint32_t)q.vplan.wire.size(), pa);
+      if (keyed) {
+        LoadPointsArgs ka{keys, w.P.p, w.status.p, w.Bpad, 1, l.pk};
+        MP_RUN(k_load_points, C, B, 1, ka);
+      }
+      check_subgroup(w, B, 0, l.pk + (keyed ? 1u : 0u));
+    }
+    {
+      VerifyFsArgs a{};
+      a.st = statement_args(w, l.deck, l.shuf, l.cA, l.x, keyed ? l.pk : NO_SLOT);
+      a.l = l;
+      a.merge = 1u;
+      MP_RUN(k_verify_fs, C, B, 1, a);
+      VerifyScalArgs sa{w.S.p, w.P.p, w.direct.p, l, q.vplan.cm, w.Bpad};
+      MP_RUN(k_verify_scal, C, B, 1, sa);
+      VerifyMergeArgs ma{w.S.p, q.mjobs.p, q.mpairs.p, w.Bpad};
+      MP_RUN(k_verify_merge, C, B, (uint32_t)q.vplan.mjobs.size(), ma);
+    }
+    // the chain equation: weights, one scalar per distinct point / fixed base, ONE bucket MSM + fixed-base part per table
+    const uint32_t nterms = chain.K + chain.nfix, bw = bk_windows(R::BITS);
+    chain_cw.alloc((size_t)L * Tpad * 8, s, false);
+    chain_cs.alloc((size_t)nterms * Tpad * 8, s);
+    chain_d8.alloc((size_t)chain.dev.b_dig_bytes * Tpad, s);
+    ChainWeightsArgs wa{w.seed.p, chain_cw.p, w.Bpad, Tpad, T, L};
+    MP_RUN(k_chain_weights, C, T, 1, wa);
+    ChainScalArgs ca{w.S.p, chain_cw.p, chain_cs.p, chain.dterms.p, w.Bpad, Tpad, T};
+    MP_RUN(k_chain_scalars, C, T, nterms, ca);
+    PhaseDev& ph = chain.dev;
+    if ((uint64_t)T * ph.n_bterms >= ((uint64_t)1 << 32)) throw std::runtime_error("chain verification: too many tables for one launch");
+    BRecodeArgs ra{chain_cs.p, chain_d8.p, ph.bterms.p, ph.bpos.p, Tpad, bw, ph.n_bterms, (size_t)ph.b_dig_bytes};
+    MP_RUN(k_bucket_recode, C, T * ph.n_bterms, 1, ra);
+    BucketArgs ba{chain_d8.p, w.P.p, w.J.p, ph.bjobs.p, ph.bterms.p, w.Bpad, bw, ph.n_b, (size_t)ph.b_dig_bytes, T};
+    ctx->prof.begin("k_bucket_msm", s);
+    MP_WAVE_LAUNCH(k_bucket_msm, C, s, T * ph.n_b * bw, bk_lds_words(ph.b_kpad_max, XyzzWords<C>::N), ba);
+    ctx->prof.end(s);
+    BFoldArgs fa{w.J.p, ph.bjobs.p, w.Bpad, bw};
+    MP_RUN(k_bucket_fold, C, T, ph.n_b, fa);
+    FixedArgs fx{chain_cs.p, w.J.p, FB.p, ph.fjobs.p, ph.fterms.p, w.Bpad, fbg, Tpad};
+    MP_RUN(k_fixed_msm, C, T, ph.n_f, fx);
+    CombineArgs cb{w.J.p, w.P.p, ph.cjobs.p, ph.cterms.p, w.Bpad};
+    MP_RUN(k_combine, C, T, ph.n_c, cb);
+    if (!vflag.n) vflag.alloc(1, s);
+    rt::dzero(vflag.p, 4, s);
+    ChainVerdictArgs va{w.J.p, w.direct.p, w.status.p, vflag.p, w.Bpad, T, L, 0u};
+    MP_RUN(k_chain_verdict, C, T, 1, va);
+    uint32_t flag = 0;
+    rt::d2h(&flag, vflag.p, 4, s);
+    rt::stream_sync(s);
+    if (!flag) {
+      rt::dzero(status, (size_t)B * 4, s);           // every link of every table passed
+      return;
+    }
+    // some table failed: the per-link verifier gives every link its exact status
+    const size_t psz = proof_size_bytes(m, n, G_::PB);
+    for (uint32_t j = 0; j < L; ++j)
+      verify_dev(T, decks + (size_t)j * T * deck_bytes, decks + (size_t)(j + 1) * T * deck_bytes, proofs + (size_t)j * T * psz,
+                 status + (size_t)j * T, keyed ? keys + (size_t)j * T * G_::PB : nullptr);
   }
 
   // ---------------------------------------------------------------- building blocks (ad-hoc plans)

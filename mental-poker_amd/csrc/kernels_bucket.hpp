@@ -78,7 +78,9 @@ struct BucketArgs {
   const Term* bterms;
   uint32_t Bpad, nwin, njobs;
   size_t dstride;
+  uint32_t link_stride;    // chain verification: term.b = P slot | link << 20, the point lives in lane b + link * link_stride
 };
+static const uint32_t BK_SLOT_MASK = 0xFFFFFu;
 template <class C>
 MP_HD void xyzz_to_words(const Xyzz<C>& p, uint32_t* w) {
   constexpr int L = sizeof(p.X.v) / 4;
@@ -205,7 +207,8 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t wid, W& wv) {
           cb[lane] -= 1;
         }
         const uint32_t e = ix[p];
-        Aff<C> q = ld_aff<C>(a.P + p_off<C>(a.bterms[job.begin + (e & 0x7FFFu)].b, a.Bpad, b));
+        const uint32_t tb = a.bterms[job.begin + (e & 0x7FFFu)].b;
+        Aff<C> q = ld_aff<C>(a.P + p_off<C>(tb & BK_SLOT_MASK, a.Bpad, b + (tb >> 20) * a.link_stride));
         if (e & 0x8000u) q = aff_neg<C>(q);
         xyzz_madd_ip<C>(run[lane], q);
       }

@@ -112,6 +112,7 @@ struct FixedArgs {
   const Term* terms;
   uint32_t Bpad;
   FbGeom g;
+  uint32_t Sbpad;       // lane stride of the scalar array (= Bpad except for the compact scalars of chain verification)
 };
 template <class C>
 MP_HD const uint32_t* fb_entry(const uint32_t* FB, const FbGeom& g, uint32_t base, uint32_t w, uint32_t d) {
@@ -132,7 +133,7 @@ MP_HD void body_fixed_msm(const FixedArgs& a, uint32_t b, uint32_t y) {
   for (uint32_t t = 0; t < job.count; ++t) {
     const Term term = a.terms[job.begin + t];
     uint32_t k[8];
-    fe_to_canonical<R>(ld_fe<R>(a.S + s_off(term.s, a.Bpad, b)), k);
+    fe_to_canonical<R>(ld_fe<R>(a.S + s_off(term.s, a.Sbpad, b)), k);
 #pragma unroll 1
     for (uint32_t w = 0; w < a.g.windows; ++w) {
       const uint32_t d = fb_digit(k, a.g, w);

@@ -658,6 +658,8 @@ MP_HD void body_verify_fs(const VerifyFsArgs& a, uint32_t b, uint32_t y) {
     FrStream st;
     frstream_init(st, seed);
     for (uint32_t k = 0; k < (uint32_t)VC_COUNT; ++k) st_fe<R>(S + s_off(l.mr + k, f.Bpad, b), frstream_next<R>(st));
+#pragma unroll
+    for (int t = 0; t < 8; ++t) f.seed[(size_t)t * f.Bpad + b] = seed[t];     // the transcript's last state: chain verification hashes it
   }
 }
 MP_KERNEL(k_verify_fs, VerifyFsArgs, body_verify_fs)
@@ -845,6 +847,77 @@ MP_HD void body_verdict_merged(const VerdictMergedArgs& a, uint32_t b, uint32_t 
   if (bad) a.flag[0] = 1u;       // same value from every failing lane: no atomic needed
 }
 MP_KERNEL(k_verdict_merged, VerdictMergedArgs, body_verdict_merged)
+
+// ---- chain verification: the L links of one card table's shuffle chain verified as ONE equation per table -------------------------
+// [REF barnett-smart-card-protocol/examples/round.rs:268-350: every player shuffles the deck the previous player produced, and
+// every shuffle is verified].  Lane layout: link j of table t is lane j T + t; its merged scalars (k_verify_merge) are already in S.
+// (1) weights: rho_j = Fr::rand of ChaCha20(Blake2s(final transcript seeds of all L links of the table)) -- they depend on every
+//     byte of every proof of the chain;
+struct ChainWeightsArgs {
+  const uint32_t* seed;    // [8][Bpad]: last transcript state per link (k_verify_fs)
+  uint32_t* CW;            // [L][Tpad] Fr
+  uint32_t Bpad, Tpad, T, L;
+};
+template <class C>
+MP_HD void body_chain_weights(const ChainWeightsArgs& a, uint32_t t, uint32_t y) {
+  typedef typename C::FrP R;
+  Blake2sState st;
+  blake2s_init(st);
+  uint32_t m[16];
+  for (uint32_t j = 0; j < a.L; j += 2) {
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      m[w] = a.seed[(size_t)w * a.Bpad + (size_t)j * a.T + t];
+      m[8 + w] = j + 1 < a.L ? a.seed[(size_t)w * a.Bpad + (size_t)(j + 1) * a.T + t] : 0u;
+    }
+    const bool last = j + 2 >= a.L;
+    blake2s_compress(st, m, last ? 32ull * a.L : 32ull * (j + 2), last);
+  }
+  FrStream fs;
+  frstream_init(fs, st.h);
+  for (uint32_t j = 0; j < a.L; ++j) st_fe<R>(a.CW + ((size_t)j * a.Tpad + t) * 8, frstream_next<R>(fs));
+}
+MP_KERNEL(k_chain_weights, ChainWeightsArgs, body_chain_weights)
+// (2) scalars of the chain equation: CS[i][t] = sum_{j = j0}^{j0 + cnt - 1} rho_j S[s][lane(j,t)]  (+ rho_{j0-1} S[s2][lane(j0-1,t)]):
+//     a deck between two links carries the scalar of its role as "shuffled deck" of the earlier link plus that as "deck" of the later
+struct ChainTerm {
+  uint32_t s, j0, cnt, s2;
+};
+struct ChainScalArgs {
+  const uint32_t* S;
+  const uint32_t* CW;
+  uint32_t* CS;            // [terms][Tpad] Fr
+  const ChainTerm* terms;
+  uint32_t Bpad, Tpad, T;
+};
+template <class C>
+MP_HD void body_chain_scalars(const ChainScalArgs& a, uint32_t t, uint32_t y) {
+  typedef typename C::FrP R;
+  const ChainTerm ct = a.terms[y];
+  Fe<R> acc = fe_zero<R>();
+  for (uint32_t j = ct.j0; j < ct.j0 + ct.cnt; ++j)
+    acc = fe_add<R>(acc, fe_mul<R>(ld_fe<R>(a.CW + ((size_t)j * a.Tpad + t) * 8), ld_fe<R>(a.S + s_off(ct.s, a.Bpad, j * a.T + t))));
+  if (ct.s2 != NO_SLOT)
+    acc = fe_add<R>(acc, fe_mul<R>(ld_fe<R>(a.CW + ((size_t)(ct.j0 - 1) * a.Tpad + t) * 8),
+                                   ld_fe<R>(a.S + s_off(ct.s2, a.Bpad, (ct.j0 - 1) * a.T + t))));
+  st_fe<R>(a.CS + ((size_t)y * a.Tpad + t) * 8, acc);
+}
+MP_KERNEL(k_chain_scalars, ChainScalArgs, body_chain_scalars)
+// (3) verdict per table: every link's direct checks passed, no encoding error, and the chain equation holds
+struct ChainVerdictArgs {
+  const uint32_t* J;
+  const uint32_t* direct;
+  int32_t* status;         // [L T] (lane order)
+  uint32_t* flag;
+  uint32_t Bpad, T, L, j_final;
+};
+template <class C>
+MP_HD void body_chain_verdict(const ChainVerdictArgs& a, uint32_t t, uint32_t y) {
+  bool bad = !fe_is_zero(ld_fe<typename C::FqP>(a.J + j_off<C>(a.j_final, a.Bpad, t) + 2 * Geo<C>::FW));
+  for (uint32_t j = 0; j < a.L; ++j) bad = bad || a.status[(size_t)j * a.T + t] != 0 || a.direct[(size_t)j * a.T + t] != 0;
+  if (bad) a.flag[0] = 1u;
+}
+MP_KERNEL(k_chain_verdict, ChainVerdictArgs, body_chain_verdict)
 
 #undef MP_LD
 #undef MP_ST

@@ -378,3 +378,50 @@ def test_toom_cook_and_karatsuba_give_the_same_proof(emu, name):
             uses_toom = on and latency_batch == 0         # the small-batch plans keep Karatsuba (fewer dependent stages)
             assert ("k_toom_points" in rep) == uses_toom and ("k_lin_comb" in rep) == uses_toom
             assert t.verify_shuffle(args[0], deck, proof) == 0
+
+
+@pytest.mark.parametrize("cvn,m,n,L,T,keyed", [("stark", 2, 3, 4, 3, False), ("stark", 3, 2, 3, 2, True), ("secp256k1", 2, 3, 2, 2, False)])
+def test_chain_verification_under_emulation(emu, coracle, cvn, m, n, L, T, keyed):
+    """mp_verify_shuffle_chain: T tables x L dependent shuffles verified as one equation per table (every inner deck a base once);
+    honest chains pass, a chain with one bad link gets exactly the per-link verifier's status words"""
+    eng = emu(cvn)
+    N, pb = m * n, eng.point_bytes
+    g0 = coracle.gen_inputs(cvn, m, n, 50)
+    params = g0["params"]
+    keys_t = [coracle.gen_inputs(cvn, m, n, 60 + t)["pk"] for t in range(T)] if keyed else [g0["pk"]] * T
+    table = eng.table(m, n, params, None if keyed else g0["pk"])
+    chain = [[coracle.gen_inputs(cvn, m, n, 70 + t)["deck"] for t in range(T)]]     # deck 0 of every table
+    proofs = []
+    for j in range(L):
+        nxt, prf = [], []
+        for t in range(T):
+            gi = coracle.gen_inputs(cvn, m, n, 100 + 10 * j + t)
+            d, p = coracle.shuffle_and_remask(cvn, m, n, params, keys_t[t], chain[j][t], gi["rho"], gi["perm"], gi["prover_seed"])
+            nxt.append(d)
+            prf.append(p)
+        chain.append(nxt)
+        proofs.append(prf)
+    decks = b"".join(b"".join(row) for row in chain)
+    pf = b"".join(b"".join(row) for row in proofs)
+    keys = b"".join(keys_t[t] for j in range(L) for t in range(T)) if keyed else None
+    eng.profile_enable(True)
+    assert table.verify_shuffle_chain(T, L, decks, pf, keys) == [0] * (L * T)
+    rep = eng.profile_report()
+    eng.profile_enable(False)
+    assert rep["k_chain_scalars"][0] == 1 and rep["k_bucket_msm"][0] == 1 and "k_var_msm" not in rep and "k_table" not in rep
+    # break link 1 of table 0 (swap in another table's proof) and one deck point of the last link of table T-1
+    bad = [row[:] for row in proofs]
+    bad[1 % L][0] = proofs[1 % L][(0 + 1) % T]
+    st = table.verify_shuffle_chain(T, L, decks, b"".join(b"".join(row) for row in bad), keys)
+    exp = []
+    for j in range(L):
+        ks = b"".join(keys_t) if keyed else None
+        row = (table.verify_shuffle_batch_keys(ks, b"".join(chain[j]), b"".join(chain[j + 1]), b"".join(bad[j])) if keyed else
+               table.verify_shuffle_batch(b"".join(chain[j]), b"".join(chain[j + 1]), b"".join(bad[j])))
+        exp += row
+    assert st == exp and st[(1 % L) * T + 0] > 0 and sum(1 for v in st if v) == 1
+    # errors that cancel between two links under equal weights are caught: the weights depend on every proof of the chain
+    tam = bytearray(decks)
+    tam[(1 * T + 0) * N * 2 * pb] ^= 1                 # first byte of deck 1 of table 0: not a curve point any more (or another one)
+    st2 = table.verify_shuffle_chain(T, L, bytes(tam), pf, keys)
+    assert st2[0 * T + 0] != 0 and st2[1 * T + 0] != 0 and all(v == 0 for i, v in enumerate(st2) if i % T != 0)

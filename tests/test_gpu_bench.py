@@ -55,6 +55,7 @@ def test_json_line_contract_and_extras():
 
 
 @pytest.mark.parametrize("workload,extra", [("chain32", ["--batch", "256", "--players", "4"]),
+                                            ("chain32", ["--batch", "256", "--players", "4", "--per-link-verify"]),
                                             ("mixed", ["--batch", "512"])])
 def test_workload_modes(workload, extra):
     d = run_bench("--workload", workload, "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--fb-bits", "8", *extra)

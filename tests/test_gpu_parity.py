@@ -564,3 +564,36 @@ def test_bucket_msm_large_and_edge_scalars(mp, coracle):
         got = t.msm(n_msm, K, sc, allp)
         for j in range(n_msm):
             assert got[64 * j:64 * j + 64] == coracle.msm(cv, sc[32 * K * j:32 * K * (j + 1)], bytes(pts)), (K, j)
+
+
+@pytest.mark.parametrize("cvn,m,n,L,T,keyed", [("stark", 2, 26, 8, 40, True), ("stark", 4, 13, 3, 5, False), ("secp256k1", 2, 7, 4, 3, True)])
+def test_chain_verification_matches_per_link_verifier(mp, coracle, cvn, m, n, L, T, keyed):
+    """mp_verify_shuffle_chain (one equation per table over all links of its shuffle chain) accepts honest chains and, when a link
+    is bad, returns exactly the status words of the per-link verifier"""
+    eng = mp.Engine(cvn, device=0)
+    N, pb = m * n, eng.point_bytes
+    g0 = coracle.gen_inputs(cvn, m, n, 50)
+    params = g0["params"]
+    keys_t = [coracle.gen_inputs(cvn, m, n, 60 + t)["pk"] for t in range(T)] if keyed else [g0["pk"]] * T
+    table = eng.table(m, n, params, None if keyed else g0["pk"])
+    decks = [[coracle.gen_inputs(cvn, m, n, 70 + t)["deck"] for t in range(T)]]
+    proofs = []
+    for j in range(L):
+        ins = [coracle.gen_inputs(cvn, m, n, 1000 + 50 * j + t) for t in range(T)]
+        args = (b"".join(decks[j]), b"".join(g["rho"] for g in ins), [v for g in ins for v in g["perm"]], b"".join(g["prover_seed"] for g in ins))
+        d, p, st = (table.shuffle_and_remask_batch_keys(b"".join(keys_t), *args) if keyed else table.shuffle_and_remask_batch(*args))
+        assert not any(st)
+        decks.append(_split(d, N * 2 * pb))
+        proofs.append(_split(p, table.proof_bytes))
+    flat_d = b"".join(b"".join(r) for r in decks)
+    keys = b"".join(keys_t) * L if keyed else None
+    assert table.verify_shuffle_chain(T, L, flat_d, b"".join(b"".join(r) for r in proofs), keys) == [0] * (L * T)
+    bad = [r[:] for r in proofs]
+    bad[L - 1][1] = proofs[L - 1][0]
+    bad[0][T - 1] = proofs[0][0]
+    st = table.verify_shuffle_chain(T, L, flat_d, b"".join(b"".join(r) for r in bad), keys)
+    exp = []
+    for j in range(L):
+        a = (b"".join(decks[j]), b"".join(decks[j + 1]), b"".join(bad[j]))
+        exp += table.verify_shuffle_batch_keys(b"".join(keys_t), *a) if keyed else table.verify_shuffle_batch(*a)
+    assert st == exp and sum(1 for v in st if v) == 2
