@@ -184,9 +184,9 @@ int mp_commit_batch(mp_table* t, size_t count, size_t len, const uint8_t* values
  * Per proof: bases g_i, publics a_i = x * g_i (nbases points each), witness x, `fs_init` = Blake2s digest of the bytes the
  * reference seeds its FiatShamirRng with (mp_blake2s of e.g. b"Masking Proof"), prover seed; proof = A_1..A_nb || z.
  * verify status: 0 Ok, 5 "Schnorr Identification", 6 "Chaum-Pedersen" [REF tests.rs:74-76,120,170], < 0 usage error.
- * SEEDS MUST NEVER REPEAT: the nonce of a proof is the first Fr::rand of ChaCha20Rng::from_seed(prover_seed) and nothing else (the
- * reference's `rng: &mut R` advances by itself; an explicit seed does not).  Two proofs for the same witness under the same seed give
- * z1 - z2 = (c1 - c2) x and reveal it.  Draw every seed from a CSPRNG (as INTEGRATION.md's binding does with `rng.fill_bytes`). */
+ * The nonce is hedged ("sigma transcript v2"): r = Fr::rand(ChaCha20Rng(Blake2s(ToBytes(bases, publics) || Blake2s(witness || fs_init ||
+ * prover_seed)))), so a repeated seed repeats the nonce only if witness and statement repeat too (the reference's `rng: &mut R` advances
+ * by itself; an explicit seed does not).  Seeds should still be fresh CSPRNG output per call (`rng.fill_bytes`). */
 int mp_sigma_prove_batch(mp_table* t, size_t B, uint32_t nbases, const uint8_t* bases, const uint8_t* publics,
                          const uint8_t* witness, const uint8_t* fs_init, const uint8_t* prover_seeds, uint8_t* out_proofs,
                          int32_t* status);

@@ -976,7 +976,7 @@ struct Table : mp_table {
       rt::h2d(dseed.p, seeds, (size_t)B * 32, s);
       LoadScalarsArgs lx{dx.p, w.S.p, w.status.p, w.Bpad, 1, l.x};
       MP_RUN(k_load_scalars, C, B, 1, lx);
-      SigmaInitArgs ia{w.S.p, dseed.p, l, w.Bpad};
+      SigmaInitArgs ia{w.S.p, dseed.p, l, w.Bpad, f, w.P.p, dfs.p};
       MP_RUN(k_sigma_init, C, B, 1, ia);
       run_phase(ad.dev, w, B);
       SigmaFsArgs fa{f, w.S.p, w.P.p, dfs.p, l, 1};

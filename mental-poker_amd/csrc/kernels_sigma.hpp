@@ -23,11 +23,18 @@ MP_HD SigmaLay make_sigma_lay(uint32_t nb) {
   return l;
 }
 
+// The nonce is HEDGED ("sigma transcript v2"): r = Fr::rand(ChaCha20Rng(s2)) with
+//   s1 = Blake2s(witness (32 B canonical) || fs_init (32 B) || prover_seed),  s2 = Blake2s(ToBytes(g.., a..) || s1)
+// so that a repeated seed does not repeat the nonce unless witness AND statement repeat as well (the reference's `rng: &mut R`
+// advances by itself; an explicit seed does not -- with the bare seed two proofs for one secret would reveal it).
 struct SigmaInitArgs {
   uint32_t* S;
   const uint8_t* seeds;   // [B][32]
   SigmaLay l;
   uint32_t Bpad;
+  FsDev f;
+  const uint32_t* P;
+  const uint8_t* fs_init; // [B][32]
 };
 template <class C>
 MP_HD void body_sigma_init(const SigmaInitArgs& a, uint32_t b, uint32_t y) {
@@ -36,6 +43,18 @@ MP_HD void body_sigma_init(const SigmaInitArgs& a, uint32_t b, uint32_t y) {
   const uint32_t* sw = reinterpret_cast<const uint32_t*>(a.seeds + (size_t)b * 32);
 #pragma unroll
   for (int i = 0; i < 8; ++i) key[i] = sw[i];
+  {
+    StageWriter w = stage_begin(a.f.stage, a.f.Bpad, b);
+    uint32_t k[8];
+    fe_to_canonical<R>(ld_fe<R>(a.S + s_off(a.l.x, a.Bpad, b)), k);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) stage_word(w, k[i]);
+    const uint32_t* fw = reinterpret_cast<const uint32_t*>(a.fs_init + (size_t)b * 32);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) stage_word(w, fw[i]);
+    fs_finish_absorb(w, key);                                   // s1
+  }
+  fs_absorb_points<C>(a.f, a.P, b, key, a.l.g, 2 * a.l.nb);     // s2: bases and publics are consecutive P slots
   FrStream st;
   frstream_init(st, key);
   st_fe<R>(a.S + s_off(a.l.r, a.Bpad, b), frstream_next<R>(st));

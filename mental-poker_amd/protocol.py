@@ -202,8 +202,8 @@ class DLCards:
         return None
 
     # ================= SURVEY.md 8f1: the rest of the trait (batched sigma protocols on the GPU) =================
-    # `rng_seed` arguments below: 32 fresh bytes PER CALL.  The nonce of a sigma proof is derived from the seed alone; the same seed
-    # with the same secret in two proofs reveals the secret (include/mpshuffle.h, "SEEDS MUST NEVER REPEAT").
+    # `rng_seed` arguments below: 32 fresh bytes per call.  (The engine hedges the sigma nonce with witness and statement --
+    # include/mpshuffle.h "sigma transcript v2" -- so an accidentally repeated seed does not leak the secret; do not rely on it.)
     def _t(self, pp, shared_key=None):
         return self.table(pp, shared_key if shared_key is not None else pp.enc_parameters)
 

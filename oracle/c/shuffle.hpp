@@ -679,7 +679,27 @@ struct Shuffle {
   };
   static SigmaProof sigma_prove(const PtVec& bases, const PtVec& publics, const Fr& x, const uint8_t* fs_init,
                                 size_t fs_init_len, const uint8_t prover_seed[32]) {
-    ChaChaRng prng(prover_seed);
+    // hedged nonce ("sigma transcript v2"): s1 = Blake2s(x || Blake2s(fs_init) || seed), s2 = Blake2s(ToBytes(bases, publics) || s1)
+    uint8_t s1[32], s2[32], fsd[32], xb[32];
+    Blake2s::digest(fs_init, fs_init_len, fsd);
+    x.to_bytes(xb);
+    {
+      Blake2s b;
+      b.update(xb, 32);
+      b.update(fsd, 32);
+      b.update(prover_seed, 32);
+      b.final(s1);
+    }
+    {
+      std::vector<uint8_t> sb;
+      pts_tobytes(bases, sb);
+      pts_tobytes(publics, sb);
+      Blake2s b;
+      b.update(sb.data(), sb.size());
+      b.update(s1, 32);
+      b.final(s2);
+    }
+    ChaChaRng prng(s2);
     Fr r = field_rand<Fr>(prng);
     SigmaProof pf;
     for (auto& g : bases) pf.A.push_back(mul(r, g));

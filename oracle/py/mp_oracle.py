@@ -930,9 +930,12 @@ CHECK_NAMES.update({5: "Schnorr Identification", 6: "Chaum-Pedersen"})
 
 @_with_curve
 def sigma_prove(cv, bases, publics, x, fs_init, prover_seed):
-    """-> (commitments, z).  `fs_init` = bytes the FiatShamirRng is seeded from; r = first Fr::rand of
-    ChaCha20Rng::from_seed(prover_seed)."""
-    r = fr_rand(cv, ChaCha20Rng(prover_seed))
+    """-> (commitments, z).  `fs_init` = bytes the FiatShamirRng is seeded from.  The nonce is hedged ("sigma transcript v2"):
+    r = Fr::rand(ChaCha20Rng(s2)), s1 = Blake2s(x (32 B LE) || Blake2s(fs_init) || prover_seed), s2 = Blake2s(ToBytes(bases, publics) || s1)
+    -- a repeated seed only repeats the nonce if witness and statement repeat too."""
+    s1 = blake2s(fe_bytes(x % cv.q) + blake2s(fs_init) + bytes(prover_seed))
+    s2 = blake2s(_pts_bytes(list(bases) + list(publics)) + s1)
+    r = fr_rand(cv, ChaCha20Rng(s2))
     A = [pt_mul(cv, r, g) for g in bases]
     fs = FiatShamirRng(fs_init)
     fs.absorb(_pts_bytes(list(bases) + list(publics) + A))

@@ -240,3 +240,19 @@ def test_published_chacha20rng_vectors(coracle, mp):
     assert coracle.chacha20_block(bytes(32), 0) == w[:16] and coracle.chacha20_block(bytes(32), 1) == w[16:]
     m = mp.ChaCha20Rng(bytes(32))                    # the host mirror used by protocol.py
     assert [m.next_u64() for _ in range(16)] == [w[2 * i] | (w[2 * i + 1] << 32) for i in range(16)]
+
+
+def test_sigma_nonce_is_hedged(coracle):
+    """the same prover seed gives the same proof only for the same witness AND statement: two proofs for one secret under a reused
+    seed (different statements) have different commitments, so z1 - z2 no longer reveals the secret"""
+    cv = po.STARK
+    with po.curve_ctx(cv):
+        seed, x = bytes(range(32)), 0x1234567
+        g1, g2 = cv.G, po.pt_mul(cv, 5, cv.G)
+        A1, z1 = po.sigma_prove(cv, [g1], [po.pt_mul(cv, x, g1)], x, b"Masking Proof", seed)
+        A1b, z1b = po.sigma_prove(cv, [g1], [po.pt_mul(cv, x, g1)], x, b"Masking Proof", seed)
+        A2, z2 = po.sigma_prove(cv, [g2], [po.pt_mul(cv, x, g2)], x, b"Masking Proof", seed)
+        A3, z3 = po.sigma_prove(cv, [g1], [po.pt_mul(cv, x, g1)], x, b"Reveal Proof", seed)
+        assert (A1, z1) == (A1b, z1b)
+        r1 = po.pt_mul(cv, pow(5, -1, cv.q), A2[0])          # A2 = r2 * 5G  ->  r2 * G
+        assert r1 != A1[0] and A3[0] != A1[0]
