@@ -160,8 +160,8 @@ int mp_set_merged_verify(mp_table* t, int on);
  * the table's static plans, which this call rebuilds. */
 int mp_set_bucket_min(mp_table* t, size_t terms);
 /* How the prover evaluates the multi-exponentiation diagonals E_k (a polynomial product of the scalar rows with the ciphertext
- * rows) for 3 <= m <= 8.  on (default): Toom-Cook with the 2m points 0, inf, +-1 .. +-(m-1) -- 2m row products; off: recursive
- * Karatsuba (13 products at m = 4, 35 at m = 8; what m > 8 always uses).  m = 2 always uses its 4-point Toom-Cook form.  The
+ * rows) for 3 <= m <= 16.  on (default): Toom-Cook with the 2m points 0, inf, +-1 .. +-(m-1) -- 2m row products; off: recursive
+ * Karatsuba (13 products at m = 4, 35 at m = 8; what m > 16 always uses).  m = 2 always uses its 4-point Toom-Cook form.  The
  * E_k are the same group elements either way: proof bytes do not change.  Rebuilds the table's static plans. */
 int mp_set_toom_cook(mp_table* t, int on);
 /* Curves with a cofactor (MP_CURVE_BLS12_377): every wire point of a call -- decks, keys, proof elements -- is tested for

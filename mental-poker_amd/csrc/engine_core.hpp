@@ -137,7 +137,7 @@ struct Table : mp_table {
     tiny_batch = latency_batch / 16 * 3;
   }
   uint32_t bucket_min = BUCKET_MIN;              // MSMs of at least this many variable-base terms use the bucket kernel (0 = never)
-  bool toom_cook = true;        // 3 <= m <= 8: Toom-Cook instead of Karatsuba for the multi-exponentiation diagonals
+  bool toom_cook = true;        // 3 <= m <= 16: Toom-Cook instead of Karatsuba for the multi-exponentiation diagonals
   void set_toom_cook(bool on) override {
     if (on == toom_cook) return;
     toom_cook = on;
@@ -529,7 +529,7 @@ struct Table : mp_table {
     run_phase(pph[0], w, B);
     run_phase(pph[4], w, B);      // Toom-Cook (m = 2) / Karatsuba operand sums (empty when unused)
     const ToomPlan& tk = q.pplan.toom;
-    if (tk.E) {                   // Toom-Cook, 3 <= m <= 8: the ciphertext polynomial at +-1 .. +-(m-1)
+    if (tk.E) {                   // Toom-Cook, 3 <= m <= 16: the ciphertext polynomial at +-1 .. +-(m-1)
       ToomPointsArgs ta{w.P.p, w.J.p, w.Bpad, m, n, l.shuf, tk.cv_first};
       MP_RUN(k_toom_points, C, B, 2 * n, ta);
       normalize_flat(w.J.p + j_off<C>(tk.cv_first, w.Bpad, 0), w.P.p + p_off<C>(tk.cv_first, w.Bpad, 0), w.NS.p,

@@ -495,7 +495,7 @@ MP_KERNEL(k_normalize, NormArgs, body_normalize)
 
 // ---- Toom-Cook, ciphertext side: C(x) = sum_s x^s c_s at x = +-1 .. +-(m-1) for one column point of the shuffled deck
 // (c_s = row m - s; x = proof, y = 2 t + component).  Even / odd split: C(+-x) = Ce(x^2) +- x Co(x^2), Horner in x^2; the small
-// integer multiples are double-and-add chains on Jacobian points (x <= 7: at most 5 doublings + 2 additions per multiple).
+// integer multiples are double-and-add chains on Jacobian points (x <= 15, x^2 <= 225: at most 7 doublings + 4 additions per multiple).
 // Jacobian out -> k_normalize -> the operand vectors of the 2m - 2 products.
 struct ToomPointsArgs {
   const uint32_t* P;
@@ -503,10 +503,10 @@ struct ToomPointsArgs {
   uint32_t Bpad, m, n, p_shuf, cv_first;
 };
 template <class C>
-MP_HD void jac_mul_small_ip(Jac<C>& p, uint32_t k) {      // p <- k p, 1 <= k < 64
+MP_HD void jac_mul_small_ip(Jac<C>& p, uint32_t k) {      // p <- k p, 1 <= k < 256
   if (k == 1) return;
   const Jac<C> base = p;
-  int top = 5;
+  int top = 7;
   while (!((k >> top) & 1u)) --top;
   for (int i = top - 1; i >= 0; --i) {
     jac_dbl_ip<C>(p);

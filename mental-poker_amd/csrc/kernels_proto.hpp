@@ -389,7 +389,7 @@ MP_HD void body_prove_scal1(const ProveScalArgs& a, uint32_t b, uint32_t y) {
 }
 MP_KERNEL(k_prove_scal1, ProveScalArgs, body_prove_scal1)
 
-// ---- Toom-Cook operands (3 <= m <= 8, layout.hpp ToomPlan) ---------------------------------------------------------------
+// ---- Toom-Cook operands (3 <= m <= 16, layout.hpp ToomPlan) ---------------------------------------------------------------
 // scalar side: S[dst + t] = sum_i consts[coef_i] * S[src_i + t]   (x = proof, y = job * n + t: one lane per output scalar)
 struct LinCombArgs {
   uint32_t* S;

@@ -326,7 +326,7 @@ struct ToomPlan {
   uint32_t n_consts = 0, w_const_first = 0;
   int32_t x_of(uint32_t e) const { return e < 2 ? 0 : ((e & 1) ? -(int32_t)(e / 2) : (int32_t)(e / 2)); }
 };
-static const uint32_t TOOM_MAX_M = 8;
+static const uint32_t TOOM_MAX_M = 16;
 // S[dst + t] = sum_i C_i S[src_i + t] with constant coefficients C_i = consts[lin_coef_i] (kernel k_lin_comb)
 struct ProvePlan {
   ProveLay lay;
@@ -429,8 +429,8 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
   ProvePlan pl;
   pl.lay = make_prove_lay(m, n);
   pl.lay.toom = m == 2 ? 1u : 0u;
-  // 3 <= m <= 8: Toom-Cook with the 2m points 0, inf, +-1 .. +-(m-1): 2m row products instead of Karatsuba's 13 (m = 4) / 35
-  // (m = 8).  The ciphertext polynomial is evaluated with doublings and additions only (small integer points), the scalar
+  // 3 <= m <= 16: Toom-Cook with the 2m points 0, inf, +-1 .. +-(m-1): 2m row products instead of Karatsuba's 13 (m = 4) / 35
+  // (m = 8) / 97 (m = 16).  (At m = 32 the evaluation of the ciphertext polynomial at +-31 would cost more than the products it saves.)  The ciphertext polynomial is evaluated with doublings and additions only (small integer points), the scalar
   // polynomial in Fr, and the coefficients E_k come back through the inverse Vandermonde matrix over Fr (phase B2: one
   // 2m-term MSM per diagonal over the 2m normalised products) -- the same group elements, so the proof bytes do not change.
   const bool toomk = toom_cook && m >= 3 && m <= TOOM_MAX_M;
