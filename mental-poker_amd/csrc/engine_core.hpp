@@ -153,30 +153,36 @@ struct Table : mp_table {
     const uint32_t E = T.E, mm = E / 2;
     auto put = [&](uint32_t idx, const Fe<R>& v) { fe_pack<R>(v, &out[(size_t)idx * 8]); };
     std::vector<Fe<R>> X(E);
-    for (uint32_t e = 0; e < E; ++e) {
+    auto powers = [&](const Fe<R>& x, uint32_t cnt) {                 // x^0 .. x^(cnt-1)
+      std::vector<Fe<R>> p(cnt);
+      p[0] = fe_one<R>();
+      for (uint32_t k = 1; k < cnt; ++k) p[k] = fe_mul<R>(p[k - 1], x);
+      return p;
+    };
+    for (uint32_t e = 2; e < E; ++e) {
       const int32_t x = T.x_of(e);
       X[e] = x >= 0 ? fe_from_u32<R>((uint32_t)x) : fe_neg<R>(fe_from_u32<R>((uint32_t)(-x)));
     }
+    // scalar operand of point e: sum_j coef_j a_j with coef_j = x^j, or x^(m - j) for a reversed point
     for (uint32_t e = 2; e < E; ++e) {
-      Fe<R> p = fe_one<R>();
-      for (uint32_t j = 0; j <= mm; ++j) {
-        put(e * (mm + 1) + j, p);
-        p = fe_mul<R>(p, X[e]);
-      }
+      const std::vector<Fe<R>> pw = powers(X[e], mm + 1);
+      for (uint32_t j = 0; j <= mm; ++j) put(e * (mm + 1) + j, T.rev_of(e) ? pw[mm - j] : pw[j]);
     }
-    // V[e][k] = x_e^k (e = 0: X = 0 -> (1, 0, ...); e = 1: X = infinity -> (0, ..., 0, 1)); W = V^-1 by Gauss-Jordan
+    // V[e][k]: the product at point e is sum_k V[e][k] E_k -- x^k, or x^(2m - 1 - k) for a reversed point (reversed operands of
+    // degrees m and m - 1); e = 0: (1, 0, ...), e = 1 (infinity): (0, ..., 0, 1).  W = V^-1 by Gauss-Jordan
     std::vector<Fe<R>> V((size_t)E * E, fe_zero<R>()), W((size_t)E * E, fe_zero<R>());
     for (uint32_t e = 0; e < E; ++e) {
       W[(size_t)e * E + e] = fe_one<R>();
+      if (e == 0) {
+        V[0] = fe_one<R>();
+        continue;
+      }
       if (e == 1) {
         V[(size_t)e * E + (E - 1)] = fe_one<R>();
         continue;
       }
-      Fe<R> p = fe_one<R>();
-      for (uint32_t k = 0; k < E; ++k) {
-        V[(size_t)e * E + k] = p;
-        p = e == 0 ? fe_zero<R>() : fe_mul<R>(p, X[e]);
-      }
+      const std::vector<Fe<R>> pw = powers(X[e], E);
+      for (uint32_t k = 0; k < E; ++k) V[(size_t)e * E + k] = T.rev_of(e) ? pw[E - 1 - k] : pw[k];
     }
     for (uint32_t col = 0; col < E; ++col) {
       uint32_t piv = col;

@@ -495,7 +495,7 @@ MP_KERNEL(k_normalize, NormArgs, body_normalize)
 
 // ---- Toom-Cook, ciphertext side: C(x) = sum_s x^s c_s at x = +-1 .. +-(m-1) for one column point of the shuffled deck
 // (c_s = row m - s; x = proof, y = 2 t + component).  Even / odd split: C(+-x) = Ce(x^2) +- x Co(x^2), Horner in x^2; the small
-// integer multiples are double-and-add chains on Jacobian points (x <= 15, x^2 <= 225: at most 7 doublings + 4 additions per multiple).
+// integer multiples are double-and-add chains on Jacobian points (x <= 8 with the reciprocal points: x^2 <= 64).
 // Jacobian out -> k_normalize -> the operand vectors of the 2m - 2 products.
 struct ToomPointsArgs {
   const uint32_t* P;
@@ -516,12 +516,16 @@ MP_HD void jac_mul_small_ip(Jac<C>& p, uint32_t k) {      // p <- k p, 1 <= k < 
 template <class C>
 MP_HD void body_toom_points(const ToomPointsArgs& a, uint32_t b, uint32_t y) {
   const uint32_t t = y >> 1, comp = y & 1u, m = a.m;
-  // c_s at P slot p_shuf + 2 ((m - 1 - s) n + t) + comp
-  auto cs = [&](uint32_t s) { return ld_aff<C>(a.P + p_off<C>(a.p_shuf + 2 * ((m - 1 - s) * a.n + t) + comp, a.Bpad, b)); };
   const uint32_t top_even = (m - 1) & ~1u, top_odd = ((m - 1) & 1u) ? m - 1 : m - 2;      // m >= 3: both exist
 #pragma unroll 1
-  for (uint32_t x = 1; x < m; ++x) {
-    const uint32_t yy = x * x;
+  for (uint32_t p = 0; p + 1 < m; ++p) {            // pair p: +-x, direct or reversed coefficient order (layout.hpp ToomPlan)
+    const uint32_t x = p == 0 ? 1u : (p + 1) / 2 + 1, yy = x * x;
+    const bool rev = p != 0 && (p & 1u) == 0;
+    // coefficient s of the (possibly reversed) polynomial: c_s = row m - s, at P slot p_shuf + 2 ((m - 1 - s) n + t) + comp
+    auto cs = [&](uint32_t s) {
+      const uint32_t row = rev ? s : m - 1 - s;
+      return ld_aff<C>(a.P + p_off<C>(a.p_shuf + 2 * (row * a.n + t) + comp, a.Bpad, b));
+    };
     Jac<C> ce = jac_from_aff<C>(cs(top_even));
 #pragma unroll 1
     for (int s = (int)top_even - 2; s >= 0; s -= 2) {
@@ -539,9 +543,9 @@ MP_HD void body_toom_points(const ToomPointsArgs& a, uint32_t b, uint32_t y) {
     jac_add_ip<C>(plus, co);
     co.Y = fe_neg<typename C::FqP>(co.Y);
     jac_add_ip<C>(ce, co);
-    // e = 2x (+x) and 2x + 1 (-x); vectors of 2n points each, e >= 2
-    st_jac<C>(a.J + j_off<C>(a.cv_first + (2 * x - 2) * 2 * a.n + y, a.Bpad, b), plus);
-    st_jac<C>(a.J + j_off<C>(a.cv_first + (2 * x - 1) * 2 * a.n + y, a.Bpad, b), ce);
+    // e = 2 + 2p (+x) and 3 + 2p (-x); vectors of 2n points each
+    st_jac<C>(a.J + j_off<C>(a.cv_first + (2 * p) * 2 * a.n + y, a.Bpad, b), plus);
+    st_jac<C>(a.J + j_off<C>(a.cv_first + (2 * p + 1) * 2 * a.n + y, a.Bpad, b), ce);
   }
 }
 MP_KERNEL_OCC(k_toom_points, ToomPointsArgs, body_toom_points, 2)

@@ -315,16 +315,26 @@ struct LinJob {
 };
 
 // Toom-Cook evaluation of the multi-exponentiation diagonals for 3 <= m <= TOOM_MAX_M (see make_prove_plan): 2m evaluation
-// points x_e -- e = 0: X = 0, e = 1: X = infinity, e = 2x / 2x + 1: X = +x / -x for x = 1 .. m - 1.
+// points -- e = 0: X = 0, e = 1: X = infinity, then m - 1 pairs +-x: pair p = (e - 2) / 2 has the integer x = pair_x(p) and is either
+// DIRECT (the polynomials at +-x) or REVERSED (the reversed polynomials at +-x, i.e. the originals at +-1/x scaled by a power of x --
+// the same Horner recurrence on the coefficients in opposite order).  Pairs: (1), (2), (1/2), (3), (1/3), (4), (1/4), ...: with
+// reciprocals the largest integer at m = 16 is 8 instead of 15 and the Horner multipliers x^2 stay <= 64.
 struct ToomPlan {
   uint32_t E = 0;                 // number of evaluation points (2m), 0 = not used
   uint32_t sv_first = 0;          // S slots of the evaluated scalar vectors, e >= 2: sv_first + (e - 2) n
   uint32_t cv_first = 0;          // P slots of the evaluated ciphertext vectors, e >= 2: cv_first + (e - 2) 2n
   uint32_t pp_first = 0;          // P slots of the 2m products (2 components each): pp_first + 2 e + c
   uint32_t w_first = 0;           // S slots of the interpolation matrix W[k][e] (constants): w_first + k E + e
-  // constants the engine computes in Fr (layout.hpp has no field arithmetic): index e (m + 1) + j = x_e^j, then W row-major
+  // constants the engine computes in Fr (layout.hpp has no field arithmetic): index e (m + 1) + j = coefficient of a_j in the
+  // scalar operand of point e, then W row-major
   uint32_t n_consts = 0, w_const_first = 0;
-  int32_t x_of(uint32_t e) const { return e < 2 ? 0 : ((e & 1) ? -(int32_t)(e / 2) : (int32_t)(e / 2)); }
+  static uint32_t pair_x(uint32_t p) { return p == 0 ? 1u : (p + 1) / 2 + 1; }        // 1, 2, 2, 3, 3, 4, 4, ...
+  static bool pair_rev(uint32_t p) { return p != 0 && (p & 1u) == 0; }                // .., direct, reversed, direct, reversed
+  int32_t x_of(uint32_t e) const {                                                    // signed integer of point e >= 2
+    const int32_t x = (int32_t)pair_x((e - 2) / 2);
+    return (e & 1u) ? -x : x;
+  }
+  bool rev_of(uint32_t e) const { return pair_rev((e - 2) / 2); }
 };
 static const uint32_t TOOM_MAX_M = 16;
 // S[dst + t] = sum_i C_i S[src_i + t] with constant coefficients C_i = consts[lin_coef_i] (kernel k_lin_comb)
