@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--tables", type=int, default=65536)
     ap.add_argument("--players", type=int, default=4)
     ap.add_argument("--check", action="store_true", help="re-run table 0's chain on the CPU oracle and compare bytes")
+    ap.add_argument("--chain-verify", action="store_true",
+                    help="keep every deck and proof in HBM and verify all tables' chains at the end with ONE equation per table "
+                         "(mp_verify_shuffle_chain_dev) instead of link by link as the proofs are produced")
     args = ap.parse_args()
     m, n, curve = 2, 26, "stark"
     N, T, P = m * n, args.tables, args.players
@@ -50,6 +53,11 @@ def main():
     st_v = torch.empty(T, dtype=torch.int32, device=gpu)
     t.reserve(T)
     trace = []
+    if args.chain_verify:
+        chain = torch.empty(P + 1, T, N * 128, dtype=torch.uint8, device=gpu)
+        chain[0] = deck
+        all_proofs = torch.empty(P, T, t.proof_bytes, dtype=torch.uint8, device=gpu)
+        st_c = torch.empty(P, T, dtype=torch.int32, device=gpu)
     # warm-up on scratch outputs: the first keyed call builds the keyed plans and grows the batch workspace
     w_rho = rand_bytes(T, N, 32)
     w_rho[:, :, 31] &= 0x07
@@ -69,13 +77,27 @@ def main():
         t0 = time.perf_counter()          # the players' random choices above are input generation, not timed
         t.shuffle_and_remask_batch_keys_dev(T, keys.data_ptr(), deck.data_ptr(), rho.data_ptr(), perms.data_ptr(), seeds.data_ptr(),
                                             nxt.data_ptr(), proofs.data_ptr(), st_p.data_ptr())
-        t.verify_shuffle_batch_keys_dev(T, keys.data_ptr(), deck.data_ptr(), nxt.data_ptr(), proofs.data_ptr(), st_v.data_ptr())
+        if args.chain_verify:
+            st_v.zero_()
+        else:
+            t.verify_shuffle_batch_keys_dev(T, keys.data_ptr(), deck.data_ptr(), nxt.data_ptr(), proofs.data_ptr(), st_v.data_ptr())
         eng.sync()
         busy += time.perf_counter() - t0
         assert int(st_p.abs().sum().item()) == 0 and int(st_v.abs().sum().item()) == 0, "a shuffle failed"
+        if args.chain_verify:
+            chain[j + 1] = nxt
+            all_proofs[j] = proofs
         if args.check:
             trace.append(tuple(bytes(x[0].cpu().numpy().tobytes()) for x in (deck, rho, seeds, nxt, proofs)) + ([int(v) for v in perms[0].tolist()],))
         deck, nxt = nxt, deck
+    if args.chain_verify:
+        kk = keys.repeat(P, 1).contiguous()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        t.verify_shuffle_chain_dev(T, P, kk.data_ptr(), chain.data_ptr(), all_proofs.data_ptr(), st_c.data_ptr())
+        eng.sync()
+        busy += time.perf_counter() - t0
+        assert int(st_c.abs().sum().item()) == 0, "a chain failed"
     print("%d tables x %d players, 52 cards, %d distinct aggregate keys: %d shuffles proved and verified in %.2f s of engine time "
           "= %.0f proofs/s" % (T, P, K, T * P, busy, T * P / busy))
     if args.check:
