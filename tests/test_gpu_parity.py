@@ -597,3 +597,51 @@ def test_chain_verification_matches_per_link_verifier(mp, coracle, cvn, m, n, L,
         a = (b"".join(decks[j]), b"".join(decks[j + 1]), b"".join(bad[j]))
         exp += table.verify_shuffle_batch_keys(b"".join(keys_t), *a) if keyed else table.verify_shuffle_batch(*a)
     assert st == exp and sum(1 for v in st if v) == 2
+
+
+@pytest.mark.parametrize("m,n", [(3, 2), (5, 3), (7, 4), (9, 3), (12, 2), (16, 2), (17, 2), (16, 5)])
+def test_every_plan_family_matches_oracle(mp, coracle, m, n):
+    """Toom-Cook (3 <= m <= 16, direct and reciprocal points), Karatsuba (m = 17) and the bucket kernel forced onto these small shapes:
+    proof bytes equal the CPU oracle's, both verification strategies accept, a rotated batch is rejected by name"""
+    cv, B = "stark", 3
+    cards = mp.DLCards(cv, device=0)
+    g0 = coracle.gen_inputs(cv, m, n, 4242)
+    pp, pk = mp.Parameters(m, n, g0["params"]), g0["pk"]
+    t = cards.table(pp, pk)
+    ins = [coracle.gen_inputs(cv, m, n, 4300 + b) for b in range(B)]
+    cb = 2 * cards.engine.point_bytes
+    for latency_batch, bucket_min, toom in ((0, 2048, True), (0, 4, True), (0, 2048, False), (8192, 2048, True)):
+        t.set_latency_batch(latency_batch)
+        t.set_bucket_min(bucket_min)
+        t.set_toom_cook(toom)
+        res = cards.shuffle_and_remask_batch([g["prover_seed"] for g in ins], pp, pk, [_split(g["deck"], cb) for g in ins],
+                                             [[int.from_bytes(x, "little") for x in _split(g["rho"], 32)] for g in ins],
+                                             [mp.Permutation(g["perm"]) for g in ins])
+        decks, shufs, proofs = [], [], []
+        for g, r in zip(ins, res):
+            assert not isinstance(r, Exception), r
+            exp_deck, exp_proof = coracle.shuffle_and_remask(cv, m, n, g0["params"], pk, g["deck"], g["rho"], g["perm"], g["prover_seed"])
+            assert b"".join(r[0]) == exp_deck and r[1] == exp_proof, (latency_batch, bucket_min, toom)
+            decks.append(_split(g["deck"], cb)); shufs.append(r[0]); proofs.append(r[1])
+        for merged in (True, False):
+            t.set_merged_verify(merged)
+            assert cards.verify_shuffle_batch(pp, pk, decks, shufs, proofs) == [None] * B
+            out = cards.verify_shuffle_batch(pp, pk, decks, shufs[1:] + shufs[:1], proofs)
+            assert all(o == mp.CryptoError("Hadamard Product (5.1)") for o in out)
+
+
+def test_chain_verification_edge_shapes(mp, coracle):
+    """one link, one table; and a chain whose LAST deck is tampered"""
+    cv, m, n = "stark", 2, 3
+    eng = mp.Engine(cv, device=0)
+    g0 = coracle.gen_inputs(cv, m, n, 9)
+    t = eng.table(m, n, g0["params"], g0["pk"])
+    d1, p1 = coracle.shuffle_and_remask(cv, m, n, g0["params"], g0["pk"], g0["deck"], g0["rho"], g0["perm"], g0["prover_seed"])
+    assert t.verify_shuffle_chain(1, 1, g0["deck"] + d1, p1) == [0]
+    g1 = coracle.gen_inputs(cv, m, n, 10)
+    d2, p2 = coracle.shuffle_and_remask(cv, m, n, g0["params"], g0["pk"], d1, g1["rho"], g1["perm"], g1["prover_seed"])
+    assert t.verify_shuffle_chain(1, 2, g0["deck"] + d1 + d2, p1 + p2) == [0, 0]
+    st = t.verify_shuffle_chain(1, 2, g0["deck"] + d1 + g1["deck"], p1 + p2)
+    assert st[0] == 0 and st[1] > 0
+    with pytest.raises(mp.NativeError):
+        t.verify_shuffle_chain(1, 2, g0["deck"] + d1, p1 + p2)          # a deck short
