@@ -62,7 +62,7 @@ def test_mirror_types(native):
 @pytest.fixture(scope="module")
 def emu(native):
     d = os.path.join(ROOT, "tools", "hostemu")
-    subprocess.check_call(["make", "-s", "-C", d])
+    subprocess.check_call(["make", "-s", "-j8", "-C", d])
     lib = native._native.bind(ctypes.CDLL(os.path.join(d, "libmpemu.so")))
     return lambda curve: native._native.Engine(curve, 0, lib=lib)
 

@@ -119,7 +119,7 @@ def _engine_worker(rank, world, port, q, total):
 
 def test_sharded_engine_output_equals_unsharded():
     import subprocess
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools", "hostemu")])
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "tools", "hostemu")])
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
