@@ -612,6 +612,7 @@ def main():
                    "peak": INT_MAD_PEAK_G, "unit": "Gmad/s",
                    "frac": mads / (kernel_ms_total * 1e-3) / 1e9 / INT_MAD_PEAK_G,
                    "mads_per_proof": int(mads_per_proof), "mads_per_op": {k: v for k, v in mc.items() if k != "field"},
+                   "plan_stats": stats, "bucket_windows": bw,
                    "mads_per_field_op": mc["field"],
                    "note": "32x32+64 multiply-adds (v_mad_u64_u32 + v_mad_i64_i32) counted in the gfx950 assembly of THIS build "
                            "(mental-poker_amd/mad_counts.json, tools/gen_mad_counts.py) x static plan; peak = 256 CU x 4 SIMD x 8 lanes/clk x "

@@ -282,7 +282,17 @@ int mp_verify_shuffle_chain_dev(mp_table* t, size_t tables, uint32_t links, cons
   if ((uint64_t)tables * links >= ((uint64_t)1 << 31)) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_chain_dev: too many proofs for one call");
   MP_TRY
   rt::set_device(t->ctx->device);
-  t->verify_chain_dev(tables, links, (const uint8_t*)d_decks, (const uint8_t*)d_proofs, (int32_t*)d_status, (const uint8_t*)d_keys);
+  // one chain equation holds at most 32 767 distinct points ((L + 1) 2N decks + L (11m + 8) proof elements + key): longer chains are
+  // verified as consecutive sub-chains (the decks array is link-major, so a sub-chain is a contiguous slice)
+  const size_t per_link = (size_t)2 * t->N + 11 * t->m + 8, fixed_part = (size_t)2 * t->N + 1;
+  uint32_t lmax = (uint32_t)std::max<size_t>(1, (32767 - fixed_part) / per_link);
+  if (const char* e = getenv("MP_CHAIN_MAX_LINKS")) lmax = std::max(1u, std::min(lmax, (uint32_t)atoi(e)));     // test hook
+  const size_t pb = t->point_bytes, deck_bytes = (size_t)2 * t->N * pb, psz = proof_size_bytes(t->m, t->n, (uint32_t)pb);
+  for (uint32_t j0 = 0; j0 < links; j0 += lmax) {
+    const uint32_t lc = std::min(lmax, links - j0);
+    t->verify_chain_dev(tables, lc, (const uint8_t*)d_decks + (size_t)j0 * tables * deck_bytes, (const uint8_t*)d_proofs + (size_t)j0 * tables * psz,
+                        (int32_t*)d_status + (size_t)j0 * tables, d_keys ? (const uint8_t*)d_keys + (size_t)j0 * tables * pb : nullptr);
+  }
   return MP_OK;
   MP_CATCH
 }

@@ -407,6 +407,12 @@ def test_chain_verification_under_emulation(emu, coracle, cvn, m, n, L, T, keyed
     eng.profile_enable(True)
     assert table.verify_shuffle_chain(T, L, decks, pf, keys) == [0] * (L * T)
     rep = eng.profile_report()
+    os.environ["MP_CHAIN_MAX_LINKS"] = "2"           # long chains are cut into sub-chains: same verdicts
+    try:
+        assert table.verify_shuffle_chain(T, L, decks, pf, keys) == [0] * (L * T)
+        eng.profile_report()
+    finally:
+        del os.environ["MP_CHAIN_MAX_LINKS"]
     eng.profile_enable(False)
     assert rep["k_chain_scalars"][0] == 1 and rep["k_bucket_msm"][0] == 1 and "k_var_msm" not in rep and "k_table" not in rep
     # break link 1 of table 0 (swap in another table's proof) and one deck point of the last link of table T-1
