@@ -669,7 +669,8 @@ def main():
                             "cgroup_cpu_quota": quota,
                             "sample": "%d threads x %d prove+verify pairs, one proof stream per thread, %.1f s wall" % (T, it_mt, wall)}
 
-    limbs = {"stark": "9x29-bit lazy base field", "bls12_377": "12x32 base field"}.get(curve, "8x32 base field")
+    limbs = {"stark": "9x29-bit lazy base field", "secp256k1": "9x29-bit lazy base field (signed sparse limbs)",
+             "bls12_377": "12x32 base field"}.get(curve, "8x32 base field")
     config = {"workload": "%s: %d-card deck, m=%d n=%d, %s curve, shuffle_and_remask + verify_shuffle" % (workload, N, m, n, curve),
               "unit_counted": units,
               "proofs_per_gpu_per_step": proofs_per_step, "streams": S, "fixed_base_window_bits": args.fb_bits,
