@@ -154,6 +154,10 @@ def find_pmc_summary(src_hash, curve, m, n, batch, workload):
     return None, None
 
 
+def a1_of(mc):
+    return mc.get("a1", 0)
+
+
 def load_mad_counts(curve):
     """multiply-add instructions (v_mad_u64_u32 + v_mad_i64_i32) per field product / square / fused product pair of this
     curve's base field, counted in the gfx950 assembly of the build (tools/gen_mad_counts.py -> mad_counts.json)"""
@@ -173,6 +177,7 @@ def load_mad_counts(curve):
         "aff": 5 * M + (1 + 8.0 / 15.0) * S + (4.0 / 15.0) * inv / 64.0,   # batched-affine table entry (k_table): 2 prefix-product steps, lam,
                                                          # lam^2, y3 (+ x^2 for the 8 doublings of 15); 4 inversions per 64 bases
         "jac": 11 * M + 5 * S,                           # Jacobian + Jacobian (k_combine)
+        "a1": a1,
         "norm": 6 * M + S + inv / 64.0,                  # Jacobian -> affine with a 64-point batched inversion
     }
 
@@ -587,8 +592,19 @@ def main():
     if mc:
         vw, fw = stats["var_windows"], stats["fixed_windows"]
         mads_per_proof = 0
+        chain_eq = workload == "chain32" and not args.per_link_verify
         for side in ("prove", "verify"):
             st_ = stats[side]
+            if side == "verify" and chain_eq:
+                # one chain equation per table instead of L per-link equations (engine_core.hpp build_chain_plan): a bucket MSM
+                # over the (L+1) decks, the L proofs' points and the key, plus one fixed-base term per shared generator
+                L_ = args.players
+                k_terms = (L_ + 1) * 2 * N + L_ * (11 * m + 7) + 1
+                bwc = {"secp256k1": 33}.get(curve, 32)
+                fmc = mc["field"]
+                red = 14 * 64 * (12 * fmc["mul"] + 2 * fmc["sqr"]) + 8 * mc["dbl"] + mc["jac"]
+                mads_per_proof += (k_terms * bwc * mc["madd"] + bwc * red + (n + 2) * fw * mc["madd"]) / L_
+                continue
             fixed_madds = st_["fixed_terms"] * fw
             if side == "prove":
                 fixed_madds -= N * (fw - 1)               # c_A commits pi(i)+1 <= N: one non-zero window per term
@@ -600,6 +616,24 @@ def main():
             mads_per_proof += st_["var_jobs"] * (vw - 1) * 5 * mc["dbl"]
             mads_per_proof += st_["table_bases"] * 15 * mc["aff"]
             mads_per_proof += st_["combine_terms"] * mc["jac"] + norm_points * mc["norm"]
+        # Toom-Cook evaluation of the ciphertext polynomials (k_toom_points, kernels_msm.hpp): per vector position and pair +-x a
+        # Horner scheme in x^2 over the even and the odd coefficients (Jacobian: doubling 3M+(4+2a)S, mixed addition 8M+3S,
+        # addition 11M+5S), multiplications by the small integers x^2 and x as double-and-add
+        tm = stats.get("toom_points_m", 0)
+        if tm:
+            fmt = mc["field"]
+            jdbl = 3 * fmt["mul"] + (4 + 2 * a1_of(mc)) * fmt["sqr"]
+            jmadd = 8 * fmt["mul"] + 3 * fmt["sqr"]
+
+            def mul_small(k):
+                return 0 if k == 1 else (k.bit_length() - 1) * jdbl + (bin(k).count("1") - 1) * mc["jac"]
+            top_even, top_odd = (tm - 1) & ~1, (tm - 1) if (tm - 1) & 1 else tm - 2
+            per_pos = 0
+            for p_ in range(tm - 1):
+                x_ = 1 if p_ == 0 else (p_ + 1) // 2 + 1
+                steps_ = top_even // 2 + (top_odd - 1) // 2
+                per_pos += steps_ * (mul_small(x_ * x_) + jmadd) + mul_small(x_) + 2 * mc["jac"]
+            mads_per_proof += 2 * n * per_pos + (2 * tm - 2) * 2 * n * mc["norm"]        # + normalisation of the evaluated vectors
         # bucket-method MSMs: one mixed addition per term and window; per (MSM, window) a 14-step wave-wide reduction on 64 lanes
         # (XYZZ + XYZZ, 12M+2S) and the fold (8 doublings + 1 addition)
         bw = {"stark": 32, "bn254": 32, "secp256k1": 33, "bls12_377": 32}.get(curve, 32)
@@ -611,7 +645,7 @@ def main():
         int_mul = {"bound": "v_mad_u64_u32 issue", "achieved": round(mads / (kernel_ms_total * 1e-3) / 1e9, 1),
                    "peak": INT_MAD_PEAK_G, "unit": "Gmad/s",
                    "frac": mads / (kernel_ms_total * 1e-3) / 1e9 / INT_MAD_PEAK_G,
-                   "mads_per_proof": int(mads_per_proof), "mads_per_op": {k: v for k, v in mc.items() if k != "field"},
+                   "mads_per_proof": int(mads_per_proof), "mads_per_op": {k: v for k, v in mc.items() if k not in ("field", "a1")},
                    "plan_stats": stats, "bucket_windows": bw,
                    "mads_per_field_op": mc["field"],
                    "note": "32x32+64 multiply-adds (v_mad_u64_u32 + v_mad_i64_i32) counted in the gfx950 assembly of THIS build "

@@ -515,7 +515,7 @@ class Table:
         self.eng._chk(self.lib.mp_plan_stats(self.h, v))
         keys = ["fixed_terms", "var_terms", "fixed_jobs", "var_jobs", "table_bases", "combine_terms"]
         out = {"prove": dict(zip(keys, v[0:6])), "verify": dict(zip(keys, v[6:12]))}
-        out.update(var_windows=v[12], fixed_windows=v[13], N=v[14])
+        out.update(var_windows=v[12], fixed_windows=v[13], N=v[14] & 0xFFFFFFFF, toom_points_m=v[14] >> 32)
         # MSMs on the bucket-method kernel (prove + verify together): terms and jobs; 8-bit windows
         out.update(bucket_terms=v[15] & 0xFFFFFFFF, bucket_jobs=v[15] >> 32)
         return out

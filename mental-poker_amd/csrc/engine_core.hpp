@@ -928,7 +928,8 @@ struct Table : mp_table {
     };
     for (int i = 0; i < 6; ++i) add(ps[0].pplan.ph[i], out);
     add(merged_verify ? ps[0].vplan.mph : ps[0].vplan.ph, out + 6);    // what an honest batch executes
-    out[12] = nwin; out[13] = fbg.windows; out[14] = N;
+    out[12] = nwin; out[13] = fbg.windows;
+    out[14] = N | ((uint64_t)(ps[0].pplan.toom.E ? m : 0u) << 32);      // high word: m if k_toom_points runs in this plan
     out[15] = bucket_terms | (bucket_jobs << 32);      // variable-base terms / MSMs on the bucket kernel (prove + verify)
   }
   // ---------------------------------------------------------------- sigma protocols
