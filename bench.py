@@ -195,7 +195,7 @@ def main():
     ap.add_argument("--n", type=int, default=26)
     ap.add_argument("--curve", default=None, help="stark (default; mixed: secp256k1), bn254, secp256k1, bls12_377")
     ap.add_argument("--streams", type=int, default=1, help="independent engine contexts (HIP streams) per GPU; the batch is split evenly")
-    ap.add_argument("--fb-bits", type=int, default=20, help="fixed-base window width (8, 16 or 20 bits; 20 = 27 GB of tables at n=26)")
+    ap.add_argument("--fb-bits", type=int, default=None, help="fixed-base window width (8, 16, 20 or 21 bits; 20 = 27 GB of tables at n=26, 21 = 48 GB and 12 instead of 13 windows on the STARK curve; default: 21 on the STARK curve, 20 elsewhere)")
     ap.add_argument("--cpu-iters", type=int, default=160, help="prove+verify pairs timed for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -250,6 +250,8 @@ def main():
     m, n = args.m, args.n
     N = m * n
     B = args.batch if args.batch is not None else (49152 if workload == "chain32" else 262144)
+    if args.fb_bits is None:
+        args.fb_bits = 21 if curve == "stark" else 20
     eng = mp.Engine(curve, device=local)
     PB = eng.point_bytes
     CB = 2 * PB

@@ -83,8 +83,9 @@ int mp_setup(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_
 int mp_table_create(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, const uint8_t* shared_key,
                     mp_table** out);
 /* same with an explicit fixed-base window width: 8 (16 MB of tables at n = 26, 32 additions per term; what
- * mp_table_create uses), 16 (2 GB, 16 additions per term) or 20 (27 GB, 13 additions per term: the throughput
- * configuration bench.py uses -- sized for the 288 GB of an MI355X) */
+ * mp_table_create uses), 16 (2 GB, 16 additions per term), 20 (27 GB, 13 additions per term: the throughput
+ * configuration bench.py uses -- sized for the 288 GB of an MI355X) or 21 (48 GB; ceil(scalar bits / 21) windows:
+ * 12 additions per term on the 252-bit STARK scalar field, 13 on the other curves) */
 int mp_table_create_ex(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, const uint8_t* shared_key,
                        uint32_t fb_window_bits, mp_table** out);
 void mp_table_destroy(mp_table* t);

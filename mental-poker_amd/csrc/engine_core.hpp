@@ -303,8 +303,10 @@ struct Table : mp_table {
 
   int init(mp_ctx* c, uint32_t m_, uint32_t n_, const uint8_t* params, const uint8_t* pk, uint32_t fb_bits) {
     ctx = c;
-    if (fb_bits != 8 && fb_bits != 16 && fb_bits != 20) return fail(MP_ERR_BAD_ARGUMENT, "fixed-base window width must be 8, 16 or 20 bits");
-    fbg = FbGeom{fb_bits, (256u + fb_bits - 1u) / fb_bits, (1u << fb_bits) - 1u};
+    if (fb_bits != 8 && fb_bits != 16 && fb_bits != 20 && fb_bits != 21)
+      return fail(MP_ERR_BAD_ARGUMENT, "fixed-base window width must be 8, 16, 20 or 21 bits");
+    // windows cover the scalar field's bit length (252 bits on the STARK curve: 12 windows of 21 bits instead of 13 of 20)
+    fbg = FbGeom{fb_bits, ((uint32_t)R::BITS + fb_bits - 1u) / fb_bits, (1u << fb_bits) - 1u};
     m = m_; n = n_; N = m * n;
     point_bytes = G_::PB;
     // plan thresholds count lanes, and a proof of N cards brings ~N/52 times the lanes of a 52-card proof
@@ -367,8 +369,9 @@ struct Table : mp_table {
   void build_fixed_tables(uint32_t nb) {
     rt::Stream s = ctx->stream;
     // narrow table first (h-bit windows: h = 8 for 8- and 16-bit tables, 10 for 20-bit tables), built by chains
-    const uint32_t h = fbg.bits == 8 ? 8u : fbg.bits / 2u;
-    const FbGeom gh{h, (256u + h - 1u) / h, (1u << h) - 1u};
+    // (a 21-bit window splits 11 + 10: the narrow windows alternate between the two widths, all of them with 2^h - 1 entries)
+    const uint32_t h = fbg.bits == 8 ? 8u : (fbg.bits + 1u) / 2u, h2 = fbg.bits == 8 ? 8u : fbg.bits - h;
+    const FbGeom gh{h, fbg.bits == 8 ? fbg.windows : 2u * fbg.windows, (1u << h) - 1u};
     DevBuf<uint32_t> WJ, W, EJ, scratch, Th;
     const size_t nwinpts = (size_t)nb * gh.windows, nent = nwinpts * gh.entries;
     WJ.alloc(nwinpts * G_::JW, s);
@@ -376,7 +379,7 @@ struct Table : mp_table {
     EJ.alloc(nent * G_::JW, s);
     scratch.alloc(nent * G_::FW, s);
     Th.alloc(nent * G_::PW, s);
-    FbWinArgs wa{fbpts.p, WJ.p, gh};
+    FbWinArgs wa{fbpts.p, WJ.p, gh, h2};
     MP_RUN(k_fb_windows, C, nb, 1, wa);
     normalize_flat(WJ.p, W.p, scratch.p, nwinpts);
     FbFillArgs fa{W.p, EJ.p, gh};

@@ -100,9 +100,9 @@ template <class C>
 MP_HD size_t j_off(uint32_t slot, uint32_t Bpad, uint32_t b) { return ((size_t)slot * Bpad + b) * Geo<C>::JW; }
 
 // ---- fixed-base MSM ---------------------------------------------------------------------------------
-// geometry of the fixed-base tables of a table context: `bits`-wide unsigned windows (8, 16 or 20)
+// geometry of the fixed-base tables of a table context: `bits`-wide unsigned windows (8, 16, 20 or 21)
 struct FbGeom {
-  uint32_t bits, windows, entries;   // windows = ceil(256 / bits), entries = 2^bits - 1
+  uint32_t bits, windows, entries;   // windows = ceil(scalar bits / bits), entries = 2^bits - 1
 };
 struct FixedArgs {
   const uint32_t* S;
@@ -582,13 +582,14 @@ struct FbWinArgs {
   const uint32_t* bases;   // [nbases] affine
   uint32_t* WJ;            // [base][window] Jacobian
   FbGeom g;
+  uint32_t bits2;          // width of the odd-numbered windows (= g.bits unless a wide window splits unevenly)
 };
 template <class C>
 MP_HD void body_fb_windows(const FbWinArgs& a, uint32_t x, uint32_t y) {
   Jac<C> acc = jac_from_aff<C>(ld_aff<C>(a.bases + (size_t)x * Geo<C>::PW));
   for (uint32_t w = 0; w < a.g.windows; ++w) {
     st_jac<C>(a.WJ + ((size_t)x * a.g.windows + w) * Geo<C>::JW, acc);
-    for (uint32_t q = 0; q < a.g.bits; ++q) jac_dbl_ip<C>(acc);
+    for (uint32_t q = 0; q < ((w & 1u) ? a.bits2 : a.g.bits); ++q) jac_dbl_ip<C>(acc);
   }
 }
 MP_KERNEL(k_fb_windows, FbWinArgs, body_fb_windows)

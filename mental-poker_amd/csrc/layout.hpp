@@ -60,7 +60,7 @@ struct FixedBases {
   MP_HD uint32_t count() const { return n + 5; }
 };
 
-// fixed-base tables: window width is a property of the table context (FbGeom in kernels_msm.hpp: 8, 16 or 20 bits)
+// fixed-base tables: window width is a property of the table context (FbGeom in kernels_msm.hpp: 8, 16, 20 or 21 bits)
 static const int VB_WINDOW_BITS = 5;     // variable-base (Straus) signed windows: digits in [-15, 16]
 static const int VB_ENTRIES = 16;
 static const uint32_t KEY_WINDOWS = 52;  // >= vb_windows(scalar bits) of every curve: window bases of a per-proof key

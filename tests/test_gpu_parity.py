@@ -96,9 +96,9 @@ def test_batch_matches_oracle(mp, engines, coracle, curve, m, n, B, plan):
     cards.table(pp, pk).set_latency_batch(8192)
 
 
-@pytest.mark.parametrize("fb_bits", [16, 20])
+@pytest.mark.parametrize("fb_bits", [16, 20, 21])
 def test_wide_fixed_base_windows_match_oracle(mp, coracle, fb_bits):
-    """the throughput configurations (16-bit fixed-base windows: 2 GB of tables; 20-bit: 27 GB, what bench.py uses) are
+    """the throughput configurations (16-bit fixed-base windows: 2 GB of tables; 20-bit: 27 GB; 21-bit: 48 GB and one window fewer on the 252-bit STARK scalars) are
     bit-identical too"""
     cv, m, n, B = "stark", 2, 26, 4
     cards = mp.DLCards(cv, device=0, fb_bits=fb_bits)
