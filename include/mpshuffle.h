@@ -91,6 +91,10 @@ int mp_table_create_ex(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* param
 void mp_table_destroy(mp_table* t);
 
 /* ---- DLCards::shuffle_and_remask / verify_shuffle (one proof; host buffers) --------------------------------- */
+/* prover_seed: 32 FRESH uniformly random bytes per proof.  It stands for the reference's `rng: &mut R` [REF src/lib.rs:181-188]
+ * and keys the ChaCha20 stream behind every blinding value of the argument; like any sigma-type proof, two proofs made from
+ * one seed with different witnesses reveal the witnesses (permutation and masking factors).  (The sigma protocols further
+ * down hedge their single nonce with witness and statement; the shuffle prover draws its O(N) blinders from the seed alone.) */
 int mp_shuffle_and_remask(mp_table* t, const uint8_t* deck, const uint8_t* masking_factors,
                           const uint32_t* permutation, const uint8_t prover_seed[32], uint8_t* out_deck,
                           uint8_t* out_proof);
