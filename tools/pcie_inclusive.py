@@ -20,7 +20,7 @@ eng = mp.Engine("stark", 0)
 params = eng.setup(m, n, bytes([1] * 32))
 pk = eng.setup(m, 2, bytes([2] * 32))[:64]
 base = eng.setup(m, 2 * N - 3, bytes([3] * 32))
-t = eng.table(m, n, params, pk, fb_bits=20)
+t = eng.table(m, n, params, pk, fb_bits=21)
 lib = t.lib
 rng = np.random.default_rng(1)
 src = dict(rho=rng.integers(0, 256, size=(B, N, 32), dtype=np.uint8), perms=np.argsort(rng.random((B, N)), axis=1).astype(np.uint32),
