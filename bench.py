@@ -209,6 +209,10 @@ def main():
                     help="variable-base MSMs of at least this many terms run on the bucket-method kernel (engine default 2048; 0 = never)")
     ap.add_argument("--per-equation", action="store_true", help="verify equation by equation (mp_set_merged_verify off)")
     ap.add_argument("--players", type=int, default=32, help="chain32: shuffles per table")
+    ap.add_argument("--no-keyset", action="store_true",
+                    help="chain32 / --keyed: pass the aggregate keys with every call (mp_*_batch_keys_dev: the key's window tables are rebuilt "
+                         "per proof) instead of preparing them once as a key set (mp_keyset_create, built outside the timed region like "
+                         "the fixed-base tables of the shared parameters)")
     ap.add_argument("--per-link-verify", action="store_true",
                     help="chain32: verify every link on its own (mp_verify_shuffle_batch_keys_dev) instead of one chain equation per table "
                          "(mp_verify_shuffle_chain_dev)")
@@ -327,6 +331,14 @@ def main():
         kt = torch.frombuffer(bytearray(kpts[:PB * K]), dtype=torch.uint8).to(gpu).view(K, PB)
         return kt[torch.arange(count, device=gpu) % K].contiguous()
 
+    def make_keyset(tbl, K, count):
+        """the same K keys as make_keys as a key set of `tbl`, and the per-proof key indices (b % K)"""
+        kpts = eng.setup(m, max(K, 2), bytes([4] * 32))
+        t0 = time.perf_counter()
+        ks = tbl.keyset(kpts[:PB * K])
+        eng.sync()
+        return ks, (torch.arange(count, device=gpu) % K).to(torch.int32).contiguous(), time.perf_counter() - t0
+
     base = torch.frombuffer(bytearray(base_deck), dtype=torch.uint8).to(gpu)
 
     def prime_decks(count, keys=None):
@@ -368,8 +380,18 @@ def main():
         def sl(t, i):
             return t[i * Bs:(i + 1) * Bs].data_ptr()
 
-        def step(kk=keys):
+        kset = None
+        if keys is not None and not args.no_keyset and S == 1:
+            kset = make_keyset(table, args.keyed, B)
+            extras["keyset_build_s"] = kset[2]
+
+        def step(kk=keys, kset=kset):
             for i, t in enumerate(tables):
+                if kset is not None:
+                    t.shuffle_and_remask_batch_keyset_dev(kset[0], Bs, kset[1].data_ptr(), sl(decks, i), sl(factors, i), sl(perms, i), sl(seeds, i),
+                                                          sl(out_decks, i), sl(out_proofs, i), sl(st_p, i))
+                    t.verify_shuffle_batch_keyset_dev(kset[0], Bs, kset[1].data_ptr(), sl(decks, i), sl(out_decks, i), sl(out_proofs, i), sl(st_v, i))
+                    continue
                 if kk is not None:
                     t.shuffle_and_remask_batch_keys_dev(Bs, sl(kk, i), sl(decks, i), sl(factors, i), sl(perms, i), sl(seeds, i),
                                                         sl(out_decks, i), sl(out_proofs, i), sl(st_p, i))
@@ -426,11 +448,20 @@ def main():
             G -= 1
         kk = keys.repeat(G, 1).contiguous()
         keyless.reserve(T if chain_verify else max(T, G * T))
+        kset = None
+        if not args.no_keyset:
+            kset = make_keyset(keyless, T, T)       # one key per table, prepared once (a table keeps its key across hands)
+            extras["keyset_build_s"] = kset[2]
         priming_launches = {}
         torch.cuda.synchronize()
 
         def step():
             for j in range(L):
+                if kset is not None:
+                    keyless.shuffle_and_remask_batch_keyset_dev(kset[0], T, kset[1].data_ptr(), chain[j].data_ptr(), fac[j & 1].data_ptr(),
+                                                                prm[j & 1].data_ptr(), sds.data_ptr(), chain[j + 1].data_ptr(),
+                                                                proofs[j].data_ptr(), st_p[j].data_ptr())
+                    continue
                 keyless.shuffle_and_remask_batch_keys_dev(T, keys.data_ptr(), chain[j].data_ptr(), fac[j & 1].data_ptr(),
                                                           prm[j & 1].data_ptr(), sds.data_ptr(), chain[j + 1].data_ptr(),
                                                           proofs[j].data_ptr(), st_p[j].data_ptr())
@@ -442,8 +473,10 @@ def main():
                                                       proofs[j].data_ptr(), st_v[j].data_ptr())
 
         proofs_per_step = T * L
-        units = ("prove+verify pairs (%d tables x %d dependent shuffles, %d proofs per prove launch; verification: %s)"
-                 % (T, L, T, "one chain equation per table (mp_verify_shuffle_chain_dev)" if chain_verify else "%d proofs per launch, link by link" % (G * T)))
+        units = ("prove+verify pairs (%d tables x %d dependent shuffles, %d proofs per prove launch; keys: %s; verification: %s)"
+                 % (T, L, T, "one key set of %d keys prepared before the timed region (mp_keyset_create)" % T if kset is not None
+                    else "passed with every call", "one chain equation per table (mp_verify_shuffle_chain_dev)" if chain_verify
+                    else "%d proofs per launch, link by link" % (G * T)))
 
         def check():
             return int((st_p != 0).sum().item()) + int((st_v != 0).sum().item())
@@ -551,8 +584,12 @@ def main():
         free_b, _ = torch.cuda.mem_get_info()
         if free_b > 40e9:
             k1000 = make_keys(1000, B)
-            extras["keyed_value"] = timed_step(lambda: step(k1000))   # one aggregate key per proof (1000 distinct), as the reference passes it per call
+            extras["keyed_value"] = timed_step(lambda: step(k1000, None))   # one aggregate key per proof (1000 distinct), as the reference passes it per call
             extras["keyed_distinct_keys"] = 1000
+            ks1000 = make_keyset(table, 1000, B)                      # the same keys prepared once as a key set (mp_keyset_create)
+            extras["keyed_keyset_value"] = timed_step(lambda: step(None, ks1000))
+            extras["keyset_build_s"] = ks1000[2]
+            ks1000[0].close()
         else:
             extras["keyed_value"] = None
         assert check() == 0

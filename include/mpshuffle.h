@@ -134,6 +134,25 @@ int mp_shuffle_and_remask_batch_keys_dev(mp_table* t, size_t B, const void* d_ke
                                          void* d_out_decks, void* d_out_proofs, void* d_status);
 int mp_verify_shuffle_batch_keys_dev(mp_table* t, size_t B, const void* d_keys, const void* d_decks, const void* d_shuffled_decks,
                                      const void* d_proofs, void* d_status);
+/* ---- key sets: the aggregate keys of many card tables, prepared once ---------------------------------------------------------
+ * A card table keeps its aggregate key for as long as its players stay [REF examples/round.rs:228-262: the key is computed once,
+ * before the shuffles], so a server that runs many tables can hand their keys over ahead of time: mp_keyset_create builds
+ * fixed-base window tables for every key (8-bit windows: 8 160 points = 0.5 MB per key on the 256-bit curves, in HBM) and the
+ * _keyset entry points name a proof's key by its index in the set (d_key_index: B uint32, device memory).  The N
+ * re-encryptions rho_i * pk then cost 32 table additions each and no per-proof table construction (keyed batches without a
+ * set: 51 additions plus the key's own window tables per proof).  Results are byte-identical to the _keys entry points and to
+ * a table created with that key.  keys: n_keys wire points in HOST memory; each must be a point of the prime-order group other
+ * than the identity (MP_ERR_BAD_ENCODING otherwise).  An index >= n_keys gives status MP_ERR_BAD_ARGUMENT for that proof.
+ * A key set belongs to the table it was created for and must be destroyed before it. */
+typedef struct mp_keyset mp_keyset;
+int mp_keyset_create(mp_table* t, size_t n_keys, const uint8_t* keys, mp_keyset** out);
+void mp_keyset_destroy(mp_keyset* ks);
+size_t mp_keyset_size(const mp_keyset* ks);
+int mp_shuffle_and_remask_batch_keyset_dev(mp_table* t, const mp_keyset* ks, size_t B, const void* d_key_index, const void* d_decks,
+                                           const void* d_masking_factors, const void* d_permutations, const void* d_prover_seeds,
+                                           void* d_out_decks, void* d_out_proofs, void* d_status);
+int mp_verify_shuffle_batch_keyset_dev(mp_table* t, const mp_keyset* ks, size_t B, const void* d_key_index, const void* d_decks,
+                                       const void* d_shuffled_decks, const void* d_proofs, void* d_status);
 /* ---- chain verification: the shuffle chain of a card table verified as one equation -------------------------------------------
  * A table's deck passes through `links` shuffles (deck_{j+1} = output of link j [REF examples/round.rs:268-350]) and every one of
  * them is verified.  These entry points verify `tables` chains at once; decks: (links + 1) x tables decks, deck j of table t at index

@@ -18,6 +18,7 @@ SYMBOLS = [
     "mp_ctx_create", "mp_ctx_destroy", "mp_last_error", "mp_check_name", "mp_proof_size", "mp_params_size",
     "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_set_subgroup_check", "mp_set_bucket_min", "mp_set_toom_cook", "mp_host_alloc", "mp_host_free", "mp_set_io_chunk", "mp_shuffle_and_remask_batch_keys", "mp_table_create_params",
     "mp_verify_shuffle_batch_keys", "mp_shuffle_and_remask_batch_keys_dev", "mp_verify_shuffle_batch_keys_dev",
+    "mp_keyset_create", "mp_keyset_destroy", "mp_keyset_size", "mp_shuffle_and_remask_batch_keyset_dev", "mp_verify_shuffle_batch_keyset_dev",
     "mp_setup", "mp_table_create", "mp_table_create_ex", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
     "mp_shuffle_and_remask_batch", "mp_verify_shuffle_batch", "mp_shuffle_and_remask_batch_dev",
     "mp_verify_shuffle_batch_dev", "mp_verify_shuffle_chain", "mp_verify_shuffle_chain_dev", "mp_sync", "mp_reserve", "mp_set_latency_batch", "mp_remask_batch", "mp_msm", "mp_commit_batch",
@@ -132,6 +133,13 @@ def bind(cdll):
     cdll.mp_verify_shuffle_batch_keys.argtypes = [c.c_void_p, c.c_size_t, u8p, u8p, u8p, u8p, i32p]
     cdll.mp_shuffle_and_remask_batch_keys_dev.argtypes = [c.c_void_p, c.c_size_t] + [c.c_void_p] * 8
     cdll.mp_verify_shuffle_batch_keys_dev.argtypes = [c.c_void_p, c.c_size_t] + [c.c_void_p] * 5
+    cdll.mp_keyset_create.argtypes = [c.c_void_p, c.c_size_t, u8p, c.POINTER(c.c_void_p)]
+    cdll.mp_keyset_destroy.argtypes = [c.c_void_p]
+    cdll.mp_keyset_destroy.restype = None
+    cdll.mp_keyset_size.argtypes = [c.c_void_p]
+    cdll.mp_keyset_size.restype = c.c_size_t
+    cdll.mp_shuffle_and_remask_batch_keyset_dev.argtypes = [c.c_void_p, c.c_void_p, c.c_size_t] + [c.c_void_p] * 8
+    cdll.mp_verify_shuffle_batch_keyset_dev.argtypes = [c.c_void_p, c.c_void_p, c.c_size_t] + [c.c_void_p] * 5
     cdll.mp_verify_shuffle_chain.argtypes = [c.c_void_p, c.c_size_t, c.c_uint32, u8p, u8p, u8p, i32p]
     cdll.mp_verify_shuffle_chain_dev.argtypes = [c.c_void_p, c.c_size_t, c.c_uint32] + [c.c_void_p] * 4
     cdll.mp_sync.argtypes = [c.c_void_p]
@@ -320,6 +328,30 @@ class Engine:
         return out
 
 
+class KeySet:
+    """mp_keyset: fixed-base window tables of n aggregate keys of one Table (include/mpshuffle.h, "key sets")"""
+
+    def __init__(self, table, keys):
+        self.table, self.lib = table, table.lib
+        if len(keys) == 0 or len(keys) % table.pb:
+            raise ValueError("keys: expected a whole number of %d-byte points" % table.pb)
+        self.size = len(keys) // table.pb
+        h = ctypes.c_void_p()
+        table.eng._chk(self.lib.mp_keyset_create(table.h, self.size, _in(keys), ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mp_keyset_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Table:
     """one mp_table: Parameters + aggregate key with their fixed-base tables in HBM"""
 
@@ -406,6 +438,18 @@ class Table:
 
     def verify_shuffle_chain_dev(self, tables, links, d_keys, d_decks, d_proofs, d_status):
         self.eng._chk(self.lib.mp_verify_shuffle_chain_dev(self.h, tables, links, d_keys, d_decks, d_proofs, d_status))
+
+    # ---- key sets: window tables of many aggregate keys, built once; proofs name their key by index (device arrays of uint32)
+    def keyset(self, keys):
+        """keys: n wire points back to back (host bytes) -> KeySet (close() it before the table)"""
+        return KeySet(self, keys)
+
+    def shuffle_and_remask_batch_keyset_dev(self, ks, B, d_key_index, d_decks, d_factors, d_perms, d_seeds, d_out_decks, d_out_proofs, d_status):
+        self.eng._chk(self.lib.mp_shuffle_and_remask_batch_keyset_dev(self.h, ks.h, B, d_key_index, d_decks, d_factors, d_perms, d_seeds,
+                                                                      d_out_decks, d_out_proofs, d_status))
+
+    def verify_shuffle_batch_keyset_dev(self, ks, B, d_key_index, d_decks, d_shuffled, d_proofs, d_status):
+        self.eng._chk(self.lib.mp_verify_shuffle_batch_keyset_dev(self.h, ks.h, B, d_key_index, d_decks, d_shuffled, d_proofs, d_status))
 
     def shuffle_and_remask_batch_keys_dev(self, B, d_keys, d_decks, d_factors, d_perms, d_seeds, d_out_decks, d_out_proofs, d_status):
         self.eng._chk(self.lib.mp_shuffle_and_remask_batch_keys_dev(self.h, B, d_keys, d_decks, d_factors, d_perms, d_seeds,

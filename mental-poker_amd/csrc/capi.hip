@@ -274,6 +274,52 @@ int mp_verify_shuffle_batch_keys_dev(mp_table* t, size_t B, const void* d_keys, 
   return MP_OK;
   MP_CATCH
 }
+int mp_keyset_create(mp_table* t, size_t n_keys, const uint8_t* keys, mp_keyset** out) {
+  if (!t || !n_keys || !keys || !out) return fail(MP_ERR_BAD_ARGUMENT, "mp_keyset_create: bad argument");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  std::unique_ptr<mp_keyset> ks(new mp_keyset());
+  ks->owner = t;
+  const int rc = t->keyset_build(*ks, n_keys, keys);
+  if (rc != MP_OK) return rc;
+  *out = ks.release();
+  return MP_OK;
+  MP_CATCH
+}
+void mp_keyset_destroy(mp_keyset* ks) {
+  if (!ks) return;
+  try {
+    rt::set_device(ks->owner->ctx->device);
+    delete ks;
+  } catch (...) {
+  }
+}
+size_t mp_keyset_size(const mp_keyset* ks) { return ks ? ks->K : 0; }
+int mp_shuffle_and_remask_batch_keyset_dev(mp_table* t, const mp_keyset* ks, size_t B, const void* d_key_index, const void* d_decks,
+                                           const void* d_masking_factors, const void* d_permutations, const void* d_prover_seeds,
+                                           void* d_out_decks, void* d_out_proofs, void* d_status) {
+  if (!t || !ks || ks->owner != t || !B || !d_key_index || !d_decks || !d_masking_factors || !d_permutations || !d_prover_seeds || !d_out_decks ||
+      !d_out_proofs || !d_status)
+    return fail(MP_ERR_BAD_ARGUMENT, "mp_shuffle_and_remask_batch_keyset_dev: bad argument (the key set must belong to this table)");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  t->prove_dev(B, (const uint8_t*)d_decks, (const uint8_t*)d_masking_factors, (const uint32_t*)d_permutations,
+               (const uint8_t*)d_prover_seeds, (uint8_t*)d_out_decks, (uint8_t*)d_out_proofs, (int32_t*)d_status, nullptr, ks,
+               (const uint32_t*)d_key_index);
+  return MP_OK;
+  MP_CATCH
+}
+int mp_verify_shuffle_batch_keyset_dev(mp_table* t, const mp_keyset* ks, size_t B, const void* d_key_index, const void* d_decks,
+                                       const void* d_shuffled_decks, const void* d_proofs, void* d_status) {
+  if (!t || !ks || ks->owner != t || !B || !d_key_index || !d_decks || !d_shuffled_decks || !d_proofs || !d_status)
+    return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_batch_keyset_dev: bad argument (the key set must belong to this table)");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  t->verify_dev(B, (const uint8_t*)d_decks, (const uint8_t*)d_shuffled_decks, (const uint8_t*)d_proofs, (int32_t*)d_status, nullptr, ks,
+                (const uint32_t*)d_key_index);
+  return MP_OK;
+  MP_CATCH
+}
 int mp_verify_shuffle_chain_dev(mp_table* t, size_t tables, uint32_t links, const void* d_keys, const void* d_decks, const void* d_proofs,
                                 void* d_status) {
   if (!t || !tables || !links || !d_decks || !d_proofs || !d_status || links > 4095)

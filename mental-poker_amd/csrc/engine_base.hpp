@@ -132,6 +132,15 @@ struct mp_io_stage {
   mp::rt::Event up = nullptr, done = nullptr, down = nullptr;   // upload finished / kernels finished / download finished
   bool used = false;
 };
+// A key set (mp_keyset_create): fixed-base window tables of many aggregate keys, built once -- a card server knows the keys
+// of its tables long before the shuffles arrive.  Proofs refer to a key by its index in the set.
+struct mp_keyset {
+  mp_table* owner = nullptr;
+  size_t K = 0;
+  mp::DevBuf<uint32_t> wire;     // [K][point_bytes / 4]: the keys as they came (gathered per proof for the transcript / the key's own terms)
+  mp::DevBuf<uint32_t> FB;       // [K][windows][entries] affine points (the layout of the table context's own fixed-base tables)
+  uint32_t bits = 0, windows = 0, entries = 0;
+};
 struct mp_table {
   mp_ctx* ctx = nullptr;
   mp_io_stage io[2];
@@ -146,11 +155,14 @@ struct mp_table {
   virtual void set_subgroup_check(bool on) = 0;
   virtual void set_bucket_min(uint32_t terms) = 0;
   virtual void set_toom_cook(bool on) = 0;
-  // keys: nullptr = the table's own aggregate key; otherwise one wire point per proof (device memory)
+  // keys: nullptr = the table's own aggregate key; otherwise one wire point per proof (device memory).
+  // ks / kidx: proof b is made under key kidx[b] (device array) of the key set instead (keys is ignored)
   virtual void prove_dev(size_t B, const uint8_t* decks, const uint8_t* rho, const uint32_t* perm, const uint8_t* seeds,
-                         uint8_t* out_decks, uint8_t* out_proofs, int32_t* status, const uint8_t* keys = nullptr) = 0;
+                         uint8_t* out_decks, uint8_t* out_proofs, int32_t* status, const uint8_t* keys = nullptr,
+                         const mp_keyset* ks = nullptr, const uint32_t* kidx = nullptr) = 0;
   virtual void verify_dev(size_t B, const uint8_t* decks, const uint8_t* shuf, const uint8_t* proofs, int32_t* status,
-                          const uint8_t* keys = nullptr) = 0;
+                          const uint8_t* keys = nullptr, const mp_keyset* ks = nullptr, const uint32_t* kidx = nullptr) = 0;
+  virtual int keyset_build(mp_keyset& ks, size_t K, const uint8_t* keys_host) = 0;
   // chain verification: T tables x L links, decks [(L + 1)][T], proofs / status / keys [L][T] (device memory)
   virtual void verify_chain_dev(size_t T, uint32_t L, const uint8_t* decks, const uint8_t* proofs, int32_t* status,
                                 const uint8_t* keys = nullptr) = 0;

@@ -366,26 +366,32 @@ struct Table : mp_table {
     MP_RUN(k_normalize, C, a.nthreads, 1, a);
   }
 
-  void build_fixed_tables(uint32_t nb) {
+  // tables with narrow windows, built by chains: out[base][gh.windows][gh.entries] affine (window widths alternate gh.bits / h2)
+  void build_narrow_tables(const uint32_t* pts, uint32_t nb, const FbGeom& gh, uint32_t h2, uint32_t* out) {
     rt::Stream s = ctx->stream;
-    // narrow table first (h-bit windows: h = 8 for 8- and 16-bit tables, 10 for 20-bit tables), built by chains
-    // (a 21-bit window splits 11 + 10: the narrow windows alternate between the two widths, all of them with 2^h - 1 entries)
-    const uint32_t h = fbg.bits == 8 ? 8u : (fbg.bits + 1u) / 2u, h2 = fbg.bits == 8 ? 8u : fbg.bits - h;
-    const FbGeom gh{h, fbg.bits == 8 ? fbg.windows : 2u * fbg.windows, (1u << h) - 1u};
-    DevBuf<uint32_t> WJ, W, EJ, scratch, Th;
+    DevBuf<uint32_t> WJ, W, EJ, scratch;
     const size_t nwinpts = (size_t)nb * gh.windows, nent = nwinpts * gh.entries;
     WJ.alloc(nwinpts * G_::JW, s);
     W.alloc(nwinpts * G_::PW, s);
     EJ.alloc(nent * G_::JW, s);
     scratch.alloc(nent * G_::FW, s);
-    Th.alloc(nent * G_::PW, s);
-    FbWinArgs wa{fbpts.p, WJ.p, gh, h2};
+    FbWinArgs wa{pts, WJ.p, gh, h2};
     MP_RUN(k_fb_windows, C, nb, 1, wa);
     normalize_flat(WJ.p, W.p, scratch.p, nwinpts);
     FbFillArgs fa{W.p, EJ.p, gh};
     MP_RUN(k_fb_fill, C, (uint32_t)nwinpts, 1, fa);
-    normalize_flat(EJ.p, Th.p, scratch.p, nent);
+    normalize_flat(EJ.p, out, scratch.p, nent);
     rt::stream_sync(s);
+  }
+  void build_fixed_tables(uint32_t nb) {
+    rt::Stream s = ctx->stream;
+    // narrow table first (h-bit windows: h = 8 for 8- and 16-bit tables, 10 for 20-bit tables)
+    // (a 21-bit window splits 11 + 10: the narrow windows alternate between the two widths, all of them with 2^h - 1 entries)
+    const uint32_t h = fbg.bits == 8 ? 8u : (fbg.bits + 1u) / 2u, h2 = fbg.bits == 8 ? 8u : fbg.bits - h;
+    const FbGeom gh{h, fbg.bits == 8 ? fbg.windows : 2u * fbg.windows, (1u << h) - 1u};
+    DevBuf<uint32_t> Th;
+    Th.alloc((size_t)nb * gh.windows * gh.entries * G_::PW, s);
+    build_narrow_tables(fbpts.p, nb, gh, h2, Th.p);
     if (fbg.bits == h) {
       std::swap(FB.p, Th.p);
       std::swap(FB.n, Th.n);
@@ -407,6 +413,44 @@ struct Table : mp_table {
       normalize_flat(EJw.p + off * G_::JW, FB.p + off * G_::PW, scratchw.p + off * G_::FW, cnt);
     }
     rt::stream_sync(s);
+  }
+
+  // ---- key sets: 8-bit fixed-base tables of K aggregate keys (32 windows x 255 entries = 8 160 points per key: 0.5 MB on the
+  // 256-bit curves), built in slices of 2 048 keys so that the Jacobian intermediates stay below 2 GB
+  int keyset_build(mp_keyset& ks, size_t K, const uint8_t* keys_host) override {
+    rt::Stream s = ctx->stream;
+    const FbGeom g8{8u, ((uint32_t)R::BITS + 7u) / 8u, 255u};
+    if (K == 0 || K * (size_t)g8.windows * g8.entries >= ((size_t)1 << 32)) return fail(MP_ERR_BAD_ARGUMENT, "mp_keyset_create: 1 .. 500 000 keys");
+    std::vector<uint32_t> flat(K * G_::PW), wire(K * (G_::PB / 4));
+    for (size_t i = 0; i < K; ++i) {
+      Aff<C> p;
+      if (!wire_point_host(keys_host + i * G_::PB, p) || aff_is_inf<C>(p) || !aff_in_subgroup_host<C>(p))
+        return fail(MP_ERR_BAD_ENCODING, "mp_keyset_create: key " + std::to_string(i) + " is not a point of the prime-order group");
+      fe_pack<F>(p.x, &flat[i * G_::PW]);
+      fe_pack<F>(p.y, &flat[i * G_::PW + G_::FW]);
+    }
+    memcpy(wire.data(), keys_host, K * G_::PB);
+    DevBuf<uint32_t> pts;
+    pts.upload(flat, s);
+    ks.wire.upload(wire, s);
+    ks.K = K;
+    ks.bits = g8.bits; ks.windows = g8.windows; ks.entries = g8.entries;
+    const size_t per_key = (size_t)g8.windows * g8.entries * G_::PW;
+    ks.FB.alloc(K * per_key, s, false);
+    const size_t slice = 2048;
+    for (size_t k0 = 0; k0 < K; k0 += slice) {
+      const uint32_t kc = (uint32_t)std::min(slice, K - k0);
+      build_narrow_tables(pts.p + k0 * G_::PW, kc, g8, 8u, ks.FB.p + k0 * per_key);
+    }
+    rt::stream_sync(s);
+    return MP_OK;
+  }
+  DevBuf<uint32_t> ks_keys;      // the wire keys of a batch, gathered from a key set
+  const uint8_t* gather_keys(uint32_t B, const mp_keyset* ks, const uint32_t* kidx, int32_t* status) {
+    ks_keys.alloc((size_t)B * (G_::PB / 4), ctx->stream, false);
+    GatherKeysArgs ga{ks->wire.p, kidx, ks_keys.p, status, (uint32_t)ks->K};
+    MP_RUN(k_gather_keys, C, B, G_::PB / 4, ga);
+    return reinterpret_cast<const uint8_t*>(ks_keys.p);
   }
 
   uint32_t stage_words_needed() const {
@@ -496,9 +540,10 @@ struct Table : mp_table {
   // keys != nullptr: keyed batch -- proof b is made under the aggregate key keys[b] (one wire point each) instead of the
   // table's own key [REF mod.rs:380-418 takes shared_key per call; tables of different card tables differ in nothing else]
   void prove_dev(size_t B_, const uint8_t* decks, const uint8_t* rho, const uint32_t* perm, const uint8_t* seeds,
-                 uint8_t* out_decks, uint8_t* out_proofs, int32_t* status, const uint8_t* keys) override {
+                 uint8_t* out_decks, uint8_t* out_proofs, int32_t* status, const uint8_t* keys, const mp_keyset* kset,
+                 const uint32_t* kidx) override {
     const uint32_t B = (uint32_t)B_;
-    const bool keyed = keys != nullptr;
+    const bool keyed = keys != nullptr || kset != nullptr;
     reserve_for(B, keyed);
     Workspace& w = ws;
     PlanSet& q = pick(B, keyed);
@@ -517,9 +562,20 @@ struct Table : mp_table {
       ProveInitArgs ia{w.S.p, w.status.p, perm, seeds, q.draws.p, l, w.Bpad};
       MP_RUN(k_prove_init, C, B, 1, ia);
       RemaskArgs ra{w.S.p, w.P.p, w.J.p, FB.p, perm, w.Bpad, N, l.rho, l.deck, l.shuf, fb.G(), fb.pk(), fbg,
-                    0, w.D.p, w.T.p, key_d_first, key_t_first, nwin};
+                    0, w.D.p, w.T.p, key_d_first, key_t_first, nwin, nullptr, nullptr, FbGeom{8, 32, 255}, 0};
       check_subgroup(w, B, l.deck, 2 * N);
-      if (keyed) {
+      if (kset) {
+        // the proof's key is a member of a key set: its multiples come from the set's tables, the key itself (transcript, its
+        // own terms in the argument) from the set's copy of the wire bytes (validated when the set was built)
+        keys = gather_keys(B, kset, kidx, w.status.p);
+        LoadPointsArgs ka{keys, w.P.p, w.status.p, w.Bpad, 1, l.pk};
+        MP_RUN(k_load_points, C, B, 1, ka);
+        ra.keyed = 2;
+        ra.KFB = kset->FB.p;
+        ra.kidx = kidx;
+        ra.kg = FbGeom{kset->bits, kset->windows, kset->entries};
+        ra.nkeys = (uint32_t)kset->K;
+      } else if (keyed) {
         // the proof's key -> window bases 2^(5w) pk -> their 16-entry tables; signed digits of the masking factors
         LoadPointsArgs ka{keys, w.P.p, w.status.p, w.Bpad, 1, l.pk};
         MP_RUN(k_load_points, C, B, 1, ka);
@@ -608,9 +664,9 @@ struct Table : mp_table {
   // name as the reference does [REF tests.rs:223-225].  A proof that passes (1) satisfies every equation except with
   // probability ~2^-250 over weights that depend on the whole proof.
   void verify_dev(size_t B_, const uint8_t* decks, const uint8_t* shuf, const uint8_t* proofs, int32_t* status,
-                  const uint8_t* keys) override {
+                  const uint8_t* keys, const mp_keyset* kset, const uint32_t* kidx) override {
     const uint32_t B = (uint32_t)B_;
-    const bool keyed = keys != nullptr;
+    const bool keyed = keys != nullptr || kset != nullptr;
     reserve_for(B, keyed);
     Workspace& w = ws;
     PlanSet& q = pick(B, keyed);
@@ -632,6 +688,7 @@ struct Table : mp_table {
         MP_RUN(k_load_points, C, B, 2 * N, b);
         ProofIoArgs pa{const_cast<uint8_t*>(proofs), w.S.p, w.P.p, w.status.p, q.vwire.p, w.Bpad, (uint32_t)proof_size_bytes(m, n, G_::PB)};
         MP_RUN(k_load_proof, C, B, (uint32_t)q.vplan.wire.size(), pa);
+        if (kset) keys = gather_keys(B, kset, kidx, w.status.p);
         if (keyed) {
           LoadPointsArgs ka{keys, w.P.p, w.status.p, w.Bpad, 1, l.pk};
           MP_RUN(k_load_points, C, B, 1, ka);
@@ -803,7 +860,7 @@ struct Table : mp_table {
     const size_t psz = proof_size_bytes(m, n, G_::PB);
     for (uint32_t j = 0; j < L; ++j)
       verify_dev(T, decks + (size_t)j * T * deck_bytes, decks + (size_t)(j + 1) * T * deck_bytes, proofs + (size_t)j * T * psz,
-                 status + (size_t)j * T, keyed ? keys + (size_t)j * T * G_::PB : nullptr);
+                 status + (size_t)j * T, keyed ? keys + (size_t)j * T * G_::PB : nullptr, nullptr, nullptr);
   }
 
   // ---------------------------------------------------------------- building blocks (ad-hoc plans)

@@ -161,6 +161,12 @@ struct RemaskArgs {
   const int8_t* D;      // [dslot][window][Bpad]
   const uint32_t* T;    // [tslot][entry][Bpad]
   uint32_t d_first, t_first, nwin;   // digit slot of rho_0, table slot of window 0
+  // keyed == 2: the proof's key is member kidx[b] of a key set (mp_keyset_create): fixed-base tables of every key of the
+  // set, geometry kg -- the keys of the card tables a server runs are known long before the shuffles are
+  const uint32_t* KFB;  // [key][window][entry] affine
+  const uint32_t* kidx; // [B]
+  FbGeom kg;
+  uint32_t nkeys;
 };
 // y = 2*i + component
 template <class C>
@@ -173,6 +179,18 @@ MP_HD void body_remask(const RemaskArgs& a, uint32_t b, uint32_t y) {
   fe_to_canonical<R>(ld_fe<R>(a.S + s_off(a.s_rho + i, a.Bpad, b)), k);
   const uint32_t base = comp ? a.base_pk : a.base_G;
   Xyzz<C> acc = xyzz_inf<C>();
+  if (a.keyed == 2 && comp) {
+    uint32_t key = a.kidx[b];
+    if (key >= a.nkeys) key = 0;      // reported through the status word (k_gather_keys)
+#pragma unroll 1
+    for (uint32_t w = 0; w < a.kg.windows; ++w) {
+      const uint32_t d = fb_digit(k, a.kg, w);
+      if (d) xyzz_madd_ip<C>(acc, ld_aff<C>(fb_entry<C>(a.KFB, a.kg, key, w, d)));
+    }
+    xyzz_madd_ip<C>(acc, ld_aff<C>(a.P + p_off<C>(a.p_deck + 2 * src + comp, a.Bpad, b)));
+    st_jac<C>(a.J + j_off<C>(a.j_out + y, a.Bpad, b), xyzz_to_jac<C>(acc));
+    return;
+  }
   if (a.keyed && comp) {
 #pragma unroll 1
     for (uint32_t w = 0; w < a.nwin; ++w) {
@@ -197,6 +215,26 @@ MP_HD void body_remask(const RemaskArgs& a, uint32_t b, uint32_t y) {
   st_jac<C>(a.J + j_off<C>(a.j_out + y, a.Bpad, b), xyzz_to_jac<C>(acc));
 }
 MP_KERNEL_OCC(k_remask, RemaskArgs, body_remask, Geo<C>::OCC4)
+
+// ---- key sets: the wire bytes of key kidx[b] for proof b (x = proof, y = 32-bit word of the point)
+struct GatherKeysArgs {
+  const uint32_t* wire;   // [nkeys][PB / 4]
+  const uint32_t* kidx;   // [B]
+  uint32_t* out;          // [B][PB / 4]
+  int32_t* status;
+  uint32_t nkeys;
+};
+template <class C>
+MP_HD void body_gather_keys(const GatherKeysArgs& a, uint32_t b, uint32_t y) {
+  constexpr uint32_t W = Geo<C>::PB / 4;
+  uint32_t key = a.kidx[b];
+  if (key >= a.nkeys) {
+    if (y == 0) a.status[b] = -3;      // MP_ERR_BAD_ARGUMENT: no such key in the set
+    key = 0;
+  }
+  a.out[(size_t)b * W + y] = a.wire[(size_t)key * W + y];
+}
+MP_KERNEL(k_gather_keys, GatherKeysArgs, body_gather_keys)
 
 // ---- window bases of a per-proof key: W_w = 2^(5w) * pk, w < nwin (lane = proof; Jacobian out -> normalise -> k_table)
 struct KeyWinArgs {
@@ -641,6 +679,7 @@ MP_KERNEL(k_fb_widen, FbWidenArgs, body_fb_widen)
   MP_KERNEL_INST(X, k_fixed_msm, FixedArgs, C) \
   MP_KERNEL_INST(X, k_remask, RemaskArgs, C) \
   MP_KERNEL_INST(X, k_key_windows, KeyWinArgs, C) \
+  MP_KERNEL_INST(X, k_gather_keys, GatherKeysArgs, C) \
   MP_KERNEL_INST(X, k_recode, RecodeArgs, C) \
   MP_KERNEL_INST(X, k_table, TableArgs, C) \
   MP_KERNEL_INST(X, k_var_msm, VarArgs, C) \

@@ -149,6 +149,56 @@ def test_emulated_keyed_batch(emu, coracle, native):
     t.close()
 
 
+def test_emulated_key_sets(emu, coracle, native):
+    """key sets (mp_keyset_create + the _keyset entry points): the keys of several card tables prepared once, proofs name their
+    key by index -- byte-identical to the oracle under each proof's key, and to the _keys entry points.  The emulator's "device"
+    memory is host memory, so ctypes buffers stand in for the device arrays."""
+    import numpy as np
+    for cv, m, n in (("stark", 2, 3), ("bls12_377", 2, 3)):
+        eng = emu(cv)
+        ins = [coracle.gen_inputs(cv, m, n, 520 + b) for b in range(3)]
+        g0 = ins[0]
+        t = eng.table(m, n, g0["params"], None)
+        keys = [coracle.gen_inputs(cv, m, n, 530 + k)["pk"] for k in range(2)]
+        ks = t.keyset(b"".join(keys))
+        assert t.lib.mp_keyset_size(ks.h) == 2
+        kidx = np.array([1, 0, 1], dtype=np.uint32)
+        B, N, cb, ps = 3, m * n, len(g0["deck"]), t.proof_bytes
+        buf = lambda b: np.frombuffer(b, dtype=np.uint8).copy()
+        decks, rho = buf(b"".join(g["deck"] for g in ins)), buf(b"".join(g["rho"] for g in ins))
+        perms = np.array([v for g in ins for v in g["perm"]], dtype=np.uint32)
+        seeds = buf(b"".join(g["prover_seed"] for g in ins))
+        ptr = lambda a: a.ctypes.data
+        for lb in (8192, 8, 0):
+            t.set_latency_batch(lb)
+            out_d, out_p = np.zeros(B * cb, dtype=np.uint8), np.zeros(B * ps, dtype=np.uint8)
+            st = np.full(B, 77, dtype=np.int32)
+            t.shuffle_and_remask_batch_keyset_dev(ks, B, ptr(kidx), ptr(decks), ptr(rho), ptr(perms), ptr(seeds), ptr(out_d), ptr(out_p), ptr(st))
+            eng.sync() if hasattr(eng, "sync") else None
+            assert st.tolist() == [0, 0, 0]
+            for b, g in enumerate(ins):
+                ed, ep = coracle.shuffle_and_remask(cv, m, n, g0["params"], keys[kidx[b]], g["deck"], g["rho"], g["perm"], g["prover_seed"])
+                assert out_d[b * cb:(b + 1) * cb].tobytes() == ed and out_p[b * ps:(b + 1) * ps].tobytes() == ep
+            sv = np.full(B, 77, dtype=np.int32)
+            t.verify_shuffle_batch_keyset_dev(ks, B, ptr(kidx), ptr(decks), ptr(out_d), ptr(out_p), ptr(sv))
+            assert sv.tolist() == [0, 0, 0]
+            other = np.array([1, 1, 1], dtype=np.uint32)           # proof 1 checked under the other table's key
+            t.verify_shuffle_batch_keyset_dev(ks, B, ptr(other), ptr(decks), ptr(out_d), ptr(out_p), ptr(sv))
+            assert sv.tolist() == [0, 1, 0]
+            assert t.verify_shuffle_batch_keys(b"".join(keys[i] for i in kidx), decks.tobytes(), out_d.tobytes(), out_p.tobytes()) == [0, 0, 0]
+        bad = np.array([1, 2, 0], dtype=np.uint32)                 # no key 2 in the set
+        t.shuffle_and_remask_batch_keyset_dev(ks, B, ptr(bad), ptr(decks), ptr(rho), ptr(perms), ptr(seeds), ptr(out_d), ptr(out_p), ptr(st))
+        assert st.tolist() == [0, native._native.MP_ERR_BAD_ARGUMENT, 0]
+        with pytest.raises(native.NativeError):
+            t.keyset(bytes(len(keys[0])))                          # the identity / not a curve point
+        t2 = eng.table(m, n, g0["params"], g0["pk"])
+        with pytest.raises(native.NativeError):                    # a key set belongs to its table
+            t2.verify_shuffle_batch_keyset_dev(ks, B, ptr(kidx), ptr(decks), ptr(out_d), ptr(out_p), ptr(sv))
+        t2.close()
+        ks.close()
+        t.close()
+
+
 def test_emulated_batch_and_status(emu, coracle):
     cv, m, n = "stark", 2, 3
     eng = emu(cv)

@@ -599,6 +599,73 @@ def test_chain_verification_matches_per_link_verifier(mp, coracle, cvn, m, n, L,
     assert st == exp and sum(1 for v in st if v) == 2
 
 
+@pytest.mark.parametrize("cvn,m,n,K,B", [("stark", 2, 26, 5, 64), ("secp256k1", 2, 26, 3, 7), ("bls12_377", 2, 5, 2, 3), ("stark", 8, 16, 4, 6000)])
+def test_key_sets_match_oracle_and_keyed_batches(mp, coracle, cvn, m, n, K, B):
+    """key sets (mp_keyset_create, _keyset_dev entry points): proofs made under key key_index[b] of the set are the oracle's bytes
+    under that key (spot-checked) and the bytes of the per-call keyed path (all of them); verification by index agrees with
+    verification under explicit keys, a wrong index is a wrong statement, an index outside the set a usage error.  The device
+    arrays are page-locked host buffers from mp_host_alloc (device-addressable; keeps torch out of this process)."""
+    import ctypes
+    import numpy as np
+    eng = mp.Engine(cvn, device=0)
+    N, pb = m * n, eng.point_bytes
+    g0 = coracle.gen_inputs(cvn, m, n, 50)
+    table = eng.table(m, n, g0["params"], None)
+    lib = table.lib
+    held = []
+
+    def dev(raw=None, dtype=np.uint8, count=None):
+        nbytes = len(raw) if raw is not None else count * np.dtype(dtype).itemsize
+        p = lib.mp_host_alloc(nbytes)
+        assert p
+        held.append(p)
+        a = np.frombuffer((ctypes.c_uint8 * nbytes).from_address(p), dtype=dtype)
+        if raw is not None:
+            a[...] = np.frombuffer(raw, dtype=dtype)
+        return a
+
+    ptr = lambda a: a.ctypes.data
+    keys = [coracle.gen_inputs(cvn, m, n, 60 + k)["pk"] for k in range(K)]
+    ks = table.keyset(b"".join(keys))
+    distinct = [coracle.gen_inputs(cvn, m, n, 3000 + i) for i in range(min(B, 11))]
+    ins = [distinct[b % 11] for b in range(B)]
+    decks, rho = dev(b"".join(g["deck"] for g in ins)), dev(b"".join(g["rho"] for g in ins))
+    perms = dev(np.array([v for g in ins for v in g["perm"]], dtype=np.uint32).tobytes(), np.uint32)
+    seeds = dev(b"".join(g["prover_seed"] for g in ins))
+    kidx = dev((np.arange(B, dtype=np.uint32) * 7 % K).astype(np.uint32).tobytes(), np.uint32)
+    out_d, out_p = dev(count=B * N * 2 * pb), dev(count=B * table.proof_bytes)
+    st, sv = dev(count=B, dtype=np.int32), dev(count=B, dtype=np.int32)
+    st[...] = 77
+    table.shuffle_and_remask_batch_keyset_dev(ks, B, ptr(kidx), ptr(decks), ptr(rho), ptr(perms), ptr(seeds), ptr(out_d), ptr(out_p), ptr(st))
+    eng.sync()
+    assert not st.any()
+    per_proof_keys = b"".join(keys[int(i)] for i in kidx)
+    d2, p2, st2 = table.shuffle_and_remask_batch_keys(per_proof_keys, decks.tobytes(), rho.tobytes(), [int(v) for v in perms], seeds.tobytes())
+    assert not any(st2) and out_d.tobytes() == d2 and out_p.tobytes() == p2
+    for b in (0, B // 2, B - 1):
+        g = ins[b]
+        ed, ep = coracle.shuffle_and_remask(cvn, m, n, g0["params"], keys[int(kidx[b])], g["deck"], g["rho"], g["perm"], g["prover_seed"])
+        assert d2[b * N * 2 * pb:(b + 1) * N * 2 * pb] == ed and p2[b * table.proof_bytes:(b + 1) * table.proof_bytes] == ep
+    sv[...] = 77
+    table.verify_shuffle_batch_keyset_dev(ks, B, ptr(kidx), ptr(decks), ptr(out_d), ptr(out_p), ptr(sv))
+    eng.sync()
+    assert not sv.any()
+    good = kidx.copy()
+    kidx[B - 1] = (int(kidx[B - 1]) + 1) % K
+    table.verify_shuffle_batch_keyset_dev(ks, B, ptr(kidx), ptr(decks), ptr(out_d), ptr(out_p), ptr(sv))
+    eng.sync()
+    assert int((sv != 0).sum()) == 1 and int(sv[B - 1]) > 0
+    kidx[...] = good
+    kidx[0] = K
+    table.shuffle_and_remask_batch_keyset_dev(ks, B, ptr(kidx), ptr(decks), ptr(rho), ptr(perms), ptr(seeds), ptr(out_d), ptr(out_p), ptr(st))
+    eng.sync()
+    assert int(st[0]) == -3 and not st[1:].any()
+    ks.close()
+    table.close()
+    for p in held:
+        lib.mp_host_free(p)
+
+
 @pytest.mark.parametrize("m,n", [(3, 2), (5, 3), (7, 4), (9, 3), (12, 2), (16, 2), (17, 2), (16, 5)])
 def test_every_plan_family_matches_oracle(mp, coracle, m, n):
     """Toom-Cook (3 <= m <= 16, direct and reciprocal points), Karatsuba (m = 17) and the bucket kernel forced onto these small shapes:
