@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--chain-verify", action="store_true",
                     help="keep every deck and proof in HBM and verify all tables' chains at the end with ONE equation per table "
                          "(mp_verify_shuffle_chain_dev) instead of link by link as the proofs are produced")
+    ap.add_argument("--keyset", action="store_true",
+                    help="hand the tables' aggregate keys over once as a key set (mp_keyset_create) and name them by index, instead of "
+                         "passing one key per proof with every call")
     args = ap.parse_args()
     m, n, curve = 2, 26, "stark"
     N, T, P = m * n, args.tables, args.players
@@ -43,8 +46,16 @@ def main():
 
     # aggregate keys: 4096 distinct random group elements spread over the tables; initial decks: random ciphertexts
     K = min(T, 4096)
-    kpts = torch.frombuffer(bytearray(eng.setup(m, max(K, 2), bytes([4] * 32))[:64 * K]), dtype=torch.uint8).to(gpu).view(K, 64)
+    key_bytes = eng.setup(m, max(K, 2), bytes([4] * 32))[:64 * K]
+    kpts = torch.frombuffer(bytearray(key_bytes), dtype=torch.uint8).to(gpu).view(K, 64)
     keys = kpts[torch.arange(T, device=gpu) % K].contiguous()
+    kset = t.keyset(key_bytes) if args.keyset else None
+    kidx = (torch.arange(T, device=gpu) % K).to(torch.int32).contiguous()
+
+    def prove(*a):
+        if kset is not None:
+            return t.shuffle_and_remask_batch_keyset_dev(kset, T, kidx.data_ptr(), *a)
+        return t.shuffle_and_remask_batch_keys_dev(T, keys.data_ptr(), *a)
     base = torch.frombuffer(bytearray(eng.setup(m, 2 * N - 3, bytes([3] * 32))), dtype=torch.uint8).to(gpu)
     deck = base.repeat(T, 1).contiguous()
     nxt = torch.empty_like(deck)
@@ -62,8 +73,7 @@ def main():
     w_rho = rand_bytes(T, N, 32)
     w_rho[:, :, 31] &= 0x07
     w_perm = torch.argsort(torch.rand(T, N, device=gpu, generator=gen), dim=1).to(torch.int32).contiguous()
-    t.shuffle_and_remask_batch_keys_dev(T, keys.data_ptr(), deck.data_ptr(), w_rho.data_ptr(), w_perm.data_ptr(), rand_bytes(T, 32).data_ptr(),
-                                        nxt.data_ptr(), proofs.data_ptr(), st_p.data_ptr())
+    prove(deck.data_ptr(), w_rho.data_ptr(), w_perm.data_ptr(), rand_bytes(T, 32).data_ptr(), nxt.data_ptr(), proofs.data_ptr(), st_p.data_ptr())
     eng.sync()
     del w_rho, w_perm
     torch.cuda.synchronize()
@@ -75,8 +85,7 @@ def main():
         seeds = rand_bytes(T, 32)
         torch.cuda.synchronize()
         t0 = time.perf_counter()          # the players' random choices above are input generation, not timed
-        t.shuffle_and_remask_batch_keys_dev(T, keys.data_ptr(), deck.data_ptr(), rho.data_ptr(), perms.data_ptr(), seeds.data_ptr(),
-                                            nxt.data_ptr(), proofs.data_ptr(), st_p.data_ptr())
+        prove(deck.data_ptr(), rho.data_ptr(), perms.data_ptr(), seeds.data_ptr(), nxt.data_ptr(), proofs.data_ptr(), st_p.data_ptr())
         if args.chain_verify:
             st_v.zero_()
         else:
