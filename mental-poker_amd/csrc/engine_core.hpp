@@ -16,13 +16,13 @@ static const uint32_t BUCKET_MIN = 2048; // variable-base terms from which an MS
 static const uint32_t BUCKET_MIN_SMALL_BATCH = 128;   // ... in the plans for small batches (latency, not throughput)
 
 struct PhaseDev {
-  DevBuf<Term> recode, tables, fterms, vterms, cterms, cterms2;
-  DevBuf<Job> fjobs, vjobs, cjobs, cjobs2;
+  DevBuf<Term> recode, tables, fterms, vterms, cterms, cterms2, cterms0;
+  DevBuf<Job> fjobs, vjobs, cjobs, cjobs2, cjobs0;
   DevBuf<BJob> bjobs;
   DevBuf<Term> bterms;
   DevBuf<BTermPos> bpos;
   uint32_t n_b = 0, n_bterms = 0, b_dig_bytes = 0, b_kpad_max = 0;
-  uint32_t n_recode = 0, n_tables = 0, n_f = 0, n_v = 0, n_c = 0, n_c2 = 0, n_tslots = 0, n_dslots = 0;
+  uint32_t n_recode = 0, n_tables = 0, n_f = 0, n_v = 0, n_c = 0, n_c2 = 0, n_c0 = 0, n_tslots = 0, n_dslots = 0;
   std::vector<std::pair<uint32_t, uint32_t>> normalize;
   void upload(const Phase& ph, rt::Stream s) {
     recode.upload(ph.recode, s);
@@ -36,6 +36,9 @@ struct PhaseDev {
     cterms2.upload(ph.cterms2, s);
     cjobs2.upload(ph.cjobs2, s);
     n_c2 = (uint32_t)ph.cjobs2.size();
+    cterms0.upload(ph.cterms0, s);
+    cjobs0.upload(ph.cjobs0, s);
+    n_c0 = (uint32_t)ph.cjobs0.size();
     bjobs.upload(ph.bjobs, s);
     bterms.upload(ph.bterms, s);
     bpos.upload(ph.bpos, s);
@@ -511,6 +514,10 @@ struct Table : mp_table {
       BFoldArgs fa{w.J.p, ph.bjobs.p, w.Bpad, bw};
       MP_RUN(k_bucket_fold, C, B, ph.n_b, fa);
     }
+    if (ph.n_c0) {   // group sums of MSMs with many partials
+      CombineArgs a{w.J.p, w.P.p, ph.cjobs0.p, ph.cterms0.p, w.Bpad};
+      MP_RUN(k_combine, C, B, ph.n_c0, a);
+    }
     if (ph.n_c) {
       CombineArgs a{w.J.p, w.P.p, ph.cjobs.p, ph.cterms.p, w.Bpad};
       MP_RUN(k_combine, C, B, ph.n_c, a);
@@ -843,6 +850,10 @@ struct Table : mp_table {
     MP_RUN(k_bucket_fold, C, T, ph.n_b, fa);
     FixedArgs fx{chain_cs.p, w.J.p, FB.p, ph.fjobs.p, ph.fterms.p, w.Bpad, fbg, Tpad};
     MP_RUN(k_fixed_msm, C, T, ph.n_f, fx);
+    if (ph.n_c0) {
+      CombineArgs cb0{w.J.p, w.P.p, ph.cjobs0.p, ph.cterms0.p, w.Bpad};
+      MP_RUN(k_combine, C, T, ph.n_c0, cb0);
+    }
     CombineArgs cb{w.J.p, w.P.p, ph.cjobs.p, ph.cterms.p, w.Bpad};
     MP_RUN(k_combine, C, T, ph.n_c, cb);
     if (!vflag.n) vflag.alloc(1, s);
@@ -982,7 +993,7 @@ struct Table : mp_table {
     uint64_t bucket_terms = 0, bucket_jobs = 0;
     auto add = [&](const Phase& ph, uint64_t* o) {
       o[0] += ph.fterms.size(); o[1] += ph.vterms.size(); o[2] += ph.fjobs.size(); o[3] += ph.vjobs.size();
-      o[4] += ph.tables.size(); o[5] += ph.cterms.size() + ph.cterms2.size();
+      o[4] += ph.tables.size(); o[5] += ph.cterms.size() + ph.cterms2.size() + ph.cterms0.size();
       bucket_terms += ph.bterms.size();
       bucket_jobs += ph.bjobs.size();
     };
@@ -1072,7 +1083,7 @@ struct Table : mp_table {
       ops += (uint64_t)ph.vterms.size() * nwin;                             // mixed additions
       ops += (uint64_t)ph.vjobs.size() * (nwin - 1) * VB_WINDOW_BITS;       // doublings
       ops += (uint64_t)ph.tables.size() * (VB_ENTRIES - 1);                 // table construction (affine additions)
-      ops += ph.cterms.size() + ph.cterms2.size();                          // combines
+      ops += ph.cterms.size() + ph.cterms2.size() + ph.cterms0.size();      // combines
       terms += ph.bterms.size();
       ops += (uint64_t)ph.bterms.size() * bk_windows(R::BITS);              // bucket method: one mixed addition per term and window
       ops += (uint64_t)ph.bjobs.size() * bk_windows(R::BITS) * (14 + BK_BITS + 1);   // wave-wide reduction + fold

@@ -72,6 +72,8 @@ struct Phase {
   std::vector<Term> tables;   // {P slot, table slot}
   std::vector<Job> fjobs, vjobs, cjobs, cjobs2;     // cjobs2: combine jobs that consume outputs of cjobs (run after them)
   std::vector<Term> fterms, vterms, cterms, cterms2;
+  std::vector<Job> cjobs0;                          // group sums of MSMs with many partials (run before cjobs: a two-level tree)
+  std::vector<Term> cterms0;
   std::vector<std::pair<uint32_t, uint32_t>> normalize;  // [first slot, count) J -> P
   uint32_t n_dslots = 0, n_tslots = 0;
   std::vector<BJob> bjobs;    // MSMs large enough for the bucket method
@@ -81,6 +83,7 @@ struct Phase {
   uint32_t b_kpad_max = 0;
 };
 
+static const size_t COMBINE_TREE_MIN = 12;
 // Host-side builder: msm(out) { fixed(..) var(..) addend(..) } -> chunked sub-jobs + one combine job.
 class PhaseBuilder {
  public:
@@ -146,9 +149,25 @@ class PhaseBuilder {
     if (!direct) {
       std::vector<Job>& cj = late ? ph_.cjobs2 : ph_.cjobs;
       std::vector<Term>& ct = late ? ph_.cterms2 : ph_.cterms;
-      cj.push_back(Job{out_, (uint32_t)ct.size(), (uint32_t)(parts.size() + a_.size())});
+      parts.insert(parts.end(), a_.begin(), a_.end());
+      // the fine splits leave an MSM with up to ~250 partial sums and one lane to add them up: from COMBINE_TREE_MIN pieces on,
+      // lanes of a first pass add groups of ~sqrt(pieces) and the MSM's own job adds the group sums (2 sqrt(n) additions deep
+      // instead of n; the throughput plans never get here)
+      if (!late && parts.size() >= COMBINE_TREE_MIN) {
+        size_t g = 1;
+        while (g * g < parts.size()) ++g;
+        std::vector<uint32_t> sums;
+        for (size_t b = 0; b < parts.size(); b += g) {
+          const size_t e = std::min(parts.size(), b + g);
+          const uint32_t out = next_partial_++;
+          ph_.cjobs0.push_back(Job{out, (uint32_t)ph_.cterms0.size(), (uint32_t)(e - b)});
+          for (size_t i = b; i < e; ++i) ph_.cterms0.push_back(Term{parts[i], 0});
+          sums.push_back(out);
+        }
+        parts.swap(sums);
+      }
+      cj.push_back(Job{out_, (uint32_t)ct.size(), (uint32_t)parts.size()});
       for (uint32_t p : parts) ct.push_back(Term{p, 0});
-      for (uint32_t p : a_) ct.push_back(Term{p, 0});
     }
   }
   void normalize(uint32_t first, uint32_t count) {
