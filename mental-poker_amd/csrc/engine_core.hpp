@@ -526,8 +526,36 @@ struct Table : mp_table {
       CombineArgs a{w.J.p, w.P.p, ph.cjobs2.p, ph.cterms2.p, w.Bpad};
       MP_RUN(k_combine, C, B, ph.n_c2, a);
     }
-    for (auto& r : ph.normalize)
-      normalize_flat(w.J.p + j_off<C>(r.first, w.Bpad, 0), w.P.p + p_off<C>(r.first, w.Bpad, 0), w.NS.p, (size_t)r.second * w.Bpad);
+    // the ranges of a phase in as few launches as possible (NORM_MAX_RANGES per launch; element offsets must fit 32 bits)
+    for (size_t i = 0; i < ph.normalize.size();) {
+      const size_t nr = std::min<size_t>(NORM_MAX_RANGES, ph.normalize.size() - i);
+      size_t last_elem = 0;
+      for (size_t k = 0; k < nr; ++k)
+        last_elem = std::max(last_elem, ((size_t)ph.normalize[i + k].first + ph.normalize[i + k].second) * w.Bpad);
+      if (nr == 1 || last_elem >= ((size_t)1 << 32)) {
+        auto& r = ph.normalize[i];
+        normalize_flat(w.J.p + j_off<C>(r.first, w.Bpad, 0), w.P.p + p_off<C>(r.first, w.Bpad, 0), w.NS.p, (size_t)r.second * w.Bpad);
+        ++i;
+        continue;
+      }
+      NormMultiArgs a{};
+      a.J = w.J.p; a.P = w.P.p; a.scratch = w.NS.p;
+      a.nr = (uint32_t)nr; a.chunk = cur_norm_chunk;
+      uint32_t threads = 0, selem = 0;
+      for (size_t k = 0; k < nr; ++k) {
+        auto& r = ph.normalize[i + k];
+        const uint32_t cnt = r.second * w.Bpad;
+        a.first[k] = r.first * w.Bpad;
+        a.count[k] = cnt;
+        a.tstart[k] = threads;
+        a.sstart[k] = selem;
+        threads += (cnt + cur_norm_chunk - 1) / cur_norm_chunk;
+        selem += cnt;
+      }
+      a.tstart[nr] = threads;
+      MP_RUN(k_normalize_multi, C, threads, 1, a);
+      i += nr;
+    }
   }
 
   FsStatementArgs statement_args(Workspace& w, uint32_t p_deck, uint32_t p_shuf, uint32_t p_cA, uint32_t s_x, uint32_t p_pk = NO_SLOT) {

@@ -530,6 +530,34 @@ MP_HD void body_normalize(const NormArgs& a, uint32_t x, uint32_t y) {
   }
 }
 MP_KERNEL(k_normalize, NormArgs, body_normalize)
+// several slot ranges of the J arena in ONE launch (the ranges a phase normalises are independent; launched one after the other
+// each of them is a full inversion deep, which is what a small batch waits for): thread x belongs to range r with
+// tstart[r] <= x < tstart[r + 1] and does there what body_normalize does
+static const uint32_t NORM_MAX_RANGES = 4;
+struct NormMultiArgs {
+  const uint32_t* J;
+  uint32_t* P;
+  uint32_t* scratch;
+  uint32_t nr, chunk;
+  uint32_t first[NORM_MAX_RANGES];     // first element (slot * Bpad) of the range in both arenas
+  uint32_t count[NORM_MAX_RANGES];     // elements
+  uint32_t tstart[NORM_MAX_RANGES + 1];   // first thread of the range
+  uint32_t sstart[NORM_MAX_RANGES];    // first scratch element of the range
+};
+template <class C>
+MP_HD void body_normalize_multi(const NormMultiArgs& a, uint32_t x, uint32_t y) {
+  uint32_t r = 0;
+  while (r + 1 < a.nr && x >= a.tstart[r + 1]) ++r;
+  NormArgs n;
+  n.src = a.J + (size_t)a.first[r] * Geo<C>::JW;
+  n.dst = a.P + (size_t)a.first[r] * Geo<C>::PW;
+  n.scratch = a.scratch + (size_t)a.sstart[r] * Geo<C>::FW;
+  n.count = a.count[r];
+  n.nthreads = a.tstart[r + 1] - a.tstart[r];
+  n.chunk = a.chunk;
+  body_normalize<C>(n, x - a.tstart[r], y);
+}
+MP_KERNEL(k_normalize_multi, NormMultiArgs, body_normalize_multi)
 
 // ---- Toom-Cook, ciphertext side: C(x) = sum_s x^s c_s at x = +-1 .. +-(m-1) for one column point of the shuffled deck
 // (c_s = row m - s; x = proof, y = 2 t + component).  Even / odd split: C(+-x) = Ce(x^2) +- x Co(x^2), Horner in x^2; the small
@@ -685,6 +713,7 @@ MP_KERNEL(k_fb_widen, FbWidenArgs, body_fb_widen)
   MP_KERNEL_INST(X, k_var_msm, VarArgs, C) \
   MP_KERNEL_INST(X, k_combine, CombineArgs, C) \
   MP_KERNEL_INST(X, k_normalize, NormArgs, C) \
+  MP_KERNEL_INST(X, k_normalize_multi, NormMultiArgs, C) \
   MP_KERNEL_INST(X, k_fb_windows, FbWinArgs, C) \
   MP_KERNEL_INST(X, k_fb_fill, FbFillArgs, C) \
   MP_KERNEL_INST(X, k_fb_widen, FbWidenArgs, C) \
