@@ -18,5 +18,5 @@ eng.profile_enable(False)
 for name, r in (("prove", rp), ("verify", rv)):
     tot = sum(v[1] for v in r.values())
     print(name, "kernel ms total %.2f, launches %d" % (tot, sum(v[0] for v in r.values())))
-    for k, v in sorted(r.items(), key=lambda kv: -kv[1][1])[:10]:
+    for k, v in sorted(r.items(), key=lambda kv: -kv[1][1])[:40]:
         print("   %-16s x%-3d %.3f ms" % (k, v[0], v[1]))
