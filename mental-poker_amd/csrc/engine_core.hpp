@@ -121,7 +121,7 @@ struct Table : mp_table {
   };
   // Four static work splits per table, identical results: [0] throughput (64 variable-base / 8 fixed-base terms per lane,
   // 64 bases per table lane: fewest operations), [1] latency (4 / 2 / 8: ~16x more lanes per proof), [2] medium (16 / 4 / 16),
-  // [3] single proofs and tiny batches (1 / 1 / 2).  Measured on an MI355X, 52 cards: [3] wins up to ~768 proofs in flight,
+  // [3] single proofs and tiny batches (1 / 1 / 2 on decks of up to 128 cards, else 2 / 1 / 4).  Measured on an MI355X, 52 cards: [3] wins up to ~768 proofs in flight,
   // latency up to ~4 k, medium up to ~14 k, throughput beyond.
   static const int N_PLANS = 4;
   PlanSet ps[N_PLANS];        // plans with the table's own aggregate key as a fixed base
@@ -256,10 +256,13 @@ struct Table : mp_table {
 
   void build_plans(PlanSet* set, bool keyed) {
     rt::Stream s = ctx->stream;
-    // ([3]: one variable-base term per lane and two bases per table lane -- the partial sums go through the two-level combine;
-    // measured on one MI355X: one 52-card proof 6.6 -> 6.1 ms against 2 terms / 4 bases, same or better up to 256 proofs)
-    static const uint32_t fch[N_PLANS] = {FCHUNK, 2, 4, 1}, vch[N_PLANS] = {VCHUNK, 4, 16, 1}, grp[N_PLANS] = {TABLE_GROUP, 8, 16, 2},
-                          nch[N_PLANS] = {NORM_CHUNK, 8, 32, 4};
+    // ([3] on decks of up to 128 cards: one variable-base term per lane and two bases per table lane -- the partial sums go through
+    // the two-level combine; measured on one MI355X: one 52-card proof 6.6 -> 6.1 ms against 2 terms / 4 bases, same or better up
+    // to 256 proofs.  A single 300-card proof already brings more lanes than the chip holds: there the finer split only adds work,
+    // BLS12-377 (30,10) 90 -> 117 ms.)
+    const uint32_t tiny_v = N <= 128 ? 1u : 2u, tiny_g = N <= 128 ? 2u : 4u;
+    const uint32_t fch[N_PLANS] = {FCHUNK, 2, 4, 1}, vch[N_PLANS] = {VCHUNK, 4, 16, tiny_v}, grp[N_PLANS] = {TABLE_GROUP, 8, 16, tiny_g},
+                   nch[N_PLANS] = {NORM_CHUNK, 8, 32, 4};
     for (int k = 0; k < N_PLANS; ++k) {
       PlanSet& q = set[k];
       // the two finest splits serve batches too small to fill the chip with one lane per Straus job: there the bucket kernel
