@@ -168,7 +168,8 @@ def load_mad_counts(curve):
     c = d.get("curves", {}).get(curve)
     if not c:
         return None
-    M, S, MS, inv = c["mul"], c["sqr"], c["mulsub"], c["inv_sqr"] * c["sqr"] + c["inv_mul"] * c["mul"]
+    M, S, MS = c["mul"], c["sqr"], c["mulsub"]
+    inv = c.get("inv_divsteps_mads", c["inv_sqr"] * c["sqr"] + c["inv_mul"] * c["mul"])
     a1 = 1 if c["a_is_one"] else 0
     return {
         "field": {"mul": M, "sqr": S, "mulsub": MS, "inv": inv},

@@ -593,7 +593,7 @@ MP_HD bool fe_canonical_in_range(const uint32_t* a) {
 // a^(2^L - 1), L = 1..5: ~256 squarings + ~45..75 products instead of one product per one-bit.
 // Not inlined: it is called once per batch of points.
 template <class P>
-MP_HD_NOINLINE Fe<P> fe_inv(const Fe<P>& a) {
+MP_HD_NOINLINE Fe<P> fe_inv_fermat(const Fe<P>& a) {
   Fe<P> run[5];                       // run[L-1] = a^(2^L - 1)
   run[0] = a;
   for (int l = 1; l < 5; ++l) run[l] = fe_mul<P>(fe_sqr<P>(run[l - 1]), a);
@@ -612,6 +612,128 @@ MP_HD_NOINLINE Fe<P> fe_inv(const Fe<P>& a) {
     i -= len;
   }
   return acc;
+}
+
+// ---- inversion by division steps (29-bit fields) -------------------------------------------------------------------------------
+// Bernstein-Yang "safegcd" [PAPER: Bernstein, Yang, "Fast constant-time gcd computation and modular inversion", CHES 2019], in the
+// half-delta form with batched 2x2 transition matrices that libsecp256k1's modinv32 made standard, restated for 9 signed limbs of
+// 29 bits: 21 batches of 29 division steps (609 >= the 590 steps that suffice for a 256-bit modulus).  A batch costs 29 x ~20
+// single-cycle operations on the low words, 36 multiply-adds to apply the matrix to (f, g) and ~54 to apply it to (d, e) modulo p:
+// ~1 900 multiply-adds and ~14 000 simple operations per inversion instead of the ~20 600 dependent multiply-adds of the Fermat
+// ladder above -- a 2.5-4x shorter chain on the lane that every batch of points waits for (k_normalize, k_table).
+// Constant number of steps, no data-dependent branches: the lanes of a wave stay together.
+MP_HD int32_t divsteps29(int32_t zeta, uint32_t f0, uint32_t g0, int32_t t[4]) {
+  uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
+#pragma unroll 1
+  for (int i = 0; i < 29; ++i) {
+    uint32_t m1 = (uint32_t)(zeta >> 31);          // zeta < 0
+    const uint32_t m2 = 0u - (g & 1u);              // g odd
+    const uint32_t x = (f ^ m1) - m1, y = (u ^ m1) - m1, z = (v ^ m1) - m1;   // (f, u, v), negated if zeta < 0
+    g += x & m2; q += y & m2; r += z & m2;
+    m1 &= m2;
+    zeta = (zeta ^ (int32_t)m1) - 1;                // -zeta - 2 or zeta - 1
+    f += g & m1; u += q & m1; v += r & m1;
+    g >>= 1; u <<= 1; v <<= 1;
+  }
+  t[0] = (int32_t)u; t[1] = (int32_t)v; t[2] = (int32_t)q; t[3] = (int32_t)r;
+  return zeta;
+}
+// (f, g) <- t (f, g) / 2^29 (exact)
+MP_HD void divsteps_update_fg(int32_t f[9], int32_t g[9], const int32_t t[4]) {
+  const int64_t u = t[0], v = t[1], q = t[2], r = t[3];
+  int64_t cf = u * f[0] + v * g[0], cg = q * f[0] + r * g[0];
+  cf >>= 29; cg >>= 29;
+#pragma unroll
+  for (int i = 1; i < 9; ++i) {
+    cf += u * f[i] + v * g[i];
+    cg += q * f[i] + r * g[i];
+    f[i - 1] = (int32_t)cf & (int32_t)M29; cf >>= 29;
+    g[i - 1] = (int32_t)cg & (int32_t)M29; cg >>= 29;
+  }
+  f[8] = (int32_t)cf;
+  g[8] = (int32_t)cg;
+}
+// (d, e) <- t (d, e) / 2^29 mod p, both kept in (-2p, p); pinv = p^-1 mod 2^29
+MP_HD void divsteps_update_de(int32_t d[9], int32_t e[9], const int32_t t[4], const int32_t p[9], uint32_t pinv) {
+  const int32_t u = t[0], v = t[1], q = t[2], r = t[3];
+  const int32_t sd = d[8] >> 31, se = e[8] >> 31;
+  int32_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
+  int64_t cd = (int64_t)u * d[0] + (int64_t)v * e[0], ce = (int64_t)q * d[0] + (int64_t)r * e[0];
+  md -= (int32_t)((pinv * (uint32_t)cd + (uint32_t)md) & M29);
+  me -= (int32_t)((pinv * (uint32_t)ce + (uint32_t)me) & M29);
+  cd += (int64_t)p[0] * md;
+  ce += (int64_t)p[0] * me;
+  cd >>= 29; ce >>= 29;
+#pragma unroll
+  for (int i = 1; i < 9; ++i) {
+    cd += (int64_t)u * d[i] + (int64_t)v * e[i] + (int64_t)p[i] * md;
+    ce += (int64_t)q * d[i] + (int64_t)r * e[i] + (int64_t)p[i] * me;
+    d[i - 1] = (int32_t)cd & (int32_t)M29; cd >>= 29;
+    e[i - 1] = (int32_t)ce & (int32_t)M29; ce >>= 29;
+  }
+  d[8] = (int32_t)cd;
+  e[8] = (int32_t)ce;
+}
+template <class P>
+MP_HD Fe<P> fe_inv_divsteps(const Fe<P>& a) {      // inlined: a function of its own is compiled without the caller's register budget (248 VGPRs, 2 waves)
+  static_assert(P::L29 && P::BITS <= 256, "division-step inversion is written for the 9 x 29-bit fields");
+  uint32_t pw[9], xw[9];
+  unpack29(P::MOD, pw);                               // p as 9 normalised limbs
+  canonical29<P>(a.v, xw);                            // the residue a R mod p as an integer in [0, p)
+  int32_t p[9], f[9], g[9], d[9], e[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    p[i] = (int32_t)pw[i]; f[i] = p[i]; g[i] = (int32_t)xw[i]; d[i] = 0; e[i] = 0;
+  }
+  e[0] = 1;
+  uint32_t pinv = pw[0];                              // Newton: p^-1 mod 2^32 from p (odd) in 4 steps, then mod 2^29
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pinv *= 2u - pw[0] * pinv;
+  pinv &= M29;
+  int32_t zeta = -1;
+#pragma unroll 1
+  for (int it = 0; it < 21; ++it) {
+    int32_t t[4];
+    zeta = divsteps29(zeta, (uint32_t)f[0], (uint32_t)g[0], t);
+    divsteps_update_de(d, e, t, p, pinv);
+    divsteps_update_fg(f, g, t);
+  }
+  // g = 0 and f = +-gcd = +-1 (or f = +-p for a = 0, with d = 0): the inverse is sign(f) d, brought into [0, p)
+  const int32_t neg = f[8] >> 31;
+  int32_t add = d[8] >> 31;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    d[i] += p[i] & add;
+    d[i] = (d[i] ^ neg) - neg;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    d[i + 1] += d[i] >> 29;
+    d[i] &= (int32_t)M29;
+  }
+  add = d[8] >> 31;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) d[i] += p[i] & add;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    d[i + 1] += d[i] >> 29;
+    d[i] &= (int32_t)M29;
+  }
+  // d = (a R)^-1 as an integer; a^-1 R = d R^2 = montmul(d, R^3), R^3 = montmul(R^2, R^2)
+  Fe<P> y, r2;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    y.v[i] = (uint32_t)d[i];
+    r2.v[i] = P::R2_29[i];
+  }
+  return fe_mul<P>(y, fe_mul<P>(r2, r2));
+}
+template <class P>
+MP_HD Fe<P> fe_inv(const Fe<P>& a) {
+  if constexpr (P::L29)
+    return fe_inv_divsteps<P>(a);
+  else
+    return fe_inv_fermat<P>(a);
 }
 
 }  // namespace mp
