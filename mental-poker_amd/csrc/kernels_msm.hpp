@@ -29,6 +29,9 @@ struct Geo {
   // there only made the compiler spill and warn
   static constexpr int OCC4 = C::FqP::NW > 8 ? 2 : 4;
   static constexpr int OCC3 = C::FqP::NW > 8 ? 2 : 3;
+  // k_table: with the division-step inversion inlined the 29-bit fields need 144 registers; capped at 128 the compiler spills 15
+  // of them and the fourth wave still wins (-1.7 % in an A/B); the 8 x 32 form (bn254) would spill 336 bytes there
+  static constexpr int OCC_TABLE = C::FqP::NW > 8 ? 2 : (C::FqP::L29 ? 4 : 3);
   static constexpr uint32_t FW = C::FqP::NW;
   static constexpr uint32_t PW = 2 * FW;
   static constexpr uint32_t JW = 3 * FW;
@@ -427,7 +430,7 @@ MP_HD void body_table(const TableArgs& a, uint32_t b, uint32_t y) {
     }
   }
 }
-MP_KERNEL_OCC(k_table, TableArgs, body_table, Geo<C>::OCC3)
+MP_KERNEL_OCC(k_table, TableArgs, body_table, Geo<C>::OCC_TABLE)
 
 // ---- variable-base MSM (Straus) -----------------------------------------------------------------------
 struct VarArgs {
