@@ -614,14 +614,16 @@ MP_HD_NOINLINE Fe<P> fe_inv_fermat(const Fe<P>& a) {
   return acc;
 }
 
-// ---- inversion by division steps (29-bit fields) -------------------------------------------------------------------------------
+// ---- inversion by division steps --------------------------------------------------------------------------------------------
 // Bernstein-Yang "safegcd" [PAPER: Bernstein, Yang, "Fast constant-time gcd computation and modular inversion", CHES 2019], in the
-// half-delta form with batched 2x2 transition matrices that libsecp256k1's modinv32 made standard, restated for 9 signed limbs of
-// 29 bits: 21 batches of 29 division steps (609 >= the 590 steps that suffice for a 256-bit modulus).  A batch costs 29 x ~20
-// single-cycle operations on the low words, 36 multiply-adds to apply the matrix to (f, g) and ~54 to apply it to (d, e) modulo p:
-// ~1 900 multiply-adds and ~14 000 simple operations per inversion instead of the ~20 600 dependent multiply-adds of the Fermat
-// ladder above -- a 2.5-4x shorter chain on the lane that every batch of points waits for (k_normalize, k_table).
-// Constant number of steps, no data-dependent branches: the lanes of a wave stay together.
+// half-delta form with batched 2x2 transition matrices that libsecp256k1's modinv32 made standard, restated for NL signed limbs of
+// 29 bits (9 limbs up to 256 bits, 14 for the 377-bit base field of BLS12-377): batches of 29 division steps on the low words, then
+// the matrix applied to (f, g) (4 NL multiply-adds) and to (d, e) modulo p (6 NL).  256 bits: 21 batches (609 >= the 590 steps that
+// suffice there), ~1 900 multiply-adds and ~14 000 single-cycle operations instead of the ~20 600 dependent multiply-adds of the
+// Fermat ladder above -- a 2.5-4x shorter chain on the lane that every batch of points waits for (k_normalize, k_table).
+// Constant number of steps, no data-dependent branches: the lanes of a wave stay together.  Beyond 256 bits the step count is the
+// (larger) bound of the original delta = 1 analysis, (49 bits + 80) / 17, and the result is CHECKED (g = 0 at the end, which
+// makes d the inverse whatever the count was): should it ever fail, the Fermat ladder answers instead.
 MP_HD int32_t divsteps29(int32_t zeta, uint32_t f0, uint32_t g0, int32_t t[4]) {
   uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
 #pragma unroll 1
@@ -639,24 +641,26 @@ MP_HD int32_t divsteps29(int32_t zeta, uint32_t f0, uint32_t g0, int32_t t[4]) {
   return zeta;
 }
 // (f, g) <- t (f, g) / 2^29 (exact)
-MP_HD void divsteps_update_fg(int32_t f[9], int32_t g[9], const int32_t t[4]) {
+template <int NL>
+MP_HD void divsteps_update_fg(int32_t* f, int32_t* g, const int32_t t[4]) {
   const int64_t u = t[0], v = t[1], q = t[2], r = t[3];
   int64_t cf = u * f[0] + v * g[0], cg = q * f[0] + r * g[0];
   cf >>= 29; cg >>= 29;
 #pragma unroll
-  for (int i = 1; i < 9; ++i) {
+  for (int i = 1; i < NL; ++i) {
     cf += u * f[i] + v * g[i];
     cg += q * f[i] + r * g[i];
     f[i - 1] = (int32_t)cf & (int32_t)M29; cf >>= 29;
     g[i - 1] = (int32_t)cg & (int32_t)M29; cg >>= 29;
   }
-  f[8] = (int32_t)cf;
-  g[8] = (int32_t)cg;
+  f[NL - 1] = (int32_t)cf;
+  g[NL - 1] = (int32_t)cg;
 }
 // (d, e) <- t (d, e) / 2^29 mod p, both kept in (-2p, p); pinv = p^-1 mod 2^29
-MP_HD void divsteps_update_de(int32_t d[9], int32_t e[9], const int32_t t[4], const int32_t p[9], uint32_t pinv) {
+template <int NL>
+MP_HD void divsteps_update_de(int32_t* d, int32_t* e, const int32_t t[4], const int32_t* p, uint32_t pinv) {
   const int32_t u = t[0], v = t[1], q = t[2], r = t[3];
-  const int32_t sd = d[8] >> 31, se = e[8] >> 31;
+  const int32_t sd = d[NL - 1] >> 31, se = e[NL - 1] >> 31;
   int32_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
   int64_t cd = (int64_t)u * d[0] + (int64_t)v * e[0], ce = (int64_t)q * d[0] + (int64_t)r * e[0];
   md -= (int32_t)((pinv * (uint32_t)cd + (uint32_t)md) & M29);
@@ -665,75 +669,126 @@ MP_HD void divsteps_update_de(int32_t d[9], int32_t e[9], const int32_t t[4], co
   ce += (int64_t)p[0] * me;
   cd >>= 29; ce >>= 29;
 #pragma unroll
-  for (int i = 1; i < 9; ++i) {
+  for (int i = 1; i < NL; ++i) {
     cd += (int64_t)u * d[i] + (int64_t)v * e[i] + (int64_t)p[i] * md;
     ce += (int64_t)q * d[i] + (int64_t)r * e[i] + (int64_t)p[i] * me;
     d[i - 1] = (int32_t)cd & (int32_t)M29; cd >>= 29;
     e[i - 1] = (int32_t)ce & (int32_t)M29; ce >>= 29;
   }
-  d[8] = (int32_t)cd;
-  e[8] = (int32_t)ce;
+  d[NL - 1] = (int32_t)cd;
+  e[NL - 1] = (int32_t)ce;
 }
-template <class P>
-MP_HD Fe<P> fe_inv_divsteps(const Fe<P>& a) {      // inlined: a function of its own is compiled without the caller's register budget (248 VGPRs, 2 waves)
-  static_assert(P::L29 && P::BITS <= 256, "division-step inversion is written for the 9 x 29-bit fields");
-  uint32_t pw[9], xw[9];
-  unpack29(P::MOD, pw);                               // p as 9 normalised limbs
-  canonical29<P>(a.v, xw);                            // the residue a R mod p as an integer in [0, p)
-  int32_t p[9], f[9], g[9], d[9], e[9];
+// NW packed 32-bit words <-> NL limbs of 29 bits (the top limb takes what is left)
+template <int NW, int NL>
+MP_HD void limbs29_from_words(const uint32_t* w, int32_t* l) {
 #pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    p[i] = (int32_t)pw[i]; f[i] = p[i]; g[i] = (int32_t)xw[i]; d[i] = 0; e[i] = 0;
+  for (int i = 0; i < NL; ++i) {
+    const int k = (29 * i) / 32, off = (29 * i) % 32;
+    uint32_t x = k < NW ? w[k] >> off : 0u;
+    if (off > 3 && k + 1 < NW) x |= w[k + 1] << (32 - off);
+    l[i] = (int32_t)(x & M29);
+  }
+}
+template <int NW, int NL>
+MP_HD void words_from_limbs29(const int32_t* l, uint32_t* w) {      // limbs normalised, value < 2^(32 NW)
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const int k = (32 * j) / 29, off = (32 * j) % 29;
+    uint32_t x = (uint32_t)l[k] >> off;
+    if (k + 1 < NL) x |= (uint32_t)l[k + 1] << (29 - off);
+    if (off > 0 && 29 - off + 29 < 32 && k + 2 < NL) x |= (uint32_t)l[k + 2] << (58 - off);
+    w[j] = x;
+  }
+}
+// inlined into its kernels: a function of its own is compiled without the caller's register budget (it came out at 248 VGPRs
+// and took k_table and k_normalize down to 2 waves per SIMD)
+template <class P>
+MP_HD Fe<P> fe_inv_divsteps(const Fe<P>& a) {
+  constexpr int NW = P::NW, NL = (P::BITS + 2 + 28) / 29;      // room for values in (-2p, p)
+  constexpr int BATCHES = P::BITS <= 256 ? 21 : ((49 * P::BITS + 80) / 17 + 28) / 29;
+  uint32_t xw[NW];
+  if constexpr (P::L29) {
+    uint32_t c[9];
+    canonical29<P>(a.v, c);                           // the residue a R mod p as an integer in [0, p)
+    pack29(c, xw);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) xw[i] = a.v[i];      // canonical Montgomery residue already
+  }
+  int32_t p[NL], f[NL], g[NL], d[NL], e[NL];
+  limbs29_from_words<NW, NL>(P::MOD, p);
+  limbs29_from_words<NW, NL>(xw, g);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    f[i] = p[i]; d[i] = 0; e[i] = 0;
   }
   e[0] = 1;
-  uint32_t pinv = pw[0];                              // Newton: p^-1 mod 2^32 from p (odd) in 4 steps, then mod 2^29
+  uint32_t pinv = (uint32_t)p[0];                     // Newton: p^-1 mod 2^32 from p (odd) in 4 steps, then mod 2^29
 #pragma unroll
-  for (int i = 0; i < 4; ++i) pinv *= 2u - pw[0] * pinv;
+  for (int i = 0; i < 4; ++i) pinv *= 2u - (uint32_t)p[0] * pinv;
   pinv &= M29;
   int32_t zeta = -1;
 #pragma unroll 1
-  for (int it = 0; it < 21; ++it) {
+  for (int it = 0; it < BATCHES; ++it) {
     int32_t t[4];
     zeta = divsteps29(zeta, (uint32_t)f[0], (uint32_t)g[0], t);
-    divsteps_update_de(d, e, t, p, pinv);
-    divsteps_update_fg(f, g, t);
+    divsteps_update_de<NL>(d, e, t, p, pinv);
+    divsteps_update_fg<NL>(f, g, t);
+  }
+  if constexpr (P::BITS > 256) {
+    // beyond 256 bits the step count is not the published bound of this variant: check the outcome (g = 0 makes d the inverse
+    // whatever the count was).  Up to 256 bits the 590-step bound is proven and the kernels stay free of an out-of-line call.
+    int32_t gnz = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) gnz |= g[i];
+    if (gnz != 0) {                                   // never observed
+#ifdef MP_DIVSTEPS_COUNT_FALLBACKS                     // (tests/cpp/inv_check.cpp counts how often this branch is taken: 0)
+      ++MP_DIVSTEPS_COUNT_FALLBACKS;
+#endif
+      return fe_inv_fermat<P>(a);
+    }
   }
   // g = 0 and f = +-gcd = +-1 (or f = +-p for a = 0, with d = 0): the inverse is sign(f) d, brought into [0, p)
-  const int32_t neg = f[8] >> 31;
-  int32_t add = d[8] >> 31;
+  const int32_t neg = f[NL - 1] >> 31;
+  int32_t add = d[NL - 1] >> 31;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) {
+  for (int i = 0; i < NL; ++i) {
     d[i] += p[i] & add;
     d[i] = (d[i] ^ neg) - neg;
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < NL - 1; ++i) {
     d[i + 1] += d[i] >> 29;
     d[i] &= (int32_t)M29;
   }
-  add = d[8] >> 31;
+  add = d[NL - 1] >> 31;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) d[i] += p[i] & add;
+  for (int i = 0; i < NL; ++i) d[i] += p[i] & add;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < NL - 1; ++i) {
     d[i + 1] += d[i] >> 29;
     d[i] &= (int32_t)M29;
   }
-  // d = (a R)^-1 as an integer; a^-1 R = d R^2 = montmul(d, R^3), R^3 = montmul(R^2, R^2)
-  Fe<P> y, r2;
+  // d = (a R)^-1 as an integer; a^-1 R = d R^2
+  if constexpr (P::L29) {
+    Fe<P> y, r2;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    y.v[i] = (uint32_t)d[i];
-    r2.v[i] = P::R2_29[i];
+    for (int i = 0; i < 9; ++i) {
+      y.v[i] = (uint32_t)d[i];
+      r2.v[i] = P::R2_29[i];
+    }
+    return fe_mul<P>(y, fe_mul<P>(r2, r2));           // montmul(d, R^3), R^3 = montmul(R^2, R^2)
+  } else {
+    Fe<P> y, r2;
+    words_from_limbs29<NW, NL>(d, y.v);
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r2.v[i] = P::R2[i];
+    return fe_mul<P>(fe_mul<P>(y, r2), r2);           // montmul(montmul(d, R^2), R^2) = d R^2
   }
-  return fe_mul<P>(y, fe_mul<P>(r2, r2));
 }
 template <class P>
 MP_HD Fe<P> fe_inv(const Fe<P>& a) {
-  if constexpr (P::L29)
-    return fe_inv_divsteps<P>(a);
-  else
-    return fe_inv_fermat<P>(a);
+  return fe_inv_divsteps<P>(a);
 }
 
 }  // namespace mp

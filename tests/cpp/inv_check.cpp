@@ -1,9 +1,11 @@
-// host check of the division-step inversion (field.hpp fe_inv_divsteps) against the Fermat ladder it replaces, on the two
-// 29-bit base fields; built and run by tests/test_cabi_and_host.py::test_division_step_inversion_matches_fermat
+// host check of the division-step inversion (field.hpp fe_inv_divsteps) against the Fermat ladder it replaces, on the base
+// fields of the four curves and two scalar fields; built and run by tests/test_cabi_and_host.py::test_division_step_inversion_matches_fermat
 //   g++ -O2 -std=c++17 -include tools/hostemu/rt.hpp -Itools/hostemu -Imental-poker_amd/csrc tests/cpp/inv_check.cpp
 #include <cstdio>
 #include <cstdlib>
 
+static long fallbacks = 0;
+#define MP_DIVSTEPS_COUNT_FALLBACKS fallbacks
 #include "curve.hpp"
 
 using namespace mp;
@@ -47,8 +49,8 @@ static long check(const char* name, long count) {
     if (!fe_canonical_in_range<F>(w)) continue;
     one(fe_from_canonical<F>(w));
   }
-  printf("%s: %ld inversions, %ld mismatches\n", name, done, bad);
-  return bad;
+  printf("%s: %ld inversions, %ld mismatches, %ld answered by the fallback\n", name, done, bad, fallbacks);
+  return bad + fallbacks;
 }
 
 int main(int argc, char** argv) {
@@ -56,5 +58,9 @@ int main(int argc, char** argv) {
   long bad = 0;
   bad += check<Stark::FqP>("stark Fq", count);
   bad += check<Secp256k1::FqP>("secp256k1 Fq", count);
+  bad += check<Bn254::FqP>("bn254 Fq", count);
+  bad += check<Bls12_377::FqP>("bls12_377 Fq", count / 4);
+  bad += check<Stark::FrP>("stark Fr", count / 4);
+  bad += check<Bls12_377::FrP>("bls12_377 Fr", count / 4);
   return bad ? 1 : 0;
 }
