@@ -63,17 +63,31 @@ struct LoadPointsArgs {
   uint32_t* P;
   int32_t* status;
   uint32_t Bpad, count, p_slot;
+  // optional: keep the wire words of every point, [w_slot + y][Bpad][words] (the layout of the P arena: 16-byte vector accesses).  A valid wire point IS its canonical coordinates, i.e.
+  // what the transcript hashes: the Fiat-Shamir lane then stages these words instead of taking every coordinate out of Montgomery
+  // form again (one field multiplication each on the one lane a proof's transcript has)
+  uint32_t* W = nullptr;
+  uint32_t w_slot = 0;
 };
 // x = proof, y = point index (a deck of N cards is 2N points: c0, c1 of card i at 2i, 2i+1)
 template <class C>
 MP_HD void body_load_points(const LoadPointsArgs& a, uint32_t b, uint32_t y) {
   Aff<C> pt;
-  const bool ok = wire_to_aff<C>(a.src + ((size_t)b * a.count + y) * Geo<C>::PB, pt);
+  const uint8_t* src = a.src + ((size_t)b * a.count + y) * Geo<C>::PB;
+  const bool ok = wire_to_aff<C>(src, pt);
   if (!ok) {
     status_fail(a.status, b, ST_BAD_ENCODING);
     pt = aff_inf<C>();
   }
   st_aff<C>(a.P + p_off<C>(a.p_slot + y, a.Bpad, b), pt);
+  if (a.W) {
+    constexpr uint32_t WW = Geo<C>::PB / 4;
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(src);
+    uint32_t k[WW];
+#pragma unroll
+    for (uint32_t i = 0; i < WW; ++i) k[i] = q[i];
+    st_words<WW>(a.W + ((size_t)(a.w_slot + y) * a.Bpad + b) * WW, k);
+  }
 }
 MP_KERNEL(k_load_points, LoadPointsArgs, body_load_points)
 
@@ -230,6 +244,25 @@ MP_HD void fs_put_point(StageWriter& w, const Aff<C>& p) {   // ark ToBytes: x |
   for (int i = 0; i < FW; ++i) stage_word(w, k[i]);
   stage_byte(w, 0);
 }
+// the same bytes from the kept wire words of a loaded point (LoadPointsArgs::W): all-zero words are the wire form of infinity
+template <class C>
+MP_HD void fs_put_wire_point(StageWriter& w, const uint32_t* W, uint32_t slot, uint32_t Bpad, uint32_t b) {
+  constexpr int FW = C::FqP::NW, WW = 2 * FW;
+  uint32_t k[WW], nz = 0;
+  ld_words<WW>(W + ((size_t)slot * Bpad + b) * WW, k);
+#pragma unroll
+  for (int i = 0; i < WW; ++i) nz |= k[i];
+  if (nz == 0) {
+    for (int i = 0; i < FW; ++i) stage_word(w, 0);
+    stage_word(w, 1);
+    for (int i = 1; i < FW; ++i) stage_word(w, 0);
+    stage_byte(w, 1);
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < WW; ++i) stage_word(w, k[i]);
+  stage_byte(w, 0);
+}
 MP_HD void fs_load_seed(const FsDev& f, uint32_t b, uint32_t seed[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) seed[i] = f.seed[(size_t)i * f.Bpad + b];
@@ -270,6 +303,8 @@ struct FsStatementArgs {
   uint32_t m, n, N;
   uint32_t p_deck, p_shuf, p_cA, s_x;
   uint32_t p_pk;               // keyed batches: P slot of the per-proof aggregate key (NO_SLOT: the table's fixed base)
+  const uint32_t* W;           // kept wire words of the loaded decks (LoadPointsArgs::W), or null
+  uint32_t w_deck, w_shuf;     // their first W slots (NO_SLOT: take the deck from its P slots)
 };
 template <class C>
 MP_HD void fs_statement_and_x(const FsStatementArgs& a, uint32_t b, uint32_t seed[8]) {
@@ -285,8 +320,14 @@ MP_HD void fs_statement_and_x(const FsStatementArgs& a, uint32_t b, uint32_t see
   fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.gen() * Geo<C>::PW));
   for (uint32_t j = 0; j < a.n; ++j) fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.ck(j) * Geo<C>::PW));
   fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.H() * Geo<C>::PW));
-  for (uint32_t i = 0; i < 2 * a.N; ++i) fs_put_point<C>(w, ld_aff<C>(a.P + p_off<C>(a.p_deck + i, a.f.Bpad, b)));
-  for (uint32_t i = 0; i < 2 * a.N; ++i) fs_put_point<C>(w, ld_aff<C>(a.P + p_off<C>(a.p_shuf + i, a.f.Bpad, b)));
+  if (a.W && a.w_deck != NO_SLOT)
+    for (uint32_t i = 0; i < 2 * a.N; ++i) fs_put_wire_point<C>(w, a.W, a.w_deck + i, a.f.Bpad, b);
+  else
+    for (uint32_t i = 0; i < 2 * a.N; ++i) fs_put_point<C>(w, ld_aff<C>(a.P + p_off<C>(a.p_deck + i, a.f.Bpad, b)));
+  if (a.W && a.w_shuf != NO_SLOT)
+    for (uint32_t i = 0; i < 2 * a.N; ++i) fs_put_wire_point<C>(w, a.W, a.w_shuf + i, a.f.Bpad, b);
+  else
+    for (uint32_t i = 0; i < 2 * a.N; ++i) fs_put_point<C>(w, ld_aff<C>(a.P + p_off<C>(a.p_shuf + i, a.f.Bpad, b)));
   stage_word(w, a.m); stage_word(w, 0); stage_word(w, a.n); stage_word(w, 0);   // u64 m, u64 n
   fs_finish_absorb(w, seed);
   fs_absorb_points<C>(a.f, a.P, b, seed, a.p_cA, a.m);
