@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Recompute the roofline figures of a bench line from the files under profiles/ alone.
 
-  python tools/roofline_report.py r02D_default
+  python tools/roofline_report.py r02E_default
 
 reads profiles/<TAG>_bench.json (the JSON line of `python bench.py <args>`), profiles/<TAG>_kernel_stats.csv (rocprofv3
 --kernel-trace of the same command) and profiles/<TAG>_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ passes) and
