@@ -183,6 +183,10 @@ int mp_set_merged_verify(mp_table* t, int on);
  * smaller ones on the Straus kernel with per-proof window tables; 0 = never.  Results are identical; the split is a property of
  * the table's static plans, which this call rebuilds. */
 int mp_set_bucket_min(mp_table* t, size_t terms);
+/* Chain verification (mp_verify_shuffle_chain*): at most `links` links share one chain equation; longer chains are verified as
+ * consecutive sub-chains.  0 (default) = as many as fit the 32 767 points of one equation (293 links of a 52-card deck).  A smaller
+ * value bounds the LDS a chain equation needs and the work that is repeated link by link when a chain fails.  Verdicts are the same. */
+int mp_set_chain_max_links(mp_table* t, uint32_t links);
 /* How the prover evaluates the multi-exponentiation diagonals E_k (a polynomial product of the scalar rows with the ciphertext
  * rows) for 3 <= m <= 16.  on (default): Toom-Cook with the 2m points 0, inf, +-1 .. +-(m-1) -- 2m row products; off: recursive
  * Karatsuba (13 products at m = 4, 35 at m = 8; what m > 16 always uses).  m = 2 always uses its 4-point Toom-Cook form.  The

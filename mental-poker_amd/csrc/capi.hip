@@ -204,6 +204,11 @@ int mp_set_bucket_min(mp_table* t, size_t terms) {
   return MP_OK;
   MP_CATCH
 }
+int mp_set_chain_max_links(mp_table* t, uint32_t links) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_chain_max_links: null table");
+  t->chain_max_links = links;
+  return MP_OK;
+}
 int mp_set_toom_cook(mp_table* t, int on) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_toom_cook: null table");
   MP_TRY
@@ -331,9 +336,17 @@ int mp_verify_shuffle_chain_dev(mp_table* t, size_t tables, uint32_t links, cons
   // one chain equation holds at most 32 767 distinct points ((L + 1) 2N decks + L (11m + 8) proof elements + key): longer chains are
   // verified as consecutive sub-chains (the decks array is link-major, so a sub-chain is a contiguous slice)
   const size_t per_link = (size_t)2 * t->N + 11 * t->m + 8, fixed_part = (size_t)2 * t->N + 1;
-  uint32_t lmax = (uint32_t)std::max<size_t>(1, (32767 - fixed_part) / per_link);
-  if (const char* e = getenv("MP_CHAIN_MAX_LINKS")) lmax = std::max(1u, std::min(lmax, (uint32_t)atoi(e)));     // test hook
   const size_t pb = t->point_bytes, deck_bytes = (size_t)2 * t->N * pb, psz = proof_size_bytes(t->m, t->n, (uint32_t)pb);
+  if (fixed_part + per_link > 32767) {
+    // not even one link fits a chain equation (decks of ~8 000 cards and more): there is nothing to share, verify link by link
+    for (uint32_t j = 0; j < links; ++j)
+      t->verify_dev(tables, (const uint8_t*)d_decks + (size_t)j * tables * deck_bytes, (const uint8_t*)d_decks + (size_t)(j + 1) * tables * deck_bytes,
+                    (const uint8_t*)d_proofs + (size_t)j * tables * psz, (int32_t*)d_status + (size_t)j * tables,
+                    d_keys ? (const uint8_t*)d_keys + (size_t)j * tables * pb : nullptr, nullptr, nullptr);
+    return MP_OK;
+  }
+  uint32_t lmax = (uint32_t)((32767 - fixed_part) / per_link);
+  if (t->chain_max_links) lmax = std::max(1u, std::min(lmax, t->chain_max_links));
   for (uint32_t j0 = 0; j0 < links; j0 += lmax) {
     const uint32_t lc = std::min(lmax, links - j0);
     t->verify_chain_dev(tables, lc, (const uint8_t*)d_decks + (size_t)j0 * tables * deck_bytes, (const uint8_t*)d_proofs + (size_t)j0 * tables * psz,
@@ -653,7 +666,7 @@ int mp_deck_deserialize(int curve_id, const uint8_t* data, size_t len, size_t ma
   if (!curve_ok(curve_id) || !data || !out_cards) return fail(MP_ERR_BAD_ARGUMENT, "mp_deck_deserialize: bad argument");
   if (len < 8) return fail(MP_ERR_BAD_ENCODING, "deck: not enough data");
   const uint64_t k = get_u64(data);
-  if (k > max_cards) return fail(MP_ERR_BAD_ARGUMENT, "deck: more cards than the output buffer holds");
+  if (k > max_cards || k > ((uint64_t)1 << 40)) return fail(MP_ERR_BAD_ARGUMENT, "deck: more cards than the output buffer holds");
   if (len != mp_serialized_deck_size(curve_id, (size_t)k)) return fail(MP_ERR_BAD_ENCODING, "deck: length does not match the card count");
   *out_cards = (size_t)k;
   return mp_points_deserialize(curve_id, 2 * (size_t)k, data + 8, out_wire_deck);
@@ -675,7 +688,7 @@ int mp_params_deserialize(int curve_id, const uint8_t* data, size_t len, size_t 
   if (!curve_ok(curve_id) || !data || !m || !n || !out_raw_params) return fail(MP_ERR_BAD_ARGUMENT, "mp_params_deserialize: bad argument");
   if (len < 16) return fail(MP_ERR_BAD_ENCODING, "parameters: not enough data");
   const uint64_t mm = get_u64(data), nn = get_u64(data + 8);
-  if (nn > max_n || mm > 0xFFFFFFFFull) return fail(MP_ERR_BAD_ARGUMENT, "parameters: n exceeds the output buffer");
+  if (nn > max_n || nn > 0x00FFFFFFull || mm > 0xFFFFFFFFull) return fail(MP_ERR_BAD_ARGUMENT, "parameters: n exceeds the output buffer");
   if (len != mp_serialized_params_size(curve_id, (uint32_t)nn)) return fail(MP_ERR_BAD_ENCODING, "parameters: length does not match n");
   const size_t pb = mp_point_size(curve_id), cb = mp_serialized_point_size(curve_id);
   if (get_u64(data + 16 + cb) != nn) return fail(MP_ERR_BAD_ENCODING, "parameters: commit key length != n");

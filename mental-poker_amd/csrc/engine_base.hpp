@@ -148,6 +148,7 @@ struct mp_table {
   uint32_t m = 0, n = 0, N = 0;
   uint32_t point_bytes = 64;   // wire size of a point on this table's curve (Geo<C>::PB)
   bool keyless = false;        // created from the parameters alone (mp_table_create_params): keyed entry points only
+  uint32_t chain_max_links = 0;   // links per chain equation (0 = as many as fit 32 767 points; mp_set_chain_max_links)
   virtual ~mp_table() {}
   virtual void reserve(size_t B) = 0;
   virtual void set_latency_batch(size_t B) = 0;

@@ -911,7 +911,7 @@ struct Table : mp_table {
     MP_RUN(k_combine, C, T, ph.n_c, cb);
     if (!vflag.n) vflag.alloc(1, s);
     rt::dzero(vflag.p, 4, s);
-    ChainVerdictArgs va{w.J.p, w.direct.p, w.status.p, vflag.p, w.Bpad, T, L, 0u};
+    ChainVerdictArgs va{w.J.p, w.direct.p, w.status.p, vflag.p, w.Bpad, T, L, 0u, w.P.p, keyed ? l.pk : NO_SLOT};
     MP_RUN(k_chain_verdict, C, T, 1, va);
     uint32_t flag = 0;
     rt::d2h(&flag, vflag.p, 4, s);

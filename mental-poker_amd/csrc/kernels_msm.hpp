@@ -29,6 +29,11 @@ struct Geo {
   // there only made the compiler spill and warn
   static constexpr int OCC4 = C::FqP::NW > 8 ? 2 : 4;
   static constexpr int OCC3 = C::FqP::NW > 8 ? 2 : 3;
+#ifdef MP_OCC_VAR      // experiment hook (tools/ab_build.py): waves per SIMD k_var_msm is compiled for
+  static constexpr int OCC_VAR = MP_OCC_VAR;
+#else
+  static constexpr int OCC_VAR = OCC4;
+#endif
   // k_table: with the division-step inversion inlined the 29-bit fields need 144 registers; capped at 128 the compiler spills 15
   // of them and the fourth wave still wins (-1.7 % in an A/B); the 8 x 32 form (bn254) would spill 336 bytes there
   static constexpr int OCC_TABLE = C::FqP::NW > 8 ? 2 : (C::FqP::L29 ? 4 : 3);
@@ -465,7 +470,7 @@ MP_HD void body_var_msm(const VarArgs& a, uint32_t b, uint32_t y) {
   }
   st_jac<C>(a.J + j_off<C>(job.out, a.Bpad, b), xyzz_to_jac<C>(acc));
 }
-MP_KERNEL_OCC(k_var_msm, VarArgs, body_var_msm, Geo<C>::OCC4)
+MP_KERNEL_OCC(k_var_msm, VarArgs, body_var_msm, Geo<C>::OCC_VAR)
 
 // ---- combine partial sums ---------------------------------------------------------------------------
 struct CombineArgs {

@@ -951,11 +951,27 @@ struct ChainVerdictArgs {
   int32_t* status;         // [L T] (lane order)
   uint32_t* flag;
   uint32_t Bpad, T, L, j_final;
+  // keyed chains: the chain equation carries ONE key term per table (link 0's key with the summed key scalars of all links), which
+  // is only the sum of the per-link equations if every link of the table was given the same key.  A table whose links name
+  // different keys takes the per-link path, where every link is checked against its own key.
+  const uint32_t* P;
+  uint32_t p_pk;           // NO_SLOT: not keyed
 };
 template <class C>
 MP_HD void body_chain_verdict(const ChainVerdictArgs& a, uint32_t t, uint32_t y) {
   bool bad = !fe_is_zero(ld_fe<typename C::FqP>(a.J + j_off<C>(a.j_final, a.Bpad, t) + 2 * Geo<C>::FW));
   for (uint32_t j = 0; j < a.L; ++j) bad = bad || a.status[(size_t)j * a.T + t] != 0 || a.direct[(size_t)j * a.T + t] != 0;
+  if (a.p_pk != NO_SLOT) {
+    uint32_t k0[Geo<C>::PW], kj[Geo<C>::PW];
+    ld_words<Geo<C>::PW>(a.P + p_off<C>(a.p_pk, a.Bpad, t), k0);
+    for (uint32_t j = 1; j < a.L; ++j) {
+      ld_words<Geo<C>::PW>(a.P + p_off<C>(a.p_pk, a.Bpad, j * a.T + t), kj);
+      uint32_t d = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < Geo<C>::PW; ++i) d |= k0[i] ^ kj[i];
+      bad = bad || d != 0;
+    }
+  }
   if (bad) a.flag[0] = 1u;
 }
 MP_KERNEL(k_chain_verdict, ChainVerdictArgs, body_chain_verdict)

@@ -1,0 +1,448 @@
+// Roof microbenchmark (round 3): which ceiling is the integer group arithmetic of the shuffle engine under on gfx950?
+//
+// Every variant is a SUSTAINED kernel (calibrated to >= ~300 ms) on a grid that fills the chip at a stated number of waves per
+// SIMD, so the numbers are taken at the clock the chip settles to under that load, not at the 2.4 GHz it starts a 5 ms
+// kernel with.  Per variant the program reports
+//   * instructions per second per class and wave-cycles per instruction: cycles = s_memtime ticks (shader clock, MI355X_MICROARCH.md)
+//     taken inside the kernel by one lane per wave;
+//   * the effective shader clock = s_memtime ticks / s_memrealtime ticks (100 MHz constant) over the kernel, per wave, averaged;
+//   * power / sclk telemetry sampled from the amdgpu hwmon sysfs files every 20 ms by a host thread while the kernel runs
+//     (average over the kernel's second half; "n/a" if the container does not expose them).
+//
+// Variants:
+//   mix(M, A)      M v_mad_u64_u32 and A cheap VALU (v_add_u32 / v_and_b32 / v_xor_b32) per group, independent registers, inline
+//                  asm so the compiler cannot reshape the stream:  pure mads, 1:1, 1:2, 1:3, pure cheap
+//   single ops     v_mul_lo_u32, v_mul_hi_u32, v_mad_i64_i32, v_mad_u32_u24, v_lshl_add_u64, v_ashrrev_i64, v_fma_f64, v_addc chain
+//   engine streams the engine's own fe_mul / fe_sqr / fe_mulsub / fe_sub / xyzz_madd_ip / xyzz_dbl_ip (field.hpp, curve.hpp) on the STARK
+//                  base field, and the 8 x 32 product on bn254's
+// each at 1, 2, 4 and (where registers allow) 8 waves per SIMD.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-sched-strategy=max-ilp -I mental-poker_amd/csrc tools/microbench/roof.hip -o tools/microbench/roof
+// Run:   tools/microbench/roof [target_ms]        (prints a table and one JSON line per variant)
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <glob.h>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../mental-poker_amd/csrc/curve.hpp"
+using namespace mp;
+
+#define CK(x)                                                                 \
+  do {                                                                        \
+    hipError_t e_ = (x);                                                      \
+    if (e_ != hipSuccess) {                                                   \
+      printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__);   \
+      exit(1);                                                                \
+    }                                                                         \
+  } while (0)
+
+struct Stamp {
+  uint64_t cyc, rt;
+};
+__device__ __forceinline__ void stamp_begin(uint64_t& c0, uint64_t& r0) {
+  c0 = __builtin_readcyclecounter();   // s_memtime
+  r0 = wall_clock64();                 // s_memrealtime, 100 MHz
+}
+__device__ __forceinline__ void stamp_end(Stamp* st, uint64_t c0, uint64_t r0) {
+  const uint64_t c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+  if ((threadIdx.x & 63u) == 0) {
+    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    st[w].cyc = c1 - c0;
+    st[w].rt = r1 - r0;
+  }
+}
+
+// ---- instruction mixes -------------------------------------------------------------------------------------------------------
+// one group = M mads on 8 rotating 64-bit accumulators + A cheap ops on 8 rotating 32-bit registers, interleaved
+#define MAD(k) "v_mad_u64_u32 %" #k ", vcc, %16, %17, %" #k "\n\t"
+#define ADDI(k) "v_add_u32 %" #k ", %" #k ", %18\n\t"
+#define ANDI(k) "v_xor_b32 %" #k ", %" #k ", %18\n\t"
+#define OPS_DECL                                                                                                              \
+  "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), \
+      "+v"(t5), "+v"(t6), "+v"(t7)
+template <int KIND>
+__global__ void __launch_bounds__(256) k_mix(Stamp* st, uint32_t* out, uint32_t iters, uint32_t seed) {
+  uint32_t x = threadIdx.x * 2654435761u + seed, y = (blockIdx.x * 40503u + 12345u) ^ seed, z = seed | 1u;
+  uint64_t a0 = x, a1 = y, a2 = x ^ y, a3 = 7, a4 = 11, a5 = x + 3, a6 = y + 5, a7 = 13;
+  uint32_t t0 = x, t1 = y, t2 = 3, t3 = 4, t4 = 5, t5 = 6, t6 = 7, t7 = 8;
+  uint64_t c0, r0;
+  stamp_begin(c0, r0);
+  for (uint32_t it = 0; it < iters; ++it) {
+    if constexpr (KIND == 0) {   // 16 mads
+      asm volatile(MAD(0) MAD(1) MAD(2) MAD(3) MAD(4) MAD(5) MAD(6) MAD(7) MAD(0) MAD(1) MAD(2) MAD(3) MAD(4) MAD(5) MAD(6) MAD(7)
+                   : OPS_DECL : "v"(x), "v"(y), "v"(z) : "vcc");
+    } else if constexpr (KIND == 1) {   // 8 mads : 8 cheap
+      asm volatile(MAD(0) ADDI(8) MAD(1) ANDI(9) MAD(2) ADDI(10) MAD(3) ANDI(11) MAD(4) ADDI(12) MAD(5) ANDI(13) MAD(6) ADDI(14) MAD(7) ANDI(15)
+                   : OPS_DECL : "v"(x), "v"(y), "v"(z) : "vcc");
+    } else if constexpr (KIND == 2) {   // 8 mads : 16 cheap
+      asm volatile(MAD(0) ADDI(8) ANDI(9) MAD(1) ADDI(10) ANDI(11) MAD(2) ADDI(12) ANDI(13) MAD(3) ADDI(14) ANDI(15) MAD(4) ADDI(8) ANDI(9)
+                       MAD(5) ADDI(10) ANDI(11) MAD(6) ADDI(12) ANDI(13) MAD(7) ADDI(14) ANDI(15)
+                   : OPS_DECL : "v"(x), "v"(y), "v"(z) : "vcc");
+    } else if constexpr (KIND == 3) {   // 8 mads : 24 cheap
+      asm volatile(MAD(0) ADDI(8) ANDI(9) ADDI(10) MAD(1) ANDI(11) ADDI(12) ANDI(13) MAD(2) ADDI(14) ANDI(15) ADDI(8) MAD(3) ANDI(9) ADDI(10)
+                       ANDI(11) MAD(4) ADDI(12) ANDI(13) ADDI(14) MAD(5) ANDI(15) ADDI(8) ANDI(9) MAD(6) ADDI(10) ANDI(11) ADDI(12) MAD(7)
+                           ANDI(13) ADDI(14) ANDI(15)
+                   : OPS_DECL : "v"(x), "v"(y), "v"(z) : "vcc");
+    } else if constexpr (KIND == 4) {   // 16 cheap
+      asm volatile(ADDI(8) ANDI(9) ADDI(10) ANDI(11) ADDI(12) ANDI(13) ADDI(14) ANDI(15) ADDI(8) ANDI(9) ADDI(10) ANDI(11) ADDI(12) ANDI(13)
+                       ADDI(14) ANDI(15)
+                   : OPS_DECL : "v"(x), "v"(y), "v"(z) : "vcc");
+    } else if constexpr (KIND == 5) {   // 12 mads : 4 cheap (3:1)
+      asm volatile(MAD(0) MAD(1) MAD(2) ADDI(8) MAD(3) MAD(4) MAD(5) ANDI(9) MAD(6) MAD(7) MAD(0) ADDI(10) MAD(1) MAD(2) MAD(3) ANDI(11)
+                   : OPS_DECL : "v"(x), "v"(y), "v"(z) : "vcc");
+    }
+  }
+  stamp_end(st, c0, r0);
+  const uint64_t r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32) ^ t0 ^ t1 ^ t2 ^ t3 ^ t4 ^ t5 ^ t6 ^ t7;
+}
+
+// ---- single instruction kinds, 8 independent chains, 16 per iteration -------------------------------------------------------------
+template <int KIND>
+__global__ void __launch_bounds__(256) k_single(Stamp* st, uint32_t* out, uint32_t iters, uint32_t seed) {
+  uint32_t x = threadIdx.x * 2654435761u + seed, y = (blockIdx.x * 40503u + 12345u) ^ seed;
+  uint64_t a[8];
+  double d[8];
+  for (int i = 0; i < 8; ++i) {
+    a[i] = ((uint64_t)x << 20) + y + i;
+    d[i] = 1.0 + 1e-9 * (double)(x + i);
+  }
+  const double dm = 1.0 + 1e-12 * (double)(seed | 1u);
+  uint64_t c0, r0;
+  stamp_begin(c0, r0);
+  for (uint32_t it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      uint64_t& v = a[u & 7];
+      if constexpr (KIND == 0) {   // v_mul_lo_u32
+        uint32_t lo = (uint32_t)v;
+        asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(lo) : "v"(y));
+        v = lo;
+      } else if constexpr (KIND == 1) {   // v_mul_hi_u32
+        uint32_t lo = (uint32_t)v;
+        asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(lo) : "v"(y));
+        v = lo;
+      } else if constexpr (KIND == 2) {   // v_mad_i64_i32
+        asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(v) : "v"(x), "v"(y) : "vcc");
+      } else if constexpr (KIND == 3) {   // v_mad_u32_u24
+        uint32_t lo = (uint32_t)v;
+        asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(lo) : "v"(y), "v"(x));
+        v = lo;
+      } else if constexpr (KIND == 4) {   // v_lshl_add_u64 (64-bit add in one instruction)
+        asm volatile("v_lshl_add_u64 %0, %0, 1, %1" : "+v"(v) : "v"(a[(u + 1) & 7]));
+      } else if constexpr (KIND == 5) {   // v_ashrrev_i64
+        asm volatile("v_ashrrev_i64 %0, 1, %0" : "+v"(v));
+      } else if constexpr (KIND == 6) {   // v_fma_f64
+        asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[u & 7]) : "v"(dm), "v"(d[(u + 1) & 7]));
+      } else if constexpr (KIND == 7) {   // v_mad_u64_u32 + v_addc_co_u32 (the 96-bit column accumulator of the 8x32 product)
+        uint32_t hi = (uint32_t)a[(u + 4) & 7];
+        asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(v), "+v"(hi) : "v"(x), "v"(y) : "vcc");
+        a[(u + 4) & 7] = (a[(u + 4) & 7] & 0xffffffff00000000ull) | hi;
+      } else if constexpr (KIND == 8) {   // v_mad_u64_u32 with an SGPR/constant multiplier (the reduction's m * p_j)
+        asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(v) : "v"(x), "s"(seed) : "vcc");
+      }
+    }
+  }
+  stamp_end(st, c0, r0);
+  uint64_t r = 0;
+  for (int i = 0; i < 8; ++i) r ^= a[i] ^ (uint64_t)d[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32);
+}
+
+// ---- instruction classes, asm only: 16 instructions per iteration on 8 rotating destination registers ------------------------
+// T32(op): "op d, d, s"  (32-bit, two sources)      T32C(op): "op d, d, s, s2" (32-bit, three sources)
+// T64S(op): "op d64, imm, d64" (64-bit shift)
+#define R8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+#define CLS_DECL "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5), "+v"(t6), "+v"(t7)
+#define CLS64_DECL "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+#define CLS_KERNEL(NAME, BODY, DECL)                                                                             \
+  __global__ void __launch_bounds__(256) NAME(Stamp* st, uint32_t* out, uint32_t iters, uint32_t seed) {        \
+    uint32_t x = threadIdx.x * 2654435761u + seed, y = (blockIdx.x * 40503u + 12345u) ^ seed;                   \
+    uint32_t t0 = x, t1 = y, t2 = 3, t3 = 4, t4 = 5, t5 = 6, t6 = 7, t7 = 8;                                     \
+    uint64_t a0 = x, a1 = y, a2 = x ^ y, a3 = 7, a4 = 11, a5 = x + 3, a6 = y + 5, a7 = 13;                       \
+    uint64_t c0, r0;                                                                                             \
+    stamp_begin(c0, r0);                                                                                         \
+    for (uint32_t it = 0; it < iters; ++it) asm volatile(BODY : DECL : "v"(x), "v"(y) : "vcc");                  \
+    stamp_end(st, c0, r0);                                                                                       \
+    const uint64_t r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                                                    \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32) ^ t0 ^ t1 ^ t2 ^ t3 ^ t4 ^ t5 ^ t6 ^ t7; \
+  }
+#define I2(op) "" op " %0, %0, %8\n\t" op " %1, %1, %9\n\t" op " %2, %2, %8\n\t" op " %3, %3, %9\n\t" op " %4, %4, %8\n\t" op " %5, %5, %9\n\t" op " %6, %6, %8\n\t" op " %7, %7, %9\n\t"
+#define I3(op) "" op " %0, %0, %8, %9\n\t" op " %1, %1, %9, %8\n\t" op " %2, %2, %8, %9\n\t" op " %3, %3, %9, %8\n\t" op " %4, %4, %8, %9\n\t" op " %5, %5, %9, %8\n\t" op " %6, %6, %8, %9\n\t" op " %7, %7, %9, %8\n\t"
+#define I3I(op, imm) "" op " %0, %0, %8, " imm "\n\t" op " %1, %1, %9, " imm "\n\t" op " %2, %2, %8, " imm "\n\t" op " %3, %3, %9, " imm "\n\t" op " %4, %4, %8, " imm "\n\t" op " %5, %5, %9, " imm "\n\t" op " %6, %6, %8, " imm "\n\t" op " %7, %7, %9, " imm "\n\t"
+#define S64(op) "" op " %0, 3, %0\n\t" op " %1, 5, %1\n\t" op " %2, 3, %2\n\t" op " %3, 5, %3\n\t" op " %4, 3, %4\n\t" op " %5, 5, %5\n\t" op " %6, 3, %6\n\t" op " %7, 5, %7\n\t"
+#define S32(op) "" op " %0, 3, %0\n\t" op " %1, 5, %1\n\t" op " %2, 3, %2\n\t" op " %3, 5, %3\n\t" op " %4, 3, %4\n\t" op " %5, 5, %5\n\t" op " %6, 3, %6\n\t" op " %7, 5, %7\n\t"
+CLS_KERNEL(c_add_u32, I2("v_add_u32") I2("v_add_u32"), CLS_DECL)
+CLS_KERNEL(c_sub_u32, I2("v_sub_u32") I2("v_sub_u32"), CLS_DECL)
+CLS_KERNEL(c_and_b32, I2("v_and_b32") I2("v_and_b32"), CLS_DECL)
+CLS_KERNEL(c_max_i32, I2("v_max_i32") I2("v_max_i32"), CLS_DECL)
+CLS_KERNEL(c_mul_u32_u24, I2("v_mul_u32_u24") I2("v_mul_u32_u24"), CLS_DECL)
+CLS_KERNEL(c_mul_i32_i24, I2("v_mul_i32_i24") I2("v_mul_i32_i24"), CLS_DECL)
+CLS_KERNEL(c_mul_lo_u32, I2("v_mul_lo_u32") I2("v_mul_lo_u32"), CLS_DECL)
+CLS_KERNEL(c_mul_hi_u32, I2("v_mul_hi_u32") I2("v_mul_hi_u32"), CLS_DECL)
+CLS_KERNEL(c_mad_u32_u24, I3("v_mad_u32_u24") I3("v_mad_u32_u24"), CLS_DECL)
+CLS_KERNEL(c_add3_u32, I3("v_add3_u32") I3("v_add3_u32"), CLS_DECL)
+CLS_KERNEL(c_or3_b32, I3("v_or3_b32") I3("v_or3_b32"), CLS_DECL)
+CLS_KERNEL(c_and_or_b32, I3("v_and_or_b32") I3("v_and_or_b32"), CLS_DECL)
+CLS_KERNEL(c_lshl_add_u32, I3I("v_lshl_add_u32", "3") I3I("v_lshl_add_u32", "3"), CLS_DECL)
+CLS_KERNEL(c_alignbit_b32, I3I("v_alignbit_b32", "29") I3I("v_alignbit_b32", "29"), CLS_DECL)
+CLS_KERNEL(c_bfe_u32, I3I("v_bfe_u32", "5") I3I("v_bfe_u32", "5"), CLS_DECL)
+CLS_KERNEL(c_ashrrev_i32, S32("v_ashrrev_i32") S32("v_ashrrev_i32"), CLS_DECL)
+CLS_KERNEL(c_lshlrev_b32, S32("v_lshlrev_b32") S32("v_lshlrev_b32"), CLS_DECL)
+CLS_KERNEL(c_ashrrev_i64, S64("v_ashrrev_i64") S64("v_ashrrev_i64"), CLS64_DECL)
+CLS_KERNEL(c_lshlrev_b64, S64("v_lshlrev_b64") S64("v_lshlrev_b64"), CLS64_DECL)
+CLS_KERNEL(c_lshrrev_b64, S64("v_lshrrev_b64") S64("v_lshrrev_b64"), CLS64_DECL)
+#define M64(op) "" op " %0, vcc, %8, %9, %0\n\t" op " %1, vcc, %9, %8, %1\n\t" op " %2, vcc, %8, %9, %2\n\t" op " %3, vcc, %9, %8, %3\n\t" op " %4, vcc, %8, %9, %4\n\t" op " %5, vcc, %9, %8, %5\n\t" op " %6, vcc, %8, %9, %6\n\t" op " %7, vcc, %9, %8, %7\n\t"
+CLS_KERNEL(c_mad_u64_u32, M64("v_mad_u64_u32") M64("v_mad_u64_u32"), CLS64_DECL)
+CLS_KERNEL(c_mad_i64_i32, M64("v_mad_i64_i32") M64("v_mad_i64_i32"), CLS64_DECL)
+#define LA64 "v_lshl_add_u64 %0, %0, 1, %1\n\tv_lshl_add_u64 %1, %1, 1, %2\n\tv_lshl_add_u64 %2, %2, 1, %3\n\tv_lshl_add_u64 %3, %3, 1, %4\n\tv_lshl_add_u64 %4, %4, 1, %5\n\tv_lshl_add_u64 %5, %5, 1, %6\n\tv_lshl_add_u64 %6, %6, 1, %7\n\tv_lshl_add_u64 %7, %7, 1, %0\n\t"
+CLS_KERNEL(c_lshl_add_u64, LA64 LA64, CLS64_DECL)
+#define CND "v_cmp_gt_u32 vcc, %0, %8\n\tv_cndmask_b32 %1, %1, %9, vcc\n\tv_cmp_gt_u32 vcc, %2, %8\n\tv_cndmask_b32 %3, %3, %9, vcc\n\tv_cmp_gt_u32 vcc, %4, %8\n\tv_cndmask_b32 %5, %5, %9, vcc\n\tv_cmp_gt_u32 vcc, %6, %8\n\tv_cndmask_b32 %7, %7, %9, vcc\n\t"
+CLS_KERNEL(c_cmp_cndmask, CND CND, CLS_DECL)
+#define ADC "v_add_co_u32 %0, vcc, %0, %8\n\tv_addc_co_u32 %1, vcc, %1, %9, vcc\n\tv_add_co_u32 %2, vcc, %2, %8\n\tv_addc_co_u32 %3, vcc, %3, %9, vcc\n\tv_add_co_u32 %4, vcc, %4, %8\n\tv_addc_co_u32 %5, vcc, %5, %9, vcc\n\tv_add_co_u32 %6, vcc, %6, %8\n\tv_addc_co_u32 %7, vcc, %7, %9, vcc\n\t"
+CLS_KERNEL(c_add_co_addc, ADC ADC, CLS_DECL)
+
+// ---- the engine's own arithmetic ---------------------------------------------------------------------------------------------------
+typedef Stark StarkC;
+template <class F>
+__device__ __forceinline__ Fe<F> mk(uint32_t s) {
+  Fe<F> a;
+  constexpr int N = F::L29 ? 9 : F::NW;
+  for (int i = 0; i < N; ++i) a.v[i] = (s * (2654435761u + 2 * i) + i * 40503u) & (F::L29 ? 0x0fffffffu : 0xffffffffu);
+  if (!F::L29) a.v[N - 1] &= 0x03ffffffu;   // < p for every 8x32 field used here
+  return a;
+}
+template <class F, int KIND, int OCC>
+__global__ void __launch_bounds__(256, OCC) k_field(Stamp* st, uint32_t* out, uint32_t iters, uint32_t seed) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  Fe<F> a = mk<F>(tid + seed), b = mk<F>(tid * 3 + seed + 1), c = mk<F>(tid * 5 + seed + 2), d = mk<F>(tid * 7 + seed + 3);
+  uint64_t c0, r0;
+  stamp_begin(c0, r0);
+  for (uint32_t it = 0; it < iters; ++it) {
+    if constexpr (KIND == 0) {          // 4 dependent products on two interleaved chains
+      a = fe_mul<F>(a, b);
+      c = fe_mul<F>(c, d);
+      b = fe_mul<F>(b, a);
+      d = fe_mul<F>(d, c);
+    } else if constexpr (KIND == 1) {   // 4 squares
+      a = fe_sqr<F>(a);
+      c = fe_sqr<F>(c);
+      b = fe_sqr<F>(b);
+      d = fe_sqr<F>(d);
+    } else if constexpr (KIND == 2) {   // 2 fused product pairs
+      a = fe_mulsub<F>(a, b, c, d);
+      c = fe_mulsub<F>(c, d, a, b);
+    } else if constexpr (KIND == 3) {   // 8 subtractions
+      a = fe_sub<F>(a, b); b = fe_sub<F>(b, c); c = fe_sub<F>(c, d); d = fe_sub<F>(d, a);
+      a = fe_sub<F>(a, c); b = fe_sub<F>(b, d); c = fe_sub<F>(c, a); d = fe_sub<F>(d, b);
+    }
+  }
+  stamp_end(st, c0, r0);
+  constexpr int N = F::L29 ? 9 : F::NW;
+  uint32_t r = 0;
+  for (int i = 0; i < N; ++i) r ^= a.v[i] ^ b.v[i] ^ c.v[i] ^ d.v[i];
+  out[tid] = r;
+}
+template <int KIND, int OCC>
+__global__ void __launch_bounds__(256, OCC) k_group(Stamp* st, uint32_t* out, uint32_t iters, uint32_t seed) {
+  typedef StarkFq F;
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  Xyzz<StarkC> p;
+  p.X = mk<F>(tid + seed); p.Y = mk<F>(tid * 3 + seed); p.ZZ = mk<F>(tid * 5 + seed); p.ZZZ = mk<F>(tid * 7 + seed);
+  uint64_t c0, r0;
+  stamp_begin(c0, r0);
+  for (uint32_t it = 0; it < iters; ++it) {
+    if constexpr (KIND == 0) {
+      // the operand comes from memory in the packed 8-word format, as a table entry does in k_var_msm (L2-resident here: 2 MB)
+      const uint32_t* src = out + (size_t)((tid + it * 4099u) & 0x7FFFu) * 16u;
+      uint32_t w[16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint4 t = reinterpret_cast<const uint4*>(src)[i];
+        w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w;
+      }
+      Aff<StarkC> q;
+      q.x = fe_unpack<F>(w);
+      q.y = fe_unpack<F>(w + 8);
+      if (it & 1u) q = aff_neg<StarkC>(q);
+      xyzz_madd_ip<StarkC>(p, q);        // arithmetic on arbitrary field elements: the formulas do not care that q is off the curve
+    } else {
+      xyzz_dbl_ip<StarkC>(p);
+    }
+  }
+  stamp_end(st, c0, r0);
+  uint32_t r = 0;
+  for (int i = 0; i < 9; ++i) r ^= p.X.v[i] ^ p.Y.v[i] ^ p.ZZ.v[i] ^ p.ZZZ.v[i];
+  if (r == 0x12345678u) out[tid] = r;     // (keeps the result alive without disturbing the operand table)
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------------------------
+struct Telemetry {
+  std::string power_path, sclk_path;
+  std::atomic<bool> run{false};
+  std::vector<double> power_w, sclk_mhz, t_ms;
+  std::thread th;
+  static std::string first_glob(const char* pat) {
+    glob_t g;
+    std::string r;
+    if (glob(pat, 0, nullptr, &g) == 0 && g.gl_pathc > 0) r = g.gl_pathv[0];
+    globfree(&g);
+    return r;
+  }
+  static double read_num(const std::string& p) {
+    FILE* f = fopen(p.c_str(), "r");
+    if (!f) return -1;
+    double v = -1;
+    if (fscanf(f, "%lf", &v) != 1) v = -1;
+    fclose(f);
+    return v;
+  }
+  void init() {
+    char bus[64] = {0};
+    std::string base = "/sys/class/drm/card*/device";
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, 0) == hipSuccess) {        // the hwmon of THIS device (a node exposes all 8 cards in sysfs)
+      for (char* c = bus; *c; ++c) *c = (char)tolower(*c);
+      base = std::string("/sys/bus/pci/devices/") + bus;
+    }
+    power_path = first_glob((base + "/hwmon/hwmon*/power1_average").c_str());
+    if (power_path.empty()) power_path = first_glob((base + "/hwmon/hwmon*/power1_input").c_str());
+    sclk_path = first_glob((base + "/hwmon/hwmon*/freq1_input").c_str());
+    printf("telemetry: power=%s sclk=%s\n", power_path.empty() ? "n/a" : power_path.c_str(), sclk_path.empty() ? "n/a" : sclk_path.c_str());
+  }
+  void start() {
+    power_w.clear(); sclk_mhz.clear(); t_ms.clear();
+    run = true;
+    th = std::thread([this] {
+      const auto t0 = std::chrono::steady_clock::now();
+      while (run) {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        t_ms.push_back(ms);
+        power_w.push_back(power_path.empty() ? -1 : read_num(power_path) * 1e-6);
+        sclk_mhz.push_back(sclk_path.empty() ? -1 : read_num(sclk_path) * 1e-6);
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+      }
+    });
+  }
+  void stop(double& pw, double& clk) {   // averages over the second half of the samples
+    run = false;
+    th.join();
+    pw = clk = -1;
+    const size_t n = power_w.size();
+    if (n < 4) return;
+    double sp = 0, sc = 0;
+    size_t k = 0;
+    for (size_t i = n / 2; i < n; ++i, ++k) {
+      sp += power_w[i];
+      sc += sclk_mhz[i];
+    }
+    pw = sp / k;
+    clk = sc / k;
+  }
+};
+
+struct Variant {
+  const char* name;
+  void (*kern)(Stamp*, uint32_t*, uint32_t, uint32_t);
+  int occ;              // waves per SIMD the grid is sized for
+  double mads, others;  // per loop iteration per lane: multiplier instructions, other VALU (static counts for the asm mixes; 0 = see asm)
+  const char* unit;
+  double units;         // units per loop iteration per lane (instructions or field operations)
+};
+
+static Telemetry tel;
+static int run_variant(const Variant& v, double target_ms, Stamp* dst, uint32_t* dout, int cus) {
+  const int waves = cus * 4 * v.occ, blocks = waves / 4;
+  auto launch = [&](uint32_t iters, float& ms) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(v.kern, dim3(blocks), dim3(256), 0, 0, dst, dout, iters, 12345u);
+    CK(hipGetLastError());
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+  };
+  float ms = 0;
+  uint32_t iters = 2000;
+  launch(iters, ms);                     // calibration (also warms the clocks up)
+  iters = (uint32_t)(iters * target_ms / (ms > 0.01f ? ms : 0.01f));
+  if (iters < 100) iters = 100;
+  tel.start();
+  launch(iters, ms);
+  double pw, clk;
+  tel.stop(pw, clk);
+  std::vector<Stamp> st(waves);
+  CK(hipMemcpy(st.data(), dst, sizeof(Stamp) * waves, hipMemcpyDeviceToHost));
+  double cyc = 0, rt = 0;
+  for (auto& s : st) { cyc += (double)s.cyc; rt += (double)s.rt; }
+  cyc /= waves; rt /= waves;
+  const double eff_mhz = rt > 0 ? cyc / rt * 100.0 : 0;          // realtime counter: 100 MHz
+  const double lanes = (double)waves * 64;
+  const double units_s = lanes * iters * v.units / (ms * 1e-3);
+  const double cyc_per_unit_wave = cyc / ((double)iters * v.units);   // wave-cycles per unit with `occ` waves sharing the SIMD
+  const double simd_cyc_per_unit = cyc_per_unit_wave / v.occ;          // SIMD cycles per wave-level unit
+  printf("%-34s occ=%d %8.1f ms  %10.2f G%s/s  %7.2f SIMD-cyc/%s  clk(s_memtime)=%6.0f MHz  sclk=%6.0f MHz  power=%6.0f W\n", v.name, v.occ, ms,
+         units_s * 1e-9, v.unit, simd_cyc_per_unit, v.unit, eff_mhz, clk, pw);
+  printf("JSON {\"variant\": \"%s\", \"occ\": %d, \"ms\": %.2f, \"iters\": %u, \"unit\": \"%s\", \"units_per_iter\": %.0f, \"mads_per_iter\": %.0f, "
+         "\"others_per_iter\": %.0f, \"G_units_per_s\": %.3f, \"simd_cycles_per_unit\": %.3f, \"clock_mhz_memtime\": %.1f, \"sclk_mhz_sysfs\": %.1f, "
+         "\"power_w\": %.1f}\n",
+         v.name, v.occ, ms, iters, v.unit, v.units, v.mads, v.others, units_s * 1e-9, simd_cyc_per_unit, eff_mhz, clk, pw);
+  fflush(stdout);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  const double target_ms = argc > 1 ? atof(argv[1]) : 300.0;
+  hipDeviceProp_t p;
+  CK(hipGetDeviceProperties(&p, 0));
+  const int cus = p.multiProcessorCount;
+  printf("device: %s CUs=%d clockRate=%d kHz  target %.0f ms per variant\n", p.name, cus, p.clockRate, target_ms);
+  tel.init();
+  Stamp* dst;
+  uint32_t* dout;
+  CK(hipMalloc(&dst, sizeof(Stamp) * cus * 4 * 8));
+  CK(hipMalloc(&dout, (size_t)cus * 4 * 8 * 64 * 4));
+  std::vector<Variant> vs;
+  const bool quick = argc > 2 && !strcmp(argv[2], "classes");
+  // warm-up: the first sustained kernel after an idle period runs while the clocks ramp; its numbers are discarded
+  { Variant w{"(warm-up, discard)", k_mix<4>, 8, 0, 16, "inst", 16}; run_variant(w, 500.0, dst, dout, cus); }
+  for (int occ : {2, 4, 8}) {
+    if (quick && occ != 8) continue;
+    vs.push_back({"mad_only (16 v_mad_u64_u32)", k_mix<0>, occ, 16, 0, "inst", 16});
+    vs.push_back({"mad:cheap 3:1 (12+4)", k_mix<5>, occ, 12, 4, "inst", 16});
+    vs.push_back({"mad:cheap 1:1 (8+8)", k_mix<1>, occ, 8, 8, "inst", 16});
+    vs.push_back({"mad:cheap 1:2 (8+16)", k_mix<2>, occ, 8, 16, "inst", 24});
+    vs.push_back({"mad:cheap 1:3 (8+24)", k_mix<3>, occ, 8, 24, "inst", 32});
+    vs.push_back({"cheap_only (16 add/xor)", k_mix<4>, occ, 0, 16, "inst", 16});
+  }
+#define CLS(NAME) vs.push_back({#NAME, NAME, 8, 0, 16, "inst", 16});
+  CLS(c_add_u32) CLS(c_sub_u32) CLS(c_and_b32) CLS(c_max_i32) CLS(c_add3_u32) CLS(c_or3_b32) CLS(c_and_or_b32) CLS(c_lshl_add_u32)
+  CLS(c_alignbit_b32) CLS(c_bfe_u32) CLS(c_ashrrev_i32) CLS(c_lshlrev_b32) CLS(c_cmp_cndmask) CLS(c_add_co_addc)
+  CLS(c_mul_u32_u24) CLS(c_mul_i32_i24) CLS(c_mad_u32_u24) CLS(c_mul_lo_u32) CLS(c_mul_hi_u32) CLS(c_mad_u64_u32) CLS(c_mad_i64_i32)
+  CLS(c_ashrrev_i64) CLS(c_lshlrev_b64) CLS(c_lshrrev_b64) CLS(c_lshl_add_u64)
+  vs.push_back({"v_fma_f64", k_single<6>, 8, 0, 16, "inst", 16});
+  // engine streams (instruction counts per unit: tools/gen_mad_counts.py reads them from the gfx950 assembly)
+  vs.push_back({"stark fe_mul  (occ 2)", k_field<StarkFq, 0, 2>, 2, 0, 0, "fmul", 4});
+  vs.push_back({"stark fe_mul  (occ 4)", k_field<StarkFq, 0, 4>, 4, 0, 0, "fmul", 4});
+  vs.push_back({"stark fe_mul  (occ 8)", k_field<StarkFq, 0, 8>, 8, 0, 0, "fmul", 4});
+  vs.push_back({"stark fe_sqr  (occ 4)", k_field<StarkFq, 1, 4>, 4, 0, 0, "fsqr", 4});
+  vs.push_back({"stark fe_mulsub (occ 4)", k_field<StarkFq, 2, 4>, 4, 0, 0, "fmulsub", 2});
+  vs.push_back({"stark fe_sub  (occ 4)", k_field<StarkFq, 3, 4>, 4, 0, 0, "fsub", 8});
+  vs.push_back({"secp256k1 fe_mul (occ 4)", k_field<Secp256k1Fq, 0, 4>, 4, 0, 0, "fmul", 4});
+  vs.push_back({"bn254 fe_mul 8x32 (occ 4)", k_field<Bn254Fq, 0, 4>, 4, 0, 0, "fmul", 4});
+  vs.push_back({"bn254 fe_sub 8x32 (occ 4)", k_field<Bn254Fq, 3, 4>, 4, 0, 0, "fsub", 8});
+  vs.push_back({"stark Fr fe_mul 8x32 (occ 4)", k_field<StarkFr, 0, 4>, 4, 0, 0, "fmul", 4});
+  vs.push_back({"stark xyzz_madd (occ 2)", k_group<0, 2>, 2, 0, 0, "madd", 1});
+  vs.push_back({"stark xyzz_madd (occ 3)", k_group<0, 3>, 3, 0, 0, "madd", 1});
+  vs.push_back({"stark xyzz_madd (occ 4)", k_group<0, 4>, 4, 0, 0, "madd", 1});
+  vs.push_back({"stark xyzz_dbl  (occ 4)", k_group<1, 4>, 4, 0, 0, "dbl", 1});
+  for (auto& v : vs) run_variant(v, target_ms, dst, dout, cus);
+  return 0;
+}
