@@ -43,7 +43,13 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "py")
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-INT_MAD_PEAK_G = 18000.0       # v_mad_u64_u32 issue rate measured with tools/microbench/intrate.hip (Gmad/s)
+# VALU issue model of gfx950 (measured: tools/microbench/roof.hip -> profiles/r03_roof.json): 256 CUs x 4 SIMDs; a wave64 instruction
+# occupies its SIMD's VALU issue port for 2 cycles (v_add/sub/and/or/xor/ashr_i32: 32 lanes per clock) or 4 cycles (every multiply,
+# every 64-bit or three-operand integer instruction, shifts, selects: 16 lanes per clock); nothing co-issues.  2.4 GHz = maximum shader
+# clock; under this path's kernels the chip settles near 2.0-2.1 GHz at ~1.3 kW (power telemetry in the same file).
+SIMDS = 256 * 4
+CLK_MAX_GHZ = 2.4
+INT_MAD_PEAK_G = 16 * SIMDS * CLK_MAX_GHZ     # v_mad_u64_u32: 16 lanes per clock per SIMD = 39 322 Gmad/s at 2.4 GHz (measured sustained: 35 300)
 
 
 # ---- distributed helpers (backend-agnostic: RCCL on GPUs, gloo in the CPU tests) -----------------------------
@@ -172,6 +178,7 @@ def load_mad_counts(curve):
     inv = c.get("inv_divsteps_mads", c["inv_sqr"] * c["sqr"] + c["inv_mul"] * c["mul"])
     a1 = 1 if c["a_is_one"] else 0
     return {
+        "issue": c.get("valu_issue"),
         "field": {"mul": M, "sqr": S, "mulsub": MS, "inv": inv},
         "madd": 6 * M + 2 * S + MS,                      # XYZZ += affine   (curve.hpp xyzz_madd_ip, main path)
         "dbl": 4 * M + (3 + a1) * S + MS,                # XYZZ doubling    (xyzz_dbl_ip)
@@ -276,7 +283,11 @@ def main():
     Bs = B // S
     assert Bs * S == B, "--batch must be a multiple of --streams"
     engines = [eng] + [mp.Engine(curve, device=local) for _ in range(S - 1)]
+    t_tab = time.perf_counter()
     tables = [e.table(m, n, params, pk, fb_bits=args.fb_bits) for e in engines]
+    for e in engines:
+        e.sync()
+    table_build_s = time.perf_counter() - t_tab      # fixed-base window tables of the shared parameters: built once per session, outside the timed region
     for t in tables:
         if args.latency_batch is not None:
             t.set_latency_batch(args.latency_batch)
@@ -439,9 +450,11 @@ def main():
         proofs = torch.empty(L, T, proof_bytes, dtype=torch.uint8, device=gpu)
         st_p = torch.empty(L, T, dtype=torch.int32, device=gpu)
         st_v = torch.empty(L, T, dtype=torch.int32, device=gpu)
-        fac = [rand_factors(10 + j) for j in range(2)]      # two sets of witnesses, alternated along the chain
-        prm = [rand_perms(20 + j) for j in range(2)]
-        sds = rand_seeds(30)
+        # every link has its own witness AND its own prover seed: a prover seed must never be reused with a different witness
+        # (include/mpshuffle.h, mp_shuffle_and_remask: two proofs from one seed reveal the permutation and the masking factors)
+        fac = [rand_factors(1000 + j) for j in range(L)]
+        prm = [rand_perms(2000 + j) for j in range(L)]
+        sds = [rand_seeds(3000 + j) for j in range(L)]
         # verification: one chain equation per table over all L links (default), or link by link in batches of G links
         chain_verify = not args.per_link_verify
         G = L if chain_verify else max(1, min(L, 262144 // T))
@@ -459,12 +472,12 @@ def main():
         def step():
             for j in range(L):
                 if kset is not None:
-                    keyless.shuffle_and_remask_batch_keyset_dev(kset[0], T, kset[1].data_ptr(), chain[j].data_ptr(), fac[j & 1].data_ptr(),
-                                                                prm[j & 1].data_ptr(), sds.data_ptr(), chain[j + 1].data_ptr(),
+                    keyless.shuffle_and_remask_batch_keyset_dev(kset[0], T, kset[1].data_ptr(), chain[j].data_ptr(), fac[j].data_ptr(),
+                                                                prm[j].data_ptr(), sds[j].data_ptr(), chain[j + 1].data_ptr(),
                                                                 proofs[j].data_ptr(), st_p[j].data_ptr())
                     continue
-                keyless.shuffle_and_remask_batch_keys_dev(T, keys.data_ptr(), chain[j].data_ptr(), fac[j & 1].data_ptr(),
-                                                          prm[j & 1].data_ptr(), sds.data_ptr(), chain[j + 1].data_ptr(),
+                keyless.shuffle_and_remask_batch_keys_dev(T, keys.data_ptr(), chain[j].data_ptr(), fac[j].data_ptr(),
+                                                          prm[j].data_ptr(), sds[j].data_ptr(), chain[j + 1].data_ptr(),
                                                           proofs[j].data_ptr(), st_p[j].data_ptr())
             if chain_verify:
                 keyless.verify_shuffle_chain_dev(T, L, kk.data_ptr(), chain.data_ptr(), proofs.data_ptr(), st_v.data_ptr())
@@ -484,7 +497,7 @@ def main():
 
         def parity_inputs():
             t_, j = T // 2, L - 1
-            return (bytes(keys[t_].cpu().numpy().tobytes()), chain[j][t_], fac[j & 1][t_], prm[j & 1][t_], sds[t_],
+            return (bytes(keys[t_].cpu().numpy().tobytes()), chain[j][t_], fac[j][t_], prm[j][t_], sds[j][t_],
                     chain[j + 1][t_], proofs[j][t_])
 
         def digest():
@@ -685,12 +698,51 @@ def main():
         int_mul = {"bound": "v_mad_u64_u32 issue", "achieved": round(mads / (kernel_ms_total * 1e-3) / 1e9, 1),
                    "peak": INT_MAD_PEAK_G, "unit": "Gmad/s",
                    "frac": mads / (kernel_ms_total * 1e-3) / 1e9 / INT_MAD_PEAK_G,
-                   "mads_per_proof": int(mads_per_proof), "mads_per_op": {k: v for k, v in mc.items() if k not in ("field", "a1")},
+                   "mads_per_proof": int(mads_per_proof), "mads_per_op": {k: v for k, v in mc.items() if k not in ("field", "a1", "issue")},
                    "plan_stats": stats, "bucket_windows": bw,
                    "mads_per_field_op": mc["field"],
                    "note": "32x32+64 multiply-adds (v_mad_u64_u32 + v_mad_i64_i32) counted in the gfx950 assembly of THIS build "
-                           "(mental-poker_amd/mad_counts.json, tools/gen_mad_counts.py) x static plan; peak = 256 CU x 4 SIMD x 8 lanes/clk x "
-                           "2.4 GHz = 19.7 T/s theoretical, 18 T/s measured (tools/microbench/intrate.hip)"}
+                           "(mental-poker_amd/mad_counts.json, tools/gen_mad_counts.py) x static plan, over the kernel time of the WHOLE step; "
+                           "peak = 1024 SIMDs x 16 lanes/clk x 2.4 GHz (sustained in tools/microbench/roof.hip: 35.3 T/s at 2.28 GHz and 1.17 kW). "
+                           "The multiplies are ~55 % of the issue slots of the group law: the binding figure is roofline.compute"}
+    # ---- compute bound of the dominant kernel: VALU issue time.  Wave-level group operations of the kernel (static plan) x the issue
+    # cycles of one operation (4 x half-rate + 2 x full-rate VALU instructions of its main path, counted in the gfx950 ISA of this
+    # build) / 1024 SIMDs = the cycles every SIMD needs at the very least; divided by the kernel's measured time = the issue rate it
+    # sustained, against the shader clock (2.4 GHz maximum; the clock measured under this kernel if a PMC pass of this build exists)
+    compute = None
+    if mc and mc.get("issue"):
+        iss = mc["issue"]
+        vw, fw = stats["var_windows"], stats["fixed_windows"]
+        ops = None                      # per proof pair (prove + verify launches of one step), lane level
+        if dom_name == "k_var_msm":
+            ops = {"madd": sum(stats[s_]["var_terms"] for s_ in ("prove", "verify")) * vw,
+                   "dbl": sum(stats[s_]["var_jobs"] for s_ in ("prove", "verify")) * (vw - 1) * 5}
+        elif dom_name == "k_fixed_msm":
+            ops = {"madd": sum(stats[s_]["fixed_terms"] for s_ in ("prove", "verify")) * fw - N * (fw - 1)}
+        elif dom_name == "k_remask":
+            ops = {"madd": 2 * N * (fw + 1)}
+        elif dom_name == "k_bucket_msm" and "xadd" in iss:
+            bw_ = {"secp256k1": 33}.get(curve, 32)
+            if workload == "chain32" and not args.per_link_verify:
+                L_ = args.players
+                terms_, jobs_ = ((L_ + 1) * 2 * N + L_ * (11 * m + 7) + 1) / L_, 1.0 / L_
+            else:
+                terms_, jobs_ = stats.get("bucket_terms", 0), stats.get("bucket_jobs", 0)
+            # one mixed addition per term and window (64 lanes share a window's terms evenly at best); per (MSM, window) the wave-wide
+            # reduction is 14 full additions on all 64 lanes
+            ops = {"madd": terms_ * bw_, "xadd": jobs_ * bw_ * 14 * 64}
+        if ops:
+            cyc_per_proof = sum(ops[k] * iss[k]["cycles"] for k in ops)                     # lane-level issue cycles x 1 lane
+            waves_cycles = cyc_per_proof * (total_proofs / world) / 64.0                        # wave-level instructions issue for 64 lanes at once
+            achieved_ghz = waves_cycles / SIMDS / (dom_ms * 1e-3) / 1e9
+            compute = {"bound": "valu_issue", "kernel": dom_name, "achieved": round(achieved_ghz, 4), "peak": CLK_MAX_GHZ,
+                       "unit": "G issue-cycles/s per SIMD (= GHz of fully used VALU issue port)", "frac": achieved_ghz / CLK_MAX_GHZ,
+                       "ops_per_proof": {k: round(v, 1) for k, v in ops.items()},
+                       "issue_cycles_per_op": {k: iss[k] for k in ops},
+                       "clock_mhz": None, "peak_at_measured_clock": None, "frac_at_measured_clock": None,
+                       "note": "ideal issue time = sum over wave-level operations of (4 x half-rate + 2 x full-rate VALU instructions) / 1024 "
+                               "SIMDs; instruction counts from the gfx950 ISA of this build (mad_counts.json: valu_issue), classes and "
+                               "the no-co-issue rule from tools/microbench/roof.hip (profiles/r03_roof.json)"}
     # HBM traffic of the dominant kernel: PMC pass (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, gfx950 x2
     # correction applied to FETCH_SIZE) of THIS build at THIS configuration, if one is committed under profiles/
     src_hash = engine_source_hash()
@@ -700,12 +752,21 @@ def main():
         e_ = pmc["kernels"][dom_name]
         traffic = e_.get("hbm_bytes_per_proof_per_step", e_["hbm_bytes_per_proof_per_step_corrected"]) * (total_proofs / world) / dom_count
         traffic_src = pmc_path
+        if compute and e_.get("clock_mhz"):
+            # effective shader clock under this kernel = GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration, both of the SAME profiled pass
+            compute["clock_mhz"] = round(e_["clock_mhz"], 1)
+            compute["peak_at_measured_clock"] = round(e_["clock_mhz"] / 1e3, 4)
+            compute["frac_at_measured_clock"] = min(1.0, compute["achieved"] / (e_["clock_mhz"] / 1e3))
+            compute["clock_source"] = pmc_path
+        if compute and e_.get("SQ_INSTS_VALU_per_launch"):
+            compute["valu_insts_per_launch_pmc"] = e_["SQ_INSTS_VALU_per_launch"]
     roofline = {
         "bound": "hbm", "kernel": dom_name, "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
         "avg_launch_ms": dom_ms / dom_count, "launches": dom_count,
         "alg_bytes_per_launch": dom_bytes / dom_count, "alg_bytes_per_proof": per_proof,
-        "note": "path is integer-ALU bound (SURVEY 8d3): see int_mul",
+        "note": "path is bound by VALU issue, not by HBM (SURVEY 8d3): see compute (dominant kernel) and int_mul (whole step)",
+        "compute": compute,
         "int_mul": int_mul,
         "whole_path_hbm_frac": value / world * whole_path_bytes / 1e9 / HBM_PEAK_GBS,
         "kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
@@ -715,7 +776,7 @@ def main():
 
     # ---- CPU baseline: the oracle's C++ restatement (port), single thread, bounded sample
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:                  # rank 0 only (the other ranks have returned); N > 1 lines carry it too
         import coracle as co
         it = args.cpu_iters if N <= 64 else max(2, args.cpu_iters * 52 // (N * max(1, m // 2)))
         t_p, t_v = co.bench(curve, m, n, 99, it)
@@ -751,6 +812,9 @@ def main():
               "aggregate_keys": (B if workload == "chain32" else (args.keyed if args.keyed else 1)),
               "verification": "per equation" if args.per_equation else "merged screening pass (per-equation pass only to name a failure)",
               "parallelism": "%d rank(s), proofs sharded, no data-path collective; parameters broadcast once (%s)" % (world, backend),
+              "rccl_world": (dist.get_world_size() if world > 1 else 1), "collective_backend": backend if world > 1 else None,
+              "table_build_s": round(table_build_s, 3),
+              "hbm_per_rank_gb": round((torch.cuda.mem_get_info(local)[1] - torch.cuda.mem_get_info(local)[0]) / 1e9, 1),
               "per_rank_proofs": [int(r[0]) for r in rows], "per_rank_failed": [int(r[1]) for r in rows],
               "per_rank_seconds": [round(r[2], 4) for r in rows],
               "parity_vs_oracle": parity}

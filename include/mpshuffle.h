@@ -75,8 +75,11 @@ void mp_host_free(void* p);
 /* proofs per pipelined chunk of the host-buffer entry points (default 65536; 0 restores the default) */
 int mp_set_io_chunk(mp_table* t, size_t proofs);
 
-/* ---- DLCards::setup -----------------------------------------------------------------------------------
- * Derives G, ck_0..ck_{n-1}, H, gen = k * G_std with k = Fr::rand(ChaCha20Rng::from_seed(seed)) in that order. */
+/* ---- DLCards::setup [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:105-121] ---------------------------
+ * "setup v2": G, ck_0..ck_{n-1}, H, gen -- n + 3 INDEPENDENT curve points sampled the way ark-ec's `C::rand` does from
+ * ChaCha20Rng::from_seed(seed), in that order: x = Fq::rand, a sign bit, the square root of x^3 + a x + b (retry if there is none),
+ * cofactor cleared.  Nobody, the holder of the seed included, knows a discrete logarithm between two of them (round 1 derived
+ * them as k * G_std, which made the seed a trapdoor of the Pedersen key).  Host work, once per table.  out_params: n + 3 wire points. */
 int mp_setup(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out_params);
 
 /* ---- table context: Parameters + aggregate public key -> fixed-base window tables in HBM ------------------ */
@@ -109,8 +112,12 @@ int mp_shuffle_and_remask_batch(mp_table* t, size_t B, const uint8_t* decks, con
 int mp_verify_shuffle_batch(mp_table* t, size_t B, const uint8_t* decks, const uint8_t* shuffled_decks,
                             const uint8_t* proofs, int32_t* status);
 
-/* ---- device-resident forms: every pointer is a DEVICE pointer (HBM); asynchronous on the context's stream;
- * mp_sync waits.  These are what bench.py times (inputs already in HBM). */
+/* ---- device-resident forms: every pointer is a DEVICE pointer (HBM).  All kernels are enqueued on the context's stream
+ * (mp_sync waits for them).  The prover returns without waiting.  The verifier waits ONCE inside the call when merged
+ * verification is on (the default): after the screening pass it reads one 4-byte flag back to decide whether the per-equation
+ * pass has to run (it does only if some proof failed), so the call returns when the screening kernels have finished;
+ * with mp_set_merged_verify(t, 0) it does not wait either.  d_status is written by the stream in both cases: read it after
+ * mp_sync.  These are what bench.py times (inputs already in HBM). */
 int mp_shuffle_and_remask_batch_dev(mp_table* t, size_t B, const void* d_decks, const void* d_masking_factors,
                                     const void* d_permutations, const void* d_prover_seeds, void* d_out_decks,
                                     void* d_out_proofs, void* d_status);

@@ -223,7 +223,9 @@ MP_HD void xyzz_dbl_ip(Xyzz<C>& p) {
   p.ZZ = fe_mul<F>(V, p.ZZ);
   p.ZZZ = fe_mul<F>(W, p.ZZZ);
 }
-template <class C>
+// PROBE = true (tools/madprobe only): the P + P case does not expand the doubling, so that the compiled function is the
+// main path plus the tests -- what a lane executes per mixed addition
+template <class C, bool PROBE = false>
 MP_HD void xyzz_madd_ip(Xyzz<C>& p, const Aff<C>& q) {
   typedef typename C::FqP F;
   if (aff_is_inf<C>(q)) return;
@@ -237,7 +239,7 @@ MP_HD void xyzz_madd_ip(Xyzz<C>& p, const Aff<C>& q) {
   const Fe<F> Pd = fe_sub<F>(fe_mul<F>(q.x, p.ZZ), p.X);
   const Fe<F> Rr = fe_sub<F>(fe_mul<F>(q.y, p.ZZZ), p.Y);
   if (fe_is_zero(Pd)) {
-    if (fe_is_zero(Rr)) {
+    if (!PROBE && fe_is_zero(Rr)) {
       xyzz_dbl_ip<C>(p);         // P + P
     } else {
       p.ZZ = fe_zero<F>();       // P + (-P)
@@ -255,7 +257,7 @@ MP_HD void xyzz_madd_ip(Xyzz<C>& p, const Aff<C>& q) {
   p.ZZZ = fe_mul<F>(p.ZZZ, PPP);
 }
 // p <- p + q, both XYZZ (12M + 2S): partial sums of the bucket method (kernels_bucket.hpp)
-template <class C>
+template <class C, bool PROBE = false>
 MP_HD void xyzz_add_ip(Xyzz<C>& p, const Xyzz<C>& q) {
   typedef typename C::FqP F;
   if (fe_is_zero(q.ZZ)) return;
@@ -268,7 +270,7 @@ MP_HD void xyzz_add_ip(Xyzz<C>& p, const Xyzz<C>& q) {
   const Fe<F> Pd = fe_sub<F>(U2, U1);
   const Fe<F> Rr = fe_sub<F>(S2, S1);
   if (fe_is_zero(Pd)) {
-    if (fe_is_zero(Rr)) {
+    if (!PROBE && fe_is_zero(Rr)) {
       xyzz_dbl_ip<C>(p);         // P + P
     } else {
       p.ZZ = fe_zero<F>();       // P + (-P)

@@ -506,7 +506,13 @@ struct Table : mp_table {
     }
     if (ph.n_v) {
       VarArgs a{w.D.p, w.T.p, w.J.p, ph.vjobs.p, ph.vterms.p, w.Bpad, nwin};
+#ifdef MP_EXP_VAR_LDS      // experiment hook (tools/ab_build.py): unused dynamic LDS per workgroup caps the waves per SIMD of k_var_msm
+      ctx->prof.begin("k_var_msm", ctx->stream);
+      hipLaunchKernelGGL((k_var_msm<C>), dim3((B + 255u) / 256u, ph.n_v), dim3(256), MP_EXP_VAR_LDS, ctx->stream, a, (uint32_t)B);
+      ctx->prof.end(ctx->stream);
+#else
       MP_RUN(k_var_msm, C, B, ph.n_v, a);
+#endif
     }
     if (ph.n_b) {   // large MSMs: bucket method, one wave per (proof, MSM, window)
       const uint32_t bw = bk_windows(R::BITS);

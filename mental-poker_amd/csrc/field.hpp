@@ -163,6 +163,21 @@ MP_HD void carry29(int32_t s[9], uint32_t out[9]) {
 // any value in [0, 8p) comes out in [0, 4p).
 template <class P>
 MP_HD void reduce_carry29(int32_t s[9], uint32_t out[9]) {
+  if constexpr (P::DENSE29) {
+    // A prime without structure (bn254): values are kept in [0, 2p), so sums and differences come here in [0, 4p).  The top
+    // limb before the carries, s_8, is within (-1.01, +3.01) of v / 2^232 (every lower s_i is in (-2^29, 3 * 2^29)), so with
+    // t = s_8 + 4 the estimate q = floor(t * QREC / 2^32), QREC = floor(2^264 / p) + 1, satisfies  floor(v/p) <= q <= floor(v/p) + 1
+    // (p / 2^232 > 3 * 10^6 absorbs both the padding of t and the 0.05 % excess of QREC).  Subtracting max(q - 1, 0) p leaves
+    // [p, 2p) if the estimate was exact and [0, p) if it was one high: always [0, 2p), never negative.  k p_i <= 3 * 2^29 keeps
+    // s_i - k p_i above -2^31.
+    const uint32_t t = (uint32_t)(s[8] + 4);
+    const uint32_t q = (uint32_t)(((uint64_t)t * P::QREC) >> 32);
+    const uint32_t k = q > 0 ? q - 1 : 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s[i] -= (int32_t)(k * P::MOD29[i]);
+    carry29(s, out);
+    return;
+  }
   int32_t q = (s[8] >> P::TOP29) - 2;
   q = q < 0 ? 0 : q;
 #pragma unroll
@@ -173,6 +188,17 @@ MP_HD void reduce_carry29(int32_t s[9], uint32_t out[9]) {
 // bring a lazily reduced value (< 8p, normalised limbs) to the canonical residue in [0, p)
 template <class P>
 MP_HD void canonical29(const uint32_t a[9], uint32_t out[9]) {
+  if constexpr (P::DENSE29) {       // a in [0, 2p) with normalised limbs: one exact conditional subtraction of p
+    int32_t d[9];
+    uint32_t t[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d[i] = (int32_t)a[i] - (int32_t)P::MOD29[i];
+    carry29(d, t);
+    const bool neg = (int32_t)t[8] < 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out[i] = neg ? a[i] : t[i];
+    return;
+  }
   int32_t s[9];
   const int32_t q = (int32_t)(a[8] >> P::TOP29);
 #pragma unroll
@@ -379,6 +405,16 @@ MP_HD bool fe_is_zero(const Fe<P>& a) {
 #pragma unroll
     for (int i = 2; i < 8; ++i) o |= a.v[i] ^ M29;
     return o == 0;
+  } else if constexpr (P::DENSE29) {
+    // a in [0, 2p) with normalised limbs: zero mod p means a = 0 or a = p.  The low limb decides almost always.
+    if (a.v[0] != 0u && a.v[0] != P::MOD29[0]) return false;
+    uint32_t z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      z |= a.v[i];
+      e |= a.v[i] ^ P::MOD29[i];
+    }
+    return z == 0 || e == 0;
   } else if constexpr (P::L29) {
     // lazily reduced: a is one of 0, p, 2p, ... ; the limbs of k*p are k*MOD29[i] (no carries: sparse p).
     // Fast path: where p has a zero limb, so has k*p -- almost every non-zero value is rejected by one OR chain.
@@ -427,7 +463,7 @@ MP_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
     // a - b + 4p in (0, 8p)
     int32_t s[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) s[i] = (int32_t)a.v[i] - (int32_t)b.v[i] + 4 * P::SMOD29[i];
+    for (int i = 0; i < 9; ++i) s[i] = (int32_t)a.v[i] - (int32_t)b.v[i] + (P::DENSE29 ? 2 : 4) * P::SMOD29[i];   // + 4p (dense primes: values < 2p, + 2p)
     reduce_carry29<P>(s, r.v);
   } else {
     uint32_t d[P::NW];

@@ -175,7 +175,11 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t wid, W& wv) {
   //   pair mode     the segment is the lane's two buckets {2l+1, 2l+2}: one switch per lane, never a real addition, lo = 2l+1;
   //   balanced mode (a window whose digits crowd into few buckets -- the top window of a 252-bit scalar has 8): equal
   //                 shares of the sorted list; the buckets are long there, so a segment still crosses at most one boundary.
+#ifdef MP_EXP_BK_BALANCED  // experiment hook (tools/ab_build.py): every window in balanced mode
+  const bool balanced = true;
+#else
   const bool balanced = maxpair > T / 64 + T / 128 + 32;
+#endif
   PerLane<Xyzz<C>> run, acc;
   PerLane<uint32_t> n, s1, cb;
   wv.lanes([&](uint32_t lane) {

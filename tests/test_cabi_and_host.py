@@ -210,6 +210,17 @@ def test_division_step_inversion_matches_fermat():
     assert out.count(" 0 mismatches, 0 answered by the fallback") == 6, out
 
 
+def test_field_arithmetic_matches_bigint_reference():
+    """field.hpp (9x29 sparse / signed-sparse / dense lazy limbs, 8x32, 12x32) against an independent schoolbook big-integer reference:
+    products, squares, fused a b - c d, chains of lazily reduced sums and differences, zero tests, packed round trips"""
+    exe = os.path.join(ROOT, "tests", "cpp", "_field_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-include", os.path.join(ROOT, "tools", "hostemu", "rt.hpp"),
+                           "-I" + os.path.join(ROOT, "tools", "hostemu"), "-I" + os.path.join(ROOT, "mental-poker_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", "field_check.cpp"), "-o", exe])
+    out = subprocess.run([exe, "6000"], stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert out.count(" 0 mismatches") == 6, out
+
+
 def test_emulated_batch_and_status(emu, coracle):
     cv, m, n = "stark", 2, 3
     eng = emu(cv)

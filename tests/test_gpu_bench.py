@@ -51,6 +51,11 @@ def test_json_line_contract_and_extras():
     assert r["traffic"] is None or r["traffic_source"].startswith("profiles/")      # only from a PMC pass of THIS build and batch
     assert r["int_mul"]["mads_per_op"]["madd"] == 900 and r["int_mul"]["mads_per_op"]["dbl"] == 828   # STARK, counted in the assembly
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
+    c = r["compute"]                                            # VALU-issue bound of the dominant kernel: a fraction, never above 1
+    assert c["bound"] == "valu_issue" and c["kernel"] == r["kernel"] and 0 < c["frac"] <= 1 and c["peak"] == 2.4
+    assert c["issue_cycles_per_op"]["madd"]["cycles"] == 4 * c["issue_cycles_per_op"]["madd"]["half_rate"] + 2 * c["issue_cycles_per_op"]["madd"]["full_rate"]
+    assert c["frac_at_measured_clock"] is None or c["frac_at_measured_clock"] <= 1
+    assert d["config"]["rccl_world"] == 1 and d["config"]["table_build_s"] > 0 and d["config"]["hbm_per_rank_gb"] > 0
     assert d["config"]["per_equation_value"] > 0 and d["config"]["keyed_value"] > 0
 
 
@@ -62,3 +67,15 @@ def test_workload_modes(workload, extra):
     assert d["config"]["workload"].startswith(workload) and d["config"]["parity_vs_oracle"] is True and d["value"] > 0
     if workload == "mixed":
         assert "secp256k1" in d["config"]["workload"]
+
+
+@pytest.mark.parametrize("workload,extra,per_rank", [("chain32", ["--batch", "96", "--players", "32"], 96 * 32), ("mixed", ["--batch", "384"], 192)])
+def test_two_ranks_other_workloads(workload, extra, per_rank):
+    """config 3 (32 dependent shuffles per table, one chain equation per table) and config 5 (mixed prove / verify stream on secp256k1)
+    through the N > 1 path: two self-launched ranks, every proof accepted on both, the N > 1 line keeps cpu_baseline and roofline"""
+    d = run_bench("--gpus", "2", "--workload", workload, "--steps", "1", "--warmup", "1", "--fb-bits", "8", "--cpu-iters", "2", *extra,
+                  env={"MP_BENCH_FORCE_DEVICE": "0", "MP_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["config"]["rccl_world"] == 2 and d["config"]["collective_backend"] == "gloo"
+    assert d["config"]["per_rank_proofs"] == [per_rank, per_rank] and d["config"]["per_rank_failed"] == [0, 0]
+    assert d["config"]["parity_vs_oracle"] is True
+    assert d["cpu_baseline"] is not None and d["cpu_baseline"]["kind"] == "port" and d["roofline"]["kernel"].startswith("k_")

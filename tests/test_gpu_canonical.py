@@ -89,11 +89,8 @@ def test_golden_vectors_through_serialisation_and_the_device(mp, engines, path):
     assert ei.value.check in ("Hadamard Product (5.1)", "Zero Argument (5.2)", "Single Value Product (5.3)", "Multi-Exponentiation Argument (4)")
     # the oracle's verifier names the same check for the same bytes
     with po.curve_ctx(cv):
-        try:
-            po.verify_shuffle(pp, pk, deck, shuffled, po.proof_from_bytes(bad_wire, m, n))
-            raise AssertionError("oracle accepted the tampered proof")
-        except po.VerifyError as e:
-            assert str(e.args[0]) == ei.value.check or getattr(e, "check", None) == ei.value.check or ei.value.check in str(e)
+        code = po.verify_shuffle(pp, pk, deck, shuffled, po.proof_from_bytes(bad_wire, m, n))
+    assert code != 0 and po.CHECK_NAMES[code] == ei.value.check
 
 
 def test_survey_known_answer_through_the_c_abi(mp):

@@ -567,7 +567,8 @@ def test_bucket_msm_large_and_edge_scalars(mp, coracle):
 
 
 @pytest.mark.parametrize("cvn,m,n,L,T,keyed", [("stark", 2, 26, 8, 40, True), ("stark", 4, 13, 3, 5, False), ("secp256k1", 2, 7, 4, 3, True),
-                                                ("stark", 8, 128, 2, 2, True)])
+                                                ("stark", 8, 128, 2, 2, True),
+                                                ("stark", 2, 26, 32, 3, True)])     # BASELINE config 3 at its stated length: 32 players
 def test_chain_verification_matches_per_link_verifier(mp, coracle, cvn, m, n, L, T, keyed):
     """mp_verify_shuffle_chain (one equation per table over all links of its shuffle chain) accepts honest chains and, when a link
     is bad, returns exactly the status words of the per-link verifier"""

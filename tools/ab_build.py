@@ -24,7 +24,8 @@ def main():
     for a in sys.argv[2:]:
         if a.startswith("--units="):
             units = a.split("=", 1)[1].split(",")
-    nat.build()                                  # product objects up to date
+    if "--no-product" not in sys.argv:
+        nat.build()                              # product objects up to date
     csrc = os.path.join(ROOT, "mental-poker_amd", "csrc")
     objdir = os.path.join(ROOT, "tools", "ab", "obj_" + name)
     os.makedirs(objdir, exist_ok=True)

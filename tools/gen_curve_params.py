@@ -53,9 +53,20 @@ def is_pm29(p):
     return p.bit_length() == 256 and (1 << 256) - p < (1 << 40)
 
 
+BN254_P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+
+
+def is_dense29(p):
+    """9x29-bit lazy limbs for a prime WITHOUT structure (field.hpp, DENSE29): full Montgomery reduction (81 + 81 limb products and
+    9 quotient digits against the 136 multiply-adds + 128 carry additions of the 8x32 product), values kept below 2p, the weak
+    reduction of an addition subtracts k p, k in {0..3}, with k from a one-multiply quotient estimate.  Used for the base field of
+    bn254 (BASELINE config 1 names ark-bn254); the scalar fields stay on 8x32 because `Fr::rand` defines their Montgomery form."""
+    return p == BN254_P
+
+
 def field_R(p):
     """the Montgomery constant R of the in-memory residue a R mod p"""
-    return 1 << (261 if (is_l29(p) or is_pm29(p)) else 32 * nwords(p))
+    return 1 << (261 if (is_l29(p) or is_pm29(p) or is_dense29(p)) else 32 * nwords(p))
 
 
 def slimbs29(v):
@@ -66,18 +77,25 @@ def field(name, p):
     inv = (-pow(p, -1, 1 << 32)) % (1 << 32)
     l29 = is_l29(p)
     pm = is_pm29(p)
+    dense = is_dense29(p)
     nw = nwords(p)
     R = field_R(p)
     s = "struct %s {\n" % name
     s += "  static constexpr int NW = %d;                 // packed 32-bit words of an element in memory (and limbs of the 32-bit form)\n" % nw
-    s += "  static constexpr bool L29 = %s;             // 9x29-bit lazy limbs (R = 2^261) instead of 8x32 (R = 2^256)\n" % ("true" if (l29 or pm) else "false")
+    s += "  static constexpr bool L29 = %s;             // 9x29-bit lazy limbs (R = 2^261) instead of 8x32 (R = 2^256)\n" % ("true" if (l29 or pm or dense) else "false")
     s += "  static constexpr bool PM29 = %s;            // ... for a pseudo-Mersenne prime 2^256 - c: signed sparse limbs of p (SMOD29)\n" % ("true" if pm else "false")
     if pm:
         c = (1 << 256) - p
         l29 = True
         s += "  static constexpr uint32_t G0 = %du, G1 = %du;     // c = G0 + G1 2^29: p = 2^256 - c\n" % (c & ((1 << 29) - 1), c >> 29)
         assert (c >> 29) < 16
+    if dense:
+        l29 = True
+    s += "  static constexpr bool DENSE29 = %s;          // ... for a prime without structure: values < 2p, quotient estimate by one multiply\n" % ("true" if dense else "false")
     if l29:
+        if dense:
+            # q_est = umulhi(top limb + 4, QREC) is never below floor(v / p) and at most one above it for v < 4p (field.hpp)
+            s += "  static constexpr uint32_t QREC = %du;         // floor(2^264 / p) + 1\n" % (((1 << 264) // p) + 1)
         s += "  static constexpr uint32_t MOD29[9] = %s;\n" % limbs29(p)
         if pm:
             c = (1 << 256) - p

@@ -68,6 +68,28 @@ def count(body):
     return sum(len(re.findall(r"^\s*%s\b" % m, body, flags=re.M)) for m in MADS)
 
 
+# VALU issue classes on gfx950, measured with tools/microbench/roof.hip (profiles/r03_roof.json, rows c_*): a wave64 instruction of
+# the FULL-rate class occupies its SIMD's issue port for 2 cycles (~27 of 32 lanes per clock sustained): plain 32-bit add / sub /
+# and / or / xor / not / mov and the right shifts.  EVERYTHING else -- every integer multiply and multiply-add, every 64-bit shift or
+# add, the three-operand forms (add3, or3, and_or, lshl_add, alignbit, bfe), left shifts, min / max, compares, selects, carry
+# chains, fp64 -- takes 4 cycles (~15 of 16 lanes per clock).  Nothing co-issues: kernel time >= sum of issue cycles / SIMDs.
+FULL_RATE = re.compile(r"^v_(add_u32|sub_u32|subrev_u32|and_b32|or_b32|xor_b32|not_b32|mov_b32|ashrrev_i32|lshrrev_b32)(_e32|_e64)?$")
+
+
+def valu_classes(body):
+    """(half-rate, full-rate) VALU instructions of a function body"""
+    half = full = 0
+    for line in body.splitlines():
+        m = re.match(r"^\s*(v_\w+)", line)
+        if not m:
+            continue
+        if FULL_RATE.match(m.group(1)):
+            full += 1
+        else:
+            half += 1
+    return half, full
+
+
 def main(flags):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     asm = subprocess.check_output([hipcc] + flags + ["--cuda-device-only", "-S", SRC, "-o", "-"]).decode()
@@ -97,7 +119,27 @@ def main(flags):
         nl = (bits + 2 + 28) // 29
         batches = 21 if bits <= 256 else ((49 * bits + 80) // 17 + 28) // 29
         res[cv]["inv_divsteps_mads"] = batches * (10 * nl + 2) + 2 * res[cv]["mul"]
-    json.dump({"_note": "v_mad_u64_u32 + v_mad_i64_i32 per base-field product / square / fused a*b-c*d (fr_mul: scalar-field product) in "
+        # VALU issue classes of the field operations and of the group operations of the MSM loops (probe_madd / probe_dbl: main path)
+        cname = {"stark": "Stark", "bn254": "Bn254", "secp256k1": "Secp256k1", "bls12_377": "Bls12_377"}[cv]
+        issue = {}
+        def with_callees(sym, body):
+            h, f = valu_classes(body)
+            for callee in fn:                     # the out-of-line 12-limb product
+                if callee != sym and callee in body:
+                    k = len(re.findall(r"^\s*s_swappc_b64", body, flags=re.M))
+                    ch, cf = valu_classes(fn[callee])
+                    h, f = h + k * ch, f + k * cf
+            return h, f
+        for kind, tag in (("mul", fq), ("sqr", fq), ("mulsub", fq)):
+            for sym, body in fn.items():
+                if ("%dprobe_%sI" % (len(kind) + 6, kind)) in sym and tag in sym:
+                    issue[kind] = with_callees(sym, body)
+        for kind in ("madd", "dbl", "xadd"):
+            for sym, body in fn.items():
+                if ("%dprobe_%sI" % (len(kind) + 6, kind)) in sym and ("_%d%sE" % (len(cname), cname)) in sym:
+                    issue[kind] = with_callees(sym, body)
+        res[cv]["valu_issue"] = {k: {"half_rate": v[0], "full_rate": v[1], "cycles": 4 * v[0] + 2 * v[1]} for k, v in issue.items()}
+    json.dump({"_valu_issue_note": "valu_issue: VALU instructions per operation by issue class in the gfx950 assembly (full_rate: v_add/sub/subrev_u32, v_and/or/xor/not/mov_b32, v_ashrrev_i32, v_lshrrev_b32 = 2 cycles of a SIMD's issue port per wave64 instruction; half_rate: every other VALU instruction = 4 cycles; classes measured by tools/microbench/roof.hip -> profiles/r03_roof.json); cycles = 4 half + 2 full = the ideal issue time of the operation on one SIMD", "_note": "v_mad_u64_u32 + v_mad_i64_i32 per base-field product / square / fused a*b-c*d (fr_mul: scalar-field product) in "
                         "the gfx950 assembly of tools/madprobe/mad_probe.hip; inv_sqr / inv_mul = operations of the Fermat inversion chain (no longer used by the kernels); inv_divsteps_mads = the division-step inversion. "
                         "GENERATED by tools/gen_mad_counts.py during build()", "flags": flags, "curves": res}, open(OUT, "w"), indent=1)
     return res

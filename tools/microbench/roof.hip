@@ -182,6 +182,22 @@ __global__ void __launch_bounds__(256) k_single(Stamp* st, uint32_t* out, uint32
 CLS_KERNEL(c_add_u32, I2("v_add_u32") I2("v_add_u32"), CLS_DECL)
 CLS_KERNEL(c_sub_u32, I2("v_sub_u32") I2("v_sub_u32"), CLS_DECL)
 CLS_KERNEL(c_and_b32, I2("v_and_b32") I2("v_and_b32"), CLS_DECL)
+CLS_KERNEL(c_or_b32, I2("v_or_b32") I2("v_or_b32"), CLS_DECL)
+CLS_KERNEL(c_xor_b32, I2("v_xor_b32") I2("v_xor_b32"), CLS_DECL)
+CLS_KERNEL(c_subrev_u32, I2("v_subrev_u32") I2("v_subrev_u32"), CLS_DECL)
+CLS_KERNEL(c_min_u32, I2("v_min_u32") I2("v_min_u32"), CLS_DECL)
+#define I2L(op, lit) "" op " %0, " lit ", %0\n\t" op " %1, " lit ", %1\n\t" op " %2, " lit ", %2\n\t" op " %3, " lit ", %3\n\t" op " %4, " lit ", %4\n\t" op " %5, " lit ", %5\n\t" op " %6, " lit ", %6\n\t" op " %7, " lit ", %7\n\t"
+CLS_KERNEL(c_and_b32_literal, I2L("v_and_b32", "0x1fffffff") I2L("v_and_b32", "0x1fffffff"), CLS_DECL)
+CLS_KERNEL(c_add_u32_literal, I2L("v_add_u32", "0x12345679") I2L("v_add_u32", "0x12345679"), CLS_DECL)
+CLS_KERNEL(c_lshrrev_b32, S32("v_lshrrev_b32") S32("v_lshrrev_b32"), CLS_DECL)
+#define U1(op) "" op " %0, %1\n\t" op " %1, %2\n\t" op " %2, %3\n\t" op " %3, %4\n\t" op " %4, %5\n\t" op " %5, %6\n\t" op " %6, %7\n\t" op " %7, %0\n\t"
+CLS_KERNEL(c_mov_b32, U1("v_mov_b32") U1("v_mov_b32"), CLS_DECL)
+CLS_KERNEL(c_not_b32, U1("v_not_b32") U1("v_not_b32"), CLS_DECL)
+CLS_KERNEL(c_bfrev_b32, U1("v_bfrev_b32") U1("v_bfrev_b32"), CLS_DECL)
+#define CMPO "v_cmp_ne_u32 vcc, %0, %8\n\tv_cmp_ne_u32 vcc, %1, %9\n\tv_cmp_ne_u32 vcc, %2, %8\n\tv_cmp_ne_u32 vcc, %3, %9\n\tv_cmp_ne_u32 vcc, %4, %8\n\tv_cmp_ne_u32 vcc, %5, %9\n\tv_cmp_ne_u32 vcc, %6, %8\n\tv_cmp_ne_u32 vcc, %7, %9\n\t"
+CLS_KERNEL(c_cmp_only, CMPO CMPO, CLS_DECL)
+#define CNDO "v_cndmask_b32 %0, %0, %8, vcc\n\tv_cndmask_b32 %1, %1, %9, vcc\n\tv_cndmask_b32 %2, %2, %8, vcc\n\tv_cndmask_b32 %3, %3, %9, vcc\n\tv_cndmask_b32 %4, %4, %8, vcc\n\tv_cndmask_b32 %5, %5, %9, vcc\n\tv_cndmask_b32 %6, %6, %8, vcc\n\tv_cndmask_b32 %7, %7, %9, vcc\n\t"
+CLS_KERNEL(c_cndmask_only, CNDO CNDO, CLS_DECL)
 CLS_KERNEL(c_max_i32, I2("v_max_i32") I2("v_max_i32"), CLS_DECL)
 CLS_KERNEL(c_mul_u32_u24, I2("v_mul_u32_u24") I2("v_mul_u32_u24"), CLS_DECL)
 CLS_KERNEL(c_mul_i32_i24, I2("v_mul_i32_i24") I2("v_mul_i32_i24"), CLS_DECL)
@@ -423,7 +439,8 @@ int main(int argc, char** argv) {
     vs.push_back({"cheap_only (16 add/xor)", k_mix<4>, occ, 0, 16, "inst", 16});
   }
 #define CLS(NAME) vs.push_back({#NAME, NAME, 8, 0, 16, "inst", 16});
-  CLS(c_add_u32) CLS(c_sub_u32) CLS(c_and_b32) CLS(c_max_i32) CLS(c_add3_u32) CLS(c_or3_b32) CLS(c_and_or_b32) CLS(c_lshl_add_u32)
+  CLS(c_add_u32) CLS(c_sub_u32) CLS(c_and_b32) CLS(c_or_b32) CLS(c_xor_b32) CLS(c_subrev_u32) CLS(c_min_u32) CLS(c_and_b32_literal) CLS(c_add_u32_literal)
+  CLS(c_lshrrev_b32) CLS(c_mov_b32) CLS(c_not_b32) CLS(c_bfrev_b32) CLS(c_cmp_only) CLS(c_cndmask_only) CLS(c_max_i32) CLS(c_add3_u32) CLS(c_or3_b32) CLS(c_and_or_b32) CLS(c_lshl_add_u32)
   CLS(c_alignbit_b32) CLS(c_bfe_u32) CLS(c_ashrrev_i32) CLS(c_lshlrev_b32) CLS(c_cmp_cndmask) CLS(c_add_co_addc)
   CLS(c_mul_u32_u24) CLS(c_mul_i32_i24) CLS(c_mad_u32_u24) CLS(c_mul_lo_u32) CLS(c_mul_hi_u32) CLS(c_mad_u64_u32) CLS(c_mad_i64_i32)
   CLS(c_ashrrev_i64) CLS(c_lshlrev_b64) CLS(c_lshrrev_b64) CLS(c_lshl_add_u64)

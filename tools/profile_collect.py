@@ -55,6 +55,9 @@ def counters(dirpath, min_grid, skip):
             continue
         out[c][k][0] += float(r["Counter_Value"])
         out[c][k][1] += 1
+        if c == "GRBM_GUI_ACTIVE":           # duration of the same dispatches in the same (profiled) pass: the effective clock needs both
+            out["__duration_ns"][k][0] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+            out["__duration_ns"][k][1] += 1
     return out
 
 
@@ -105,8 +108,13 @@ def main():
                  "hbm_bytes_per_proof_per_step_corrected": (2 * f + w) * 1024 / batch / passes,
                  "hbm_bytes_per_proof_per_step_raw": (f + w) * 1024 / batch / passes}
             for c, per in SQ.items():
-                if k in per:
+                if k in per and not c.startswith("__"):
                     e[c + "_per_launch"] = per[k][0] / max(per[k][1], 1)
+            dur = SQ.get("__duration_ns", {}).get(k)
+            if dur and dur[1] and "GRBM_GUI_ACTIVE_per_launch" in e:
+                e["duration_ms_per_launch_sq_pass"] = dur[0] / dur[1] * 1e-6
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs; shader cycles of one XCD / wall time of the dispatch = effective clock
+                e["clock_mhz"] = e["GRBM_GUI_ACTIVE_per_launch"] / 8.0 / (dur[0] / dur[1]) * 1e3
             kernels[k] = e
         wl = pb["config"]["workload"]
         mm = re.search(r"m=(\d+) n=(\d+), (\w+) curve", wl)
@@ -115,7 +123,9 @@ def main():
                          "(fetch_calibration x FETCH + WRITE) KB: x2 for wide coalesced reads (gfx950 FETCH_SIZE under-reports them, "
                          "MI355X_MICROARCH.md), x1 for the 64-byte gathers of k_var_msm (profiles/r02_fetch_calibration.txt); `_corrected` = x2 "
                          "for every kernel (round 1's convention); per proof per prove+verify step; "
-                         "SQ_* = per-launch averages (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES / SQ_WAIT_* count quad-cycles)",
+                         "SQ_* = per-launch averages (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES / SQ_WAIT_* count quad-cycles; on gfx950 rocprofv3 returns "
+                         "SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU: one quad-cycle per VALU instruction whatever its issue class, it is not an "
+                         "independent measurement); clock_mhz = GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration of the SAME pass",
                 "engine_src": pb["roofline"].get("engine_src") or (sys.argv[2] if len(sys.argv) > 2 else None),
                 "workload": wl.split(":")[0] if ":" in wl else "pairs",
                 "curve": mm.group(3) if mm else None, "m": int(mm.group(1)) if mm else None, "n": int(mm.group(2)) if mm else None,
