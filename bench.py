@@ -263,7 +263,16 @@ def main():
     N = m * n
     B = args.batch if args.batch is not None else (49152 if workload == "chain32" else 262144)
     if args.fb_bits is None:
-        args.fb_bits = 21 if curve == "stark" else 20
+        # widest fixed-base windows whose tables ((n + 5) bases x windows x (2^bits - 1) entries) stay below 30 % of this GPU's HBM:
+        # 21 bits (48 GB) at n = 26 on the STARK curve, 20 bits elsewhere, 16 bits for the 1024-card shapes (n >= 64)
+        hbm_total = torch.cuda.mem_get_info(local)[1]
+        sbits = {"stark": 252, "bn254": 254, "secp256k1": 256, "bls12_377": 253}[curve]
+        pbytes = 96 if curve == "bls12_377" else 64
+        args.fb_bits = 8
+        for bits in ((21, 20, 16) if curve == "stark" else (20, 16)):
+            if (n + 5) * ((sbits + bits - 1) // bits) * ((1 << bits) - 1) * pbytes <= 0.30 * hbm_total:
+                args.fb_bits = bits
+                break
     eng = mp.Engine(curve, device=local)
     PB = eng.point_bytes
     CB = 2 * PB
@@ -731,15 +740,23 @@ def main():
             # one mixed addition per term and window (64 lanes share a window's terms evenly at best); per (MSM, window) the wave-wide
             # reduction is 14 full additions on all 64 lanes
             ops = {"madd": terms_ * bw_, "xadd": jobs_ * bw_ * 14 * 64}
-        if ops:
+        if ops and sum(ops.values()) > 0:       # (plan_stats describes the throughput plan: small batches on the finer splits have no entry)
             cyc_per_proof = sum(ops[k] * iss[k]["cycles"] for k in ops)                     # lane-level issue cycles x 1 lane
             waves_cycles = cyc_per_proof * (total_proofs / world) / 64.0                        # wave-level instructions issue for 64 lanes at once
             achieved_ghz = waves_cycles / SIMDS / (dom_ms * 1e-3) / 1e9
+            # second view, the one the SQ counters see: every VALU instruction takes one 4-cycle issue slot of its SIMD (in streams that
+            # mix the two classes the cheap instructions do not get their 2-cycle rate: roof microbenchmark, mad:cheap rows)
+            insts_per_proof = sum(ops[k] * (iss[k]["half_rate"] + iss[k]["full_rate"]) for k in ops)
+            slot_ginst = insts_per_proof * (total_proofs / world) / 64.0 / (dom_ms * 1e-3) / 1e9
+            slots = {"valu_insts_per_op": {k: iss[k]["half_rate"] + iss[k]["full_rate"] for k in ops},
+                     "achieved_G_wave_insts_per_s": round(slot_ginst, 2), "peak_G_wave_insts_per_s": SIMDS * CLK_MAX_GHZ / 4.0,
+                     "frac": slot_ginst / (SIMDS * CLK_MAX_GHZ / 4.0), "frac_at_measured_clock": None,
+                     "note": "one VALU instruction per 4-cycle slot per SIMD; static instruction counts x plan"}
             compute = {"bound": "valu_issue", "kernel": dom_name, "achieved": round(achieved_ghz, 4), "peak": CLK_MAX_GHZ,
                        "unit": "G issue-cycles/s per SIMD (= GHz of fully used VALU issue port)", "frac": achieved_ghz / CLK_MAX_GHZ,
                        "ops_per_proof": {k: round(v, 1) for k, v in ops.items()},
                        "issue_cycles_per_op": {k: iss[k] for k in ops},
-                       "clock_mhz": None, "peak_at_measured_clock": None, "frac_at_measured_clock": None,
+                       "clock_mhz": None, "peak_at_measured_clock": None, "frac_at_measured_clock": None, "issue_slots": slots,
                        "note": "ideal issue time = sum over wave-level operations of (4 x half-rate + 2 x full-rate VALU instructions) / 1024 "
                                "SIMDs; instruction counts from the gfx950 ISA of this build (mad_counts.json: valu_issue), classes and "
                                "the no-co-issue rule from tools/microbench/roof.hip (profiles/r03_roof.json)"}
@@ -758,6 +775,7 @@ def main():
             compute["peak_at_measured_clock"] = round(e_["clock_mhz"] / 1e3, 4)
             compute["frac_at_measured_clock"] = min(1.0, compute["achieved"] / (e_["clock_mhz"] / 1e3))
             compute["clock_source"] = pmc_path
+            compute["issue_slots"]["frac_at_measured_clock"] = min(1.0, compute["issue_slots"]["achieved_G_wave_insts_per_s"] / (SIMDS * e_["clock_mhz"] / 1e3 / 4.0))
         if compute and e_.get("SQ_INSTS_VALU_per_launch"):
             compute["valu_insts_per_launch_pmc"] = e_["SQ_INSTS_VALU_per_launch"]
     roofline = {

@@ -55,7 +55,8 @@ def build(verbose=False):
     hdr_time = max(os.path.getmtime(h) for h in headers)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # max-ilp scheduling: +0.8 % on the MSM kernels in a back-to-back A/B (interleaves the mad chains with the carry handling)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+             "-mllvm", "-pragma-unroll-threshold=1000000"]   # the 14-limb products (27 columns x 14) must unroll completely: rolled, their operands are re-read from the stack with dynamic indices
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))

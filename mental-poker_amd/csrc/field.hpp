@@ -28,7 +28,7 @@ namespace mp {
 
 template <class P>
 struct Fe {
-  uint32_t v[P::L29 ? 9 : P::NW];   // NW = 8 packed words (256-bit fields) or 12 (BLS12-377 Fq)
+  uint32_t v[P::L29 ? P::NL29 : P::NW];   // 29-bit form: NL29 = 9 limbs (256-bit fields) or 14 (BLS12-377 Fq); else NW = 8 packed words
 };
 
 static constexpr uint32_t M29 = (1u << 29) - 1;
@@ -149,67 +149,73 @@ MP_HD void mul32(uint32_t* r, const uint32_t* a, const uint32_t* b) {
 // helpers of representation (2)
 // =====================================================================================================
 // one signed carry pass: s (each |s_i| < 2^31) -> limbs < 2^29, the top limb keeps the rest (must be >= 0)
-MP_HD void carry29(int32_t s[9], uint32_t out[9]) {
+template <int NL>
+MP_HD void carry29(int32_t* s, uint32_t* out) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < NL - 1; ++i) {
     const int32_t c = s[i] >> 29;
     out[i] = (uint32_t)s[i] & M29;
     s[i + 1] += c;
   }
-  out[8] = (uint32_t)s[8];
+  out[NL - 1] = (uint32_t)s[NL - 1];
 }
 // weak reduction folded into the carry pass: subtract max(q - 2, 0) * p with q = s_8 >> TOP29 (an estimate of
 // floor(value / 2^(232+TOP29)) that is off by at most one either way before the carries are propagated):
 // any value in [0, 8p) comes out in [0, 4p).
 template <class P>
-MP_HD void reduce_carry29(int32_t s[9], uint32_t out[9]) {
+MP_HD void reduce_carry29(int32_t* s, uint32_t* out) {
+  constexpr int NL = P::NL29;
   if constexpr (P::DENSE29) {
-    // A prime without structure (bn254): values are kept in [0, 2p), so sums and differences come here in [0, 4p).  The top
-    // limb before the carries, s_8, is within (-1.01, +3.01) of v / 2^232 (every lower s_i is in (-2^29, 3 * 2^29)), so with
-    // t = s_8 + 4 the estimate q = floor(t * QREC / 2^32), QREC = floor(2^264 / p) + 1, satisfies  floor(v/p) <= q <= floor(v/p) + 1
-    // (p / 2^232 > 3 * 10^6 absorbs both the padding of t and the 0.05 % excess of QREC).  Subtracting max(q - 1, 0) p leaves
-    // [p, 2p) if the estimate was exact and [0, p) if it was one high: always [0, 2p), never negative.  k p_i <= 3 * 2^29 keeps
-    // s_i - k p_i above -2^31.
-    const uint32_t t = (uint32_t)(s[8] + 4);
+    // A prime without structure (bn254, BLS12-377): values are kept in [0, 2p), so sums and differences come here in [0, 4p).
+    // t = the top limbs before the carries, aligned so that p / 2^QBIT is ~2^21 (bn254: s_8 alone; BLS12-377: s_13 2^21 + s_12 / 2^8),
+    // is within (-1.01, +3.01) of v / 2^QBIT (every lower s_i is in (-2^29, 3 * 2^29)), so with the padding of 4 the estimate
+    // q = floor((t + 4) QREC / 2^32), QREC = floor(2^(32 + QBIT) / p) + 1, satisfies  floor(v/p) <= q <= floor(v/p) + 1
+    // (p / 2^QBIT > 10^6 absorbs both the padding and the excess of QREC).  Subtracting max(q - 1, 0) p leaves [p, 2p) if the
+    // estimate was exact and [0, p) if it was one high: always [0, 2p), never negative.  k p_i <= 3 * 2^29 keeps s_i - k p_i
+    // above -2^31.
+    int32_t top = s[NL - 1] << P::QHI;
+    if constexpr (P::QLO < 29) top += s[NL - 2] >> P::QLO;
+    const uint32_t t = (uint32_t)(top + 4);
     const uint32_t q = (uint32_t)(((uint64_t)t * P::QREC) >> 32);
     const uint32_t k = q > 0 ? q - 1 : 0;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) s[i] -= (int32_t)(k * P::MOD29[i]);
-    carry29(s, out);
-    return;
-  }
-  int32_t q = (s[8] >> P::TOP29) - 2;
-  q = q < 0 ? 0 : q;
+    for (int i = 0; i < NL; ++i) s[i] -= (int32_t)(k * P::MOD29[i]);
+    carry29<NL>(s, out);
+  } else {
+    int32_t q = (s[NL - 1] >> P::TOP29) - 2;
+    q = q < 0 ? 0 : q;
 #pragma unroll
-  for (int i = 0; i < 9; ++i)
-    if (P::SMOD29[i] != 0) s[i] -= q * P::SMOD29[i];
-  carry29(s, out);
+    for (int i = 0; i < NL; ++i)
+      if (P::SMOD29[i] != 0) s[i] -= q * P::SMOD29[i];
+    carry29<NL>(s, out);
+  }
 }
 // bring a lazily reduced value (< 8p, normalised limbs) to the canonical residue in [0, p)
 template <class P>
-MP_HD void canonical29(const uint32_t a[9], uint32_t out[9]) {
+MP_HD void canonical29(const uint32_t* a, uint32_t* out) {
+  constexpr int NL = P::NL29;
   if constexpr (P::DENSE29) {       // a in [0, 2p) with normalised limbs: one exact conditional subtraction of p
-    int32_t d[9];
-    uint32_t t[9];
+    int32_t d[NL];
+    uint32_t t[NL];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) d[i] = (int32_t)a[i] - (int32_t)P::MOD29[i];
-    carry29(d, t);
-    const bool neg = (int32_t)t[8] < 0;
+    for (int i = 0; i < NL; ++i) d[i] = (int32_t)a[i] - (int32_t)P::MOD29[i];
+    carry29<NL>(d, t);
+    const bool neg = (int32_t)t[NL - 1] < 0;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) out[i] = neg ? a[i] : t[i];
+    for (int i = 0; i < NL; ++i) out[i] = neg ? a[i] : t[i];
     return;
   }
-  int32_t s[9];
-  const int32_t q = (int32_t)(a[8] >> P::TOP29);
+  int32_t s[NL];
+  const int32_t q = (int32_t)(a[NL - 1] >> (P::DENSE29 ? 0 : P::TOP29));
 #pragma unroll
-  for (int i = 0; i < 9; ++i) s[i] = (int32_t)a[i] - (P::SMOD29[i] != 0 ? q * P::SMOD29[i] : 0);
-  uint32_t t[9];
-  carry29(s, t);
+  for (int i = 0; i < NL; ++i) s[i] = (int32_t)a[i] - (P::SMOD29[i] != 0 ? q * P::SMOD29[i] : 0);
+  uint32_t t[NL];
+  carry29<NL>(s, t);
   // now in (-p, p) (pseudo-Mersenne p = 2^256 - c: in [0, p + 8c)): add p back if negative
-  const int32_t neg = (int32_t)t[8] < 0 ? 1 : 0;
+  const int32_t neg = (int32_t)t[NL - 1] < 0 ? 1 : 0;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) s[i] = (int32_t)t[i] + (P::SMOD29[i] != 0 ? neg * P::SMOD29[i] : 0);
-  carry29(s, out);
+  for (int i = 0; i < NL; ++i) s[i] = (int32_t)t[i] + (P::SMOD29[i] != 0 ? neg * P::SMOD29[i] : 0);
+  carry29<NL>(s, out);
   if constexpr (P::PM29) {
     // 2^256 > p: the remainder below 2^256 may still be >= p.  t >= p  <=>  t + c >= 2^256
 #pragma unroll
@@ -217,27 +223,33 @@ MP_HD void canonical29(const uint32_t a[9], uint32_t out[9]) {
     s[0] += (int32_t)P::G0;
     s[1] += (int32_t)P::G1;
     uint32_t u[9];
-    carry29(s, u);
+    carry29<9>(s, u);
     const bool ge = (u[8] >> 24) != 0;
     u[8] &= 0x00FFFFFFu;
 #pragma unroll
     for (int i = 0; i < 9; ++i) out[i] = ge ? u[i] : out[i];
   }
 }
-MP_HD void pack29(const uint32_t l[9], uint32_t w[8]) {
+// NL limbs of 29 bits (normalised, value < 2^(32 NW)) <-> NW packed 32-bit words
+template <int NW, int NL>
+MP_HD void pack29(const uint32_t* l, uint32_t* w) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < NW; ++j) {
     const int k = (32 * j) / 29, off = (32 * j) % 29;
-    w[j] = (l[k] >> off) | (l[k + 1] << (29 - off));
+    uint32_t x = l[k] >> off;
+    if (k + 1 < NL) x |= l[k + 1] << (29 - off);
+    if (off > 26 && k + 2 < NL) x |= l[k + 2] << (58 - off);
+    w[j] = x;
   }
 }
-MP_HD void unpack29(const uint32_t w[8], uint32_t l[9]) {
+template <int NW, int NL>
+MP_HD void unpack29(const uint32_t* w, uint32_t* l) {
 #pragma unroll
-  for (int i = 0; i < 9; ++i) {
+  for (int i = 0; i < NL; ++i) {
     const int k = (29 * i) / 32, off = (29 * i) % 32;
-    uint32_t x = w[k] >> off;
-    if (off > 3 && k + 1 < 8) x |= w[k + 1] << (32 - off);
-    l[i] = i < 8 ? (x & M29) : x;
+    uint32_t x = k < NW ? w[k] >> off : 0u;
+    if (off > 3 && k + 1 < NW) x |= w[k + 1] << (32 - off);
+    l[i] = i < NL - 1 ? (x & M29) : x;
   }
 }
 // Montgomery product (R = 2^261): inputs with limbs < 2^29 and value < 4p, output in (0, 2p) with limbs < 2^29.
@@ -276,20 +288,21 @@ MP_HD void mont_sub_limb(uint64_t& acc, uint32_t m, int32_t pj) {
   }
 }
 template <class P, bool SQR>
-MP_HD void mont29(uint32_t r[9], const uint32_t a[9], const uint32_t b[9]) {
+MP_HD void mont29(uint32_t* r, const uint32_t* a, const uint32_t* b) {
+  constexpr int NL = P::NL29;
   constexpr uint32_t PINV = (0u - P::INV29) & M29;   // +p^-1 mod 2^29
-  uint32_t m[9], a2[9];
+  uint32_t m[NL], a2[NL];
   if (SQR) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) a2[i] = a[i] << 1;
+    for (int i = 0; i < NL; ++i) a2[i] = a[i] << 1;
   }
   uint64_t acc = 0;
 #pragma unroll
-  for (int k = 0; k < 17; ++k) {
+  for (int k = 0; k < 2 * NL - 1; ++k) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
+    for (int i = 0; i < NL; ++i) {
       const int j = k - i;
-      if (j < 0 || j > 8) continue;
+      if (j < 0 || j > NL - 1) continue;
       if (SQR) {
         if (j < i) continue;
         acc += (uint64_t)(i == j ? a[i] : a2[i]) * a[j];
@@ -299,71 +312,73 @@ MP_HD void mont29(uint32_t r[9], const uint32_t a[9], const uint32_t b[9]) {
       MP_CHAIN(acc);
     }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
+    for (int i = 0; i < NL; ++i) {
       const int j = k - i;
-      if (j < 1 || j > 8 || i >= k) continue;
+      if (j < 1 || j > NL - 1 || i >= k) continue;
       if (P::SMOD29[j] != 0) {
         mont_sub_limb<P>(acc, m[i], P::SMOD29[j]);
         MP_CHAIN(acc);
       }
     }
-    if (k >= 9 && P::SMOD29[k - 9] != 0) acc += (uint64_t)(int64_t)P::SMOD29[k - 9];   // + R p (limbs 0..7; limb 8 below)
-    if (k < 9) {
+    if (k >= NL && P::SMOD29[k - NL] != 0) acc += (uint64_t)(int64_t)P::SMOD29[k - NL];   // + R p (limbs 0..7; limb 8 below)
+    if (k < NL) {
       m[k] = ((uint32_t)acc * PINV) & M29;
       if (P::PM29) MP_OPAQUE(m[k]);
       if (P::SMOD29[0] != 1) mont_sub_limb<P>(acc, m[k], P::SMOD29[0]);
     } else {
-      r[k - 9] = (uint32_t)acc & M29;
+      r[k - NL] = (uint32_t)acc & M29;
     }
     acc = (uint64_t)((int64_t)acc >> 29);
   }
-  r[8] = (uint32_t)acc + (uint32_t)P::SMOD29[8];
+  r[NL - 1] = (uint32_t)acc + (uint32_t)P::SMOD29[NL - 1];
 }
 template <class P>
-MP_HD void mul29(uint32_t r[9], const uint32_t a[9], const uint32_t b[9]) {
+MP_HD void mul29(uint32_t* r, const uint32_t* a, const uint32_t* b) {
   mont29<P, false>(r, a, b);
 }
 // (a b + c d) / R with ONE reduction: both products go into the same column sums (18 limb products per column:
 // |acc| < 18 * 2^58 + 2^59 < 2^63), so the pair costs 162 + 18 mads instead of 2 x 99.  Inputs as for mul29, output in (0, 2p).
 template <class P>
-MP_HD void muladd29(uint32_t r[9], const uint32_t a[9], const uint32_t b[9], const uint32_t c[9], const uint32_t d[9]) {
+MP_HD void muladd29(uint32_t* r, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d) {
+  constexpr int NL = P::NL29;
+  static_assert(NL <= 9, "two products per column overflow the 64-bit accumulator beyond 9 limbs");
   constexpr uint32_t PINV = (0u - P::INV29) & M29;
-  uint32_t m[9];
+  uint32_t m[NL];
   uint64_t acc = 0;
 #pragma unroll
-  for (int k = 0; k < 17; ++k) {
+  for (int k = 0; k < 2 * NL - 1; ++k) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
+    for (int i = 0; i < NL; ++i) {
       const int j = k - i;
-      if (j < 0 || j > 8) continue;
+      if (j < 0 || j > NL - 1) continue;
       acc += (uint64_t)a[i] * b[j];
       MP_CHAIN(acc);
       acc += (uint64_t)c[i] * d[j];
       MP_CHAIN(acc);
     }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
+    for (int i = 0; i < NL; ++i) {
       const int j = k - i;
-      if (j < 1 || j > 8 || i >= k) continue;
+      if (j < 1 || j > NL - 1 || i >= k) continue;
       if (P::SMOD29[j] != 0) {
         mont_sub_limb<P>(acc, m[i], P::SMOD29[j]);
         MP_CHAIN(acc);
       }
     }
-    if (k >= 9 && P::SMOD29[k - 9] != 0) acc += (uint64_t)(int64_t)P::SMOD29[k - 9];
-    if (k < 9) {
+    if (k >= NL && P::SMOD29[k - NL] != 0) acc += (uint64_t)(int64_t)P::SMOD29[k - NL];
+    if (k < NL) {
       m[k] = ((uint32_t)acc * PINV) & M29;
       if (P::PM29) MP_OPAQUE(m[k]);
       if (P::SMOD29[0] != 1) mont_sub_limb<P>(acc, m[k], P::SMOD29[0]);
     } else {
-      r[k - 9] = (uint32_t)acc & M29;
+      r[k - NL] = (uint32_t)acc & M29;
     }
     acc = (uint64_t)((int64_t)acc >> 29);
   }
-  r[8] = (uint32_t)acc + (uint32_t)P::SMOD29[8];
+  r[NL - 1] = (uint32_t)acc + (uint32_t)P::SMOD29[NL - 1];
 }
 template <class P>
-MP_HD void sqr29(uint32_t r[9], const uint32_t a[9]) {
+MP_HD void sqr29(uint32_t* r, const uint32_t* a) {
   mont29<P, true>(r, a, a);
 }
 
@@ -374,7 +389,7 @@ template <class P>
 MP_HD Fe<P> fe_zero() {
   Fe<P> r;
 #pragma unroll
-  for (int i = 0; i < (P::L29 ? 9 : P::NW); ++i) r.v[i] = 0;
+  for (int i = 0; i < (P::L29 ? P::NL29 : P::NW); ++i) r.v[i] = 0;
   return r;
 }
 template <class P>
@@ -382,7 +397,7 @@ MP_HD Fe<P> fe_one() {
   Fe<P> r;
   if constexpr (P::L29) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) r.v[i] = P::R1_29[i];
+    for (int i = 0; i < P::NL29; ++i) r.v[i] = P::R1_29[i];
   } else {
 #pragma unroll
     for (int i = 0; i < P::NW; ++i) r.v[i] = P::R1[i];
@@ -410,7 +425,7 @@ MP_HD bool fe_is_zero(const Fe<P>& a) {
     if (a.v[0] != 0u && a.v[0] != P::MOD29[0]) return false;
     uint32_t z = 0, e = 0;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
+    for (int i = 0; i < P::NL29; ++i) {
       z |= a.v[i];
       e |= a.v[i] ^ P::MOD29[i];
     }
@@ -420,13 +435,13 @@ MP_HD bool fe_is_zero(const Fe<P>& a) {
     // Fast path: where p has a zero limb, so has k*p -- almost every non-zero value is rejected by one OR chain.
     uint32_t z = 0;
 #pragma unroll
-    for (int i = 0; i < 9; ++i)
+    for (int i = 0; i < P::NL29; ++i)
       if (P::MOD29[i] == 0) z |= a.v[i];
     if (z != 0) return false;
-    const uint32_t k = a.v[8] >> P::TOP29;
+    const uint32_t k = a.v[P::NL29 - 1] >> P::TOP29;
     uint32_t o = 0;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) o |= a.v[i] ^ (k * P::MOD29[i]);
+    for (int i = 0; i < P::NL29; ++i) o |= a.v[i] ^ (k * P::MOD29[i]);
     return o == 0;
   } else {
     uint32_t o = 0;
@@ -439,9 +454,9 @@ template <class P>
 MP_HD Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
   Fe<P> r;
   if constexpr (P::L29) {
-    int32_t s[9];
+    int32_t s[P::NL29];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) s[i] = (int32_t)(a.v[i] + b.v[i]);
+    for (int i = 0; i < P::NL29; ++i) s[i] = (int32_t)(a.v[i] + b.v[i]);
     reduce_carry29<P>(s, r.v);
   } else {
     uint32_t s[P::NW];
@@ -461,9 +476,9 @@ MP_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
   Fe<P> r;
   if constexpr (P::L29) {
     // a - b + 4p in (0, 8p)
-    int32_t s[9];
+    int32_t s[P::NL29];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) s[i] = (int32_t)a.v[i] - (int32_t)b.v[i] + (P::DENSE29 ? 2 : 4) * P::SMOD29[i];   // + 4p (dense primes: values < 2p, + 2p)
+    for (int i = 0; i < P::NL29; ++i) s[i] = (int32_t)a.v[i] - (int32_t)b.v[i] + (P::DENSE29 ? 2 : 4) * P::SMOD29[i];   // + 4p (dense primes: values < 2p, + 2p)
     reduce_carry29<P>(s, r.v);
   } else {
     uint32_t d[P::NW];
@@ -529,10 +544,26 @@ template <class P>
 MP_HD_NOINLINE void mul32_call(uint32_t* r, const uint32_t* a, const uint32_t* b) {
   mul32<P>(r, a, b);
 }
+// the same for the 14-limb product of the 29-bit form (BLS12-377 Fq: 196 + 182 multiply-adds)
+// (operands and result by value: they travel in registers, not through the stack)
+template <class P>
+MP_HD_NOINLINE Fe<P> mul29_call(Fe<P> a, Fe<P> b) {
+  Fe<P> r;
+  mul29<P>(r.v, a.v, b.v);
+  return r;
+}
+template <class P>
+MP_HD_NOINLINE Fe<P> sqr29_call(Fe<P> a) {
+  Fe<P> r;
+  sqr29<P>(r.v, a.v);
+  return r;
+}
 template <class P>
 MP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
   Fe<P> r;
-  if constexpr (P::L29)
+  if constexpr (P::L29 && P::NL29 > 9)
+    return mul29_call<P>(a, b);
+  else if constexpr (P::L29)
     mul29<P>(r.v, a.v, b.v);
   else if constexpr (P::NW > 8)
     mul32_call<P>(r.v, a.v, b.v);
@@ -543,7 +574,7 @@ MP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
 // a b - c d (one reduction for the pair in the 29-bit form)
 template <class P>
 MP_HD Fe<P> fe_mulsub(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d) {
-  if constexpr (P::L29) {
+  if constexpr (P::L29 && P::NL29 <= 9) {
     Fe<P> r;
     const Fe<P> nc = fe_neg<P>(c);
     muladd29<P>(r.v, a.v, b.v, nc.v, d.v);
@@ -555,7 +586,9 @@ MP_HD Fe<P> fe_mulsub(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P
 template <class P>
 MP_HD Fe<P> fe_sqr(const Fe<P>& a) {
   Fe<P> r;
-  if constexpr (P::L29)
+  if constexpr (P::L29 && P::NL29 > 9)
+    return sqr29_call<P>(a);
+  else if constexpr (P::L29)
     sqr29<P>(r.v, a.v);
   else if constexpr (P::NW > 8)
     mul32_call<P>(r.v, a.v, a.v);
@@ -569,7 +602,7 @@ template <class P>
 MP_HD Fe<P> fe_unpack(const uint32_t* w) {
   Fe<P> r;
   if constexpr (P::L29) {
-    unpack29(w, r.v);
+    unpack29<P::NW, P::NL29>(w, r.v);
   } else {
 #pragma unroll
     for (int i = 0; i < P::NW; ++i) r.v[i] = w[i];
@@ -579,9 +612,9 @@ MP_HD Fe<P> fe_unpack(const uint32_t* w) {
 template <class P>
 MP_HD void fe_pack(const Fe<P>& a, uint32_t* w) {
   if constexpr (P::L29) {
-    uint32_t c[9];
+    uint32_t c[P::NL29];
     canonical29<P>(a.v, c);
-    pack29(c, w);
+    pack29<P::NW, P::NL29>(c, w);
   } else {
 #pragma unroll
     for (int i = 0; i < P::NW; ++i) w[i] = a.v[i];
@@ -594,7 +627,7 @@ MP_HD Fe<P> fe_from_canonical(const uint32_t* a) {
   Fe<P> t = fe_unpack<P>(a), r2;
   if constexpr (P::L29) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) r2.v[i] = P::R2_29[i];
+    for (int i = 0; i < P::NL29; ++i) r2.v[i] = P::R2_29[i];
   } else {
 #pragma unroll
     for (int i = 0; i < P::NW; ++i) r2.v[i] = P::R2[i];
@@ -744,9 +777,9 @@ MP_HD Fe<P> fe_inv_divsteps(const Fe<P>& a) {
   constexpr int BATCHES = P::BITS <= 256 ? 21 : ((49 * P::BITS + 80) / 17 + 28) / 29;
   uint32_t xw[NW];
   if constexpr (P::L29) {
-    uint32_t c[9];
+    uint32_t c[P::NL29];
     canonical29<P>(a.v, c);                           // the residue a R mod p as an integer in [0, p)
-    pack29(c, xw);
+    pack29<NW, P::NL29>(c, xw);
   } else {
 #pragma unroll
     for (int i = 0; i < NW; ++i) xw[i] = a.v[i];      // canonical Montgomery residue already
@@ -808,8 +841,9 @@ MP_HD Fe<P> fe_inv_divsteps(const Fe<P>& a) {
   // d = (a R)^-1 as an integer; a^-1 R = d R^2
   if constexpr (P::L29) {
     Fe<P> y, r2;
+    static_assert(!P::L29 || NL == P::NL29, "the division steps work on the field's own limb count");
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
+    for (int i = 0; i < NL; ++i) {
       y.v[i] = (uint32_t)d[i];
       r2.v[i] = P::R2_29[i];
     }

@@ -1,4 +1,4 @@
-// host check of the base-field arithmetic (field.hpp: 9x29 sparse / signed-sparse / dense lazy limbs, 8x32 and 12x32 words) against an
+// host check of the base-field arithmetic (field.hpp: 9x29 sparse / signed-sparse / dense and 14x29 dense lazy limbs, 8x32 words) against an
 // independent schoolbook big-integer reference (multi-word product, remainder by shift-and-subtract): products, squares, fused
 // a b - c d, sums and differences of LAZILY reduced operands (chains of additions and subtractions that leave values anywhere in the
 // representation's allowed range), zero tests on every representative of zero a chain can produce, pack / unpack round trips.
@@ -179,7 +179,7 @@ int main(int argc, char** argv) {
   bad += check<Stark::FqP>("stark Fq (9x29 sparse)", count);
   bad += check<Secp256k1::FqP>("secp256k1 Fq (9x29 signed sparse)", count);
   bad += check<Bn254::FqP>("bn254 Fq (9x29 dense)", count);
-  bad += check<Bls12_377::FqP>("bls12-377 Fq (12x32)", count / 2);
+  bad += check<Bls12_377::FqP>("bls12-377 Fq (14x29 dense)", count / 2);
   bad += check<Stark::FrP>("stark Fr (8x32)", count);
   bad += check<Bn254::FrP>("bn254 Fr (8x32)", count);
   return bad ? 1 : 0;

@@ -42,7 +42,7 @@ def test_self_launch_two_ranks_equals_unsharded():
 
 
 def test_json_line_contract_and_extras():
-    d = run_bench("--batch", "4096", "--steps", "2", "--warmup", "1", "--fb-bits", "8", "--cpu-iters", "2")
+    d = run_bench("--batch", "16384", "--steps", "2", "--warmup", "1", "--fb-bits", "8", "--cpu-iters", "2")      # (throughput plan: > 14 336 proofs)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d

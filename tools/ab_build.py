@@ -29,7 +29,8 @@ def main():
     csrc = os.path.join(ROOT, "mental-poker_amd", "csrc")
     objdir = os.path.join(ROOT, "tools", "ab", "obj_" + name)
     os.makedirs(objdir, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-sched-strategy=max-ilp"] + extra
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+             "-mllvm", "-pragma-unroll-threshold=1000000"] + extra    # same flags as mental-poker_amd/_native.py
 
     def cc(u):
         obj = os.path.join(objdir, u.replace(".hip", ".o"))

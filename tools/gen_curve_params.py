@@ -33,8 +33,13 @@ def limbs(v, n=8):
     return "{" + ", ".join("0x%08xu" % ((v >> (32 * i)) & 0xFFFFFFFF) for i in range(n)) + "}"
 
 
-def limbs29(v):
-    return "{" + ", ".join("0x%08xu" % ((v >> (29 * i)) & ((1 << 29) - 1 if i < 8 else 0xFFFFFFFF)) for i in range(9)) + "}"
+def nl29(p):
+    """limbs of the 29-bit form: room for values below 4p"""
+    return (p.bit_length() + 2 + 28) // 29
+
+
+def limbs29(v, nl=9):
+    return "{" + ", ".join("0x%08xu" % ((v >> (29 * i)) & ((1 << 29) - 1 if i < nl - 1 else 0xFFFFFFFF)) for i in range(nl)) + "}"
 
 
 def is_l29(p):
@@ -54,6 +59,7 @@ def is_pm29(p):
 
 
 BN254_P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+BLS12_377_P = 0x01ae3a4617c510eac63b05c06ca1493b1a22d9f300f5138f1ef3622fba094800170b5d44300000008508c00000000001
 
 
 def is_dense29(p):
@@ -61,12 +67,12 @@ def is_dense29(p):
     9 quotient digits against the 136 multiply-adds + 128 carry additions of the 8x32 product), values kept below 2p, the weak
     reduction of an addition subtracts k p, k in {0..3}, with k from a one-multiply quotient estimate.  Used for the base field of
     bn254 (BASELINE config 1 names ark-bn254); the scalar fields stay on 8x32 because `Fr::rand` defines their Montgomery form."""
-    return p == BN254_P
+    return p in (BN254_P, BLS12_377_P)
 
 
 def field_R(p):
-    """the Montgomery constant R of the in-memory residue a R mod p"""
-    return 1 << (261 if (is_l29(p) or is_pm29(p) or is_dense29(p)) else 32 * nwords(p))
+    """the Montgomery constant R of the in-memory residue a R mod p: 2^(29 limbs) in the 29-bit form, 2^(32 words) otherwise"""
+    return 1 << (29 * nl29(p) if (is_l29(p) or is_pm29(p) or is_dense29(p)) else 32 * nwords(p))
 
 
 def slimbs29(v):
@@ -92,22 +98,34 @@ def field(name, p):
     if dense:
         l29 = True
     s += "  static constexpr bool DENSE29 = %s;          // ... for a prime without structure: values < 2p, quotient estimate by one multiply\n" % ("true" if dense else "false")
+    nl = nl29(p)
+    s += "  static constexpr int NL29 = %d;               // limbs of the 29-bit form\n" % nl
     if l29:
         if dense:
-            # q_est = umulhi(top limb + 4, QREC) is never below floor(v / p) and at most one above it for v < 4p (field.hpp)
-            s += "  static constexpr uint32_t QREC = %du;         // floor(2^264 / p) + 1\n" % (((1 << 264) // p) + 1)
-        s += "  static constexpr uint32_t MOD29[9] = %s;\n" % limbs29(p)
+            # t = (top limb << QHI) + (next limb >> QLO) = floor(v / 2^QBIT) up to the carries, with p / 2^QBIT ~ 2^21;
+            # q_est = umulhi(t + 4, QREC) is never below floor(v / p) and at most one above it for v < 4p (field.hpp)
+            qbit = p.bit_length() - 22
+            top_bit = 29 * (nl - 1)
+            if qbit >= top_bit:
+                assert qbit == top_bit or p.bit_length() - top_bit >= 20
+                qbit, qhi, qlo = top_bit, 0, 29
+            else:
+                qhi, qlo = top_bit - qbit, 29 - (top_bit - qbit)
+                assert 0 < qhi < 29 and (4 * p >> qbit) < (1 << 30)
+            s += "  static constexpr int QHI = %d, QLO = %d;       // quotient estimate: t = (top limb << QHI) + (next limb >> QLO)   (QLO = 29: top limb alone)\n" % (qhi, qlo)
+            s += "  static constexpr uint32_t QREC = %du;         // floor(2^(32 + %d) / p) + 1\n" % (((1 << (32 + qbit)) // p) + 1, qbit)
+        s += "  static constexpr uint32_t MOD29[%d] = %s;\n" % (nl, limbs29(p, nl))
         if pm:
             c = (1 << 256) - p
             sm = [-(c & ((1 << 29) - 1)), -(c >> 29), 0, 0, 0, 0, 0, 0, 1 << 24]
         else:
-            sm = [(p >> (29 * i)) & ((1 << 29) - 1 if i < 8 else 0xFFFFFFFF) for i in range(9)]
+            sm = [(p >> (29 * i)) & ((1 << 29) - 1 if i < nl - 1 else 0xFFFFFFFF) for i in range(nl)]
         assert sum(x << (29 * i) for i, x in enumerate(sm)) == p
-        s += "  static constexpr int32_t SMOD29[9] = %s;   // p as signed sparse 29-bit limbs: sum SMOD29[i] 2^(29 i) = p\n" % slimbs29(sm)
-        s += "  static constexpr uint32_t R1_29[9] = %s;   // R mod p, 29-bit limbs\n" % limbs29(R % p)
-        s += "  static constexpr uint32_t R2_29[9] = %s;   // R^2 mod p, 29-bit limbs\n" % limbs29(R * R % p)
+        s += "  static constexpr int32_t SMOD29[%d] = %s;   // p as signed sparse 29-bit limbs: sum SMOD29[i] 2^(29 i) = p\n" % (nl, slimbs29(sm))
+        s += "  static constexpr uint32_t R1_29[%d] = %s;   // R mod p, 29-bit limbs\n" % (nl, limbs29(R % p, nl))
+        s += "  static constexpr uint32_t R2_29[%d] = %s;   // R^2 mod p, 29-bit limbs\n" % (nl, limbs29(R * R % p, nl))
         s += "  static constexpr uint32_t INV29 = 0x%08xu;   // -p^{-1} mod 2^29\n" % ((-pow(p, -1, 1 << 29)) % (1 << 29))
-        s += "  static constexpr int TOP29 = %d;             // p's top (signed) limb is 2^TOP29\n" % (24 if pm else ((p >> 232)).bit_length() - 1)
+        s += "  static constexpr int TOP29 = %d;             // p's top (signed) limb is 2^TOP29\n" % (24 if pm else ((p >> (29 * (nl - 1)))).bit_length() - 1)
     s += "  static constexpr uint32_t MOD[%d] = %s;\n" % (nw, limbs(p, nw))
     s += "  static constexpr uint32_t R1[%d] = %s;   // R mod p\n" % (nw, limbs(R % p, nw))
     s += "  static constexpr uint32_t R2[%d] = %s;   // R^2 mod p\n" % (nw, limbs(R * R % p, nw))

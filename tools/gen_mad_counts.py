@@ -122,22 +122,31 @@ def main(flags):
         # VALU issue classes of the field operations and of the group operations of the MSM loops (probe_madd / probe_dbl: main path)
         cname = {"stark": "Stark", "bn254": "Bn254", "secp256k1": "Secp256k1", "bls12_377": "Bls12_377"}[cv]
         issue = {}
-        def with_callees(sym, body):
+        # out-of-line field products (the 14-limb form of BLS12-377): calls per operation from the formulas of curve.hpp / field.hpp
+        # (checked against the number of s_swappc_b64 in the body), callee bodies counted once per call
+        a0 = 0 if a == 0 else 1
+        CALLS = {"mul": (1, 0), "sqr": (0, 1), "mulsub": (2, 0), "madd": (8, 2), "dbl": (6, 3 + a0), "xadd": (12, 2)}
+
+        def with_callees(sym, body, kind):
             h, f = valu_classes(body)
-            for callee in fn:                     # the out-of-line 12-limb product
-                if callee != sym and callee in body:
-                    k = len(re.findall(r"^\s*s_swappc_b64", body, flags=re.M))
+            ncall = len(re.findall(r"^\s*s_swappc_b64", body, flags=re.M))
+            if ncall == 0:
+                return h, f
+            nm, ns = CALLS[kind]
+            assert nm + ns == ncall, (sym, kind, ncall)
+            for callee, k in ((c_, k_) for c_ in fn for k_ in [nm if "mul29_call" in c_ or "mul32_call" in c_ else ns if "sqr29_call" in c_ else 0]):
+                if k and callee != sym and callee in body:
                     ch, cf = valu_classes(fn[callee])
                     h, f = h + k * ch, f + k * cf
             return h, f
         for kind, tag in (("mul", fq), ("sqr", fq), ("mulsub", fq)):
             for sym, body in fn.items():
                 if ("%dprobe_%sI" % (len(kind) + 6, kind)) in sym and tag in sym:
-                    issue[kind] = with_callees(sym, body)
+                    issue[kind] = with_callees(sym, body, kind)
         for kind in ("madd", "dbl", "xadd"):
             for sym, body in fn.items():
                 if ("%dprobe_%sI" % (len(kind) + 6, kind)) in sym and ("_%d%sE" % (len(cname), cname)) in sym:
-                    issue[kind] = with_callees(sym, body)
+                    issue[kind] = with_callees(sym, body, kind)
         res[cv]["valu_issue"] = {k: {"half_rate": v[0], "full_rate": v[1], "cycles": 4 * v[0] + 2 * v[1]} for k, v in issue.items()}
     json.dump({"_valu_issue_note": "valu_issue: VALU instructions per operation by issue class in the gfx950 assembly (full_rate: v_add/sub/subrev_u32, v_and/or/xor/not/mov_b32, v_ashrrev_i32, v_lshrrev_b32 = 2 cycles of a SIMD's issue port per wave64 instruction; half_rate: every other VALU instruction = 4 cycles; classes measured by tools/microbench/roof.hip -> profiles/r03_roof.json); cycles = 4 half + 2 full = the ideal issue time of the operation on one SIMD", "_note": "v_mad_u64_u32 + v_mad_i64_i32 per base-field product / square / fused a*b-c*d (fr_mul: scalar-field product) in "
                         "the gfx950 assembly of tools/madprobe/mad_probe.hip; inv_sqr / inv_mul = operations of the Fermat inversion chain (no longer used by the kernels); inv_divsteps_mads = the division-step inversion. "
@@ -146,4 +155,4 @@ def main(flags):
 
 
 if __name__ == "__main__":
-    print(json.dumps(main(["--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]), indent=1))
+    print(json.dumps(main(["--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-pragma-unroll-threshold=1000000"]), indent=1))

@@ -7,12 +7,12 @@ namespace mp {
 template <class F>
 __device__ __forceinline__ Fe<F> probe_ld(const uint32_t* p) {
   Fe<F> a;
-  for (int i = 0; i < (F::L29 ? 9 : F::NW); ++i) a.v[i] = p[i];
+  for (int i = 0; i < (F::L29 ? F::NL29 : F::NW); ++i) a.v[i] = p[i];
   return a;
 }
 template <class F>
 __device__ __forceinline__ void probe_st(uint32_t* p, const Fe<F>& a) {
-  for (int i = 0; i < (F::L29 ? 9 : F::NW); ++i) p[i] = a.v[i];
+  for (int i = 0; i < (F::L29 ? F::NL29 : F::NW); ++i) p[i] = a.v[i];
 }
 template <class F>
 __global__ void probe_mul(uint32_t* io) {

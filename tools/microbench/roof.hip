@@ -230,7 +230,7 @@ typedef Stark StarkC;
 template <class F>
 __device__ __forceinline__ Fe<F> mk(uint32_t s) {
   Fe<F> a;
-  constexpr int N = F::L29 ? 9 : F::NW;
+  constexpr int N = F::L29 ? F::NL29 : F::NW;
   for (int i = 0; i < N; ++i) a.v[i] = (s * (2654435761u + 2 * i) + i * 40503u) & (F::L29 ? 0x0fffffffu : 0xffffffffu);
   if (!F::L29) a.v[N - 1] &= 0x03ffffffu;   // < p for every 8x32 field used here
   return a;
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256, OCC) k_field(Stamp* st, uint32_t* out, ui
     }
   }
   stamp_end(st, c0, r0);
-  constexpr int N = F::L29 ? 9 : F::NW;
+  constexpr int N = F::L29 ? F::NL29 : F::NW;
   uint32_t r = 0;
   for (int i = 0; i < N; ++i) r ^= a.v[i] ^ b.v[i] ^ c.v[i] ^ d.v[i];
   out[tid] = r;
