@@ -724,8 +724,10 @@ def main():
         vw, fw = stats["var_windows"], stats["fixed_windows"]
         ops = None                      # per proof pair (prove + verify launches of one step), lane level
         if dom_name == "k_var_msm":
-            ops = {"madd": sum(stats[s_]["var_terms"] for s_ in ("prove", "verify")) * vw,
-                   "dbl": sum(stats[s_]["var_jobs"] for s_ in ("prove", "verify")) * (vw - 1) * 5}
+            # (chain32 with chain verification: the verifier's equation runs on the bucket kernel, only the prover uses k_var_msm)
+            sides = ("prove",) if (workload == "chain32" and not args.per_link_verify) else ("prove", "verify")
+            ops = {"madd": sum(stats[s_]["var_terms"] for s_ in sides) * vw,
+                   "dbl": sum(stats[s_]["var_jobs"] for s_ in sides) * (vw - 1) * 5}
         elif dom_name == "k_fixed_msm":
             ops = {"madd": sum(stats[s_]["fixed_terms"] for s_ in ("prove", "verify")) * fw - N * (fw - 1)}
         elif dom_name == "k_remask":
@@ -778,6 +780,8 @@ def main():
             compute["issue_slots"]["frac_at_measured_clock"] = min(1.0, compute["issue_slots"]["achieved_G_wave_insts_per_s"] / (SIMDS * e_["clock_mhz"] / 1e3 / 4.0))
         if compute and e_.get("SQ_INSTS_VALU_per_launch"):
             compute["valu_insts_per_launch_pmc"] = e_["SQ_INSTS_VALU_per_launch"]
+            # measured, not modelled: SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x shader cycles of the dispatch), same PMC pass
+            compute["issue_slots"]["measured_pmc"] = e_.get("valu_slot_utilisation")
     roofline = {
         "bound": "hbm", "kernel": dom_name, "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

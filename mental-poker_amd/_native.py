@@ -73,7 +73,7 @@ def build(verbose=False):
         res = list(ex.map(compile_one, SOURCES))
     objs = [r[0] for r in res]
     if any(r[1] for r in res) or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(o) for o in objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB_PATH] + objs      # serialize_host.hpp uses std::thread
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -544,26 +544,13 @@ template <class P>
 MP_HD_NOINLINE void mul32_call(uint32_t* r, const uint32_t* a, const uint32_t* b) {
   mul32<P>(r, a, b);
 }
-// the same for the 14-limb product of the 29-bit form (BLS12-377 Fq: 196 + 182 multiply-adds)
-// (operands and result by value: they travel in registers, not through the stack)
-template <class P>
-MP_HD_NOINLINE Fe<P> mul29_call(Fe<P> a, Fe<P> b) {
-  Fe<P> r;
-  mul29<P>(r.v, a.v, b.v);
-  return r;
-}
-template <class P>
-MP_HD_NOINLINE Fe<P> sqr29_call(Fe<P> a) {
-  Fe<P> r;
-  sqr29<P>(r.v, a.v);
-  return r;
-}
+// (the 14-limb product of the 29-bit form -- BLS12-377 Fq, 196 + 168 multiply-adds -- is inlined like the 9-limb ones: with the
+// loops fully unrolled its translation unit compiles in 90 s, and kept out of line it cost the group law its registers: 812 bytes of
+// stack per lane in every kernel against none inlined)
 template <class P>
 MP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
   Fe<P> r;
-  if constexpr (P::L29 && P::NL29 > 9)
-    return mul29_call<P>(a, b);
-  else if constexpr (P::L29)
+  if constexpr (P::L29)
     mul29<P>(r.v, a.v, b.v);
   else if constexpr (P::NW > 8)
     mul32_call<P>(r.v, a.v, b.v);
@@ -586,9 +573,7 @@ MP_HD Fe<P> fe_mulsub(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P
 template <class P>
 MP_HD Fe<P> fe_sqr(const Fe<P>& a) {
   Fe<P> r;
-  if constexpr (P::L29 && P::NL29 > 9)
-    return sqr29_call<P>(a);
-  else if constexpr (P::L29)
+  if constexpr (P::L29)
     sqr29<P>(r.v, a.v);
   else if constexpr (P::NW > 8)
     mul32_call<P>(r.v, a.v, a.v);

@@ -158,14 +158,31 @@ struct WaveCtx {
     BODY<C>(a, wid, wv);                                                                       \
   }
 #define MP_WAVE_KERNEL_INST(X, NAME, ARGS, C) X MP_GLOBAL void NAME<C>(ARGS, uint32_t, uint32_t);
-// waves per workgroup: as many (<= 4) as fit twice into the CU's 160 KB of LDS
+// LDS a workgroup may use on the current device (gfx950: 160 KB per CU; queried, so that a part with less fails with a message)
+namespace mp {
+namespace rt {
+inline size_t lds_per_workgroup() {
+  static size_t v = 0;
+  if (!v) {
+    int dev = 0, b = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&b, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || b <= 0)
+      b = 64 * 1024;
+    v = (size_t)b;
+  }
+  return v;
+}
+}  // namespace rt
+}  // namespace mp
+// waves per workgroup: as many (<= 4) as fit twice into the CU's LDS
 #define MP_WAVE_LAUNCH(NAME, C, stream, nwaves, lds_words, args)                                                              \
   do {                                                                                                                        \
     if ((nwaves) > 0) {                                                                                                       \
-      const size_t bytes_ = (size_t)(lds_words) * 4;                                                                          \
+      const size_t bytes_ = (size_t)(lds_words) * 4, cap_ = mp::rt::lds_per_workgroup();                                      \
       uint32_t wpb_ = 4;                                                                                                      \
-      while (wpb_ > 1 && wpb_ * bytes_ > 80u * 1024u) wpb_ >>= 1;                                                             \
-      if (wpb_ * bytes_ > 160u * 1024u) throw std::runtime_error(#NAME ": work item does not fit the LDS");                    \
+      while (wpb_ > 1 && wpb_ * bytes_ > cap_ / 2) wpb_ >>= 1;                                                                \
+      if (wpb_ * bytes_ > cap_)                                                                                               \
+        throw std::runtime_error(#NAME ": one work item needs " + std::to_string(bytes_) + " bytes of LDS, the device offers " + \
+                                 std::to_string(cap_) + " per workgroup (fewer terms per MSM / links per chain equation)");      \
       if (wpb_ * bytes_ > 64u * 1024u)                                                                                        \
         mp::rt::check(hipFuncSetAttribute(reinterpret_cast<const void*>(&NAME<C>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                           (int)(wpb_ * bytes_)), "LDS size attribute");                                       \

@@ -210,6 +210,33 @@ def test_division_step_inversion_matches_fermat():
     assert out.count(" 0 mismatches, 0 answered by the fallback") == 6, out
 
 
+@pytest.mark.parametrize("cvn", ["stark", "bn254", "secp256k1", "bls12_377"])
+def test_emulated_edge_inputs(emu, cvn):
+    """identity permutation, rho in {0, 1, q-1}, duplicate cards, a card and its negative, a point-at-infinity component: the kernel
+    bodies under emulation give the Python oracle's bytes on every base-field form (equal points meet as P + P and P - P in the window
+    tables and accumulators, where a lazily reduced zero has to be recognised) in all three work splits"""
+    import mp_oracle as po
+    m, n = 2, 3
+    cv = po.CURVES[cvn]
+    with po.curve_ctx(cv):
+        pp, pk, deck, rho, perm, ps = po.gen_inputs(cv, m, n, 42)
+        deck[1] = deck[0]
+        deck[2] = (None, deck[2][1])
+        deck[4] = (deck[3][0], po.pt_neg(cv, deck[3][1]))
+        rho = [0, 1, cv.q - 1, rho[3], rho[4], 0]
+        perm = list(range(m * n))
+        sh, pf = po.shuffle_and_remask(pp, pk, deck, rho, perm, ps)
+        want_deck, want_proof, wdeck, wparams, wpk = po.deck_to_bytes(sh), po.proof_to_bytes(pf), po.deck_to_bytes(deck), po.params_to_bytes(pp), po.pt_wire(pk)
+    eng = emu(cvn)
+    t = eng.table(m, n, wparams, wpk)
+    rho_b = b"".join(r.to_bytes(32, "little") for r in rho)
+    for latency_batch in (8192, 8, 0):
+        t.set_latency_batch(latency_batch)
+        d, p = t.shuffle_and_remask(wdeck, rho_b, perm, ps)
+        assert d == want_deck and p == want_proof
+        assert t.verify_shuffle(wdeck, d, p) == 0
+
+
 def test_field_arithmetic_matches_bigint_reference():
     """field.hpp (9x29 sparse / signed-sparse / dense lazy limbs, 8x32, 12x32) against an independent schoolbook big-integer reference:
     products, squares, fused a b - c d, chains of lazily reduced sums and differences, zero tests, packed round trips"""

@@ -115,6 +115,11 @@ def main():
                 e["duration_ms_per_launch_sq_pass"] = dur[0] / dur[1] * 1e-6
                 # GRBM_GUI_ACTIVE is summed over the 8 XCDs; shader cycles of one XCD / wall time of the dispatch = effective clock
                 e["clock_mhz"] = e["GRBM_GUI_ACTIVE_per_launch"] / 8.0 / (dur[0] / dur[1]) * 1e3
+                if "SQ_INSTS_VALU_per_launch" in e:
+                    # wave-level VALU instructions / (1024 SIMDs x one 4-cycle issue slot per instruction) over the shader cycles of the
+                    # dispatch: 1.0 = every SIMD issued a VALU instruction in every slot of the kernel (two 2-cycle instructions can
+                    # share a slot in runs of their own kind, so a value slightly above 1 is possible)
+                    e["valu_slot_utilisation"] = e["SQ_INSTS_VALU_per_launch"] * 4.0 / (1024.0 * e["GRBM_GUI_ACTIVE_per_launch"] / 8.0)
             kernels[k] = e
         wl = pb["config"]["workload"]
         mm = re.search(r"m=(\d+) n=(\d+), (\w+) curve", wl)
@@ -134,7 +139,9 @@ def main():
         json.dump(meta, open(os.path.join(prof, tag + "_pmc_summary.json"), "w"), indent=1)
         for k, v in list(kernels.items())[:8]:
             extra = ""
-            if "SQ_INSTS_VALU_per_launch" in v and "SQ_BUSY_CYCLES_per_launch" in v:
+            if "valu_slot_utilisation" in v:
+                extra = "  clock %.0f MHz  VALU issue slots used %.3f" % (v["clock_mhz"], v["valu_slot_utilisation"])
+            elif "SQ_INSTS_VALU_per_launch" in v and "SQ_BUSY_CYCLES_per_launch" in v:
                 extra = "  VALU insts/launch %.3g  wave-cycles %.3g  wait_any %.3g  wait_inst %.3g" % (
                     v["SQ_INSTS_VALU_per_launch"], v.get("SQ_WAVE_CYCLES_per_launch", 0), v.get("SQ_WAIT_ANY_per_launch", 0),
                     v.get("SQ_WAIT_INST_ANY_per_launch", 0))
