@@ -218,26 +218,36 @@ MP_HD void xyzz_dbl_ip(Xyzz<C>& p) {
   Fe<F> M = fe_add<F>(fe_dbl<F>(XX), XX);
   if (C::A == 1) M = fe_add<F>(M, fe_sqr<F>(p.ZZ));
   const Fe<F> X3 = fe_sub<F>(fe_sqr<F>(M), fe_dbl<F>(S));
-  p.Y = fe_mulsub<F>(M, fe_sub<F>(S, X3), W, p.Y);
+  p.Y = fe_mulsub<F>(M, fe_sub_lazy<F>(S, X3), W, p.Y);      // the difference only feeds this product: no carry pass (field.hpp LazySub)
   p.X = X3;
   p.ZZ = fe_mul<F>(V, p.ZZ);
   p.ZZZ = fe_mul<F>(W, p.ZZZ);
 }
 // PROBE = true (tools/madprobe only): the P + P case does not expand the doubling, so that the compiled function is the
 // main path plus the tests -- what a lane executes per mixed addition
+// p <- p + q or p - q (neg).  The negated y only feeds one product, so on the sparse prime it is formed without a carry pass
+// (field.hpp LazySub); the rare paths that keep y normalise it.
 template <class C, bool PROBE = false>
-MP_HD void xyzz_madd_ip(Xyzz<C>& p, const Aff<C>& q) {
+MP_HD void xyzz_madd_signed_ip(Xyzz<C>& p, const Aff<C>& q, bool neg) {
   typedef typename C::FqP F;
   if (aff_is_inf<C>(q)) return;
   if (fe_is_zero(p.ZZ)) {
     p.X = q.x;
-    p.Y = q.y;
+    p.Y = neg ? fe_neg<F>(q.y) : q.y;
     p.ZZ = fe_one<F>();
     p.ZZZ = fe_one<F>();
     return;
   }
+  Fe<F> qy = q.y;
+  if constexpr (LazySub<F>::ON) {
+    const Fe<F> ny = fe_neg_lazy<F>(q.y);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) qy.v[i] = neg ? ny.v[i] : q.y.v[i];
+  } else {
+    if (neg) qy = fe_neg<F>(q.y);
+  }
   const Fe<F> Pd = fe_sub<F>(fe_mul<F>(q.x, p.ZZ), p.X);
-  const Fe<F> Rr = fe_sub<F>(fe_mul<F>(q.y, p.ZZZ), p.Y);
+  const Fe<F> Rr = fe_sub<F>(fe_mul<F>(qy, p.ZZZ), p.Y);
   if (fe_is_zero(Pd)) {
     if (!PROBE && fe_is_zero(Rr)) {
       xyzz_dbl_ip<C>(p);         // P + P
@@ -251,10 +261,14 @@ MP_HD void xyzz_madd_ip(Xyzz<C>& p, const Aff<C>& q) {
   const Fe<F> PPP = fe_mul<F>(Pd, PP);
   const Fe<F> Q = fe_mul<F>(p.X, PP);
   const Fe<F> X3 = fe_sub<F>(fe_sub<F>(fe_sqr<F>(Rr), PPP), fe_dbl<F>(Q));
-  p.Y = fe_mulsub<F>(Rr, fe_sub<F>(Q, X3), p.Y, PPP);     // one reduction for the two products
+  p.Y = fe_mulsub<F>(Rr, fe_sub_lazy<F>(Q, X3), p.Y, PPP);     // one reduction for the two products; the difference skips its carry pass
   p.X = X3;
   p.ZZ = fe_mul<F>(p.ZZ, PP);
   p.ZZZ = fe_mul<F>(p.ZZZ, PPP);
+}
+template <class C, bool PROBE = false>
+MP_HD void xyzz_madd_ip(Xyzz<C>& p, const Aff<C>& q) {
+  xyzz_madd_signed_ip<C, PROBE>(p, q, false);
 }
 // p <- p + q, both XYZZ (12M + 2S): partial sums of the bucket method (kernels_bucket.hpp)
 template <class C, bool PROBE = false>
@@ -282,7 +296,7 @@ MP_HD void xyzz_add_ip(Xyzz<C>& p, const Xyzz<C>& q) {
   const Fe<F> PPP = fe_mul<F>(Pd, PP);
   const Fe<F> Q = fe_mul<F>(U1, PP);
   const Fe<F> X3 = fe_sub<F>(fe_sub<F>(fe_sqr<F>(Rr), PPP), fe_dbl<F>(Q));
-  p.Y = fe_mulsub<F>(Rr, fe_sub<F>(Q, X3), S1, PPP);
+  p.Y = fe_mulsub<F>(Rr, fe_sub_lazy<F>(Q, X3), S1, PPP);
   p.X = X3;
   p.ZZ = fe_mul<F>(fe_mul<F>(p.ZZ, q.ZZ), PP);
   p.ZZZ = fe_mul<F>(fe_mul<F>(p.ZZZ, q.ZZZ), PPP);

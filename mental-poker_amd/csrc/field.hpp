@@ -508,6 +508,44 @@ template <class P>
 MP_HD Fe<P> fe_dbl(const Fe<P>& a) {
   return fe_add<P>(a, a);
 }
+// ---- carry-free differences for operands that ONLY feed a product (sparse 29-bit form) ------------------------------------------
+// On the sparse prime (STARK) a subtraction whose result is used as ONE multiplicand and nothing else can skip its carry pass:
+//   r_i = a_i - b_i + K_i     with K = 8p written so that every limb but the top one is >= 2^29 - 1
+//                             (K_0 = 8 p_0 + 2^29, K_i = 8 p_i + 2^29 - 1 for 0 < i < 8, K_8 = 8 p_8 - 1 = 2^22 - 1: the same integer 8p).
+// For normalised a, b < 4p (limbs < 2^29, top limbs <= 2^21) every r_i is >= 0 and < 2^30.05, the value is a - b + 8p < 12p.  A product
+// with a NORMALISED second operand then has column sums < 9 * 2^29 * 2^30.05 = 2^62.2, and the fused pair a b - c d with b = such a
+// difference and c = such a negation (limbs <= K_i < 2^29.1) < 9 * 2^29 * (2^30.05 + 2^29.1) = 2^62.82 < 2^63: the signed 64-bit
+// accumulator of mont29 / muladd29 holds (the subtracted reduction terms are < 2^52 on this prime).  Results: (12 * 4 + 8 * 4) p^2 / R
+// + p < 1.08 p.  NOT a field element in the lazy invariant: never store it, never add or subtract it, never test it for zero.
+// Saves 23 (difference) / 32 (negation) of the 41 instructions of a normalising subtraction.  Other primes: the plain functions
+// (pseudo-Mersenne and dense limbs of 8p are ~2^29 each: the fused pair would reach 2^63.1).
+template <class P>
+struct LazySub {
+  static constexpr bool ON = P::L29 && !P::PM29 && !P::DENSE29 && P::NL29 == 9;
+  static constexpr int32_t k(int i) { return 8 * P::SMOD29[i] + (i == 0 ? (1 << 29) : i == 8 ? -1 : (1 << 29) - 1); }
+};
+template <class P>
+MP_HD Fe<P> fe_sub_lazy(const Fe<P>& a, const Fe<P>& b) {
+  if constexpr (LazySub<P>::ON) {
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v[i] = a.v[i] - b.v[i] + (uint32_t)LazySub<P>::k(i);
+    return r;
+  } else {
+    return fe_sub<P>(a, b);
+  }
+}
+template <class P>
+MP_HD Fe<P> fe_neg_lazy(const Fe<P>& a) {
+  if constexpr (LazySub<P>::ON) {
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v[i] = (uint32_t)LazySub<P>::k(i) - a.v[i];
+    return r;
+  } else {
+    return fe_neg<P>(a);
+  }
+}
 // a / 2 (8x32 representation only: the scalar fields).  Works on the Montgomery residue: (a + (a odd ? p : 0)) >> 1
 template <class P>
 MP_HD Fe<P> fe_half(const Fe<P>& a) {
@@ -563,7 +601,7 @@ template <class P>
 MP_HD Fe<P> fe_mulsub(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d) {
   if constexpr (P::L29 && P::NL29 <= 9) {
     Fe<P> r;
-    const Fe<P> nc = fe_neg<P>(c);
+    const Fe<P> nc = fe_neg_lazy<P>(c);          // c, a and d normalised; b normalised or a fe_sub_lazy difference (bounds above)
     muladd29<P>(r.v, a.v, b.v, nc.v, d.v);
     return r;
   } else {

@@ -212,9 +212,8 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t wid, W& wv) {
         }
         const uint32_t e = ix[p];
         const uint32_t tb = a.bterms[job.begin + (e & 0x7FFFu)].b;
-        Aff<C> q = ld_aff<C>(a.P + p_off<C>(tb & BK_SLOT_MASK, a.Bpad, b + (tb >> 20) * a.link_stride));
-        if (e & 0x8000u) q = aff_neg<C>(q);
-        xyzz_madd_ip<C>(run[lane], q);
+        const Aff<C> q = ld_aff<C>(a.P + p_off<C>(tb & BK_SLOT_MASK, a.Bpad, b + (tb >> 20) * a.link_stride));
+        xyzz_madd_signed_ip<C>(run[lane], q, (e & 0x8000u) != 0);
       }
     });
   }

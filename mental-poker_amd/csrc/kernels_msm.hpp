@@ -205,9 +205,8 @@ MP_HD void body_remask(const RemaskArgs& a, uint32_t b, uint32_t y) {
       const int d = a.D[((size_t)(a.d_first + i) * a.nwin + w) * a.Bpad + b];
       if (d != 0) {
         const uint32_t e = (uint32_t)(d < 0 ? -d : d) - 1;
-        Aff<C> q = ld_aff<C>(a.T + p_off<C>((a.t_first + w) * VB_ENTRIES + e, a.Bpad, b));
-        if (d < 0) q = aff_neg<C>(q);
-        xyzz_madd_ip<C>(acc, q);
+        const Aff<C> q = ld_aff<C>(a.T + p_off<C>((a.t_first + w) * VB_ENTRIES + e, a.Bpad, b));
+        xyzz_madd_signed_ip<C>(acc, q, d < 0);
       }
     }
     xyzz_madd_ip<C>(acc, ld_aff<C>(a.P + p_off<C>(a.p_deck + 2 * src + comp, a.Bpad, b)));
@@ -462,9 +461,8 @@ MP_HD void body_var_msm(const VarArgs& a, uint32_t b, uint32_t y) {
       const int d = a.D[((size_t)term.s * a.nwin + w) * a.Bpad + b];
       if (d != 0) {
         const uint32_t e = (uint32_t)(d < 0 ? -d : d) - 1;
-        Aff<C> q = ld_aff<C>(a.T + p_off<C>(term.b * VB_ENTRIES + e, a.Bpad, b));
-        if (d < 0) q = aff_neg<C>(q);
-        xyzz_madd_ip<C>(acc, q);
+        const Aff<C> q = ld_aff<C>(a.T + p_off<C>(term.b * VB_ENTRIES + e, a.Bpad, b));
+        xyzz_madd_signed_ip<C>(acc, q, d < 0);
       }
     }
   }

@@ -169,6 +169,48 @@ static long check(const char* name, long count) {
     for (int j = 0; j < N; ++j) xz = xz && x[j] == 0;
     if (fe_is_zero(X) != xz) ++bad;
   }
+  // the fused a (b - c) - d e with a carry-free difference and negation (field.hpp LazySub; plain functions on the other forms) against
+  // the unfused, fully normalising evaluation -- on random operands and on the limb patterns that maximise the column sums
+  // (every limb 2^29 - 1 under the largest top limb a value below 4p / 2p can have)
+  if constexpr (F::L29) {
+    constexpr int NL = F::NL29;
+    auto extreme = [&](int kind) {
+      Fe<F> e;
+      for (int i = 0; i < NL - 1; ++i) e.v[i] = kind == 2 ? 0u : M29;
+      uint32_t top = (uint32_t)((F::DENSE29 ? 2 : 4) * (uint64_t)F::MOD29[NL - 1]);
+      if (F::PM29) top = (4u << 24) - 1u;
+      e.v[NL - 1] = kind == 1 ? 0u : (top > 0 ? top - 1 : 0);
+      return e;
+    };
+    long lazy_bad = 0, lazy_done = 0;
+    for (long i = 0; i < count + 81; ++i) {
+      Fe<F> o[5];
+      for (int j = 0; j < 5; ++j) {
+        uint32_t w[N];
+        rand_canon(w, i + j);
+        o[j] = fe_from_canonical<F>(w);
+        if (i < 81) {                       // all 3^4 combinations of the extreme patterns in b, c, d, e (a = the largest)
+          int sel = (int)(i / (j == 0 ? 1 : j == 1 ? 1 : j == 2 ? 3 : j == 3 ? 9 : 27)) % 3;
+          o[j] = extreme(j == 0 ? 0 : sel);
+        } else if ((i + j) % 5 == 0) {
+          o[j] = fe_sub<F>(o[j], fe_from_canonical<F>(w));      // a lazily reduced zero
+        }
+      }
+      const Fe<F> fused = fe_mulsub<F>(o[0], fe_sub_lazy<F>(o[1], o[2]), o[3], o[4]);
+      const Fe<F> plain = fe_sub<F>(fe_mul<F>(o[0], fe_sub<F>(o[1], o[2])), fe_mul<F>(o[3], o[4]));
+      const Fe<F> single = fe_mul<F>(o[0], fe_neg_lazy<F>(o[3]));
+      const Fe<F> single_plain = fe_mul<F>(o[0], fe_neg<F>(o[3]));
+      if (!fe_eq<F>(fused, plain) || !fe_eq<F>(single, single_plain)) {
+        if (lazy_bad < 5) printf("  %s: fused lazy product differs (case %ld)\n", name, i);
+        ++lazy_bad;
+      }
+      for (int l = 0; l < NL - 1; ++l)
+        if (fused.v[l] > M29) ++lazy_bad;                        // outputs are normalised
+      ++lazy_done;
+    }
+    printf("  %s: %ld fused products with carry-free operands, %ld mismatches\n", name, lazy_done, lazy_bad);
+    bad += lazy_bad;
+  }
   printf("%s: %ld checks, %ld mismatches\n", name, done, bad);
   return bad;
 }

@@ -245,7 +245,7 @@ def test_field_arithmetic_matches_bigint_reference():
                            "-I" + os.path.join(ROOT, "tools", "hostemu"), "-I" + os.path.join(ROOT, "mental-poker_amd", "csrc"),
                            os.path.join(ROOT, "tests", "cpp", "field_check.cpp"), "-o", exe])
     out = subprocess.run([exe, "6000"], stdout=subprocess.PIPE, check=True).stdout.decode()
-    assert out.count(" 0 mismatches") == 6, out
+    assert out.count(" 0 mismatches") == 10 and "fused products with carry-free operands, 0 mismatches" in out, out
 
 
 def test_emulated_batch_and_status(emu, coracle):

@@ -50,8 +50,7 @@ __global__ void probe_madd(uint32_t* io, int neg) {
   Aff<C> q;
   q.x = fe_unpack<F>(p + 64);
   q.y = fe_unpack<F>(p + 64 + F::NW);
-  if (neg) q = aff_neg<C>(q);
-  xyzz_madd_ip<C, true>(a, q);
+  xyzz_madd_signed_ip<C, true>(a, q, neg != 0);
   probe_st<F>(p, a.X); probe_st<F>(p + 16, a.Y); probe_st<F>(p + 32, a.ZZ); probe_st<F>(p + 48, a.ZZZ);
 }
 template <class C>
