@@ -215,9 +215,8 @@ MP_HD void xyzz_dbl_ip(Xyzz<C>& p) {
   const Fe<F> W = fe_mul<F>(U, V);
   const Fe<F> S = fe_mul<F>(p.X, V);
   const Fe<F> XX = fe_sqr<F>(p.X);
-  Fe<F> M = fe_add<F>(fe_dbl<F>(XX), XX);
-  if (C::A == 1) M = fe_add<F>(M, fe_sqr<F>(p.ZZ));
-  const Fe<F> X3 = fe_sub<F>(fe_sqr<F>(M), fe_dbl<F>(S));
+  const Fe<F> M = C::A == 1 ? fe_triple_add<F>(XX, fe_sqr<F>(p.ZZ)) : fe_add<F>(fe_dbl<F>(XX), XX);     // 3 X^2 + a ZZ^2, one carry pass
+  const Fe<F> X3 = fe_sub_dbl<F>(fe_sqr<F>(M), S);                                                     // M^2 - 2 S, one carry pass
   p.Y = fe_mulsub<F>(M, fe_sub_lazy<F>(S, X3), W, p.Y);      // the difference only feeds this product: no carry pass (field.hpp LazySub)
   p.X = X3;
   p.ZZ = fe_mul<F>(V, p.ZZ);
@@ -260,7 +259,7 @@ MP_HD void xyzz_madd_signed_ip(Xyzz<C>& p, const Aff<C>& q, bool neg) {
   const Fe<F> PP = fe_sqr<F>(Pd);
   const Fe<F> PPP = fe_mul<F>(Pd, PP);
   const Fe<F> Q = fe_mul<F>(p.X, PP);
-  const Fe<F> X3 = fe_sub<F>(fe_sub<F>(fe_sqr<F>(Rr), PPP), fe_dbl<F>(Q));
+  const Fe<F> X3 = fe_sub_sub_dbl<F>(fe_sqr<F>(Rr), PPP, Q);                                            // R^2 - PPP - 2 Q, one carry pass
   p.Y = fe_mulsub<F>(Rr, fe_sub_lazy<F>(Q, X3), p.Y, PPP);     // one reduction for the two products; the difference skips its carry pass
   p.X = X3;
   p.ZZ = fe_mul<F>(p.ZZ, PP);
@@ -295,7 +294,7 @@ MP_HD void xyzz_add_ip(Xyzz<C>& p, const Xyzz<C>& q) {
   const Fe<F> PP = fe_sqr<F>(Pd);
   const Fe<F> PPP = fe_mul<F>(Pd, PP);
   const Fe<F> Q = fe_mul<F>(U1, PP);
-  const Fe<F> X3 = fe_sub<F>(fe_sub<F>(fe_sqr<F>(Rr), PPP), fe_dbl<F>(Q));
+  const Fe<F> X3 = fe_sub_sub_dbl<F>(fe_sqr<F>(Rr), PPP, Q);
   p.Y = fe_mulsub<F>(Rr, fe_sub_lazy<F>(Q, X3), S1, PPP);
   p.X = X3;
   p.ZZ = fe_mul<F>(fe_mul<F>(p.ZZ, q.ZZ), PP);

@@ -508,6 +508,53 @@ template <class P>
 MP_HD Fe<P> fe_dbl(const Fe<P>& a) {
   return fe_add<P>(a, a);
 }
+// ---- short linear combinations of PRODUCTS with one carry pass (sparse and pseudo-Mersenne 29-bit forms) -------------------------
+// Montgomery products come out in (0, 2p).  Combinations of them that stay inside [0, 8p) after adding a multiple of p need ONE
+// reducing carry pass instead of one per addition / subtraction:
+//   fe_sub_sub_dbl(a, u, v) = a - u - 2v    (+ 6p: (-6p, 2p) -> (0, 8p))      the x coordinate of an addition: R^2 - PPP - 2Q
+//   fe_sub_dbl(a, v)        = a - 2v        (+ 4p: (-4p, 2p) -> (0, 6p))      the x coordinate of a doubling: M^2 - 2S
+//   fe_triple_add(a, b)     = 3a + b        ((0, 8p))                          the slope numerator 3 X^2 + ZZ^2 (a = 1 curves)
+// Every argument MUST be the direct result of fe_mul / fe_sqr / fe_mulsub.  Limb sums stay inside (-2^31, 2^31) (|.| <= 4 * 2^29 + 6 p_i).
+// The dense form keeps values below 2p and reduces [0, 4p) only: it composes the plain functions.
+template <class P>
+MP_HD Fe<P> fe_sub_sub_dbl(const Fe<P>& a, const Fe<P>& u, const Fe<P>& v) {
+  if constexpr (P::L29 && !P::DENSE29) {
+    Fe<P> r;
+    int32_t s[P::NL29];
+#pragma unroll
+    for (int i = 0; i < P::NL29; ++i) s[i] = (int32_t)a.v[i] - (int32_t)u.v[i] - 2 * (int32_t)v.v[i] + 6 * P::SMOD29[i];
+    reduce_carry29<P>(s, r.v);
+    return r;
+  } else {
+    return fe_sub<P>(fe_sub<P>(a, u), fe_dbl<P>(v));
+  }
+}
+template <class P>
+MP_HD Fe<P> fe_sub_dbl(const Fe<P>& a, const Fe<P>& v) {
+  if constexpr (P::L29 && !P::DENSE29) {
+    Fe<P> r;
+    int32_t s[P::NL29];
+#pragma unroll
+    for (int i = 0; i < P::NL29; ++i) s[i] = (int32_t)a.v[i] - 2 * (int32_t)v.v[i] + 4 * P::SMOD29[i];
+    reduce_carry29<P>(s, r.v);
+    return r;
+  } else {
+    return fe_sub<P>(a, fe_dbl<P>(v));
+  }
+}
+template <class P>
+MP_HD Fe<P> fe_triple_add(const Fe<P>& a, const Fe<P>& b) {
+  if constexpr (P::L29 && !P::DENSE29) {
+    Fe<P> r;
+    int32_t s[P::NL29];
+#pragma unroll
+    for (int i = 0; i < P::NL29; ++i) s[i] = 3 * (int32_t)a.v[i] + (int32_t)b.v[i];
+    reduce_carry29<P>(s, r.v);
+    return r;
+  } else {
+    return fe_add<P>(fe_add<P>(fe_dbl<P>(a), a), b);
+  }
+}
 // ---- carry-free differences for operands that ONLY feed a product (sparse 29-bit form) ------------------------------------------
 // On the sparse prime (STARK) a subtraction whose result is used as ONE multiplicand and nothing else can skip its carry pass:
 //   r_i = a_i - b_i + K_i     with K = 8p written so that every limb but the top one is >= 2^29 - 1

@@ -158,6 +158,19 @@ static long check(const char* name, long count) {
     ref_sub<N>(y, x, F::MOD, r);
     expect(fe_sub<F>(Y, X), r, "sub of lazy operands");
     expect(fe_neg<F>(fe_neg<F>(X)), x, "double negation");
+    // one-pass combinations of products (fe_sub_sub_dbl, fe_sub_dbl, fe_triple_add: arguments are direct products, as in curve.hpp)
+    {
+      const Fe<F> P1 = fe_mul<F>(X, Y), P2 = fe_sqr<F>(X), P3 = fe_mulsub<F>(X, Y, AB, C);
+      uint32_t p1[N], p2[N], p3[N], w1[N], w2[N];
+      ref_mul<N>(x, y, F::MOD, p1); ref_mul<N>(x, x, F::MOD, p2);
+      ref_mul<N>(ab, c, F::MOD, w1); ref_sub<N>(p1, w1, F::MOD, p3);
+      ref_sub<N>(p2, p1, F::MOD, w1); ref_add<N>(p3, p3, F::MOD, w2); ref_sub<N>(w1, w2, F::MOD, r);
+      expect(fe_sub_sub_dbl<F>(P2, P1, P3), r, "a - u - 2v");
+      ref_add<N>(p1, p1, F::MOD, w1); ref_sub<N>(p2, w1, F::MOD, r);
+      expect(fe_sub_dbl<F>(P2, P1), r, "a - 2v");
+      ref_add<N>(p2, p2, F::MOD, w1); ref_add<N>(w1, p2, F::MOD, w1); ref_add<N>(w1, p3, F::MOD, r);
+      expect(fe_triple_add<F>(P2, P3), r, "3a + b");
+    }
     // representatives of zero
     const Fe<F> Z1 = fe_sub<F>(X, X), Z2 = fe_add<F>(X, fe_neg<F>(X)), Z3 = fe_sub<F>(fe_add<F>(A, B), fe_add<F>(B, A));
     const Fe<F> Z4 = fe_add<F>(fe_add<F>(Z1, Z2), fe_add<F>(Z3, Z2));
