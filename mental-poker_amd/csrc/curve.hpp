@@ -245,8 +245,8 @@ MP_HD void xyzz_madd_signed_ip(Xyzz<C>& p, const Aff<C>& q, bool neg) {
   } else {
     if (neg) qy = fe_neg<F>(q.y);
   }
-  const Fe<F> Pd = fe_sub<F>(fe_mul<F>(q.x, p.ZZ), p.X);
-  const Fe<F> Rr = fe_sub<F>(fe_mul<F>(qy, p.ZZZ), p.Y);
+  const Fe<F> Pd = fe_sub_wide<F>(fe_mul<F>(q.x, p.ZZ), p.X);      // only squared, multiplied and tested for zero: no weak reduction
+  const Fe<F> Rr = fe_sub_wide<F>(fe_mul<F>(qy, p.ZZZ), p.Y);
   if (fe_is_zero(Pd)) {
     if (!PROBE && fe_is_zero(Rr)) {
       xyzz_dbl_ip<C>(p);         // P + P

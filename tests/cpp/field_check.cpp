@@ -170,6 +170,16 @@ static long check(const char* name, long count) {
       expect(fe_sub_dbl<F>(P2, P1), r, "a - 2v");
       ref_add<N>(p2, p2, F::MOD, w1); ref_add<N>(w1, p2, F::MOD, w1); ref_add<N>(w1, p3, F::MOD, r);
       expect(fe_triple_add<F>(P2, P3), r, "3a + b");
+      // product minus a lazily reduced value without the weak reduction: as a multiplicand, squared, and as a zero
+      const Fe<F> Wd = fe_sub_wide<F>(P1, X);
+      ref_sub<N>(p1, x, F::MOD, w1); ref_mul<N>(w1, y, F::MOD, r);
+      expect(fe_mul<F>(Wd, Y), r, "(product - x) y, wide difference");
+      ref_mul<N>(w1, w1, F::MOD, r);
+      expect(fe_sqr<F>(Wd), r, "(product - x)^2, wide difference");
+      if (!fe_is_zero(fe_sub_wide<F>(P1, fe_add<F>(P1, fe_sub<F>(X, X)))) || !fe_is_zero(fe_sub_wide<F>(P2, fe_sqr<F>(fe_neg<F>(X))))) {
+        if (bad < 5) printf("  %s: a wide zero is not recognised\n", name);
+        ++bad;
+      }
     }
     // representatives of zero
     const Fe<F> Z1 = fe_sub<F>(X, X), Z2 = fe_add<F>(X, fe_neg<F>(X)), Z3 = fe_sub<F>(fe_add<F>(A, B), fe_add<F>(B, A));
