@@ -72,6 +72,25 @@ MP_HD void st_fe(uint32_t* p, const Fe<F>& a) {
   fe_pack<F>(a, w);
   st_words<F::NW>(p, w);
 }
+// A lazily reduced element stored WITHOUT canonicalising it (pack only: 16 instructions instead of 81).  Allowed where every reader
+// unpacks it into the lazy invariant again and nobody compares or hashes the words: the window tables and the prefix-product scratch
+// of k_table.  The value must fit the packed words: < 4p < 2^254 on the sparse STARK prime, < 2p on the dense ones; the pseudo-
+// Mersenne form (4p ~ 2^258 > 2^256) keeps the canonical store.
+template <class F>
+MP_HD void st_fe_lazy(uint32_t* p, const Fe<F>& a) {
+  if constexpr (F::L29 && !F::PM29) {
+    uint32_t w[F::NW];
+    pack29<F::NW, F::NL29>(a.v, w);
+    st_words<F::NW>(p, w);
+  } else {
+    st_fe<F>(p, a);
+  }
+}
+template <class C>
+MP_HD void st_aff_lazy(uint32_t* p, const Aff<C>& a) {
+  st_fe_lazy<typename C::FqP>(p, a.x);
+  st_fe_lazy<typename C::FqP>(p + Geo<C>::FW, a.y);
+}
 template <class C>
 MP_HD Aff<C> ld_aff(const uint32_t* p) {
   Aff<C> a;
@@ -327,7 +346,7 @@ template <class C>
 MP_HD void table_emit(const TableArgs& a, uint32_t b, uint32_t ts, uint32_t e0n, uint32_t t, Fe<typename C::FqP>& prod,
                       const Fe<typename C::FqP>& den) {
   typedef typename C::FqP F;
-  st_fe<F>(a.scratch + f_off<C>(ts * 8 + table_key(e0n, t), a.Bpad, b), prod);
+  st_fe_lazy<F>(a.scratch + f_off<C>(ts * 8 + table_key(e0n, t), a.Bpad, b), prod);      // (a product: < 2p)
   if (!fe_is_zero(den)) prod = fe_mul<F>(prod, den);
 }
 // target t of the current round from its operands (doubling of lo, or lo + hi); consumes one step of the running inverse
@@ -335,7 +354,7 @@ template <class C>
 MP_HD Aff<C> table_step(const TableArgs& a, uint32_t b, uint32_t ts, uint32_t e0, uint32_t t, Fe<typename C::FqP>& inv,
                         const Aff<C>& lo, const Aff<C>& hi, bool dbl) {
   typedef typename C::FqP F;
-  const Fe<F> den = dbl ? fe_dbl<F>(lo.y) : fe_sub<F>(hi.x, lo.x);
+  const Fe<F> den = dbl ? fe_dbl<F>(lo.y) : fe_sub_wide<F>(hi.x, lo.x);      // only multiplied and tested for zero (entries are < 2p here: loaded canonical or lazily stored products' differences)
   Aff<C> out = aff_inf<C>();
   if (!fe_is_zero(den)) {
     const Fe<F> dinv = fe_mul<F>(inv, ld_fe<F>(a.scratch + f_off<C>(ts * 8 + table_key(e0, t), a.Bpad, b)));
@@ -343,17 +362,16 @@ MP_HD Aff<C> table_step(const TableArgs& a, uint32_t b, uint32_t ts, uint32_t e0
     Fe<F> num;
     if (dbl) {
       const Fe<F> xx = fe_sqr<F>(lo.x);
-      num = fe_add<F>(fe_dbl<F>(xx), xx);
-      if (C::A == 1) num = fe_add<F>(num, fe_one<F>());
+      num = C::A == 1 ? fe_triple_add<F>(xx, fe_one<F>()) : fe_add<F>(fe_dbl<F>(xx), xx);      // 3 x^2 + a, one carry pass (R mod p < p)
     } else {
       num = fe_sub<F>(hi.y, lo.y);
     }
     const Fe<F> lam = fe_mul<F>(num, dinv);
     const Fe<F>& x2 = dbl ? lo.x : hi.x;
     out.x = fe_sub<F>(fe_sub<F>(fe_sqr<F>(lam), lo.x), x2);
-    out.y = fe_sub<F>(fe_mul<F>(lam, fe_sub<F>(lo.x, out.x)), lo.y);
+    out.y = fe_sub<F>(fe_mul<F>(lam, fe_sub_lazy<F>(lo.x, out.x)), lo.y);      // the inner difference only feeds the product
   }
-  st_aff<C>(a.T + p_off<C>(ts * VB_ENTRIES + t - 1, a.Bpad, b), out);
+  st_aff_lazy<C>(a.T + p_off<C>(ts * VB_ENTRIES + t - 1, a.Bpad, b), out);
   return out;
 }
 template <class C>
