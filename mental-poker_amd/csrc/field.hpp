@@ -1,19 +1,19 @@
-// 256-bit prime-field arithmetic for the gfx950 vector ALU.  Two representations, chosen per modulus at compile
-// time (curve_params.hpp, `P::L29`); everything else in the engine goes through the fe_* functions below and the
-// packed 8-word memory format, never through the limbs.
+// Prime-field arithmetic for the gfx950 vector ALU.  Two representations, chosen per modulus at compile time (curve_params.hpp,
+// `P::L29`); everything else in the engine goes through the fe_* functions below and the packed memory format, never through the limbs.
 //
-//  (1) 8 x 32-bit limbs, Montgomery R = 2^256, always fully reduced.  Product = product scanning (Comba) with a
-//      96-bit column accumulator: one v_mad_u64_u32 (32x32+64 -> 64, carry-out to VCC) + one v_addc_co_u32 per limb
-//      product (inline asm: hipcc cannot express the carry-out of the mad from C).  Used for the scalar fields
-//      and the dense base fields (bn254, secp256k1).
+//  (1) NW x 32-bit limbs, Montgomery R = 2^(32 NW), always fully reduced.  Product = product scanning (Comba) with a 96-bit column
+//      accumulator: one v_mad_u64_u32 (32x32+64 -> 64, carry-out to VCC) + one v_addc_co_u32 per limb product (inline asm: hipcc
+//      cannot express the carry-out of the mad from C).  Used for the scalar fields (`Fr::rand` defines their Montgomery form w.r.t.
+//      2^256; moving them to (2) was measured at +-0: they are 1.4 % of a step).
 //
-//  (2) 9 x 29-bit limbs, Montgomery R = 2^261, LAZILY reduced: limbs < 2^29, value in [0, 4p).  A column sum of
-//      9 limb products fits a 64-bit accumulator (9 * 2^58 < 2^62), so the whole product is a chain of plain
-//      `acc = a*b + acc` mads with NO carry handling (81 for a product, 45 for a square, +2 per column for the
-//      Montgomery step on the sparse STARK prime 2^251 + 17*2^192 + 1); additions / subtractions fold a weak
-//      reduction into their single signed carry pass.  Plain C, identical on host and device.
-//      Measured on MI355X (tools/microbench/fmul.hip, products per second, STARK Fq):
-//      C CIOS 101 G/s, (1) 171 G/s, (2) 216 G/s.
+//  (2) NL29 x 29-bit limbs (9; 14 for BLS12-377 Fq), Montgomery R = 2^(29 NL29), LAZILY reduced: limbs < 2^29, value in [0, 4p)
+//      ([0, 2p) for dense primes).  A column sum of limb products fits a 64-bit accumulator, so the whole product is a chain of plain
+//      `acc = a*b + acc` multiply-adds with NO carry handling; additions / subtractions fold a weak reduction into their single signed
+//      carry pass.  Three flavours of the modulus: sparse (STARK 2^251 + 17*2^192 + 1: 2 reduction multiplies per column), signed
+//      sparse (secp256k1 2^256 - 2^32 - 977, `PM29`), dense (bn254, BLS12-377, `DENSE29`: full Montgomery reduction, quotient estimate
+//      by one multiply).  Plain C, identical on host and device.  All base fields use it: every VALU instruction costs a 4-cycle issue
+//      slot on gfx950 whatever it is, so the form with the fewest instructions wins, and (1) pays one v_addc per mad.
+//      Checked against a schoolbook big-integer reference: tests/cpp/field_check.cpp.
 //
 // Replaces ark-ff 0.3 `Fp256` (4x64 limbs) used by every reference call on the hot path
 // [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:7-8].

@@ -24,8 +24,8 @@ namespace mp {
 // an affine point 2 FW, a Jacobian point 3 FW; a scalar (Fr) is 8 words on every supported curve.
 template <class C>
 struct Geo {
-  // waves per SIMD the group-arithmetic kernels are compiled for: 4 (128 VGPRs) on the 256-bit curves; the 12-word base field of
-  // BLS12-377 needs > 200 registers for an XYZZ accumulator plus the temporaries of one addition, i.e. 2 waves -- asking for 4
+  // waves per SIMD the group-arithmetic kernels are compiled for: 4 (128 VGPRs) on the 256-bit curves; the 14-limb base field of
+  // BLS12-377 needs ~200 registers for an XYZZ accumulator plus the temporaries of one addition, i.e. 2 waves -- asking for 4
   // there only made the compiler spill and warn
   static constexpr int OCC4 = C::FqP::NW > 8 ? 2 : 4;
   static constexpr int OCC3 = C::FqP::NW > 8 ? 2 : 3;
@@ -34,8 +34,8 @@ struct Geo {
 #else
   static constexpr int OCC_VAR = OCC4;
 #endif
-  // k_table: with the division-step inversion inlined the 29-bit fields need 144 registers; capped at 128 the compiler spills 15
-  // of them and the fourth wave still wins (-1.7 % in an A/B); the 8 x 32 form (bn254) would spill 336 bytes there
+  // k_table: with the division-step inversion inlined the 29-bit fields need 144 registers; capped at 128 the compiler spills 15-20
+  // of them and the fourth wave still wins (-1.7 % in an A/B)
   static constexpr int OCC_TABLE = C::FqP::NW > 8 ? 2 : (C::FqP::L29 ? 4 : 3);
   static constexpr uint32_t FW = C::FqP::NW;
   static constexpr uint32_t PW = 2 * FW;
