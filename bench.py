@@ -215,6 +215,8 @@ def main():
                          "(mp_*_batch_keys_dev); 0 = every proof under the table's own key")
     ap.add_argument("--bucket-min", type=int, default=None,
                     help="variable-base MSMs of at least this many terms run on the bucket-method kernel (engine default 2048; 0 = never)")
+    ap.add_argument("--transcript-lanes", type=int, default=None, choices=[0, 1, 4],
+                    help="lanes per Fiat-Shamir transcript hash (mp_set_transcript_lanes; default: by batch size)")
     ap.add_argument("--per-equation", action="store_true", help="verify equation by equation (mp_set_merged_verify off)")
     ap.add_argument("--players", type=int, default=32, help="chain32: shuffles per table")
     ap.add_argument("--no-keyset", action="store_true",
@@ -304,6 +306,8 @@ def main():
             t.set_merged_verify(False)
         if args.bucket_min is not None:
             t.set_bucket_min(args.bucket_min)
+        if args.transcript_lanes is not None:
+            t.set_transcript_lanes(args.transcript_lanes)
     table = tables[0]
     proof_bytes = table.proof_bytes
 

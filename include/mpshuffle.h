@@ -194,6 +194,11 @@ int mp_set_bucket_min(mp_table* t, size_t terms);
  * consecutive sub-chains.  0 (default) = as many as fit the 32 767 points of one equation (293 links of a 52-card deck).  A smaller
  * value bounds the LDS a chain equation needs and the work that is repeated link by link when a chain fails.  Verdicts are the same. */
 int mp_set_chain_max_links(mp_table* t, uint32_t links);
+/* Lanes per Fiat-Shamir transcript.  A proof's transcript is one BLAKE2s chain (13.6 KB of statement for a 52-card deck): 1 = one
+ * lane per proof (what a batch that fills the chip wants), 4 = the four G functions of a half-round on four adjacent lanes (2.7x
+ * fewer instructions in the chain: what a single proof or a few thousand large decks wait for), 0 (default) = 4 for batches of up
+ * to 32 768 proofs, 1 above.  Digests, challenges and proofs are the same. */
+int mp_set_transcript_lanes(mp_table* t, uint32_t lanes);
 /* How the prover evaluates the multi-exponentiation diagonals E_k (a polynomial product of the scalar rows with the ciphertext
  * rows) for 3 <= m <= 16.  on (default): Toom-Cook with the 2m points 0, inf, +-1 .. +-(m-1) -- 2m row products; off: recursive
  * Karatsuba (13 products at m = 4, 35 at m = 8; what m > 16 always uses).  m = 2 always uses its 4-point Toom-Cook form.  The

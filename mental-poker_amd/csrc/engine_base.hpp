@@ -117,6 +117,17 @@ struct mp_ctx {
   mp::Profiler prof;
 };
 
+// batches of up to this many proofs hash their transcripts with four lanes per BLAKE2s state (kernels_proto.hpp: k_fsq_*): up to
+// 512 waves of lone transcript lanes leave half the SIMDs idle and the others waiting 8-10 cycles per instruction
+static const uint32_t FSQ_MAX_BATCH = 32768;
+// batches of up to this many proofs draw the prover's randomness with a wave per proof (kernels_proto.hpp: k_prove_init_w)
+static const uint32_t PROVE_INIT_WAVE_MAX = 2048;
+#define MP_WAVE_RUN(NAME, C, nwaves, lds_words, args)                             \
+  do {                                                                            \
+    ctx->prof.begin(#NAME, ctx->stream);                                          \
+    MP_WAVE_LAUNCH(NAME, C, ctx->stream, (nwaves), (lds_words), (args));          \
+    ctx->prof.end(ctx->stream);                                                   \
+  } while (0)
 #define MP_RUN(NAME, C, nx, ny, args)                      \
   do {                                                     \
     ctx->prof.begin(#NAME, ctx->stream);                   \
@@ -149,6 +160,7 @@ struct mp_table {
   uint32_t point_bytes = 64;   // wire size of a point on this table's curve (Geo<C>::PB)
   bool keyless = false;        // created from the parameters alone (mp_table_create_params): keyed entry points only
   uint32_t chain_max_links = 0;   // links per chain equation (0 = as many as fit 32 767 points; mp_set_chain_max_links)
+  uint32_t fs_lanes = 0;          // lanes per transcript hash: 1, 4, or 0 = by batch size (mp_set_transcript_lanes)
   virtual ~mp_table() {}
   virtual void reserve(size_t B) = 0;
   virtual void set_latency_batch(size_t B) = 0;

@@ -584,6 +584,40 @@ struct Table : mp_table {
     a.w_deck = a.w_shuf = NO_SLOT;
     return a;
   }
+  // The transcript kernels: one lane per proof, or four lanes per hash (k_fsq_*: the lanes of a wave dealt to 64 / lpp proofs)
+  // for batches that would leave the chip to a few hundred lone lanes.  Crossover: a lone wave issues every 8-10 cycles, four
+  // waves per SIMD every ~4.3, and the quad kernels run ~2.7x fewer instructions per hash on 16x more waves.
+  FsqGeom fsq_geom(uint32_t B) const {
+    uint32_t lpp = 64;
+    while (lpp > 4 && (uint64_t)B * lpp > 65536u) lpp >>= 1;
+    return FsqGeom{lpp, B};
+  }
+  static uint32_t fsq_waves(const FsqGeom& g) { return (g.B + 64u / g.lpp - 1) / (64u / g.lpp); }
+  bool fs_quad(uint32_t B) const { return fs_lanes == 4 || (fs_lanes == 0 && B <= FSQ_MAX_BATCH); }
+  void run_fs_round1(const FsStatementArgs& a, uint32_t B) {
+    if (fs_quad(B)) {
+      FsqStatementArgs q{a, fsq_geom(B)};
+      MP_WAVE_RUN(k_fsq_round1, C, fsq_waves(q.g), 0, q);
+    } else {
+      MP_RUN(k_fs_round1, C, B, 1, a);
+    }
+  }
+  void run_fs_round(const FsRoundArgs& a, uint32_t B) {
+    if (fs_quad(B)) {
+      FsqRoundArgs q{a, fsq_geom(B)};
+      MP_WAVE_RUN(k_fsq_round, C, fsq_waves(q.g), 0, q);
+    } else {
+      MP_RUN(k_fs_round, C, B, 1, a);
+    }
+  }
+  void run_verify_fs(const VerifyFsArgs& a, uint32_t B) {
+    if (fs_quad(B)) {
+      FsqVerifyArgs q{a, fsq_geom(B)};
+      MP_WAVE_RUN(k_fsq_verify, C, fsq_waves(q.g), 0, q);
+    } else {
+      MP_RUN(k_verify_fs, C, B, 1, a);
+    }
+  }
   // room for the wire words of `decks` decks per proof (their transcript bytes, kept by k_load_points) -- for the small-batch
   // plans only: there the transcript lane is what a proof waits for (a 300-card BLS12-377 verification: 24 -> 19 ms, a 52-card one
   // 3.5 -> 3.3 ms), while a full batch hides that lane behind thousands of others and would only pay for the extra 64 bytes
@@ -620,7 +654,10 @@ struct Table : mp_table {
       LoadScalarsArgs sa{rho, w.S.p, w.status.p, w.Bpad, N, l.rho};
       MP_RUN(k_load_scalars, C, B, N, sa);
       ProveInitArgs ia{w.S.p, w.status.p, perm, seeds, q.draws.p, l, w.Bpad};
-      MP_RUN(k_prove_init, C, B, 1, ia);
+      if (B <= PROVE_INIT_WAVE_MAX)      // a wave per proof: 64 ChaCha20 blocks at a time instead of one lane's ~300 in a row
+        MP_WAVE_RUN(k_prove_init_w, C, B, N, ia);
+      else
+        MP_RUN(k_prove_init, C, B, 1, ia);
       RemaskArgs ra{w.S.p, w.P.p, w.J.p, FB.p, perm, w.Bpad, N, l.rho, l.deck, l.shuf, fb.G(), fb.pk(), fbg,
                     0, w.D.p, w.T.p, key_d_first, key_t_first, nwin, nullptr, nullptr, FbGeom{8, 32, 255}, 0};
       check_subgroup(w, B, l.deck, 2 * N);
@@ -664,7 +701,7 @@ struct Table : mp_table {
       FsStatementArgs a = statement_args(w, l.deck, l.shuf, l.cA, l.x, keyed ? l.pk : NO_SLOT);
       a.W = wire_words(w, B, 1);
       a.w_deck = 0;             // the input deck as it came; the shuffled deck was computed here and is taken from its P slots
-      MP_RUN(k_fs_round1, C, B, 1, a);
+      run_fs_round1(a, B);
     }
     ProveScalArgs sc{w.S.p, perm, l, w.Bpad, q.lin.p, q.lin_src.p, tk.E ? 0u : (uint32_t)q.pplan.lin.size()};
     MP_RUN(k_prove_scal1, C, B, 1, sc);
@@ -683,7 +720,7 @@ struct Table : mp_table {
       a.step[0] = FsStep{l.cB, m, 0, 0, l.y, l.z};
       a.nsteps = 1;
       a.copy_from = NO_SLOT; a.copy_to = NO_SLOT;
-      MP_RUN(k_fs_round, C, B, 1, a);
+      run_fs_round(a, B);
     }
     MP_RUN(k_prove_scal2, C, B, 1, sc);
     run_phase(pph[2], w, B);
@@ -694,7 +731,7 @@ struct Table : mp_table {
       a.step[0] = FsStep{l.cb, 1, 0, 0, NO_SLOT, NO_SLOT};
       a.step[1] = FsStep{l.hB, m, 0, 0, l.hx, l.hy};
       a.nsteps = 2;
-      MP_RUN(k_fs_round, C, B, 1, a);
+      run_fs_round(a, B);
     }
     MP_RUN(k_prove_scal3, C, B, 1, sc);
     MP_RUN(k_prove_scal3d, C, B, 2 * m + 1, sc);
@@ -707,7 +744,7 @@ struct Table : mp_table {
       a.step[1] = FsStep{l.svcd, 3, 0, 0, l.svx, NO_SLOT};
       a.step[2] = FsStep{l.mecA0, 1 + 6 * m, 0, 0, l.mx, NO_SLOT};
       a.nsteps = 3;
-      MP_RUN(k_fs_round, C, B, 1, a);
+      run_fs_round(a, B);
     }
     MP_RUN(k_prove_scal4, C, B, 1, sc);
     {
@@ -767,7 +804,7 @@ struct Table : mp_table {
         a.st.w_shuf = 2 * N;
         a.l = l;
         a.merge = merged ? 1u : 0u;
-        MP_RUN(k_verify_fs, C, B, 1, a);
+        run_verify_fs(a, B);
         VerifyScalArgs sa{w.S.p, w.P.p, w.direct.p, l, q.vplan.cm, w.Bpad};
         MP_RUN(k_verify_scal, C, B, 1, sa);
       }
@@ -882,7 +919,7 @@ struct Table : mp_table {
       a.st = statement_args(w, l.deck, l.shuf, l.cA, l.x, keyed ? l.pk : NO_SLOT);
       a.l = l;
       a.merge = 1u;
-      MP_RUN(k_verify_fs, C, B, 1, a);
+      run_verify_fs(a, B);
       VerifyScalArgs sa{w.S.p, w.P.p, w.direct.p, l, q.vplan.cm, w.Bpad};
       MP_RUN(k_verify_scal, C, B, 1, sa);
       VerifyMergeArgs ma{w.S.p, q.mjobs.p, q.mpairs.p, w.Bpad};

@@ -92,6 +92,15 @@ MP_HD StageWriter stage_begin(uint32_t* stage, uint32_t stride, uint32_t b) {
   w.nb = 0;
   return w;
 }
+// a writer that starts at word `widx` of the proof's buffer (several lanes staging word-aligned pieces of one message)
+MP_HD StageWriter stage_begin_at(uint32_t* stage, uint32_t stride, uint32_t b, uint32_t widx) {
+  StageWriter w = stage_begin(stage, stride, b);
+  w.widx = widx;
+  return w;
+}
+MP_HD void stage_flush(StageWriter& w) {      // the partial last word, zero padded
+  if (w.nb) w.base[(size_t)w.widx * w.stride] = (uint32_t)w.acc;
+}
 MP_HD void stage_word(StageWriter& w, uint32_t x) {
   w.acc |= (uint64_t)x << (8 * w.nb);
   w.base[(size_t)w.widx * w.stride] = (uint32_t)w.acc;
@@ -133,6 +142,112 @@ MP_HD void blake2s_staged(StageWriter& w, uint32_t out[8]) {
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) out[i] = s.h[i];
+}
+
+// ---- four lanes on one BLAKE2s state -----------------------------------------------------------------------------------------
+// The transcript of a proof is ONE hash chain: with a lane per proof a small batch waits ~5 us per 64-byte block (a lone wave issues
+// one instruction every 8-10 cycles) and a batch of a few thousand 1024-card decks fills a quarter of the SIMDs with such lanes.
+// The four G functions of a half-round are independent, so a QUAD (four adjacent lanes) keeps the 4 x 4 working matrix one column
+// per lane: the column step is lane-local, the diagonal step is the same code after rotating rows b, c, d by 1, 2, 3 lanes inside
+// the quad (one DPP move each, WaveCtx::quad_rot) -- ~42 instructions per round instead of ~112.  Every lane of the quad holds the
+// whole message block (16 redundant loads, prefetched one block ahead) and picks its two words of a half-round by lane number.
+// Written against the wave interface of rt.hpp, so the development emulator runs the same source.
+struct B2sBlock {
+  uint32_t w[16];
+};
+struct B2sSeed {
+  uint32_t s[8];
+};
+MP_HD uint32_t sel4(uint32_t j, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+  const uint32_t lo = (j & 1u) ? w1 : w0, hi = (j & 1u) ? w3 : w2;
+  return (j & 2u) ? hi : lo;
+}
+#define MP_B2Q_HALF(x, y)                                                             \
+  wv.lanes([&](uint32_t l) {                                                          \
+    const uint32_t j = l & 3u;                                                        \
+    const B2sBlock& q = m[l];                                                         \
+    uint32_t a = va[l], b = vb[l], c = vc[l], d = vd[l];                              \
+    a = a + b + (x);                                                                  \
+    d = rotr32(d ^ a, 16);                                                            \
+    c = c + d;                                                                        \
+    b = rotr32(b ^ c, 12);                                                            \
+    a = a + b + (y);                                                                  \
+    d = rotr32(d ^ a, 8);                                                             \
+    c = c + d;                                                                        \
+    b = rotr32(b ^ c, 7);                                                             \
+    va[l] = a; vb[l] = b; vc[l] = c; vd[l] = d;                                       \
+  });
+#define MP_B2Q_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)                                   \
+  MP_B2Q_HALF(sel4(j, q.w[s0], q.w[s2], q.w[s4], q.w[s6]), sel4(j, q.w[s1], q.w[s3], q.w[s5], q.w[s7]))                     \
+  wv.template quad_rot<1>(vb); wv.template quad_rot<2>(vc); wv.template quad_rot<3>(vd);                                    \
+  MP_B2Q_HALF(sel4(j, q.w[s8], q.w[s10], q.w[s12], q.w[s14]), sel4(j, q.w[s9], q.w[s11], q.w[s13], q.w[s15]))               \
+  wv.template quad_rot<3>(vb); wv.template quad_rot<2>(vc); wv.template quad_rot<1>(vd);
+// state: lane j of the quad holds h[j] in ha and h[4 + j] in hb; t, last as in blake2s_compress (the same for every lane)
+template <class W>
+MP_HD void blake2s_compress_quad(W& wv, PerLane<uint32_t>& ha, PerLane<uint32_t>& hb, const PerLane<B2sBlock>& m, uint64_t t, bool last) {
+  PerLane<uint32_t> va, vb, vc, vd;
+  wv.lanes([&](uint32_t l) {
+    const uint32_t j = l & 3u;
+    va[l] = ha[l];
+    vb[l] = hb[l];
+    vc[l] = sel4(j, 0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au);
+    vd[l] = sel4(j, 0x510E527Fu ^ (uint32_t)t, 0x9B05688Cu ^ (uint32_t)(t >> 32), last ? ~0x1F83D9ABu : 0x1F83D9ABu, 0x5BE0CD19u);
+  });
+  MP_B2Q_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+  MP_B2Q_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+  MP_B2Q_ROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+  MP_B2Q_ROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+  MP_B2Q_ROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+  MP_B2Q_ROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+  MP_B2Q_ROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+  MP_B2Q_ROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+  MP_B2Q_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+  MP_B2Q_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+  wv.lanes([&](uint32_t l) {
+    ha[l] ^= va[l] ^ vc[l];
+    hb[l] ^= vb[l] ^ vd[l];
+  });
+}
+// BLAKE2s-256 of the staged bytes [0, len) of each lane's proof: word w at base[l][w * stride] (StageWriter layout), zero-padded by
+// the writer up to the next word.  len is the same for every lane.  Every lane of a quad ends up with the whole digest.
+template <class W>
+MP_HD void blake2s_staged_quad(W& wv, const PerLane<const uint32_t*>& base, uint32_t stride, uint32_t len, PerLane<B2sSeed>& out) {
+  const uint32_t nwords = (len + 3u) / 4u;
+  uint32_t nblocks = (len + 63u) / 64u;
+  if (nblocks == 0) nblocks = 1;
+  PerLane<uint32_t> ha, hb;
+  wv.lanes([&](uint32_t l) {
+    const uint32_t j = l & 3u;
+    ha[l] = sel4(j, 0x6A09E667u ^ 0x01010020u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au);
+    hb[l] = sel4(j, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u);
+  });
+  PerLane<B2sBlock> m, mn;
+  auto load = [&](PerLane<B2sBlock>& dst, uint32_t blk) {
+    wv.lanes([&](uint32_t l) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const uint32_t wi = blk * 16u + i;
+        dst[l].w[i] = wi < nwords ? base[l][(size_t)wi * stride] : 0u;
+      }
+    });
+  };
+  load(m, 0);
+#pragma unroll 1
+  for (uint32_t blk = 0; blk < nblocks; ++blk) {
+    const bool last = blk + 1 == nblocks;
+    if (!last) load(mn, blk + 1);            // one block ahead: the loads fly while this block is compressed
+    blake2s_compress_quad(wv, ha, hb, m, last ? (uint64_t)len : (uint64_t)(blk + 1) * 64u, last);
+    if (!last) wv.lanes([&](uint32_t l) { m[l] = mn[l]; });
+  }
+  PerLane<uint32_t> t;
+  wv.template quad_bcast<0>(ha, t); wv.lanes([&](uint32_t l) { out[l].s[0] = t[l]; });
+  wv.template quad_bcast<1>(ha, t); wv.lanes([&](uint32_t l) { out[l].s[1] = t[l]; });
+  wv.template quad_bcast<2>(ha, t); wv.lanes([&](uint32_t l) { out[l].s[2] = t[l]; });
+  wv.template quad_bcast<3>(ha, t); wv.lanes([&](uint32_t l) { out[l].s[3] = t[l]; });
+  wv.template quad_bcast<0>(hb, t); wv.lanes([&](uint32_t l) { out[l].s[4] = t[l]; });
+  wv.template quad_bcast<1>(hb, t); wv.lanes([&](uint32_t l) { out[l].s[5] = t[l]; });
+  wv.template quad_bcast<2>(hb, t); wv.lanes([&](uint32_t l) { out[l].s[6] = t[l]; });
+  wv.template quad_bcast<3>(hb, t); wv.lanes([&](uint32_t l) { out[l].s[7] = t[l]; });
 }
 
 MP_HD void chacha20_block(const uint32_t key[8], uint64_t counter, uint32_t out[16]) {

@@ -217,6 +217,86 @@ MP_HD void body_prove_init(const ProveInitArgs& a, uint32_t b, uint32_t y) {
   st_fe<R>(a.S + s_off(l.svdelta + l.n - 1, a.Bpad, b), fe_zero<R>());
 }
 MP_KERNEL(k_prove_init, ProveInitArgs, body_prove_init)
+// The same with one WAVE per proof, for small batches (a lone lane spends 0.45 ms of a 52-card proof's 4.7 here, nearly all of it
+// in ~300 sequential ChaCha20 blocks): lane i checks and converts cards i, i + 64, ...; the rejection sampler generates 64 blocks
+// (128 candidates) at a time and a prefix sum over the accept flags gives every accepted candidate its place in the draw order --
+// the values and their order are those of the sequential sampler, the surplus candidates of the last round are dropped.
+// LDS: N counters (how often each card index occurs in the permutation).
+template <class C, class W>
+MP_HD void body_prove_init_w(const ProveInitArgs& a, uint32_t b, W& wv) {
+  typedef typename C::FrP R;
+  const ProveLay& l = a.l;
+  uint32_t* cnt = wv.lds;
+  wv.lanes([&](uint32_t lane) {
+    for (uint32_t i = lane; i < l.N; i += 64) cnt[i] = 0;
+  });
+  wv.sync();
+  PerLane<uint32_t> bad;
+  wv.lanes([&](uint32_t lane) {
+    bad[lane] = 0;
+    for (uint32_t i = lane; i < l.N; i += 64) {
+      uint32_t v = a.perm[(size_t)b * l.N + i];
+      if (v >= l.N) {
+        bad[lane] = 1;
+        v = 0;
+      } else {
+        wv.atomic_add(&cnt[v], 1u);
+      }
+      st_fe<R>(a.S + s_off(l.a + i, a.Bpad, b), fe_from_u32<R>(v + 1));
+    }
+  });
+  wv.sync();
+  wv.lanes([&](uint32_t lane) {
+    for (uint32_t i = lane; i < l.N; i += 64)
+      if (cnt[i] > 1) bad[lane] = 1;
+  });
+  if (wv.any(bad)) wv.lanes([&](uint32_t lane) {
+    if (lane == 0) status_fail(a.status, b, ST_BAD_PERMUTATION);
+  });
+  const uint32_t* sw = reinterpret_cast<const uint32_t*>(a.seeds + (size_t)b * 32);
+  uint32_t got = 0;
+  uint64_t counter = 0;
+  while (got < l.n_draws) {
+    PerLane<Fe<R>> c0, c1;
+    PerLane<uint32_t> ok0, ok1, pos, incl;
+    wv.lanes([&](uint32_t lane) {
+      uint32_t key[8], blk[16];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) key[i] = sw[i];
+      chacha20_block(key, counter + lane, blk);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        c0[lane].v[i] = blk[i];
+        c1[lane].v[i] = blk[8 + i];
+      }
+      if (R::BITS < 256) {
+        c0[lane].v[7] &= 0xFFFFFFFFu >> (256 - R::BITS);
+        c1[lane].v[7] &= 0xFFFFFFFFu >> (256 - R::BITS);
+      }
+      ok0[lane] = fe_canonical_in_range<R>(c0[lane].v) ? 1u : 0u;
+      ok1[lane] = fe_canonical_in_range<R>(c1[lane].v) ? 1u : 0u;
+      pos[lane] = ok0[lane] + ok1[lane];
+      incl[lane] = pos[lane];
+    });
+    wv.excl_scan(pos);
+    wv.lanes([&](uint32_t lane) {
+      incl[lane] += pos[lane];
+      const uint32_t i0 = got + pos[lane], i1 = i0 + ok0[lane];
+      if (ok0[lane] && i0 < l.n_draws) st_fe<R>(a.S + s_off(a.draw_slots[i0], a.Bpad, b), c0[lane]);
+      if (ok1[lane] && i1 < l.n_draws) st_fe<R>(a.S + s_off(a.draw_slots[i1], a.Bpad, b), c1[lane]);
+    });
+    got += wv.max(incl);
+    counter += 64;
+  }
+  wv.lanes([&](uint32_t lane) {
+    if (lane != 0) return;
+    st_fe<R>(a.S + s_off(l.zt + l.m + 1, a.Bpad, b), fe_zero<R>());
+    st_fe<R>(a.S + s_off(l.meb + l.m, a.Bpad, b), fe_zero<R>());
+    st_fe<R>(a.S + s_off(l.mes + l.m, a.Bpad, b), fe_zero<R>());
+    st_fe<R>(a.S + s_off(l.svdelta + l.n - 1, a.Bpad, b), fe_zero<R>());
+  });
+}
+MP_WAVE_KERNEL(k_prove_init_w, ProveInitArgs, body_prove_init_w)
 
 // ---- Fiat-Shamir helpers ------------------------------------------------------------------------------
 struct FsDev {
@@ -306,28 +386,38 @@ struct FsStatementArgs {
   const uint32_t* W;           // kept wire words of the loaded decks (LoadPointsArgs::W), or null
   uint32_t w_deck, w_shuf;     // their first W slots (NO_SLOT: take the deck from its P slots)
 };
+// The statement message: G, pk, gen, ck_0 .. ck_{n-1}, H, the 2N points of the deck, the 2N of the shuffled deck (then u64 m, u64 n
+// and the old seed).  Point i of that list:
+MP_HD uint32_t fs_statement_points(const FsStatementArgs& a) { return 4 + a.n + 4 * a.N; }
+template <class C>
+MP_HD void fs_put_statement_point(StageWriter& w, const FsStatementArgs& a, uint32_t b, uint32_t i) {
+  const FixedBases fb{a.n};
+  const uint32_t nfix = 4 + a.n;
+  if (i < nfix) {
+    if (i == 1 && a.p_pk != NO_SLOT) {
+      fs_put_point<C>(w, ld_aff<C>(a.P + p_off<C>(a.p_pk, a.f.Bpad, b)));
+      return;
+    }
+    const uint32_t base = i == 0 ? fb.G() : i == 1 ? fb.pk() : i == 2 ? fb.gen() : i == nfix - 1 ? fb.H() : fb.ck(i - 3);
+    fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)base * Geo<C>::PW));
+    return;
+  }
+  i -= nfix;
+  const bool second = i >= 2 * a.N;
+  if (second) i -= 2 * a.N;
+  const uint32_t wslot = second ? a.w_shuf : a.w_deck;
+  if (a.W && wslot != NO_SLOT)
+    fs_put_wire_point<C>(w, a.W, wslot + i, a.f.Bpad, b);
+  else
+    fs_put_point<C>(w, ld_aff<C>(a.P + p_off<C>((second ? a.p_shuf : a.p_deck) + i, a.f.Bpad, b)));
+}
 template <class C>
 MP_HD void fs_statement_and_x(const FsStatementArgs& a, uint32_t b, uint32_t seed[8]) {
-  const FixedBases fb{a.n};
 #pragma unroll
   for (int i = 0; i < 8; ++i) seed[i] = a.init_seed[i];
   StageWriter w = stage_begin(a.f.stage, a.f.Bpad, b);
-  fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.G() * Geo<C>::PW));
-  if (a.p_pk != NO_SLOT)
-    fs_put_point<C>(w, ld_aff<C>(a.P + p_off<C>(a.p_pk, a.f.Bpad, b)));
-  else
-    fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.pk() * Geo<C>::PW));
-  fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.gen() * Geo<C>::PW));
-  for (uint32_t j = 0; j < a.n; ++j) fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.ck(j) * Geo<C>::PW));
-  fs_put_point<C>(w, ld_aff<C>(a.fbpts + (size_t)fb.H() * Geo<C>::PW));
-  if (a.W && a.w_deck != NO_SLOT)
-    for (uint32_t i = 0; i < 2 * a.N; ++i) fs_put_wire_point<C>(w, a.W, a.w_deck + i, a.f.Bpad, b);
-  else
-    for (uint32_t i = 0; i < 2 * a.N; ++i) fs_put_point<C>(w, ld_aff<C>(a.P + p_off<C>(a.p_deck + i, a.f.Bpad, b)));
-  if (a.W && a.w_shuf != NO_SLOT)
-    for (uint32_t i = 0; i < 2 * a.N; ++i) fs_put_wire_point<C>(w, a.W, a.w_shuf + i, a.f.Bpad, b);
-  else
-    for (uint32_t i = 0; i < 2 * a.N; ++i) fs_put_point<C>(w, ld_aff<C>(a.P + p_off<C>(a.p_shuf + i, a.f.Bpad, b)));
+  const uint32_t npts = fs_statement_points(a);
+  for (uint32_t i = 0; i < npts; ++i) fs_put_statement_point<C>(w, a, b, i);
   stage_word(w, a.m); stage_word(w, 0); stage_word(w, a.n); stage_word(w, 0);   // u64 m, u64 n
   fs_finish_absorb(w, seed);
   fs_absorb_points<C>(a.f, a.P, b, seed, a.p_cA, a.m);
@@ -704,6 +794,185 @@ MP_HD void body_verify_fs(const VerifyFsArgs& a, uint32_t b, uint32_t y) {
   }
 }
 MP_KERNEL(k_verify_fs, VerifyFsArgs, body_verify_fs)
+
+// ---- the same transcripts with FOUR LANES per hash (hash.hpp: blake2s_compress_quad) ---------------------------------------------
+// Used for batches that cannot fill the chip with one-lane transcripts (FSQ_MAX_BATCH, engine_core.hpp): a single 52-card proof
+// waits 1.2 ms for its verifier's transcript lane and 1.1 ms for the prover's, a batch of 16 384 1024-card decks 20 ms per pass.
+// A wave serves 64 / lpp proofs: the lpp lanes of a proof (4 .. 64, a power of two) share the staging of a message -- aligned groups
+// of four points (32 FW + 4 bytes = 8 FW + 1 words) go round the lanes, the unaligned rest, the trailing words and the old seed to
+// one lane of the first quad -- and the first quad hashes.  Same bytes, same digests, same challenges as the one-lane kernels.
+struct FsqGeom {
+  uint32_t lpp, B;      // lanes per proof; proofs in the batch
+};
+struct FsqLane {
+  uint32_t b, sub;      // proof (clamped into the batch), lane within the proof
+  bool live;            // the proof exists
+};
+MP_HD FsqLane fsq_lane(const FsqGeom& g, uint32_t wid, uint32_t l) {
+  FsqLane q;
+  const uint32_t b = wid * (64u / g.lpp) + l / g.lpp;
+  q.live = b < g.B;
+  q.b = q.live ? b : g.B - 1;
+  q.sub = l & (g.lpp - 1u);
+  return q;
+}
+// absorb: npts points (put_point(w, b, i) appends point i), `tail(w, b)` appends whole words, then the old seed; seed <- digest
+template <class C, class W, class PutPoint, class PutTail>
+MP_HD void fsq_absorb(W& wv, const FsDev& f, const FsqGeom& g, uint32_t wid, uint32_t npts, PutPoint put_point, uint32_t tail_words,
+                      PutTail tail, PerLane<B2sSeed>& seed) {
+  constexpr uint32_t GW = 8 * C::FqP::NW + 1;     // words of four points
+  const uint32_t ngroups = npts / 4;
+  PerLane<const uint32_t*> base;
+  wv.lanes([&](uint32_t l) {
+    const FsqLane q = fsq_lane(g, wid, l);
+    base[l] = f.stage + q.b;
+    if (!q.live) return;
+    for (uint32_t gi = q.sub; gi < ngroups; gi += g.lpp) {
+      StageWriter w = stage_begin_at(f.stage, f.Bpad, q.b, gi * GW);
+      for (uint32_t k = 0; k < 4; ++k) put_point(w, q.b, 4 * gi + k);
+    }
+    if (q.sub == (ngroups & 3u)) {                 // the next lane of the first quad: it has the seed
+      StageWriter w = stage_begin_at(f.stage, f.Bpad, q.b, ngroups * GW);
+      for (uint32_t i = 4 * ngroups; i < npts; ++i) put_point(w, q.b, i);
+      tail(w, q.b);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) stage_word(w, seed[l].s[i]);
+      stage_flush(w);
+    }
+  });
+  wv.sync_global();
+  blake2s_staged_quad(wv, base, f.Bpad, npts * GW + 4 * tail_words + 32, seed);   // (a point is GW BYTES)
+  wv.sync_global();        // the buffer is free for the next message only when every lane has read this one
+}
+template <class C, class W>
+MP_HD void fsq_absorb_points(W& wv, const FsDev& f, const FsqGeom& g, uint32_t wid, const uint32_t* P, uint32_t first, uint32_t count,
+                             uint32_t first2, uint32_t count2, PerLane<B2sSeed>& seed) {
+  fsq_absorb<C>(wv, f, g, wid, count + count2,
+                [&](StageWriter& w, uint32_t b, uint32_t i) {
+                  fs_put_point<C>(w, ld_aff<C>(P + p_off<C>(i < count ? first + i : first2 + (i - count), f.Bpad, b)));
+                },
+                0, [](StageWriter&, uint32_t) {}, seed);
+}
+template <class C, class W>
+MP_HD void fsq_challenges(W& wv, const FsDev& f, const FsqGeom& g, uint32_t wid, uint32_t* S, const PerLane<B2sSeed>& seed, uint32_t slot0,
+                          uint32_t slot1) {
+  wv.lanes([&](uint32_t l) {
+    const FsqLane q = fsq_lane(g, wid, l);
+    if (q.live && q.sub == 0) fs_challenges<C>(seed[l].s, S, f.Bpad, q.b, slot0, slot1);
+  });
+}
+template <class W>
+MP_HD void fsq_store_seed(W& wv, const FsDev& f, const FsqGeom& g, uint32_t wid, const PerLane<B2sSeed>& seed) {
+  wv.lanes([&](uint32_t l) {
+    const FsqLane q = fsq_lane(g, wid, l);
+    if (q.live && q.sub == 0) fs_store_seed(f, q.b, seed[l].s);
+  });
+}
+template <class C, class W>
+MP_HD void fsq_statement_and_x(W& wv, const FsStatementArgs& a, const FsqGeom& g, uint32_t wid, PerLane<B2sSeed>& seed) {
+  wv.lanes([&](uint32_t l) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) seed[l].s[i] = a.init_seed[i];
+  });
+  fsq_absorb<C>(wv, a.f, g, wid, fs_statement_points(a),
+                [&](StageWriter& w, uint32_t b, uint32_t i) { fs_put_statement_point<C>(w, a, b, i); }, 4,
+                [&](StageWriter& w, uint32_t) { stage_word(w, a.m); stage_word(w, 0); stage_word(w, a.n); stage_word(w, 0); }, seed);
+  fsq_absorb_points<C>(wv, a.f, g, wid, a.P, a.p_cA, a.m, 0, 0, seed);
+  fsq_challenges<C>(wv, a.f, g, wid, a.S, seed, a.s_x, NO_SLOT);
+}
+struct FsqStatementArgs {
+  FsStatementArgs st;
+  FsqGeom g;
+};
+template <class C, class W>
+MP_HD void body_fsq_round1(const FsqStatementArgs& a, uint32_t wid, W& wv) {
+  PerLane<B2sSeed> seed;
+  fsq_statement_and_x<C>(wv, a.st, a.g, wid, seed);
+  fsq_store_seed(wv, a.st.f, a.g, wid, seed);
+}
+MP_WAVE_KERNEL(k_fsq_round1, FsqStatementArgs, body_fsq_round1)
+struct FsqRoundArgs {
+  FsRoundArgs r;
+  FsqGeom g;
+};
+template <class C, class W>
+MP_HD void body_fsq_round(const FsqRoundArgs& a, uint32_t wid, W& wv) {
+  const FsDev& f = a.r.f;
+  PerLane<B2sSeed> seed;
+  wv.lanes([&](uint32_t l) {
+    const FsqLane q = fsq_lane(a.g, wid, l);
+    if (a.r.copy_from != NO_SLOT && q.live && q.sub == 0)
+      st_aff<C>(a.r.P + p_off<C>(a.r.copy_to, f.Bpad, q.b), ld_aff<C>(a.r.P + p_off<C>(a.r.copy_from, f.Bpad, q.b)));
+    fs_load_seed(f, q.b, seed[l].s);
+  });
+  if (a.r.copy_from != NO_SLOT) wv.sync_global();
+  for (uint32_t s = 0; s < a.r.nsteps; ++s) {
+    const FsStep st = a.r.step[s];
+    fsq_absorb_points<C>(wv, f, a.g, wid, a.r.P, st.first, st.count, st.first2, st.count2, seed);
+    if (st.slot0 != NO_SLOT) fsq_challenges<C>(wv, f, a.g, wid, a.r.S, seed, st.slot0, st.slot1);
+  }
+  fsq_store_seed(wv, f, a.g, wid, seed);
+}
+MP_WAVE_KERNEL(k_fsq_round, FsqRoundArgs, body_fsq_round)
+struct FsqVerifyArgs {
+  VerifyFsArgs v;
+  FsqGeom g;
+};
+template <class C, class W>
+MP_HD void body_fsq_verify(const FsqVerifyArgs& a, uint32_t wid, W& wv) {
+  typedef typename C::FrP R;
+  const VerifyLay& l = a.v.l;
+  const uint32_t m = l.m;
+  const FsDev& f = a.v.st.f;
+  uint32_t* S = a.v.st.S;
+  const uint32_t* P = a.v.st.P;
+  const FsqGeom& g = a.g;
+  PerLane<B2sSeed> seed;
+  fsq_statement_and_x<C>(wv, a.v.st, g, wid, seed);
+  fsq_absorb_points<C>(wv, f, g, wid, P, l.cB, m, 0, 0, seed);
+  fsq_challenges<C>(wv, f, g, wid, S, seed, l.y, l.z);
+  fsq_absorb_points<C>(wv, f, g, wid, P, l.cb, 1, 0, 0, seed);
+  fsq_absorb_points<C>(wv, f, g, wid, P, l.hB, m, 0, 0, seed);
+  fsq_challenges<C>(wv, f, g, wid, S, seed, l.hx, l.hy);
+  fsq_absorb_points<C>(wv, f, g, wid, P, l.zcA0, 2 + 2 * m + 1, 0, 0, seed);
+  fsq_challenges<C>(wv, f, g, wid, S, seed, l.zx, NO_SLOT);
+  fsq_absorb_points<C>(wv, f, g, wid, P, l.svcd, 3, 0, 0, seed);
+  fsq_challenges<C>(wv, f, g, wid, S, seed, l.svx, NO_SLOT);
+  fsq_absorb_points<C>(wv, f, g, wid, P, l.mecA0, 1 + 2 * m + 4 * m, 0, 0, seed);
+  fsq_challenges<C>(wv, f, g, wid, S, seed, l.mx, NO_SLOT);
+  if (a.v.merge) {      // the weights of the merged equation (body_verify_fs): the 5n + 9 response scalars, 8 aligned words each
+    const uint32_t nsc = 5 * l.n + 9;
+    PerLane<const uint32_t*> base;
+    wv.lanes([&](uint32_t ln) {
+      const FsqLane q = fsq_lane(g, wid, ln);
+      base[ln] = f.stage + q.b;
+      if (!q.live) return;
+      for (uint32_t i = q.sub; i < nsc; i += g.lpp) {
+        uint32_t k[8];
+        fe_to_canonical<R>(ld_fe<R>(S + s_off(l.zabar + i, f.Bpad, q.b)), k);
+        StageWriter w = stage_begin_at(f.stage, f.Bpad, q.b, 8 * i);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) stage_word(w, k[t]);
+      }
+      if (q.sub == 0) {
+        StageWriter w = stage_begin_at(f.stage, f.Bpad, q.b, 8 * nsc);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) stage_word(w, seed[ln].s[t]);
+      }
+    });
+    wv.sync_global();
+    blake2s_staged_quad(wv, base, f.Bpad, 32 * nsc + 32, seed);
+    wv.lanes([&](uint32_t ln) {
+      const FsqLane q = fsq_lane(g, wid, ln);
+      if (!q.live || q.sub != 0) return;
+      FrStream st;
+      frstream_init(st, seed[ln].s);
+      for (uint32_t k = 0; k < (uint32_t)VC_COUNT; ++k) st_fe<R>(S + s_off(l.mr + k, f.Bpad, q.b), frstream_next<R>(st));
+      fs_store_seed(f, q.b, seed[ln].s);      // the transcript's last state: chain verification hashes it
+    });
+  }
+}
+MP_WAVE_KERNEL(k_fsq_verify, FsqVerifyArgs, body_fsq_verify)
 
 // merged scalars: S[dst] = sum_{pairs} S[r] * S[coef]      (lane = (proof, merge job))
 struct VerifyMergeArgs {

@@ -106,6 +106,7 @@ inline void host_free(void* p) {
 //   wv.lds                                  this wave's slice of LDS (32-bit words)
 //   wv.atomic_add(p, v)                     LDS atomic, returns the old value
 //   wv.excl_scan(x) / wv.max(x)             wave-level exclusive prefix sum / maximum over a PerLane<uint32_t>
+//   wv.quad_rot<K>(x) / wv.quad_bcast<K>(x, out)   exchanges inside aligned groups of four lanes;  wv.sync_global(): as sync(), for HBM
 namespace mp {
 template <class T>
 struct PerLane {
@@ -145,6 +146,24 @@ struct WaveCtx {
   }
   // does any lane of the wave hold a non-zero flag?  (wavefront ballot)
   __device__ __forceinline__ bool any(const PerLane<uint32_t>& x) { return __ballot(x.v != 0) != 0; }
+  // QUADS = aligned groups of four lanes (the transcript kernels put one BLAKE2s state on a quad, hash.hpp).  One DPP move each:
+  // quad_rot<K>: lane j takes the value of lane (j + K) mod 4 of its quad; quad_bcast<K>: every lane takes lane K's
+  template <int K>
+  __device__ __forceinline__ void quad_rot(PerLane<uint32_t>& x) {
+    constexpr int ctrl = ((0 + K) & 3) | (((1 + K) & 3) << 2) | (((2 + K) & 3) << 4) | (((3 + K) & 3) << 6);
+    x.v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.v, ctrl, 0xF, 0xF, true);
+  }
+  template <int K>
+  __device__ __forceinline__ void quad_bcast(const PerLane<uint32_t>& x, PerLane<uint32_t>& out) {
+    constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);
+    out.v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.v, ctrl, 0xF, 0xF, true);
+  }
+  // global-memory words written by any lane of the wave before are visible to every lane of the wave afterwards
+  __device__ __forceinline__ void sync_global() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
 };
 }  // namespace mp
 // a workgroup holds up to 4 waves (= 4 independent work items); `lds_words` 32-bit words of dynamic LDS per wave

@@ -547,6 +547,55 @@ def test_bucket_kernel_matches_oracle(mp, coracle, curve, m, n, B):
     assert rep["k_bucket_msm"][0] >= 3
 
 
+@pytest.mark.parametrize("curve,m,n,B,keyed", [("stark", 2, 26, 70, False), ("stark", 4, 13, 1500, False), ("stark", 2, 3, 20000, False),
+                                               ("secp256k1", 2, 7, 3, True), ("bls12_377", 2, 5, 3, False), ("bn254", 3, 5, 1, True)])
+def test_transcript_lane_modes_agree(mp, coracle, curve, m, n, B, keyed):
+    """mp_set_transcript_lanes: one lane per proof and four lanes per BLAKE2s state (k_fsq_*: 64, 32 and 4 lanes of a wave per proof
+    at these batch sizes) produce the same proofs -- the oracle's -- and the same verdicts, honest and tampered"""
+    cards = mp.DLCards(curve, device=0)
+    g0 = coracle.gen_inputs(curve, m, n, 100)
+    pp, pk = mp.Parameters(m, n, g0["params"]), g0["pk"]
+    t = cards.table(pp, pk)
+    cards.engine.profile_enable(True)
+    distinct = min(B, 6)
+    ins = [coracle.gen_inputs(curve, m, n, 700 + b) for b in range(distinct)]
+    rep = (B + distinct - 1) // distinct
+    cat = lambda key: (b"".join(g[key] for g in ins) * rep)[:B * len(ins[0][key])]
+    decks, rho, seeds = cat("deck"), cat("rho"), cat("prover_seed")
+    perms = ([x for g in ins for x in g["perm"]] * rep)[:B * m * n]
+    keys = (b"".join(coracle.gen_inputs(curve, m, n, 800 + b)["pk"] for b in range(distinct)) * rep)[:B * cards.engine.point_bytes]
+    out = {}
+    for lanes in (1, 4):
+        t.set_transcript_lanes(lanes)
+        if keyed:
+            sh, pf, st = t.shuffle_and_remask_batch_keys(keys, decks, rho, perms, seeds)
+        else:
+            sh, pf, st = t.shuffle_and_remask_batch(decks, rho, perms, seeds)
+        assert st == [0] * B
+        bad = bytearray(pf)
+        bad[-96] ^= 1                                        # low byte of a response scalar of the last proof
+        ver = (lambda d, s_, p: t.verify_shuffle_batch_keys(keys, d, s_, p)) if keyed else t.verify_shuffle_batch
+        verdicts = []
+        for merged in (True, False):
+            t.set_merged_verify(merged)
+            verdicts.append((ver(decks, sh, pf), ver(decks, sh, bytes(bad))))
+        t.set_merged_verify(True)
+        out[lanes] = (sh, pf, verdicts)
+    t.set_transcript_lanes(0)
+    assert out[1] == out[4]
+    sh, pf, verdicts = out[4]
+    assert verdicts[0][0] == [0] * B and verdicts[0] == verdicts[1] and verdicts[0][1][:-1] == [0] * (B - 1) and verdicts[0][1][-1] > 0
+    if not keyed:
+        psz = len(pf) // B
+        for b in range(distinct):
+            g = ins[b]
+            exp_deck, exp_proof = coracle.shuffle_and_remask(curve, m, n, g0["params"], pk, g["deck"], g["rho"], g["perm"], g["prover_seed"])
+            assert sh[b * len(exp_deck):(b + 1) * len(exp_deck)] == exp_deck and pf[b * psz:(b + 1) * psz] == exp_proof
+    rp = cards.engine.profile_report()
+    for k in ("k_fsq_round1", "k_fsq_round", "k_fsq_verify", "k_fs_round1", "k_fs_round", "k_verify_fs"):
+        assert rp[k][0] >= 1, k
+
+
 def test_bucket_msm_large_and_edge_scalars(mp, coracle):
     cv = "stark"
     q = 0x0800000000000010ffffffffffffffffb781126dcae7b2321e66a241adc64d2f

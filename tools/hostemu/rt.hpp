@@ -105,6 +105,22 @@ struct WaveCtx {
       if (x.v[l]) return true;
     return false;
   }
+  template <int K>
+  void quad_rot(PerLane<uint32_t>& x) {
+    for (uint32_t q = 0; q < 64; q += 4) {
+      uint32_t t[4];
+      for (uint32_t j = 0; j < 4; ++j) t[j] = x.v[q + ((j + K) & 3)];
+      for (uint32_t j = 0; j < 4; ++j) x.v[q + j] = t[j];
+    }
+  }
+  template <int K>
+  void quad_bcast(const PerLane<uint32_t>& x, PerLane<uint32_t>& out) {
+    for (uint32_t q = 0; q < 64; q += 4) {
+      const uint32_t t = x.v[q + K];
+      for (uint32_t j = 0; j < 4; ++j) out.v[q + j] = t;
+    }
+  }
+  void sync_global() {}
 };
 }  // namespace mp
 #define MP_WAVE_KERNEL(NAME, ARGS, BODY)                                   \

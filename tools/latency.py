@@ -10,9 +10,12 @@ m, n = 2, 26
 g = co.gen_inputs("stark", m, n, 7)
 eng = mp.Engine("stark", 0)
 t = eng.table(m, n, g["params"], g["pk"], fb_bits=16)
-for name, lb, bm in (("finest split, Straus only", 8192, 0), ("finest split (default: bucket kernel from 128 terms)", 8192, 2048), ("throughput plan", 0, 2048)):
+for name, lb, bm, lanes in (("finest split, Straus only", 8192, 0, 0), ("finest split, one-lane transcripts", 8192, 2048, 1),
+                            ("finest split (default: bucket kernel from 128 terms, 4-lane transcripts)", 8192, 2048, 0),
+                            ("throughput plan", 0, 2048, 0)):
     t.set_latency_batch(lb)
     t.set_bucket_min(bm)
+    t.set_transcript_lanes(lanes)
     for B in (1, 4, 64):
         decks, rho, perm, seeds = g["deck"] * B, g["rho"] * B, g["perm"] * B, g["prover_seed"] * B
         d, p, st = t.shuffle_and_remask_batch(decks, rho, perm, seeds)
@@ -25,4 +28,4 @@ for name, lb, bm in (("finest split, Straus only", 8192, 0), ("finest split (def
             sv = t.verify_shuffle_batch(decks, d, p)
         tv = (time.perf_counter() - t0) / K
         assert not any(st) and not any(sv)
-        print("%-56s B=%3d  prove %.1f ms  verify %.1f ms" % (name, B, 1e3 * tp, 1e3 * tv))
+        print("%-80s B=%3d  prove %.1f ms  verify %.1f ms" % (name, B, 1e3 * tp, 1e3 * tv))
