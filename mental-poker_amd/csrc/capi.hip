@@ -106,6 +106,10 @@ int mp_ctx_create(int curve_id, int device, mp_ctx** out) {
   c->stream = rt::stream_create();
   c->h2d = rt::stream_create();
   c->d2h = rt::stream_create();
+  c->side = rt::stream_create();
+  c->ev_fork = rt::event_create();
+  c->ev_shuf = rt::event_create();
+  c->ev_tab = rt::event_create();
   *out = c;
   return MP_OK;
   MP_CATCH
@@ -115,6 +119,10 @@ void mp_ctx_destroy(mp_ctx* ctx) {
   rt::stream_destroy(ctx->stream);
   rt::stream_destroy(ctx->h2d);
   rt::stream_destroy(ctx->d2h);
+  rt::stream_destroy(ctx->side);
+  rt::event_destroy(ctx->ev_fork);
+  rt::event_destroy(ctx->ev_shuf);
+  rt::event_destroy(ctx->ev_tab);
   delete ctx;
 }
 

@@ -114,6 +114,10 @@ struct mp_ctx {
   int device = 0;
   mp::rt::Stream stream{};      // all kernels
   mp::rt::Stream h2d{}, d2h{};  // host-buffer API: uploads and downloads of neighbouring chunks overlap the kernels
+  // small and medium batches: the prover's challenge-independent group work (re-encryption, operand sums, window tables) runs on
+  // `side` next to the randomness, c_A and the statement hash on `stream` (engine_core.hpp: prove_dev)
+  mp::rt::Stream side{};
+  mp::rt::Event ev_fork{}, ev_shuf{}, ev_tab{};
   mp::Profiler prof;
 };
 
@@ -122,6 +126,8 @@ struct mp_ctx {
 static const uint32_t FSQ_MAX_BATCH = 32768;
 // batches of up to this many proofs draw the prover's randomness with a wave per proof (kernels_proto.hpp: k_prove_init_w)
 static const uint32_t PROVE_INIT_WAVE_MAX = 2048;
+// batches of up to this many proofs overlap the two halves of the prover's first stretch on two streams (prove_dev)
+static const uint32_t OVERLAP_MAX_BATCH = 32768;
 #define MP_WAVE_RUN(NAME, C, nwaves, lds_words, args)                             \
   do {                                                                            \
     ctx->prof.begin(#NAME, ctx->stream);                                          \

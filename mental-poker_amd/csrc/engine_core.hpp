@@ -62,11 +62,12 @@ struct Workspace {
   uint32_t fw = 8;      // words of a base-field element (Geo<C>::FW of the owning table: 8, or 12 on BLS12-377)
   uint32_t Bpad = 0;
   uint32_t nS = 0, nP = 0, nJ = 0, nD = 0, nT = 0, nwin = 0, stage_words = 0;
-  DevBuf<uint32_t> S, P, J, T, NS, stage, seed, direct;
+  DevBuf<uint32_t> S, P, J, T, NS, NS2, stage, seed, direct;      // NS2: inversion scratch of the main stream while `side` has NS (prove_dev): ns2_elems points per proof
   DevBuf<uint32_t> W;       // wire words of the loaded decks, [slot][word][Bpad] (what the transcript hashes; LoadPointsArgs::W)
   DevBuf<int8_t> D;
   DevBuf<int8_t> D8;        // bucket-method digits, proof-major: [b][d8_bytes]
   uint32_t d8_bytes = 0;
+  uint32_t ns2_elems = 64;   // points per proof NS2 has room for (the owning table: max(64, m))
   DevBuf<int32_t> status;
   void ensure(uint32_t B, uint32_t nS_, uint32_t nP_, uint32_t nJ_, uint32_t nD_, uint32_t nT_, uint32_t nwin_,
               uint32_t stage_words_, rt::Stream s, uint32_t d8_bytes_ = 0) {
@@ -79,7 +80,7 @@ struct Workspace {
     nwin = nwin_;
     stage_words = std::max(stage_words, stage_words_);
     // re-allocate everything (capacity grows monotonically); zero-filled so padding lanes hold valid data
-    S.n = P.n = J.n = T.n = NS.n = stage.n = seed.n = direct.n = 0;
+    S.n = P.n = J.n = T.n = NS.n = NS2.n = stage.n = seed.n = direct.n = 0;
     D.n = 0;
     D8.n = 0;
     d8_bytes = std::max(d8_bytes, d8_bytes_);
@@ -92,6 +93,7 @@ struct Workspace {
     T.alloc((size_t)std::max(nT, 1u) * VB_ENTRIES * Bpad * 2 * fw, s);
     size_t norm_max = std::max((size_t)nT * 8, (size_t)nJ) * Bpad;   // k_table prefix products (8 per base), k_normalize ranges
     NS.alloc(norm_max * fw, s);
+    NS2.alloc((size_t)ns2_elems * Bpad * fw, s);
     stage.alloc((size_t)stage_words * Bpad, s);
     seed.alloc((size_t)8 * Bpad, s);
     direct.alloc(Bpad, s);
@@ -487,19 +489,35 @@ struct Table : mp_table {
       nT = std::max(nT, key_t_first + nwin);
     }
     ws.fw = G_::FW;
+    ws.ns2_elems = std::max(64u, m);
     ws.ensure((uint32_t)B, nS, nP, nJ, nD, nT, nwin, stage_words_needed(), ctx->stream, d8);
   }
 
   // ---------------------------------------------------------------- one dependency level of group work
-  void run_phase(PhaseDev& ph, Workspace& w, uint32_t B) {
+  // parts: which of (recode, window tables, MSMs + combines, normalisations) to run; norm_only / norm_skip: the normalisation range
+  // that starts at this slot alone / every range but it; scratch: the inversion scratch to use (default: w.NS)
+  enum : uint32_t { PH_RECODE = 1, PH_TABLES = 2, PH_MSM = 4, PH_NORM = 8, PH_ALL = 15 };
+  void run_phase(PhaseDev& ph, Workspace& w, uint32_t B, uint32_t parts = PH_ALL, uint32_t norm_only = NO_SLOT, uint32_t norm_skip = NO_SLOT,
+                 uint32_t* scratch = nullptr) {
+    if (!scratch) scratch = w.NS.p;
+    if (parts & PH_TABLES) run_tables(ph, w, B, scratch);
+    if (parts & PH_RECODE) run_recode(ph, w, B);
+    if (parts & PH_MSM) run_msms(ph, w, B);
+    if (parts & PH_NORM) run_normalize(ph, w, B, norm_only, norm_skip, scratch);
+  }
+  void run_recode(PhaseDev& ph, Workspace& w, uint32_t B) {
     if (ph.n_recode) {
       RecodeArgs a{w.S.p, w.D.p, ph.recode.p, w.Bpad, nwin};
       MP_RUN(k_recode, C, B, ph.n_recode, a);
     }
+  }
+  void run_tables(PhaseDev& ph, Workspace& w, uint32_t B, uint32_t* scratch) {
     if (ph.n_tables) {
-      TableArgs a{w.P.p, w.T.p, w.NS.p, ph.tables.p, w.Bpad, ph.n_tables, cur_table_group};
+      TableArgs a{w.P.p, w.T.p, scratch, ph.tables.p, w.Bpad, ph.n_tables, cur_table_group};
       MP_RUN(k_table, C, B, (ph.n_tables + cur_table_group - 1) / cur_table_group, a);
     }
+  }
+  void run_msms(PhaseDev& ph, Workspace& w, uint32_t B) {
     if (ph.n_f) {
       FixedArgs a{w.S.p, w.J.p, FB.p, ph.fjobs.p, ph.fterms.p, w.Bpad, fbg, w.Bpad};
       MP_RUN(k_fixed_msm, C, B, ph.n_f, a);
@@ -538,24 +556,29 @@ struct Table : mp_table {
       CombineArgs a{w.J.p, w.P.p, ph.cjobs2.p, ph.cterms2.p, w.Bpad};
       MP_RUN(k_combine, C, B, ph.n_c2, a);
     }
+  }
+  void run_normalize(PhaseDev& ph, Workspace& w, uint32_t B, uint32_t norm_only, uint32_t norm_skip, uint32_t* scratch) {
+    std::vector<std::pair<uint32_t, uint32_t>> ranges;
+    for (auto& r : ph.normalize)
+      if ((norm_only == NO_SLOT || r.first == norm_only) && r.first != norm_skip) ranges.push_back(r);
     // the ranges of a phase in as few launches as possible (NORM_MAX_RANGES per launch; element offsets must fit 32 bits)
-    for (size_t i = 0; i < ph.normalize.size();) {
-      const size_t nr = std::min<size_t>(NORM_MAX_RANGES, ph.normalize.size() - i);
+    for (size_t i = 0; i < ranges.size();) {
+      const size_t nr = std::min<size_t>(NORM_MAX_RANGES, ranges.size() - i);
       size_t last_elem = 0;
       for (size_t k = 0; k < nr; ++k)
-        last_elem = std::max(last_elem, ((size_t)ph.normalize[i + k].first + ph.normalize[i + k].second) * w.Bpad);
+        last_elem = std::max(last_elem, ((size_t)ranges[i + k].first + ranges[i + k].second) * w.Bpad);
       if (nr == 1 || last_elem >= ((size_t)1 << 32)) {
-        auto& r = ph.normalize[i];
-        normalize_flat(w.J.p + j_off<C>(r.first, w.Bpad, 0), w.P.p + p_off<C>(r.first, w.Bpad, 0), w.NS.p, (size_t)r.second * w.Bpad);
+        auto& r = ranges[i];
+        normalize_flat(w.J.p + j_off<C>(r.first, w.Bpad, 0), w.P.p + p_off<C>(r.first, w.Bpad, 0), scratch, (size_t)r.second * w.Bpad);
         ++i;
         continue;
       }
       NormMultiArgs a{};
-      a.J = w.J.p; a.P = w.P.p; a.scratch = w.NS.p;
+      a.J = w.J.p; a.P = w.P.p; a.scratch = scratch;
       a.nr = (uint32_t)nr; a.chunk = cur_norm_chunk;
       uint32_t threads = 0, selem = 0;
       for (size_t k = 0; k < nr; ++k) {
-        auto& r = ph.normalize[i + k];
+        auto& r = ranges[i + k];
         const uint32_t cnt = r.second * w.Bpad;
         a.first[k] = r.first * w.Bpad;
         a.count[k] = cnt;
@@ -629,6 +652,33 @@ struct Table : mp_table {
     return w.W.p;
   }
 
+  void prove_init(const ProveInitArgs& ia, uint32_t B) {
+    if (B <= PROVE_INIT_WAVE_MAX)      // a wave per proof: 64 ChaCha20 blocks at a time instead of one lane's ~300 in a row
+      MP_WAVE_RUN(k_prove_init_w, C, B, N, ia);
+    else
+      MP_RUN(k_prove_init, C, B, 1, ia);
+  }
+  // the challenge-independent group work behind the re-encryption (after the shuffled deck is normalised): operand sums of its
+  // rows (m = 2 Toom-Cook / Karatsuba), their Toom-Cook evaluations (3 <= m <= 16); with `overlap` also the window tables of level B
+  bool overlap = false;
+#ifdef MP_EXP_OVERLAP_MAX      // experiment hook (tools/ab_build.py): 0 = never
+  uint32_t overlap_max = MP_EXP_OVERLAP_MAX;
+#else
+  uint32_t overlap_max = OVERLAP_MAX_BATCH;
+#endif
+  void prove_side_work(PlanSet& q, Workspace& w, uint32_t B) {
+    const ProveLay& l = q.pplan.lay;
+    run_phase(q.pph[4], w, B);      // Toom-Cook (m = 2) / Karatsuba operand sums (empty when unused)
+    const ToomPlan& tk = q.pplan.toom;
+    if (tk.E) {                   // Toom-Cook, 3 <= m <= 16: the ciphertext polynomial at +-1 .. +-(m-1)
+      ToomPointsArgs ta{w.P.p, w.J.p, w.Bpad, m, n, l.shuf, tk.cv_first};
+      MP_RUN(k_toom_points, C, B, 2 * n, ta);
+      normalize_flat(w.J.p + j_off<C>(tk.cv_first, w.Bpad, 0), w.P.p + p_off<C>(tk.cv_first, w.Bpad, 0), w.NS.p,
+                     (size_t)(tk.E - 2) * 2 * n * w.Bpad);
+    }
+    if (overlap) run_phase(q.pph[1], w, B, PH_TABLES);
+  }
+
   // ---------------------------------------------------------------- prove
   // keys != nullptr: keyed batch -- proof b is made under the aggregate key keys[b] (one wire point each) instead of the
   // table's own key [REF mod.rs:380-418 takes shared_key per call; tables of different card tables differ in nothing else]
@@ -646,6 +696,7 @@ struct Table : mp_table {
     PhaseDev* pph = q.pph;
     rt::Stream s = ctx->stream;
     FixedBases fb{n};
+    overlap = overlap_max && B <= overlap_max;
     rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
     {
       uint32_t* const ww = wire_words(w, B, 1);
@@ -654,10 +705,7 @@ struct Table : mp_table {
       LoadScalarsArgs sa{rho, w.S.p, w.status.p, w.Bpad, N, l.rho};
       MP_RUN(k_load_scalars, C, B, N, sa);
       ProveInitArgs ia{w.S.p, w.status.p, perm, seeds, q.draws.p, l, w.Bpad};
-      if (B <= PROVE_INIT_WAVE_MAX)      // a wave per proof: 64 ChaCha20 blocks at a time instead of one lane's ~300 in a row
-        MP_WAVE_RUN(k_prove_init_w, C, B, N, ia);
-      else
-        MP_RUN(k_prove_init, C, B, 1, ia);
+      if (!overlap) prove_init(ia, B);
       RemaskArgs ra{w.S.p, w.P.p, w.J.p, FB.p, perm, w.Bpad, N, l.rho, l.deck, l.shuf, fb.G(), fb.pk(), fbg,
                     0, w.D.p, w.T.p, key_d_first, key_t_first, nwin, nullptr, nullptr, FbGeom{8, 32, 255}, 0};
       check_subgroup(w, B, l.deck, 2 * N);
@@ -686,17 +734,38 @@ struct Table : mp_table {
         MP_RUN(k_table, C, B, (nwin + cur_table_group - 1) / cur_table_group, ta);
         ra.keyed = 1;
       }
-      MP_RUN(k_remask, C, B, 2 * N, ra);
+      // Everything up to the first challenge falls into two independent halves.  On `side`: the re-encryption, the shuffled deck
+      // in affine form, the operand sums / Toom-Cook evaluations of its rows and the window tables of all of them -- none of it
+      // depends on the prover's randomness or on a challenge.  On the main stream: the randomness, c_A, then (once the shuffled
+      // deck is there) the statement hash and the scalar program behind it.  A batch that fills the chip gains nothing from
+      // running them side by side; a small one hides its transcript lanes and ChaCha draws behind the group work, or the other way.
+      if (overlap) {
+        struct Restore {      // (kernel launches take their stream from the context)
+          mp_ctx* c;
+          rt::Stream keep;
+          ~Restore() { c->stream = keep; }
+        } restore{ctx, s};
+        rt::event_record(ctx->ev_fork, s);
+        ctx->stream = ctx->side;
+        rt::stream_wait(ctx->side, ctx->ev_fork);
+        MP_RUN(k_remask, C, B, 2 * N, ra);
+        run_phase(pph[0], w, B, PH_NORM, l.shuf);
+        rt::event_record(ctx->ev_shuf, ctx->side);
+        prove_side_work(q, w, B);
+        rt::event_record(ctx->ev_tab, ctx->side);
+      } else {
+        MP_RUN(k_remask, C, B, 2 * N, ra);
+      }
+      if (overlap) {
+        prove_init(ia, B);
+        run_phase(pph[0], w, B, PH_ALL, NO_SLOT, l.shuf, w.NS2.p);
+        rt::stream_wait(s, ctx->ev_shuf);
+      } else {
+        run_phase(pph[0], w, B);
+        prove_side_work(q, w, B);
+      }
     }
-    run_phase(pph[0], w, B);
-    run_phase(pph[4], w, B);      // Toom-Cook (m = 2) / Karatsuba operand sums (empty when unused)
     const ToomPlan& tk = q.pplan.toom;
-    if (tk.E) {                   // Toom-Cook, 3 <= m <= 16: the ciphertext polynomial at +-1 .. +-(m-1)
-      ToomPointsArgs ta{w.P.p, w.J.p, w.Bpad, m, n, l.shuf, tk.cv_first};
-      MP_RUN(k_toom_points, C, B, 2 * n, ta);
-      normalize_flat(w.J.p + j_off<C>(tk.cv_first, w.Bpad, 0), w.P.p + p_off<C>(tk.cv_first, w.Bpad, 0), w.NS.p,
-                     (size_t)(tk.E - 2) * 2 * n * w.Bpad);
-    }
     {
       FsStatementArgs a = statement_args(w, l.deck, l.shuf, l.cA, l.x, keyed ? l.pk : NO_SLOT);
       a.W = wire_words(w, B, 1);
@@ -711,7 +780,12 @@ struct Table : mp_table {
       FillConstArgs fa{w.S.p, q.consts.p, w.Bpad, tk.w_first, tk.w_const_first};
       MP_RUN(k_fill_consts, C, B, tk.E * tk.E, fa);
     }
-    run_phase(pph[1], w, B);
+    if (overlap) {
+      rt::stream_wait(s, ctx->ev_tab);
+      run_phase(pph[1], w, B, PH_ALL & ~PH_TABLES);
+    } else {
+      run_phase(pph[1], w, B);
+    }
     run_phase(pph[5], w, B);      // Toom-Cook interpolation: the diagonals E_k from the 2m products (empty otherwise)
     const FsDev f{w.stage.p, w.seed.p, w.Bpad};
     {
