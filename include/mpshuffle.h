@@ -199,6 +199,12 @@ int mp_set_chain_max_links(mp_table* t, uint32_t links);
  * fewer instructions in the chain: what a single proof or a few thousand large decks wait for), 0 (default) = 4 for batches of up
  * to 32 768 proofs, 1 above.  Digests, challenges and proofs are the same. */
 int mp_set_transcript_lanes(mp_table* t, uint32_t lanes);
+/* Lanes per group operation in the dependency chains of the multi-scalar multiplications (the Straus accumulators, the window fold
+ * of the bucket method).  1 = one lane per chain (fewest instructions: what a batch that fills the chip wants); 4 = the independent
+ * field products of a doubling / addition on four adjacent lanes, 3-4 products deep instead of 10-14 (what a single proof waits for:
+ * every MSM has ~250 dependent doublings); 0 (default) = 4 while the chains of a launch need at most 65 536 lanes that way (a few
+ * dozen 52-card proofs), 1 above.  The results are the same group elements. */
+int mp_set_group_lanes(mp_table* t, uint32_t lanes);
 /* How the prover evaluates the multi-exponentiation diagonals E_k (a polynomial product of the scalar rows with the ciphertext
  * rows) for 3 <= m <= 16.  on (default): Toom-Cook with the 2m points 0, inf, +-1 .. +-(m-1) -- 2m row products; off: recursive
  * Karatsuba (13 products at m = 4, 35 at m = 8; what m > 16 always uses).  m = 2 always uses its 4-point Toom-Cook form.  The

@@ -223,6 +223,12 @@ int mp_set_transcript_lanes(mp_table* t, uint32_t lanes) {
   t->fs_lanes = lanes;
   return MP_OK;
 }
+int mp_set_group_lanes(mp_table* t, uint32_t lanes) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_lanes: null table");
+  if (lanes != 0 && lanes != 1 && lanes != 4) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_lanes: 0 (by batch size), 1 or 4");
+  t->group_lanes = lanes;
+  return MP_OK;
+}
 int mp_set_toom_cook(mp_table* t, int on) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_toom_cook: null table");
   MP_TRY

@@ -505,6 +505,21 @@ struct Table : mp_table {
     if (parts & PH_MSM) run_msms(ph, w, B);
     if (parts & PH_NORM) run_normalize(ph, w, B, norm_only, norm_skip, scratch);
   }
+  // kernels_quad.hpp: up to this many lanes' worth of (proof, job) pairs run their group operations on four lanes each
+#ifdef MP_EXP_QUAD_MAX      // experiment hook (tools/ab_build.py): 0 = never
+  uint32_t quad_max_lanes = MP_EXP_QUAD_MAX;
+#else
+  uint32_t quad_max_lanes = 65536;
+#endif
+  bool quad_ops(uint32_t B, uint32_t njobs) const { return group_lanes == 4 || (group_lanes == 0 && (uint64_t)B * njobs * 4u <= quad_max_lanes); }
+  void run_combine(const CombineArgs& a, uint32_t B, uint32_t njobs) {
+    if (quad_ops(B, njobs)) {
+      CombineQuadArgs qa{a, B, njobs};
+      MP_WAVE_RUN(k_combine_q, C, (B * njobs + 15u) / 16u, 0, qa);
+    } else {
+      MP_RUN(k_combine, C, B, njobs, a);
+    }
+  }
   void run_recode(PhaseDev& ph, Workspace& w, uint32_t B) {
     if (ph.n_recode) {
       RecodeArgs a{w.S.p, w.D.p, ph.recode.p, w.Bpad, nwin};
@@ -520,7 +535,12 @@ struct Table : mp_table {
   void run_msms(PhaseDev& ph, Workspace& w, uint32_t B) {
     if (ph.n_f) {
       FixedArgs a{w.S.p, w.J.p, FB.p, ph.fjobs.p, ph.fterms.p, w.Bpad, fbg, w.Bpad};
-      MP_RUN(k_fixed_msm, C, B, ph.n_f, a);
+      if (quad_ops(B, ph.n_f)) {
+        FixedQuadArgs qa{a, B, ph.n_f};
+        MP_WAVE_RUN(k_fixed_msm_q, C, (B * ph.n_f + 15u) / 16u, 0, qa);
+      } else {
+        MP_RUN(k_fixed_msm, C, B, ph.n_f, a);
+      }
     }
     if (ph.n_v) {
       VarArgs a{w.D.p, w.T.p, w.J.p, ph.vjobs.p, ph.vterms.p, w.Bpad, nwin};
@@ -529,7 +549,12 @@ struct Table : mp_table {
       hipLaunchKernelGGL((k_var_msm<C>), dim3((B + 255u) / 256u, ph.n_v), dim3(256), MP_EXP_VAR_LDS, ctx->stream, a, (uint32_t)B);
       ctx->prof.end(ctx->stream);
 #else
-      MP_RUN(k_var_msm, C, B, ph.n_v, a);
+      if (quad_ops(B, ph.n_v)) {      // a handful of proofs: four lanes per group operation, 3-4 products deep instead of 10
+        VarQuadArgs qa{a, B, ph.n_v};
+        MP_WAVE_RUN(k_var_msm_q, C, (B * ph.n_v + 15u) / 16u, 0, qa);
+      } else {
+        MP_RUN(k_var_msm, C, B, ph.n_v, a);
+      }
 #endif
     }
     if (ph.n_b) {   // large MSMs: bucket method, one wave per (proof, MSM, window)
@@ -542,19 +567,24 @@ struct Table : mp_table {
       MP_WAVE_LAUNCH(k_bucket_msm, C, ctx->stream, B * ph.n_b * bw, bk_lds_words(ph.b_kpad_max, XyzzWords<C>::N), ba);
       ctx->prof.end(ctx->stream);
       BFoldArgs fa{w.J.p, ph.bjobs.p, w.Bpad, bw};
-      MP_RUN(k_bucket_fold, C, B, ph.n_b, fa);
+      if (quad_ops(B, ph.n_b)) {
+        BFoldQuadArgs qa{fa, B, ph.n_b};
+        MP_WAVE_RUN(k_bucket_fold_q, C, (B * ph.n_b + 15u) / 16u, 0, qa);
+      } else {
+        MP_RUN(k_bucket_fold, C, B, ph.n_b, fa);
+      }
     }
     if (ph.n_c0) {   // group sums of MSMs with many partials
       CombineArgs a{w.J.p, w.P.p, ph.cjobs0.p, ph.cterms0.p, w.Bpad};
-      MP_RUN(k_combine, C, B, ph.n_c0, a);
+      run_combine(a, B, ph.n_c0);
     }
     if (ph.n_c) {
       CombineArgs a{w.J.p, w.P.p, ph.cjobs.p, ph.cterms.p, w.Bpad};
-      MP_RUN(k_combine, C, B, ph.n_c, a);
+      run_combine(a, B, ph.n_c);
     }
     if (ph.n_c2) {   // second stage: consumers of first-stage combine outputs
       CombineArgs a{w.J.p, w.P.p, ph.cjobs2.p, ph.cterms2.p, w.Bpad};
-      MP_RUN(k_combine, C, B, ph.n_c2, a);
+      run_combine(a, B, ph.n_c2);
     }
   }
   void run_normalize(PhaseDev& ph, Workspace& w, uint32_t B, uint32_t norm_only, uint32_t norm_skip, uint32_t* scratch) {

@@ -289,9 +289,13 @@ MP_HD void body_bucket_fold(const BFoldArgs& a, uint32_t b, uint32_t y) {
 }
 MP_KERNEL_OCC(k_bucket_fold, BFoldArgs, body_bucket_fold, Geo<C>::OCC4)
 
+}  // namespace mp
+#include "kernels_quad.hpp"
 #define MP_BUCKET_KERNELS(X, C)                          \
   MP_KERNEL_INST(X, k_bucket_recode, BRecodeArgs, C)     \
   MP_WAVE_KERNEL_INST(X, k_bucket_msm, BucketArgs, C)    \
-  MP_KERNEL_INST(X, k_bucket_fold, BFoldArgs, C)
-
-}  // namespace mp
+  MP_KERNEL_INST(X, k_bucket_fold, BFoldArgs, C)         \
+  MP_WAVE_KERNEL_INST(X, k_var_msm_q, VarQuadArgs, C)    \
+  MP_WAVE_KERNEL_INST(X, k_bucket_fold_q, BFoldQuadArgs, C) \
+  MP_WAVE_KERNEL_INST(X, k_fixed_msm_q, FixedQuadArgs, C)   \
+  MP_WAVE_KERNEL_INST(X, k_combine_q, CombineQuadArgs, C)

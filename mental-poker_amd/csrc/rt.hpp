@@ -118,7 +118,9 @@ struct WaveCtx {
   uint32_t lane;
   uint32_t* lds;
   template <class Fn>
-  __device__ __forceinline__ void lanes(Fn f) { f(lane); }
+  __device__ __forceinline__ void lanes(Fn f) {
+    f(lane);
+  }
   __device__ __forceinline__ void sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -146,17 +148,37 @@ struct WaveCtx {
   }
   // does any lane of the wave hold a non-zero flag?  (wavefront ballot)
   __device__ __forceinline__ bool any(const PerLane<uint32_t>& x) { return __ballot(x.v != 0) != 0; }
+  // (every DPP move below ends in an empty asm that makes its result opaque: LLVM's DPP combiner (GCNDPPCombine, ROCm 7.2) folds such a
+  // move into a following v_subrev_u32 as `v_subrev_u32_dpp`, and the folded form returned lane-dependent differences on gfx950 --
+  // tools/quadcheck; with the move kept as an instruction of its own the results are right)
+  static __device__ __forceinline__ uint32_t dpp_keep(uint32_t x) {
+    asm("" : "+v"(x));
+    return x;
+  }
   // QUADS = aligned groups of four lanes (the transcript kernels put one BLAKE2s state on a quad, hash.hpp).  One DPP move each:
   // quad_rot<K>: lane j takes the value of lane (j + K) mod 4 of its quad; quad_bcast<K>: every lane takes lane K's
   template <int K>
   __device__ __forceinline__ void quad_rot(PerLane<uint32_t>& x) {
     constexpr int ctrl = ((0 + K) & 3) | (((1 + K) & 3) << 2) | (((2 + K) & 3) << 4) | (((3 + K) & 3) << 6);
-    x.v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.v, ctrl, 0xF, 0xF, true);
+    x.v = dpp_keep((uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.v, ctrl, 0xF, 0xF, true));
   }
   template <int K>
   __device__ __forceinline__ void quad_bcast(const PerLane<uint32_t>& x, PerLane<uint32_t>& out) {
     constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);
-    out.v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.v, ctrl, 0xF, 0xF, true);
+    out.v = dpp_keep((uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.v, ctrl, 0xF, 0xF, true));
+  }
+  // lane K's copy of a per-lane value (any struct of 32-bit words), read from inside a lanes() section -- only of values written
+  // in an EARLIER section
+  template <int K, class T>
+  __device__ __forceinline__ T quad_read(const PerLane<T>& x, uint32_t) const {
+    static_assert(sizeof(T) % 4 == 0, "whole words");
+    constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);
+    T r;
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(&x.v);
+    uint32_t* d = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; ++i) d[i] = dpp_keep((uint32_t)__builtin_amdgcn_update_dpp(0, (int)s[i], ctrl, 0xF, 0xF, true));
+    return r;
   }
   // global-memory words written by any lane of the wave before are visible to every lane of the wave afterwards
   __device__ __forceinline__ void sync_global() {

@@ -550,8 +550,9 @@ def test_bucket_kernel_matches_oracle(mp, coracle, curve, m, n, B):
 @pytest.mark.parametrize("curve,m,n,B,keyed", [("stark", 2, 26, 70, False), ("stark", 4, 13, 1500, False), ("stark", 2, 3, 20000, False),
                                                ("secp256k1", 2, 7, 3, True), ("bls12_377", 2, 5, 3, False), ("bn254", 3, 5, 1, True)])
 def test_transcript_lane_modes_agree(mp, coracle, curve, m, n, B, keyed):
-    """mp_set_transcript_lanes: one lane per proof and four lanes per BLAKE2s state (k_fsq_*: 64, 32 and 4 lanes of a wave per proof
-    at these batch sizes) produce the same proofs -- the oracle's -- and the same verdicts, honest and tampered"""
+    """mp_set_transcript_lanes / mp_set_group_lanes: one lane per proof and four lanes per BLAKE2s state (k_fsq_*: 64, 32 and 4 lanes
+    of a wave per proof at these batch sizes), one lane and four lanes per group operation of the MSM chains (k_var_msm_q,
+    k_bucket_fold_q) produce the same proofs -- the oracle's -- and the same verdicts, honest and tampered"""
     cards = mp.DLCards(curve, device=0)
     g0 = coracle.gen_inputs(curve, m, n, 100)
     pp, pk = mp.Parameters(m, n, g0["params"]), g0["pk"]
@@ -567,6 +568,7 @@ def test_transcript_lane_modes_agree(mp, coracle, curve, m, n, B, keyed):
     out = {}
     for lanes in (1, 4):
         t.set_transcript_lanes(lanes)
+        t.set_group_lanes(lanes if B <= 1500 else 1)         # (kernels_quad.hpp: four lanes per group operation)
         if keyed:
             sh, pf, st = t.shuffle_and_remask_batch_keys(keys, decks, rho, perms, seeds)
         else:
@@ -582,6 +584,7 @@ def test_transcript_lane_modes_agree(mp, coracle, curve, m, n, B, keyed):
         t.set_merged_verify(True)
         out[lanes] = (sh, pf, verdicts)
     t.set_transcript_lanes(0)
+    t.set_group_lanes(0)
     assert out[1] == out[4]
     sh, pf, verdicts = out[4]
     assert verdicts[0][0] == [0] * B and verdicts[0] == verdicts[1] and verdicts[0][1][:-1] == [0] * (B - 1) and verdicts[0][1][-1] > 0
@@ -592,7 +595,8 @@ def test_transcript_lane_modes_agree(mp, coracle, curve, m, n, B, keyed):
             exp_deck, exp_proof = coracle.shuffle_and_remask(curve, m, n, g0["params"], pk, g["deck"], g["rho"], g["perm"], g["prover_seed"])
             assert sh[b * len(exp_deck):(b + 1) * len(exp_deck)] == exp_deck and pf[b * psz:(b + 1) * psz] == exp_proof
     rp = cards.engine.profile_report()
-    for k in ("k_fsq_round1", "k_fsq_round", "k_fsq_verify", "k_fs_round1", "k_fs_round", "k_verify_fs"):
+    for k in ("k_fsq_round1", "k_fsq_round", "k_fsq_verify", "k_fs_round1", "k_fs_round", "k_verify_fs", "k_var_msm") + \
+            (("k_var_msm_q",) if B <= 1500 else ()):
         assert rp[k][0] >= 1, k
 
 

@@ -120,6 +120,8 @@ struct WaveCtx {
       for (uint32_t j = 0; j < 4; ++j) out.v[q + j] = t;
     }
   }
+  template <int K, class T>
+  T quad_read(const PerLane<T>& x, uint32_t l) const { return x.v[(l & ~3u) + K]; }
   void sync_global() {}
 };
 }  // namespace mp
