@@ -2,8 +2,8 @@
 // engine_base.hpp -- shared declarations of libmpshuffle.so
 // libmpshuffle.so: host orchestration of the gfx950 shuffle-proof engine and its C ABI (include/mpshuffle.h).
 //
-// A batch of B independent proofs goes through a fixed sequence of kernels on one HIP stream with NO host
-// round-trip inside a batch: Fiat-Shamir challenges are derived on the device.  The prover's group work is
+// A batch of B independent proofs goes through a fixed sequence of kernels on one HIP stream (two for the prover's first stretch
+// of batches up to 32 768 proofs: engine_core.hpp prove_dev) with NO host round-trip inside a batch: Fiat-Shamir challenges are derived on the device.  The prover's group work is
 // packed into four dependency levels (everything that can be computed between two squeeze points runs in one
 // launch of each kernel class), the verifier's into one.
 //
