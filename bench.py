@@ -837,6 +837,9 @@ def main():
               "proofs_per_gpu_per_step": proofs_per_step, "streams": S, "fixed_base_window_bits": args.fb_bits,
               "aggregate_keys": (B if workload == "chain32" else (args.keyed if args.keyed else 1)),
               "verification": "per equation" if args.per_equation else "merged screening pass (per-equation pass only to name a failure)",
+              # engine choices by batch size (include/mpshuffle.h: mp_set_transcript_lanes; engine_base.hpp: OVERLAP_MAX_BATCH)
+              "transcript_lanes": (args.transcript_lanes or (4 if Bs <= 32768 else 1)),
+              "prover_streams": (2 if Bs <= 32768 and workload != "chain32" else 1),
               "parallelism": "%d rank(s), proofs sharded, no data-path collective; parameters broadcast once (%s)" % (world, backend),
               "rccl_world": (dist.get_world_size() if world > 1 else 1), "collective_backend": backend if world > 1 else None,
               "table_build_s": round(table_build_s, 3),

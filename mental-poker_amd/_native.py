@@ -69,8 +69,22 @@ def build(verbose=False):
         subprocess.check_call(cmd)
         return obj, True
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+    def compile_check():
+        """tools/quadcheck/quad_check: on-device unit test of the four-lane group law (kernels_quad.hpp) against the one-lane one;
+        built here so that it travels to the GPU box with the library (tests/test_gpu_parity.py runs it)"""
+        src = os.path.join(ROOT, "tools", "quadcheck", "quad_check.hip")
+        exe = os.path.join(ROOT, "tools", "quadcheck", "quad_check")
+        if not os.path.exists(src) or (os.path.exists(exe) and os.path.getmtime(exe) >= max(hdr_time, os.path.getmtime(src))):
+            return
+        cmd = [hipcc] + [f for f in flags if f != "-fPIC"] + ["-I", csrc, src, "-o", exe]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES) + 1) as ex:
+        chk = ex.submit(compile_check)
         res = list(ex.map(compile_one, SOURCES))
+        chk.result()
     objs = [r[0] for r in res]
     if any(r[1] for r in res) or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(o) for o in objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB_PATH] + objs      # serialize_host.hpp uses std::thread

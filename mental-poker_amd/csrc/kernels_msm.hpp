@@ -656,6 +656,31 @@ MP_HD void body_subgroup_check(const SubgroupArgs& a, uint32_t b, uint32_t y) {
   typedef typename C::FrP R;
   const Aff<C> p = ld_aff<C>(a.P + p_off<C>(a.p_first + y, a.Bpad, b));
   if (aff_is_inf<C>(p)) return;
+  if constexpr (C::ENDO_SUBGROUP) {
+    // The same verdict from 126 doublings + 12 additions instead of 253 + 126 (round 3: this kernel was half of a BLS12-377 step).
+    // phi(x, y) = (beta x, y) acts on G1 as -u^2 (u = the curve's seed, r = u^4 - u^2 + 1), and psi = phi + [u^2] has degree
+    // Norm(u^2 + omega) = r, so its kernel IS the subgroup of order r:  P in G1  <=>  phi(P) = -[u^2] P  (curve_params.hpp;
+    // checked against [r]P = O by tools/gen_curve_params.py's note and tests/test_gpu_canonical.py's off-subgroup points).
+    typedef typename C::FqP F;
+    Jac<C> q1 = jac_from_aff<C>(p);
+#pragma unroll 1
+    for (int i = 62; i >= 0; --i) {              // [u] P  (u has bit 63 set)
+      jac_dbl_ip<C>(q1);
+      if ((C::SEED >> i) & 1u) jac_madd_ip<C>(q1, p);
+    }
+    Jac<C> q2 = q1;
+#pragma unroll 1
+    for (int i = 62; i >= 0; --i) {              // [u] ([u] P)
+      jac_dbl_ip<C>(q2);
+      if ((C::SEED >> i) & 1u) jac_add_ip<C>(q2, q1);
+    }
+    bool ok = !jac_is_inf<C>(q2);                // (X : Y : Z) = -(beta x, y):  beta x Z^2 = X,  y Z^3 = -Y
+    const Fe<F> zz = fe_sqr<F>(q2.Z);
+    ok = ok && fe_is_zero(fe_sub<F>(fe_mul<F>(fe_mul<F>(fe_unpack<F>(C::BETA_MONT), p.x), zz), q2.X));
+    ok = ok && fe_is_zero(fe_add<F>(fe_mul<F>(fe_mul<F>(p.y, zz), q2.Z), q2.Y));
+    if (!ok) a.status[b] = -1;                   // ST_BAD_ENCODING (kernels_proto.hpp)
+    return;
+  }
   Jac<C> acc = jac_from_aff<C>(p);
 #pragma unroll 1
   for (int i = R::BITS - 2; i >= 0; --i) {

@@ -383,6 +383,8 @@ def test_points_outside_the_prime_order_subgroup_are_rejected(emu, native):
         low = po.pt_mul_raw(cv, cv.q, (x, y))      # ... times q: non-trivial, of order dividing the cofactor
         assert cv.is_on_curve(low) and po.pt_mul_raw(cv, po.COFACTOR["bls12_377"], low) is None
         bad = po.pt_wire(low)
+        # the device's test is phi(P) = -[u^2]P (kernels_msm.hpp): also the untouched curve point and a subgroup point plus `low`
+        others = [po.pt_wire((x, y)), po.pt_wire(po.pt_add(cv, low, cv.G))]
     eng = emu("bls12_377")
     params, pk = bytes.fromhex(g["params"]), bytes.fromhex(g["pk"])
     with pytest.raises(native.NativeError):
@@ -394,6 +396,8 @@ def test_points_outside_the_prime_order_subgroup_are_rejected(emu, native):
     assert t.verify_shuffle_batch(deck, shuf, proof) == [0]
     tampered = bad + deck[96:]
     assert t.verify_shuffle_batch(tampered, shuf, proof) == [native._native.MP_ERR_BAD_ENCODING]
+    for o in others:
+        assert t.verify_shuffle_batch(o + deck[96:], shuf, proof) == [native._native.MP_ERR_BAD_ENCODING]
     _, _, st = t.shuffle_and_remask_batch(tampered, bytes.fromhex(g["rho"]), g["perm"], bytes.fromhex(g["prover_seed"]))
     assert st == [native._native.MP_ERR_BAD_ENCODING]
     t.set_subgroup_check(False)                     # the caller vouches for its points: the same input is now merely a wrong statement

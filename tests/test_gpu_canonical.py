@@ -143,6 +143,13 @@ def test_points_outside_the_prime_order_subgroup_are_rejected(mp, engines):
     shuf[0] = qwire + shuf[0][len(qwire):]
     with pytest.raises((mp.CardProtocolError, mp.NativeError)):
         cards.verify_shuffle(P, bytes.fromhex(g["pk"]), deck, shuf, bytes.fromhex(g["proof"]))
+    # (the device tests phi(P) = -[u^2]P: also a subgroup point plus that low-order point, in every position of a batch)
+    with po.curve_ctx(cv):
+        mixed = po.pt_wire(po.pt_add(cv, Q, po.pt_mul(cv, 12345, cv.G)))
+    t = cards.table(P, bytes.fromhex(g["pk"]))
+    good_d, good_s, pf = bytes.fromhex(g["deck"]), bytes.fromhex(g["shuffled"]), bytes.fromhex(g["proof"])
+    bad_s = mixed + good_s[len(mixed):]
+    assert t.verify_shuffle_batch(good_d * 5, good_s + bad_s + good_s * 2 + bad_s, pf * 5) == [0, -1, 0, 0, -1]
 
 
 def test_malformed_encodings(mp):

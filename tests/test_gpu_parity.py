@@ -600,6 +600,21 @@ def test_transcript_lane_modes_agree(mp, coracle, curve, m, n, B, keyed):
         assert rp[k][0] >= 1, k
 
 
+def test_four_lane_group_law_matches_one_lane(mp):
+    """kernels_quad.hpp on the device: doubling, mixed addition / subtraction and full addition (incl. P + P) on four lanes per
+    operation against curve.hpp's one-lane forms, 16 different points per curve, with and without divergence between the quads of a
+    wave (tools/quadcheck/quad_check.hip, built with the library)"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "quadcheck", "quad_check")
+    if not os.path.exists(exe):
+        mp._native.build()
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600).stdout
+    lines = [l for l in out.splitlines() if "fails mask" in l]
+    assert len(lines) == 4, out
+    for l in lines:
+        assert "fails mask 0x0 " in l, l
+
+
 def test_bucket_msm_large_and_edge_scalars(mp, coracle):
     cv = "stark"
     q = 0x0800000000000010ffffffffffffffffb781126dcae7b2321e66a241adc64d2f

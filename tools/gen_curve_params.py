@@ -137,6 +137,18 @@ def field(name, p):
     return s
 
 
+# Curves with a cofactor whose prime-order subgroup has a fast membership test through the endomorphism (x, y) -> (beta x, y):
+# BLS12-377 G1, seed u = 0x8508c00000000001, r = u^4 - u^2 + 1.  psi = phi + [u^2] has degree Norm(u^2 + omega) = u^4 - u^2 + 1 = r,
+# so ker psi has r elements and contains G1 (phi acts on it as -u^2 for the beta below): P in G1  <=>  phi(P) = -[u^2] P, exactly.
+# (Checked against [r]P = O on random curve points, cofactor-cleared points, points of order dividing the cofactor and mixtures with
+# the Python oracle's big-integer curve arithmetic.)
+ENDO = {"Bls12_377": dict(seed=0x8508c00000000001,
+                          beta=0x1ae3a4617c510eabc8756ba8f8c524eb8882a75cc9bc8e359064ee822fb5bffd1e945779fffffffffffffffffffffff)}
+for (nm_, cid_, p_, a_, b_, q_, gx_, gy_) in CURVES:
+    if nm_ in ENDO:
+        e_ = ENDO[nm_]
+        assert pow(e_["beta"], 3, p_) == 1 and e_["beta"] != 1 and q_ == e_["seed"] ** 4 - e_["seed"] ** 2 + 1
+
 out = ["// GENERATED by tools/gen_curve_params.py -- do not edit.  Constants: SURVEY.md App. C.",
        "#pragma once", "#include <cstdint>", "namespace mp {", ""]
 for (nm, cid, p, a, b, q, gx, gy) in CURVES:
@@ -146,8 +158,13 @@ for (nm, cid, p, a, b, q, gx, gy) in CURVES:
     out.append(field(nm + "Fr", q))
     out.append("struct %s {\n  typedef %sFq FqP;\n  typedef %sFr FrP;\n  static constexpr int ID = %d;\n  static constexpr int A = %d;\n"
                "  static constexpr uint32_t B_MONT[%d] = %s;   // b, gx, gy: Montgomery form w.r.t. the base field's R, packed words\n"
-               "  static constexpr uint32_t GX_MONT[%d] = %s;\n  static constexpr uint32_t GY_MONT[%d] = %s;\n};\n"
-               % (nm, nm, nm, cid, a, nw, limbs(b * RQ % p, nw), nw, limbs(gx * RQ % p, nw), nw, limbs(gy * RQ % p, nw)))
+               "  static constexpr uint32_t GX_MONT[%d] = %s;\n  static constexpr uint32_t GY_MONT[%d] = %s;\n"
+               % (nm, nm, nm, cid, a, nw, limbs(b * RQ % p, nw), nw, limbs(gx * RQ % p, nw), nw, limbs(gy * RQ % p, nw))
+               + ("  // prime-order subgroup test through the endomorphism (x, y) -> (beta x, y): P in G1 <=> phi(P) = -[SEED^2] P\n"
+                  "  static constexpr bool ENDO_SUBGROUP = true;\n  static constexpr uint64_t SEED = 0x%xull;\n"
+                  "  static constexpr uint32_t BETA_MONT[%d] = %s;\n" % (ENDO[nm]["seed"], nw, limbs(ENDO[nm]["beta"] * RQ % p, nw))
+                  if nm in ENDO else "  static constexpr bool ENDO_SUBGROUP = false;\n")
+               + "};\n")
 out.append("}  // namespace mp\n")
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mental-poker_amd", "csrc", "curve_params.hpp")
 open(path, "w").write("\n".join(out))
