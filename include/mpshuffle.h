@@ -175,9 +175,9 @@ int mp_sync(mp_ctx* ctx);
 int mp_reserve(mp_table* t, size_t B);           /* pre-allocate the batch workspace for B proofs */
 /* Every table holds four static work splits with identical results: a throughput plan (large sub-jobs, fewest operations),
  * a latency plan (small sub-jobs: ~16x more lanes per proof), a medium plan in between and a finest split for single proofs.
- * Batches of at most 3/16 B proofs use the finest split, up to `B` the latency plan, up to 3.5 B the medium plan, larger ones
- * the throughput plan (default B = 4096 * 52 / N, at least 64:
- * measured on an MI355X with 52 and 1024 cards; 0 = always throughput). */
+ * Batches of at most B/4 proofs use the finest split, up to `B` the latency plan, up to 32/3 B the medium plan, larger ones
+ * the throughput plan (default B = 3072 * 52 / N, at least 64: 768 / 3 072 / 32 768 proofs of 52 cards, the crossovers
+ * measured on an MI355X; 0 = always throughput). */
 int mp_set_latency_batch(mp_table* t, size_t B);
 /* Verification strategy.  on (default): the verifier first evaluates ALL group equations of a proof merged into one
  * multi-scalar multiplication with random weights derived from the whole proof (soundness loss ~2^-250); a batch in which

@@ -132,15 +132,17 @@ struct Table : mp_table {
   bool psk_ready = false;
   DevBuf<Term> key_recode, key_tables;          // static job lists of the per-proof key tables
   uint32_t key_d_first = 0, key_t_first = 0;     // first digit slot (rho_0) / table slot (window 0) of the key machinery
-  uint32_t latency_batch = 4096;                 // batches up to this size use the latency plan (mp_set_latency_batch),
-  uint32_t medium_batch = 14336;                 // up to this size the medium plan (3.5 x latency_batch), larger ones throughput
-  uint32_t tiny_batch = 768;                     // up to this size the finest split (3/16 x latency_batch)
+  // (crossovers measured on 52-card decks at the end of round 3, profiles/r03k_plan_sweep.txt: 768 / 3 072 / 32 768 -- the shorter
+  // transcripts and chains of small batches moved them from round 2's 768 / 4 096 / 14 336)
+  uint32_t latency_batch = 3072;                 // batches up to this size use the latency plan (mp_set_latency_batch),
+  uint32_t medium_batch = 32768;                 // up to this size the medium plan (32/3 x latency_batch), larger ones throughput
+  uint32_t tiny_batch = 768;                     // up to this size the finest split (1/4 x latency_batch, in steps of 4)
   int plan_of(uint32_t B) const { return B <= tiny_batch ? 3 : (B <= latency_batch ? 1 : (B <= medium_batch ? 2 : 0)); }
   PlanSet& pick(uint32_t B, bool keyed = false) { return (keyed ? psk : ps)[plan_of(B)]; }
   void set_latency_batch(size_t b) override {
     latency_batch = (uint32_t)std::min<size_t>(b, 0x20000000u);
-    medium_batch = latency_batch / 2 * 7;
-    tiny_batch = latency_batch / 16 * 3;
+    medium_batch = (uint32_t)std::min<uint64_t>((uint64_t)latency_batch * 32 / 3, 0x40000000u);
+    tiny_batch = latency_batch / 16 * 4;
   }
   uint32_t bucket_min = BUCKET_MIN;              // MSMs of at least this many variable-base terms use the bucket kernel (0 = never)
   bool toom_cook = true;        // 3 <= m <= 16: Toom-Cook instead of Karatsuba for the multi-exponentiation diagonals
@@ -321,7 +323,7 @@ struct Table : mp_table {
     m = m_; n = n_; N = m * n;
     point_bytes = G_::PB;
     // plan thresholds count lanes, and a proof of N cards brings ~N/52 times the lanes of a 52-card proof
-    set_latency_batch(std::max<size_t>(64, (size_t)4096 * 52 / N));
+    set_latency_batch(std::max<size_t>(64, (size_t)3072 * 52 / N));
     nwin = (uint32_t)vb_windows(R::BITS);
     FixedBases fb{n};
     std::vector<Aff<C>> bases(fb.count());

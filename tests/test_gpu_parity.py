@@ -600,6 +600,34 @@ def test_transcript_lane_modes_agree(mp, coracle, curve, m, n, B, keyed):
         assert rp[k][0] >= 1, k
 
 
+def test_alternating_batch_sizes_are_consistent(mp, coracle):
+    """one table, batches of very different sizes back to back (they take different kernels -- four-lane or one-lane transcripts and
+    group operations, one or two prover streams, the four static plans -- and share the context's streams, events and arenas):
+    proof 0 is the oracle's every time, every batch verifies, and a batch verified right after a larger one gets its own verdicts"""
+    curve, m, n = "stark", 2, 4
+    cards = mp.DLCards(curve, device=0)
+    g0 = coracle.gen_inputs(curve, m, n, 100)
+    pp, pk = mp.Parameters(m, n, g0["params"]), g0["pk"]
+    t = cards.table(pp, pk)
+    ins = [coracle.gen_inputs(curve, m, n, 300 + b) for b in range(4)]
+    exp = [coracle.shuffle_and_remask(curve, m, n, g0["params"], pk, g["deck"], g["rho"], g["perm"], g["prover_seed"]) for g in ins]
+    dsz, psz = len(exp[0][0]), len(exp[0][1])
+    for rnd, B in enumerate([1, 40000, 3, 70, 1500, 2, 33000, 5, 1, 9000]):
+        rep = (B + 3) // 4
+        cat = lambda key: (b"".join(g[key] for g in ins) * rep)[:B * len(ins[0][key])]
+        decks, rho, seeds = cat("deck"), cat("rho"), cat("prover_seed")
+        perms = ([x for g in ins for x in g["perm"]] * rep)[:B * m * n]
+        sh, pf, st = t.shuffle_and_remask_batch(decks, rho, perms, seeds)
+        assert st == [0] * B, (B, [x for x in st if x][:3])
+        for b in sorted({0, B // 2, B - 1}):
+            assert sh[b * dsz:(b + 1) * dsz] == exp[b % 4][0] and pf[b * psz:(b + 1) * psz] == exp[b % 4][1], (B, b)
+        bad = bytearray(pf)
+        bad[(B - 1) * psz + psz - 96] ^= 1
+        assert t.verify_shuffle_batch(decks, sh, pf) == [0] * B
+        v = t.verify_shuffle_batch(decks, sh, bytes(bad))
+        assert v[:-1] == [0] * (B - 1) and v[-1] > 0, (B, v[-3:])
+
+
 def test_four_lane_group_law_matches_one_lane(mp):
     """kernels_quad.hpp on the device: doubling, mixed addition / subtraction and full addition (incl. P + P) on four lanes per
     operation against curve.hpp's one-lane forms, 16 different points per curve, with and without divergence between the quads of a

@@ -80,16 +80,22 @@ __global__ void __launch_bounds__(64) k_check(uint32_t* out) {
 template <class C>
 void run(const char* name) {
   uint32_t* d;
-  hipMalloc(&d, 64 * 4);
+  if (hipMalloc(&d, 64 * 4) != hipSuccess) {
+    printf("%-10s hipMalloc failed\n", name);
+    return;
+  }
   hipLaunchKernelGGL((k_check<C>), dim3(1), dim3(64), 0, 0, d);
   uint32_t h[64];
-  hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+  if (hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) {
+    printf("%-10s kernel failed\n", name);
+    return;
+  }
   uint32_t any = 0;
   for (int i = 0; i < 64; ++i) any |= h[i];
   printf("%-10s fails mask 0x%x  per lane:", name, any);
   for (int i = 0; i < 64; ++i) printf(" %x", h[i]);
   printf("\n");
-  hipFree(d);
+  (void)hipFree(d);
 }
 int main() {
   run<Stark>("stark");
