@@ -691,14 +691,13 @@ struct Table : mp_table {
       MP_RUN(k_prove_init, C, B, 1, ia);
   }
   // the challenge-independent group work behind the re-encryption (after the shuffled deck is normalised): operand sums of its
-  // rows (m = 2 Toom-Cook / Karatsuba), their Toom-Cook evaluations (3 <= m <= 16); with `overlap` also the window tables of level B
-  bool overlap = false;
+  // rows (m = 2 Toom-Cook / Karatsuba), their Toom-Cook evaluations (3 <= m <= 16); with_tables: also the window tables of level B
 #ifdef MP_EXP_OVERLAP_MAX      // experiment hook (tools/ab_build.py): 0 = never
   uint32_t overlap_max = MP_EXP_OVERLAP_MAX;
 #else
   uint32_t overlap_max = OVERLAP_MAX_BATCH;
 #endif
-  void prove_side_work(PlanSet& q, Workspace& w, uint32_t B) {
+  void prove_side_work(PlanSet& q, Workspace& w, uint32_t B, bool with_tables) {
     const ProveLay& l = q.pplan.lay;
     run_phase(q.pph[4], w, B);      // Toom-Cook (m = 2) / Karatsuba operand sums (empty when unused)
     const ToomPlan& tk = q.pplan.toom;
@@ -708,7 +707,7 @@ struct Table : mp_table {
       normalize_flat(w.J.p + j_off<C>(tk.cv_first, w.Bpad, 0), w.P.p + p_off<C>(tk.cv_first, w.Bpad, 0), w.NS.p,
                      (size_t)(tk.E - 2) * 2 * n * w.Bpad);
     }
-    if (overlap) run_phase(q.pph[1], w, B, PH_TABLES);
+    if (with_tables) run_phase(q.pph[1], w, B, PH_TABLES);
   }
 
   // ---------------------------------------------------------------- prove
@@ -728,7 +727,7 @@ struct Table : mp_table {
     PhaseDev* pph = q.pph;
     rt::Stream s = ctx->stream;
     FixedBases fb{n};
-    overlap = overlap_max && B <= overlap_max;
+    const bool overlap = overlap_max && B <= overlap_max;      // two streams for the stretch before the first challenge
     rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
     {
       uint32_t* const ww = wire_words(w, B, 1);
@@ -783,7 +782,7 @@ struct Table : mp_table {
         MP_RUN(k_remask, C, B, 2 * N, ra);
         run_phase(pph[0], w, B, PH_NORM, l.shuf);
         rt::event_record(ctx->ev_shuf, ctx->side);
-        prove_side_work(q, w, B);
+        prove_side_work(q, w, B, true);
         rt::event_record(ctx->ev_tab, ctx->side);
       } else {
         MP_RUN(k_remask, C, B, 2 * N, ra);
@@ -794,7 +793,7 @@ struct Table : mp_table {
         rt::stream_wait(s, ctx->ev_shuf);
       } else {
         run_phase(pph[0], w, B);
-        prove_side_work(q, w, B);
+        prove_side_work(q, w, B, false);
       }
     }
     const ToomPlan& tk = q.pplan.toom;
