@@ -70,17 +70,32 @@ def emu(native):
 @pytest.mark.parametrize("name", ["shuffle_stark_m2_n3_s1.json", "shuffle_stark_m3_n4_s11.json", "shuffle_bn254_m2_n4_s3.json",
                                   "shuffle_secp256k1_m3_n3_s5.json", "shuffle_stark_m4_n13_s9.json",
                                   "shuffle_bls12_377_m2_n3_s13.json"])
-def test_kernel_bodies_under_emulation_match_golden(emu, name):
+def test_kernel_bodies_under_emulation_match_golden(emu, native, name):
     g = load_json(os.path.join(GOLDEN, name))
     eng = emu(g["curve"])
     m, n = g["m"], g["n"]
     t = eng.table(m, n, bytes.fromhex(g["params"]), bytes.fromhex(g["pk"]))
-    for latency_batch in (8192, 8, 0):   # finest split, latency plan, throughput plan (large sub-jobs, Toom-Cook for m = 2)
+    # a single proof takes the four-lane transcripts and group operations by default (k_fsq_*, kernels_quad.hpp); lanes = 1 forces
+    # the kernels a full batch runs (one lane per proof, one lane per chain)
+    for latency_batch, lanes in ((8192, 0), (8, 0), (0, 0), (8192, 1), (0, 1)):   # finest split, latency plan, throughput plan (large sub-jobs, Toom-Cook for m = 2)
         t.set_latency_batch(latency_batch)
+        t.set_transcript_lanes(lanes)
+        t.set_group_lanes(lanes)
+        eng.profile_enable(True)
         deck, proof = t.shuffle_and_remask(bytes.fromhex(g["deck"]), bytes.fromhex(g["rho"]), g["perm"], bytes.fromhex(g["prover_seed"]))
         assert deck.hex() == g["shuffled"]
         assert proof.hex() == g["proof"]
         assert t.verify_shuffle(bytes.fromhex(g["deck"]), deck, proof) == 0
+        rep = eng.profile_report()
+        eng.profile_enable(False)
+        assert ("k_fsq_verify" in rep) == (lanes == 0) and ("k_verify_fs" in rep) == (lanes == 1), sorted(rep)
+        assert ("k_fixed_msm_q" in rep) == (lanes == 0) and ("k_fixed_msm" in rep) == (lanes == 1), sorted(rep)
+    with pytest.raises(native.NativeError):
+        t.set_transcript_lanes(3)
+    with pytest.raises(native.NativeError):
+        t.set_group_lanes(2)
+    t.set_transcript_lanes(0)
+    t.set_group_lanes(0)
     bad = bytearray(proof)
     bad[-1] ^= 0          # unchanged copy still verifies
     cb = 2 * eng.point_bytes          # one card = two points
