@@ -96,7 +96,7 @@ struct Workspace {
     NS2.alloc((size_t)ns2_elems * Bpad * fw, s);
     stage.alloc((size_t)stage_words * Bpad, s);
     seed.alloc((size_t)8 * Bpad, s);
-    direct.alloc(Bpad, s);
+    direct.alloc((size_t)2 * Bpad, s);
     status.alloc(Bpad, s);
   }
 };
@@ -804,7 +804,8 @@ struct Table : mp_table {
       run_fs_round1(a, B);
     }
     ProveScalArgs sc{w.S.p, perm, l, w.Bpad, q.lin.p, q.lin_src.p, tk.E ? 0u : (uint32_t)q.pplan.lin.size()};
-    MP_RUN(k_prove_scal1, C, B, 1, sc);
+    MP_RUN(k_prove_scal1, C, B, N, sc);
+    MP_RUN(k_prove_scal1b, C, B, 1 + n + sc.n_lin * n, sc);
     if (tk.E) {                   // the scalar polynomial at the same points; the interpolation matrix as MSM scalars
       LinCombArgs la{w.S.p, q.lin.p, q.lin_src.p, q.lin_coef.p, q.consts.p, w.Bpad, n};
       MP_RUN(k_lin_comb, C, B, (uint32_t)q.pplan.lin.size() * n, la);
@@ -827,7 +828,8 @@ struct Table : mp_table {
       a.copy_from = NO_SLOT; a.copy_to = NO_SLOT;
       run_fs_round(a, B);
     }
-    MP_RUN(k_prove_scal2, C, B, 1, sc);
+    MP_RUN(k_prove_scal2, C, B, n + 1, sc);
+    MP_RUN(k_prove_scal2b, C, B, n, sc);
     run_phase(pph[2], w, B);
     {
       FsRoundArgs a{};
@@ -838,7 +840,7 @@ struct Table : mp_table {
       a.nsteps = 2;
       run_fs_round(a, B);
     }
-    MP_RUN(k_prove_scal3, C, B, 1, sc);
+    MP_RUN(k_prove_scal3, C, B, n + 1, sc);
     MP_RUN(k_prove_scal3d, C, B, 2 * m + 1, sc);
     run_phase(pph[3], w, B);
     {
@@ -851,7 +853,7 @@ struct Table : mp_table {
       a.nsteps = 3;
       run_fs_round(a, B);
     }
-    MP_RUN(k_prove_scal4, C, B, 1, sc);
+    MP_RUN(k_prove_scal4, C, B, n + 3, sc);
     {
       StorePointsArgs a{out_decks, w.P.p, w.Bpad, 2 * N, l.shuf};
       MP_RUN(k_store_points, C, B, 2 * N, a);
@@ -911,7 +913,7 @@ struct Table : mp_table {
         a.merge = merged ? 1u : 0u;
         run_verify_fs(a, B);
         VerifyScalArgs sa{w.S.p, w.P.p, w.direct.p, l, q.vplan.cm, w.Bpad};
-        MP_RUN(k_verify_scal, C, B, 1, sa);
+        MP_RUN(k_verify_scal, C, B, n + 2, sa);
       }
       if (merged) {
         VerifyMergeArgs ma{w.S.p, q.mjobs.p, q.mpairs.p, w.Bpad};
@@ -1026,7 +1028,7 @@ struct Table : mp_table {
       a.merge = 1u;
       run_verify_fs(a, B);
       VerifyScalArgs sa{w.S.p, w.P.p, w.direct.p, l, q.vplan.cm, w.Bpad};
-      MP_RUN(k_verify_scal, C, B, 1, sa);
+      MP_RUN(k_verify_scal, C, B, n + 2, sa);
       VerifyMergeArgs ma{w.S.p, q.mjobs.p, q.mpairs.p, w.Bpad};
       MP_RUN(k_verify_merge, C, B, (uint32_t)q.vplan.mjobs.size(), ma);
     }

@@ -480,45 +480,66 @@ struct ProveScalArgs {
 #define MP_LD(slot) ld_fe<R>(a.S + s_off((slot), a.Bpad, b))
 #define MP_ST(slot, val) st_fe<R>(a.S + s_off((slot), a.Bpad, b), (val))
 
-// after x: b_i = x^(pi(i)+1), rho_hat = -sum rho_i b_i -> tau[m]
+// The prover's scalar programs (Fr vector algebra between the Fiat-Shamir rounds).  They were one lane per proof; for every batch that
+// does not fill the chip with such lanes that lane is what the proof waits for -- ~1 ms of a single 52-card proof's 3.0, 7 % of a
+// 4 096-proof step -- and most of it is dependent loads, not arithmetic.  Each program is now cut along its data flow into lanes that
+// need nothing from each other inside a launch (y = entry of a vector / column of the m x n matrices / one of the scalar results);
+// sums of powers are Horner recurrences on the lane that owns them and single powers square-and-multiply, so no table of powers goes
+// through memory.  Where a result needs every lane's output (rho_hat, the prefix products of the single-value product) a second
+// small launch follows.  Same field elements, same bytes.
+template <class R>
+MP_HD Fe<R> fe_pow_small(const Fe<R>& x, uint32_t e) {      // x^e, e >= 1 (a card index / vector position: <= 13 bits)
+  int top = 31;
+  while (!((e >> top) & 1u)) --top;
+  Fe<R> acc = x;
+  for (int i = top - 1; i >= 0; --i) {
+    acc = fe_sqr<R>(acc);
+    if ((e >> i) & 1u) acc = fe_mul<R>(acc, x);
+  }
+  return acc;
+}
+// after x, first launch: y = i < N: b_i = x^(pi(i)+1) and the product rho_i b_i (tmp[i])
 template <class C>
 MP_HD void body_prove_scal1(const ProveScalArgs& a, uint32_t b, uint32_t y) {
   typedef typename C::FrP R;
   const ProveLay& l = a.l;
-  const Fe<R> x = MP_LD(l.x);
-  Fe<R> acc = fe_one<R>();
-  MP_ST(l.tmp + 0, acc);
-  for (uint32_t j = 1; j <= l.N; ++j) {
-    acc = fe_mul<R>(acc, x);
-    MP_ST(l.tmp + j, acc);
-  }
-  Fe<R> rho_hat = fe_zero<R>();
-  for (uint32_t i = 0; i < l.N; ++i) {
-    uint32_t pi = a.perm[(size_t)b * l.N + i];
-    if (pi >= l.N) pi = 0;
-    const Fe<R> bi = MP_LD(l.tmp + pi + 1);
-    MP_ST(l.b + i, bi);
-    rho_hat = fe_sub<R>(rho_hat, fe_mul<R>(MP_LD(l.rho + i), bi));
-  }
-  MP_ST(l.metau + l.m, rho_hat);
-  if (l.toom) {   // m = 2: halved evaluation scalars of the Toom-Cook diagonals (layout.hpp)
-    for (uint32_t j = 0; j < l.n; ++j) {
-      const Fe<R> a0 = MP_LD(l.mea0 + j), a1 = MP_LD(l.b + j), a2 = MP_LD(l.b + l.n + j);
-      const Fe<R> e = fe_add<R>(a0, a2);
-      MP_ST(l.tsp + j, fe_half<R>(fe_add<R>(e, a1)));
-      MP_ST(l.tsm + j, fe_half<R>(fe_sub<R>(e, a1)));
-    }
-  }
-  for (uint32_t q = 0; q < a.n_lin; ++q) {   // m >= 3: sums of scalar rows (Karatsuba operands)
-    const LinJob lj = a.lin[q];
-    for (uint32_t j = 0; j < l.n; ++j) {
-      Fe<R> acc = MP_LD(a.lin_src[lj.begin] + j);
-      for (uint32_t i = 1; i < lj.count; ++i) acc = fe_add<R>(acc, MP_LD(a.lin_src[lj.begin + i] + j));
-      MP_ST(lj.dst + j, acc);
-    }
-  }
+  uint32_t pi = a.perm[(size_t)b * l.N + y];
+  if (pi >= l.N) pi = 0;
+  const Fe<R> bi = fe_pow_small<R>(MP_LD(l.x), pi + 1);
+  MP_ST(l.b + y, bi);
+  MP_ST(l.tmp + y, fe_mul<R>(MP_LD(l.rho + y), bi));
 }
 MP_KERNEL(k_prove_scal1, ProveScalArgs, body_prove_scal1)
+// second launch: y = 0: rho_hat = -sum rho_i b_i -> tau[m];  y = 1 + j, j < n: the halved evaluation scalars of the m = 2 Toom-Cook
+// diagonals (layout.hpp);  y = 1 + n + q n + j: entry j of scalar-row sum q of the Karatsuba plan (m >= 3)
+template <class C>
+MP_HD void body_prove_scal1b(const ProveScalArgs& a, uint32_t b, uint32_t y) {
+  typedef typename C::FrP R;
+  const ProveLay& l = a.l;
+  if (y == 0) {
+    Fe<R> rho_hat = fe_zero<R>();
+    for (uint32_t i = 0; i < l.N; ++i) rho_hat = fe_sub<R>(rho_hat, MP_LD(l.tmp + i));
+    MP_ST(l.metau + l.m, rho_hat);
+    return;
+  }
+  y -= 1;
+  if (y < l.n) {
+    if (!l.toom) return;
+    const uint32_t j = y;
+    const Fe<R> a0 = MP_LD(l.mea0 + j), a1 = MP_LD(l.b + j), a2 = MP_LD(l.b + l.n + j);
+    const Fe<R> e = fe_add<R>(a0, a2);
+    MP_ST(l.tsp + j, fe_half<R>(fe_add<R>(e, a1)));
+    MP_ST(l.tsm + j, fe_half<R>(fe_sub<R>(e, a1)));
+    return;
+  }
+  y -= l.n;
+  const LinJob lj = a.lin[y / l.n];
+  const uint32_t j = y % l.n;
+  Fe<R> acc = MP_LD(a.lin_src[lj.begin] + j);
+  for (uint32_t i = 1; i < lj.count; ++i) acc = fe_add<R>(acc, MP_LD(a.lin_src[lj.begin + i] + j));
+  MP_ST(lj.dst + j, acc);
+}
+MP_KERNEL(k_prove_scal1b, ProveScalArgs, body_prove_scal1b)
 
 // ---- Toom-Cook operands (3 <= m <= 16, layout.hpp ToomPlan) ---------------------------------------------------------------
 // scalar side: S[dst + t] = sum_i consts[coef_i] * S[src_i + t]   (x = proof, y = job * n + t: one lane per output scalar)
@@ -556,44 +577,60 @@ MP_HD void body_fill_consts(const FillConstArgs& a, uint32_t b, uint32_t y) {
 }
 MP_KERNEL(k_fill_consts, FillConstArgs, body_fill_consts)
 
-// after y, z: d - z, t, Hadamard partial products, single-value-product first-message vectors
+// after y, z, first launch: y < n: column j of d - z and of the Hadamard partial products;  y = n: t and the Hadamard blinders
 template <class C>
 MP_HD void body_prove_scal2(const ProveScalArgs& a, uint32_t b, uint32_t y_) {
   typedef typename C::FrP R;
   const ProveLay& l = a.l;
   const uint32_t m = l.m, n = l.n;
-  const Fe<R> y = MP_LD(l.y), z = MP_LD(l.z);
-  for (uint32_t i = 0; i < l.N; ++i)
-    MP_ST(l.dz + i, fe_sub<R>(fe_add<R>(fe_mul<R>(y, MP_LD(l.a + i)), MP_LD(l.b + i)), z));
-  for (uint32_t k = 0; k < m; ++k) MP_ST(l.t + k, fe_add<R>(fe_mul<R>(y, MP_LD(l.r + k)), MP_LD(l.s + k)));
-  MP_ST(l.hs + 0, MP_LD(l.t + 0));
-  MP_ST(l.hs + m - 1, MP_LD(l.sb));
-  for (uint32_t j = 0; j < n; ++j) {
-    Fe<R> acc = MP_LD(l.dz + j);
-    MP_ST(l.bp + j, acc);
-    for (uint32_t k = 1; k < m; ++k) {
-      acc = fe_mul<R>(acc, MP_LD(l.dz + k * n + j));
-      MP_ST(l.bp + k * n + j, acc);
+  const Fe<R> y = MP_LD(l.y);
+  if (y_ == n) {
+    for (uint32_t k = 0; k < m; ++k) {
+      const Fe<R> tk = fe_add<R>(fe_mul<R>(y, MP_LD(l.r + k)), MP_LD(l.s + k));
+      MP_ST(l.t + k, tk);
+      if (k == 0) MP_ST(l.hs + 0, tk);
     }
+    MP_ST(l.hs + m - 1, MP_LD(l.sb));
+    return;
   }
-  // single value product on a = bvec = bp[m-1], randomness sb
-  const uint32_t av = l.bp + (m - 1) * n;
-  Fe<R> pref = MP_LD(av);
-  MP_ST(l.svbp + 0, pref);
-  for (uint32_t i = 1; i < n; ++i) {
-    pref = fe_mul<R>(pref, MP_LD(av + i));
-    MP_ST(l.svbp + i, pref);
-  }
-  MP_ST(l.svdelta + 0, MP_LD(l.svd + 0));
-  for (uint32_t i = 0; i + 1 < n; ++i) {
-    const Fe<R> di1 = MP_LD(l.svd + i + 1), deli = MP_LD(l.svdelta + i);
-    MP_ST(l.svv1 + i, fe_neg<R>(fe_mul<R>(deli, di1)));
-    Fe<R> v2 = fe_sub<R>(MP_LD(l.svdelta + i + 1), fe_mul<R>(MP_LD(av + i + 1), deli));
-    v2 = fe_sub<R>(v2, fe_mul<R>(MP_LD(l.svbp + i), di1));
-    MP_ST(l.svv2 + i, v2);
+  const uint32_t j = y_;
+  const Fe<R> z = MP_LD(l.z);
+  Fe<R> acc;
+  for (uint32_t k = 0; k < m; ++k) {
+    const uint32_t i = k * n + j;
+    const Fe<R> dz = fe_sub<R>(fe_add<R>(fe_mul<R>(y, MP_LD(l.a + i)), MP_LD(l.b + i)), z);
+    MP_ST(l.dz + i, dz);
+    acc = k == 0 ? dz : fe_mul<R>(acc, dz);
+    MP_ST(l.bp + i, acc);
   }
 }
 MP_KERNEL(k_prove_scal2, ProveScalArgs, body_prove_scal2)
+// second launch, single value product on a = bvec = bp[m-1] (randomness sb): y = i < n: the prefix product b_i = a_0 .. a_i (every
+// lane multiplies its own -- n products deep like the one chain was, but nobody waits for it) and the first-message entries i
+template <class C>
+MP_HD void body_prove_scal2b(const ProveScalArgs& a, uint32_t b, uint32_t i) {
+  typedef typename C::FrP R;
+  const ProveLay& l = a.l;
+  const uint32_t n = l.n, av = l.bp + (l.m - 1) * n;
+  Fe<R> pref = MP_LD(av);
+  for (uint32_t t = 1; t <= i; ++t) pref = fe_mul<R>(pref, MP_LD(av + t));
+  MP_ST(l.svbp + i, pref);
+  Fe<R> deli;
+  if (i == 0) {
+    deli = MP_LD(l.svd + 0);
+    MP_ST(l.svdelta + 0, deli);
+  } else {
+    deli = MP_LD(l.svdelta + i);
+  }
+  if (i + 1 < n) {
+    const Fe<R> di1 = MP_LD(l.svd + i + 1);
+    MP_ST(l.svv1 + i, fe_neg<R>(fe_mul<R>(deli, di1)));
+    Fe<R> v2 = fe_sub<R>(MP_LD(l.svdelta + i + 1), fe_mul<R>(MP_LD(av + i + 1), deli));
+    v2 = fe_sub<R>(v2, fe_mul<R>(pref, di1));
+    MP_ST(l.svv2 + i, v2);
+  }
+}
+MP_KERNEL(k_prove_scal2b, ProveScalArgs, body_prove_scal2b)
 
 // zero-argument witness accessors (rows a_0..a_m and b_0..b_m of section 5.2)
 template <class C>
@@ -612,47 +649,37 @@ MP_HD Fe<typename C::FrP> zero_Bb(const ProveScalArgs& a, uint32_t b, uint32_t i
   return MP_LD(l.zB + i * l.n + j);
 }
 
-// after the Hadamard challenges (hx, hy): zero-argument statement witness and the d_k
+// after the Hadamard challenges (hx, hy): zero-argument statement witness.  y = j < n: column j of the rows zB and of the weighted rows
+// wb[jj][j] = Bb[jj][j] hy^(j+1) (tmp + m + 1 + n: read by k_prove_scal3d, which computes the d_k one lane per k);  y = n: zs
 template <class C>
 MP_HD void body_prove_scal3(const ProveScalArgs& a, uint32_t b, uint32_t y_) {
   typedef typename C::FrP R;
   const ProveLay& l = a.l;
   const uint32_t m = l.m, n = l.n;
-  const Fe<R> hx = MP_LD(l.hx), hy = MP_LD(l.hy);
-  // tmp: [0, m] powers of hx ; [m+1, m+1+n) y^(j+1) ; then (m+1) weighted B rows
-  const uint32_t t_xp = l.tmp, t_yp = l.tmp + m + 1, t_wb = l.tmp + m + 1 + n;
-  Fe<R> acc = fe_one<R>();
-  for (uint32_t i = 0; i <= m; ++i) {
-    MP_ST(t_xp + i, acc);
-    acc = fe_mul<R>(acc, hx);
-  }
-  acc = hy;
-  for (uint32_t j = 0; j < n; ++j) {
-    MP_ST(t_yp + j, acc);
-    acc = fe_mul<R>(acc, hy);
-  }
-  // zB rows and zs
-  for (uint32_t j = 0; j < n; ++j) {
-    Fe<R> last = fe_zero<R>();
+  const Fe<R> hx = MP_LD(l.hx);
+  if (y_ == n) {
+    Fe<R> last = fe_zero<R>(), xi = hx;                    // xi = hx^(i+1)
     for (uint32_t i = 0; i + 1 < m; ++i) {
-      const Fe<R> xi = MP_LD(t_xp + i + 1);
-      MP_ST(l.zB + i * n + j, fe_mul<R>(xi, MP_LD(l.bp + i * n + j)));
-      last = fe_add<R>(last, fe_mul<R>(xi, MP_LD(l.bp + (i + 1) * n + j)));
-    }
-    MP_ST(l.zB + (m - 1) * n + j, last);
-  }
-  {
-    Fe<R> last = fe_zero<R>();
-    for (uint32_t i = 0; i + 1 < m; ++i) {
-      const Fe<R> xi = MP_LD(t_xp + i + 1);
       MP_ST(l.zs + i, fe_mul<R>(xi, MP_LD(l.hs + i)));
       last = fe_add<R>(last, fe_mul<R>(xi, MP_LD(l.hs + i + 1)));
+      xi = fe_mul<R>(xi, hx);
     }
     MP_ST(l.zs + m - 1, last);
+    return;
   }
-  // weighted rows wb[jj][j] = Bb[jj][j] * y^(j+1); the d_k themselves are computed by k_prove_scal3d (one lane per k)
-  for (uint32_t jj = 0; jj <= m; ++jj)
-    for (uint32_t j = 0; j < n; ++j) MP_ST(t_wb + jj * n + j, fe_mul<R>(zero_Bb<C>(a, b, jj, j), MP_LD(t_yp + j)));
+  const uint32_t j = y_, t_wb = l.tmp + m + 1 + n;
+  const Fe<R> yp = fe_pow_small<R>(MP_LD(l.hy), j + 1);
+  Fe<R> last = fe_zero<R>(), xi = hx;
+  for (uint32_t i = 0; i + 1 < m; ++i) {
+    const Fe<R> v = fe_mul<R>(xi, MP_LD(l.bp + i * n + j));
+    MP_ST(l.zB + i * n + j, v);
+    MP_ST(t_wb + i * n + j, fe_mul<R>(v, yp));
+    last = fe_add<R>(last, fe_mul<R>(xi, MP_LD(l.bp + (i + 1) * n + j)));
+    xi = fe_mul<R>(xi, hx);
+  }
+  MP_ST(l.zB + (m - 1) * n + j, last);
+  MP_ST(t_wb + (m - 1) * n + j, fe_mul<R>(last, yp));
+  MP_ST(t_wb + m * n + j, fe_mul<R>(MP_LD(l.zbm + j), yp));
 }
 MP_KERNEL(k_prove_scal3, ProveScalArgs, body_prove_scal3)
 
@@ -673,73 +700,65 @@ MP_HD void body_prove_scal3d(const ProveScalArgs& a, uint32_t b, uint32_t k) {
 }
 MP_KERNEL(k_prove_scal3d, ProveScalArgs, body_prove_scal3d)
 
-// after the last challenges: all responses
+// after the last challenges: all responses.  y < n: entry y of the five response vectors; y = n, n + 1, n + 2: the scalar responses of
+// the zero argument, the single-value product and the multi-exponentiation argument.  Every sum sum_i x^i v_i is a Horner recurrence
+// on the lane that owns it (no table of powers shared through memory, so the lanes of a proof need nothing from each other): a
+// response costs one lane ~3m + 4 products instead of one lane per proof ~(3m + 4)(n + 3) in a row -- 0.35 ms of a single proof.
 template <class C>
 MP_HD void body_prove_scal4(const ProveScalArgs& a, uint32_t b, uint32_t y_) {
   typedef typename C::FrP R;
   const ProveLay& l = a.l;
   const uint32_t m = l.m, n = l.n;
-  const uint32_t t_xp = l.tmp;   // powers, up to 2m+1
-  // --- zero argument
-  {
-    const Fe<R> x = MP_LD(l.zx);
-    Fe<R> acc = fe_one<R>();
-    for (uint32_t i = 0; i <= 2 * m; ++i) {
-      MP_ST(t_xp + i, acc);
-      acc = fe_mul<R>(acc, x);
-    }
-    for (uint32_t j = 0; j < n; ++j) {
-      Fe<R> ab = fe_zero<R>(), bb = fe_zero<R>();
-      for (uint32_t i = 0; i <= m; ++i) {
-        ab = fe_add<R>(ab, fe_mul<R>(MP_LD(t_xp + i), zero_Aa<C>(a, b, i, j)));
-        bb = fe_add<R>(bb, fe_mul<R>(MP_LD(t_xp + m - i), zero_Bb<C>(a, b, i, j)));
-      }
+  if (y_ < n) {
+    const uint32_t j = y_;
+    {   // zero argument: abar_j = sum_i x^i A_i[j], bbar_j = sum_i x^(m-i) B_i[j]
+      const Fe<R> x = MP_LD(l.zx);
+      Fe<R> ab = zero_Aa<C>(a, b, m, j), bb = zero_Bb<C>(a, b, 0, j);
+      for (uint32_t i = m; i-- > 0;) ab = fe_add<R>(fe_mul<R>(ab, x), zero_Aa<C>(a, b, i, j));
+      for (uint32_t i = 1; i <= m; ++i) bb = fe_add<R>(fe_mul<R>(bb, x), zero_Bb<C>(a, b, i, j));
       MP_ST(l.zabar + j, ab);
       MP_ST(l.zbbar + j, bb);
     }
-    Fe<R> rb = MP_LD(l.zr0), sbar = fe_zero<R>(), tb = fe_zero<R>();
-    for (uint32_t i = 1; i < m; ++i) rb = fe_add<R>(rb, fe_mul<R>(MP_LD(t_xp + i), MP_LD(l.t + i)));   // r' = (t_1..t_{m-1}, 0)
-    for (uint32_t j = 0; j < m; ++j) sbar = fe_add<R>(sbar, fe_mul<R>(MP_LD(t_xp + m - j), MP_LD(l.zs + j)));
-    sbar = fe_add<R>(sbar, MP_LD(l.zsm));
-    for (uint32_t k = 0; k <= 2 * m; ++k) tb = fe_add<R>(tb, fe_mul<R>(MP_LD(t_xp + k), MP_LD(l.zt + k)));
-    MP_ST(l.zrbar, rb);
-    MP_ST(l.zsbar, sbar);
-    MP_ST(l.ztbar, tb);
-  }
-  // --- single value product
-  {
-    const Fe<R> x = MP_LD(l.svx);
-    const uint32_t av = l.bp + (m - 1) * n;
-    for (uint32_t i = 0; i < n; ++i) {
-      MP_ST(l.svat + i, fe_add<R>(fe_mul<R>(x, MP_LD(av + i)), MP_LD(l.svd + i)));
-      MP_ST(l.svbt + i, fe_add<R>(fe_mul<R>(x, MP_LD(l.svbp + i)), MP_LD(l.svdelta + i)));
+    {   // single value product
+      const Fe<R> x = MP_LD(l.svx);
+      MP_ST(l.svat + j, fe_add<R>(fe_mul<R>(x, MP_LD(l.bp + (m - 1) * n + j)), MP_LD(l.svd + j)));
+      MP_ST(l.svbt + j, fe_add<R>(fe_mul<R>(x, MP_LD(l.svbp + j)), MP_LD(l.svdelta + j)));
     }
+    {   // multi-exponentiation: abar_j = a0_j + sum_{i=1..m} x^i b_{i-1}[j]
+      const Fe<R> x = MP_LD(l.mx);
+      Fe<R> ab = MP_LD(l.b + (m - 1) * n + j);
+      for (uint32_t i = m - 1; i >= 1; --i) ab = fe_add<R>(fe_mul<R>(ab, x), MP_LD(l.b + (i - 1) * n + j));
+      MP_ST(l.meabar + j, fe_add<R>(fe_mul<R>(ab, x), MP_LD(l.mea0 + j)));
+    }
+    return;
+  }
+  if (y_ == n) {   // zero argument: rbar = r0 + sum_{i=1..m-1} x^i t_i  (r' = (t_1..t_{m-1}, 0)), sbar = sum_{j<m} x^(m-j) s_j + s_m, tbar = sum_k x^k t_k
+    const Fe<R> x = MP_LD(l.zx);
+    Fe<R> rb = fe_zero<R>(), sbar = fe_zero<R>(), tb = fe_zero<R>();
+    for (uint32_t i = m - 1; i >= 1; --i) rb = fe_mul<R>(fe_add<R>(rb, MP_LD(l.t + i)), x);
+    for (uint32_t j = 0; j < m; ++j) sbar = fe_mul<R>(fe_add<R>(sbar, MP_LD(l.zs + j)), x);
+    for (uint32_t k = 2 * m + 1; k-- > 0;) tb = fe_add<R>(fe_mul<R>(tb, x), MP_LD(l.zt + k));
+    MP_ST(l.zrbar, fe_add<R>(rb, MP_LD(l.zr0)));
+    MP_ST(l.zsbar, fe_add<R>(sbar, MP_LD(l.zsm)));
+    MP_ST(l.ztbar, tb);
+    return;
+  }
+  if (y_ == n + 1) {
+    const Fe<R> x = MP_LD(l.svx);
     MP_ST(l.svrt, fe_add<R>(fe_mul<R>(x, MP_LD(l.sb)), MP_LD(l.svrd)));
     MP_ST(l.svst, fe_add<R>(fe_mul<R>(x, MP_LD(l.svsx)), MP_LD(l.svs1)));
+    return;
   }
-  // --- multi-exponentiation
-  {
+  {   // multi-exponentiation: rbar = r0 + sum_{i=1..m} x^i s_{i-1}; bbar, sbar, taubar = sum_{k<2m} x^k (b_k, s_k, tau_k)
     const Fe<R> x = MP_LD(l.mx);
-    Fe<R> acc = fe_one<R>();
-    for (uint32_t i = 0; i < 2 * m; ++i) {
-      MP_ST(t_xp + i, acc);
-      acc = fe_mul<R>(acc, x);
+    Fe<R> rb = fe_zero<R>(), bb = fe_zero<R>(), sbar = fe_zero<R>(), tb = fe_zero<R>();
+    for (uint32_t i = m; i >= 1; --i) rb = fe_mul<R>(fe_add<R>(rb, MP_LD(l.s + i - 1)), x);
+    for (uint32_t k = 2 * m; k-- > 0;) {
+      bb = fe_add<R>(fe_mul<R>(bb, x), MP_LD(l.meb + k));
+      sbar = fe_add<R>(fe_mul<R>(sbar, x), MP_LD(l.mes + k));
+      tb = fe_add<R>(fe_mul<R>(tb, x), MP_LD(l.metau + k));
     }
-    for (uint32_t j = 0; j < n; ++j) {
-      Fe<R> ab = MP_LD(l.mea0 + j);
-      for (uint32_t i = 1; i <= m; ++i) ab = fe_add<R>(ab, fe_mul<R>(MP_LD(t_xp + i), MP_LD(l.b + (i - 1) * n + j)));
-      MP_ST(l.meabar + j, ab);
-    }
-    Fe<R> rb = MP_LD(l.mer0);
-    for (uint32_t i = 1; i <= m; ++i) rb = fe_add<R>(rb, fe_mul<R>(MP_LD(t_xp + i), MP_LD(l.s + i - 1)));
-    Fe<R> bb = fe_zero<R>(), sbar = fe_zero<R>(), tb = fe_zero<R>();
-    for (uint32_t k = 0; k < 2 * m; ++k) {
-      const Fe<R> xk = MP_LD(t_xp + k);
-      bb = fe_add<R>(bb, fe_mul<R>(xk, MP_LD(l.meb + k)));
-      sbar = fe_add<R>(sbar, fe_mul<R>(xk, MP_LD(l.mes + k)));
-      tb = fe_add<R>(tb, fe_mul<R>(xk, MP_LD(l.metau + k)));
-    }
-    MP_ST(l.merbar, rb);
+    MP_ST(l.merbar, fe_add<R>(rb, MP_LD(l.mer0)));
     MP_ST(l.mebbar, bb);
     MP_ST(l.mesbar, sbar);
     MP_ST(l.metaubar, tb);
@@ -997,22 +1016,56 @@ MP_KERNEL(k_verify_merge, VerifyMergeArgs, body_verify_merge)
 struct VerifyScalArgs {
   uint32_t* S;
   const uint32_t* P;
-  uint32_t* direct;      // [Bpad] bit i set = direct check i failed
+  uint32_t* direct;      // [2][Bpad] bit i set = direct check i failed (two lanes of k_verify_scal report, one word each)
   VerifyLay l;
   VCoefMap c;
   uint32_t Bpad;
 };
+// y = 0: the O(m) coefficients, the bilinear value and the direct checks on points (failure bits -> direct[b]);  y = 1: the product
+// value prod_{i=1..N} (y i + x^i - z) with the deck coefficients x^i (the one chain of length N) and the scalar checks of the
+// single-value product (-> direct[Bpad + b]);  y = 2 + j, j < n: entry j of the commitment-key coefficient vectors
 template <class C>
 MP_HD void body_verify_scal(const VerifyScalArgs& a, uint32_t b, uint32_t y_) {
   typedef typename C::FrP R;
   const VerifyLay& l = a.l;
   const VCoefMap& c = a.c;
   const uint32_t m = l.m, n = l.n, N = l.N;
-  uint32_t fail = 0;
   const Fe<R> one = fe_one<R>();
+  if (y_ >= 2) {
+    const uint32_t j = y_ - 2;
+    MP_ST(c.za_ck + j, fe_neg<R>(MP_LD(l.zabar + j)));
+    MP_ST(c.zb_ck + j, fe_neg<R>(MP_LD(l.zbbar + j)));
+    const Fe<R> sx = MP_LD(l.svx), at = MP_LD(l.svat + j);
+    MP_ST(c.sa_ck + j, fe_neg<R>(at));
+    if (j + 1 < n)      // -(x bt_{j+1} - bt_j at_{j+1})
+      MP_ST(c.sd_ck + j, fe_sub<R>(fe_mul<R>(MP_LD(l.svbt + j), MP_LD(l.svat + j + 1)), fe_mul<R>(sx, MP_LD(l.svbt + j + 1))));
+    const Fe<R> ab = MP_LD(l.meabar + j), mx = MP_LD(l.mx);
+    MP_ST(c.ma_ck + j, fe_neg<R>(ab));
+    Fe<R> co = fe_neg<R>(one);                       // -mx^(m-i), i = m .. 1
+    for (uint32_t i = m; i >= 1; --i) {
+      MP_ST(c.me_c + (i - 1) * n + j, fe_mul<R>(co, ab));
+      co = fe_mul<R>(co, mx);
+    }
+    return;
+  }
+  const Fe<R> x = MP_LD(l.x), y = MP_LD(l.y), z = MP_LD(l.z);
+  if (y_ == 1) {
+    const Fe<R> sx = MP_LD(l.svx);
+    Fe<R> prod = one, xi = one, yi = fe_zero<R>();
+    for (uint32_t i = 1; i <= N; ++i) {
+      xi = fe_mul<R>(xi, x);
+      yi = fe_add<R>(yi, y);
+      prod = fe_mul<R>(prod, fe_sub<R>(fe_add<R>(yi, xi), z));
+      MP_ST(c.em_x + i - 1, xi);                      // x^i: coefficient of deck[i-1] in Cx
+    }
+    uint32_t fail = 0;
+    if (!fe_eq(MP_LD(l.svbt + 0), MP_LD(l.svat + 0)) || !fe_eq(MP_LD(l.svbt + n - 1), fe_mul<R>(sx, prod))) fail |= 1u << VC_SVP_SCALARS;
+    a.direct[(size_t)a.Bpad + b] = fail;
+    return;
+  }
+  uint32_t fail = 0;
   MP_ST(l.one, one);
   MP_ST(c.minus_one, fe_neg<R>(one));
-  const Fe<R> x = MP_LD(l.x), y = MP_LD(l.y), z = MP_LD(l.z);
   // --- Hadamard: first commitment, last commitment
   MP_ST(c.had_y, y);
   MP_ST(c.had_mz, fe_neg<R>(z));
@@ -1042,7 +1095,6 @@ MP_HD void body_verify_scal(const VerifyScalArgs& a, uint32_t b, uint32_t y_) {
     }
     gs = fe_neg<R>(fe_add<R>(fe_mul<R>(gs, z), MP_LD(t_zx + m)));
     MP_ST(c.za_gsum, gs);
-    for (uint32_t j = 0; j < n; ++j) MP_ST(c.za_ck + j, fe_neg<R>(MP_LD(l.zabar + j)));
     MP_ST(c.za_H, fe_neg<R>(MP_LD(l.zrbar)));
     // VC_ZERO_B: hB[j] gets [j <= m-2] zx^(m-j) hx^(j+1) + [j >= 1] zx hx^j
     for (uint32_t j = 0; j < m; ++j) {
@@ -1051,7 +1103,6 @@ MP_HD void body_verify_scal(const VerifyScalArgs& a, uint32_t b, uint32_t y_) {
       if (j >= 1) co = fe_add<R>(co, fe_mul<R>(zx, MP_LD(t_hx + j)));
       MP_ST(c.zb_hB + j, co);
     }
-    for (uint32_t j = 0; j < n; ++j) MP_ST(c.zb_ck + j, fe_neg<R>(MP_LD(l.zbbar + j)));
     MP_ST(c.zb_H, fe_neg<R>(MP_LD(l.zsbar)));
     // VC_ZERO_D
     for (uint32_t k = 0; k <= 2 * m; ++k) MP_ST(c.zd_cD + k, MP_LD(t_zx + k));
@@ -1063,49 +1114,28 @@ MP_HD void body_verify_scal(const VerifyScalArgs& a, uint32_t b, uint32_t y_) {
     MP_ST(c.zd_ck0, fe_neg<R>(bil));
     MP_ST(c.zd_H, fe_neg<R>(MP_LD(l.ztbar)));
   }
-  // --- single value product; product value prod_{i=1..N} (y i + x^i - z)
+  // --- single value product
   {
     const Fe<R> sx = MP_LD(l.svx);
     MP_ST(c.sa_x, sx);
-    for (uint32_t j = 0; j < n; ++j) MP_ST(c.sa_ck + j, fe_neg<R>(MP_LD(l.svat + j)));
     MP_ST(c.sa_H, fe_neg<R>(MP_LD(l.svrt)));
     MP_ST(c.sd_x, sx);
-    for (uint32_t j = 0; j + 1 < n; ++j) {
-      // -(x bt_{j+1} - bt_j at_{j+1})
-      const Fe<R> v = fe_sub<R>(fe_mul<R>(MP_LD(l.svbt + j), MP_LD(l.svat + j + 1)), fe_mul<R>(sx, MP_LD(l.svbt + j + 1)));
-      MP_ST(c.sd_ck + j, v);
-    }
     MP_ST(c.sd_H, fe_neg<R>(MP_LD(l.svst)));
-    Fe<R> prod = one, xi = one, yi = fe_zero<R>();
-    for (uint32_t i = 1; i <= N; ++i) {
-      xi = fe_mul<R>(xi, x);
-      yi = fe_add<R>(yi, y);
-      prod = fe_mul<R>(prod, fe_sub<R>(fe_add<R>(yi, xi), z));
-      MP_ST(c.em_x + i - 1, xi);                      // x^i: coefficient of deck[i-1] in Cx
-    }
-    if (!fe_eq(MP_LD(l.svbt + 0), MP_LD(l.svat + 0)) || !fe_eq(MP_LD(l.svbt + n - 1), fe_mul<R>(sx, prod))) fail |= 1u << VC_SVP_SCALARS;
   }
   // --- multi-exponentiation
   {
     const Fe<R> mx = MP_LD(l.mx);
     if (!aff_is_inf<C>(ld_aff<C>(a.P + p_off<C>(l.mecB + m, a.Bpad, b)))) fail |= 1u << VC_ME_BM;
-    const uint32_t t_mx = l.tmp;    // mx^0 .. mx^(2m-1)
-    Fe<R> acc = one;
+    Fe<R> acc = one;          // mx^0 .. mx^(2m-1)
     for (uint32_t k = 0; k < 2 * m; ++k) {
-      MP_ST(t_mx + k, acc);
       MP_ST(c.mb_x + k, acc);
       MP_ST(c.me_x + k, acc);
+      if (k <= m) MP_ST(c.ma_x + k, acc);
       acc = fe_mul<R>(acc, mx);
     }
-    for (uint32_t j = 0; j <= m; ++j) MP_ST(c.ma_x + j, MP_LD(t_mx + j));
-    for (uint32_t j = 0; j < n; ++j) MP_ST(c.ma_ck + j, fe_neg<R>(MP_LD(l.meabar + j)));
     MP_ST(c.ma_H, fe_neg<R>(MP_LD(l.merbar)));
     MP_ST(c.mb_ck0, fe_neg<R>(MP_LD(l.mebbar)));
     MP_ST(c.mb_H, fe_neg<R>(MP_LD(l.mesbar)));
-    for (uint32_t i = 1; i <= m; ++i) {
-      const Fe<R> co = fe_neg<R>(MP_LD(t_mx + m - i));
-      for (uint32_t j = 0; j < n; ++j) MP_ST(c.me_c + (i - 1) * n + j, fe_mul<R>(co, MP_LD(l.meabar + j)));
-    }
     const Fe<R> ntau = fe_neg<R>(MP_LD(l.metaubar));
     MP_ST(c.me_tauG, ntau);
     MP_ST(c.me_taupk, ntau);
@@ -1124,7 +1154,7 @@ struct VerdictArgs {
 template <class C>
 MP_HD void body_verdict(const VerdictArgs& a, uint32_t b, uint32_t y) {
   if (a.status[b] < 0) return;   // usage error already recorded
-  const uint32_t direct = a.direct[b];
+  const uint32_t direct = a.direct[b] | a.direct[(size_t)a.Bpad + b];
   int32_t code = 0;
   for (int cidx = 0; cidx < (int)VC_COUNT && code == 0; ++cidx) {
     bool failed;
@@ -1151,7 +1181,7 @@ struct VerdictMergedArgs {
 template <class C>
 MP_HD void body_verdict_merged(const VerdictMergedArgs& a, uint32_t b, uint32_t y) {
   if (a.status[b] < 0) return;   // usage error already recorded
-  const bool bad = a.direct[b] != 0 ||
+  const bool bad = (a.direct[b] | a.direct[(size_t)a.Bpad + b]) != 0 ||
                    !fe_is_zero(ld_fe<typename C::FqP>(a.J + j_off<C>(a.chk_merged, a.Bpad, b) + 2 * Geo<C>::FW));
   a.status[b] = bad ? 1 : 0;
   if (bad) a.flag[0] = 1u;       // same value from every failing lane: no atomic needed
@@ -1229,7 +1259,7 @@ struct ChainVerdictArgs {
 template <class C>
 MP_HD void body_chain_verdict(const ChainVerdictArgs& a, uint32_t t, uint32_t y) {
   bool bad = !fe_is_zero(ld_fe<typename C::FqP>(a.J + j_off<C>(a.j_final, a.Bpad, t) + 2 * Geo<C>::FW));
-  for (uint32_t j = 0; j < a.L; ++j) bad = bad || a.status[(size_t)j * a.T + t] != 0 || a.direct[(size_t)j * a.T + t] != 0;
+  for (uint32_t j = 0; j < a.L; ++j) bad = bad || a.status[(size_t)j * a.T + t] != 0 || (a.direct[(size_t)j * a.T + t] | a.direct[(size_t)a.Bpad + (size_t)j * a.T + t]) != 0;
   if (a.p_pk != NO_SLOT) {
     uint32_t k0[Geo<C>::PW], kj[Geo<C>::PW];
     ld_words<Geo<C>::PW>(a.P + p_off<C>(a.p_pk, a.Bpad, t), k0);
