@@ -173,12 +173,15 @@ int mp_verify_shuffle_chain_dev(mp_table* t, size_t tables, uint32_t links, cons
                                 void* d_status);
 int mp_sync(mp_ctx* ctx);
 int mp_reserve(mp_table* t, size_t B);           /* pre-allocate the batch workspace for B proofs */
-/* Every table holds four static work splits with identical results: a throughput plan (large sub-jobs, fewest operations),
- * a latency plan (small sub-jobs: ~16x more lanes per proof), a medium plan in between and a finest split for single proofs.
- * Batches of at most B/4 proofs use the finest split, up to `B` the latency plan, up to 32/3 B the medium plan, larger ones
- * the throughput plan (default B = 3072 * 52 / N, at least 64: 768 / 3 072 / 32 768 proofs of 52 cards, the crossovers
- * measured on an MI355X; 0 = always throughput). */
+/* Every table holds five static work splits with identical results: a throughput plan (large sub-jobs, fewest operations),
+ * a latency plan (small sub-jobs: ~16x more lanes per proof), a medium and a wide plan in between and a finest split for single
+ * proofs.  Batches of at most B/4 proofs use the finest split, up to `B` the latency plan, up to 4 B the medium plan, up to 16 B the
+ * wide plan, larger ones the throughput plan (default B = 3072 * 52 / N, at least 64: 768 / 3 072 / 12 288 / 49 152 proofs of 52
+ * cards, the crossovers measured on an MI355X; 0 = always throughput). */
 int mp_set_latency_batch(mp_table* t, size_t B);
+/* Every batch takes work split `split` whatever its size: 0 throughput, 1 latency, 2 medium, 3 finest, 4 wide; -1 (default) = by
+ * batch size as above.  For tests and measurements: the results do not depend on it. */
+int mp_set_work_split(mp_table* t, int split);
 /* Verification strategy.  on (default): the verifier first evaluates ALL group equations of a proof merged into one
  * multi-scalar multiplication with random weights derived from the whole proof (soundness loss ~2^-250); a batch in which
  * every proof passes ends there.  Only if some proof fails is the batch re-evaluated equation by equation, so that the

@@ -229,6 +229,12 @@ int mp_set_group_lanes(mp_table* t, uint32_t lanes) {
   t->group_lanes = lanes;
   return MP_OK;
 }
+int mp_set_work_split(mp_table* t, int split) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_work_split: null table");
+  if (split < -1 || split > 4) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_work_split: -1 (by batch size) or 0 .. 4");
+  t->forced_split = split;
+  return MP_OK;
+}
 int mp_set_toom_cook(mp_table* t, int on) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_toom_cook: null table");
   MP_TRY

@@ -168,6 +168,7 @@ struct mp_table {
   uint32_t chain_max_links = 0;   // links per chain equation (0 = as many as fit 32 767 points; mp_set_chain_max_links)
   uint32_t fs_lanes = 0;          // lanes per transcript hash: 1, 4, or 0 = by batch size (mp_set_transcript_lanes)
   uint32_t group_lanes = 0;       // lanes per group operation of the MSM chains: 1, 4, or 0 = by batch size (mp_set_group_lanes)
+  int forced_split = -1;          // work split every batch takes: 0 throughput, 1 latency, 2 medium, 3 finest, 4 wide; -1 = by batch size (mp_set_work_split)
   virtual ~mp_table() {}
   virtual void reserve(size_t B) = 0;
   virtual void set_latency_batch(size_t B) = 0;

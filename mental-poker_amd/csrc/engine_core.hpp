@@ -122,26 +122,31 @@ struct Table : mp_table {
     uint32_t table_group = TABLE_GROUP;
     uint32_t norm_chunk = NORM_CHUNK;
   };
-  // Four static work splits per table, identical results: [0] throughput (64 variable-base / 8 fixed-base terms per lane,
+  // Five static work splits per table, identical results: [0] throughput (64 variable-base / 8 fixed-base terms per lane,
   // 64 bases per table lane: fewest operations), [1] latency (4 / 2 / 8: ~16x more lanes per proof), [2] medium (16 / 4 / 16),
-  // [3] single proofs and tiny batches (1 / 1 / 2 on decks of up to 128 cards, else 2 / 1 / 4).  Measured on an MI355X, 52 cards: [3] wins up to ~768 proofs in flight,
-  // latency up to ~4 k, medium up to ~14 k, throughput beyond.
-  static const int N_PLANS = 4;
+  // [4] wide (32 / 4 / 16), [3] single proofs and tiny batches (1 / 1 / 2 on decks of up to 128 cards, else 2 / 1 / 4).  Measured on
+  // an MI355X, 52 cards: [3] wins up to ~768 proofs in flight, latency up to ~3 k, medium up to ~12 k, wide up to ~48 k, throughput beyond.
+  static const int N_PLANS = 5;
   PlanSet ps[N_PLANS];        // plans with the table's own aggregate key as a fixed base
   PlanSet psk[N_PLANS];       // plans for keyed batches (per-proof aggregate key): built on first use
   bool psk_ready = false;
   DevBuf<Term> key_recode, key_tables;          // static job lists of the per-proof key tables
   uint32_t key_d_first = 0, key_t_first = 0;     // first digit slot (rho_0) / table slot (window 0) of the key machinery
-  // (crossovers measured on 52-card decks at the end of round 3, profiles/r03k_plan_sweep.txt: 768 / 3 072 / 32 768 -- the shorter
-  // transcripts and chains of small batches moved them from round 2's 768 / 4 096 / 14 336)
+  // (crossovers measured on 52-card decks at the end of round 3, profiles/r03k_plan_sweep.txt and r03q_wide_split.txt: 768 / 3 072 /
+  // 12 288 / 49 152 -- the shorter transcripts and chains of small batches moved them from round 2's 768 / 4 096 / 14 336)
   uint32_t latency_batch = 3072;                 // batches up to this size use the latency plan (mp_set_latency_batch),
-  uint32_t medium_batch = 32768;                 // up to this size the medium plan (32/3 x latency_batch), larger ones throughput
+  uint32_t medium_batch = 12288;                 // up to this size the medium plan (4 x latency_batch),
+  uint32_t wide_batch = 49152;                   // up to this size the wide plan (16 x latency_batch), larger ones throughput
   uint32_t tiny_batch = 768;                     // up to this size the finest split (1/4 x latency_batch, in steps of 4)
-  int plan_of(uint32_t B) const { return B <= tiny_batch ? 3 : (B <= latency_batch ? 1 : (B <= medium_batch ? 2 : 0)); }
+  int plan_of(uint32_t B) const {
+    if (forced_split >= 0 && forced_split < N_PLANS) return forced_split;
+    return B <= tiny_batch ? 3 : (B <= latency_batch ? 1 : (B <= medium_batch ? 2 : (B <= wide_batch ? 4 : 0)));
+  }
   PlanSet& pick(uint32_t B, bool keyed = false) { return (keyed ? psk : ps)[plan_of(B)]; }
   void set_latency_batch(size_t b) override {
     latency_batch = (uint32_t)std::min<size_t>(b, 0x20000000u);
-    medium_batch = (uint32_t)std::min<uint64_t>((uint64_t)latency_batch * 32 / 3, 0x40000000u);
+    medium_batch = (uint32_t)std::min<uint64_t>((uint64_t)latency_batch * 4, 0x40000000u);
+    wide_batch = (uint32_t)std::min<uint64_t>((uint64_t)latency_batch * 16, 0x40000000u);
     tiny_batch = latency_batch / 16 * 4;
   }
   uint32_t bucket_min = BUCKET_MIN;              // MSMs of at least this many variable-base terms use the bucket kernel (0 = never)
@@ -266,8 +271,8 @@ struct Table : mp_table {
     // to 256 proofs.  A single 300-card proof already brings more lanes than the chip holds: there the finer split only adds work,
     // BLS12-377 (30,10) 90 -> 117 ms.)
     const uint32_t tiny_v = N <= 128 ? 1u : 2u, tiny_g = N <= 128 ? 2u : 4u;
-    const uint32_t fch[N_PLANS] = {FCHUNK, 2, 4, 1}, vch[N_PLANS] = {VCHUNK, 4, 16, tiny_v}, grp[N_PLANS] = {TABLE_GROUP, 8, 16, tiny_g},
-                   nch[N_PLANS] = {NORM_CHUNK, 8, 32, 4};
+    const uint32_t fch[N_PLANS] = {FCHUNK, 2, 4, 1, 4}, vch[N_PLANS] = {VCHUNK, 4, 16, tiny_v, 32}, grp[N_PLANS] = {TABLE_GROUP, 8, 16, tiny_g, 16},
+                   nch[N_PLANS] = {NORM_CHUNK, 8, 32, 4, 32};
     for (int k = 0; k < N_PLANS; ++k) {
       PlanSet& q = set[k];
       // the two finest splits serve batches too small to fill the chip with one lane per Straus job: there the bucket kernel
@@ -276,7 +281,7 @@ struct Table : mp_table {
       const uint32_t bmin = (bucket_min && (k == 1 || k == 3)) ? std::min(bucket_min, BUCKET_MIN_SMALL_BATCH) : bucket_min;
       // Toom-Cook adds two dependent stages (operand evaluation, interpolation): a win when the batch fills the chip (throughput and
       // medium plans), a loss for a handful of proofs, where the small-batch plans keep Karatsuba (BLS12-377 (6,50), one proof: 78 vs 94 ms)
-      q.pplan = make_prove_plan(m, n, fch[k], vch[k], G_::PB, keyed, bmin, bk_windows(R::BITS), toom_cook && (k == 0 || k == 2));
+      q.pplan = make_prove_plan(m, n, fch[k], vch[k], G_::PB, keyed, bmin, bk_windows(R::BITS), toom_cook && (k == 0 || k == 2 || k == 4));
       q.vplan = make_verify_plan(m, n, fch[k], vch[k], G_::PB, keyed, bmin, bk_windows(R::BITS));
       q.table_group = grp[k];
       q.norm_chunk = nch[k];       // fewer points per serial inversion chain when lanes are idle
@@ -884,7 +889,7 @@ struct Table : mp_table {
     // dependency chain and its flag read-back a round trip -- it pays from the medium plan on (+3 % there, measured)
     const int plan = plan_of(B);
     // (unless the merged equation runs on the bucket kernel, which spreads ONE MSM over windows x 64 lanes)
-    for (int pass = (merged_verify && (plan == 0 || plan == 2 || q.vmph.n_b)) ? 0 : 1; pass < 2; ++pass) {
+    for (int pass = (merged_verify && (plan == 0 || plan == 2 || plan == 4 || q.vmph.n_b)) ? 0 : 1; pass < 2; ++pass) {
       const bool merged = pass == 0;
       rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
       {

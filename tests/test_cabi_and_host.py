@@ -77,8 +77,9 @@ def test_kernel_bodies_under_emulation_match_golden(emu, native, name):
     t = eng.table(m, n, bytes.fromhex(g["params"]), bytes.fromhex(g["pk"]))
     # a single proof takes the four-lane transcripts and group operations by default (k_fsq_*, kernels_quad.hpp); lanes = 1 forces
     # the kernels a full batch runs (one lane per proof, one lane per chain)
-    for latency_batch, lanes in ((8192, 0), (8, 0), (0, 0), (8192, 1), (0, 1)):   # finest split, latency plan, throughput plan (large sub-jobs, Toom-Cook for m = 2)
-        t.set_latency_batch(latency_batch)
+    for latency_batch, lanes in ((8192, 0), (8, 0), (0, 0), (8192, 1), (0, 1), (-4, 0)):   # finest split, latency plan, throughput plan (large sub-jobs, Toom-Cook for m = 2); -4: the wide split forced
+        t.set_work_split(4 if latency_batch < 0 else -1)
+        t.set_latency_batch(max(latency_batch, 0))
         t.set_transcript_lanes(lanes)
         t.set_group_lanes(lanes)
         eng.profile_enable(True)
@@ -94,6 +95,9 @@ def test_kernel_bodies_under_emulation_match_golden(emu, native, name):
         t.set_transcript_lanes(3)
     with pytest.raises(native.NativeError):
         t.set_group_lanes(2)
+    with pytest.raises(native.NativeError):
+        t.set_work_split(5)
+    t.set_work_split(-1)
     t.set_transcript_lanes(0)
     t.set_group_lanes(0)
     bad = bytearray(proof)

@@ -63,7 +63,7 @@ def test_golden_vectors(mp, engines, path):
 
 @pytest.mark.parametrize("curve,m,n,B", [("stark", 2, 26, 6), ("stark", 4, 13, 5), ("stark", 6, 5, 3),
                                          ("bn254", 3, 5, 3), ("secp256k1", 2, 7, 3), ("bls12_377", 2, 5, 3)])
-@pytest.mark.parametrize("plan", ["tiny", "latency", "medium", "throughput"])
+@pytest.mark.parametrize("plan", ["tiny", "latency", "medium", "wide", "throughput"])
 def test_batch_matches_oracle(mp, engines, coracle, curve, m, n, B, plan):
     cards = engines(curve)
     g0 = coracle.gen_inputs(curve, m, n, 100)
@@ -71,7 +71,8 @@ def test_batch_matches_oracle(mp, engines, coracle, curve, m, n, B, plan):
     pk = g0["pk"]
     # finest split up to 3/16 L proofs, latency plan up to L, medium plan up to 3.5 L, throughput beyond (L = 0: always
     # throughput); B is 3..6 here
-    cards.table(pp, pk).set_latency_batch({"tiny": 8192, "latency": 8, "medium": 2, "throughput": 0}[plan])
+    cards.table(pp, pk).set_latency_batch({"tiny": 8192, "latency": 8, "medium": 2, "wide": 8192, "throughput": 0}[plan])
+    cards.table(pp, pk).set_work_split(4 if plan == "wide" else -1)      # (the wide split starts at 4x the medium one's batch)
     ins = []
     for b in range(B):
         g = coracle.gen_inputs(curve, m, n, 200 + b)     # same draw order => same params? no: own params per seed
@@ -94,6 +95,7 @@ def test_batch_matches_oracle(mp, engines, coracle, curve, m, n, B, plan):
     out = cards.verify_shuffle_batch(pp, pk, decks, rot, proofs)
     assert all(o == mp.CryptoError("Hadamard Product (5.1)") for o in out)
     cards.table(pp, pk).set_latency_batch(8192)
+    cards.table(pp, pk).set_work_split(-1)
 
 
 @pytest.mark.parametrize("fb_bits", [16, 20, 21])
