@@ -604,7 +604,7 @@ def test_transcript_lane_modes_agree(mp, coracle, curve, m, n, B, keyed):
 
 def test_alternating_batch_sizes_are_consistent(mp, coracle):
     """one table, batches of very different sizes back to back (they take different kernels -- four-lane or one-lane transcripts and
-    group operations, one or two prover streams, the four static plans -- and share the context's streams, events and arenas):
+    group operations, one or two prover streams, the five static work splits -- and share the context's streams, events and arenas):
     proof 0 is the oracle's every time, every batch verifies, and a batch verified right after a larger one gets its own verdicts"""
     curve, m, n = "stark", 2, 4
     cards = mp.DLCards(curve, device=0)
