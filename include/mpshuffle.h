@@ -175,9 +175,9 @@ int mp_sync(mp_ctx* ctx);
 int mp_reserve(mp_table* t, size_t B);           /* pre-allocate the batch workspace for B proofs */
 /* Every table holds five static work splits with identical results: a throughput plan (large sub-jobs, fewest operations),
  * a latency plan (small sub-jobs: ~16x more lanes per proof), a medium and a wide plan in between and a finest split for single
- * proofs.  Batches of at most B/4 proofs use the finest split, up to `B` the latency plan, up to 4 B the medium plan, up to 16 B the
- * wide plan, larger ones the throughput plan (default B = 3072 * 52 / N, at least 64: 768 / 3 072 / 12 288 / 49 152 proofs of 52
- * cards, the crossovers measured on an MI355X; 0 = always throughput). */
+ * proofs.  Batches of at most 5/32 B proofs use the finest split, up to `B` the latency plan, up to 3.2 B the medium plan, up to
+ * 12.8 B the wide plan, larger ones the throughput plan (default B = 3840 * 52 / N, at least 64: 600 / 3 840 / 12 288 / 49 152 proofs
+ * of 52 cards, the crossovers measured on an MI355X; 0 = always throughput). */
 int mp_set_latency_batch(mp_table* t, size_t B);
 /* Every batch takes work split `split` whatever its size: 0 throughput, 1 latency, 2 medium, 3 finest, 4 wide; -1 (default) = by
  * batch size as above.  For tests and measurements: the results do not depend on it. */

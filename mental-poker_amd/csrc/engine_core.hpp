@@ -107,9 +107,7 @@ struct Table : mp_table {
   typedef typename C::FrP R;
   typedef Geo<C> G_;      // element sizes of this curve (words in the arenas, bytes on the wire)
 
-  // Two static plans per table: [0] throughput (large sub-jobs: fewest operations, one lane per job is fine when
-  // there are thousands of proofs) and [1] latency (small sub-jobs and table groups: ~16x more lanes per proof, used
-  // when the batch is too small to fill the chip otherwise).  Same results, different work split.
+  // One static plan per work split (below): the same results from sub-jobs of different sizes.
   struct PlanSet {
     ProvePlan pplan;
     VerifyPlan vplan;
@@ -125,19 +123,19 @@ struct Table : mp_table {
   // Five static work splits per table, identical results: [0] throughput (64 variable-base / 8 fixed-base terms per lane,
   // 64 bases per table lane: fewest operations), [1] latency (4 / 2 / 8: ~16x more lanes per proof), [2] medium (16 / 4 / 16),
   // [4] wide (32 / 4 / 16), [3] single proofs and tiny batches (1 / 1 / 2 on decks of up to 128 cards, else 2 / 1 / 4).  Measured on
-  // an MI355X, 52 cards: [3] wins up to ~768 proofs in flight, latency up to ~3 k, medium up to ~12 k, wide up to ~48 k, throughput beyond.
+  // an MI355X, 52 cards: [3] wins up to ~640 proofs in flight, latency up to ~4 k, medium up to ~12 k, wide up to ~48 k, throughput beyond.
   static const int N_PLANS = 5;
   PlanSet ps[N_PLANS];        // plans with the table's own aggregate key as a fixed base
   PlanSet psk[N_PLANS];       // plans for keyed batches (per-proof aggregate key): built on first use
   bool psk_ready = false;
   DevBuf<Term> key_recode, key_tables;          // static job lists of the per-proof key tables
   uint32_t key_d_first = 0, key_t_first = 0;     // first digit slot (rho_0) / table slot (window 0) of the key machinery
-  // (crossovers measured on 52-card decks at the end of round 3, profiles/r03k_plan_sweep.txt and r03q_wide_split.txt: 768 / 3 072 /
-  // 12 288 / 49 152 -- the shorter transcripts and chains of small batches moved them from round 2's 768 / 4 096 / 14 336)
-  uint32_t latency_batch = 3072;                 // batches up to this size use the latency plan (mp_set_latency_batch),
-  uint32_t medium_batch = 12288;                 // up to this size the medium plan (4 x latency_batch),
-  uint32_t wide_batch = 49152;                   // up to this size the wide plan (16 x latency_batch), larger ones throughput
-  uint32_t tiny_batch = 768;                     // up to this size the finest split (1/4 x latency_batch, in steps of 4)
+  // (crossovers measured on 52-card decks at the end of round 3, profiles/r03k_plan_sweep.txt, r03q_wide_split.txt, r03s_small_splits.txt:
+  // ~640 / ~4 000 / 12 288 / 49 152 -- the shorter transcripts and chains of small batches moved them from round 2's 768 / 4 096 / 14 336)
+  uint32_t latency_batch = 3840;                 // batches up to this size use the latency plan (mp_set_latency_batch): 4 096 proofs are the medium plan's
+  uint32_t medium_batch = 12288;                 // up to this size the medium plan (3.2 x latency_batch),
+  uint32_t wide_batch = 49152;                   // up to this size the wide plan (12.8 x latency_batch), larger ones throughput
+  uint32_t tiny_batch = 600;                     // up to this size the finest split (5/32 x latency_batch, in steps of 5)
   int plan_of(uint32_t B) const {
     if (forced_split >= 0 && forced_split < N_PLANS) return forced_split;
     return B <= tiny_batch ? 3 : (B <= latency_batch ? 1 : (B <= medium_batch ? 2 : (B <= wide_batch ? 4 : 0)));
@@ -145,9 +143,9 @@ struct Table : mp_table {
   PlanSet& pick(uint32_t B, bool keyed = false) { return (keyed ? psk : ps)[plan_of(B)]; }
   void set_latency_batch(size_t b) override {
     latency_batch = (uint32_t)std::min<size_t>(b, 0x20000000u);
-    medium_batch = (uint32_t)std::min<uint64_t>((uint64_t)latency_batch * 4, 0x40000000u);
-    wide_batch = (uint32_t)std::min<uint64_t>((uint64_t)latency_batch * 16, 0x40000000u);
-    tiny_batch = latency_batch / 16 * 4;
+    medium_batch = (uint32_t)std::min<uint64_t>((uint64_t)latency_batch * 16 / 5, 0x40000000u);
+    wide_batch = (uint32_t)std::min<uint64_t>((uint64_t)latency_batch * 64 / 5, 0x40000000u);
+    tiny_batch = latency_batch / 32 * 5;
   }
   uint32_t bucket_min = BUCKET_MIN;              // MSMs of at least this many variable-base terms use the bucket kernel (0 = never)
   bool toom_cook = true;        // 3 <= m <= 16: Toom-Cook instead of Karatsuba for the multi-exponentiation diagonals
@@ -275,10 +273,11 @@ struct Table : mp_table {
                    nch[N_PLANS] = {NORM_CHUNK, 8, 32, 4, 32};
     for (int k = 0; k < N_PLANS; ++k) {
       PlanSet& q = set[k];
-      // the two finest splits serve batches too small to fill the chip with one lane per Straus job: there the bucket kernel
+      // the finest split serves batches too small to fill the chip with one lane per Straus job: there the bucket kernel
       // (windows x 64 lanes per MSM) already pays from 128 terms on -- the merged verifier equation of a 52-card proof has 239
-      // (one proof: verify 4.4 -> 3.6 ms, profiles/r02_latency.txt)
-      const uint32_t bmin = (bucket_min && (k == 1 || k == 3)) ? std::min(bucket_min, BUCKET_MIN_SMALL_BATCH) : bucket_min;
+      // (one proof: verify 4.4 -> 3.6 ms, profiles/r02_latency.txt).  The latency split had it too until the end of round 3: from ~1 000
+      // proofs on the fixed 14-addition reduction per window is 3x the work of Straus (2 048 proofs: 164 k -> 184 k/s without it)
+      const uint32_t bmin = (bucket_min && k == 3) ? std::min(bucket_min, BUCKET_MIN_SMALL_BATCH) : bucket_min;
       // Toom-Cook adds two dependent stages (operand evaluation, interpolation): a win when the batch fills the chip (throughput and
       // medium plans), a loss for a handful of proofs, where the small-batch plans keep Karatsuba (BLS12-377 (6,50), one proof: 78 vs 94 ms)
       q.pplan = make_prove_plan(m, n, fch[k], vch[k], G_::PB, keyed, bmin, bk_windows(R::BITS), toom_cook && (k == 0 || k == 2 || k == 4));
@@ -328,7 +327,7 @@ struct Table : mp_table {
     m = m_; n = n_; N = m * n;
     point_bytes = G_::PB;
     // plan thresholds count lanes, and a proof of N cards brings ~N/52 times the lanes of a 52-card proof
-    set_latency_batch(std::max<size_t>(64, (size_t)3072 * 52 / N));
+    set_latency_batch(std::max<size_t>(64, (size_t)3840 * 52 / N));
     nwin = (uint32_t)vb_windows(R::BITS);
     FixedBases fb{n};
     std::vector<Aff<C>> bases(fb.count());
