@@ -217,6 +217,8 @@ def main():
                     help="variable-base MSMs of at least this many terms run on the bucket-method kernel (engine default 2048; 0 = never)")
     ap.add_argument("--transcript-lanes", type=int, default=None, choices=[0, 1, 4],
                     help="lanes per Fiat-Shamir transcript hash (mp_set_transcript_lanes; default: by batch size)")
+    ap.add_argument("--group-lanes", type=int, default=None, choices=[0, 1, 4],
+                    help="lanes per group operation of the MSM chains (mp_set_group_lanes; default: by batch size)")
     ap.add_argument("--work-split", type=int, default=None, choices=[-1, 0, 1, 2, 3, 4],
                     help="force one of the table's work splits (mp_set_work_split; default: by batch size)")
     ap.add_argument("--per-equation", action="store_true", help="verify equation by equation (mp_set_merged_verify off)")
@@ -312,6 +314,8 @@ def main():
             t.set_transcript_lanes(args.transcript_lanes)
         if args.work_split is not None:
             t.set_work_split(args.work_split)
+        if args.group_lanes is not None:
+            t.set_group_lanes(args.group_lanes)
     table = tables[0]
     proof_bytes = table.proof_bytes
 
