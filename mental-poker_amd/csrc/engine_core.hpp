@@ -515,7 +515,7 @@ struct Table : mp_table {
 #ifdef MP_EXP_QUAD_MAX      // experiment hook (tools/ab_build.py): 0 = never
   uint32_t quad_max_lanes = MP_EXP_QUAD_MAX;
 #else
-  uint32_t quad_max_lanes = 65536;
+  uint32_t quad_max_lanes = 65536;       // (per launch; 262 144 was tried: the many short chains of a 4 096-proof batch -- combines, fixed-base sums -- then go four lanes wide too: 239 k -> 161 k/s)
 #endif
   bool quad_ops(uint32_t B, uint32_t njobs) const { return group_lanes == 4 || (group_lanes == 0 && (uint64_t)B * njobs * 4u <= quad_max_lanes); }
   void run_combine(const CombineArgs& a, uint32_t B, uint32_t njobs) {
