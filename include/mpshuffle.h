@@ -182,6 +182,25 @@ int mp_set_latency_batch(mp_table* t, size_t B);
 /* Every batch takes work split `split` whatever its size: 0 throughput, 1 latency, 2 medium, 3 finest, 4 wide; -1 (default) = by
  * batch size as above.  For tests and measurements: the results do not depend on it. */
 int mp_set_work_split(mp_table* t, int split);
+/* Pipelined verification (off by default).  A card server proves the next batch while the previous one is verified; with this on,
+ * the device-resident verify calls (mp_verify_shuffle_batch[_keys|_keyset]_dev) run on a second lane of the context -- streams and
+ * arenas of their own -- ordered behind everything the context held when they were issued, and return WITHOUT waiting for their
+ * screening verdict, so that the caller's next mp_shuffle_and_remask_batch*_dev call runs beside them on the chip (batches that do
+ * not fill it alone: 1 024 proofs +40 %, 4 096 +20 %).  The verdict of verify call k is looked at when verify
+ * call k + 1 comes in or at mp_sync, and only then -- only if some proof failed the screen -- does the per-equation pass of call k run.
+ * The caller's side of the contract: the buffers a verify call reads (decks, shuffled decks, proofs, keys) stay untouched until the
+ * NEXT verify call on that table or mp_sync has returned (alternate between two sets of prover outputs); d_status is final after
+ * mp_sync, as before.  Status words are identical in both modes.  The host-buffer entry points and chain verification are unaffected. */
+int mp_set_pipeline(mp_table* t, int on);
+/* The sizes behind work split `split` (0 .. 4 as above): fixed-base / variable-base terms per sub-job, bases per window-table lane,
+ * points per shared inversion, and `window_lanes` = lanes per variable-base sub-job: the Straus windows of a sub-job are dealt to that
+ * many lanes (each runs its share as a chain of its own) and one fold per multi-scalar multiplication puts the range sums together --
+ * k times the lanes for < 250 extra doublings per MSM instead of k times the doubling chains (1 = one lane runs all windows).
+ * mp_set_plan_thresholds: the largest batch that takes the finest / latency / medium / wide split.  For measurements and tuning on
+ * other parts: results do not depend on either.  Both rebuild nothing a running batch uses (call between batches). */
+int mp_set_plan_params(mp_table* t, int split, uint32_t fixed_terms, uint32_t var_terms, uint32_t table_group, uint32_t norm_chunk,
+                       uint32_t window_lanes);
+int mp_set_plan_thresholds(mp_table* t, size_t finest, size_t latency, size_t medium, size_t wide);
 /* Verification strategy.  on (default): the verifier first evaluates ALL group equations of a proof merged into one
  * multi-scalar multiplication with random weights derived from the whole proof (soundness loss ~2^-250); a batch in which
  * every proof passes ends there.  Only if some proof fails is the batch re-evaluated equation by equation, so that the

@@ -65,6 +65,16 @@ uint64_t get_u64(const uint8_t* p) {
   return v;
 }
 bool curve_ok(int c) { return c >= 0 && c <= 3; }
+// the host-buffer entry points and chain verification order their own transfers around verify_dev: not pipelined
+struct NoPipeline {
+  mp_table* t;
+  int keep;
+  explicit NoPipeline(mp_table* tt) : t(tt), keep(tt->pipeline) {
+    if (keep) t->flush();
+    t->pipeline = 0;
+  }
+  ~NoPipeline() { t->pipeline = keep; }
+};
 }  // namespace
 
 extern "C" {
@@ -110,6 +120,12 @@ int mp_ctx_create(int curve_id, int device, mp_ctx** out) {
   c->ev_fork = rt::event_create();
   c->ev_shuf = rt::event_create();
   c->ev_tab = rt::event_create();
+  c->vstream = rt::stream_create();
+  c->vside = rt::stream_create();
+  c->ev_vfork = rt::event_create();
+  c->ev_vshuf = rt::event_create();
+  c->ev_vtab = rt::event_create();
+  c->ev_vin = rt::event_create();
   *out = c;
   return MP_OK;
   MP_CATCH
@@ -123,6 +139,12 @@ void mp_ctx_destroy(mp_ctx* ctx) {
   rt::event_destroy(ctx->ev_fork);
   rt::event_destroy(ctx->ev_shuf);
   rt::event_destroy(ctx->ev_tab);
+  rt::stream_destroy(ctx->vstream);
+  rt::stream_destroy(ctx->vside);
+  rt::event_destroy(ctx->ev_vfork);
+  rt::event_destroy(ctx->ev_vshuf);
+  rt::event_destroy(ctx->ev_vtab);
+  rt::event_destroy(ctx->ev_vin);
   delete ctx;
 }
 
@@ -160,6 +182,7 @@ int mp_table_create_ex(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* param
     delete t;
     return rc;
   }
+  ctx->tables.push_back(t);
   *out = t;
   return MP_OK;
   MP_CATCH
@@ -172,6 +195,13 @@ int mp_table_create_params(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* p
 }
 void mp_table_destroy(mp_table* t) {
   if (!t) return;
+  try {
+    rt::set_device(t->ctx->device);
+    t->flush();
+  } catch (...) {
+  }
+  auto& reg = t->ctx->tables;
+  reg.erase(std::remove(reg.begin(), reg.end(), t), reg.end());
   for (auto& st : t->io) {
     if (st.up) rt::event_destroy(st.up);
     if (st.done) rt::event_destroy(st.done);
@@ -233,6 +263,31 @@ int mp_set_work_split(mp_table* t, int split) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_work_split: null table");
   if (split < -1 || split > 4) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_work_split: -1 (by batch size) or 0 .. 4");
   t->forced_split = split;
+  return MP_OK;
+}
+int mp_set_pipeline(mp_table* t, int on) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_pipeline: null table");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  t->flush();
+  t->pipeline = on != 0;
+  return MP_OK;
+  MP_CATCH
+}
+int mp_set_plan_params(mp_table* t, int split, uint32_t fixed_terms, uint32_t var_terms, uint32_t table_group, uint32_t norm_chunk,
+                       uint32_t window_lanes) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_plan_params: null table");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  if (t->set_plan_params(split, fixed_terms, var_terms, table_group, norm_chunk, window_lanes) != MP_OK)
+    return fail(MP_ERR_BAD_ARGUMENT, "mp_set_plan_params: split 0 .. 4, sizes >= 1, table_group <= 64, window_lanes <= 16");
+  return MP_OK;
+  MP_CATCH
+}
+int mp_set_plan_thresholds(mp_table* t, size_t finest, size_t latency, size_t medium, size_t wide) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_plan_thresholds: null table");
+  if (finest > latency || latency > medium || medium > wide) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_plan_thresholds: finest <= latency <= medium <= wide");
+  t->set_plan_thresholds(finest, latency, medium, wide);
   return MP_OK;
 }
 int mp_set_toom_cook(mp_table* t, int on) {
@@ -359,6 +414,7 @@ int mp_verify_shuffle_chain_dev(mp_table* t, size_t tables, uint32_t links, cons
   if ((uint64_t)tables * links >= ((uint64_t)1 << 31)) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_chain_dev: too many proofs for one call");
   MP_TRY
   rt::set_device(t->ctx->device);
+  NoPipeline nopipe(t);
   // one chain equation holds at most 32 767 distinct points ((L + 1) 2N decks + L (11m + 8) proof elements + key): longer chains are
   // verified as consecutive sub-chains (the decks array is link-major, so a sub-chain is a contiguous slice)
   const size_t per_link = (size_t)2 * t->N + 11 * t->m + 8, fixed_part = (size_t)2 * t->N + 1;
@@ -409,7 +465,9 @@ int mp_verify_shuffle_chain(mp_table* t, size_t tables, uint32_t links, const ui
 int mp_sync(mp_ctx* ctx) {
   if (!ctx) return fail(MP_ERR_BAD_ARGUMENT, "mp_sync: null");
   MP_TRY
+  rt::set_device(ctx->device);
   rt::stream_sync(ctx->stream);
+  for (mp_table* t : ctx->tables) t->flush();      // pipelined verify calls: deferred per-equation passes, then the verify lane
   return MP_OK;
   MP_CATCH
 }
@@ -484,6 +542,7 @@ static int verify_batch_host(mp_table* t, size_t B, const uint8_t* keys, const u
   if (t->keyless && !keys) return fail(MP_ERR_BAD_ARGUMENT, "this table has no aggregate key: use the _keys entry points");
   MP_TRY
   rt::set_device(t->ctx->device);
+  NoPipeline nopipe(t);
   rt::Stream s = t->ctx->stream, up = t->ctx->h2d, down = t->ctx->d2h;
   const size_t N = t->N, psz = proof_size_bytes(t->m, t->n, t->point_bytes), dsz = N * 2 * t->point_bytes;
   const size_t chunk = std::min(B, t->io_chunk ? t->io_chunk : IO_CHUNK), nchunks = (B + chunk - 1) / chunk;

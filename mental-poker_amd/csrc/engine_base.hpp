@@ -118,8 +118,30 @@ struct mp_ctx {
   // `side` next to the randomness, c_A and the statement hash on `stream` (engine_core.hpp: prove_dev)
   mp::rt::Stream side{};
   mp::rt::Event ev_fork{}, ev_shuf{}, ev_tab{};
+  // pipelined verification (mp_set_pipeline): verify calls run on a lane of their own -- stream, side stream, events -- next to the
+  // prove calls on the lane above; ev_vin orders a verify call behind everything the main stream held when it was issued
+  mp::rt::Stream vstream{}, vside{};
+  mp::rt::Event ev_vfork{}, ev_vshuf{}, ev_vtab{}, ev_vin{};
+  std::vector<mp_table*> tables;      // the tables of this context (mp_sync completes their deferred verification passes)
   mp::Profiler prof;
 };
+namespace mp {
+// for the duration of a pipelined verify call the context's stream / side stream / events ARE the verify lane's
+struct LaneSwap {
+  mp_ctx* c;
+  explicit LaneSwap(mp_ctx* ctx) : c(ctx) { swap(); }
+  ~LaneSwap() { swap(); }
+  LaneSwap(const LaneSwap&) = delete;
+  LaneSwap& operator=(const LaneSwap&) = delete;
+  void swap() {
+    std::swap(c->stream, c->vstream);
+    std::swap(c->side, c->vside);
+    std::swap(c->ev_fork, c->ev_vfork);
+    std::swap(c->ev_shuf, c->ev_vshuf);
+    std::swap(c->ev_tab, c->ev_vtab);
+  }
+};
+}  // namespace mp
 
 // batches of up to this many proofs hash their transcripts with four lanes per BLAKE2s state (kernels_proto.hpp: k_fsq_*): up to
 // 512 waves of lone transcript lanes leave half the SIMDs idle and the others waiting 8-10 cycles per instruction
@@ -169,13 +191,17 @@ struct mp_table {
   uint32_t fs_lanes = 0;          // lanes per transcript hash: 1, 4, or 0 = by batch size (mp_set_transcript_lanes)
   uint32_t group_lanes = 0;       // lanes per group operation of the MSM chains: 1, 4, or 0 = by batch size (mp_set_group_lanes)
   int forced_split = -1;          // work split every batch takes: 0 throughput, 1 latency, 2 medium, 3 finest, 4 wide; -1 = by batch size (mp_set_work_split)
+  int pipeline = 0;               // device-resident verify calls run on the context's second lane, next to the prove calls (mp_set_pipeline)
   virtual ~mp_table() {}
+  virtual void flush() = 0;       // complete deferred verification passes and wait for the verify lane
   virtual void reserve(size_t B) = 0;
   virtual void set_latency_batch(size_t B) = 0;
   virtual void set_merged_verify(bool on) = 0;
   virtual void set_subgroup_check(bool on) = 0;
   virtual void set_bucket_min(uint32_t terms) = 0;
   virtual void set_toom_cook(bool on) = 0;
+  virtual int set_plan_params(int plan, uint32_t fch, uint32_t vch, uint32_t grp, uint32_t nch, uint32_t vsp) = 0;
+  virtual void set_plan_thresholds(size_t tiny, size_t latency, size_t medium, size_t wide) = 0;
   // keys: nullptr = the table's own aggregate key; otherwise one wire point per proof (device memory).
   // ks / kidx: proof b is made under key kidx[b] (device array) of the key set instead (keys is ignored)
   virtual void prove_dev(size_t B, const uint8_t* decks, const uint8_t* rho, const uint32_t* perm, const uint8_t* seeds,

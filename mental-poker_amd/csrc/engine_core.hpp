@@ -21,6 +21,10 @@ struct PhaseDev {
   DevBuf<BJob> bjobs;
   DevBuf<Term> bterms;
   DevBuf<BTermPos> bpos;
+  DevBuf<Job> wcjobs;       // window-split Straus jobs (layout.hpp Phase::vsplit): range sums over an MSM's sub-jobs,
+  DevBuf<Term> wcterms;
+  DevBuf<BJob> wjobs;       // and the fold of an MSM's range sums
+  uint32_t vsplit = 1, n_wc = 0, n_w = 0;
   uint32_t n_b = 0, n_bterms = 0, b_dig_bytes = 0, b_kpad_max = 0;
   uint32_t n_recode = 0, n_tables = 0, n_f = 0, n_v = 0, n_c = 0, n_c2 = 0, n_c0 = 0, n_tslots = 0, n_dslots = 0;
   std::vector<std::pair<uint32_t, uint32_t>> normalize;
@@ -39,6 +43,12 @@ struct PhaseDev {
     cterms0.upload(ph.cterms0, s);
     cjobs0.upload(ph.cjobs0, s);
     n_c0 = (uint32_t)ph.cjobs0.size();
+    wcjobs.upload(ph.wcjobs, s);
+    wcterms.upload(ph.wcterms, s);
+    wjobs.upload(ph.wjobs, s);
+    vsplit = ph.vsplit;
+    n_wc = (uint32_t)ph.wcjobs.size();
+    n_w = (uint32_t)ph.wjobs.size();
     bjobs.upload(ph.bjobs, s);
     bterms.upload(ph.bterms, s);
     bpos.upload(ph.bpos, s);
@@ -125,6 +135,39 @@ struct Table : mp_table {
   // [4] wide (32 / 4 / 16), [3] single proofs and tiny batches (1 / 1 / 2 on decks of up to 128 cards, else 2 / 1 / 4).  Measured on
   // an MI355X, 52 cards: [3] wins up to ~640 proofs in flight, latency up to ~4 k, medium up to ~12 k, wide up to ~48 k, throughput beyond.
   static const int N_PLANS = 5;
+  // sub-job sizes of the five splits: fixed-base terms / variable-base terms per lane, bases per table lane, points per inversion,
+  // lanes per variable-base sub-job (window split, layout.hpp vsplit_lo); mp_set_plan_params changes them (results do not)
+  struct PlanParams {
+    uint32_t fch, vch, grp, nch, vsp;
+  };
+  PlanParams pprm[N_PLANS];
+  void default_plan_params() {
+    // ([3] on decks of up to 128 cards: one variable-base term per lane and two bases per table lane -- the partial sums go through
+    // the two-level combine; measured on one MI355X: one 52-card proof 6.6 -> 6.1 ms against 2 terms / 4 bases, same or better up
+    // to 256 proofs.  A single 300-card proof already brings more lanes than the chip holds: there the finer split only adds work,
+    // BLS12-377 (30,10) 90 -> 117 ms.)
+    const uint32_t tiny_v = N <= 128 ? 1u : 2u, tiny_g = N <= 128 ? 2u : 4u;
+    pprm[0] = PlanParams{FCHUNK, VCHUNK, TABLE_GROUP, NORM_CHUNK, 1};
+    pprm[1] = PlanParams{2, 4, 8, 8, 1};
+    pprm[2] = PlanParams{4, 16, 16, 32, 1};
+    pprm[3] = PlanParams{1, tiny_v, tiny_g, 4, 1};
+    pprm[4] = PlanParams{4, 32, 16, 32, 1};
+  }
+  int set_plan_params(int plan, uint32_t fch, uint32_t vch, uint32_t grp, uint32_t nch, uint32_t vsp) override {
+    if (plan < 0 || plan >= N_PLANS || !fch || !vch || !grp || grp > TABLE_GROUP || !nch || !vsp || vsp > VSPLIT_MAX) return MP_ERR_BAD_ARGUMENT;
+    pprm[plan] = PlanParams{fch, vch, grp, nch, vsp};
+    flush();
+    rt::stream_sync(ctx->stream);
+    build_plans(ps, false);
+    psk_ready = false;
+    chain.L = 0;
+    rt::stream_sync(ctx->stream);
+    return MP_OK;
+  }
+  void set_plan_thresholds(size_t tiny, size_t latency, size_t medium, size_t wide) override {
+    auto cap = [](size_t v) { return (uint32_t)std::min<size_t>(v, 0x40000000u); };
+    tiny_batch = cap(tiny); latency_batch = cap(latency); medium_batch = cap(medium); wide_batch = cap(wide);
+  }
   PlanSet ps[N_PLANS];        // plans with the table's own aggregate key as a fixed base
   PlanSet psk[N_PLANS];       // plans for keyed batches (per-proof aggregate key): built on first use
   bool psk_ready = false;
@@ -152,6 +195,7 @@ struct Table : mp_table {
   void set_toom_cook(bool on) override {
     if (on == toom_cook) return;
     toom_cook = on;
+    flush();
     rt::stream_sync(ctx->stream);
     build_plans(ps, false);
     psk_ready = false;
@@ -226,6 +270,7 @@ struct Table : mp_table {
   void set_bucket_min(uint32_t terms) override {
     if (terms == bucket_min) return;
     bucket_min = terms;
+    flush();
     rt::stream_sync(ctx->stream);
     build_plans(ps, false);          // the split between Straus sub-jobs and bucket jobs is part of the static plans
     psk_ready = false;
@@ -264,15 +309,9 @@ struct Table : mp_table {
 
   void build_plans(PlanSet* set, bool keyed) {
     rt::Stream s = ctx->stream;
-    // ([3] on decks of up to 128 cards: one variable-base term per lane and two bases per table lane -- the partial sums go through
-    // the two-level combine; measured on one MI355X: one 52-card proof 6.6 -> 6.1 ms against 2 terms / 4 bases, same or better up
-    // to 256 proofs.  A single 300-card proof already brings more lanes than the chip holds: there the finer split only adds work,
-    // BLS12-377 (30,10) 90 -> 117 ms.)
-    const uint32_t tiny_v = N <= 128 ? 1u : 2u, tiny_g = N <= 128 ? 2u : 4u;
-    const uint32_t fch[N_PLANS] = {FCHUNK, 2, 4, 1, 4}, vch[N_PLANS] = {VCHUNK, 4, 16, tiny_v, 32}, grp[N_PLANS] = {TABLE_GROUP, 8, 16, tiny_g, 16},
-                   nch[N_PLANS] = {NORM_CHUNK, 8, 32, 4, 32};
     for (int k = 0; k < N_PLANS; ++k) {
       PlanSet& q = set[k];
+      const PlanParams& pp = pprm[k];
       // the finest split serves batches too small to fill the chip with one lane per Straus job: there the bucket kernel
       // (windows x 64 lanes per MSM) already pays from 128 terms on -- the merged verifier equation of a 52-card proof has 239
       // (one proof: verify 4.4 -> 3.6 ms, profiles/r02_latency.txt).  The latency split had it too until the end of round 3: from ~1 000
@@ -280,10 +319,10 @@ struct Table : mp_table {
       const uint32_t bmin = (bucket_min && k == 3) ? std::min(bucket_min, BUCKET_MIN_SMALL_BATCH) : bucket_min;
       // Toom-Cook adds two dependent stages (operand evaluation, interpolation): a win when the batch fills the chip (throughput and
       // medium plans), a loss for a handful of proofs, where the small-batch plans keep Karatsuba (BLS12-377 (6,50), one proof: 78 vs 94 ms)
-      q.pplan = make_prove_plan(m, n, fch[k], vch[k], G_::PB, keyed, bmin, bk_windows(R::BITS), toom_cook && (k == 0 || k == 2 || k == 4));
-      q.vplan = make_verify_plan(m, n, fch[k], vch[k], G_::PB, keyed, bmin, bk_windows(R::BITS));
-      q.table_group = grp[k];
-      q.norm_chunk = nch[k];       // fewer points per serial inversion chain when lanes are idle
+      q.pplan = make_prove_plan(m, n, pp.fch, pp.vch, G_::PB, keyed, bmin, bk_windows(R::BITS), toom_cook && (k == 0 || k == 2 || k == 4), pp.vsp);
+      q.vplan = make_verify_plan(m, n, pp.fch, pp.vch, G_::PB, keyed, bmin, bk_windows(R::BITS), pp.vsp);
+      q.table_group = pp.grp;
+      q.norm_chunk = pp.nch;       // fewer points per serial inversion chain when lanes are idle
       for (int i = 0; i < 6; ++i) q.pph[i].upload(q.pplan.ph[i], s);
       q.vph.upload(q.vplan.ph, s);
       q.vmph.upload(q.vplan.mph, s);
@@ -329,6 +368,7 @@ struct Table : mp_table {
     // plan thresholds count lanes, and a proof of N cards brings ~N/52 times the lanes of a 52-card proof
     set_latency_batch(std::max<size_t>(64, (size_t)3840 * 52 / N));
     nwin = (uint32_t)vb_windows(R::BITS);
+    default_plan_params();
     FixedBases fb{n};
     std::vector<Aff<C>> bases(fb.count());
     bool ok = true;
@@ -462,8 +502,9 @@ struct Table : mp_table {
     rt::stream_sync(s);
     return MP_OK;
   }
-  DevBuf<uint32_t> ks_keys;      // the wire keys of a batch, gathered from a key set
-  const uint8_t* gather_keys(uint32_t B, const mp_keyset* ks, const uint32_t* kidx, int32_t* status) {
+  DevBuf<uint32_t> ks_keys_main, ks_keys_vlane;      // the wire keys of a batch, gathered from a key set (one buffer per lane)
+  const uint8_t* gather_keys(uint32_t B, const mp_keyset* ks, const uint32_t* kidx, int32_t* status, bool vlane = false) {
+    DevBuf<uint32_t>& ks_keys = vlane ? ks_keys_vlane : ks_keys_main;
     ks_keys.alloc((size_t)B * (G_::PB / 4), ctx->stream, false);
     GatherKeysArgs ga{ks->wire.p, kidx, ks_keys.p, status, (uint32_t)ks->K};
     MP_RUN(k_gather_keys, C, B, G_::PB / 4, ga);
@@ -478,7 +519,8 @@ struct Table : mp_table {
   }
 
   void reserve(size_t B) override { reserve_for(B, false); }
-  void reserve_for(size_t B, bool keyed) {
+  void reserve_for(size_t B, bool keyed) { reserve_ws(ws, B, keyed); }
+  void reserve_ws(Workspace& ws, size_t B, bool keyed) {
     if (keyed) ensure_keyed();
     PlanSet& q = pick((uint32_t)B, keyed);
     uint32_t nS = std::max(q.pplan.lay.nS, q.vplan.lay.nS), nP = std::max(q.pplan.lay.nP, q.vplan.lay.nP);
@@ -517,11 +559,18 @@ struct Table : mp_table {
 #else
   uint32_t quad_max_lanes = 65536;       // (per launch; 262 144 was tried: the many short chains of a 4 096-proof batch -- combines, fixed-base sums -- then go four lanes wide too: 239 k -> 161 k/s)
 #endif
-  bool quad_ops(uint32_t B, uint32_t njobs) const { return group_lanes == 4 || (group_lanes == 0 && (uint64_t)B * njobs * 4u <= quad_max_lanes); }
+  // (the quad kernels index their items -- (proof, job) pairs -- with 32 bits: a forced mp_set_group_lanes(t, 4) on a launch with more
+  // items than that falls back to one lane per chain)
+  bool quad_ops(uint32_t B, uint32_t njobs) const {
+    const uint64_t items = (uint64_t)B * njobs;
+    if (items > 0xFFFFFFF0ull) return false;
+    return group_lanes == 4 || (group_lanes == 0 && items * 4u <= quad_max_lanes);
+  }
+  static uint32_t quad_waves(uint32_t B, uint32_t njobs) { return (uint32_t)(((uint64_t)B * njobs + 15u) / 16u); }
   void run_combine(const CombineArgs& a, uint32_t B, uint32_t njobs) {
     if (quad_ops(B, njobs)) {
       CombineQuadArgs qa{a, B, njobs};
-      MP_WAVE_RUN(k_combine_q, C, (B * njobs + 15u) / 16u, 0, qa);
+      MP_WAVE_RUN(k_combine_q, C, quad_waves(B, njobs), 0, qa);
     } else {
       MP_RUN(k_combine, C, B, njobs, a);
     }
@@ -543,25 +592,43 @@ struct Table : mp_table {
       FixedArgs a{w.S.p, w.J.p, FB.p, ph.fjobs.p, ph.fterms.p, w.Bpad, fbg, w.Bpad};
       if (quad_ops(B, ph.n_f)) {
         FixedQuadArgs qa{a, B, ph.n_f};
-        MP_WAVE_RUN(k_fixed_msm_q, C, (B * ph.n_f + 15u) / 16u, 0, qa);
+        MP_WAVE_RUN(k_fixed_msm_q, C, quad_waves(B, ph.n_f), 0, qa);
       } else {
         MP_RUN(k_fixed_msm, C, B, ph.n_f, a);
       }
     }
     if (ph.n_v) {
-      VarArgs a{w.D.p, w.T.p, w.J.p, ph.vjobs.p, ph.vterms.p, w.Bpad, nwin};
+      VarArgs a{w.D.p, w.T.p, w.J.p, ph.vjobs.p, ph.vterms.p, w.Bpad, nwin, ph.vsplit};
+      const uint32_t nvl = ph.n_v * ph.vsplit;      // lanes per proof: (job, window range) pairs
 #ifdef MP_EXP_VAR_LDS      // experiment hook (tools/ab_build.py): unused dynamic LDS per workgroup caps the waves per SIMD of k_var_msm
       ctx->prof.begin("k_var_msm", ctx->stream);
-      hipLaunchKernelGGL((k_var_msm<C>), dim3((B + 255u) / 256u, ph.n_v), dim3(256), MP_EXP_VAR_LDS, ctx->stream, a, (uint32_t)B);
+      hipLaunchKernelGGL((k_var_msm<C>), dim3((B + 255u) / 256u, nvl), dim3(256), MP_EXP_VAR_LDS, ctx->stream, a, (uint32_t)B);
       ctx->prof.end(ctx->stream);
 #else
-      if (quad_ops(B, ph.n_v)) {      // a handful of proofs: four lanes per group operation, 3-4 products deep instead of 10
-        VarQuadArgs qa{a, B, ph.n_v};
-        MP_WAVE_RUN(k_var_msm_q, C, (B * ph.n_v + 15u) / 16u, 0, qa);
+      if (quad_ops(B, nvl)) {      // a handful of proofs: four lanes per group operation, 3-4 products deep instead of 10
+        VarQuadArgs qa{a, B, nvl};
+        MP_WAVE_RUN(k_var_msm_q, C, quad_waves(B, nvl), 0, qa);
       } else {
-        MP_RUN(k_var_msm, C, B, ph.n_v, a);
+        MP_RUN(k_var_msm, C, B, nvl, a);
       }
 #endif
+      if (ph.n_wc) {      // window-split jobs: the range sums of an MSM's sub-jobs, range by range ...
+        CombineArgs ca{w.J.p, w.P.p, ph.wcjobs.p, ph.wcterms.p, w.Bpad};
+        run_combine(ca, B, ph.n_wc);
+      }
+      if (ph.n_w) {       // ... and the fold R = sum_r 2^(5 lo(r)) S_r, once per MSM
+        BFoldArgs fa{w.J.p, ph.wjobs.p, w.Bpad, 0u, nwin};
+        if (quad_ops(B, ph.n_w)) {
+          BFoldQuadArgs qa{fa, B, ph.n_w};
+          ctx->prof.begin("k_wfold_q", ctx->stream);
+          MP_WAVE_LAUNCH(k_bucket_fold_q, C, ctx->stream, quad_waves(B, ph.n_w), 0, qa);
+          ctx->prof.end(ctx->stream);
+        } else {
+          ctx->prof.begin("k_wfold", ctx->stream);
+          MP_LAUNCH(k_bucket_fold, C, ctx->stream, B, ph.n_w, fa);
+          ctx->prof.end(ctx->stream);
+        }
+      }
     }
     if (ph.n_b) {   // large MSMs: bucket method, one wave per (proof, MSM, window)
       const uint32_t bw = bk_windows(R::BITS);
@@ -575,7 +642,7 @@ struct Table : mp_table {
       BFoldArgs fa{w.J.p, ph.bjobs.p, w.Bpad, bw};
       if (quad_ops(B, ph.n_b)) {
         BFoldQuadArgs qa{fa, B, ph.n_b};
-        MP_WAVE_RUN(k_bucket_fold_q, C, (B * ph.n_b + 15u) / 16u, 0, qa);
+        MP_WAVE_RUN(k_bucket_fold_q, C, quad_waves(B, ph.n_b), 0, qa);
       } else {
         MP_RUN(k_bucket_fold, C, B, ph.n_b, fa);
       }
@@ -701,6 +768,20 @@ struct Table : mp_table {
 #else
   uint32_t overlap_max = OVERLAP_MAX_BATCH;
 #endif
+  // work forked onto ctx->side: until the main stream has been made to wait for it (joined = true), an exception on the way out
+  // must not leave kernels of this batch running on the shared arenas behind the caller's back
+  struct SideGuard {
+    mp_ctx* c;
+    bool joined = false;
+    ~SideGuard() {
+      if (!joined) {
+        try {
+          rt::stream_sync(c->side);
+        } catch (...) {
+        }
+      }
+    }
+  };
   void prove_side_work(PlanSet& q, Workspace& w, uint32_t B, bool with_tables) {
     const ProveLay& l = q.pplan.lay;
     run_phase(q.pph[4], w, B);      // Toom-Cook (m = 2) / Karatsuba operand sums (empty when unused)
@@ -732,6 +813,7 @@ struct Table : mp_table {
     rt::Stream s = ctx->stream;
     FixedBases fb{n};
     const bool overlap = overlap_max && B <= overlap_max;      // two streams for the stretch before the first challenge
+    SideGuard side_guard{ctx, !overlap};
     rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
     {
       uint32_t* const ww = wire_words(w, B, 1);
@@ -818,6 +900,7 @@ struct Table : mp_table {
     }
     if (overlap) {
       rt::stream_wait(s, ctx->ev_tab);
+      side_guard.joined = true;
       run_phase(pph[1], w, B, PH_ALL & ~PH_TABLES);
     } else {
       run_phase(pph[1], w, B);
@@ -873,71 +956,164 @@ struct Table : mp_table {
   // ends here.  (2) Only if some proof failed the screen: the equations one by one, to report the FIRST failing check by
   // name as the reference does [REF tests.rs:223-225].  A proof that passes (1) satisfies every equation except with
   // probability ~2^-250 over weights that depend on the whole proof.
-  void verify_dev(size_t B_, const uint8_t* decks, const uint8_t* shuf, const uint8_t* proofs, int32_t* status,
-                  const uint8_t* keys, const mp_keyset* kset, const uint32_t* kidx) override {
-    const uint32_t B = (uint32_t)B_;
-    const bool keyed = keys != nullptr || kset != nullptr;
-    reserve_for(B, keyed);
-    Workspace& w = ws;
+  struct VArgs {
+    uint32_t B;
+    const uint8_t *decks, *shuf, *proofs;
+    int32_t* status;
+    const uint8_t* keys;
+    const mp_keyset* kset;
+    const uint32_t* kidx;
+  };
+  DevBuf<uint32_t> vflag_vlane;      // the screening flag of the pipelined lane
+  uint32_t* h_vflag = nullptr;       // ... read back into page-locked memory without waiting,
+  rt::Event ev_vflag = nullptr;      // ... valid once this event has passed
+  struct Pending {
+    bool valid = false;
+    VArgs v{};
+  } pend;                            // a pipelined verify call whose screening verdict has not been looked at yet
+  Workspace vws;                     // the verify lane's arenas (pipelined mode: a prove call uses `ws` at the same time)
+  ~Table() {
+    if (ev_vflag) rt::event_destroy(ev_vflag);
+    rt::host_free(h_vflag);
+  }
+  // one pass over a batch on the context's CURRENT lane: merged = the screening equation, else equation by equation
+  void verify_pass(Workspace& w, const VArgs& v, bool merged, bool vlane) {
+    const uint32_t B = v.B;
+    const bool keyed = v.keys != nullptr || v.kset != nullptr;
+    const uint8_t* keys = v.keys;
     PlanSet& q = pick(B, keyed);
     cur_table_group = q.table_group;
     cur_norm_chunk = q.norm_chunk;
     const VerifyLay& l = q.vplan.lay;
     rt::Stream s = ctx->stream;
-    // small batches (the two finest splits) go straight to the per-equation pass: with an idle chip the merged MSM is one long
-    // dependency chain and its flag read-back a round trip -- it pays from the medium plan on (+3 % there, measured)
+    rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
+    {
+      uint32_t* const ww = wire_words(w, B, 2);
+      LoadPointsArgs a{v.decks, w.P.p, w.status.p, w.Bpad, 2 * N, l.deck, ww, 0};
+      MP_RUN(k_load_points, C, B, 2 * N, a);
+      LoadPointsArgs b{v.shuf, w.P.p, w.status.p, w.Bpad, 2 * N, l.shuf, ww, 2 * N};
+      MP_RUN(k_load_points, C, B, 2 * N, b);
+      ProofIoArgs pa{const_cast<uint8_t*>(v.proofs), w.S.p, w.P.p, w.status.p, q.vwire.p, w.Bpad, (uint32_t)proof_size_bytes(m, n, G_::PB)};
+      MP_RUN(k_load_proof, C, B, (uint32_t)q.vplan.wire.size(), pa);
+      if (v.kset) keys = gather_keys(B, v.kset, v.kidx, w.status.p, vlane);
+      if (keyed) {
+        LoadPointsArgs ka{keys, w.P.p, w.status.p, w.Bpad, 1, l.pk};
+        MP_RUN(k_load_points, C, B, 1, ka);
+      }
+      // decks and proof points are the P slots [0, pk); the key follows
+      check_subgroup(w, B, 0, l.pk + (keyed ? 1u : 0u));
+    }
+    // The window tables of the verifier's bases need the loaded points and nothing else: batches that do not fill the chip build
+    // them on `side` while the main stream hashes the transcript and derives the scalars (the table kernel leans on HBM, the
+    // transcript lanes on latency: they do not compete)
+    PhaseDev& ph = merged ? q.vmph : q.vph;
+    const bool vtab_forked = overlap_max && B <= overlap_max && ph.n_tables != 0;
+    SideGuard vguard{ctx, !vtab_forked};
+    if (vtab_forked) {
+      struct Restore {
+        mp_ctx* c;
+        rt::Stream keep;
+        ~Restore() { c->stream = keep; }
+      } restore{ctx, s};
+      rt::event_record(ctx->ev_fork, s);
+      ctx->stream = ctx->side;
+      rt::stream_wait(ctx->side, ctx->ev_fork);
+      run_tables(ph, w, B, w.NS.p);
+      rt::event_record(ctx->ev_tab, ctx->side);
+    }
+    {
+      VerifyFsArgs a{};
+      a.st = statement_args(w, l.deck, l.shuf, l.cA, l.x, keyed ? l.pk : NO_SLOT);
+      a.st.W = wire_words(w, B, 2);
+      a.st.w_deck = 0;
+      a.st.w_shuf = 2 * N;
+      a.l = l;
+      a.merge = merged ? 1u : 0u;
+      run_verify_fs(a, B);
+      VerifyScalArgs sa{w.S.p, w.P.p, w.direct.p, l, q.vplan.cm, w.Bpad};
+      MP_RUN(k_verify_scal, C, B, n + 2, sa);
+    }
+    if (merged) {
+      VerifyMergeArgs ma{w.S.p, q.mjobs.p, q.mpairs.p, w.Bpad};
+      MP_RUN(k_verify_merge, C, B, (uint32_t)q.vplan.mjobs.size(), ma);
+    }
+    if (vtab_forked) {
+      rt::stream_wait(s, ctx->ev_tab);
+      vguard.joined = true;
+    }
+    run_phase(ph, w, B, vtab_forked ? (PH_ALL & ~PH_TABLES) : PH_ALL);
+    if (merged) {
+      DevBuf<uint32_t>& fl = vlane ? vflag_vlane : vflag;
+      if (!fl.n) fl.alloc(1, s);
+      rt::dzero(fl.p, 4, s);
+      VerdictMergedArgs a{w.J.p, w.direct.p, w.status.p, fl.p, w.Bpad, l.chk_merged};
+      MP_RUN(k_verdict_merged, C, B, 1, a);
+    } else {
+      VerdictArgs a{w.J.p, w.direct.p, w.status.p, w.Bpad, l.chk_first};
+      MP_RUN(k_verdict, C, B, 1, a);
+    }
+    rt::d2d(v.status, w.status.p, (size_t)B * 4, s);
+  }
+  // whether a batch of this size is screened with the merged equation first: small batches (the two finest splits) go straight to
+  // the per-equation pass -- with an idle chip the merged MSM is one long dependency chain and its flag read-back a round trip; it
+  // pays from the medium plan on (+3 % there, measured) -- unless the merged equation runs on the bucket kernel, which spreads ONE
+  // MSM over windows x 64 lanes
+  bool screens(uint32_t B, bool keyed) {
     const int plan = plan_of(B);
-    // (unless the merged equation runs on the bucket kernel, which spreads ONE MSM over windows x 64 lanes)
-    for (int pass = (merged_verify && (plan == 0 || plan == 2 || plan == 4 || q.vmph.n_b)) ? 0 : 1; pass < 2; ++pass) {
-      const bool merged = pass == 0;
-      rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
-      {
-        uint32_t* const ww = wire_words(w, B, 2);
-        LoadPointsArgs a{decks, w.P.p, w.status.p, w.Bpad, 2 * N, l.deck, ww, 0};
-        MP_RUN(k_load_points, C, B, 2 * N, a);
-        LoadPointsArgs b{shuf, w.P.p, w.status.p, w.Bpad, 2 * N, l.shuf, ww, 2 * N};
-        MP_RUN(k_load_points, C, B, 2 * N, b);
-        ProofIoArgs pa{const_cast<uint8_t*>(proofs), w.S.p, w.P.p, w.status.p, q.vwire.p, w.Bpad, (uint32_t)proof_size_bytes(m, n, G_::PB)};
-        MP_RUN(k_load_proof, C, B, (uint32_t)q.vplan.wire.size(), pa);
-        if (kset) keys = gather_keys(B, kset, kidx, w.status.p);
-        if (keyed) {
-          LoadPointsArgs ka{keys, w.P.p, w.status.p, w.Bpad, 1, l.pk};
-          MP_RUN(k_load_points, C, B, 1, ka);
+    return merged_verify && (plan == 0 || plan == 2 || plan == 4 || pick(B, keyed).vmph.n_b);
+  }
+  void verify_dev(size_t B_, const uint8_t* decks, const uint8_t* shuf, const uint8_t* proofs, int32_t* status,
+                  const uint8_t* keys, const mp_keyset* kset, const uint32_t* kidx) override {
+    const VArgs v{(uint32_t)B_, decks, shuf, proofs, status, keys, kset, kidx};
+    const bool keyed = keys != nullptr || kset != nullptr;
+    if (keyed) ensure_keyed();
+    if (pipeline) {
+      // Pipelined mode: the call runs on the verify lane with arenas of its own and does NOT wait for its screening verdict, so the
+      // caller's next prove call overlaps it on the chip.  The verdict of call k is looked at when call k + 1 comes in (or at
+      // mp_sync); only then -- and only if some proof failed the screen -- does the per-equation pass run.
+      resolve_pending();
+      reserve_ws(vws, v.B, keyed);
+      rt::event_record(ctx->ev_vin, ctx->stream);
+      LaneSwap lane(ctx);
+      rt::stream_wait(ctx->stream, ctx->ev_vin);
+      const bool screen = screens(v.B, keyed);
+      verify_pass(vws, v, screen, true);
+      if (screen) {
+        if (!h_vflag) {
+          h_vflag = (uint32_t*)rt::host_alloc(4);
+          ev_vflag = rt::event_create();
         }
-        // decks and proof points are the P slots [0, pk); the key follows
-        check_subgroup(w, B, 0, l.pk + (keyed ? 1u : 0u));
+        rt::d2h(h_vflag, vflag_vlane.p, 4, ctx->stream);
+        rt::event_record(ev_vflag, ctx->stream);
+        pend.valid = true;
+        pend.v = v;
       }
-      {
-        VerifyFsArgs a{};
-        a.st = statement_args(w, l.deck, l.shuf, l.cA, l.x, keyed ? l.pk : NO_SLOT);
-        a.st.W = wire_words(w, B, 2);
-        a.st.w_deck = 0;
-        a.st.w_shuf = 2 * N;
-        a.l = l;
-        a.merge = merged ? 1u : 0u;
-        run_verify_fs(a, B);
-        VerifyScalArgs sa{w.S.p, w.P.p, w.direct.p, l, q.vplan.cm, w.Bpad};
-        MP_RUN(k_verify_scal, C, B, n + 2, sa);
-      }
-      if (merged) {
-        VerifyMergeArgs ma{w.S.p, q.mjobs.p, q.mpairs.p, w.Bpad};
-        MP_RUN(k_verify_merge, C, B, (uint32_t)q.vplan.mjobs.size(), ma);
-        run_phase(q.vmph, w, B);
-        if (!vflag.n) vflag.alloc(1, s);
-        rt::dzero(vflag.p, 4, s);
-        VerdictMergedArgs a{w.J.p, w.direct.p, w.status.p, vflag.p, w.Bpad, l.chk_merged};
-        MP_RUN(k_verdict_merged, C, B, 1, a);
+      return;
+    }
+    reserve_for(v.B, keyed);
+    // Two passes.  (1) Screening; every honest batch ends here.  (2) Only if some proof failed the screen: the equations one by one
+    for (int pass = screens(v.B, keyed) ? 0 : 1; pass < 2; ++pass) {
+      verify_pass(ws, v, pass == 0, false);
+      if (pass == 0) {
         uint32_t flag = 0;
-        rt::d2h(&flag, vflag.p, 4, s);
-        rt::stream_sync(s);
+        rt::d2h(&flag, vflag.p, 4, ctx->stream);
+        rt::stream_sync(ctx->stream);
         if (!flag) break;       // nobody needs a closer look
-      } else {
-        run_phase(q.vph, w, B);
-        VerdictArgs a{w.J.p, w.direct.p, w.status.p, w.Bpad, l.chk_first};
-        MP_RUN(k_verdict, C, B, 1, a);
       }
     }
-    rt::d2d(status, w.status.p, (size_t)B * 4, s);
+  }
+  void resolve_pending() {
+    if (!pend.valid) return;
+    pend.valid = false;
+    rt::event_sync(ev_vflag);
+    if (!*h_vflag) return;
+    LaneSwap lane(ctx);
+    verify_pass(vws, pend.v, false, true);      // some proof failed the screen: name the first failing check of each
+    rt::stream_sync(ctx->stream);
+  }
+  void flush() override {
+    resolve_pending();
+    rt::stream_sync(ctx->vstream);
   }
 
 

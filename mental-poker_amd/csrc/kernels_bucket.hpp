@@ -270,19 +270,29 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t wid, W& wv) {
 MP_WAVE_KERNEL(k_bucket_msm, BucketArgs, body_bucket_msm)
 
 // ---- fold the window results: R = sum_w 2^(8w) R_w (x = proof, y = bucket job)
+// The same kernel folds the range sums of window-split Straus jobs (layout.hpp vsplit_lo; vb_nwin != 0): job.count parts, part w
+// starts at the 5-bit window vsplit_lo(w, job.count, vb_nwin), R = sum_w 2^(5 vsplit_lo(w)) R_w.
 struct BFoldArgs {
   uint32_t* J;
   const BJob* jobs;
   uint32_t Bpad, nwin;
+  uint32_t vb_nwin;      // 0: bucket windows (nwin parts, BK_BITS apart); else the Straus windows a split job's parts share
 };
+MP_HD uint32_t fold_parts(const BFoldArgs& a, const BJob& job) { return a.vb_nwin ? job.count : a.nwin; }
+// doublings between part w + 1 and part w
+MP_HD uint32_t fold_bits(const BFoldArgs& a, const BJob& job, uint32_t w) {
+  return a.vb_nwin ? (uint32_t)VB_WINDOW_BITS * (vsplit_lo(w + 1, job.count, a.vb_nwin) - vsplit_lo(w, job.count, a.vb_nwin)) : (uint32_t)BK_BITS;
+}
 template <class C>
 MP_HD void body_bucket_fold(const BFoldArgs& a, uint32_t b, uint32_t y) {
   const BJob job = a.jobs[y];
-  Jac<C> acc = ld_jac<C>(a.J + j_off<C>(job.win_first + a.nwin - 1, a.Bpad, b));
+  const uint32_t parts = fold_parts(a, job);
+  Jac<C> acc = ld_jac<C>(a.J + j_off<C>(job.win_first + parts - 1, a.Bpad, b));
 #pragma unroll 1
-  for (int w = (int)a.nwin - 2; w >= 0; --w) {
+  for (int w = (int)parts - 2; w >= 0; --w) {
+    const uint32_t nd = fold_bits(a, job, (uint32_t)w);
 #pragma unroll 1
-    for (int q = 0; q < BK_BITS; ++q) jac_dbl_ip<C>(acc);
+    for (uint32_t q = 0; q < nd; ++q) jac_dbl_ip<C>(acc);
     jac_add_ip<C>(acc, ld_jac<C>(a.J + j_off<C>(job.win_first + (uint32_t)w, a.Bpad, b)));
   }
   st_jac<C>(a.J + j_off<C>(job.out, a.Bpad, b), acc);

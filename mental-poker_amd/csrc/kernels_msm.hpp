@@ -462,14 +462,19 @@ struct VarArgs {
   const Job* jobs;
   const Term* terms;     // {digit slot, table slot}
   uint32_t Bpad, nwin;
+  uint32_t split;        // lanes per job (layout.hpp vsplit_lo): y = job * split + r, lane r runs the windows [lo(r), lo(r + 1)) and
+                         // writes J slot job.out + r; 1 = the whole chain in one lane
 };
 template <class C>
 MP_HD void body_var_msm(const VarArgs& a, uint32_t b, uint32_t y) {
-  const Job job = a.jobs[y];
+  const uint32_t jidx = a.split > 1 ? y / a.split : y, r = y - jidx * a.split;
+  const Job job = a.jobs[jidx];
+  const int w_top = a.split > 1 ? (int)vsplit_lo(r + 1, a.split, a.nwin) - 1 : (int)a.nwin - 1;
+  const int w_low = a.split > 1 ? (int)vsplit_lo(r, a.split, a.nwin) : 0;
   Xyzz<C> acc = xyzz_inf<C>();     // XYZZ accumulator: a job is ~25..60 mixed additions per 5 doublings
 #pragma unroll 1
-  for (int w = (int)a.nwin - 1; w >= 0; --w) {
-    if (w != (int)a.nwin - 1) {
+  for (int w = w_top; w >= w_low; --w) {
+    if (w != w_top) {
 #pragma unroll 1
       for (int q = 0; q < VB_WINDOW_BITS; ++q) xyzz_dbl_ip<C>(acc);
     }
@@ -484,7 +489,7 @@ MP_HD void body_var_msm(const VarArgs& a, uint32_t b, uint32_t y) {
       }
     }
   }
-  st_jac<C>(a.J + j_off<C>(job.out, a.Bpad, b), xyzz_to_jac<C>(acc));
+  st_jac<C>(a.J + j_off<C>(job.out + r, a.Bpad, b), xyzz_to_jac<C>(acc));
 }
 MP_KERNEL_OCC(k_var_msm, VarArgs, body_var_msm, Geo<C>::OCC_VAR)
 

@@ -226,25 +226,45 @@ MP_HD void body_var_msm_q(const VarQuadArgs& a, uint32_t wid, W& wv) {
     acc[l] = xyzz_inf<C>();
   });
   // (the jobs of a wave may differ in length: every quad runs the longest, idle where it has no term)
+  // (window-split jobs, a.v.split > 1: njobs counts (job, range) pairs; the quads of a wave step through their ranges together --
+  // step i is window lo(r + 1) - 1 - i of the quad's own range r, ranges differ in length by at most one window)
+  const uint32_t sp = a.v.split > 1 ? a.v.split : 1u;
+  uint32_t maxwin = 0;
   for (uint32_t k = 0; k < 16; ++k) {
     const uint32_t item = wid * 16u + k;
-    if (item < nitems) maxcount = a.v.jobs[item / a.B].count > maxcount ? a.v.jobs[item / a.B].count : maxcount;
+    if (item >= nitems) continue;
+    const uint32_t jr = item / a.B, r = jr % sp;
+    maxcount = a.v.jobs[jr / sp].count > maxcount ? a.v.jobs[jr / sp].count : maxcount;
+    const uint32_t nw = sp > 1 ? vsplit_lo(r + 1, sp, a.v.nwin) - vsplit_lo(r, sp, a.v.nwin) : a.v.nwin;
+    maxwin = nw > maxwin ? nw : maxwin;
   }
+  PerLane<uint32_t> wtop, wcnt, dblon;
+  wv.lanes([&](uint32_t l) {
+    wtop[l] = 0;
+    wcnt[l] = 0;
+    if (!live[l]) return;
+    const uint32_t jr = (wid * 16u + (l >> 2)) / a.B, r = jr % sp;
+    const uint32_t lo = sp > 1 ? vsplit_lo(r, sp, a.v.nwin) : 0u, hi = sp > 1 ? vsplit_lo(r + 1, sp, a.v.nwin) : a.v.nwin;
+    wtop[l] = hi - 1;
+    wcnt[l] = hi - lo;
+  });
 #pragma unroll 1
-  for (int w = (int)a.v.nwin - 1; w >= 0; --w) {
-    if (w != (int)a.v.nwin - 1) {
+  for (uint32_t i = 0; i < maxwin; ++i) {
+    if (i != 0) {
+      wv.lanes([&](uint32_t l) { dblon[l] = live[l] && i < wcnt[l]; });
 #pragma unroll 1
-      for (int d = 0; d < VB_WINDOW_BITS; ++d) xyzz_dbl_quad<C>(wv, acc, live);
+      for (int d = 0; d < VB_WINDOW_BITS; ++d) xyzz_dbl_quad<C>(wv, acc, dblon);
     }
 #pragma unroll 1
     for (uint32_t t = 0; t < maxcount; ++t) {
       wv.lanes([&](uint32_t l) {
         on[l] = 0;
-        if (!live[l]) return;
+        if (!live[l] || i >= wcnt[l]) return;
         const uint32_t item = wid * 16u + (l >> 2), b = item % a.B;
-        const Job job = a.v.jobs[item / a.B];
+        const Job job = a.v.jobs[(item / a.B) / sp];
         if (t >= job.count) return;
         const Term term = a.v.terms[job.begin + t];
+        const uint32_t w = wtop[l] - i;
         const int d = a.v.D[((size_t)term.s * a.v.nwin + w) * a.v.Bpad + b];
         if (d == 0) return;
         const uint32_t e = (uint32_t)(d < 0 ? -d : d) - 1;
@@ -256,8 +276,8 @@ MP_HD void body_var_msm_q(const VarQuadArgs& a, uint32_t wid, W& wv) {
   }
   wv.lanes([&](uint32_t l) {
     if (!live[l] || (l & 3u) != 0) return;
-    const uint32_t item = wid * 16u + (l >> 2), b = item % a.B;
-    st_jac<C>(a.v.J + j_off<C>(a.v.jobs[item / a.B].out, a.v.Bpad, b), xyzz_to_jac<C>(acc[l]));
+    const uint32_t item = wid * 16u + (l >> 2), b = item % a.B, jr = item / a.B;
+    st_jac<C>(a.v.J + j_off<C>(a.v.jobs[jr / sp].out + jr % sp, a.v.Bpad, b), xyzz_to_jac<C>(acc[l]));
   });
 }
 MP_WAVE_KERNEL(k_var_msm_q, VarQuadArgs, body_var_msm_q)
@@ -397,12 +417,16 @@ MP_HD void body_bucket_fold_q(const BFoldQuadArgs& a, uint32_t wid, W& wv) {
     acc[l] = xyzz_inf<C>();
     if (!live[l]) return;
     const BJob job = a.f.jobs[item / a.B];
-    acc[l] = xyzz_from_jac<C>(ld_jac<C>(a.f.J + j_off<C>(job.win_first + a.f.nwin - 1, a.f.Bpad, item % a.B)));
+    acc[l] = xyzz_from_jac<C>(ld_jac<C>(a.f.J + j_off<C>(job.win_first + fold_parts(a.f, job) - 1, a.f.Bpad, item % a.B)));
   });
+  // (the jobs of a launch have the same number of parts and the same spacing: bucket windows, or the ranges of one split factor)
+  const BJob job0 = a.f.jobs[0];
+  const uint32_t parts = fold_parts(a.f, job0);
 #pragma unroll 1
-  for (int w = (int)a.f.nwin - 2; w >= 0; --w) {
+  for (int w = (int)parts - 2; w >= 0; --w) {
+    const uint32_t nd = fold_bits(a.f, job0, (uint32_t)w);
 #pragma unroll 1
-    for (int d = 0; d < BK_BITS; ++d) xyzz_dbl_quad<C>(wv, acc, live);
+    for (uint32_t d = 0; d < nd; ++d) xyzz_dbl_quad<C>(wv, acc, live);
     wv.lanes([&](uint32_t l) {
       if (!live[l]) return;
       const uint32_t item = wid * 16u + (l >> 2);

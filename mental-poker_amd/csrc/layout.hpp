@@ -65,6 +65,13 @@ static const int VB_WINDOW_BITS = 5;     // variable-base (Straus) signed window
 static const int VB_ENTRIES = 16;
 static const uint32_t KEY_WINDOWS = 52;  // >= vb_windows(scalar bits) of every curve: window bases of a per-proof key
 static inline int vb_windows(int scalar_bits) { return (scalar_bits + 1 + VB_WINDOW_BITS - 1) / VB_WINDOW_BITS; }
+// Window-split Straus jobs (round 4).  The nwin windows of a variable-base job are dealt to k lanes: lane r runs the windows
+// [vsplit_lo(r), vsplit_lo(r + 1)) as a Straus chain of its own (5 (windows - 1) doublings instead of 5 (nwin - 1)) and a fold
+// R = sum_r 2^(5 vsplit_lo(r)) S_r -- once per MSM, after the partial sums of the MSM's sub-jobs have been added up range by
+// range -- puts the pieces together (k_bucket_fold with Straus geometry).  k times the lanes of a job for < 250 extra doublings per
+// MSM output: what a batch too small to fill the chip wants instead of ever smaller sub-jobs with a full doubling chain each.
+MP_HD uint32_t vsplit_lo(uint32_t r, uint32_t k, uint32_t nwin) { return r * nwin / k; }
+static const uint32_t VSPLIT_MAX = 16;
 
 // One phase = everything that can run between two Fiat-Shamir squeeze points.
 struct Phase {
@@ -76,6 +83,12 @@ struct Phase {
   std::vector<Term> cterms0;
   std::vector<std::pair<uint32_t, uint32_t>> normalize;  // [first slot, count) J -> P
   uint32_t n_dslots = 0, n_tslots = 0;
+  // window-split Straus jobs (vsplit > 1): job c writes its vsplit range sums to the J slots [out, out + vsplit); wcjobs add up the
+  // range sums of an MSM's sub-jobs range by range; wjobs fold the vsplit range sums of an MSM (BJob: out, win_first, count = vsplit)
+  uint32_t vsplit = 1;
+  std::vector<Job> wcjobs;
+  std::vector<Term> wcterms;
+  std::vector<BJob> wjobs;
   std::vector<BJob> bjobs;    // MSMs large enough for the bucket method
   std::vector<Term> bterms;   // {S slot, P slot}
   std::vector<BTermPos> bpos;
@@ -88,8 +101,13 @@ static const size_t COMBINE_TREE_MIN = 12;
 class PhaseBuilder {
  public:
   // bucket_min: MSMs with at least this many variable-base terms go to the bucket kernel (0 = never); bwin = its windows
-  PhaseBuilder(Phase& ph, uint32_t& next_partial, uint32_t fchunk, uint32_t vchunk, uint32_t bucket_min = 0, uint32_t bwin = 0)
-      : ph_(ph), next_partial_(next_partial), fchunk_(fchunk), vchunk_(vchunk), bucket_min_(bucket_min), bwin_(bwin) {}
+  // vsplit: lanes per variable-base (Straus) sub-job, each with a share of the windows (1 = one lane runs all of them)
+  PhaseBuilder(Phase& ph, uint32_t& next_partial, uint32_t fchunk, uint32_t vchunk, uint32_t bucket_min = 0, uint32_t bwin = 0,
+               uint32_t vsplit = 1)
+      : ph_(ph), next_partial_(next_partial), fchunk_(fchunk), vchunk_(vchunk), bucket_min_(bucket_min), bwin_(bwin),
+        vsplit_(vsplit < 1 ? 1 : (vsplit > VSPLIT_MAX ? VSPLIT_MAX : vsplit)) {
+    ph_.vsplit = vsplit_;
+  }
   void begin(uint32_t out_slot) {
     out_ = out_slot;
     f_.clear();
@@ -116,7 +134,8 @@ class PhaseBuilder {
     if ((f_.size() + fchunk_ - 1) / fchunk_ > MAXP) fchunk_ = (f_.size() + MAXP - 1) / MAXP;
     if ((v_.size() + vchunk_ - 1) / vchunk_ > MAXP) vchunk_ = (v_.size() + MAXP - 1) / MAXP;
     size_t nf = (f_.size() + fchunk_ - 1) / fchunk_, nv = bucket ? 1 : (v_.size() + vchunk_ - 1) / vchunk_;
-    size_t pieces = nf + nv + a_.size();
+    const bool wsplit = !bucket && vsplit_ > 1 && nv > 0;      // the Straus part comes back as ONE folded piece
+    size_t pieces = nf + (wsplit ? 1 : nv) + a_.size();
     if (pieces == 0) throw std::logic_error("empty msm");
     bool direct = pieces == 1 && a_.empty();
     std::vector<uint32_t> parts;
@@ -139,7 +158,29 @@ class PhaseBuilder {
       ph_.bjobs.push_back(bj);
       parts.push_back(out);
     }
-    for (size_t c = 0; !bucket && c < nv; ++c) {
+    if (wsplit) {
+      std::vector<uint32_t> first(nv);
+      for (size_t c = 0; c < nv; ++c) {
+        first[c] = next_partial_;
+        next_partial_ += vsplit_;
+        size_t b = c * vchunk_, e = std::min(v_.size(), b + vchunk_);
+        ph_.vjobs.push_back(Job{first[c], (uint32_t)ph_.vterms.size(), (uint32_t)(e - b)});
+        ph_.vterms.insert(ph_.vterms.end(), v_.begin() + b, v_.begin() + e);
+      }
+      uint32_t sums = first[0];
+      if (nv > 1) {
+        sums = next_partial_;
+        next_partial_ += vsplit_;
+        for (uint32_t r = 0; r < vsplit_; ++r) {
+          ph_.wcjobs.push_back(Job{sums + r, (uint32_t)ph_.wcterms.size(), (uint32_t)nv});
+          for (size_t c = 0; c < nv; ++c) ph_.wcterms.push_back(Term{first[c] + r, 0});
+        }
+      }
+      const uint32_t out = direct ? out_ : next_partial_++;
+      ph_.wjobs.push_back(BJob{out, sums, 0, vsplit_, 0, 0});
+      parts.push_back(out);
+    }
+    for (size_t c = 0; !bucket && !wsplit && c < nv; ++c) {
       uint32_t out = direct ? out_ : next_partial_++;
       size_t b = c * vchunk_, e = std::min(v_.size(), b + vchunk_);
       ph_.vjobs.push_back(Job{out, (uint32_t)ph_.vterms.size(), (uint32_t)(e - b)});
@@ -193,7 +234,7 @@ class PhaseBuilder {
   }
   Phase& ph_;
   uint32_t& next_partial_;
-  uint32_t fchunk_, vchunk_, bucket_min_, bwin_;
+  uint32_t fchunk_, vchunk_, bucket_min_, bwin_, vsplit_;
   uint32_t out_ = 0;
   std::vector<Term> f_, v_;
   std::vector<uint32_t> a_;
@@ -454,7 +495,8 @@ static inline std::vector<KLeaf> k_merge(const std::vector<KLeaf>& in) {
 // keyed: the aggregate key is a per-proof point (P slot lay.pk) instead of the table's fixed base: its terms become
 // variable-base terms (the re-encryption uses the key's own window tables, kernels_msm.hpp body_remask)
 static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk, uint32_t point_bytes = 64,
-                                        bool keyed = false, uint32_t bucket_min = 0, uint32_t bwin = 0, bool toom_cook = true) {
+                                        bool keyed = false, uint32_t bucket_min = 0, uint32_t bwin = 0, bool toom_cook = true,
+                                        uint32_t vsplit = 1) {
   ProvePlan pl;
   pl.lay = make_prove_lay(m, n);
   pl.lay.toom = m == 2 ? 1u : 0u;
@@ -527,13 +569,13 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
     B.end();
   };
   {  // phase A: c_A (the re-encryption itself is the dedicated remask kernel)
-    PhaseBuilder B(pl.ph[0], next_partial, fchunk, vchunk, bucket_min, bwin);
+    PhaseBuilder B(pl.ph[0], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit);
     for (uint32_t k = 0; k < m; ++k) commit(B, l.cA + k, l.a + k * n, n, l.r + k);
     B.normalize(l.shuf, 2 * l.N);
     B.normalize(l.cA, m);
   }
   if (pl.lay.toom) {  // phase A2 (m = 2): D+ = C'_1 + C'_2, D- = C'_2 - C'_1 (affine + affine, then normalised)
-    PhaseBuilder B(pl.ph[4], next_partial, fchunk, vchunk, bucket_min, bwin);
+    PhaseBuilder B(pl.ph[4], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit);
     for (uint32_t t = 0; t < n; ++t)
       for (uint32_t c = 0; c < 2; ++c) {
         B.begin(l.tDp + 2 * t + c);
@@ -548,7 +590,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
     B.normalize(l.tDp, 4 * n);
   }
   if (karatsuba && l.nP > kP0) {  // phase A2 (m >= 3): sums of ciphertext rows used as Karatsuba operands
-    PhaseBuilder B(pl.ph[4], next_partial, fchunk, vchunk, bucket_min, bwin);
+    PhaseBuilder B(pl.ph[4], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit);
     for (auto& kv : cvec) {
       if (kv.first.size() == 1) continue;
       for (uint32_t t = 0; t < n; ++t)
@@ -561,7 +603,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
     B.normalize(kP0, l.nP - kP0);
   }
   {  // phase B: c_B, multi-exponentiation first message
-    PhaseBuilder B(pl.ph[1], next_partial, fchunk, vchunk, bucket_min, bwin);
+    PhaseBuilder B(pl.ph[1], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit);
     for (uint32_t k = 0; k < m; ++k) commit(B, l.cB + k, l.b + k * n, n, l.s + k);
     commit(B, l.mecA0, l.mea0, n, l.mer0);
     for (uint32_t k = 0; k < 2 * m; ++k) commit(B, l.mecB + k, l.meb + k, 1, l.mes + k);
@@ -663,7 +705,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
   }
   if (toomk) {  // phase B2: E_k = E(b_k gen; tau_k) + sum_e W[k][e] P_e  (E_0 = P_0 and E_{2m-1} = P_inf exactly)
     const ToomPlan& T = pl.toom;
-    PhaseBuilder B(pl.ph[5], next_partial, fchunk, vchunk, bucket_min, bwin);
+    PhaseBuilder B(pl.ph[5], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit);
     for (uint32_t k = 0; k < 2 * m; ++k)
       for (uint32_t c = 0; c < 2; ++c) {
         B.begin(l.meE + 2 * k + c);
@@ -685,7 +727,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
     B.normalize(l.meE, 4 * m);
   }
   {  // phase C: product-argument first messages that do not depend on later challenges
-    PhaseBuilder B(pl.ph[2], next_partial, fchunk, vchunk, bucket_min, bwin);
+    PhaseBuilder B(pl.ph[2], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit);
     commit(B, l.cb, l.bp + (m - 1) * n, n, l.sb);
     commit(B, l.hB + 0, l.dz, n, l.t);                       // = c_A[0] of the product statement (c_D0 + c_{-z})
     for (uint32_t i = 1; i + 1 < m; ++i) commit(B, l.hB + i, l.bp + i * n, n, l.hs + i);
@@ -697,7 +739,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
     B.normalize(l.svcd, 3);
   }
   {  // phase D: zero-argument first message
-    PhaseBuilder B(pl.ph[3], next_partial, fchunk, vchunk, bucket_min, bwin);
+    PhaseBuilder B(pl.ph[3], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit);
     commit(B, l.zcA0, l.za0, n, l.zr0);
     commit(B, l.zcBm, l.zbm, n, l.zsm);
     for (uint32_t k = 0; k < 2 * m + 1; ++k) commit(B, l.zcD + k, l.zd + k, 1, l.zt + k);
@@ -936,7 +978,7 @@ struct MergeSink {
 };
 
 static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk, uint32_t point_bytes = 64,
-                                          bool keyed = false, uint32_t bucket_min = 0, uint32_t bwin = 0) {
+                                          bool keyed = false, uint32_t bucket_min = 0, uint32_t bwin = 0, uint32_t vsplit = 1) {
   VerifyPlan pl;
   pl.lay = make_verify_lay(m, n);
   const VerifyLay& l = pl.lay;
@@ -944,7 +986,7 @@ static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchun
   const VCoefMap& c = pl.cm;
   {
     uint32_t next_partial = l.chk_first + l.n_chk;
-    PhaseBuilder B(pl.ph, next_partial, fchunk, vchunk, bucket_min, bwin);
+    PhaseBuilder B(pl.ph, next_partial, fchunk, vchunk, bucket_min, bwin, vsplit);
     PerCheckSink sink{B, l.chk_first};
     describe_verify(l, c, sink, keyed);
     pl.nJ = next_partial;
@@ -956,7 +998,7 @@ static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchun
     MergeSink ms{l.mr};
     describe_verify(l, c, ms, keyed);
     uint32_t next_partial = l.chk_first + l.n_chk;
-    PhaseBuilder B(pl.mph, next_partial, fchunk, vchunk, bucket_min, bwin);
+    PhaseBuilder B(pl.mph, next_partial, fchunk, vchunk, bucket_min, bwin, vsplit);
     B.begin(l.chk_merged);
     auto job = [&](uint32_t dst, const std::vector<MergePair>& v) {
       pl.mjobs.push_back(MergeJob{dst, (uint32_t)pl.mpairs.size(), (uint32_t)v.size()});
