@@ -41,6 +41,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "py")):
     if p not in sys.path:
         sys.path.insert(0, p)
+# before the HIP runtime starts: enough hardware queues for the engine's two lanes of streams (include/mpshuffle.h: mp_set_pipeline)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 # VALU issue model of gfx950 (measured: tools/microbench/roof.hip -> profiles/r03_roof.json): 256 CUs x 4 SIMDs; a wave64 instruction
@@ -107,6 +109,42 @@ def gather_objects(obj):
         dist.all_gather_object(out, obj)
         return out
     return [obj]
+
+
+def rccl_smoke(dist, device):
+    """tools/rccl_smoke.py: the collectives this bench needs, run once before anything expensive is built; exits non-zero naming the
+    failing call"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rccl_smoke", os.path.join(ROOT, "tools", "rccl_smoke.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    try:
+        return mod.run_checks(dist, device)
+    except mod.CollectiveCheckFailed as e:
+        print("bench.py: rank %s: collective check failed before any table was built: %s" % (os.environ.get("RANK", "?"), e),
+              file=sys.stderr, flush=True)
+        os._exit(3)
+
+
+def pin_to_gpu_numa_node(local):
+    """the cpu_baseline leg on the cores next to this rank's GPU: PCI address -> NUMA node -> cpulist (best effort; returns a note)"""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(local)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return {"gpu_pci": bdf, "numa_node": None}
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = os.sched_getaffinity(0) & cpus
+        if allowed:
+            os.sched_setaffinity(0, allowed)
+        return {"gpu_pci": bdf, "numa_node": node, "cpus_pinned": len(allowed) if allowed else 0}
+    except Exception as e:           # no sysfs entry, no affinity call: report and carry on unpinned
+        return {"numa_node": None, "note": "%s: %s" % (type(e).__name__, e)}
 
 
 def shard_range(total, rank, world):
@@ -209,7 +247,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the two extra one-step measurements (keyed batch, per-equation verification) reported in config")
     ap.add_argument("--latency-batch", type=int, default=None,
-                    help="batches up to this size use the latency plan (engine default 8192): mp_set_latency_batch")
+                    help="batches up to this size use the latency plan (engine default 1536 x 52 / N): mp_set_latency_batch")
     ap.add_argument("--keyed", type=int, default=0, metavar="K",
                     help="keyed batches: K distinct aggregate keys (card tables) spread over the batch, one key per proof "
                          "(mp_*_batch_keys_dev); 0 = every proof under the table's own key")
@@ -219,7 +257,7 @@ def main():
                     help="lanes per Fiat-Shamir transcript hash (mp_set_transcript_lanes; default: by batch size)")
     ap.add_argument("--group-lanes", type=int, default=None, choices=[0, 1, 4],
                     help="lanes per group operation of the MSM chains (mp_set_group_lanes; default: by batch size)")
-    ap.add_argument("--work-split", type=int, default=None, choices=[-1, 0, 1, 2, 3, 4],
+    ap.add_argument("--work-split", type=int, default=None, choices=[-1, 0, 1, 2, 3, 4, 5],
                     help="force one of the table's work splits (mp_set_work_split; default: by batch size)")
     ap.add_argument("--per-equation", action="store_true", help="verify equation by equation (mp_set_merged_verify off)")
     ap.add_argument("--players", type=int, default=32, help="chain32: shuffles per table")
@@ -230,6 +268,11 @@ def main():
     ap.add_argument("--per-link-verify", action="store_true",
                     help="chain32: verify every link on its own (mp_verify_shuffle_batch_keys_dev) instead of one chain equation per table "
                          "(mp_verify_shuffle_chain_dev)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = --batch proofs per GPU per step (default); strong = --batch proofs per step in total, 1/N per GPU")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="pairs: mp_set_pipeline depth for the timed region (verify calls on the engine's second lane; 0 = off, the default; "
+                         "the extra `batch_curve` always reports both)")
     ap.add_argument("--digest", action="store_true",
                     help="test hook: sha256 of every rank's outputs of the last step in config.digests (inputs are seeded per "
                          "block of --seed-block proofs, so a sharded run and an unsharded run of the same blocks must agree)")
@@ -261,6 +304,7 @@ def main():
             dist.init_process_group(backend)
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    smoke_log = rccl_smoke(dist, dev) if world > 1 else None      # fails fast, before any table is built
 
     mp = importlib.import_module("mental-poker_amd")
     workload = args.workload
@@ -268,6 +312,13 @@ def main():
     m, n = args.m, args.n
     N = m * n
     B = args.batch if args.batch is not None else (49152 if workload == "chain32" else 262144)
+    if args.scaling == "strong":
+        # the batch is the WHOLE job's: every rank takes its contiguous 1/N of the proof indices (inputs are seeded per block of the
+        # global batch, so the bytes are those of the unsharded run)
+        assert B % world == 0, "--scaling strong: --batch must be a multiple of the number of ranks"
+        if args.seed_block is None:
+            args.seed_block = B // world
+        B //= world
     if args.fb_bits is None:
         # widest fixed-base windows whose tables ((n + 5) bases x windows x (2^bits - 1) entries) stay below 30 % of this GPU's HBM:
         # 21 bits (48 GB) at n = 26 on the STARK curve, 20 bits elsewhere, 16 bits for the 1024-card shapes (n >= 64)
@@ -403,12 +454,17 @@ def main():
             for k, (cnt, _) in e.profile_report().items():
                 priming_launches[k] = priming_launches.get(k, 0) + cnt
             e.profile_enable(False)
-        out_decks = torch.empty(B, N * CB, dtype=torch.uint8, device=gpu)
-        out_proofs = torch.empty(B, proof_bytes, dtype=torch.uint8, device=gpu)
+        # (--pipeline D: a verify call's inputs stay untouched until D further verify calls have returned -> D + 1 sets of prover outputs)
+        out_sets = [(torch.empty(B, N * CB, dtype=torch.uint8, device=gpu), torch.empty(B, proof_bytes, dtype=torch.uint8, device=gpu),
+                     torch.empty(B, dtype=torch.int32, device=gpu)) for _ in range(max(args.pipeline, 0) + 1)]
+        out_decks, out_proofs, st_v = out_sets[0]
         st_p = torch.empty(B, dtype=torch.int32, device=gpu)
-        st_v = torch.empty(B, dtype=torch.int32, device=gpu)
         factors, perms, seeds = rand_factors(1), rand_perms(2), rand_seeds(3)
         torch.cuda.synchronize()
+        if args.pipeline > 0:
+            assert S == 1 and args.keyed == 0, "--pipeline: one context, the table's own key"
+            table.set_pipeline(args.pipeline)
+        rot = {"i": 0}
 
         def sl(t, i):
             return t[i * Bs:(i + 1) * Bs].data_ptr()
@@ -430,15 +486,16 @@ def main():
                                                         sl(out_decks, i), sl(out_proofs, i), sl(st_p, i))
                     t.verify_shuffle_batch_keys_dev(Bs, sl(kk, i), sl(decks, i), sl(out_decks, i), sl(out_proofs, i), sl(st_v, i))
                     continue
-                t.shuffle_and_remask_batch_dev(Bs, sl(decks, i), sl(factors, i), sl(perms, i), sl(seeds, i), sl(out_decks, i),
-                                               sl(out_proofs, i), sl(st_p, i))
-                t.verify_shuffle_batch_dev(Bs, sl(decks, i), sl(out_decks, i), sl(out_proofs, i), sl(st_v, i))
+                od, op_, sv = out_sets[rot["i"]]
+                rot["i"] = (rot["i"] + 1) % len(out_sets)
+                t.shuffle_and_remask_batch_dev(Bs, sl(decks, i), sl(factors, i), sl(perms, i), sl(seeds, i), sl(od, i), sl(op_, i), sl(st_p, i))
+                t.verify_shuffle_batch_dev(Bs, sl(decks, i), sl(od, i), sl(op_, i), sl(sv, i))
 
         proofs_per_step = B
         units = "prove+verify pairs"
 
         def check():
-            return int((st_p != 0).sum().item()) + int((st_v != 0).sum().item())
+            return int((st_p != 0).sum().item()) + sum(int((o[2] != 0).sum().item()) for o in out_sets)
 
         def parity_inputs():
             b = B // 2
@@ -584,6 +641,7 @@ def main():
             prof[k] = (c0 + cnt, m0 + ms)
         e.profile_enable(False)
     elapsed = reduce_max(my_elapsed, dev)
+    hbm_used_gb = round((torch.cuda.mem_get_info(local)[1] - torch.cuda.mem_get_info(local)[0]) / 1e9, 1)
 
     # ---- correctness of what was timed (outside the timed region); verdicts gathered from every rank
     bad = check()
@@ -613,6 +671,8 @@ def main():
             fn()
             barrier()
             return B / (time.perf_counter() - t1)
+        # proof bytes of the timed region at the rows the extras below compare against (the keyed steps overwrite the output buffers)
+        ref_rows = {i: out_proofs[i].clone() for i in {512, 2048, 8192, 16384, B // 2} if i < B}
         table.set_merged_verify(False)
         extras["per_equation_value"] = timed_step(step)          # every equation its own MSM, as the reference evaluates them
         table.set_merged_verify(True)
@@ -628,6 +688,92 @@ def main():
         else:
             extras["keyed_value"] = None
         assert check() == 0
+        # ---- the throughput at the batch sizes a card server actually has in flight.  Same table, the first Bc proofs
+        # of the same inputs; the engine picks its work split by batch size (include/mpshuffle.h: mp_set_latency_batch).  `serial`: the calls
+        # as in the timed region (prove, then verify, one lane); `pipelined`: mp_set_pipeline(1) -- the verify call of batch k runs on the
+        # engine's second lane beside the prove call of batch k + 1 (two sets of prover outputs, verdicts examined one call later)
+        def curve_point(Bc, depth, seconds=0.5):
+            sets = [(torch.empty(Bc, N * CB, dtype=torch.uint8, device=gpu), torch.empty(Bc, proof_bytes, dtype=torch.uint8, device=gpu),
+                     torch.zeros(Bc, dtype=torch.int32, device=gpu)) for _ in range(depth + 1)]
+            stp = torch.zeros(Bc, dtype=torch.int32, device=gpu)
+            torch.cuda.synchronize()
+            table.set_pipeline(depth)
+            state = {"i": 0}
+
+            def one():
+                od, op_, sv = sets[state["i"]]
+                state["i"] = (state["i"] + 1) % len(sets)
+                table.shuffle_and_remask_batch_dev(Bc, decks.data_ptr(), factors.data_ptr(), perms.data_ptr(), seeds.data_ptr(),
+                                                   od.data_ptr(), op_.data_ptr(), stp.data_ptr())
+                table.verify_shuffle_batch_dev(Bc, decks.data_ptr(), od.data_ptr(), op_.data_ptr(), sv.data_ptr())
+            one()
+            eng.sync()
+            t1 = time.perf_counter()
+            one()
+            eng.sync()
+            k = max(2, min(400, int(seconds / max(time.perf_counter() - t1, 1e-4))))
+            k += (-k) % len(sets)
+            t1 = time.perf_counter()
+            for _ in range(k):
+                one()
+            eng.sync()
+            dt = time.perf_counter() - t1
+            table.set_pipeline(0)
+            assert int((stp != 0).sum().item()) + sum(int((o[2] != 0).sum().item()) for o in sets) == 0, "batch_curve: a proof failed"
+            assert torch.equal(sets[0][1][Bc // 2], ref_rows[Bc // 2]), "batch_curve: proof bytes depend on the batch size"
+            return round(Bc * k / dt, 1)
+        if B >= 32768 and not args.pipeline:
+            extras["batch_curve"] = {str(Bc): {"serial": curve_point(Bc, 0), "pipelined": curve_point(Bc, 1)} for Bc in (1024, 4096, 16384, 32768)}
+            extras["batch_curve_note"] = ("proofs/s (prove + verify) with Bc proofs in flight, same table and inputs as the headline; serial = one "
+                                          "lane, calls as in the timed region; pipelined = mp_set_pipeline(1): verify of batch k beside prove "
+                                          "of batch k + 1, two sets of prover outputs")
+        # ---- the same step through the reference-shaped host-buffer API (mp_shuffle_and_remask_batch + mp_verify_shuffle_batch: inputs
+        # start in host memory, outputs end there; PCIe-inclusive, never `value`), page-locked (mp_host_alloc) and ordinary buffers
+        def api_host(Bh):
+            import ctypes
+            import numpy as np
+            lib = table.lib
+            src = {"decks": decks[:Bh].cpu().numpy(), "rho": factors[:Bh].cpu().numpy(), "perms": perms[:Bh].cpu().numpy().astype(np.uint32),
+                   "seeds": seeds[:Bh].cpu().numpy()}
+            outs = {"od": ((Bh, N * CB), np.uint8), "op": ((Bh, proof_bytes), np.uint8), "st": ((Bh,), np.int32), "sv": ((Bh,), np.int32)}
+            res = {}
+            for kind in ("pinned", "pageable"):
+                held, a, o = [], {}, {}
+                if kind == "pinned":
+                    def pinned(shape, dtype):
+                        nb = int(np.prod(shape)) * np.dtype(dtype).itemsize
+                        p_ = lib.mp_host_alloc(nb)
+                        assert p_, "mp_host_alloc failed"
+                        held.append(p_)
+                        return np.frombuffer((ctypes.c_uint8 * nb).from_address(p_), dtype=dtype).reshape(shape)
+                    for k_, v in src.items():
+                        a[k_] = pinned(v.shape, v.dtype)
+                        a[k_][...] = v
+                    o = {k_: pinned(*v) for k_, v in outs.items()}
+                else:
+                    a = {k_: np.ascontiguousarray(v) for k_, v in src.items()}
+                    o = {k_: np.empty(*v) for k_, v in outs.items()}
+                ptr = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+
+                def run():
+                    assert lib.mp_shuffle_and_remask_batch(table.h, Bh, ptr(a["decks"]), ptr(a["rho"]), ptr(a["perms"]), ptr(a["seeds"]),
+                                                           ptr(o["od"]), ptr(o["op"]), ptr(o["st"])) == 0
+                    assert lib.mp_verify_shuffle_batch(table.h, Bh, ptr(a["decks"]), ptr(o["od"]), ptr(o["op"]), ptr(o["sv"])) == 0
+                run()
+                reps = 2 if Bh >= 65536 else 6
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    run()
+                res[kind] = round(Bh * reps / (time.perf_counter() - t1), 1)
+                assert not o["st"].any() and not o["sv"].any()
+                assert bytes(o["op"][Bh // 2]) == bytes(ref_rows[Bh // 2].cpu().numpy().tobytes()), "host-buffer API: different proof bytes"
+                del a, o
+                for p_ in held:
+                    lib.mp_host_free(p_)
+            return res
+        extras["api_host_value"] = {str(Bh): api_host(Bh) for Bh in sorted({min(B, 262144), min(B, 16384)}, reverse=True)}
+        extras["api_host_note"] = ("mp_shuffle_and_remask_batch + mp_verify_shuffle_batch, proofs/s: inputs and outputs in host memory "
+                                   "(22 KB per proof over PCIe), chunks of 65 536 proofs pipelined over three streams")
 
     if rank != 0:
         if world > 1:
@@ -812,12 +958,13 @@ def main():
     cpu = None
     if not args.no_cpu_baseline:                  # rank 0 only (the other ranks have returned); N > 1 lines carry it too
         import coracle as co
+        numa = pin_to_gpu_numa_node(local)        # the host cores next to this rank's GPU
         it = args.cpu_iters if N <= 64 else max(2, args.cpu_iters * 52 // (N * max(1, m // 2)))
         t_p, t_v = co.bench(curve, m, n, 99, it)
         cpu = {"value": it / (t_p + t_v), "unit": "proofs/s", "cores": 1, "kind": "port",
                "sample": "%d prove+verify pairs, %d-card deck (m=%d,n=%d), %s, single thread; prove %.1f ms verify %.1f ms each"
                          % (it, N, m, n, curve, 1e3 * t_p / it, 1e3 * t_v / it),
-               "host_cores_available": os.cpu_count()}
+               "host_cores_available": os.cpu_count(), "numa": numa}
         # the same port on every host core, one independent proof stream per thread (the reference itself is
         # single-threaded: BASELINE.md section 2); ctypes releases the GIL for the duration of the C call
         from concurrent.futures import ThreadPoolExecutor
@@ -838,6 +985,33 @@ def main():
                             "cgroup_cpu_quota": quota,
                             "sample": "%d threads x %d prove+verify pairs, one proof stream per thread, %.1f s wall" % (T, it_mt, wall)}
 
+    # ---- the same device-resident step on a table from plain mp_table_create (the call INTEGRATION.md's Rust `table_for` makes): the
+    # engine sizes the fixed-base windows by the HBM that is free.  Last, because the benchmarked table has to go first.
+    if workload == "pairs" and world == 1 and not args.no_extras and args.keyed == 0 and not args.per_equation and S == 1 and not args.pipeline:
+        table.close()
+        del tables[:]
+        torch.cuda.empty_cache()
+        t_tab = time.perf_counter()
+        dtab = eng.table(m, n, params, pk, fb_bits=0)
+        eng.sync()
+        extras["default_table_build_s"] = round(time.perf_counter() - t_tab, 3)
+        extras["default_table_window_bits"] = dtab.fb_bits
+        dtab.reserve(B)
+
+        def dstep():
+            dtab.shuffle_and_remask_batch_dev(B, decks.data_ptr(), factors.data_ptr(), perms.data_ptr(), seeds.data_ptr(), out_decks.data_ptr(),
+                                              out_proofs.data_ptr(), st_p.data_ptr())
+            dtab.verify_shuffle_batch_dev(B, decks.data_ptr(), out_decks.data_ptr(), out_proofs.data_ptr(), st_v.data_ptr())
+        dstep()
+        barrier()
+        t1 = time.perf_counter()
+        dstep()
+        dstep()
+        barrier()
+        extras["default_table_value"] = round(2 * B / (time.perf_counter() - t1), 1)
+        assert int((st_p != 0).sum().item()) + int((st_v != 0).sum().item()) == 0
+        dtab.close()
+
     limbs = {"stark": "9x29-bit lazy base field", "secp256k1": "9x29-bit lazy base field (signed sparse limbs)",
              "bls12_377": "12x32 base field"}.get(curve, "8x32 base field")
     config = {"workload": "%s: %d-card deck, m=%d n=%d, %s curve, shuffle_and_remask + verify_shuffle" % (workload, N, m, n, curve),
@@ -847,11 +1021,14 @@ def main():
               "verification": "per equation" if args.per_equation else "merged screening pass (per-equation pass only to name a failure)",
               # engine choices by batch size (include/mpshuffle.h: mp_set_transcript_lanes; engine_base.hpp: OVERLAP_MAX_BATCH)
               "transcript_lanes": (args.transcript_lanes or (4 if Bs <= 32768 else 1)),
-              "prover_streams": (2 if Bs <= 32768 and workload != "chain32" else 1),
+              # (engine_base.hpp OVERLAP_MAX_BATCH: prove launches of up to 32 768 proofs run their first stretch on two streams, and their
+              # per-kernel event times then overlap -- kernels_ms / int_mul are not additive there)
+              "prover_streams": (2 if {"pairs": Bs, "chain32": B, "mixed": B // 2}[workload] <= 32768 else 1),
               "parallelism": "%d rank(s), proofs sharded, no data-path collective; parameters broadcast once (%s)" % (world, backend),
               "rccl_world": (dist.get_world_size() if world > 1 else 1), "collective_backend": backend if world > 1 else None,
+              "rccl_smoke": smoke_log, "pipeline_depth": args.pipeline,
               "table_build_s": round(table_build_s, 3),
-              "hbm_per_rank_gb": round((torch.cuda.mem_get_info(local)[1] - torch.cuda.mem_get_info(local)[0]) / 1e9, 1),
+              "hbm_per_rank_gb": hbm_used_gb,
               "per_rank_proofs": [int(r[0]) for r in rows], "per_rank_failed": [int(r[1]) for r in rows],
               "per_rank_seconds": [round(r[2], 4) for r in rows],
               "parity_vs_oracle": parity}
@@ -861,7 +1038,7 @@ def main():
     out = {
         "metric": "shuffle proofs/sec (prove+verify)", "value": value, "unit": "proofs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u32 limbs (256-bit Montgomery: %s, 8x32 scalar field)" % limbs,
         "data": "synthetic",
         "config": config,

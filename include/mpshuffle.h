@@ -82,15 +82,20 @@ int mp_set_io_chunk(mp_table* t, size_t proofs);
  * them as k * G_std, which made the seed a trapdoor of the Pedersen key).  Host work, once per table.  out_params: n + 3 wire points. */
 int mp_setup(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out_params);
 
-/* ---- table context: Parameters + aggregate public key -> fixed-base window tables in HBM ------------------ */
+/* ---- table context: Parameters + aggregate public key -> fixed-base window tables in HBM ------------------
+ * mp_table_create sizes the tables for the GPU it runs on: the widest windows -- 21 bits (48 GB at n = 26, 12 additions per term on the
+ * 252-bit STARK scalars), 20 (27 GB, 13 additions), 16 (2 GB, 16 additions), 8 (16 MB, 32 additions) -- whose tables take at most 30 % of
+ * the HBM that is free at the call and whose construction (~3.3x the table for a moment) fits 85 % of it.  On an otherwise empty
+ * MI355X that is the configuration bench.py measures; a caller that keeps many tables alive (one per aggregate key) should rather
+ * create ONE table of the shared parameters and name the keys through a key set (below).  Construction takes 0.1 s (8 / 16 bits) to
+ * ~3 s (21 bits, first touch of 150 GB). */
 int mp_table_create(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, const uint8_t* shared_key,
                     mp_table** out);
-/* same with an explicit fixed-base window width: 8 (16 MB of tables at n = 26, 32 additions per term; what
- * mp_table_create uses), 16 (2 GB, 16 additions per term), 20 (27 GB, 13 additions per term: the throughput
- * configuration bench.py uses -- sized for the 288 GB of an MI355X) or 21 (48 GB; ceil(scalar bits / 21) windows:
- * 12 additions per term on the 252-bit STARK scalar field, 13 on the other curves) */
+/* same with an explicit fixed-base window width: 8, 16, 20 or 21 bits (21: ceil(scalar bits / 21) windows -- 12 on the STARK curve, 13
+ * on the other curves, where 20 bits give the same count for half the memory); 0 = choose as mp_table_create does */
 int mp_table_create_ex(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, const uint8_t* shared_key,
                        uint32_t fb_window_bits, mp_table** out);
+uint32_t mp_table_window_bits(const mp_table* t);      /* the width in use */
 void mp_table_destroy(mp_table* t);
 
 /* ---- DLCards::shuffle_and_remask / verify_shuffle (one proof; host buffers) --------------------------------- */
@@ -173,34 +178,34 @@ int mp_verify_shuffle_chain_dev(mp_table* t, size_t tables, uint32_t links, cons
                                 void* d_status);
 int mp_sync(mp_ctx* ctx);
 int mp_reserve(mp_table* t, size_t B);           /* pre-allocate the batch workspace for B proofs */
-/* Every table holds five static work splits with identical results: a throughput plan (large sub-jobs, fewest operations),
- * a latency plan (small sub-jobs: ~16x more lanes per proof), a medium and a wide plan in between and a finest split for single
- * proofs.  Batches of at most 5/32 B proofs use the finest split, up to `B` the latency plan, up to 3.2 B the medium plan, up to
- * 12.8 B the wide plan, larger ones the throughput plan (default B = 3840 * 52 / N, at least 64: 600 / 3 840 / 12 288 / 49 152 proofs
- * of 52 cards, the crossovers measured on an MI355X; 0 = always throughput). */
+/* Every table holds six static work splits with identical results: a throughput plan (large sub-jobs, fewest operations) and five
+ * finer ones -- wide, medium, latency, small, finest -- that give a proof more lanes (smaller sub-jobs; the windows of a variable-base
+ * sub-job dealt to several lanes).  Batches of at most B / 12 proofs use the finest split, up to B / 2 the small one, up to `B` the
+ * latency plan, up to 4 B the medium plan, up to 32 B the wide plan, larger ones the throughput plan (default B = 1536 * 52 / N, at
+ * least 24: 128 / 768 / 1 536 / 6 144 / 49 152 proofs of 52 cards, the crossovers measured on an MI355X; 0 = always throughput). */
 int mp_set_latency_batch(mp_table* t, size_t B);
-/* Every batch takes work split `split` whatever its size: 0 throughput, 1 latency, 2 medium, 3 finest, 4 wide; -1 (default) = by
- * batch size as above.  For tests and measurements: the results do not depend on it. */
+/* Every batch takes work split `split` whatever its size: 0 throughput, 1 latency, 2 medium, 3 finest, 4 wide, 5 small; -1 (default) =
+ * by batch size as above.  For tests and measurements: the results do not depend on it. */
 int mp_set_work_split(mp_table* t, int split);
-/* Pipelined verification (off by default).  A card server proves the next batch while the previous one is verified; with this on,
- * the device-resident verify calls (mp_verify_shuffle_batch[_keys|_keyset]_dev) run on a second lane of the context -- streams and
- * arenas of their own -- ordered behind everything the context held when they were issued, and return WITHOUT waiting for their
- * screening verdict, so that the caller's next mp_shuffle_and_remask_batch*_dev call runs beside them on the chip (batches that do
- * not fill it alone: 1 024 proofs +40 %, 4 096 +20 %).  The verdict of verify call k is looked at when verify
- * call k + 1 comes in or at mp_sync, and only then -- only if some proof failed the screen -- does the per-equation pass of call k run.
- * The caller's side of the contract: the buffers a verify call reads (decks, shuffled decks, proofs, keys) stay untouched until the
- * NEXT verify call on that table or mp_sync has returned (alternate between two sets of prover outputs); d_status is final after
- * mp_sync, as before.  Status words are identical in both modes.  The host-buffer entry points and chain verification are unaffected. */
-int mp_set_pipeline(mp_table* t, int on);
-/* The sizes behind work split `split` (0 .. 4 as above): fixed-base / variable-base terms per sub-job, bases per window-table lane,
+/* Pipelined verification (depth 0 = off, the default).  A card server proves the next batch while the previous one is verified;
+ * with depth >= 1 the device-resident verify calls (mp_verify_shuffle_batch[_keys|_keyset]_dev) run on a second lane of the context --
+ * streams and arenas of their own -- ordered behind everything the context held when they were issued, and return WITHOUT waiting for
+ * their screening verdict, so that the caller's next mp_shuffle_and_remask_batch*_dev call runs beside them on the chip (batches that
+ * do not fill it alone).  The verdict of verify call k is looked at when verify call k + depth comes in, or at
+ * mp_sync; only then -- and only if some proof failed the screen -- does the per-equation pass of call k run.  The caller's side of
+ * the contract: the buffers a verify call reads (decks, shuffled decks, proofs, keys) stay untouched until `depth` further verify
+ * calls on that table, or mp_sync, have returned (rotate depth + 1 sets of prover outputs); d_status is final after mp_sync, as
+ * before.  Status words are identical in every mode.  The host-buffer entry points and chain verification are unaffected. */
+int mp_set_pipeline(mp_table* t, int depth);
+/* The sizes behind work split `split` (0 .. 5 as above): fixed-base / variable-base terms per sub-job, bases per window-table lane,
  * points per shared inversion, and `window_lanes` = lanes per variable-base sub-job: the Straus windows of a sub-job are dealt to that
  * many lanes (each runs its share as a chain of its own) and one fold per multi-scalar multiplication puts the range sums together --
  * k times the lanes for < 250 extra doublings per MSM instead of k times the doubling chains (1 = one lane runs all windows).
- * mp_set_plan_thresholds: the largest batch that takes the finest / latency / medium / wide split.  For measurements and tuning on
+ * mp_set_plan_thresholds: the largest batch that takes the finest / small / latency / medium / wide split.  For measurements and tuning on
  * other parts: results do not depend on either.  Both rebuild nothing a running batch uses (call between batches). */
 int mp_set_plan_params(mp_table* t, int split, uint32_t fixed_terms, uint32_t var_terms, uint32_t table_group, uint32_t norm_chunk,
                        uint32_t window_lanes);
-int mp_set_plan_thresholds(mp_table* t, size_t finest, size_t latency, size_t medium, size_t wide);
+int mp_set_plan_thresholds(mp_table* t, size_t finest, size_t small, size_t latency, size_t medium, size_t wide);
 /* Verification strategy.  on (default): the verifier first evaluates ALL group equations of a proof merged into one
  * multi-scalar multiplication with random weights derived from the whole proof (soundness loss ~2^-250); a batch in which
  * every proof passes ends there.  Only if some proof fails is the batch re-evaluated equation by equation, so that the

@@ -19,7 +19,7 @@ SYMBOLS = [
     "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_set_subgroup_check", "mp_set_bucket_min", "mp_set_chain_max_links", "mp_set_transcript_lanes", "mp_set_group_lanes", "mp_set_work_split", "mp_set_pipeline", "mp_set_plan_params", "mp_set_plan_thresholds", "mp_set_toom_cook", "mp_host_alloc", "mp_host_free", "mp_set_io_chunk", "mp_shuffle_and_remask_batch_keys", "mp_table_create_params",
     "mp_verify_shuffle_batch_keys", "mp_shuffle_and_remask_batch_keys_dev", "mp_verify_shuffle_batch_keys_dev",
     "mp_keyset_create", "mp_keyset_destroy", "mp_keyset_size", "mp_shuffle_and_remask_batch_keyset_dev", "mp_verify_shuffle_batch_keyset_dev",
-    "mp_setup", "mp_table_create", "mp_table_create_ex", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
+    "mp_setup", "mp_table_create", "mp_table_create_ex", "mp_table_window_bits", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
     "mp_shuffle_and_remask_batch", "mp_verify_shuffle_batch", "mp_shuffle_and_remask_batch_dev",
     "mp_verify_shuffle_batch_dev", "mp_verify_shuffle_chain", "mp_verify_shuffle_chain_dev", "mp_sync", "mp_reserve", "mp_set_latency_batch", "mp_remask_batch", "mp_msm", "mp_commit_batch",
     "mp_profile_enable", "mp_profile_report", "mp_work_census", "mp_plan_stats", "mp_sigma_prove_batch",
@@ -127,7 +127,7 @@ def bind(cdll):
     cdll.mp_set_work_split.argtypes = [c.c_void_p, c.c_int]
     cdll.mp_set_pipeline.argtypes = [c.c_void_p, c.c_int]
     cdll.mp_set_plan_params.argtypes = [c.c_void_p, c.c_int] + [c.c_uint32] * 5
-    cdll.mp_set_plan_thresholds.argtypes = [c.c_void_p] + [c.c_size_t] * 4
+    cdll.mp_set_plan_thresholds.argtypes = [c.c_void_p] + [c.c_size_t] * 5
     cdll.mp_set_io_chunk.argtypes = [c.c_void_p, c.c_size_t]
     cdll.mp_host_alloc.argtypes = [c.c_size_t]
     cdll.mp_host_alloc.restype = c.c_void_p
@@ -142,6 +142,8 @@ def bind(cdll):
     cdll.mp_setup.argtypes = [c.c_void_p, c.c_uint32, c.c_uint32, u8p, u8p]
     cdll.mp_table_create.argtypes = [c.c_void_p, c.c_uint32, c.c_uint32, u8p, u8p, c.POINTER(c.c_void_p)]
     cdll.mp_table_create_ex.argtypes = [c.c_void_p, c.c_uint32, c.c_uint32, u8p, u8p, c.c_uint32, c.POINTER(c.c_void_p)]
+    cdll.mp_table_window_bits.argtypes = [c.c_void_p]
+    cdll.mp_table_window_bits.restype = c.c_uint32
     cdll.mp_table_destroy.argtypes = [c.c_void_p]
     cdll.mp_table_destroy.restype = None
     cdll.mp_shuffle_and_remask.argtypes = [c.c_void_p, u8p, u8p, u32p, u8p, u8p, u8p]
@@ -391,6 +393,7 @@ class Table:
         else:
             eng._chk(self.lib.mp_table_create_ex(eng.h, m, n, _in(self.params), _in(self.shared_key), fb_bits, ctypes.byref(h)))
         self.h = h
+        self.fb_bits = self.lib.mp_table_window_bits(h)      # (fb_bits = 0: the engine chose by free HBM, as mp_table_create does)
         self.proof_bytes = eng.proof_size(m, n)
 
     def close(self):
@@ -581,22 +584,23 @@ class Table:
         self.eng._chk(self.lib.mp_set_group_lanes(self.h, lanes))
 
     def set_work_split(self, split):
-        """every batch takes work split `split` (0 throughput, 1 latency, 2 medium, 3 finest, 4 wide); -1 = by batch size"""
+        """every batch takes work split `split` (0 throughput, 1 latency, 2 medium, 3 finest, 4 wide, 5 small); -1 = by batch size"""
         self.eng._chk(self.lib.mp_set_work_split(self.h, split))
 
-    def set_pipeline(self, on=True):
-        """device-resident verify calls run on the context's second lane beside the next prove call and do not wait for their
-        screening verdict (include/mpshuffle.h: mp_set_pipeline); their inputs must stay untouched until the next verify call / sync"""
-        self.eng._chk(self.lib.mp_set_pipeline(self.h, 1 if on else 0))
+    def set_pipeline(self, depth=1):
+        """depth >= 1: device-resident verify calls run on the context's second lane beside the next prove call and do not wait for
+        their screening verdict (include/mpshuffle.h: mp_set_pipeline); their inputs must stay untouched until `depth` further verify
+        calls or a sync have returned; 0 = off"""
+        self.eng._chk(self.lib.mp_set_pipeline(self.h, int(depth)))
 
     def set_plan_params(self, split, fixed_terms, var_terms, table_group, norm_chunk, window_lanes=1):
         """sizes of work split `split`: terms per fixed-base / variable-base sub-job, bases per table lane, points per inversion,
         lanes per variable-base sub-job (window split)"""
         self.eng._chk(self.lib.mp_set_plan_params(self.h, split, fixed_terms, var_terms, table_group, norm_chunk, window_lanes))
 
-    def set_plan_thresholds(self, finest, latency, medium, wide):
-        """largest batch that takes the finest / latency / medium / wide split"""
-        self.eng._chk(self.lib.mp_set_plan_thresholds(self.h, finest, latency, medium, wide))
+    def set_plan_thresholds(self, finest, small, latency, medium, wide):
+        """largest batch that takes the finest / small / latency / medium / wide split"""
+        self.eng._chk(self.lib.mp_set_plan_thresholds(self.h, finest, small, latency, medium, wide))
 
     def set_toom_cook(self, on=True):
         """3 <= m <= 8: Toom-Cook (default) or Karatsuba evaluation of the multi-exponentiation diagonals"""

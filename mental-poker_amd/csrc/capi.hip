@@ -113,15 +113,18 @@ int mp_ctx_create(int curve_id, int device, mp_ctx** out) {
   mp_ctx* c = new mp_ctx();
   c->curve = curve_id;
   c->device = device;
+  // The runtime deals HIP streams to a small number of hardware queues round robin in creation order (4 by default, GPU_MAX_HW_QUEUES),
+  // and streams that share a queue do not overlap: the four compute streams -- the two lanes and their side streams -- come first so
+  // that they land on different queues; the copy streams of the host-buffer entry points share with them
   c->stream = rt::stream_create();
+  c->vstream = rt::stream_create();
+  c->side = rt::stream_create();
+  c->vside = rt::stream_create();
   c->h2d = rt::stream_create();
   c->d2h = rt::stream_create();
-  c->side = rt::stream_create();
   c->ev_fork = rt::event_create();
   c->ev_shuf = rt::event_create();
   c->ev_tab = rt::event_create();
-  c->vstream = rt::stream_create();
-  c->vside = rt::stream_create();
   c->ev_vfork = rt::event_create();
   c->ev_vshuf = rt::event_create();
   c->ev_vtab = rt::event_create();
@@ -161,8 +164,23 @@ int mp_setup(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_
   MP_CATCH
 }
 
+// mp_table_create: the widest fixed-base windows whose tables fit the HBM that is free right now.  A table of b-bit windows holds
+// (n + 5) bases x ceil(scalar bits / b) windows x (2^b - 1) affine points; building it needs ~3.3x that for a moment (Jacobian
+// entries and inversion scratch before the normalisation).  Rule: table <= 30 % of the free memory and the build <= 85 % of it.
+static uint32_t auto_window_bits(int curve, uint32_t n) {
+  size_t free_b = 0, total_b = 0;
+  rt::mem_info(&free_b, &total_b);
+  const uint32_t sbits[4] = {252, 254, 256, 253};
+  const size_t pbytes = curve == MP_CURVE_BLS12_377 ? 96 : 64;
+  for (uint32_t bits : {21u, 20u, 16u}) {
+    if (bits == 21 && sbits[curve] > 252) continue;      // 21 bits only save a window on the 252-bit STARK scalars
+    const double tbl = (double)(n + 5) * ((sbits[curve] + bits - 1) / bits) * (double)((1u << bits) - 1u) * (double)pbytes;
+    if (tbl <= 0.30 * (double)free_b && 3.3 * tbl <= 0.85 * (double)free_b) return bits;
+  }
+  return 8;
+}
 int mp_table_create(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, const uint8_t* shared_key, mp_table** out) {
-  return mp_table_create_ex(ctx, m, n, params, shared_key, 8, out);
+  return mp_table_create_ex(ctx, m, n, params, shared_key, 0, out);
 }
 int mp_table_create_ex(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, const uint8_t* shared_key,
                        uint32_t fb_window_bits, mp_table** out) {
@@ -170,6 +188,7 @@ int mp_table_create_ex(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* param
   if (m < 2 || n < 2 || (uint64_t)m * n > 4096) return fail(MP_ERR_BAD_ARGUMENT, "mp_table_create: need m >= 2, n >= 2, m*n <= 4096");
   MP_TRY
   rt::set_device(ctx->device);
+  if (fb_window_bits == 0) fb_window_bits = auto_window_bits(ctx->curve, n);
   int rc;
   mp_table* t = nullptr;
   switch (ctx->curve) {
@@ -219,6 +238,7 @@ void* mp_host_alloc(size_t bytes) {
 }
 void mp_host_free(void* p) { rt::host_free(p); }
 
+uint32_t mp_table_window_bits(const mp_table* t) { return t ? t->fb_bits : 0; }
 int mp_set_latency_batch(mp_table* t, size_t B) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_latency_batch: null table");
   t->set_latency_batch(B);
@@ -261,16 +281,17 @@ int mp_set_group_lanes(mp_table* t, uint32_t lanes) {
 }
 int mp_set_work_split(mp_table* t, int split) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_work_split: null table");
-  if (split < -1 || split > 4) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_work_split: -1 (by batch size) or 0 .. 4");
+  if (split < -1 || split > 5) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_work_split: -1 (by batch size) or 0 .. 5");
   t->forced_split = split;
   return MP_OK;
 }
-int mp_set_pipeline(mp_table* t, int on) {
+int mp_set_pipeline(mp_table* t, int depth) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_pipeline: null table");
   MP_TRY
   rt::set_device(t->ctx->device);
+  if (depth < 0 || depth > 8) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_pipeline: depth 0 (off) .. 8");
   t->flush();
-  t->pipeline = on != 0;
+  t->pipeline = depth;
   return MP_OK;
   MP_CATCH
 }
@@ -280,14 +301,15 @@ int mp_set_plan_params(mp_table* t, int split, uint32_t fixed_terms, uint32_t va
   MP_TRY
   rt::set_device(t->ctx->device);
   if (t->set_plan_params(split, fixed_terms, var_terms, table_group, norm_chunk, window_lanes) != MP_OK)
-    return fail(MP_ERR_BAD_ARGUMENT, "mp_set_plan_params: split 0 .. 4, sizes >= 1, table_group <= 64, window_lanes <= 16");
+    return fail(MP_ERR_BAD_ARGUMENT, "mp_set_plan_params: split 0 .. 5, sizes >= 1, table_group <= 64, window_lanes <= 16");
   return MP_OK;
   MP_CATCH
 }
-int mp_set_plan_thresholds(mp_table* t, size_t finest, size_t latency, size_t medium, size_t wide) {
+int mp_set_plan_thresholds(mp_table* t, size_t finest, size_t small, size_t latency, size_t medium, size_t wide) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_plan_thresholds: null table");
-  if (finest > latency || latency > medium || medium > wide) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_plan_thresholds: finest <= latency <= medium <= wide");
-  t->set_plan_thresholds(finest, latency, medium, wide);
+  if (finest > small || small > latency || latency > medium || medium > wide)
+    return fail(MP_ERR_BAD_ARGUMENT, "mp_set_plan_thresholds: finest <= small <= latency <= medium <= wide");
+  t->set_plan_thresholds(finest, small, latency, medium, wide);
   return MP_OK;
 }
 int mp_set_toom_cook(mp_table* t, int on) {

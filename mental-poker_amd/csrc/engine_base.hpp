@@ -16,6 +16,7 @@
 // [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:105-121, 380-418, 420-443].
 #include <algorithm>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -186,12 +187,14 @@ struct mp_table {
   size_t io_chunk = 0;         // proofs per pipelined chunk of the host-buffer entry points (0 = default, mp_set_io_chunk)
   uint32_t m = 0, n = 0, N = 0;
   uint32_t point_bytes = 64;   // wire size of a point on this table's curve (Geo<C>::PB)
+  uint32_t fb_bits = 8;        // window width of the fixed-base tables (mp_table_window_bits)
   bool keyless = false;        // created from the parameters alone (mp_table_create_params): keyed entry points only
   uint32_t chain_max_links = 0;   // links per chain equation (0 = as many as fit 32 767 points; mp_set_chain_max_links)
   uint32_t fs_lanes = 0;          // lanes per transcript hash: 1, 4, or 0 = by batch size (mp_set_transcript_lanes)
   uint32_t group_lanes = 0;       // lanes per group operation of the MSM chains: 1, 4, or 0 = by batch size (mp_set_group_lanes)
-  int forced_split = -1;          // work split every batch takes: 0 throughput, 1 latency, 2 medium, 3 finest, 4 wide; -1 = by batch size (mp_set_work_split)
-  int pipeline = 0;               // device-resident verify calls run on the context's second lane, next to the prove calls (mp_set_pipeline)
+  int forced_split = -1;          // work split every batch takes: 0 throughput, 1 latency, 2 medium, 3 finest, 4 wide, 5 small; -1 = by batch size (mp_set_work_split)
+  int pipeline = 0;               // > 0: device-resident verify calls run on the context's second lane, next to the prove calls, and up
+                                  // to this many of their screening verdicts stay unexamined when a call returns (mp_set_pipeline)
   virtual ~mp_table() {}
   virtual void flush() = 0;       // complete deferred verification passes and wait for the verify lane
   virtual void reserve(size_t B) = 0;
@@ -201,7 +204,7 @@ struct mp_table {
   virtual void set_bucket_min(uint32_t terms) = 0;
   virtual void set_toom_cook(bool on) = 0;
   virtual int set_plan_params(int plan, uint32_t fch, uint32_t vch, uint32_t grp, uint32_t nch, uint32_t vsp) = 0;
-  virtual void set_plan_thresholds(size_t tiny, size_t latency, size_t medium, size_t wide) = 0;
+  virtual void set_plan_thresholds(size_t tiny, size_t small, size_t latency, size_t medium, size_t wide) = 0;
   // keys: nullptr = the table's own aggregate key; otherwise one wire point per proof (device memory).
   // ks / kidx: proof b is made under key kidx[b] (device array) of the key set instead (keys is ignored)
   virtual void prove_dev(size_t B, const uint8_t* decks, const uint8_t* rho, const uint32_t* perm, const uint8_t* seeds,

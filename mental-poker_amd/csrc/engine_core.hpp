@@ -72,42 +72,53 @@ struct Workspace {
   uint32_t fw = 8;      // words of a base-field element (Geo<C>::FW of the owning table: 8, or 12 on BLS12-377)
   uint32_t Bpad = 0;
   uint32_t nS = 0, nP = 0, nJ = 0, nD = 0, nT = 0, nwin = 0, stage_words = 0;
-  DevBuf<uint32_t> S, P, J, T, NS, NS2, stage, seed, direct;      // NS2: inversion scratch of the main stream while `side` has NS (prove_dev): ns2_elems points per proof
+  DevBuf<uint32_t> S, P, J, T, NS, NS2, stage, seed, direct;      // NS2: inversion scratch of the main stream while `side` has NS (prove_dev: m points per proof, allocated by reserve_ws for batches that fork)
   DevBuf<uint32_t> W;       // wire words of the loaded decks, [slot][word][Bpad] (what the transcript hashes; LoadPointsArgs::W)
   DevBuf<int8_t> D;
   DevBuf<int8_t> D8;        // bucket-method digits, proof-major: [b][d8_bytes]
   uint32_t d8_bytes = 0;
-  uint32_t ns2_elems = 64;   // points per proof NS2 has room for (the owning table: max(64, m))
   DevBuf<int32_t> status;
+  // The arenas are slot-major with the lane stride Bpad.  Bpad follows the batch (B rounded up to a wave), whatever the arenas were
+  // allocated for (`cap` lanes): a 1 024-proof batch laid out with the stride of an earlier 262 144-proof one touches 32 KB out of
+  // every 8 MB -- a TLB miss per slot -- and ran at 100 k proofs/s instead of 160 k (round 4).  Lanes [B, Bpad) of the J arena are
+  // read by the flat normalisation kernels and must hold zeros (Z = 0: skipped), so a change of stride clears the part in use.
+  uint32_t cap = 0;
   void ensure(uint32_t B, uint32_t nS_, uint32_t nP_, uint32_t nJ_, uint32_t nD_, uint32_t nT_, uint32_t nwin_,
               uint32_t stage_words_, rt::Stream s, uint32_t d8_bytes_ = 0) {
-    uint32_t need = (B + 63u) & ~63u;
-    if (need <= Bpad && nS_ <= nS && nP_ <= nP && nJ_ <= nJ && nD_ <= nD && nT_ <= nT && stage_words_ <= stage_words &&
-        d8_bytes_ <= d8_bytes)
+    const uint32_t need = (B + 63u) & ~63u;
+    const bool grow = !(need <= cap && nS_ <= nS && nP_ <= nP && nJ_ <= nJ && nD_ <= nD && nT_ <= nT && stage_words_ <= stage_words &&
+                        d8_bytes_ <= d8_bytes);
+    if (grow) {
+      cap = std::max(cap, need);
+      nS = std::max(nS, nS_); nP = std::max(nP, nP_); nJ = std::max(nJ, nJ_); nD = std::max(nD, nD_); nT = std::max(nT, nT_);
+      nwin = nwin_;
+      stage_words = std::max(stage_words, stage_words_);
+      // re-allocate everything (capacity grows monotonically); zero-filled so padding lanes hold valid data
+      S.n = P.n = J.n = T.n = NS.n = stage.n = seed.n = direct.n = 0;
+      D.n = 0;
+      D8.n = 0;
+      d8_bytes = std::max(d8_bytes, d8_bytes_);
+      D8.alloc((size_t)std::max(d8_bytes, 4u) * cap, s);      // zero-filled: the padding digits of an MSM stay zero
+      status.n = 0;
+      S.alloc((size_t)nS * cap * 8, s);
+      P.alloc((size_t)nP * cap * 2 * fw, s);
+      J.alloc((size_t)nJ * cap * 3 * fw, s);
+      D.alloc((size_t)std::max(nD, 1u) * nwin * cap, s);
+      T.alloc((size_t)std::max(nT, 1u) * VB_ENTRIES * cap * 2 * fw, s);
+      size_t norm_max = std::max((size_t)nT * 8, (size_t)nJ) * cap;   // k_table prefix products (8 per base), k_normalize ranges
+      NS.alloc(norm_max * fw, s);
+      stage.alloc((size_t)stage_words * cap, s);
+      seed.alloc((size_t)8 * cap, s);
+      direct.alloc((size_t)2 * cap, s);
+      status.alloc(cap, s);
+      Bpad = need;
       return;
-    Bpad = std::max(Bpad, need);
-    nS = std::max(nS, nS_); nP = std::max(nP, nP_); nJ = std::max(nJ, nJ_); nD = std::max(nD, nD_); nT = std::max(nT, nT_);
-    nwin = nwin_;
-    stage_words = std::max(stage_words, stage_words_);
-    // re-allocate everything (capacity grows monotonically); zero-filled so padding lanes hold valid data
-    S.n = P.n = J.n = T.n = NS.n = NS2.n = stage.n = seed.n = direct.n = 0;
-    D.n = 0;
-    D8.n = 0;
-    d8_bytes = std::max(d8_bytes, d8_bytes_);
-    D8.alloc((size_t)std::max(d8_bytes, 4u) * Bpad, s);      // zero-filled: the padding digits of an MSM stay zero
-    status.n = 0;
-    S.alloc((size_t)nS * Bpad * 8, s);
-    P.alloc((size_t)nP * Bpad * 2 * fw, s);
-    J.alloc((size_t)nJ * Bpad * 3 * fw, s);
-    D.alloc((size_t)std::max(nD, 1u) * nwin * Bpad, s);
-    T.alloc((size_t)std::max(nT, 1u) * VB_ENTRIES * Bpad * 2 * fw, s);
-    size_t norm_max = std::max((size_t)nT * 8, (size_t)nJ) * Bpad;   // k_table prefix products (8 per base), k_normalize ranges
-    NS.alloc(norm_max * fw, s);
-    NS2.alloc((size_t)ns2_elems * Bpad * fw, s);
-    stage.alloc((size_t)stage_words * Bpad, s);
-    seed.alloc((size_t)8 * Bpad, s);
-    direct.alloc((size_t)2 * Bpad, s);
-    status.alloc(Bpad, s);
+    }
+    if (Bpad != need) {
+      Bpad = need;
+      rt::dzero(J.p, (size_t)nJ * Bpad * 3 * fw * sizeof(uint32_t), s);
+      if (d8_bytes) rt::dzero(D8.p, (size_t)d8_bytes * Bpad, s);
+    }
   }
 };
 
@@ -130,13 +141,20 @@ struct Table : mp_table {
     uint32_t table_group = TABLE_GROUP;
     uint32_t norm_chunk = NORM_CHUNK;
   };
-  // Five static work splits per table, identical results: [0] throughput (64 variable-base / 8 fixed-base terms per lane,
-  // 64 bases per table lane: fewest operations), [1] latency (4 / 2 / 8: ~16x more lanes per proof), [2] medium (16 / 4 / 16),
-  // [4] wide (32 / 4 / 16), [3] single proofs and tiny batches (1 / 1 / 2 on decks of up to 128 cards, else 2 / 1 / 4).  Measured on
-  // an MI355X, 52 cards: [3] wins up to ~640 proofs in flight, latency up to ~4 k, medium up to ~12 k, wide up to ~48 k, throughput beyond.
-  static const int N_PLANS = 5;
-  // sub-job sizes of the five splits: fixed-base terms / variable-base terms per lane, bases per table lane, points per inversion,
-  // lanes per variable-base sub-job (window split, layout.hpp vsplit_lo); mp_set_plan_params changes them (results do not)
+  // Six static work splits per table, identical results.  Sub-job sizes (PlanParams below): fixed-base / variable-base terms per lane,
+  // bases per table lane, points per shared inversion, and -- since round 4 -- lanes per variable-base sub-job (window split,
+  // layout.hpp vsplit_lo: the windows of a sub-job dealt to k lanes, one fold per MSM).  Measured on an MI355X, 52 cards, proofs/s with
+  // the verify calls pipelined (profiles/r04_plan_sweep.txt):
+  //   [3] finest      1 / 1 / 2 / 4 / 1     up to ~128 proofs in flight (plus the bucket kernel for the merged verifier equation)
+  //   [5] small       1 / 8 / 2 / 4 / 8     up to ~768      (256: 83 k against 55 k on the finest split, 512: 137 k against 90 k)
+  //   [1] latency     2 / 16 / 4 / 8 / 8    up to ~1 536    (1 024: 188-200 k; round 3's 2 / 4 / 8 / 8 / 1: 122 k)
+  //   [2] medium      4 / 32 / 8 / 16 / 4   up to ~6 144    (4 096: 338 k; round 3's 4 / 16 / 16 / 32 / 1: 242-255 k)
+  //   [4] wide        4 / 64 / 32 / 32 / 16 up to ~49 152   (16 384: 454 k, 32 768: 477 k; round 3's 4 / 32 / 16 / 32 / 1: 402 k, 440 k)
+  //   [0] throughput  8 / 64 / 64 / 64 / 1  beyond: fewest operations
+  // Window lanes instead of ever smaller sub-jobs: a sub-job of T terms costs 250 doublings + 51 T additions whatever T is, so cutting
+  // 64-term jobs into 4-term jobs for 16x the lanes multiplied the doublings by 16; dealing the 51 windows to 16 lanes gives the same
+  // lanes for one extra fold (< 250 doublings) per MSM output.
+  static const int N_PLANS = 6;
   struct PlanParams {
     uint32_t fch, vch, grp, nch, vsp;
   };
@@ -148,10 +166,11 @@ struct Table : mp_table {
     // BLS12-377 (30,10) 90 -> 117 ms.)
     const uint32_t tiny_v = N <= 128 ? 1u : 2u, tiny_g = N <= 128 ? 2u : 4u;
     pprm[0] = PlanParams{FCHUNK, VCHUNK, TABLE_GROUP, NORM_CHUNK, 1};
-    pprm[1] = PlanParams{2, 4, 8, 8, 1};
-    pprm[2] = PlanParams{4, 16, 16, 32, 1};
+    pprm[1] = PlanParams{2, 16, 4, 8, 8};
+    pprm[2] = PlanParams{4, 32, 8, 16, 4};
     pprm[3] = PlanParams{1, tiny_v, tiny_g, 4, 1};
-    pprm[4] = PlanParams{4, 32, 16, 32, 1};
+    pprm[4] = PlanParams{4, 64, 32, 32, 16};
+    pprm[5] = PlanParams{1, 8, 2, 4, 8};
   }
   int set_plan_params(int plan, uint32_t fch, uint32_t vch, uint32_t grp, uint32_t nch, uint32_t vsp) override {
     if (plan < 0 || plan >= N_PLANS || !fch || !vch || !grp || grp > TABLE_GROUP || !nch || !vsp || vsp > VSPLIT_MAX) return MP_ERR_BAD_ARGUMENT;
@@ -164,31 +183,32 @@ struct Table : mp_table {
     rt::stream_sync(ctx->stream);
     return MP_OK;
   }
-  void set_plan_thresholds(size_t tiny, size_t latency, size_t medium, size_t wide) override {
+  void set_plan_thresholds(size_t tiny, size_t small, size_t latency, size_t medium, size_t wide) override {
     auto cap = [](size_t v) { return (uint32_t)std::min<size_t>(v, 0x40000000u); };
-    tiny_batch = cap(tiny); latency_batch = cap(latency); medium_batch = cap(medium); wide_batch = cap(wide);
+    tiny_batch = cap(tiny); small_batch = cap(small); latency_batch = cap(latency); medium_batch = cap(medium); wide_batch = cap(wide);
   }
   PlanSet ps[N_PLANS];        // plans with the table's own aggregate key as a fixed base
   PlanSet psk[N_PLANS];       // plans for keyed batches (per-proof aggregate key): built on first use
   bool psk_ready = false;
   DevBuf<Term> key_recode, key_tables;          // static job lists of the per-proof key tables
   uint32_t key_d_first = 0, key_t_first = 0;     // first digit slot (rho_0) / table slot (window 0) of the key machinery
-  // (crossovers measured on 52-card decks at the end of round 3, profiles/r03k_plan_sweep.txt, r03q_wide_split.txt, r03s_small_splits.txt:
-  // ~640 / ~4 000 / 12 288 / 49 152 -- the shorter transcripts and chains of small batches moved them from round 2's 768 / 4 096 / 14 336)
-  uint32_t latency_batch = 3840;                 // batches up to this size use the latency plan (mp_set_latency_batch): 4 096 proofs are the medium plan's
-  uint32_t medium_batch = 12288;                 // up to this size the medium plan (3.2 x latency_batch),
-  uint32_t wide_batch = 49152;                   // up to this size the wide plan (12.8 x latency_batch), larger ones throughput
-  uint32_t tiny_batch = 600;                     // up to this size the finest split (5/32 x latency_batch, in steps of 5)
+  // crossovers on 52-card decks (round 4, with window lanes; round 3 had 600 / 3 840 / 12 288 / 49 152 for its four finer splits)
+  uint32_t tiny_batch = 128;                     // up to this size the finest split,
+  uint32_t small_batch = 768;                    // the small split,
+  uint32_t latency_batch = 1536;                 // the latency plan (mp_set_latency_batch scales all of them),
+  uint32_t medium_batch = 6144;                  // the medium plan,
+  uint32_t wide_batch = 49152;                   // the wide plan; larger batches: throughput
   int plan_of(uint32_t B) const {
     if (forced_split >= 0 && forced_split < N_PLANS) return forced_split;
-    return B <= tiny_batch ? 3 : (B <= latency_batch ? 1 : (B <= medium_batch ? 2 : (B <= wide_batch ? 4 : 0)));
+    return B <= tiny_batch ? 3 : (B <= small_batch ? 5 : (B <= latency_batch ? 1 : (B <= medium_batch ? 2 : (B <= wide_batch ? 4 : 0))));
   }
   PlanSet& pick(uint32_t B, bool keyed = false) { return (keyed ? psk : ps)[plan_of(B)]; }
   void set_latency_batch(size_t b) override {
-    latency_batch = (uint32_t)std::min<size_t>(b, 0x20000000u);
-    medium_batch = (uint32_t)std::min<uint64_t>((uint64_t)latency_batch * 16 / 5, 0x40000000u);
-    wide_batch = (uint32_t)std::min<uint64_t>((uint64_t)latency_batch * 64 / 5, 0x40000000u);
-    tiny_batch = latency_batch / 32 * 5;
+    latency_batch = (uint32_t)std::min<size_t>(b, 0x02000000u);
+    tiny_batch = latency_batch / 12;
+    small_batch = latency_batch / 2;
+    medium_batch = latency_batch * 4;
+    wide_batch = latency_batch * 32;
   }
   uint32_t bucket_min = BUCKET_MIN;              // MSMs of at least this many variable-base terms use the bucket kernel (0 = never)
   bool toom_cook = true;        // 3 <= m <= 16: Toom-Cook instead of Karatsuba for the multi-exponentiation diagonals
@@ -363,10 +383,11 @@ struct Table : mp_table {
       return fail(MP_ERR_BAD_ARGUMENT, "fixed-base window width must be 8, 16, 20 or 21 bits");
     // windows cover the scalar field's bit length (252 bits on the STARK curve: 12 windows of 21 bits instead of 13 of 20)
     fbg = FbGeom{fb_bits, ((uint32_t)R::BITS + fb_bits - 1u) / fb_bits, (1u << fb_bits) - 1u};
+    this->fb_bits = fb_bits;
     m = m_; n = n_; N = m * n;
     point_bytes = G_::PB;
     // plan thresholds count lanes, and a proof of N cards brings ~N/52 times the lanes of a 52-card proof
-    set_latency_batch(std::max<size_t>(64, (size_t)3840 * 52 / N));
+    set_latency_batch(std::max<size_t>(24, (size_t)1536 * 52 / N));
     nwin = (uint32_t)vb_windows(R::BITS);
     default_plan_params();
     FixedBases fb{n};
@@ -537,8 +558,10 @@ struct Table : mp_table {
       nT = std::max(nT, key_t_first + nwin);
     }
     ws.fw = G_::FW;
-    ws.ns2_elems = std::max(64u, m);
+    // NS2 = the main stream's inversion scratch while `side` has NS (prove_dev: only c_A's m points are normalised there, and only
+    // batches up to overlap_max fork); the verify lane's, chain and ad-hoc workspaces never need it
     ws.ensure((uint32_t)B, nS, nP, nJ, nD, nT, nwin, stage_words_needed(), ctx->stream, d8);
+    if (&ws == &this->ws && overlap_max && B <= overlap_max) ws.NS2.alloc((size_t)m * ws.Bpad * G_::FW, ctx->stream, false);
   }
 
   // ---------------------------------------------------------------- one dependency level of group work
@@ -750,7 +773,7 @@ struct Table : mp_table {
   // written per point (-0.3 % on the default bench, A/B)
   uint32_t* wire_words(Workspace& w, uint32_t B, uint32_t decks) {
     const int plan = plan_of(B);
-    if (plan != 1 && plan != 3) return nullptr;
+    if (plan != 1 && plan != 3 && plan != 5) return nullptr;
     w.W.alloc((size_t)decks * 2 * N * (G_::PB / 4) * w.Bpad, ctx->stream, false);
     return w.W.p;
   }
@@ -964,20 +987,23 @@ struct Table : mp_table {
     const mp_keyset* kset;
     const uint32_t* kidx;
   };
-  DevBuf<uint32_t> vflag_vlane;      // the screening flag of the pipelined lane
-  uint32_t* h_vflag = nullptr;       // ... read back into page-locked memory without waiting,
-  rt::Event ev_vflag = nullptr;      // ... valid once this event has passed
+  // a pipelined verify call whose screening verdict has not been looked at yet: k_verdict_merged writes the flag straight into a
+  // page-locked host word (zero-copy; no copy call on the lane, which would make the runtime wait); it is valid once `ev` has passed
   struct Pending {
-    bool valid = false;
     VArgs v{};
-  } pend;                            // a pipelined verify call whose screening verdict has not been looked at yet
+    uint32_t* h_flag = nullptr;      // host address
+    uint32_t* d_flag = nullptr;      // the same word as the device sees it
+    rt::Event ev = nullptr;
+  };
+  std::deque<Pending> pend;          // oldest first; at most `pipeline` of them stay unexamined when a verify call returns
+  std::vector<Pending> pend_pool;    // flag words and events for reuse
   Workspace vws;                     // the verify lane's arenas (pipelined mode: a prove call uses `ws` at the same time)
   ~Table() {
-    if (ev_vflag) rt::event_destroy(ev_vflag);
-    rt::host_free(h_vflag);
+    for (auto* q : {&pend_pool}) for (auto& p_ : *q) { if (p_.ev) rt::event_destroy(p_.ev); rt::host_free(p_.h_flag); }
+    for (auto& p_ : pend) { if (p_.ev) rt::event_destroy(p_.ev); rt::host_free(p_.h_flag); }
   }
   // one pass over a batch on the context's CURRENT lane: merged = the screening equation, else equation by equation
-  void verify_pass(Workspace& w, const VArgs& v, bool merged, bool vlane) {
+  void verify_pass(Workspace& w, const VArgs& v, bool merged, bool vlane, uint32_t* host_flag = nullptr) {
     const uint32_t B = v.B;
     const bool keyed = v.keys != nullptr || v.kset != nullptr;
     const uint8_t* keys = v.keys;
@@ -1043,10 +1069,13 @@ struct Table : mp_table {
     }
     run_phase(ph, w, B, vtab_forked ? (PH_ALL & ~PH_TABLES) : PH_ALL);
     if (merged) {
-      DevBuf<uint32_t>& fl = vlane ? vflag_vlane : vflag;
-      if (!fl.n) fl.alloc(1, s);
-      rt::dzero(fl.p, 4, s);
-      VerdictMergedArgs a{w.J.p, w.direct.p, w.status.p, fl.p, w.Bpad, l.chk_merged};
+      uint32_t* fl = host_flag;      // (already zero)
+      if (!fl) {
+        if (!vflag.n) vflag.alloc(1, s);
+        rt::dzero(vflag.p, 4, s);
+        fl = vflag.p;
+      }
+      VerdictMergedArgs a{w.J.p, w.direct.p, w.status.p, fl, w.Bpad, l.chk_merged};
       MP_RUN(k_verdict_merged, C, B, 1, a);
     } else {
       VerdictArgs a{w.J.p, w.direct.p, w.status.p, w.Bpad, l.chk_first};
@@ -1060,7 +1089,7 @@ struct Table : mp_table {
   // MSM over windows x 64 lanes
   bool screens(uint32_t B, bool keyed) {
     const int plan = plan_of(B);
-    return merged_verify && (plan == 0 || plan == 2 || plan == 4 || pick(B, keyed).vmph.n_b);
+    return merged_verify && (plan != 3 || pick(B, keyed).vmph.n_b);
   }
   void verify_dev(size_t B_, const uint8_t* decks, const uint8_t* shuf, const uint8_t* proofs, int32_t* status,
                   const uint8_t* keys, const mp_keyset* kset, const uint32_t* kidx) override {
@@ -1071,23 +1100,30 @@ struct Table : mp_table {
       // Pipelined mode: the call runs on the verify lane with arenas of its own and does NOT wait for its screening verdict, so the
       // caller's next prove call overlaps it on the chip.  The verdict of call k is looked at when call k + 1 comes in (or at
       // mp_sync); only then -- and only if some proof failed the screen -- does the per-equation pass run.
-      resolve_pending();
+      resolve_pending((size_t)pipeline - 1);      // this call makes it `pipeline` unexamined ones
       reserve_ws(vws, v.B, keyed);
       rt::event_record(ctx->ev_vin, ctx->stream);
       LaneSwap lane(ctx);
       rt::stream_wait(ctx->stream, ctx->ev_vin);
-      const bool screen = screens(v.B, keyed);
-      verify_pass(vws, v, screen, true);
-      if (screen) {
-        if (!h_vflag) {
-          h_vflag = (uint32_t*)rt::host_alloc(4);
-          ev_vflag = rt::event_create();
-        }
-        rt::d2h(h_vflag, vflag_vlane.p, 4, ctx->stream);
-        rt::event_record(ev_vflag, ctx->stream);
-        pend.valid = true;
-        pend.v = v;
+      if (!screens(v.B, keyed)) {
+        verify_pass(vws, v, false, true);
+        return;
       }
+      Pending pn;
+      if (!pend_pool.empty()) {
+        pn = pend_pool.back();
+        pend_pool.pop_back();
+      } else {
+        void* dp = nullptr;
+        pn.h_flag = (uint32_t*)rt::host_alloc_mapped(4, &dp);
+        pn.d_flag = (uint32_t*)dp;
+        pn.ev = rt::event_create();
+      }
+      pn.v = v;
+      *pn.h_flag = 0;
+      pend.push_back(pn);                   // (before the launches: an exception on the way still leaves the slot owned)
+      verify_pass(vws, v, true, true, pn.d_flag);
+      rt::event_record(pn.ev, ctx->stream);
       return;
     }
     reserve_for(v.B, keyed);
@@ -1102,17 +1138,21 @@ struct Table : mp_table {
       }
     }
   }
-  void resolve_pending() {
-    if (!pend.valid) return;
-    pend.valid = false;
-    rt::event_sync(ev_vflag);
-    if (!*h_vflag) return;
-    LaneSwap lane(ctx);
-    verify_pass(vws, pend.v, false, true);      // some proof failed the screen: name the first failing check of each
-    rt::stream_sync(ctx->stream);
+  // look at the screening verdicts of all but the `keep` most recent pipelined verify calls
+  void resolve_pending(size_t keep) {
+    while (pend.size() > keep) {
+      Pending pn = pend.front();
+      pend.pop_front();
+      pend_pool.push_back(pn);
+      rt::event_sync(pn.ev);
+      if (!*pn.h_flag) continue;
+      LaneSwap lane(ctx);
+      verify_pass(vws, pn.v, false, true);      // some proof failed the screen: name the first failing check of each
+      rt::stream_sync(ctx->stream);
+    }
   }
   void flush() override {
-    resolve_pending();
+    resolve_pending(0);
     rt::stream_sync(ctx->vstream);
   }
 

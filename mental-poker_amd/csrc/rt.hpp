@@ -69,6 +69,7 @@ inline void stream_wait(Stream s, Event e) { check(hipStreamWaitEvent(s, e, 0), 
 inline void event_sync(Event e) { check(hipEventSynchronize(e), "event sync"); }
 // page-locked host memory: DMA at PCIe speed and truly asynchronous copies (pageable buffers go through the runtime's
 // bounce buffers at ~9 GB/s and block the calling thread)
+inline void mem_info(size_t* free_b, size_t* total_b) { check(hipMemGetInfo(free_b, total_b), "hipMemGetInfo"); }
 inline void* host_alloc(size_t bytes) {
   void* p = nullptr;
   check(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault), "hipHostMalloc");
@@ -76,6 +77,14 @@ inline void* host_alloc(size_t bytes) {
 }
 inline void host_free(void* p) {
   if (p) (void)hipHostFree(p);
+}
+// a page-locked host word the DEVICE can write directly (zero-copy): a kernel leaves a flag there and the host reads it after an
+// event, without a copy call in between.  *dev_ptr = the address kernels use
+inline void* host_alloc_mapped(size_t bytes, void** dev_ptr) {
+  void* p = nullptr;
+  check(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc(mapped)");
+  check(hipHostGetDevicePointer(dev_ptr, p, 0), "hipHostGetDevicePointer");
+  return p;
 }
 
 }  // namespace rt

@@ -20,6 +20,12 @@ def pytest_configure(config):
 
 def load_pkg():
     """the package directory is `mental-poker_amd` (not a valid identifier): import it by name"""
+    try:
+        # torch ships a HIP runtime of its own: it has to be in the process BEFORE libmpshuffle.so pulls in /opt/rocm's, or
+        # torch.cuda finds no GPU afterwards (bench.py imports torch first for the same reason)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     return importlib.import_module("mental-poker_amd")
 
 

@@ -77,8 +77,10 @@ def test_kernel_bodies_under_emulation_match_golden(emu, native, name):
     t = eng.table(m, n, bytes.fromhex(g["params"]), bytes.fromhex(g["pk"]))
     # a single proof takes the four-lane transcripts and group operations by default (k_fsq_*, kernels_quad.hpp); lanes = 1 forces
     # the kernels a full batch runs (one lane per proof, one lane per chain)
-    for latency_batch, lanes in ((8192, 0), (8, 0), (0, 0), (8192, 1), (0, 1), (-4, 0)):   # finest split, latency plan, throughput plan (large sub-jobs, Toom-Cook for m = 2); -4: the wide split forced
-        t.set_work_split(4 if latency_batch < 0 else -1)
+    # finest split, latency plan, throughput plan (large sub-jobs, Toom-Cook for m = 2); negative: split -latency_batch forced (wide: 16
+    # window lanes per variable-base sub-job, small: 8; medium: 4)
+    for latency_batch, lanes in ((8192, 0), (1, 0), (0, 0), (8192, 1), (0, 1), (-4, 0), (-5, 1), (-2, 1), (-5, 0)):
+        t.set_work_split(-latency_batch if latency_batch < 0 else -1)
         t.set_latency_batch(max(latency_batch, 0))
         t.set_transcript_lanes(lanes)
         t.set_group_lanes(lanes)
@@ -96,7 +98,11 @@ def test_kernel_bodies_under_emulation_match_golden(emu, native, name):
     with pytest.raises(native.NativeError):
         t.set_group_lanes(2)
     with pytest.raises(native.NativeError):
-        t.set_work_split(5)
+        t.set_work_split(6)
+    with pytest.raises(native.NativeError):
+        t.set_plan_params(2, 4, 16, 65, 8, 1)          # more than 64 bases per table lane
+    with pytest.raises(native.NativeError):
+        t.set_plan_thresholds(10, 5, 20, 30, 40)       # not ascending
     t.set_work_split(-1)
     t.set_transcript_lanes(0)
     t.set_group_lanes(0)
@@ -508,99 +514,62 @@ def test_toom_cook_and_karatsuba_give_the_same_proof(emu, name):
 def test_chain_verification_under_emulation(emu, coracle, cvn, m, n, L, T, keyed):
     """mp_verify_shuffle_chain: T tables x L dependent shuffles verified as one equation per table (every inner deck a base once);
     honest chains pass, a chain with one bad link gets exactly the per-link verifier's status words"""
-    eng = emu(cvn)
-    N, pb = m * n, eng.point_bytes
-    g0 = coracle.gen_inputs(cvn, m, n, 50)
-    params = g0["params"]
-    keys_t = [coracle.gen_inputs(cvn, m, n, 60 + t)["pk"] for t in range(T)] if keyed else [g0["pk"]] * T
-    table = eng.table(m, n, params, None if keyed else g0["pk"])
-    chain = [[coracle.gen_inputs(cvn, m, n, 70 + t)["deck"] for t in range(T)]]     # deck 0 of every table
-    proofs = []
-    for j in range(L):
-        nxt, prf = [], []
-        for t in range(T):
-            gi = coracle.gen_inputs(cvn, m, n, 100 + 10 * j + t)
-            d, p = coracle.shuffle_and_remask(cvn, m, n, params, keys_t[t], chain[j][t], gi["rho"], gi["perm"], gi["prover_seed"])
-            nxt.append(d)
-            prf.append(p)
-        chain.append(nxt)
-        proofs.append(prf)
-    decks = b"".join(b"".join(row) for row in chain)
-    pf = b"".join(b"".join(row) for row in proofs)
-    keys = b"".join(keys_t[t] for j in range(L) for t in range(T)) if keyed else None
-    eng.profile_enable(True)
-    assert table.verify_shuffle_chain(T, L, decks, pf, keys) == [0] * (L * T)
-    rep = eng.profile_report()
-    table.set_chain_max_links(2)                     # long chains are cut into sub-chains: same verdicts
-    try:
-        assert table.verify_shuffle_chain(T, L, decks, pf, keys) == [0] * (L * T)
-        eng.profile_report()
-    finally:
-        table.set_chain_max_links(0)
-    eng.profile_enable(False)
-    assert rep["k_chain_scalars"][0] == 1 and rep["k_bucket_msm"][0] == 1 and "k_var_msm" not in rep and "k_table" not in rep
-    # break link 1 of table 0 (swap in another table's proof) and one deck point of the last link of table T-1
-    bad = [row[:] for row in proofs]
-    bad[1 % L][0] = proofs[1 % L][(0 + 1) % T]
-    st = table.verify_shuffle_chain(T, L, decks, b"".join(b"".join(row) for row in bad), keys)
-    exp = []
-    for j in range(L):
-        ks = b"".join(keys_t) if keyed else None
-        row = (table.verify_shuffle_batch_keys(ks, b"".join(chain[j]), b"".join(chain[j + 1]), b"".join(bad[j])) if keyed else
-               table.verify_shuffle_batch(b"".join(chain[j]), b"".join(chain[j + 1]), b"".join(bad[j])))
-        exp += row
-    assert st == exp and st[(1 % L) * T + 0] > 0 and sum(1 for v in st if v) == 1
-    # errors that cancel between two links under equal weights are caught: the weights depend on every proof of the chain
-    tam = bytearray(decks)
-    tam[(1 * T + 0) * N * 2 * pb] ^= 1                 # first byte of deck 1 of table 0: not a curve point any more (or another one)
-    st2 = table.verify_shuffle_chain(T, L, bytes(tam), pf, keys)
-    assert st2[0 * T + 0] != 0 and st2[1 * T + 0] != 0 and all(v == 0 for i, v in enumerate(st2) if i % T != 0)
-    if keyed and L >= 2:
-        # the links of a table need not name the same key.  (i) the verifier is told another key for link 1 of table 0 than the one the
-        # link was proven under: exactly that link fails, as it does link by link; (ii) link 1 of table 0 really IS proven under
-        # another key and the verifier is told so: every link passes, although the chain equation's single key term does not apply
-        other = coracle.gen_inputs(cvn, m, n, 99)["pk"]
-        klist = [[keys_t[t] for t in range(T)] for j in range(L)]
-        klist[1][0] = other
-        mixed = b"".join(b"".join(row) for row in klist)
-        st3 = table.verify_shuffle_chain(T, L, decks, pf, mixed)
-        exp3 = []
-        for j in range(L):
-            exp3 += table.verify_shuffle_batch_keys(b"".join(klist[j]), b"".join(chain[j]), b"".join(chain[j + 1]), b"".join(proofs[j]))
-        assert st3 == exp3 and st3[1 * T + 0] != 0 and sum(1 for v in st3 if v) == 1
-        ch2 = [row[:] for row in chain]
-        pf2 = [row[:] for row in proofs]
-        for j in range(1, L):                          # table 0 from link 1 on: link 1 under `other`, the rest under the table's key again
-            gi = coracle.gen_inputs(cvn, m, n, 123 + j)
-            ch2[j + 1][0], pf2[j][0] = coracle.shuffle_and_remask(cvn, m, n, params, other if j == 1 else keys_t[0], ch2[j][0], gi["rho"],
-                                                                   gi["perm"], gi["prover_seed"])
-        st4 = table.verify_shuffle_chain(T, L, b"".join(b"".join(r) for r in ch2), b"".join(b"".join(r) for r in pf2), mixed)
-        assert st4 == [0] * (L * T)
-        # (iii) a cheating prover: link 1 of table 0 is made under the table's key but its transcript absorbs `other`, and the
-        # verifier is told `other` for that link.  Link by link the multi-exponentiation check fails (the algebra runs under
-        # `other`); a chain equation that took link 0's key for every link would accept it.
-        import mp_oracle as po
-        cv = po.CURVES[cvn]
-        with po.curve_ctx(cv):
-            w = po.point_bytes()
-            pts = [po.pt_from_wire(params[i:i + w]) for i in range(0, len(params), w)]
-            pp = po.Params(cv, m, n, pts[0], pts[1:1 + n], pts[1 + n], pts[2 + n])
-            gi = coracle.gen_inputs(cvn, m, n, 777)
-            rho = [int.from_bytes(gi["rho"][i:i + 32], "little") for i in range(0, 32 * N, 32)]
-            honest_statement = po.statement_bytes
-            po.statement_bytes = lambda pp_, pk_, d_, s_: honest_statement(pp_, po.pt_from_wire(other), d_, s_)
-            try:
-                sh, prf = po.shuffle_and_remask(pp, po.pt_from_wire(keys_t[0]), po.deck_from_bytes(chain[1][0]), rho, list(gi["perm"]), gi["prover_seed"])
-            finally:
-                po.statement_bytes = honest_statement
-            ch3 = [row[:] for row in chain]
-            pf3 = [row[:] for row in proofs]
-            ch3[2][0], pf3[1][0] = po.deck_to_bytes(sh), po.proof_to_bytes(prf)
-        for j in range(2, L):
-            gj = coracle.gen_inputs(cvn, m, n, 800 + j)
-            ch3[j + 1][0], pf3[j][0] = coracle.shuffle_and_remask(cvn, m, n, params, keys_t[0], ch3[j][0], gj["rho"], gj["perm"], gj["prover_seed"])
-        st5 = table.verify_shuffle_chain(T, L, b"".join(b"".join(r) for r in ch3), b"".join(b"".join(r) for r in pf3), mixed)
-        exp5 = []
-        for j in range(L):
-            exp5 += table.verify_shuffle_batch_keys(b"".join(klist[j]), b"".join(ch3[j]), b"".join(ch3[j + 1]), b"".join(pf3[j]))
-        assert st5 == exp5 and st5[1 * T + 0] != 0 and sum(1 for v in st5 if v) == 1
+    from chain_cases import run_chain_cases
+    run_chain_cases(emu(cvn), coracle, cvn, m, n, L, T, keyed)
+
+
+def test_emulated_window_lanes_and_pipelined_verification(emu, coracle):
+    """round 4: (a) the windows of a variable-base sub-job dealt to k lanes + one fold per MSM give the same bytes for every k;
+    (b) pipelined verify calls (mp_set_pipeline: second lane, verdict looked at `depth` calls later) give the same status words as
+    the waiting ones, including a batch whose per-equation pass is deferred, and mp_sync completes everything outstanding"""
+    import ctypes
+    cv, m, n, B = "stark", 2, 3, 3
+    eng = emu(cv)
+    ins = [coracle.gen_inputs(cv, m, n, 4100 + b) for b in range(B)]
+    g0 = ins[0]
+    t = eng.table(m, n, g0["params"], g0["pk"])
+    args = (b"".join(g["deck"] for g in ins), b"".join(g["rho"] for g in ins), [v for g in ins for v in g["perm"]],
+            b"".join(g["prover_seed"] for g in ins))
+    ref = t.shuffle_and_remask_batch(*args)
+    for g, d, p in zip(ins, [ref[0][i * len(g0["deck"]):(i + 1) * len(g0["deck"])] for i in range(B)],
+                       [ref[1][i * t.proof_bytes:(i + 1) * t.proof_bytes] for i in range(B)]):
+        assert (d, p) == coracle.shuffle_and_remask(cv, m, n, g0["params"], g0["pk"], g["deck"], g["rho"], g["perm"], g["prover_seed"])
+    for split, prm in ((2, (4, 16, 16, 32, 3)), (0, (8, 64, 64, 64, 16)), (1, (1, 2, 2, 4, 5)), (5, (1, 1, 2, 4, 2))):
+        t.set_plan_params(split, *prm)
+        t.set_work_split(split)
+        for lanes in (1, 0):
+            t.set_group_lanes(lanes)
+            assert t.shuffle_and_remask_batch(*args) == ref
+            assert t.verify_shuffle_batch(args[0], ref[0], ref[1]) == [0] * B
+    t.set_group_lanes(0)
+    # ---- pipelined verify calls through the device-pointer entry points (the emulator's "device" memory is host memory)
+    t.set_work_split(2)                                  # a split that screens with the merged equation
+    dsz, psz = len(g0["deck"]), t.proof_bytes
+    buf = lambda b: (ctypes.c_uint8 * len(b)).from_buffer_copy(b)
+    decks, good_d, good_p = buf(args[0]), buf(ref[0]), buf(ref[1])
+    bad_p = bytearray(ref[1])
+    bad_p[psz + 40] ^= 1                                 # proof 1: one bit of c_A
+    bad_p = buf(bytes(bad_p))
+    rot_d = buf(ref[0][dsz:] + ref[0][:dsz])             # every proof against its neighbour's deck
+    expect = {}
+    for name, d, p in (("good", good_d, good_p), ("badproof", good_d, bad_p), ("rotated", rot_d, good_p)):
+        expect[name] = t.verify_shuffle_batch(args[0], bytes(d), bytes(p))
+    assert expect["good"] == [0] * B and expect["badproof"][0] == 0 and expect["badproof"][1] != 0 and all(expect["rotated"])
+    addr = ctypes.addressof
+    for depth in (1, 2):
+        t.set_pipeline(depth)
+        sts = [(ctypes.c_int32 * B)(*([77] * B)) for _ in range(4)]
+        order = ["good", "badproof", "rotated", "good"]
+        srcs = {"good": (good_d, good_p), "badproof": (good_d, bad_p), "rotated": (rot_d, good_p)}
+        for st, name in zip(sts, order):
+            d, p = srcs[name]
+            t.verify_shuffle_batch_dev(B, addr(decks), addr(d), addr(p), addr(st))
+        eng.sync()                                       # deferred per-equation passes run here at the latest
+        for st, name in zip(sts, order):
+            assert list(st) == expect[name], (depth, name, list(st))
+        # the host-buffer entry points are not pipelined and may be mixed in
+        assert t.verify_shuffle_batch(args[0], ref[0], ref[1]) == [0] * B
+    t.set_pipeline(0)
+    with pytest.raises(Exception):
+        t.set_pipeline(9)
+    t.close()

@@ -1,0 +1,212 @@
+"""-m gpu: round 4 -- window lanes, pipelined verification, tables sized by free HBM, the cheating-prover chain case on the HIP build.
+Every comparison is byte-for-byte against the C++ oracle (coracle) through the C ABI; nothing here reads /root/reference."""
+import hashlib
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(coracle, cv, m, n, B, seed0):
+    ins = [coracle.gen_inputs(cv, m, n, seed0 + b) for b in range(B)]
+    args = (b"".join(g["deck"] for g in ins), b"".join(g["rho"] for g in ins), [v for g in ins for v in g["perm"]],
+            b"".join(g["prover_seed"] for g in ins))
+    return ins, args
+
+
+def _expected(coracle, cv, m, n, g0, ins):
+    d, p = [], []
+    for g in ins:
+        ed, ep = coracle.shuffle_and_remask(cv, m, n, g0["params"], g0["pk"], g["deck"], g["rho"], g["perm"], g["prover_seed"])
+        d.append(ed)
+        p.append(ep)
+    return b"".join(d), b"".join(p)
+
+
+@pytest.mark.parametrize("cv,m,n,B", [("stark", 2, 26, 5), ("stark", 4, 13, 3), ("secp256k1", 2, 7, 3), ("bls12_377", 2, 5, 2)])
+def test_window_lanes_match_oracle(mp, coracle, cv, m, n, B):
+    """the windows of a variable-base sub-job dealt to k lanes (+ one fold per MSM): same bytes as the oracle for every k, on every work
+    split, with one and with four lanes per group operation, merged and per-equation verification"""
+    eng = mp._native.Engine(cv, 0)
+    ins, args = _inputs(coracle, cv, m, n, B, 5100)
+    g0 = ins[0]
+    t = eng.table(m, n, g0["params"], g0["pk"])
+    exp = _expected(coracle, cv, m, n, g0, ins)
+    dsz = len(g0["deck"])
+    rot = exp[0][dsz:] + exp[0][:dsz]
+    for split, prm in ((2, (4, 16, 16, 32, 3)), (0, (8, 64, 64, 64, 16)), (1, (1, 2, 2, 4, 5)), (5, (1, 1, 2, 4, 2)), (4, (4, 64, 32, 32, 7)),
+                       (3, (1, 1, 2, 4, 4))):
+        t.set_plan_params(split, *prm)
+        t.set_work_split(split)
+        for lanes in (1, 0, 4):
+            t.set_group_lanes(lanes)
+            eng.profile_enable(True)
+            out = t.shuffle_and_remask_batch(*args)
+            rep = eng.profile_report()
+            eng.profile_enable(False)
+            assert (out[0], out[1]) == exp, (split, prm, lanes)
+            assert any(k.startswith("k_wfold") for k in rep), sorted(rep)
+            for merged in (True, False):
+                t.set_merged_verify(merged)
+                assert t.verify_shuffle_batch(args[0], out[0], out[1]) == [0] * B
+                st = t.verify_shuffle_batch(args[0], rot, out[1])
+                assert [eng.check_name(v) for v in st] == ["Hadamard Product (5.1)"] * B
+            t.set_merged_verify(True)
+    t.close()
+    eng.close()
+
+
+def test_default_plans_by_batch_size_match_oracle(mp, coracle):
+    """the engine's own choice of split by batch size (finest / small / latency / medium thresholds scaled down so that 2 .. 7 proofs
+    cross all of them): byte-identical outputs"""
+    cv, m, n, B = "stark", 2, 26, 7
+    eng = mp._native.Engine(cv, 0)
+    ins, args = _inputs(coracle, cv, m, n, B, 5200)
+    g0 = ins[0]
+    t = eng.table(m, n, g0["params"], g0["pk"])
+    exp = _expected(coracle, cv, m, n, g0, ins)
+    dsz, psz = len(g0["deck"]), t.proof_bytes
+    t.set_plan_thresholds(1, 2, 3, 4, 6)      # 1: finest, 2: small, 3: latency, 4: medium, 5-6: wide, 7: throughput
+    for k in range(1, B + 1):
+        sub = (args[0][:k * dsz], args[1][:k * 32 * m * n], args[2][:k * m * n], args[3][:k * 32])
+        out = t.shuffle_and_remask_batch(*sub)
+        assert out[0] == exp[0][:k * dsz] and out[1] == exp[1][:k * psz], k
+        assert t.verify_shuffle_batch(sub[0], out[0], out[1]) == [0] * k
+    t.close()
+    eng.close()
+
+
+def test_pipelined_verification_status_words(mp, coracle):
+    """mp_set_pipeline: verify calls on the second lane, verdicts examined `depth` calls later -- status words identical to the waiting
+    calls, for honest batches, a batch with one bad proof (deferred per-equation pass) and a batch in which every proof fails; prove calls
+    issued in between are unaffected; mp_sync completes everything"""
+    import torch
+    cv, m, n, B = "stark", 2, 26, 6
+    eng = mp._native.Engine(cv, 0)
+    ins, args = _inputs(coracle, cv, m, n, B, 5300)
+    g0 = ins[0]
+    t = eng.table(m, n, g0["params"], g0["pk"])
+    exp = _expected(coracle, cv, m, n, g0, ins)
+    dsz, psz = len(g0["deck"]), t.proof_bytes
+    gpu = torch.device("cuda", 0)
+    dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(gpu)
+    bad = bytearray(exp[1])
+    bad[2 * psz + 70] ^= 4
+    cases = {"good": (dev(exp[0]), dev(exp[1])), "badproof": (dev(exp[0]), dev(bytes(bad))),
+             "rotated": (dev(exp[0][dsz:] + exp[0][:dsz]), dev(exp[1]))}
+    decks = dev(args[0])
+    rho, seeds = dev(args[1]), dev(args[3])
+    perm = torch.tensor(args[2], dtype=torch.int32, device=gpu)
+    for split in (2, 0, 4):                                   # splits that screen with the merged equation
+        t.set_work_split(split)
+        t.set_pipeline(0)
+        want = {}
+        for name, (d, p) in cases.items():
+            st = torch.full((B,), 77, dtype=torch.int32, device=gpu)
+            t.verify_shuffle_batch_dev(B, decks.data_ptr(), d.data_ptr(), p.data_ptr(), st.data_ptr())
+            eng.sync()
+            want[name] = st.cpu().tolist()
+        assert want["good"] == [0] * B and want["badproof"][2] != 0 and sum(1 for v in want["badproof"] if v) == 1 and all(want["rotated"])
+        for depth in (1, 3):
+            t.set_pipeline(depth)
+            order = ["good", "badproof", "good", "rotated", "badproof", "good"]
+            sts = [torch.full((B,), 77, dtype=torch.int32, device=gpu) for _ in order]
+            od = torch.empty(B * dsz, dtype=torch.uint8, device=gpu)
+            op = torch.empty(B * psz, dtype=torch.uint8, device=gpu)
+            sp = torch.full((B,), 77, dtype=torch.int32, device=gpu)
+            for st, name in zip(sts, order):
+                d, p = cases[name]
+                t.verify_shuffle_batch_dev(B, decks.data_ptr(), d.data_ptr(), p.data_ptr(), st.data_ptr())
+                # a prove call of the next batch runs beside it (outputs of its own: nothing a pending verify reads is touched)
+                t.shuffle_and_remask_batch_dev(B, decks.data_ptr(), rho.data_ptr(), perm.data_ptr(), seeds.data_ptr(), od.data_ptr(),
+                                               op.data_ptr(), sp.data_ptr())
+            eng.sync()
+            for st, name in zip(sts, order):
+                assert st.cpu().tolist() == want[name], (split, depth, name)
+            assert sp.cpu().tolist() == [0] * B
+            assert bytes(od.cpu().numpy().tobytes()) == exp[0] and bytes(op.cpu().numpy().tobytes()) == exp[1]
+    t.set_pipeline(0)
+    t.set_work_split(-1)
+    t.close()
+    eng.close()
+
+
+def test_table_sized_by_free_hbm_gives_identical_proofs(mp, coracle):
+    """mp_table_create (fb_bits = 0): the engine picks the widest fixed-base windows the free HBM allows -- at least 16 bits on an MI355X
+    -- and the proofs are byte-identical to those of the 8-bit table and to the oracle's"""
+    cv, m, n, B = "stark", 2, 26, 4
+    eng = mp._native.Engine(cv, 0)
+    ins, args = _inputs(coracle, cv, m, n, B, 5400)
+    g0 = ins[0]
+    exp = _expected(coracle, cv, m, n, g0, ins)
+    t8 = eng.table(m, n, g0["params"], g0["pk"], fb_bits=8)
+    assert t8.fb_bits == 8
+    out8 = t8.shuffle_and_remask_batch(*args)
+    t8.close()
+    ta = eng.table(m, n, g0["params"], g0["pk"], fb_bits=0)
+    assert ta.fb_bits in (16, 20, 21), ta.fb_bits
+    outa = ta.shuffle_and_remask_batch(*args)
+    assert (outa[0], outa[1]) == (out8[0], out8[1]) == exp
+    assert ta.verify_shuffle_batch(args[0], outa[0], outa[1]) == [0] * B
+    ta.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("cvn,m,n,L,T,keyed", [("stark", 3, 2, 3, 2, True), ("stark", 2, 3, 4, 3, False)])
+def test_chain_cases_on_the_hip_engine(mp, coracle, cvn, m, n, L, T, keyed):
+    """the chain-verification cases of the emulator test on the HIP build -- among them the cheating prover whose inner link is made under
+    the table's key while its transcript absorbs another one (tested only under emulation until now)"""
+    from chain_cases import run_chain_cases
+    eng = mp._native.Engine(cvn, 0)
+    run_chain_cases(eng, coracle, cvn, m, n, L, T, keyed)
+    eng.close()
+    maps = open("/proc/self/maps").read()
+    assert "libmpshuffle.so" in maps and "libmpemu" not in maps
+
+
+def test_outputs_do_not_depend_on_batch_position_or_lane_mode(mp, coracle):
+    """a size-independent property at a size the oracle cannot cover: 3 000 proofs (medium split by default), the digest of all outputs
+    is the same on the throughput split, with window lanes 1 .. 16, and with the verify calls pipelined; every proof verifies"""
+    import torch
+    cv, m, n, B = "stark", 2, 26, 3000
+    eng = mp._native.Engine(cv, 0)
+    g0 = coracle.gen_inputs(cv, m, n, 5500)
+    t = eng.table(m, n, g0["params"], g0["pk"], fb_bits=16)
+    gpu = torch.device("cuda", 0)
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(99)
+    N = m * n
+    decks = torch.frombuffer(bytearray(g0["deck"]), dtype=torch.uint8).to(gpu).repeat(B, 1).contiguous()
+    rho = torch.randint(0, 256, (B, N, 32), dtype=torch.uint8, device=gpu, generator=gen)
+    rho[:, :, 31] &= 7
+    perm = torch.argsort(torch.rand(B, N, device=gpu, generator=gen), dim=1).to(torch.int32).contiguous()
+    seeds = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device=gpu, generator=gen)
+    od = torch.empty(B, len(g0["deck"]), dtype=torch.uint8, device=gpu)
+    op = torch.empty(B, t.proof_bytes, dtype=torch.uint8, device=gpu)
+    sp = torch.empty(B, dtype=torch.int32, device=gpu)
+    sv = torch.empty(B, dtype=torch.int32, device=gpu)
+    digests = set()
+    for split, vsp, pipe in ((-1, None, 0), (0, None, 0), (2, 1, 0), (2, 16, 0), (4, 5, 1), (-1, None, 2)):
+        if vsp is not None:
+            t.set_plan_params(split, 4, 32, 8, 16, vsp)
+        t.set_work_split(split)
+        t.set_pipeline(pipe)
+        for _ in range(2):
+            t.shuffle_and_remask_batch_dev(B, decks.data_ptr(), rho.data_ptr(), perm.data_ptr(), seeds.data_ptr(), od.data_ptr(), op.data_ptr(),
+                                           sp.data_ptr())
+            t.verify_shuffle_batch_dev(B, decks.data_ptr(), od.data_ptr(), op.data_ptr(), sv.data_ptr())
+        eng.sync()
+        assert int(sp.abs().sum().item()) == 0 and int(sv.abs().sum().item()) == 0
+        h = hashlib.sha256()
+        h.update(od.cpu().numpy().tobytes())
+        h.update(op.cpu().numpy().tobytes())
+        digests.add(h.hexdigest())
+    assert len(digests) == 1
+    # one of them against the oracle
+    b = 1234
+    tb = lambda x: bytes(x.cpu().numpy().tobytes())
+    ed, ep = coracle.shuffle_and_remask(cv, m, n, g0["params"], g0["pk"], g0["deck"], tb(rho[b]), [int(v) for v in perm[b].cpu().tolist()], tb(seeds[b]))
+    assert tb(od[b]) == ed and tb(op[b]) == ep
+    t.set_pipeline(0)
+    t.close()
+    eng.close()

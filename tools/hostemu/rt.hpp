@@ -51,8 +51,14 @@ inline float event_ms(Event a, Event b) { return (float)(*b - *a); }
 inline void launch_check(const char*) {}
 inline void stream_wait(Stream, Event) {}
 inline void event_sync(Event) {}
+inline void mem_info(size_t* free_b, size_t* total_b) { *free_b = *total_b = 0; }      // (auto-sized tables fall back to 8-bit windows)
 inline void* host_alloc(size_t bytes) { return dmalloc(bytes); }
 inline void host_free(void* p) { free(p); }
+inline void* host_alloc_mapped(size_t bytes, void** dev_ptr) {
+  void* p = dmalloc(bytes);
+  *dev_ptr = p;
+  return p;
+}
 }  // namespace rt
 }  // namespace mp
 

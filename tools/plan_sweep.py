@@ -17,6 +17,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime starts: the engine's two lanes and their side streams on queues of their own
 
 
 def main():
@@ -77,10 +78,11 @@ def main():
     assert int(st0.abs().sum().item()) == 0
     del d0
     # two output sets: with pipelining on, a verify call's inputs must stay untouched until the next verify call has been issued
-    out_decks = [torch.empty(Bmax, N * CB, dtype=torch.uint8, device=gpu) for _ in range(2)]
-    out_proofs = [torch.empty(Bmax, proof_bytes, dtype=torch.uint8, device=gpu) for _ in range(2)]
-    st_p = [torch.empty(Bmax, dtype=torch.int32, device=gpu) for _ in range(2)]
-    st_v = [torch.empty(Bmax, dtype=torch.int32, device=gpu) for _ in range(2)]
+    NSETS = max(args.pipeline, 1) + 1
+    out_decks = [torch.empty(Bmax, N * CB, dtype=torch.uint8, device=gpu) for _ in range(NSETS)]
+    out_proofs = [torch.empty(Bmax, proof_bytes, dtype=torch.uint8, device=gpu) for _ in range(NSETS)]
+    st_p = [torch.empty(Bmax, dtype=torch.int32, device=gpu) for _ in range(NSETS)]
+    st_v = [torch.empty(Bmax, dtype=torch.int32, device=gpu) for _ in range(NSETS)]
     torch.cuda.synchronize()
     state = {"i": 0}
 
@@ -89,7 +91,7 @@ def main():
         table.shuffle_and_remask_batch_dev(B, decks.data_ptr(), factors.data_ptr(), perms.data_ptr(), seeds.data_ptr(),
                                            out_decks[i].data_ptr(), out_proofs[i].data_ptr(), st_p[i].data_ptr())
         table.verify_shuffle_batch_dev(B, decks.data_ptr(), out_decks[i].data_ptr(), out_proofs[i].data_ptr(), st_v[i].data_ptr())
-        state["i"] = 1 - i
+        state["i"] = (i + 1) % NSETS
 
     rows = []
     ref = {}
@@ -110,10 +112,11 @@ def main():
             eng.sync()
             probe = time.perf_counter() - t1
             steps = max(2, min(200, int(args.seconds / max(probe, 1e-4))))
-            steps += steps & 1
+            steps += (-steps) % NSETS
             t1 = time.perf_counter()
             for _ in range(steps):
                 step(B)
+            t_host = time.perf_counter() - t1          # the calls have returned (pipelined mode: nothing waited for but the previous verdict)
             eng.sync()
             dt = time.perf_counter() - t1
             bad = sum(int((x[:B] != 0).sum().item()) for x in st_p + st_v)
@@ -123,7 +126,8 @@ def main():
             if B in ref:
                 assert sig == ref[B], "outputs differ between configurations at B=%d cfg=%s" % (B, label)
             ref[B] = sig
-            row = {"batch": B, "config": label, "proofs_per_s": round(B * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps}
+            row = {"batch": B, "config": label, "proofs_per_s": round(B * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps,
+                   "host_ms_per_step": round(1e3 * t_host / steps, 4)}
             if args.profile:
                 eng.profile_enable(True)
                 step(B)
@@ -134,9 +138,9 @@ def main():
                 row["kernels_ms_per_step"] = {k: round(v[1] / 2, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1][1])}
             rows.append(row)
             print(json.dumps(row), flush=True)
-    print("%8s %-20s %12s %10s" % ("batch", "config", "proofs/s", "ms/step"), file=sys.stderr)
+    print("%8s %-20s %12s %10s %10s" % ("batch", "config", "proofs/s", "ms/step", "host ms"), file=sys.stderr)
     for r in rows:
-        print("%8d %-20s %12.0f %10.3f" % (r["batch"], r["config"], r["proofs_per_s"], r["ms_per_step"]), file=sys.stderr)
+        print("%8d %-20s %12.0f %10.3f %10.3f" % (r["batch"], r["config"], r["proofs_per_s"], r["ms_per_step"], r["host_ms_per_step"]), file=sys.stderr)
 
 
 if __name__ == "__main__":
