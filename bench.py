@@ -147,6 +147,21 @@ def pin_to_gpu_numa_node(local):
         return {"numa_node": None, "note": "%s: %s" % (type(e).__name__, e)}
 
 
+def scaled_batch(batch, world, scaling, seed_block):
+    """proofs per rank per step and the seeding block: weak = `batch` each; strong = `batch` in total, a contiguous 1/N per rank, seeded
+    per rank-sized block of the global batch so that the bytes are those of the unsharded run of the same proofs"""
+    if scaling == "weak":
+        return batch, seed_block
+    if batch % world:
+        raise SystemExit("--scaling strong: --batch (%d) must be a multiple of the number of ranks (%d)" % (batch, world))
+    per = batch // world
+    if seed_block is None:
+        seed_block = per
+    if per % seed_block:
+        raise SystemExit("--scaling strong: --seed-block (%d) must divide the per-rank batch (%d)" % (seed_block, per))
+    return per, seed_block
+
+
 def shard_range(total, rank, world):
     """static contiguous block partition of proof indices"""
     base, rem = divmod(total, world)
@@ -312,13 +327,8 @@ def main():
     m, n = args.m, args.n
     N = m * n
     B = args.batch if args.batch is not None else (49152 if workload == "chain32" else 262144)
-    if args.scaling == "strong":
-        # the batch is the WHOLE job's: every rank takes its contiguous 1/N of the proof indices (inputs are seeded per block of the
-        # global batch, so the bytes are those of the unsharded run)
-        assert B % world == 0, "--scaling strong: --batch must be a multiple of the number of ranks"
-        if args.seed_block is None:
-            args.seed_block = B // world
-        B //= world
+    # (--scaling strong: the batch is the WHOLE job's, every rank takes its contiguous 1/N of the proof indices)
+    B, args.seed_block = scaled_batch(B, world, args.scaling, args.seed_block)
     if args.fb_bits is None:
         # widest fixed-base windows whose tables ((n + 5) bases x windows x (2^bits - 1) entries) stay below 30 % of this GPU's HBM:
         # 21 bits (48 GB) at n = 26 on the STARK curve, 20 bits elsewhere, 16 bits for the 1024-card shapes (n >= 64)

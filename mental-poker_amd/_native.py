@@ -71,7 +71,8 @@ def build(verbose=False):
 
     def compile_check():
         """tools/quadcheck/quad_check: on-device unit test of the four-lane group law (kernels_quad.hpp) against the one-lane one;
-        built here so that it travels to the GPU box with the library (tests/test_gpu_parity.py runs it)"""
+        built here so that it travels to the GPU box with the library (tests/test_gpu_parity.py runs it).  A test tool: its failure to
+        build is reported, never the library's"""
         src = os.path.join(ROOT, "tools", "quadcheck", "quad_check.hip")
         exe = os.path.join(ROOT, "tools", "quadcheck", "quad_check")
         if not os.path.exists(src) or (os.path.exists(exe) and os.path.getmtime(exe) >= max(hdr_time, os.path.getmtime(src))):
@@ -79,7 +80,10 @@ def build(verbose=False):
         cmd = [hipcc] + [f for f in flags if f != "-fPIC"] + ["-I", csrc, src, "-o", exe]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        try:
+            subprocess.check_call(cmd)
+        except (subprocess.CalledProcessError, OSError) as e:
+            print("warning: tools/quadcheck/quad_check did not build (%s); the library is unaffected" % e, flush=True)
 
     with ThreadPoolExecutor(max_workers=len(SOURCES) + 1) as ex:
         chk = ex.submit(compile_check)

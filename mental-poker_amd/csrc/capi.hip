@@ -114,41 +114,39 @@ int mp_ctx_create(int curve_id, int device, mp_ctx** out) {
   c->curve = curve_id;
   c->device = device;
   // The runtime deals HIP streams to a small number of hardware queues round robin in creation order (4 by default, GPU_MAX_HW_QUEUES),
-  // and streams that share a queue do not overlap: the four compute streams -- the two lanes and their side streams -- come first so
-  // that they land on different queues; the copy streams of the host-buffer entry points share with them
+  // and streams that share a queue do not overlap.  Only the two streams every call uses are created here; the copy streams of the
+  // host-buffer entry points and the verify lane of pipelined mode follow on first use (ensure_io_streams / ensure_verify_lane), so
+  // that a caller of either kind gets four streams on four queues
   c->stream = rt::stream_create();
-  c->vstream = rt::stream_create();
   c->side = rt::stream_create();
-  c->vside = rt::stream_create();
-  c->h2d = rt::stream_create();
-  c->d2h = rt::stream_create();
   c->ev_fork = rt::event_create();
   c->ev_shuf = rt::event_create();
   c->ev_tab = rt::event_create();
-  c->ev_vfork = rt::event_create();
-  c->ev_vshuf = rt::event_create();
-  c->ev_vtab = rt::event_create();
-  c->ev_vin = rt::event_create();
   *out = c;
   return MP_OK;
   MP_CATCH
 }
 void mp_ctx_destroy(mp_ctx* ctx) {
   if (!ctx) return;
-  rt::stream_destroy(ctx->stream);
-  rt::stream_destroy(ctx->h2d);
-  rt::stream_destroy(ctx->d2h);
-  rt::stream_destroy(ctx->side);
-  rt::event_destroy(ctx->ev_fork);
-  rt::event_destroy(ctx->ev_shuf);
-  rt::event_destroy(ctx->ev_tab);
-  rt::stream_destroy(ctx->vstream);
-  rt::stream_destroy(ctx->vside);
-  rt::event_destroy(ctx->ev_vfork);
-  rt::event_destroy(ctx->ev_vshuf);
-  rt::event_destroy(ctx->ev_vtab);
-  rt::event_destroy(ctx->ev_vin);
+  for (rt::Stream st : {ctx->stream, ctx->side, ctx->h2d, ctx->d2h, ctx->vstream, ctx->vside})
+    if (st) rt::stream_destroy(st);
+  for (rt::Event e : {ctx->ev_fork, ctx->ev_shuf, ctx->ev_tab, ctx->ev_vfork, ctx->ev_vshuf, ctx->ev_vtab, ctx->ev_vin})
+    if (e) rt::event_destroy(e);
   delete ctx;
+}
+static void ensure_io_streams(mp_ctx* c) {
+  if (c->h2d) return;
+  c->h2d = rt::stream_create();
+  c->d2h = rt::stream_create();
+}
+static void ensure_verify_lane(mp_ctx* c) {
+  if (c->vstream) return;
+  c->vstream = rt::stream_create();
+  c->vside = rt::stream_create();
+  c->ev_vfork = rt::event_create();
+  c->ev_vshuf = rt::event_create();
+  c->ev_vtab = rt::event_create();
+  c->ev_vin = rt::event_create();
 }
 
 int mp_setup(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out_params) {
@@ -290,6 +288,7 @@ int mp_set_pipeline(mp_table* t, int depth) {
   MP_TRY
   rt::set_device(t->ctx->device);
   if (depth < 0 || depth > 8) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_pipeline: depth 0 (off) .. 8");
+  if (depth) ensure_verify_lane(t->ctx);
   t->flush();
   t->pipeline = depth;
   return MP_OK;
@@ -441,14 +440,8 @@ int mp_verify_shuffle_chain_dev(mp_table* t, size_t tables, uint32_t links, cons
   // verified as consecutive sub-chains (the decks array is link-major, so a sub-chain is a contiguous slice)
   const size_t per_link = (size_t)2 * t->N + 11 * t->m + 8, fixed_part = (size_t)2 * t->N + 1;
   const size_t pb = t->point_bytes, deck_bytes = (size_t)2 * t->N * pb, psz = proof_size_bytes(t->m, t->n, (uint32_t)pb);
-  if (fixed_part + per_link > 32767) {
-    // not even one link fits a chain equation (decks of ~8 000 cards and more): there is nothing to share, verify link by link
-    for (uint32_t j = 0; j < links; ++j)
-      t->verify_dev(tables, (const uint8_t*)d_decks + (size_t)j * tables * deck_bytes, (const uint8_t*)d_decks + (size_t)(j + 1) * tables * deck_bytes,
-                    (const uint8_t*)d_proofs + (size_t)j * tables * psz, (int32_t*)d_status + (size_t)j * tables,
-                    d_keys ? (const uint8_t*)d_keys + (size_t)j * tables * pb : nullptr, nullptr, nullptr);
-    return MP_OK;
-  }
+  // (one link always fits: 4N + 11m + 9 <= 32 767 for every table mp_table_create accepts, m n <= 4096)
+  if (fixed_part + per_link > 32767) return fail(MP_ERR_INTERNAL, "mp_verify_shuffle_chain_dev: deck too large for one chain equation");
   uint32_t lmax = (uint32_t)((32767 - fixed_part) / per_link);
   if (t->chain_max_links) lmax = std::max(1u, std::min(lmax, t->chain_max_links));
   for (uint32_t j0 = 0; j0 < links; j0 += lmax) {
@@ -499,6 +492,28 @@ int mp_sync(mp_ctx* ctx) {
 // (PCIe is full duplex).  Staging buffers are persistent (two chunks in flight).  With page-locked caller buffers
 // (mp_host_alloc) every copy is an asynchronous DMA; with pageable buffers the runtime stages them and the overlap is partial.
 static const size_t IO_CHUNK = 65536;   // default proofs per chunk: the kernels need ~64 k lanes to run at full rate
+// The chunks of one call: full chunks in the middle, a ramp of C/8 and 3C/8 at either end -- the first upload and the last download
+// are the only transfers nothing overlaps, so the first and the last chunk are small (262 144 proofs: 22 + 34 ms of exposed copies per
+// prove call with four equal chunks, 3 + 4 ms with the ramp, for ~15 ms of less efficient small-batch kernels).  Calls of less
+// than three chunks are cut evenly as before.
+static std::vector<size_t> io_schedule(size_t B, size_t C) {
+  std::vector<size_t> v;
+  if (B < 2 * C || C < 8) {
+    for (size_t o = 0; o < B; o += C) v.push_back(std::min(C, B - o));
+    return v;
+  }
+  const size_t r0 = C / 8, r1 = 3 * C / 8;
+  v.push_back(r0);
+  v.push_back(r1);
+  for (size_t left = B - 2 * (r0 + r1); left;) {
+    const size_t c = std::min(C, left);
+    v.push_back(c);
+    left -= c;
+  }
+  v.push_back(r1);
+  v.push_back(r0);
+  return v;
+}
 static void io_events(mp_io_stage& st) {
   if (!st.up) {
     st.up = rt::event_create();
@@ -515,9 +530,14 @@ static int prove_batch_host(mp_table* t, size_t B, const uint8_t* keys, const ui
   if (t->keyless && !keys) return fail(MP_ERR_BAD_ARGUMENT, "this table has no aggregate key: use the _keys entry points");
   MP_TRY
   rt::set_device(t->ctx->device);
+  ensure_io_streams(t->ctx);
   rt::Stream s = t->ctx->stream, up = t->ctx->h2d, down = t->ctx->d2h;
   const size_t N = t->N, psz = proof_size_bytes(t->m, t->n, t->point_bytes), dsz = N * 2 * t->point_bytes;
-  const size_t chunk = std::min(B, t->io_chunk ? t->io_chunk : IO_CHUNK), nchunks = (B + chunk - 1) / chunk;
+  const size_t chunk = std::min(B, t->io_chunk ? t->io_chunk : IO_CHUNK);
+  const std::vector<size_t> sched = io_schedule(B, chunk);
+  std::vector<size_t> first(sched.size() + 1, 0);
+  for (size_t k = 0; k < sched.size(); ++k) first[k + 1] = first[k] + sched[k];
+  const size_t nchunks = sched.size();
   for (auto& st : t->io) {
     io_events(st);
     st.used = false;
@@ -528,7 +548,7 @@ static int prove_batch_host(mp_table* t, size_t B, const uint8_t* keys, const ui
   }
   auto upload = [&](size_t k) {
     mp_io_stage& st = t->io[k & 1];
-    const size_t o = k * chunk, c = std::min(chunk, B - o);
+    const size_t o = first[k], c = sched[k];
     if (st.used) rt::stream_wait(up, st.done);          // the kernels of chunk k-2 have consumed these buffers
     rt::h2d(st.in0.p, decks + o * dsz, c * dsz, up);
     rt::h2d(st.in1.p, masking_factors + o * N * 32, c * N * 32, up);
@@ -540,7 +560,7 @@ static int prove_batch_host(mp_table* t, size_t B, const uint8_t* keys, const ui
   upload(0);
   for (size_t k = 0; k < nchunks; ++k) {
     mp_io_stage& st = t->io[k & 1];
-    const size_t o = k * chunk, c = std::min(chunk, B - o);
+    const size_t o = first[k], c = sched[k];
     rt::stream_wait(s, st.up);
     if (st.used) rt::stream_wait(s, st.down);            // results of chunk k-2 have left the output buffers
     t->prove_dev(c, st.in0.p, st.in1.p, st.perm.p, st.in2.p, st.out0.p, st.out1.p, st.status.p, keys ? st.keys.p : nullptr);
@@ -565,9 +585,14 @@ static int verify_batch_host(mp_table* t, size_t B, const uint8_t* keys, const u
   MP_TRY
   rt::set_device(t->ctx->device);
   NoPipeline nopipe(t);
+  ensure_io_streams(t->ctx);
   rt::Stream s = t->ctx->stream, up = t->ctx->h2d, down = t->ctx->d2h;
   const size_t N = t->N, psz = proof_size_bytes(t->m, t->n, t->point_bytes), dsz = N * 2 * t->point_bytes;
-  const size_t chunk = std::min(B, t->io_chunk ? t->io_chunk : IO_CHUNK), nchunks = (B + chunk - 1) / chunk;
+  const size_t chunk = std::min(B, t->io_chunk ? t->io_chunk : IO_CHUNK);
+  const std::vector<size_t> sched = io_schedule(B, chunk);
+  std::vector<size_t> first(sched.size() + 1, 0);
+  for (size_t k = 0; k < sched.size(); ++k) first[k + 1] = first[k] + sched[k];
+  const size_t nchunks = sched.size();
   for (auto& st : t->io) {
     io_events(st);
     st.used = false;
@@ -577,7 +602,7 @@ static int verify_batch_host(mp_table* t, size_t B, const uint8_t* keys, const u
   }
   auto upload = [&](size_t k) {
     mp_io_stage& st = t->io[k & 1];
-    const size_t o = k * chunk, c = std::min(chunk, B - o);
+    const size_t o = first[k], c = sched[k];
     if (st.used) rt::stream_wait(up, st.done);
     rt::h2d(st.in0.p, decks + o * dsz, c * dsz, up);
     rt::h2d(st.in3.p, shuffled_decks + o * dsz, c * dsz, up);
@@ -588,7 +613,7 @@ static int verify_batch_host(mp_table* t, size_t B, const uint8_t* keys, const u
   upload(0);
   for (size_t k = 0; k < nchunks; ++k) {
     mp_io_stage& st = t->io[k & 1];
-    const size_t o = k * chunk, c = std::min(chunk, B - o);
+    const size_t o = first[k], c = sched[k];
     if (k + 1 < nchunks) upload(k + 1);                  // before verify_dev: it ends with a read-back of the screening flag
     rt::stream_wait(s, st.up);
     if (st.used) rt::stream_wait(s, st.down);

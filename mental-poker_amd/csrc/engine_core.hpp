@@ -116,8 +116,7 @@ struct Workspace {
     }
     if (Bpad != need) {
       Bpad = need;
-      rt::dzero(J.p, (size_t)nJ * Bpad * 3 * fw * sizeof(uint32_t), s);
-      if (d8_bytes) rt::dzero(D8.p, (size_t)d8_bytes * Bpad, s);
+      rt::dzero(J.p, (size_t)nJ * Bpad * 3 * fw * sizeof(uint32_t), s);      // (the bucket digits D8 are proof-major: no stride in them)
     }
   }
 };
@@ -1153,7 +1152,7 @@ struct Table : mp_table {
   }
   void flush() override {
     resolve_pending(0);
-    rt::stream_sync(ctx->vstream);
+    if (ctx->vstream) rt::stream_sync(ctx->vstream);
   }
 
 

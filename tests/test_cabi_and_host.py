@@ -136,6 +136,15 @@ def test_emulated_chunked_host_pipeline(emu, coracle):
     swapped = ref[1][ps:2 * ps] + ref[1][:ps] + ref[1][2 * ps:]     # proofs 0 and 1 exchanged: both fail, the other chunks pass
     st = t.verify_shuffle_batch(args[0], ref[0], swapped)
     assert st[0] > 0 and st[1] > 0 and st[2:] == [0] * 3
+    # a call of three chunks and more ramps up and down (C/8, 3C/8, C ..., 3C/8, C/8): 27 proofs in chunks of 8 = 1 3 8 8 3 1 + ragged 3
+    ins2 = [coracle.gen_inputs(cv, m, n, 900 + b % 3) for b in range(27)]
+    args2 = (b"".join(g["deck"] for g in ins2), b"".join(g["rho"] for g in ins2), [v for g in ins2 for v in g["perm"]],
+             b"".join(g["prover_seed"] for g in ins2))
+    t.set_io_chunk(0)
+    ref2 = t.shuffle_and_remask_batch(*args2)
+    t.set_io_chunk(8)
+    assert t.shuffle_and_remask_batch(*args2) == ref2
+    assert t.verify_shuffle_batch(args2[0], ref2[0], ref2[1]) == [0] * 27
     t.set_io_chunk(0)
     t.close()
 

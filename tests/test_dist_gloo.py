@@ -35,6 +35,8 @@ def _worker(rank, world, port, q):
     rows = bench.gather_rows([hi - lo, rank, 0.5], dev)
     assert rows == [[501.0, 0.0, 0.5], [500.0, 1.0, 0.5]]
     assert bench.gather_objects({"r": rank}) == [{"r": 0}, {"r": 1}]
+    smoke = bench.rccl_smoke(dist, dev)                  # tools/rccl_smoke.py: what bench.py runs first when WORLD_SIZE > 1
+    assert smoke["rccl_world"] == world and all(k in smoke for k in ("broadcast_parameters_ms", "all_gather_rows_ms", "all_reduce_max_ms", "barrier_ms"))
     q.put((rank, got == bytes(range(256)) * 7, (lo, hi), t, s))
     dist.barrier()
     dist.destroy_process_group()
@@ -55,6 +57,49 @@ def test_world_size_two_gloo():
     assert res[0][2] == (0, 501) and res[1][2] == (501, 1001)
     assert res[0][3] == res[1][3] == 2.0
     assert res[0][4] == res[1][4] == 1001.0
+
+
+def test_strong_scaling_batches():
+    """--scaling strong: the batch is the job's; ranks get equal contiguous parts, seeded per part (the unsharded run seeds per the same
+    blocks, so the bytes agree: tests/test_gpu_bench.py); weak keeps the batch per rank"""
+    import bench
+    import pytest
+    assert bench.scaled_batch(262144, 8, "weak", None) == (262144, None)
+    assert bench.scaled_batch(262144, 8, "strong", None) == (32768, 32768)
+    assert bench.scaled_batch(384, 2, "strong", 96) == (192, 96)
+    assert bench.scaled_batch(384, 1, "strong", 192) == (384, 192)
+    with pytest.raises(SystemExit):
+        bench.scaled_batch(100, 8, "strong", None)
+    with pytest.raises(SystemExit):
+        bench.scaled_batch(384, 2, "strong", 100)
+    # rank r of a strong run seeds block (r * per) // seed_block + k: the blocks of the global batch in order
+    per, sb = bench.scaled_batch(384, 2, "strong", None)
+    assert [(r * per) // sb + k for r in range(2) for k in range(per // sb)] == [0, 1]
+
+
+def test_rccl_smoke_names_the_failing_call():
+    """a collective that misbehaves is reported by name (tools/rccl_smoke.py), not as a hang or a bare stack trace"""
+    import importlib.util
+    import pytest
+    spec = importlib.util.spec_from_file_location("rccl_smoke", os.path.join(ROOT, "tools", "rccl_smoke.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    class Broken:
+        class ReduceOp:
+            MAX = 0
+
+        def get_rank(self):
+            return 0
+
+        def get_world_size(self):
+            return 2
+
+        def broadcast(self, t, src):
+            raise RuntimeError("NCCL error: unhandled system error")
+    with pytest.raises(mod.CollectiveCheckFailed) as ei:
+        mod.run_checks(Broken(), torch.device("cpu"))
+    assert "broadcast_parameters failed" in str(ei.value) and "unhandled system error" in str(ei.value)
 
 
 def test_shard_range_covers_everything():

@@ -41,6 +41,19 @@ def test_self_launch_two_ranks_equals_unsharded():
     assert single["config"]["parity_vs_oracle"] is True and sharded["config"]["parity_vs_oracle"] is True
 
 
+def test_strong_scaling_two_ranks_equals_unsharded():
+    """--scaling strong: 384 proofs in total, 192 per rank; digests equal those of the unsharded run of the same 384 proofs; the line says
+    "strong" and carries the timings of the collectives checked before any table was built (tools/rccl_smoke.py)"""
+    strong = run_bench("--gpus", "2", "--scaling", "strong", "--batch", "384", *COMMON, env={"MP_BENCH_FORCE_DEVICE": "0", "MP_BENCH_BACKEND": "gloo"})
+    assert strong["n_gpus"] == 2 and strong["scaling"] == "strong"
+    assert strong["config"]["per_rank_proofs"] == [192, 192] and strong["config"]["per_rank_failed"] == [0, 0]
+    assert strong["config"]["rccl_smoke"]["rccl_world"] == 2 and strong["config"]["rccl_smoke"]["broadcast_parameters_ms"] >= 0
+    single = run_bench("--gpus", "1", "--batch", "384", *COMMON)
+    assert single["scaling"] == "weak" and single["config"]["rccl_smoke"] is None
+    flat = [d for per_rank in strong["config"]["digests"] for d in per_rank]
+    assert flat == single["config"]["digests"][0] and len(flat) == 2
+
+
 def test_json_line_contract_and_extras():
     d = run_bench("--batch", "16384", "--steps", "2", "--warmup", "1", "--fb-bits", "8", "--cpu-iters", "2")      # (throughput plan: > 14 336 proofs)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -57,6 +70,21 @@ def test_json_line_contract_and_extras():
     assert c["frac_at_measured_clock"] is None or c["frac_at_measured_clock"] <= 1
     assert d["config"]["rccl_world"] == 1 and d["config"]["table_build_s"] > 0 and d["config"]["hbm_per_rank_gb"] > 0
     assert d["config"]["per_equation_value"] > 0 and d["config"]["keyed_value"] > 0
+    # round 4: the reference-shaped calls beside the headline (host-buffer API incl. PCIe; a table from plain mp_table_create)
+    api = d["config"]["api_host_value"]["16384"]
+    assert api["pinned"] > 0 and api["pageable"] > 0
+    assert d["config"]["default_table_value"] > 0 and d["config"]["default_table_window_bits"] in (16, 20, 21)
+
+
+def test_batch_curve_on_the_line():
+    """config.batch_curve: proofs/s with 1 024 .. 32 768 proofs in flight, serial and with the verify calls pipelined, measured after the
+    timed region on the benchmarked table"""
+    d = run_bench("--batch", "32768", "--steps", "1", "--warmup", "1", "--fb-bits", "16", "--no-cpu-baseline")
+    bc = d["config"]["batch_curve"]
+    assert sorted(bc, key=int) == ["1024", "4096", "16384", "32768"]
+    for k, v in bc.items():
+        assert v["serial"] > 0 and v["pipelined"] > 0
+    assert bc["32768"]["serial"] > bc["1024"]["serial"]
 
 
 @pytest.mark.parametrize("workload,extra", [("chain32", ["--batch", "256", "--players", "4"]),

@@ -14,7 +14,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 mp = importlib.import_module("mental-poker_amd")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 m, n, B = 2, 26, int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+CHUNK = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 N = m * n
 eng = mp.Engine("stark", 0)
 params = eng.setup(m, n, bytes([1] * 32))
@@ -22,6 +24,8 @@ pk = eng.setup(m, 2, bytes([2] * 32))[:64]
 base = eng.setup(m, 2 * N - 3, bytes([3] * 32))
 t = eng.table(m, n, params, pk, fb_bits=21)
 lib = t.lib
+if CHUNK:
+    t.set_io_chunk(CHUNK)
 rng = np.random.default_rng(1)
 src = dict(rho=rng.integers(0, 256, size=(B, N, 32), dtype=np.uint8), perms=np.argsort(rng.random((B, N)), axis=1).astype(np.uint32),
            seeds=rng.integers(0, 256, size=(B, 32), dtype=np.uint8), decks=np.frombuffer(base, dtype=np.uint8)[None, :].repeat(B, 0))
@@ -40,7 +44,7 @@ def ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-for kind in ("pageable", "page-locked"):
+for kind in (("page-locked",) if CHUNK else ("pageable", "page-locked")):
     held = []
     if kind == "pageable":
         a = dict(src)
@@ -69,9 +73,15 @@ for kind in ("pageable", "page-locked"):
         run()
     dt = time.perf_counter() - t0
     assert not o["st"].any() and not o["st2"].any()
+    eng.profile_enable(True)
+    run()
+    rep = eng.profile_report()
+    eng.profile_enable(False)
+    print("   kernel time of one batch (HIP events): %.1f ms; largest: %s" % (sum(v[1] for v in rep.values()),
+          ", ".join("%s %.1f" % (k, v[1]) for k, v in sorted(rep.items(), key=lambda kv: -kv[1][1])[:5])))
     nbytes = N * 128 * 4 + N * 36 + 32 + 2 * t.proof_bytes
-    print("host-buffer API, %-11s buffers, B=%d: %.0f proofs/s (%.1f ms per batch), %.2f GB/s over PCIe"
-          % (kind, B, B * K / dt, 1e3 * dt / K, B * K * nbytes / dt / 1e9))
+    print("host-buffer API, %-11s buffers, B=%d chunk=%d: %.0f proofs/s (%.1f ms per batch), %.2f GB/s over PCIe"
+          % (kind, B, CHUNK or 65536, B * K / dt, 1e3 * dt / K, B * K * nbytes / dt / 1e9))
     del a, o
     for p in held:
         lib.mp_host_free(p)
