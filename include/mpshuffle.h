@@ -289,6 +289,17 @@ int mp_params_serialize(int curve_id, uint32_t m, uint32_t n, const uint8_t* raw
 int mp_params_deserialize(int curve_id, const uint8_t* data, size_t len, size_t max_n, uint32_t* m, uint32_t* n, uint8_t* out_raw_params);
 int mp_proof_serialize(int curve_id, uint32_t m, uint32_t n, const uint8_t* proof_wire, uint8_t* out);
 int mp_proof_deserialize(int curve_id, uint32_t m, uint32_t n, const uint8_t* data, size_t len, uint8_t* out_proof_wire);
+/* The same conversion ON THE DEVICE for the bulk data (round 4): decks that arrive as arkworks bytes go to HBM as they are -- half the
+ * bytes of wire v1 over PCIe -- and are decompressed there, one lane per point, the square root as a windowed walk through the 2-Sylow
+ * subgroup of the base field (4 512 squarings on the STARK prime, whose p - 1 has 2-adicity 192; the host path needs ~10^4), with the
+ * validation of the host functions above: canonical x, flags, x on the curve, prime-order subgroup where there is a cofactor.  All
+ * pointers are DEVICE pointers; the kernel is enqueued on the context's stream (mp_sync, or any later call on the context, orders
+ * behind it).  d_status receives 0 or MP_ERR_BAD_ENCODING: one int32 per point (mp_points_deserialize_dev: `count` compressed points
+ * back to back) / per deck (mp_deck_deserialize_dev: `decks` serialised Vec<MaskedCard> of `cards` cards each, back to back, every
+ * one mp_serialized_deck_size bytes with its u64 length in front); a failing point leaves an all-zero wire point.  The output of
+ * mp_deck_deserialize_dev is what mp_shuffle_and_remask_batch_dev / mp_verify_shuffle_batch_dev take as d_decks. */
+int mp_points_deserialize_dev(mp_ctx* ctx, size_t count, const void* d_data, void* d_out_wire_points, void* d_status);
+int mp_deck_deserialize_dev(mp_ctx* ctx, size_t decks, size_t cards, const void* d_data, void* d_out_wire_decks, void* d_status);
 
 /* ---- measurement hooks ---------------------------------------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by HIP events on the context's stream;

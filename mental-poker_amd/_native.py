@@ -26,7 +26,7 @@ SYMBOLS = [
     "mp_sigma_verify_batch", "mp_blake2s",
     "mp_serialized_point_size", "mp_serialized_deck_size", "mp_serialized_params_size", "mp_serialized_proof_size",
     "mp_points_serialize", "mp_points_deserialize", "mp_deck_serialize", "mp_deck_deserialize", "mp_params_serialize",
-    "mp_params_deserialize", "mp_proof_serialize", "mp_proof_deserialize",
+    "mp_params_deserialize", "mp_proof_serialize", "mp_proof_deserialize", "mp_points_deserialize_dev", "mp_deck_deserialize_dev",
 ]
 
 
@@ -193,6 +193,8 @@ def bind(cdll):
     cdll.mp_deck_deserialize.argtypes = [c.c_int, u8p, c.c_size_t, c.c_size_t, u8p, c.POINTER(c.c_size_t)]
     cdll.mp_params_serialize.argtypes = [c.c_int, c.c_uint32, c.c_uint32, u8p, u8p]
     cdll.mp_params_deserialize.argtypes = [c.c_int, u8p, c.c_size_t, c.c_size_t, c.POINTER(c.c_uint32), c.POINTER(c.c_uint32), u8p]
+    cdll.mp_points_deserialize_dev.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p, c.c_void_p, c.c_void_p]
+    cdll.mp_deck_deserialize_dev.argtypes = [c.c_void_p, c.c_size_t, c.c_size_t, c.c_void_p, c.c_void_p, c.c_void_p]
     cdll.mp_proof_serialize.argtypes = [c.c_int, c.c_uint32, c.c_uint32, u8p, u8p]
     cdll.mp_proof_deserialize.argtypes = [c.c_int, c.c_uint32, c.c_uint32, u8p, c.c_size_t, u8p]
     return cdll
@@ -342,6 +344,14 @@ class Engine:
 
     def sync(self):
         self._chk(self.lib.mp_sync(self.h))
+
+    def points_deserialize_dev(self, count, d_data, d_out_wire, d_status):
+        """compressed arkworks points in device memory -> wire v1 in device memory; d_status: one int32 per point"""
+        self._chk(self.lib.mp_points_deserialize_dev(self.h, count, d_data, d_out_wire, d_status))
+
+    def deck_deserialize_dev(self, decks, cards, d_data, d_out_wire_decks, d_status):
+        """`decks` serialised Vec<MaskedCard> of `cards` cards each (device memory) -> wire decks; d_status: one int32 per deck"""
+        self._chk(self.lib.mp_deck_deserialize_dev(self.h, decks, cards, d_data, d_out_wire_decks, d_status))
 
     def profile_enable(self, on=True):
         self._chk(self.lib.mp_profile_enable(self.h, 1 if on else 0))

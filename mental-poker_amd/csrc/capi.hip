@@ -834,6 +834,27 @@ int mp_params_deserialize(int curve_id, const uint8_t* data, size_t len, size_t 
   *n = (uint32_t)nn;
   return MP_OK;
 }
+// ---- on-device decompression: compressed arkworks points in HBM -> wire v1 in HBM (kernels_decompress.hpp)
+static int decompress_dev(mp_ctx* ctx, size_t groups, uint32_t per_group, uint32_t prefix, const void* d_in, void* d_out, void* d_status) {
+  MP_TRY
+  rt::set_device(ctx->device);
+  switch (ctx->curve) {
+    case 0: return decompress_dev_Stark(ctx, groups, per_group, prefix, (const uint8_t*)d_in, (uint8_t*)d_out, (int32_t*)d_status);
+    case 1: return decompress_dev_Bn254(ctx, groups, per_group, prefix, (const uint8_t*)d_in, (uint8_t*)d_out, (int32_t*)d_status);
+    case 3: return decompress_dev_Bls12_377(ctx, groups, per_group, prefix, (const uint8_t*)d_in, (uint8_t*)d_out, (int32_t*)d_status);
+    default: return decompress_dev_Secp256k1(ctx, groups, per_group, prefix, (const uint8_t*)d_in, (uint8_t*)d_out, (int32_t*)d_status);
+  }
+  MP_CATCH
+}
+int mp_points_deserialize_dev(mp_ctx* ctx, size_t count, const void* d_data, void* d_out_wire_points, void* d_status) {
+  if (!ctx || !count || !d_data || !d_out_wire_points || !d_status) return fail(MP_ERR_BAD_ARGUMENT, "mp_points_deserialize_dev: bad argument");
+  return decompress_dev(ctx, count, 1, 0, d_data, d_out_wire_points, d_status);
+}
+int mp_deck_deserialize_dev(mp_ctx* ctx, size_t decks, size_t cards, const void* d_data, void* d_out_wire_decks, void* d_status) {
+  if (!ctx || !decks || !cards || cards > 4096 || !d_data || !d_out_wire_decks || !d_status)
+    return fail(MP_ERR_BAD_ARGUMENT, "mp_deck_deserialize_dev: bad argument");
+  return decompress_dev(ctx, decks, (uint32_t)(2 * cards), 8, d_data, d_out_wire_decks, d_status);
+}
 int mp_proof_serialize(int curve_id, uint32_t m, uint32_t n, const uint8_t* proof_wire, uint8_t* out) {
   if (!curve_ok(curve_id) || !proof_wire || !out || m < 2 || n < 2) return fail(MP_ERR_BAD_ARGUMENT, "mp_proof_serialize: bad argument");
   const size_t pb = mp_point_size(curve_id), cb = mp_serialized_point_size(curve_id);

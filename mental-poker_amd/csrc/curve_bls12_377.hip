@@ -3,5 +3,6 @@
 namespace mp {
 MP_MSM_KERNELS(extern template, Bls12_377)
 MP_BUCKET_KERNELS(extern template, Bls12_377)
+MP_DECOMPRESS_KERNELS(extern template, Bls12_377)
 }
 MP_DEFINE_CURVE(Bls12_377)

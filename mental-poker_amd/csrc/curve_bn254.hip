@@ -3,5 +3,6 @@
 namespace mp {
 MP_MSM_KERNELS(extern template, Bn254)
 MP_BUCKET_KERNELS(extern template, Bn254)
+MP_DECOMPRESS_KERNELS(extern template, Bn254)
 }
 MP_DEFINE_CURVE(Bn254)

@@ -3,5 +3,6 @@
 namespace mp {
 MP_MSM_KERNELS(extern template, Secp256k1)
 MP_BUCKET_KERNELS(extern template, Secp256k1)
+MP_DECOMPRESS_KERNELS(extern template, Secp256k1)
 }
 MP_DEFINE_CURVE(Secp256k1)

@@ -3,5 +3,6 @@
 namespace mp {
 MP_MSM_KERNELS(extern template, Stark)
 MP_BUCKET_KERNELS(extern template, Stark)
+MP_DECOMPRESS_KERNELS(extern template, Stark)
 }
 MP_DEFINE_CURVE(Stark)

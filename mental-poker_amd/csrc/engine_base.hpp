@@ -124,6 +124,10 @@ struct mp_ctx {
   mp::rt::Stream vstream{}, vside{};
   mp::rt::Event ev_vfork{}, ev_vshuf{}, ev_vtab{}, ev_vin{};
   std::vector<mp_table*> tables;      // the tables of this context (mp_sync completes their deferred verification passes)
+  // square-root tables of the curve's base field for on-device point decompression (kernels_decompress.hpp), built on first use
+  mp::DevBuf<uint32_t> sq_ginv, sq_ghalf, sq_hh;
+  uint32_t sq_geom[4] = {0, 0, 0, 0};     // S, w, k, bits of the fixed exponent; S = 0: not built yet
+  uint32_t sq_exp[12] = {0};
   mp::Profiler prof;
 };
 namespace mp {
@@ -233,6 +237,8 @@ namespace mp {
                               uint32_t fb_bits, int* rc);                                                              \
   int setup_##NAME(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out);                                   \
   long ser_points_##NAME(bool de, size_t count, const uint8_t* in, uint8_t* out);                                                \
+  int decompress_dev_##NAME(mp_ctx* ctx, size_t groups, uint32_t per_group, uint32_t prefix, const uint8_t* d_in, uint8_t* d_out, \
+                            int32_t* d_status);                                                                                   \
   bool ser_scalars_ok_##NAME(size_t count, const uint8_t* in);
 MP_DECLARE_CURVE(Stark)
 MP_DECLARE_CURVE(Bn254)

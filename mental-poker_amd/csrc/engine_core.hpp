@@ -3,6 +3,7 @@
 #pragma once
 #include "engine_base.hpp"
 #include "kernels_bucket.hpp"
+#include "kernels_decompress.hpp"
 #include "kernels_sigma.hpp"
 #include "serialize_host.hpp"
 #include "setup_host.hpp"
@@ -1536,6 +1537,87 @@ static int setup_device(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[
   return MP_OK;
 }
 
+// ---- on-device point decompression (kernels_decompress.hpp): square-root tables of the base field, once per context (host work with
+// the kernels' own field code), then one lane per point
+template <class C>
+static void build_sqrt_tables(mp_ctx* ctx) {
+  typedef typename C::FqP F;
+  constexpr int W = F::NW;
+  uint32_t q[W], half[W], e[W];
+  for (int i = 0; i < W; ++i) q[i] = F::MOD[i];
+  q[0] -= 1u;                                                // p - 1
+  auto shr1 = [](uint32_t* r, const uint32_t* x) {
+    for (int i = 0; i < W; ++i) r[i] = (x[i] >> 1) | (i + 1 < W ? x[i + 1] << 31 : 0u);
+  };
+  shr1(half, q);                                             // (p - 1) / 2
+  uint32_t S = 0;
+  while (!(q[0] & 1u)) {
+    shr1(q, q);
+    ++S;
+  }
+  for (int i = 0; i < W; ++i) e[i] = q[i];
+  e[0] -= 1u;                                                // q odd
+  shr1(e, e);                                                // (q - 1) / 2
+  const uint32_t w = S % 4 == 0 ? 4u : (S % 2 == 0 ? 2u : 1u), k = S / w, nd = 1u << w;
+  const Fe<F> one = fe_one<F>(), minus_one = fe_neg<F>(one);
+  Fe<F> z = fe_from_u32<F>(2);
+  for (uint32_t c = 2; !fe_eq<F>(fe_pow_host<F>(z, half, W), minus_one); ++c) z = fe_from_u32<F>(c + 1);      // smallest non-residue
+  const Fe<F> g = fe_pow_host<F>(z, q, W), ginv = fe_inv<F>(g);
+  std::vector<uint32_t> t_ginv((size_t)k * nd * W), t_ghalf((size_t)k * nd * W, 0u), t_hh((size_t)nd * W);
+  Fe<F> gi = ginv, gh = ginv, prev = ginv;                   // gi = ginv^(2^(w i)); gh = ginv^(2^(w i - 1)) for i >= 1
+  for (uint32_t i = 0; i < k; ++i) {
+    if (i) {
+      gh = gi;                                               // still ginv^(2^(w (i-1)))
+      for (uint32_t j = 0; j + 1 < w; ++j) gh = fe_sqr<F>(gh);
+      gi = fe_sqr<F>(gh);
+    }
+    Fe<F> pi = one, ph = one;
+    for (uint32_t d = 0; d < nd; ++d) {
+      fe_pack<F>(pi, &t_ginv[((size_t)i * nd + d) * W]);
+      if (i) {
+        fe_pack<F>(ph, &t_ghalf[((size_t)i * nd + d) * W]);
+        ph = fe_mul<F>(ph, gh);
+      } else if (!(d & 1u)) {
+        fe_pack<F>(ph, &t_ghalf[(size_t)d * W]);             // ginv^(d / 2)
+        ph = fe_mul<F>(ph, ginv);
+      }
+      pi = fe_mul<F>(pi, gi);
+    }
+    prev = gi;
+  }
+  (void)prev;
+  Fe<F> h = g;
+  for (uint32_t j = 0; j < S - w; ++j) h = fe_sqr<F>(h);      // order 2^w
+  Fe<F> hp = one;
+  for (uint32_t d = 0; d < nd; ++d) {
+    fe_pack<F>(hp, &t_hh[(size_t)d * W]);
+    hp = fe_mul<F>(hp, h);
+  }
+  ctx->sq_ginv.upload(t_ginv, ctx->stream);
+  ctx->sq_ghalf.upload(t_ghalf, ctx->stream);
+  ctx->sq_hh.upload(t_hh, ctx->stream);
+  uint32_t ebits = 32 * W;
+  while (ebits && !((e[(ebits - 1) >> 5] >> ((ebits - 1) & 31)) & 1u)) --ebits;
+  ctx->sq_geom[0] = S; ctx->sq_geom[1] = w; ctx->sq_geom[2] = k; ctx->sq_geom[3] = ebits;
+  for (int i = 0; i < 12; ++i) ctx->sq_exp[i] = i < W ? e[i] : 0u;
+  rt::stream_sync(ctx->stream);
+}
+template <class C>
+static int decompress_device(mp_ctx* ctx, size_t groups, uint32_t per_group, uint32_t prefix, const uint8_t* d_in, uint8_t* d_out,
+                             int32_t* d_status) {
+  if (!ctx->sq_geom[0]) build_sqrt_tables<C>(ctx);
+  if ((uint64_t)groups * per_group >= ((uint64_t)1 << 32)) return fail(MP_ERR_BAD_ARGUMENT, "point decompression: too many points for one call");
+  rt::dzero(d_status, groups * sizeof(int32_t), ctx->stream);
+  DecompressArgs a{};
+  a.in = d_in; a.out = d_out; a.status = d_status;
+  a.ginv = ctx->sq_ginv.p; a.ghalf = ctx->sq_ghalf.p; a.hh = ctx->sq_hh.p;
+  a.per_group = per_group; a.prefix = prefix;
+  a.g = SqrtGeom{ctx->sq_geom[0], ctx->sq_geom[1], ctx->sq_geom[2], ctx->sq_geom[3]};
+  for (int i = 0; i < 12; ++i) a.e[i] = ctx->sq_exp[i];
+  MP_RUN(k_decompress, C, (uint32_t)(groups * per_group), 1, a);
+  return MP_OK;
+}
+
 }  // namespace mp
 
 #define MP_DEFINE_CURVE(NAME)                                                                                  \
@@ -1553,4 +1635,8 @@ static int setup_device(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[
     return Ser<NAME>::points(de, count, in, out);                                                              \
   }                                                                                                            \
   bool ser_scalars_ok_##NAME(size_t count, const uint8_t* in) { return Ser<NAME>::scalars_ok(count, in); }     \
+  int decompress_dev_##NAME(mp_ctx* ctx, size_t groups, uint32_t per_group, uint32_t prefix, const uint8_t* d_in,  \
+                            uint8_t* d_out, int32_t* d_status) {                                               \
+    return decompress_device<NAME>(ctx, groups, per_group, prefix, d_in, d_out, d_status);                     \
+  }                                                                                                            \
   }

@@ -656,11 +656,10 @@ struct SubgroupArgs {
   int32_t* status;
   uint32_t Bpad, p_first;
 };
+// is the affine point p (on the curve, not the identity) in the prime-order subgroup?
 template <class C>
-MP_HD void body_subgroup_check(const SubgroupArgs& a, uint32_t b, uint32_t y) {
+MP_HD bool aff_in_subgroup_dev(const Aff<C>& p) {
   typedef typename C::FrP R;
-  const Aff<C> p = ld_aff<C>(a.P + p_off<C>(a.p_first + y, a.Bpad, b));
-  if (aff_is_inf<C>(p)) return;
   if constexpr (C::ENDO_SUBGROUP) {
     // The same verdict from 126 doublings + 12 additions instead of 253 + 126 (round 3: this kernel was half of a BLS12-377 step).
     // phi(x, y) = (beta x, y) acts on G1 as -u^2 (u = the curve's seed, r = u^4 - u^2 + 1), and psi = phi + [u^2] has degree
@@ -683,16 +682,22 @@ MP_HD void body_subgroup_check(const SubgroupArgs& a, uint32_t b, uint32_t y) {
     const Fe<F> zz = fe_sqr<F>(q2.Z);
     ok = ok && fe_is_zero(fe_sub<F>(fe_mul<F>(fe_mul<F>(fe_unpack<F>(C::BETA_MONT), p.x), zz), q2.X));
     ok = ok && fe_is_zero(fe_add<F>(fe_mul<F>(fe_mul<F>(p.y, zz), q2.Z), q2.Y));
-    if (!ok) a.status[b] = -1;                   // ST_BAD_ENCODING (kernels_proto.hpp)
-    return;
-  }
-  Jac<C> acc = jac_from_aff<C>(p);
+    return ok;
+  } else {
+    Jac<C> acc = jac_from_aff<C>(p);
 #pragma unroll 1
-  for (int i = R::BITS - 2; i >= 0; --i) {
-    jac_dbl_ip<C>(acc);
-    if ((R::MOD[i >> 5] >> (i & 31)) & 1u) jac_madd_ip<C>(acc, p);
+    for (int i = R::BITS - 2; i >= 0; --i) {
+      jac_dbl_ip<C>(acc);
+      if ((R::MOD[i >> 5] >> (i & 31)) & 1u) jac_madd_ip<C>(acc, p);
+    }
+    return jac_is_inf<C>(acc);
   }
-  if (!jac_is_inf<C>(acc)) a.status[b] = -1;      // ST_BAD_ENCODING (kernels_proto.hpp)
+}
+template <class C>
+MP_HD void body_subgroup_check(const SubgroupArgs& a, uint32_t b, uint32_t y) {
+  const Aff<C> p = ld_aff<C>(a.P + p_off<C>(a.p_first + y, a.Bpad, b));
+  if (aff_is_inf<C>(p)) return;
+  if (!aff_in_subgroup_dev<C>(p)) a.status[b] = -1;      // ST_BAD_ENCODING (kernels_proto.hpp)
 }
 MP_KERNEL_OCC(k_subgroup_check, SubgroupArgs, body_subgroup_check, 2)
 

@@ -582,3 +582,30 @@ def test_emulated_window_lanes_and_pipelined_verification(emu, coracle):
     with pytest.raises(Exception):
         t.set_pipeline(9)
     t.close()
+
+
+class _HostMem:
+    """the emulator's "device" memory is host memory: ctypes buffers stand in for HBM"""
+
+    def put(self, b):
+        import ctypes
+        buf = (ctypes.c_uint8 * max(len(b), 1)).from_buffer_copy(b if b else b"\0")
+        return buf, ctypes.addressof(buf)
+
+    def new(self, nbytes):
+        import ctypes
+        buf = (ctypes.c_uint8 * max(nbytes, 1))()
+        return buf, ctypes.addressof(buf)
+
+    def get(self, h, nbytes):
+        return bytes(h)[:nbytes]
+
+
+@pytest.mark.parametrize("name", ["shuffle_stark_m2_n3_s1.json", "shuffle_bn254_m2_n4_s3.json", "shuffle_secp256k1_m3_n3_s5.json",
+                                  "shuffle_bls12_377_m2_n3_s13.json"])
+def test_emulated_device_decompression_matches_oracle(emu, name):
+    """mp_deck_deserialize_dev / mp_points_deserialize_dev (kernel body under emulation): arkworks-compressed points -> wire v1 with the
+    windowed square root, against the oracle's encoder and decoder -- golden decks, random points, every malformed case"""
+    from decompress_cases import run_decompress_cases
+    g = load_json(os.path.join(GOLDEN, name))
+    run_decompress_cases(emu(g["curve"]), _HostMem(), g["curve"], g, n_random=6 if g["curve"] != "bls12_377" else 3)

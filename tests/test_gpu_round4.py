@@ -210,3 +210,68 @@ def test_outputs_do_not_depend_on_batch_position_or_lane_mode(mp, coracle):
     t.set_pipeline(0)
     t.close()
     eng.close()
+
+
+class _TorchMem:
+    def __init__(self):
+        import torch
+        self.torch, self.gpu = torch, torch.device("cuda", 0)
+
+    def put(self, b):
+        t = self.torch.frombuffer(bytearray(b), dtype=self.torch.uint8).to(self.gpu)
+        return t, t.data_ptr()
+
+    def new(self, nbytes):
+        t = self.torch.full((max(nbytes, 4),), 0x5A, dtype=self.torch.uint8, device=self.gpu)
+        return t, t.data_ptr()
+
+    def get(self, h, nbytes):
+        return bytes(h[:nbytes].cpu().numpy().tobytes())
+
+
+@pytest.mark.parametrize("name", ["shuffle_stark_m2_n26_s7.json", "shuffle_stark_m4_n13_s9.json", "shuffle_bn254_m2_n4_s3.json",
+                                  "shuffle_secp256k1_m3_n3_s5.json", "shuffle_bls12_377_m2_n3_s13.json"])
+def test_device_decompression_matches_oracle(mp, name):
+    """mp_deck_deserialize_dev / mp_points_deserialize_dev on the MI355X: arkworks-compressed decks and points -> wire v1 in HBM (windowed
+    square root, one lane per point) against the oracle's encoder / decoder: every golden deck, random points, non-residues,
+    non-canonical x, malformed flags, points outside the prime-order subgroup"""
+    import os
+    from conftest import GOLDEN, load_json
+    from decompress_cases import run_decompress_cases
+    g = load_json(os.path.join(GOLDEN, name))
+    eng = mp._native.Engine(g["curve"], 0)
+    run_decompress_cases(eng, _TorchMem(), g["curve"], g, n_random=200)
+    eng.close()
+
+
+def test_decompressed_decks_go_straight_into_the_prover(mp, coracle):
+    """arkworks bytes -> HBM -> mp_deck_deserialize_dev -> mp_shuffle_and_remask_batch_dev / mp_verify_shuffle_batch_dev without a host
+    square root: same proofs as from the wire decks"""
+    import torch
+    import ark_canonical as ac
+    import mp_oracle as po
+    cv, m, n, B = "stark", 2, 26, 4
+    eng = mp._native.Engine(cv, 0)
+    ins, args = _inputs(coracle, cv, m, n, B, 5600)
+    g0 = ins[0]
+    t = eng.table(m, n, g0["params"], g0["pk"])
+    exp = _expected(coracle, cv, m, n, g0, ins)
+    gpu = torch.device("cuda", 0)
+    dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(gpu)
+    with po.curve_ctx(po.CURVES[cv]):
+        ser = b"".join(ac.enc_deck(po.CURVES[cv], po.deck_from_bytes(g["deck"])) for g in ins)
+    d_ser, d_decks = dev(ser), torch.empty(len(args[0]), dtype=torch.uint8, device=gpu)
+    d_st = torch.full((B,), 9, dtype=torch.int32, device=gpu)
+    eng.deck_deserialize_dev(B, m * n, d_ser.data_ptr(), d_decks.data_ptr(), d_st.data_ptr())
+    rho, seeds = dev(args[1]), dev(args[3])
+    perm = torch.tensor(args[2], dtype=torch.int32, device=gpu)
+    od, op = torch.empty(len(exp[0]), dtype=torch.uint8, device=gpu), torch.empty(len(exp[1]), dtype=torch.uint8, device=gpu)
+    sp, sv = torch.full((B,), 9, dtype=torch.int32, device=gpu), torch.full((B,), 9, dtype=torch.int32, device=gpu)
+    t.shuffle_and_remask_batch_dev(B, d_decks.data_ptr(), rho.data_ptr(), perm.data_ptr(), seeds.data_ptr(), od.data_ptr(), op.data_ptr(), sp.data_ptr())
+    t.verify_shuffle_batch_dev(B, d_decks.data_ptr(), od.data_ptr(), op.data_ptr(), sv.data_ptr())
+    eng.sync()
+    assert d_st.cpu().tolist() == [0] * B and sp.cpu().tolist() == [0] * B and sv.cpu().tolist() == [0] * B
+    assert bytes(d_decks.cpu().numpy().tobytes()) == args[0]
+    assert bytes(od.cpu().numpy().tobytes()) == exp[0] and bytes(op.cpu().numpy().tobytes()) == exp[1]
+    t.close()
+    eng.close()
