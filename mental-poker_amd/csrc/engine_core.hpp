@@ -914,7 +914,8 @@ struct Table : mp_table {
     }
     ProveScalArgs sc{w.S.p, perm, l, w.Bpad, q.lin.p, q.lin_src.p, tk.E ? 0u : (uint32_t)q.pplan.lin.size()};
     MP_RUN(k_prove_scal1, C, B, N, sc);
-    MP_RUN(k_prove_scal1b, C, B, 1 + n + sc.n_lin * n, sc);
+    MP_RUN(k_prove_scal1b, C, B, n + sc.n_lin * n, sc);
+    MP_RUN(k_prove_scal1c, C, B, 1, sc);
     if (tk.E) {                   // the scalar polynomial at the same points; the interpolation matrix as MSM scalars
       LinCombArgs la{w.S.p, q.lin.p, q.lin_src.p, q.lin_coef.p, q.consts.p, w.Bpad, n};
       MP_RUN(k_lin_comb, C, B, (uint32_t)q.pplan.lin.size() * n, la);

@@ -510,22 +510,20 @@ MP_HD void body_prove_scal1(const ProveScalArgs& a, uint32_t b, uint32_t y) {
   MP_ST(l.tmp + y, fe_mul<R>(MP_LD(l.rho + y), bi));
 }
 MP_KERNEL(k_prove_scal1, ProveScalArgs, body_prove_scal1)
-// second launch: y = 0: rho_hat = -sum rho_i b_i -> tau[m];  y = 1 + j, j < n: the halved evaluation scalars of the m = 2 Toom-Cook
-// diagonals (layout.hpp);  y = 1 + n + q n + j: entry j of scalar-row sum q of the Karatsuba plan (m >= 3)
+// second launch: y = j < n: column j of rho_hat's sum (sum_k rho_i b_i over the m rows, i = k n + j -> tmp[N + j]) and the halved
+// evaluation scalars of the m = 2 Toom-Cook diagonals (layout.hpp);  y = n + q n + j: entry j of scalar-row sum q of the Karatsuba
+// plan (m >= 3).  Third launch (k_prove_scal1c): rho_hat = -sum_j of the column sums -> tau[m].  (Until round 4 one lane added up all
+// N products: 1 024 dependent loads on 256 waves -- 64 ms of a (16,64) step at 16 384 proofs.)
 template <class C>
 MP_HD void body_prove_scal1b(const ProveScalArgs& a, uint32_t b, uint32_t y) {
   typedef typename C::FrP R;
   const ProveLay& l = a.l;
-  if (y == 0) {
-    Fe<R> rho_hat = fe_zero<R>();
-    for (uint32_t i = 0; i < l.N; ++i) rho_hat = fe_sub<R>(rho_hat, MP_LD(l.tmp + i));
-    MP_ST(l.metau + l.m, rho_hat);
-    return;
-  }
-  y -= 1;
   if (y < l.n) {
-    if (!l.toom) return;
     const uint32_t j = y;
+    Fe<R> col = MP_LD(l.tmp + j);
+    for (uint32_t k = 1; k < l.m; ++k) col = fe_add<R>(col, MP_LD(l.tmp + k * l.n + j));
+    MP_ST(l.tmp + l.N + j, col);
+    if (!l.toom) return;
     const Fe<R> a0 = MP_LD(l.mea0 + j), a1 = MP_LD(l.b + j), a2 = MP_LD(l.b + l.n + j);
     const Fe<R> e = fe_add<R>(a0, a2);
     MP_ST(l.tsp + j, fe_half<R>(fe_add<R>(e, a1)));
@@ -539,6 +537,15 @@ MP_HD void body_prove_scal1b(const ProveScalArgs& a, uint32_t b, uint32_t y) {
   for (uint32_t i = 1; i < lj.count; ++i) acc = fe_add<R>(acc, MP_LD(a.lin_src[lj.begin + i] + j));
   MP_ST(lj.dst + j, acc);
 }
+template <class C>
+MP_HD void body_prove_scal1c(const ProveScalArgs& a, uint32_t b, uint32_t) {
+  typedef typename C::FrP R;
+  const ProveLay& l = a.l;
+  Fe<R> rho_hat = fe_zero<R>();
+  for (uint32_t j = 0; j < l.n; ++j) rho_hat = fe_sub<R>(rho_hat, MP_LD(l.tmp + l.N + j));
+  MP_ST(l.metau + l.m, rho_hat);
+}
+MP_KERNEL(k_prove_scal1c, ProveScalArgs, body_prove_scal1c)
 MP_KERNEL(k_prove_scal1b, ProveScalArgs, body_prove_scal1b)
 
 // ---- Toom-Cook operands (3 <= m <= 16, layout.hpp ToomPlan) ---------------------------------------------------------------
