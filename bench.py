@@ -262,7 +262,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the two extra one-step measurements (keyed batch, per-equation verification) reported in config")
     ap.add_argument("--latency-batch", type=int, default=None,
-                    help="batches up to this size use the latency plan (engine default 1536 x 52 / N): mp_set_latency_batch")
+                    help="batches up to this size use the latency plan (engine default 2560 x 52 / N): mp_set_latency_batch")
     ap.add_argument("--keyed", type=int, default=0, metavar="K",
                     help="keyed batches: K distinct aggregate keys (card tables) spread over the batch, one key per proof "
                          "(mp_*_batch_keys_dev); 0 = every proof under the table's own key")

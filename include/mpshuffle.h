@@ -180,9 +180,9 @@ int mp_sync(mp_ctx* ctx);
 int mp_reserve(mp_table* t, size_t B);           /* pre-allocate the batch workspace for B proofs */
 /* Every table holds six static work splits with identical results: a throughput plan (large sub-jobs, fewest operations) and five
  * finer ones -- wide, medium, latency, small, finest -- that give a proof more lanes (smaller sub-jobs; the windows of a variable-base
- * sub-job dealt to several lanes).  Batches of at most B / 12 proofs use the finest split, up to B / 2 the small one, up to `B` the
- * latency plan, up to 4 B the medium plan, up to 32 B the wide plan, larger ones the throughput plan (default B = 1536 * 52 / N, at
- * least 24: 128 / 768 / 1 536 / 6 144 / 49 152 proofs of 52 cards, the crossovers measured on an MI355X; 0 = always throughput). */
+ * sub-job dealt to several lanes).  Batches of at most B / 20 proofs use the finest split, up to 0.3 B the small one, up to `B` the
+ * latency plan, up to 2.4 B the medium plan, up to 19.2 B the wide plan, larger ones the throughput plan (default B = 2560 * 52 / N, at
+ * least 40: 128 / 768 / 2 560 / 6 144 / 49 152 proofs of 52 cards, the crossovers measured on an MI355X; 0 = always throughput). */
 int mp_set_latency_batch(mp_table* t, size_t B);
 /* Every batch takes work split `split` whatever its size: 0 throughput, 1 latency, 2 medium, 3 finest, 4 wide, 5 small; -1 (default) =
  * by batch size as above.  For tests and measurements: the results do not depend on it. */

@@ -125,7 +125,7 @@ struct mp_ctx {
   mp::rt::Event ev_vfork{}, ev_vshuf{}, ev_vtab{}, ev_vin{};
   std::vector<mp_table*> tables;      // the tables of this context (mp_sync completes their deferred verification passes)
   // square-root tables of the curve's base field for on-device point decompression (kernels_decompress.hpp), built on first use
-  mp::DevBuf<uint32_t> sq_ginv, sq_ghalf, sq_hh;
+  mp::DevBuf<uint32_t> sq_ghalf, sq_hh, sq_rr, sq_chain;
   uint32_t sq_geom[4] = {0, 0, 0, 0};     // S, w, k, bits of the fixed exponent; S = 0: not built yet
   uint32_t sq_exp[12] = {0};
   mp::Profiler prof;

@@ -147,9 +147,9 @@ struct Table : mp_table {
   // the verify calls pipelined (profiles/r04_plan_sweep.txt):
   //   [3] finest      1 / 1 / 2 / 4 / 1     up to ~128 proofs in flight (plus the bucket kernel for the merged verifier equation)
   //   [5] small       1 / 8 / 2 / 4 / 8     up to ~768      (256: 83 k against 55 k on the finest split, 512: 137 k against 90 k)
-  //   [1] latency     2 / 16 / 4 / 8 / 8    up to ~1 536    (1 024: 188-200 k; round 3's 2 / 4 / 8 / 8 / 1: 122 k)
+  //   [1] latency     2 / 16 / 4 / 8 / 8    up to ~2 560    (1 024: 188-200 k; round 3's 2 / 4 / 8 / 8 / 1: 122 k)
   //   [2] medium      4 / 32 / 8 / 16 / 4   up to ~6 144    (4 096: 338 k; round 3's 4 / 16 / 16 / 32 / 1: 242-255 k)
-  //   [4] wide        4 / 64 / 32 / 32 / 16 up to ~49 152   (16 384: 454 k, 32 768: 477 k; round 3's 4 / 32 / 16 / 32 / 1: 402 k, 440 k)
+  //   [4] wide        4 / 64 / 16 / 32 / 16 up to ~49 152   (16 384: 462 k, 32 768: 483 k; round 3's 4 / 32 / 16 / 32 / 1: 402 k, 440 k)
   //   [0] throughput  8 / 64 / 64 / 64 / 1  beyond: fewest operations
   // Window lanes instead of ever smaller sub-jobs: a sub-job of T terms costs 250 doublings + 51 T additions whatever T is, so cutting
   // 64-term jobs into 4-term jobs for 16x the lanes multiplied the doublings by 16; dealing the 51 windows to 16 lanes gives the same
@@ -169,7 +169,7 @@ struct Table : mp_table {
     pprm[1] = PlanParams{2, 16, 4, 8, 8};
     pprm[2] = PlanParams{4, 32, 8, 16, 4};
     pprm[3] = PlanParams{1, tiny_v, tiny_g, 4, 1};
-    pprm[4] = PlanParams{4, 64, 32, 32, 16};
+    pprm[4] = PlanParams{4, 64, 16, 32, 16};
     pprm[5] = PlanParams{1, 8, 2, 4, 8};
   }
   int set_plan_params(int plan, uint32_t fch, uint32_t vch, uint32_t grp, uint32_t nch, uint32_t vsp) override {
@@ -195,7 +195,7 @@ struct Table : mp_table {
   // crossovers on 52-card decks (round 4, with window lanes; round 3 had 600 / 3 840 / 12 288 / 49 152 for its four finer splits)
   uint32_t tiny_batch = 128;                     // up to this size the finest split,
   uint32_t small_batch = 768;                    // the small split,
-  uint32_t latency_batch = 1536;                 // the latency plan (mp_set_latency_batch scales all of them),
+  uint32_t latency_batch = 2560;                 // the latency plan (mp_set_latency_batch scales all of them),
   uint32_t medium_batch = 6144;                  // the medium plan,
   uint32_t wide_batch = 49152;                   // the wide plan; larger batches: throughput
   int plan_of(uint32_t B) const {
@@ -205,10 +205,10 @@ struct Table : mp_table {
   PlanSet& pick(uint32_t B, bool keyed = false) { return (keyed ? psk : ps)[plan_of(B)]; }
   void set_latency_batch(size_t b) override {
     latency_batch = (uint32_t)std::min<size_t>(b, 0x02000000u);
-    tiny_batch = latency_batch / 12;
-    small_batch = latency_batch / 2;
-    medium_batch = latency_batch * 4;
-    wide_batch = latency_batch * 32;
+    tiny_batch = latency_batch / 20;
+    small_batch = (uint32_t)((uint64_t)latency_batch * 3 / 10);
+    medium_batch = (uint32_t)((uint64_t)latency_batch * 12 / 5);
+    wide_batch = (uint32_t)((uint64_t)latency_batch * 96 / 5);
   }
   uint32_t bucket_min = BUCKET_MIN;              // MSMs of at least this many variable-base terms use the bucket kernel (0 = never)
   bool toom_cook = true;        // 3 <= m <= 16: Toom-Cook instead of Karatsuba for the multi-exponentiation diagonals
@@ -387,7 +387,7 @@ struct Table : mp_table {
     m = m_; n = n_; N = m * n;
     point_bytes = G_::PB;
     // plan thresholds count lanes, and a proof of N cards brings ~N/52 times the lanes of a 52-card proof
-    set_latency_batch(std::max<size_t>(24, (size_t)1536 * 52 / N));
+    set_latency_batch(std::max<size_t>(40, (size_t)2560 * 52 / N));
     nwin = (uint32_t)vb_windows(R::BITS);
     default_plan_params();
     FixedBases fb{n};
@@ -1564,17 +1564,16 @@ static void build_sqrt_tables(mp_ctx* ctx) {
   Fe<F> z = fe_from_u32<F>(2);
   for (uint32_t c = 2; !fe_eq<F>(fe_pow_host<F>(z, half, W), minus_one); ++c) z = fe_from_u32<F>(c + 1);      // smallest non-residue
   const Fe<F> g = fe_pow_host<F>(z, q, W), ginv = fe_inv<F>(g);
-  std::vector<uint32_t> t_ginv((size_t)k * nd * W), t_ghalf((size_t)k * nd * W, 0u), t_hh((size_t)nd * W);
-  Fe<F> gi = ginv, gh = ginv, prev = ginv;                   // gi = ginv^(2^(w i)); gh = ginv^(2^(w i - 1)) for i >= 1
+  std::vector<uint32_t> t_ghalf((size_t)k * nd * W, 0u), t_hh((size_t)nd * W);
+  Fe<F> gi = ginv, gh = ginv;                                // gi = ginv^(2^(w i)); gh = ginv^(2^(w i - 1)) for i >= 1
   for (uint32_t i = 0; i < k; ++i) {
     if (i) {
       gh = gi;                                               // still ginv^(2^(w (i-1)))
       for (uint32_t j = 0; j + 1 < w; ++j) gh = fe_sqr<F>(gh);
       gi = fe_sqr<F>(gh);
     }
-    Fe<F> pi = one, ph = one;
+    Fe<F> ph = one;
     for (uint32_t d = 0; d < nd; ++d) {
-      fe_pack<F>(pi, &t_ginv[((size_t)i * nd + d) * W]);
       if (i) {
         fe_pack<F>(ph, &t_ghalf[((size_t)i * nd + d) * W]);
         ph = fe_mul<F>(ph, gh);
@@ -1582,11 +1581,22 @@ static void build_sqrt_tables(mp_ctx* ctx) {
         fe_pack<F>(ph, &t_ghalf[(size_t)d * W]);             // ginv^(d / 2)
         ph = fe_mul<F>(ph, ginv);
       }
-      pi = fe_mul<F>(pi, gi);
     }
-    prev = gi;
   }
-  (void)prev;
+  // R[c][d] = ginv^(d 2^(S - w c)), c = 1 .. k (c = k: ginv itself; row 1 is h^-d, unused; row 0 empty)
+  std::vector<uint32_t> t_rr((size_t)(k + 1) * nd * W, 0u);
+  {
+    Fe<F> base = ginv;                                       // ginv^(2^(S - w c)) for c = k, k-1, ..
+    for (uint32_t c = k; c >= 1; --c) {
+      Fe<F> pr = one;
+      for (uint32_t d = 0; d < nd; ++d) {
+        fe_pack<F>(pr, &t_rr[((size_t)c * nd + d) * W]);
+        pr = fe_mul<F>(pr, base);
+      }
+      for (uint32_t j = 0; j < w; ++j) base = fe_sqr<F>(base);
+    }
+  }
+  ctx->sq_rr.upload(t_rr, ctx->stream);
   Fe<F> h = g;
   for (uint32_t j = 0; j < S - w; ++j) h = fe_sqr<F>(h);      // order 2^w
   Fe<F> hp = one;
@@ -1594,7 +1604,6 @@ static void build_sqrt_tables(mp_ctx* ctx) {
     fe_pack<F>(hp, &t_hh[(size_t)d * W]);
     hp = fe_mul<F>(hp, h);
   }
-  ctx->sq_ginv.upload(t_ginv, ctx->stream);
   ctx->sq_ghalf.upload(t_ghalf, ctx->stream);
   ctx->sq_hh.upload(t_hh, ctx->stream);
   uint32_t ebits = 32 * W;
@@ -1611,11 +1620,19 @@ static int decompress_device(mp_ctx* ctx, size_t groups, uint32_t per_group, uin
   rt::dzero(d_status, groups * sizeof(int32_t), ctx->stream);
   DecompressArgs a{};
   a.in = d_in; a.out = d_out; a.status = d_status;
-  a.ginv = ctx->sq_ginv.p; a.ghalf = ctx->sq_ghalf.p; a.hh = ctx->sq_hh.p;
+  a.ghalf = ctx->sq_ghalf.p; a.hh = ctx->sq_hh.p; a.rr = ctx->sq_rr.p;
   a.per_group = per_group; a.prefix = prefix;
   a.g = SqrtGeom{ctx->sq_geom[0], ctx->sq_geom[1], ctx->sq_geom[2], ctx->sq_geom[3]};
   for (int i = 0; i < 12; ++i) a.e[i] = ctx->sq_exp[i];
-  MP_RUN(k_decompress, C, (uint32_t)(groups * per_group), 1, a);
+  // launches of up to 2^20 points: the scratch column of a point (its chain of k - 1 powers) is 1.5 KB on the STARK prime
+  const size_t total = groups * per_group, chunk = std::min<size_t>(total, (size_t)1 << 20);
+  if (a.g.k > 1) ctx->sq_chain.alloc((size_t)(a.g.k - 1) * chunk * C::FqP::NW, ctx->stream, false);
+  a.chain = ctx->sq_chain.p;
+  for (size_t off = 0; off < total; off += chunk) {
+    a.first = (uint32_t)off;
+    a.lanes = (uint32_t)std::min(chunk, total - off);
+    MP_RUN(k_decompress, C, a.lanes, 1, a);
+  }
   return MP_OK;
 }
 

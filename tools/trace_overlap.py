@@ -18,12 +18,15 @@ def main():
     last_ms = None
     if "--last-ms" in sys.argv:
         last_ms = float(sys.argv[sys.argv.index("--last-ms") + 1])
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else "mp::"      # the engine's kernels (not torch's)
     files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
     if not files:
         raise SystemExit("no *kernel_trace.csv under " + d)
     rows = []
     for f in files:
         for r in csv.DictReader(open(f)):
+            if only and only not in r["Kernel_Name"]:
+                continue
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"), r["Kernel_Name"].split("(")[0][:48]))
     rows.sort()
     t_end = max(r[1] for r in rows)
