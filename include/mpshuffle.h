@@ -195,7 +195,8 @@ int mp_set_work_split(mp_table* t, int split);
  * mp_sync; only then -- and only if some proof failed the screen -- does the per-equation pass of call k run.  The caller's side of
  * the contract: the buffers a verify call reads (decks, shuffled decks, proofs, keys) stay untouched until `depth` further verify
  * calls on that table, or mp_sync, have returned (rotate depth + 1 sets of prover outputs); d_status is final after mp_sync, as
- * before.  Status words are identical in every mode.  The host-buffer entry points and chain verification are unaffected. */
+ * before.  Status words are identical in every mode.  The host-buffer entry points and chain verification are unaffected.
+ * (A context owns four HIP streams -- two lanes of two -- which the runtime's default of four hardware queues serves.) */
 int mp_set_pipeline(mp_table* t, int depth);
 /* The sizes behind work split `split` (0 .. 5 as above): fixed-base / variable-base terms per sub-job, bases per window-table lane,
  * points per shared inversion, and `window_lanes` = lanes per variable-base sub-job: the Straus windows of a sub-job are dealt to that

@@ -113,42 +113,37 @@ int mp_ctx_create(int curve_id, int device, mp_ctx** out) {
   mp_ctx* c = new mp_ctx();
   c->curve = curve_id;
   c->device = device;
-  // The runtime deals HIP streams to a small number of hardware queues round robin in creation order (4 by default, GPU_MAX_HW_QUEUES),
-  // and streams that share a queue do not overlap.  Only the two streams every call uses are created here; the copy streams of the
-  // host-buffer entry points and the verify lane of pipelined mode follow on first use (ensure_io_streams / ensure_verify_lane), so
-  // that a caller of either kind gets four streams on four queues
+  // HIP streams become hardware queues in the order they are created, the queues sit on the compute pipes round robin (four of them), and
+  // two streams overlap fully only on different pipes -- measured, not documented: with the verify lane's streams created fifth and sixth
+  // (GPU_MAX_HW_QUEUES=8) or on first use, a pipelined 1 024-proof step ran at 172-176 k proofs/s; created second and fourth, at 198-202 k
+  // with 4 or 8 queues.  So a context has exactly four streams, the two lanes interleaved; the host-buffer entry points -- which do not
+  // pipeline their verify calls -- run their uploads and downloads on the verify lane's two streams (with copy streams of their own,
+  // fifth and sixth, they lost 2-9 %).
   c->stream = rt::stream_create();
+  c->vstream = rt::stream_create();
   c->side = rt::stream_create();
+  c->vside = rt::stream_create();
+  c->h2d = c->vstream;
+  c->d2h = c->vside;
   c->ev_fork = rt::event_create();
   c->ev_shuf = rt::event_create();
   c->ev_tab = rt::event_create();
+  c->ev_vfork = rt::event_create();
+  c->ev_vshuf = rt::event_create();
+  c->ev_vtab = rt::event_create();
+  c->ev_vin = rt::event_create();
   *out = c;
   return MP_OK;
   MP_CATCH
 }
 void mp_ctx_destroy(mp_ctx* ctx) {
   if (!ctx) return;
-  for (rt::Stream st : {ctx->stream, ctx->side, ctx->h2d, ctx->d2h, ctx->vstream, ctx->vside})
+  for (rt::Stream st : {ctx->stream, ctx->side, ctx->vstream, ctx->vside})      // (h2d / d2h are the verify lane's)
     if (st) rt::stream_destroy(st);
   for (rt::Event e : {ctx->ev_fork, ctx->ev_shuf, ctx->ev_tab, ctx->ev_vfork, ctx->ev_vshuf, ctx->ev_vtab, ctx->ev_vin})
     if (e) rt::event_destroy(e);
   delete ctx;
 }
-static void ensure_io_streams(mp_ctx* c) {
-  if (c->h2d) return;
-  c->h2d = rt::stream_create();
-  c->d2h = rt::stream_create();
-}
-static void ensure_verify_lane(mp_ctx* c) {
-  if (c->vstream) return;
-  c->vstream = rt::stream_create();
-  c->vside = rt::stream_create();
-  c->ev_vfork = rt::event_create();
-  c->ev_vshuf = rt::event_create();
-  c->ev_vtab = rt::event_create();
-  c->ev_vin = rt::event_create();
-}
-
 int mp_setup(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out_params) {
   if (!ctx || !seed || !out_params || m < 2 || n < 2) return fail(MP_ERR_BAD_ARGUMENT, "mp_setup: bad argument");
   MP_TRY
@@ -288,7 +283,6 @@ int mp_set_pipeline(mp_table* t, int depth) {
   MP_TRY
   rt::set_device(t->ctx->device);
   if (depth < 0 || depth > 8) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_pipeline: depth 0 (off) .. 8");
-  if (depth) ensure_verify_lane(t->ctx);
   t->flush();
   t->pipeline = depth;
   return MP_OK;
@@ -530,7 +524,6 @@ static int prove_batch_host(mp_table* t, size_t B, const uint8_t* keys, const ui
   if (t->keyless && !keys) return fail(MP_ERR_BAD_ARGUMENT, "this table has no aggregate key: use the _keys entry points");
   MP_TRY
   rt::set_device(t->ctx->device);
-  ensure_io_streams(t->ctx);
   rt::Stream s = t->ctx->stream, up = t->ctx->h2d, down = t->ctx->d2h;
   const size_t N = t->N, psz = proof_size_bytes(t->m, t->n, t->point_bytes), dsz = N * 2 * t->point_bytes;
   const size_t chunk = std::min(B, t->io_chunk ? t->io_chunk : IO_CHUNK);
@@ -585,7 +578,6 @@ static int verify_batch_host(mp_table* t, size_t B, const uint8_t* keys, const u
   MP_TRY
   rt::set_device(t->ctx->device);
   NoPipeline nopipe(t);
-  ensure_io_streams(t->ctx);
   rt::Stream s = t->ctx->stream, up = t->ctx->h2d, down = t->ctx->d2h;
   const size_t N = t->N, psz = proof_size_bytes(t->m, t->n, t->point_bytes), dsz = N * 2 * t->point_bytes;
   const size_t chunk = std::min(B, t->io_chunk ? t->io_chunk : IO_CHUNK);

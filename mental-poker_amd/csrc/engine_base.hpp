@@ -114,7 +114,7 @@ struct mp_ctx {
   int curve = 0;
   int device = 0;
   mp::rt::Stream stream{};      // all kernels
-  mp::rt::Stream h2d{}, d2h{};  // host-buffer API: uploads and downloads of neighbouring chunks overlap the kernels
+  mp::rt::Stream h2d{}, d2h{};  // host-buffer API: uploads and downloads of neighbouring chunks overlap the kernels (= vstream / vside: capi.hip)
   // small and medium batches: the prover's challenge-independent group work (re-encryption, operand sums, window tables) runs on
   // `side` next to the randomness, c_A and the statement hash on `stream` (engine_core.hpp: prove_dev)
   mp::rt::Stream side{};

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=-1, help="mp_set_pipeline value for every run (-1: leave the default)")
     ap.add_argument("--group-lanes", type=int, default=None)
     ap.add_argument("--merged", type=int, default=None, help="1/0: mp_set_merged_verify")
+    ap.add_argument("--late-pipeline", action="store_true", help="switch pipelining on only after the priming pass (as bench.py's batch_curve does)")
     ap.add_argument("--profile", action="store_true", help="per-kernel milliseconds of one step per configuration")
     args = ap.parse_args()
 
@@ -55,7 +56,7 @@ def main():
         table.set_group_lanes(args.group_lanes)
     if args.merged is not None:
         table.set_merged_verify(bool(args.merged))
-    if args.pipeline >= 0:
+    if args.pipeline >= 0 and not args.late_pipeline:
         table.set_pipeline(args.pipeline)
     proof_bytes = table.proof_bytes
     batches = [int(b) for b in args.batches.split(",")]
@@ -93,6 +94,8 @@ def main():
         table.verify_shuffle_batch_dev(B, decks.data_ptr(), out_decks[i].data_ptr(), out_proofs[i].data_ptr(), st_v[i].data_ptr())
         state["i"] = (i + 1) % NSETS
 
+    if args.pipeline >= 0 and args.late_pipeline:
+        table.set_pipeline(args.pipeline)
     rows = []
     ref = {}
     for B in batches:
