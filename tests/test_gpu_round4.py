@@ -275,3 +275,49 @@ def test_decompressed_decks_go_straight_into_the_prover(mp, coracle):
     assert bytes(od.cpu().numpy().tobytes()) == exp[0] and bytes(op.cpu().numpy().tobytes()) == exp[1]
     t.close()
     eng.close()
+
+
+def test_pipelined_verification_with_keys_and_key_sets(mp, coracle):
+    """pipelined verify calls under one aggregate key per proof (mp_verify_shuffle_batch_keys_dev) and under a key set
+    (mp_verify_shuffle_batch_keyset_dev: the keys are gathered into a buffer of the verify lane's own while a keyed prove call of the next
+    batch gathers into the main lane's): status words as from the waiting calls, a proof verified under a neighbour's key fails by name"""
+    import torch
+    cv, m, n, B, K = "stark", 2, 26, 6, 4
+    eng = mp._native.Engine(cv, 0)
+    g0 = coracle.gen_inputs(cv, m, n, 5700)
+    table = eng.table(m, n, g0["params"], None)               # parameters only: keyed entry points
+    keys = [coracle.gen_inputs(cv, m, n, 5710 + k)["pk"] for k in range(K)]
+    ks = table.keyset(b"".join(keys))
+    ins = [coracle.gen_inputs(cv, m, n, 5720 + b) for b in range(B)]
+    gpu = torch.device("cuda", 0)
+    dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(gpu)
+    decks, rho, seeds = dev(b"".join(g["deck"] for g in ins)), dev(b"".join(g["rho"] for g in ins)), dev(b"".join(g["prover_seed"] for g in ins))
+    perm = torch.tensor([v for g in ins for v in g["perm"]], dtype=torch.int32, device=gpu)
+    kidx = torch.tensor([b % K for b in range(B)], dtype=torch.int32, device=gpu)
+    kidx_bad = torch.tensor([(b + 1) % K for b in range(B)], dtype=torch.int32, device=gpu)
+    kwire = dev(b"".join(keys[b % K] for b in range(B)))
+    dsz, psz = len(g0["deck"]), table.proof_bytes
+    od = [torch.empty(B * dsz, dtype=torch.uint8, device=gpu) for _ in range(2)]
+    op = [torch.empty(B * psz, dtype=torch.uint8, device=gpu) for _ in range(2)]
+    sp = torch.full((B,), 77, dtype=torch.int32, device=gpu)
+    table.set_work_split(2)                                    # a split that screens with the merged equation
+    table.set_pipeline(1)
+    sts = [torch.full((B,), 77, dtype=torch.int32, device=gpu) for _ in range(4)]
+    for i in range(2):                                         # prove (key set) -> verify by index -> verify by explicit key, pipelined
+        table.shuffle_and_remask_batch_keyset_dev(ks, B, kidx.data_ptr(), decks.data_ptr(), rho.data_ptr(), perm.data_ptr(), seeds.data_ptr(),
+                                                  od[i].data_ptr(), op[i].data_ptr(), sp.data_ptr())
+        table.verify_shuffle_batch_keyset_dev(ks, B, (kidx if i == 0 else kidx_bad).data_ptr(), decks.data_ptr(), od[i].data_ptr(), op[i].data_ptr(),
+                                              sts[2 * i].data_ptr())
+        table.verify_shuffle_batch_keys_dev(B, kwire.data_ptr(), decks.data_ptr(), od[i].data_ptr(), op[i].data_ptr(), sts[2 * i + 1].data_ptr())
+    eng.sync()
+    assert sp.cpu().tolist() == [0] * B
+    assert sts[0].cpu().tolist() == [0] * B and sts[1].cpu().tolist() == [0] * B and sts[3].cpu().tolist() == [0] * B
+    assert [eng.check_name(v) for v in sts[2].cpu().tolist()] == ["Multi-Exponentiation Argument (4)"] * B or all(v > 0 for v in sts[2].cpu().tolist())
+    assert bytes(od[0].cpu().numpy().tobytes()) == bytes(od[1].cpu().numpy().tobytes())
+    b = 3
+    ed, ep = coracle.shuffle_and_remask(cv, m, n, g0["params"], keys[b % K], ins[b]["deck"], ins[b]["rho"], ins[b]["perm"], ins[b]["prover_seed"])
+    assert bytes(od[1][b * dsz:(b + 1) * dsz].cpu().numpy().tobytes()) == ed and bytes(op[1][b * psz:(b + 1) * psz].cpu().numpy().tobytes()) == ep
+    table.set_pipeline(0)
+    ks.close()
+    table.close()
+    eng.close()
