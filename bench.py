@@ -686,6 +686,10 @@ def main():
         table.set_merged_verify(False)
         extras["per_equation_value"] = timed_step(step)          # every equation its own MSM, as the reference evaluates them
         table.set_merged_verify(True)
+        if table.group_size(Bs):
+            table.set_group_verify(0, 0)
+            extras["per_proof_screen_value"] = timed_step(step)  # one merged equation per PROOF (Straus), the headline of rounds 1-3
+            table.set_group_verify(16, 6144)
         free_b, _ = torch.cuda.mem_get_info()
         if free_b > 40e9:
             k1000 = make_keys(1000, B)
@@ -792,6 +796,17 @@ def main():
 
     # ---- roofline of the dominant kernel (live HIP-event timings of the timed region)
     stats = table.plan_stats()
+    # group verification (include/mpshuffle.h: mp_set_group_verify): the verifier's screen of this batch is one bucket-method MSM per group of
+    # `gl` proofs -- every point of the group's proofs once, the n + 5 fixed bases once per group -- instead of one Straus MSM per proof
+    gl = 0
+    if workload in ("pairs", "mixed") and not args.per_equation and args.keyed == 0:
+        gl = table.group_size(Bs if workload == "pairs" else B // 2)
+    if gl:
+        per_proof_pts = 4 * N + 11 * m + 8
+        stats["verify"] = {"fixed_terms": (n + 5) / gl, "var_terms": 0, "fixed_jobs": 4.0 / gl, "var_jobs": 0, "table_bases": 0, "combine_terms": 5.0 / gl}
+        stats["bucket_terms"] = stats.get("bucket_terms", 0) + per_proof_pts
+        stats["bucket_jobs"] = stats.get("bucket_jobs", 0) + 1.0 / gl
+        stats["verify_group_size"] = gl
     dom = max(prof.items(), key=lambda kv: kv[1][1])
     dom_name, (dom_count, dom_ms) = dom
     kernel_ms_total = sum(v[1] for v in prof.values())
@@ -1028,7 +1043,10 @@ def main():
               "unit_counted": units,
               "proofs_per_gpu_per_step": proofs_per_step, "streams": S, "fixed_base_window_bits": args.fb_bits,
               "aggregate_keys": (B if workload == "chain32" else (args.keyed if args.keyed else 1)),
-              "verification": "per equation" if args.per_equation else "merged screening pass (per-equation pass only to name a failure)",
+              "verification": ("per equation" if args.per_equation else
+                               ("screening pass: one equation per group of %d proofs, weights from every proof of the group, on the bucket-method "
+                                "kernel (per-equation pass only to name a failure)" % gl) if gl else
+                               "merged screening pass per proof (per-equation pass only to name a failure)"),
               # engine choices by batch size (include/mpshuffle.h: mp_set_transcript_lanes; engine_base.hpp: OVERLAP_MAX_BATCH)
               "transcript_lanes": (args.transcript_lanes or (4 if Bs <= 32768 else 1)),
               # (engine_base.hpp OVERLAP_MAX_BATCH: prove launches of up to 32 768 proofs run their first stretch on two streams, and their

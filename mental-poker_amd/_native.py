@@ -16,7 +16,7 @@ MP_ERR_BAD_ENCODING, MP_ERR_BAD_PERMUTATION, MP_ERR_BAD_ARGUMENT, MP_ERR_NO_DEVI
 
 SYMBOLS = [
     "mp_ctx_create", "mp_ctx_destroy", "mp_last_error", "mp_check_name", "mp_proof_size", "mp_params_size",
-    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_set_subgroup_check", "mp_set_bucket_min", "mp_set_chain_max_links", "mp_set_transcript_lanes", "mp_set_group_lanes", "mp_set_work_split", "mp_set_pipeline", "mp_set_plan_params", "mp_set_plan_thresholds", "mp_set_toom_cook", "mp_host_alloc", "mp_host_free", "mp_set_io_chunk", "mp_shuffle_and_remask_batch_keys", "mp_table_create_params",
+    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_set_subgroup_check", "mp_set_bucket_min", "mp_set_chain_max_links", "mp_set_transcript_lanes", "mp_set_group_lanes", "mp_set_work_split", "mp_set_group_verify", "mp_group_size", "mp_set_pipeline", "mp_set_plan_params", "mp_set_plan_thresholds", "mp_set_toom_cook", "mp_host_alloc", "mp_host_free", "mp_set_io_chunk", "mp_shuffle_and_remask_batch_keys", "mp_table_create_params",
     "mp_verify_shuffle_batch_keys", "mp_shuffle_and_remask_batch_keys_dev", "mp_verify_shuffle_batch_keys_dev",
     "mp_keyset_create", "mp_keyset_destroy", "mp_keyset_size", "mp_shuffle_and_remask_batch_keyset_dev", "mp_verify_shuffle_batch_keyset_dev",
     "mp_setup", "mp_table_create", "mp_table_create_ex", "mp_table_window_bits", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
@@ -129,6 +129,9 @@ def bind(cdll):
     cdll.mp_set_transcript_lanes.argtypes = [c.c_void_p, c.c_uint32]
     cdll.mp_set_group_lanes.argtypes = [c.c_void_p, c.c_uint32]
     cdll.mp_set_work_split.argtypes = [c.c_void_p, c.c_int]
+    cdll.mp_set_group_verify.argtypes = [c.c_void_p, c.c_uint32, c.c_size_t]
+    cdll.mp_group_size.argtypes = [c.c_void_p, c.c_size_t]
+    cdll.mp_group_size.restype = c.c_uint32
     cdll.mp_set_pipeline.argtypes = [c.c_void_p, c.c_int]
     cdll.mp_set_plan_params.argtypes = [c.c_void_p, c.c_int] + [c.c_uint32] * 5
     cdll.mp_set_plan_thresholds.argtypes = [c.c_void_p] + [c.c_size_t] * 5
@@ -600,6 +603,14 @@ class Table:
     def set_work_split(self, split):
         """every batch takes work split `split` (0 throughput, 1 latency, 2 medium, 3 finest, 4 wide, 5 small); -1 = by batch size"""
         self.eng._chk(self.lib.mp_set_work_split(self.h, split))
+
+    def group_size(self, B):
+        """proofs per group of the screening pass for a batch of B (0: per-proof screen)"""
+        return self.lib.mp_group_size(self.h, B)
+
+    def set_group_verify(self, proofs_per_group=16, min_batch=6144):
+        """screening pass of large batches: one equation per group of proofs on the bucket kernel (0 = off)"""
+        self.eng._chk(self.lib.mp_set_group_verify(self.h, proofs_per_group, min_batch))
 
     def set_pipeline(self, depth=1):
         """depth >= 1: device-resident verify calls run on the context's second lane beside the next prove call and do not wait for

@@ -1097,16 +1097,17 @@ struct Table : mp_table {
     const VArgs v{(uint32_t)B_, decks, shuf, proofs, status, keys, kset, kidx};
     const bool keyed = keys != nullptr || kset != nullptr;
     if (keyed) ensure_keyed();
+    const uint32_t gl = group_size(v.B, keyed);      // > 0: the screen is one equation per group of gl proofs (bucket kernel)
     if (pipeline) {
       // Pipelined mode: the call runs on the verify lane with arenas of its own and does NOT wait for its screening verdict, so the
       // caller's next prove call overlaps it on the chip.  The verdict of call k is looked at when call k + 1 comes in (or at
       // mp_sync); only then -- and only if some proof failed the screen -- does the per-equation pass run.
       resolve_pending((size_t)pipeline - 1);      // this call makes it `pipeline` unexamined ones
-      reserve_ws(vws, v.B, keyed);
+      if (!gl) reserve_ws(vws, v.B, keyed);
       rt::event_record(ctx->ev_vin, ctx->stream);
       LaneSwap lane(ctx);
       rt::stream_wait(ctx->stream, ctx->ev_vin);
-      if (!screens(v.B, keyed)) {
+      if (!gl && !screens(v.B, keyed)) {
         verify_pass(vws, v, false, true);
         return;
       }
@@ -1123,8 +1124,19 @@ struct Table : mp_table {
       pn.v = v;
       *pn.h_flag = 0;
       pend.push_back(pn);                   // (before the launches: an exception on the way still leaves the slot owned)
-      verify_pass(vws, v, true, true, pn.d_flag);
+      if (gl) verify_group_pass(v, gl, true, pn.d_flag);
+      else verify_pass(vws, v, true, true, pn.d_flag);
       rt::event_record(pn.ev, ctx->stream);
+      return;
+    }
+    if (gl) {
+      verify_group_pass(v, gl, false, nullptr);
+      uint32_t flag = 0;
+      rt::d2h(&flag, vflag.p, 4, ctx->stream);
+      rt::stream_sync(ctx->stream);
+      if (!flag) return;                    // every group's equation holds
+      reserve_for(v.B, keyed);
+      verify_pass(ws, v, false, false);     // some group failed: name the first failing check of every proof
       return;
     }
     reserve_for(v.B, keyed);
@@ -1148,6 +1160,7 @@ struct Table : mp_table {
       rt::event_sync(pn.ev);
       if (!*pn.h_flag) continue;
       LaneSwap lane(ctx);
+      reserve_ws(vws, pn.v.B, pn.v.keys != nullptr || pn.v.kset != nullptr);
       verify_pass(vws, pn.v, false, true);      // some proof failed the screen: name the first failing check of each
       rt::stream_sync(ctx->stream);
     }
@@ -1296,6 +1309,152 @@ struct Table : mp_table {
     for (uint32_t j = 0; j < L; ++j)
       verify_dev(T, decks + (size_t)j * T * deck_bytes, decks + (size_t)(j + 1) * T * deck_bytes, proofs + (size_t)j * T * psz,
                  status + (size_t)j * T, keyed ? keys + (size_t)j * T * G_::PB : nullptr, nullptr, nullptr);
+  }
+
+  // ---------------------------------------------------------------- group verification (round 4)
+  // The screening pass of a LARGE batch, one level up from the merged equation of one proof: the merged equations of L independent proofs
+  // are added up with weights rho_j that depend on every proof of the group (the machinery of chain verification, without its shared
+  // decks), and the resulting multi-scalar multiplication -- L (4N + 11m + 8) points, 7 616 for 32 proofs of a 52-card deck -- runs on
+  // the bucket-method kernel: 33 additions per term and window-sorted, wave-reduced buckets instead of 51 additions, 15 window-table
+  // entries and a share of four 250-doubling chains per term on the Straus path; the n + 5 fixed bases appear once per GROUP.  The
+  // verifier's half of a 52-card step is the north star's kernel from here on (Pippenger: LDS-staged digits, counting sort by wavefront
+  // prefix sum).  Soundness as for the merged equation (weights = Fr::rand of ChaCha20(Blake2s(final transcript states of the group's
+  // proofs)): an error in one proof cannot cancel against another's except with probability ~2^-250).  A batch in which some group
+  // fails is re-verified equation by equation, so the status words are exactly those of the other paths.  Lane of (member j, group t)
+  // = j T + t with T = B / L groups: the members of a group are T proofs apart.
+  ChainPlan gplan;
+  Workspace gws;                      // lean workspace of the group pass: no window tables, no digit planes (68 KB per proof)
+  // (measured on 52-card decks, proofs/s at 262 144 / 65 536 / 16 384 / 8 192 / 4 096 in flight: off 521 / 495 / 437 / 383 / 315 k; groups of
+  // 8: 538 / 517 / 443 / 389 / 305 k; of 16: 591 / 565 / 471 / 401 / 314 k; of 32: 574 / 545 / 455 / - / 287 k; of 64: 494 / 474 / 395 k -- a
+  // wave of the bucket kernel sorts the whole equation in LDS, 12.5 KB at 16 proofs, and larger equations cost occupancy)
+  uint32_t group_links = 16;          // proofs per group aimed at (mp_set_group_verify; 0 = off)
+  uint32_t group_min_batch = 6144;    // smaller batches keep the per-proof screen (the bucket kernel wants T x 33 waves)
+  void set_group_verify(uint32_t links, size_t min_batch) override {
+    group_links = links;
+    group_min_batch = (uint32_t)std::min<size_t>(min_batch, 0x7FFFFFFFu);
+  }
+  // proofs per group for a batch of B: the divisor of B nearest to group_links in [group_links / 2, 2 group_links] whose equation
+  // fits the 32 767 points of one bucket job; 0 = this batch takes the per-proof screen
+  uint32_t group_size_of(size_t B) const override { return B < 0x7FFFFFFFu ? group_size((uint32_t)B, false) : 0; }
+  uint32_t group_size(uint32_t B, bool keyed) const {
+    const uint32_t per = 4 * N + 11 * m + 8 + (keyed ? 1u : 0u);
+    if (!group_links || !merged_verify || B < group_min_batch || per > 1024) return 0;
+    for (uint32_t d = 0; d <= group_links; ++d)
+      for (int sgn = 1; sgn >= -1; sgn -= 2) {
+        const int64_t L = (int64_t)group_links + sgn * (int64_t)d;
+        if (L < 2 || L < (int64_t)group_links / 2 || L > 2 * (int64_t)group_links || (uint64_t)L * per > 32767u) continue;
+        if (B % (uint32_t)L == 0) return (uint32_t)L;
+      }
+    return 0;
+  }
+  void build_group_plan(uint32_t L, bool keyed) {
+    if (gplan.L == L && gplan.keyed == keyed) return;
+    if (keyed) ensure_keyed();
+    PlanSet& q = (keyed ? psk : ps)[0];
+    const VerifyLay& l = q.vplan.lay;
+    gplan.ph = Phase();
+    gplan.cterms.clear();
+    gplan.L = L;
+    gplan.keyed = keyed;
+    uint32_t next_partial = 1;                  // J slot 0 = the group equation's value
+    PhaseBuilder pb(gplan.ph, next_partial, FCHUNK, VCHUNK, 1u, bk_windows(R::BITS));
+    pb.begin(0);
+    for (uint32_t j = 0; j < L; ++j)
+      for (uint32_t slot = 0; slot < l.pk + (keyed ? 1u : 0u); ++slot) {      // decks, proof points [, the proof's own key]
+        pb.var((uint32_t)gplan.cterms.size(), slot | (j << 20));
+        gplan.cterms.push_back(ChainTerm{l.mvar + slot, j, 1, NO_SLOT});
+      }
+    gplan.K = (uint32_t)gplan.cterms.size();
+    FixedBases fb{n};
+    for (uint32_t f = 0; f < fb.count(); ++f) {
+      if (keyed && f == fb.pk()) continue;
+      pb.fixed((uint32_t)gplan.cterms.size(), f);
+      gplan.cterms.push_back(ChainTerm{l.mfix + f, 0, L, NO_SLOT});
+    }
+    gplan.nfix = (uint32_t)gplan.cterms.size() - gplan.K;
+    pb.end();
+    gplan.nJ = next_partial;
+    gplan.dev.upload(gplan.ph, ctx->stream);
+    gplan.dterms.upload(gplan.cterms, ctx->stream);
+  }
+  // the group pass on the context's CURRENT lane; the flag word (host_flag, or vflag) is raised if some group needs a closer look
+  void verify_group_pass(const VArgs& v, uint32_t L, bool vlane, uint32_t* host_flag) {
+    const uint32_t B = v.B, T = B / L, Tpad = (T + 63u) & ~63u;
+    const bool keyed = v.keys != nullptr || v.kset != nullptr;
+    const uint8_t* keys = v.keys;
+    build_group_plan(L, keyed);
+    PlanSet& q = (keyed ? psk : ps)[0];
+    const VerifyLay& l = q.vplan.lay;
+    rt::Stream s = ctx->stream;
+    Workspace& w = gws;
+    w.fw = G_::FW;
+    w.ensure(B, l.nS, l.nP, std::max(gplan.nJ, 8u), 0, 0, nwin, stage_words_needed(), s, 0);
+    rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
+    {
+      LoadPointsArgs a{v.decks, w.P.p, w.status.p, w.Bpad, 2 * N, l.deck};
+      MP_RUN(k_load_points, C, B, 2 * N, a);
+      LoadPointsArgs b{v.shuf, w.P.p, w.status.p, w.Bpad, 2 * N, l.shuf};
+      MP_RUN(k_load_points, C, B, 2 * N, b);
+      ProofIoArgs pa{const_cast<uint8_t*>(v.proofs), w.S.p, w.P.p, w.status.p, q.vwire.p, w.Bpad, (uint32_t)proof_size_bytes(m, n, G_::PB)};
+      MP_RUN(k_load_proof, C, B, (uint32_t)q.vplan.wire.size(), pa);
+      if (v.kset) keys = gather_keys(B, v.kset, v.kidx, w.status.p, vlane);
+      if (keyed) {
+        LoadPointsArgs ka{keys, w.P.p, w.status.p, w.Bpad, 1, l.pk};
+        MP_RUN(k_load_points, C, B, 1, ka);
+      }
+      check_subgroup(w, B, 0, l.pk + (keyed ? 1u : 0u));
+    }
+    {
+      VerifyFsArgs a{};
+      a.st = statement_args(w, l.deck, l.shuf, l.cA, l.x, keyed ? l.pk : NO_SLOT);
+      a.l = l;
+      a.merge = 1u;
+      run_verify_fs(a, B);
+      VerifyScalArgs sa{w.S.p, w.P.p, w.direct.p, l, q.vplan.cm, w.Bpad};
+      MP_RUN(k_verify_scal, C, B, n + 2, sa);
+      VerifyMergeArgs ma{w.S.p, q.mjobs.p, q.mpairs.p, w.Bpad};
+      MP_RUN(k_verify_merge, C, B, (uint32_t)q.vplan.mjobs.size(), ma);
+    }
+    const uint32_t nterms = gplan.K + gplan.nfix, bw = bk_windows(R::BITS);
+    chain_cw.alloc((size_t)L * Tpad * 8, s, false);
+    chain_cs.alloc((size_t)nterms * Tpad * 8, s);
+    chain_d8.alloc((size_t)gplan.dev.b_dig_bytes * Tpad, s);
+    ChainWeightsArgs wa{w.seed.p, chain_cw.p, w.Bpad, Tpad, T, L};
+    MP_RUN(k_chain_weights, C, T, 1, wa);
+    ChainScalArgs ca{w.S.p, chain_cw.p, chain_cs.p, gplan.dterms.p, w.Bpad, Tpad, T};
+    MP_RUN(k_chain_scalars, C, T, nterms, ca);
+    PhaseDev& ph = gplan.dev;
+    if ((uint64_t)T * ph.n_bterms >= ((uint64_t)1 << 32)) throw std::runtime_error("group verification: too many groups for one launch");
+    BRecodeArgs ra{chain_cs.p, chain_d8.p, ph.bterms.p, ph.bpos.p, Tpad, bw, ph.n_bterms, (size_t)ph.b_dig_bytes};
+    MP_RUN(k_bucket_recode, C, T * ph.n_bterms, 1, ra);
+    BucketArgs ba{chain_d8.p, w.P.p, w.J.p, ph.bjobs.p, ph.bterms.p, w.Bpad, bw, ph.n_b, (size_t)ph.b_dig_bytes, T};
+    ctx->prof.begin("k_bucket_msm", s);
+    MP_WAVE_LAUNCH(k_bucket_msm, C, s, T * ph.n_b * bw, bk_lds_words(ph.b_kpad_max, XyzzWords<C>::N), ba);
+    ctx->prof.end(s);
+    BFoldArgs fa{w.J.p, ph.bjobs.p, w.Bpad, bw};
+    if (quad_ops(T, ph.n_b)) {              // few groups: the fold's 256 dependent doublings on four lanes each
+      BFoldQuadArgs qa{fa, T, ph.n_b};
+      MP_WAVE_RUN(k_bucket_fold_q, C, quad_waves(T, ph.n_b), 0, qa);
+    } else {
+      MP_RUN(k_bucket_fold, C, T, ph.n_b, fa);
+    }
+    FixedArgs fx{chain_cs.p, w.J.p, FB.p, ph.fjobs.p, ph.fterms.p, w.Bpad, fbg, Tpad};
+    MP_RUN(k_fixed_msm, C, T, ph.n_f, fx);
+    if (ph.n_c0) {
+      CombineArgs cb0{w.J.p, w.P.p, ph.cjobs0.p, ph.cterms0.p, w.Bpad};
+      MP_RUN(k_combine, C, T, ph.n_c0, cb0);
+    }
+    CombineArgs cb{w.J.p, w.P.p, ph.cjobs.p, ph.cterms.p, w.Bpad};
+    MP_RUN(k_combine, C, T, ph.n_c, cb);
+    uint32_t* fl = host_flag;
+    if (!fl) {
+      if (!vflag.n) vflag.alloc(1, s);
+      rt::dzero(vflag.p, 4, s);
+      fl = vflag.p;
+    }
+    ChainVerdictArgs va{w.J.p, w.direct.p, w.status.p, fl, w.Bpad, T, L, 0u, w.P.p, NO_SLOT};
+    MP_RUN(k_chain_verdict, C, T, 1, va);
+    rt::d2d(v.status, w.status.p, (size_t)B * 4, s);      // zeros unless an input was refused (final if the flag stays down)
   }
 
   // ---------------------------------------------------------------- building blocks (ad-hoc plans)

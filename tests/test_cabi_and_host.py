@@ -609,3 +609,59 @@ def test_emulated_device_decompression_matches_oracle(emu, name):
     from decompress_cases import run_decompress_cases
     g = load_json(os.path.join(GOLDEN, name))
     run_decompress_cases(emu(g["curve"]), _HostMem(), g["curve"], g, n_random=6 if g["curve"] != "bls12_377" else 3)
+
+
+@pytest.mark.parametrize("cv,keyed", [("stark", False), ("stark", True), ("secp256k1", False)])
+def test_emulated_group_verification(emu, coracle, cv, keyed):
+    """round 4, group verification: the screening pass of a batch as one equation per group of proofs on the bucket kernel -- same status
+    words as the per-proof screen for honest batches, one bad proof, a bad input encoding, every proof bad; with and without pipelining"""
+    import ctypes
+    m, n, B = 2, 3, 6
+    eng = emu(cv)
+    ins = [coracle.gen_inputs(cv, m, n, 6100 + b) for b in range(B)]
+    g0 = ins[0]
+    keys = b"".join(coracle.gen_inputs(cv, m, n, 6200 + b % 2)["pk"] for b in range(B))
+    t = eng.table(m, n, g0["params"], None if keyed else g0["pk"])
+    args = (b"".join(g["deck"] for g in ins), b"".join(g["rho"] for g in ins), [v for g in ins for v in g["perm"]],
+            b"".join(g["prover_seed"] for g in ins))
+    prove = (lambda: t.shuffle_and_remask_batch_keys(keys, *args)) if keyed else (lambda: t.shuffle_and_remask_batch(*args))
+    verify = (lambda d, s_, p: t.verify_shuffle_batch_keys(keys, d, s_, p)) if keyed else (lambda d, s_, p: t.verify_shuffle_batch(d, s_, p))
+    t.set_work_split(0)
+    t.set_group_verify(0, 0)
+    ref = prove()
+    dsz, psz = len(g0["deck"]), t.proof_bytes
+    bad_p = bytearray(ref[1])
+    bad_p[5 * psz - 31] ^= 2                              # proof 4: one bit of its last response scalar
+    bad_d = bytearray(ref[0])
+    bad_d[1 * dsz + 5] ^= 1                                # deck 1: a coordinate that is not on the curve any more
+    rot = ref[0][dsz:] + ref[0][:dsz]
+    cases = {"good": (ref[0], ref[1]), "badproof": (ref[0], bytes(bad_p)), "badpoint": (bytes(bad_d), ref[1]), "rotated": (rot, ref[1])}
+    want = {k: verify(args[0], d, p) for k, (d, p) in cases.items()}
+    assert want["good"] == [0] * B and want["badproof"][4] > 0 and want["badpoint"][1] < 0 and all(v > 0 for v in want["rotated"])
+    for links in (3, 2, 6):
+        t.set_group_verify(links, 2)
+        eng.profile_enable(True)
+        for k, (d, p) in cases.items():
+            assert verify(args[0], d, p) == want[k], (links, k)
+        rep = eng.profile_report()
+        eng.profile_enable(False)
+        assert "k_chain_scalars" in rep and "k_bucket_msm" in rep
+    if not keyed:                                          # pipelined: the group pass is the deferred screen
+        buf = lambda b: (ctypes.c_uint8 * len(b)).from_buffer_copy(b)
+        addr = ctypes.addressof
+        decks = buf(args[0])
+        t.set_group_verify(3, 2)
+        t.set_pipeline(1)
+        held = []
+        for k, (d, p) in cases.items():
+            st = (ctypes.c_int32 * B)(*([55] * B))
+            db, pb_ = buf(d), buf(p)
+            held.append((k, st, db, pb_))
+            t.verify_shuffle_batch_dev(B, addr(decks), addr(db), addr(pb_), addr(st))
+        eng.sync()
+        for k, st, _, _ in held:
+            assert list(st) == want[k], k
+        t.set_pipeline(0)
+    t.set_group_verify(16, 6144)
+    t.set_work_split(-1)
+    t.close()

@@ -321,3 +321,102 @@ def test_pipelined_verification_with_keys_and_key_sets(mp, coracle):
     ks.close()
     table.close()
     eng.close()
+
+
+@pytest.mark.parametrize("cv,m,n", [("stark", 2, 26), ("secp256k1", 2, 7), ("bn254", 3, 5)])
+def test_group_verification_status_words(mp, coracle, cv, m, n):
+    """group verification (mp_set_group_verify): the screen of a batch is one bucket-method equation per group of proofs -- status words equal
+    those of the per-proof screen and of per-equation verification for honest batches, one bad response scalar, one bad input point,
+    every proof against a neighbour's deck; group sizes that divide the batch, one that does not (falls back to the per-proof screen);
+    pipelined too.  The oracle verifies / rejects the same proofs."""
+    import torch
+    B = 12
+    eng = mp._native.Engine(cv, 0)
+    ins, args = _inputs(coracle, cv, m, n, B, 5800)
+    g0 = ins[0]
+    t = eng.table(m, n, g0["params"], g0["pk"])
+    t.set_work_split(0)
+    t.set_group_verify(0, 0)
+    out = t.shuffle_and_remask_batch(*args)
+    assert (out[0], out[1]) == _expected(coracle, cv, m, n, g0, ins)
+    dsz, psz = len(g0["deck"]), t.proof_bytes
+    bad_p = bytearray(out[1])
+    bad_p[8 * psz - 31] ^= 2                              # proof 7: its last response scalar
+    bad_d = bytearray(out[0])
+    bad_d[3 * dsz + 5] ^= 1                               # shuffled deck 3: not a curve point any more
+    cases = {"good": (out[0], out[1]), "badproof": (out[0], bytes(bad_p)), "badpoint": (bytes(bad_d), out[1]),
+             "rotated": (out[0][dsz:] + out[0][:dsz], out[1])}
+    want = {k: t.verify_shuffle_batch(args[0], d, p) for k, (d, p) in cases.items()}
+    assert want["good"] == [0] * B and want["badproof"][7] > 0 and sum(1 for v in want["badproof"] if v) == 1
+    assert want["badpoint"][3] < 0 and all(v > 0 for v in want["rotated"])
+    assert coracle.verify_shuffle(cv, m, n, g0["params"], g0["pk"], ins[7]["deck"], out[0][7 * dsz:8 * dsz], bytes(bad_p[7 * psz:8 * psz])) == want["badproof"][7]
+    t.set_merged_verify(False)
+    assert {k: t.verify_shuffle_batch(args[0], d, p) for k, (d, p) in cases.items()} == want
+    t.set_merged_verify(True)
+    for links, expect_group in ((4, 4), (6, 6), (12, 12), (3, 3), (5, 6), (7, 6)):
+        t.set_group_verify(links, 2)
+        assert t.group_size(B) == expect_group
+        eng.profile_enable(True)
+        got = {k: t.verify_shuffle_batch(args[0], d, p) for k, (d, p) in cases.items()}
+        rep = eng.profile_report()
+        eng.profile_enable(False)
+        assert got == want, links
+        assert "k_chain_scalars" in rep and "k_bucket_msm" in rep
+    t.set_group_verify(4, 13)                               # batch below the minimum: per-proof screen
+    assert t.group_size(B) == 0
+    assert t.verify_shuffle_batch(args[0], out[0], out[1]) == [0] * B
+    # pipelined: the group pass is the deferred screen
+    gpu = torch.device("cuda", 0)
+    dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(gpu)
+    t.set_group_verify(4, 2)
+    t.set_pipeline(1)
+    decks = dev(args[0])
+    held = []
+    for k, (d, p) in cases.items():
+        st = torch.full((B,), 55, dtype=torch.int32, device=gpu)
+        dd, pp_ = dev(d), dev(p)
+        held.append((k, st, dd, pp_))
+        t.verify_shuffle_batch_dev(B, decks.data_ptr(), dd.data_ptr(), pp_.data_ptr(), st.data_ptr())
+    eng.sync()
+    for k, st, _, _ in held:
+        assert st.cpu().tolist() == want[k], k
+    t.set_pipeline(0)
+    t.close()
+    eng.close()
+
+
+def test_group_verification_at_full_size(mp, coracle):
+    """a size the oracle cannot cover: 8 192 proofs (512 groups of 16): every proof accepted; ONE tampered proof anywhere makes exactly that
+    proof fail with the reference's check name, as without groups"""
+    import torch
+    cv, m, n, B = "stark", 2, 26, 8192
+    eng = mp._native.Engine(cv, 0)
+    g0 = coracle.gen_inputs(cv, m, n, 5900)
+    t = eng.table(m, n, g0["params"], g0["pk"], fb_bits=16)
+    assert t.group_size(B) == 16
+    gpu = torch.device("cuda", 0)
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(5)
+    N = m * n
+    decks = torch.frombuffer(bytearray(g0["deck"]), dtype=torch.uint8).to(gpu).repeat(B, 1).contiguous()
+    rho = torch.randint(0, 256, (B, N, 32), dtype=torch.uint8, device=gpu, generator=gen)
+    rho[:, :, 31] &= 7
+    perm = torch.argsort(torch.rand(B, N, device=gpu, generator=gen), dim=1).to(torch.int32).contiguous()
+    seeds = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device=gpu, generator=gen)
+    od = torch.empty(B, len(g0["deck"]), dtype=torch.uint8, device=gpu)
+    op = torch.empty(B, t.proof_bytes, dtype=torch.uint8, device=gpu)
+    sp = torch.empty(B, dtype=torch.int32, device=gpu)
+    sv = torch.empty(B, dtype=torch.int32, device=gpu)
+    t.shuffle_and_remask_batch_dev(B, decks.data_ptr(), rho.data_ptr(), perm.data_ptr(), seeds.data_ptr(), od.data_ptr(), op.data_ptr(), sp.data_ptr())
+    t.verify_shuffle_batch_dev(B, decks.data_ptr(), od.data_ptr(), op.data_ptr(), sv.data_ptr())
+    eng.sync()
+    assert int(sp.abs().sum().item()) == 0 and int(sv.abs().sum().item()) == 0
+    op[4321, t.proof_bytes - 31] ^= 2
+    od[77, 0:64] = od[78, 0:64]                             # card 0 of deck 77 replaced by a neighbour's: a valid point, a wrong statement
+    t.verify_shuffle_batch_dev(B, decks.data_ptr(), od.data_ptr(), op.data_ptr(), sv.data_ptr())
+    eng.sync()
+    st = sv.cpu().tolist()
+    assert [i for i, v in enumerate(st) if v] == [77, 4321]
+    assert eng.check_name(st[77]) == "Hadamard Product (5.1)" and st[4321] > 0
+    t.close()
+    eng.close()
