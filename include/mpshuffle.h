@@ -213,15 +213,16 @@ int mp_set_plan_thresholds(mp_table* t, size_t finest, size_t small, size_t late
  * FIRST failing check is reported by name exactly as the reference does [REF tests.rs:223-225].  off: always evaluate
  * the equations one by one.  Results (status words) are identical in both modes. */
 int mp_set_merged_verify(mp_table* t, int on);
-/* Group verification (round 4; on by default for decks of up to ~230 cards).  The screening pass of a batch of at least `min_batch`
- * proofs (default 6 144) adds the merged equations of `proofs_per_group` proofs (default 16; the divisor of the batch size nearest to
- * it between half and twice that; batches without one keep the per-proof screen) with weights derived from every proof of the group
- * and evaluates the sum -- 3 808 points for 16 proofs of a 52-card deck -- on the bucket-method kernel (LDS-staged digits, counting sort
- * by wavefront prefix sum, wave-wide bucket reduction): 33 additions per point instead of 51 plus window tables and doubling chains,
- * and the fixed bases once per group (521 k -> 591 k proofs/s at 262 144 in flight).  A batch in which some group fails is re-evaluated
- * equation by equation: status words are identical to every other strategy.  0 switches it off.  Needs merged verification on.
- * mp_group_size: the group size a batch of B proofs takes under the table's own key (0: per-proof screen). */
-int mp_set_group_verify(mp_table* t, uint32_t proofs_per_group, size_t min_batch);
+/* Group verification (round 4; on by default for decks whose own verifier equation is below the bucket kernel's threshold: up to ~500
+ * cards).  The screening pass of a batch of at least `min_batch` x 52 / N proofs (default 6 144 for 52-card decks) adds the merged equations of a GROUP of proofs with
+ * weights derived from every proof of the group and evaluates the sum on the bucket-method kernel (LDS-staged digits, counting sort by
+ * wavefront prefix sum, wave-wide bucket reduction): 33 additions per point instead of 51 plus window tables and doubling chains, and the
+ * fixed bases once per group (52-card decks: 521 k -> 591 k proofs/s at 262 144 in flight).  `points_per_group` (default 3 808) is the size
+ * of a group's equation aimed at: a proof brings 4N + 11m + 8 points, so 16 proofs of a 52-card deck, 3 of a 300-card one; the group size
+ * is the divisor of the batch size nearest to that (between half and twice it; a batch without one keeps the per-proof screen).  A batch in
+ * which some group fails is re-evaluated equation by equation: status words are identical to every other strategy.  0 switches it off.
+ * Needs merged verification on.  mp_group_size: the group size a batch of B proofs takes under the table's own key (0: per-proof screen). */
+int mp_set_group_verify(mp_table* t, uint32_t points_per_group, size_t min_batch);
 uint32_t mp_group_size(const mp_table* t, size_t B);
 /* Variable-base MSMs with at least `terms` terms (default 2048: the verifier's products over a 1024-card deck) run on the
  * wave-cooperative bucket-method kernel (LDS-staged digits, counting sort by wavefront prefix sum, wave-wide bucket reduction),

@@ -608,9 +608,10 @@ class Table:
         """proofs per group of the screening pass for a batch of B (0: per-proof screen)"""
         return self.lib.mp_group_size(self.h, B)
 
-    def set_group_verify(self, proofs_per_group=16, min_batch=6144):
-        """screening pass of large batches: one equation per group of proofs on the bucket kernel (0 = off)"""
-        self.eng._chk(self.lib.mp_set_group_verify(self.h, proofs_per_group, min_batch))
+    def set_group_verify(self, points_per_group=3808, min_batch=6144):
+        """screening pass of large batches: one equation of ~points_per_group points per group of proofs on the bucket kernel (a proof
+        brings 4N + 11m + 8 points; 0 = off)"""
+        self.eng._chk(self.lib.mp_set_group_verify(self.h, points_per_group, min_batch))
 
     def set_pipeline(self, depth=1):
         """depth >= 1: device-resident verify calls run on the context's second lane beside the next prove call and do not wait for

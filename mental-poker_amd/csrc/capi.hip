@@ -278,13 +278,13 @@ int mp_set_work_split(mp_table* t, int split) {
   t->forced_split = split;
   return MP_OK;
 }
-int mp_set_group_verify(mp_table* t, uint32_t proofs_per_group, size_t min_batch) {
+int mp_set_group_verify(mp_table* t, uint32_t points_per_group, size_t min_batch) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_verify: null table");
-  if (proofs_per_group == 1 || proofs_per_group > 1024) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_verify: 0 (off) or 2 .. 1024 proofs per group");
+  if (points_per_group > 32767) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_verify: 0 (off) or up to 32 767 points per group equation");
   MP_TRY
   rt::set_device(t->ctx->device);
   t->flush();
-  t->set_group_verify(proofs_per_group, min_batch);
+  t->set_group_verify(points_per_group, min_batch);
   return MP_OK;
   MP_CATCH
 }

@@ -1327,22 +1327,27 @@ struct Table : mp_table {
   // (measured on 52-card decks, proofs/s at 262 144 / 65 536 / 16 384 / 8 192 / 4 096 in flight: off 521 / 495 / 437 / 383 / 315 k; groups of
   // 8: 538 / 517 / 443 / 389 / 305 k; of 16: 591 / 565 / 471 / 401 / 314 k; of 32: 574 / 545 / 455 / - / 287 k; of 64: 494 / 474 / 395 k -- a
   // wave of the bucket kernel sorts the whole equation in LDS, 12.5 KB at 16 proofs, and larger equations cost occupancy)
-  uint32_t group_links = 16;          // proofs per group aimed at (mp_set_group_verify; 0 = off)
-  uint32_t group_min_batch = 6144;    // smaller batches keep the per-proof screen (the bucket kernel wants T x 33 waves)
-  void set_group_verify(uint32_t links, size_t min_batch) override {
-    group_links = links;
+  uint32_t group_points = 3808;       // points per group equation aimed at (mp_set_group_verify; 0 = off): 16 proofs of a 52-card deck
+  uint32_t group_min_batch = 6144;    // smaller batches (in 52-card proofs: x 52 / N) keep the per-proof screen (the bucket kernel wants T x 33 waves)
+  void set_group_verify(uint32_t points, size_t min_batch) override {
+    group_points = points;
     group_min_batch = (uint32_t)std::min<size_t>(min_batch, 0x7FFFFFFFu);
   }
-  // proofs per group for a batch of B: the divisor of B nearest to group_links in [group_links / 2, 2 group_links] whose equation
+  // proofs per group for a batch of B: the divisor of B nearest to the wanted size (between half and twice it) whose equation
   // fits the 32 767 points of one bucket job; 0 = this batch takes the per-proof screen
   uint32_t group_size_of(size_t B) const override { return B < 0x7FFFFFFFu ? group_size((uint32_t)B, false) : 0; }
   uint32_t group_size(uint32_t B, bool keyed) const {
     const uint32_t per = 4 * N + 11 * m + 8 + (keyed ? 1u : 0u);
-    if (!group_links || !merged_verify || B < group_min_batch || per > 1024) return 0;
-    for (uint32_t d = 0; d <= group_links; ++d)
+    // (a proof whose own equation already runs on the bucket kernel -- 1024-card decks -- gains nothing from a group)
+    // (the minimum counts lanes like the work-split thresholds: a proof of N cards brings N / 52 times the points of a 52-card one)
+    if (!group_points || !merged_verify || (uint64_t)B * N < (uint64_t)group_min_batch * 52u || (bucket_min && per >= bucket_min)) return 0;
+    // as many proofs per group as bring its equation nearest to group_points points (3 808: what a wave of the bucket kernel sorts
+    // comfortably in LDS -- 16 proofs of a 52-card deck, 3 of a 300-card one)
+    const uint32_t want = std::max<uint32_t>(2u, (group_points + per / 2) / per);
+    for (uint32_t d = 0; d <= want; ++d)
       for (int sgn = 1; sgn >= -1; sgn -= 2) {
-        const int64_t L = (int64_t)group_links + sgn * (int64_t)d;
-        if (L < 2 || L < (int64_t)group_links / 2 || L > 2 * (int64_t)group_links || (uint64_t)L * per > 32767u) continue;
+        const int64_t L = (int64_t)want + sgn * (int64_t)d;
+        if (L < 2 || 2 * L < (int64_t)want || L > 2 * (int64_t)want || (uint64_t)L * per > 32767u) continue;
         if (B % (uint32_t)L == 0) return (uint32_t)L;
       }
     return 0;

@@ -639,7 +639,7 @@ def test_emulated_group_verification(emu, coracle, cv, keyed):
     want = {k: verify(args[0], d, p) for k, (d, p) in cases.items()}
     assert want["good"] == [0] * B and want["badproof"][4] > 0 and want["badpoint"][1] < 0 and all(v > 0 for v in want["rotated"])
     for links in (3, 2, 6):
-        t.set_group_verify(links, 2)
+        t.set_group_verify(links * (4 * m * n + 11 * m + 8 + (1 if keyed else 0)), 0)
         eng.profile_enable(True)
         for k, (d, p) in cases.items():
             assert verify(args[0], d, p) == want[k], (links, k)
@@ -650,7 +650,7 @@ def test_emulated_group_verification(emu, coracle, cv, keyed):
         buf = lambda b: (ctypes.c_uint8 * len(b)).from_buffer_copy(b)
         addr = ctypes.addressof
         decks = buf(args[0])
-        t.set_group_verify(3, 2)
+        t.set_group_verify(3 * (4 * m * n + 11 * m + 8), 0)
         t.set_pipeline(1)
         held = []
         for k, (d, p) in cases.items():
@@ -662,6 +662,6 @@ def test_emulated_group_verification(emu, coracle, cv, keyed):
         for k, st, _, _ in held:
             assert list(st) == want[k], k
         t.set_pipeline(0)
-    t.set_group_verify(16, 6144)
+    t.set_group_verify(3808, 6144)
     t.set_work_split(-1)
     t.close()

@@ -354,7 +354,7 @@ def test_group_verification_status_words(mp, coracle, cv, m, n):
     assert {k: t.verify_shuffle_batch(args[0], d, p) for k, (d, p) in cases.items()} == want
     t.set_merged_verify(True)
     for links, expect_group in ((4, 4), (6, 6), (12, 12), (3, 3), (5, 6), (7, 6)):
-        t.set_group_verify(links, 2)
+        t.set_group_verify(links * (4 * m * n + 11 * m + 8), 0)
         assert t.group_size(B) == expect_group
         eng.profile_enable(True)
         got = {k: t.verify_shuffle_batch(args[0], d, p) for k, (d, p) in cases.items()}
@@ -362,13 +362,13 @@ def test_group_verification_status_words(mp, coracle, cv, m, n):
         eng.profile_enable(False)
         assert got == want, links
         assert "k_chain_scalars" in rep and "k_bucket_msm" in rep
-    t.set_group_verify(4, 13)                               # batch below the minimum: per-proof screen
+    t.set_group_verify(4 * (4 * m * n + 11 * m + 8), 60)    # batch below the minimum (60 x 52 / N proofs): per-proof screen
     assert t.group_size(B) == 0
     assert t.verify_shuffle_batch(args[0], out[0], out[1]) == [0] * B
     # pipelined: the group pass is the deferred screen
     gpu = torch.device("cuda", 0)
     dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(gpu)
-    t.set_group_verify(4, 2)
+    t.set_group_verify(4 * (4 * m * n + 11 * m + 8), 0)
     t.set_pipeline(1)
     decks = dev(args[0])
     held = []

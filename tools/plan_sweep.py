@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=-1, help="mp_set_pipeline value for every run (-1: leave the default)")
     ap.add_argument("--group-lanes", type=int, default=None)
     ap.add_argument("--merged", type=int, default=None, help="1/0: mp_set_merged_verify")
-    ap.add_argument("--group", default=None, help="mp_set_group_verify as links:min_batch (0:0 = off)")
+    ap.add_argument("--group", default=None, help="mp_set_group_verify as points:min_batch (0:0 = off; 3808 points = 16 proofs of 52 cards)")
     ap.add_argument("--late-pipeline", action="store_true", help="switch pipelining on only after the priming pass (as bench.py's batch_curve does)")
     ap.add_argument("--profile", action="store_true", help="per-kernel milliseconds of one step per configuration")
     args = ap.parse_args()
