@@ -2,23 +2,25 @@
 // 1024-card deck (4N + 11m + 9 = 4193 terms in one equation at m = 8, n = 128) -- as a WAVE-COOPERATIVE kernel: one 64-lane
 // wave owns one (proof, MSM, window) and computes sum_t d_t P_t for the window's signed 8-bit digits d_t:
 //
-//   A  the window's K digits are staged into LDS (coalesced 4-byte loads of the proof-major digit array);
+//   A  the window's K digits are read as words of four from the proof-major digit array (twice: B and D; 4 KB that stay in cache);
 //   B  histogram of |d| over the 128 buckets (LDS atomics);
-//   C  bucket offsets: every lane owns the two buckets {2l+1, 2l+2}; an exclusive wavefront prefix sum over the lanes'
-//      pair counts gives the offsets of a counting sort;
+//   C  bucket offsets: an exclusive wavefront prefix sum over the pair counts {2l+1, 2l+2} gives the offsets of a counting sort;
 //   D  scatter: term indices (sign in bit 15) sorted by bucket into LDS;
-//   E  accumulation: the lane walks its two buckets from the top, run += +-P_t (XYZZ + affine, 8M+2S; the points come
-//      from the P arena, once per window and L2-resident across the windows of a proof); at the switch between its two
-//      buckets it copies the running sum (acc = S_{2l+2}), so that at the end  (2l+2) S_{2l+2} + (2l+1) S_{2l+1} = (2l+1) run + acc
-//      with NO multiplication by a bucket number and no bucket array in memory; a window whose digits crowd into a few
-//      buckets (the top window of a 252-bit scalar has 8) is cut into equal shares of the sorted list instead;
-//   F  bucket reduction across the wave: sum_l [(2l+1) run_l + acc_l] = sum_l acc_l + Suf_0 + 2 sum_{l>=1} Suf_l with the
-//      inclusive suffix sums Suf_l = sum_{l'>=l} run_l' -- a 6-step wavefront suffix scan and a 6-step tree reduction of
-//      XYZZ points exchanged through LDS (14 point additions per window instead of the 2 x 128 of the serial running sum).
+//   E  accumulation: every lane sums two buckets, run += +-P_t (XYZZ + affine, 8M+2S; the points come from the P arena, once
+//      per window and L2-resident across the windows of a proof).  WHICH two is a matter of balance -- the wave waits for its
+//      slowest lane: the r-th fullest odd bucket goes with the r-th emptiest even one (ranks by counting, round 4), so the lanes'
+//      shares differ by a term or two; a window whose digits crowd into a few buckets (the top window of a 252-bit scalar has 8)
+//      is cut into equal shares of the sorted list instead;
+//   F  bucket reduction across the wave: the sums travel through LDS to the lanes that own the pairs {2l+1, 2l+2}; there
+//      (2l+2) S_{2l+2} + (2l+1) S_{2l+1} = (2l+1) run_l + acc_l with run_l = S_{2l+2} + S_{2l+1}, acc_l = S_{2l+2} (one addition, NO
+//      multiplication by a bucket number, no bucket array in memory) and
+//      sum_l [(2l+1) run_l + acc_l] = sum_l acc_l + Suf_0 + 2 sum_{l>=1} Suf_l with the inclusive suffix sums
+//      Suf_l = sum_{l'>=l} run_l' -- a 6-step wavefront suffix scan and a 6-step tree reduction of XYZZ points exchanged through
+//      LDS (15 point additions per window instead of the 2 x 128 of the serial running sum).
 //
 // The W window results of an MSM are folded (8 doublings + 1 addition per window) by k_bucket_fold; its output slot joins
 // the MSM's other partial sums in k_combine exactly like a Straus sub-job's.  Per term and window this is one mixed
-// addition plus (load imbalance + 14 wave-wide additions) / terms-per-lane -- 33 windows instead of Straus' 51 and no
+// addition plus (load imbalance + 15 wave-wide additions) / terms-per-lane -- 33 windows instead of Straus' 51 and no
 // per-base window tables at all (no k_table work, no 1 KB of table per base): it wins from ~2 000 terms per MSM on
 // (DESIGN.md "bucket MSM"); below that the Straus kernel (kernels_msm.hpp) stays.
 // Replaces ark-ec 0.3 `VariableBaseMSM::multi_scalar_mul` (the bucket method, sequential on the CPU) inside the
@@ -33,7 +35,7 @@ static const uint32_t BK_BUCKETS = 128;          // |d| = 1 .. 128: two buckets 
 static const uint32_t BK_HDR = 272;              // LDS words in front of the sort arrays: counts[132] + cursors[132] (+ pad)
 static inline uint32_t bk_windows(int scalar_bits) { return (uint32_t)(scalar_bits + BK_BITS) / BK_BITS; }
 // LDS words one wave needs for an MSM of kpad (multiple of 64) terms on a curve whose XYZZ point is xw words
-static inline uint32_t bk_lds_words(uint32_t kpad, uint32_t xw) { return BK_HDR + std::max(3u * kpad / 4u, 64u * xw); }
+static inline uint32_t bk_lds_words(uint32_t kpad, uint32_t xw) { return BK_HDR + std::max(kpad / 2u, 64u * xw); }
 
 // ---- digits: canonical scalar -> W signed bytes, d_w in [-128, 127] (top window non-negative), proof-major:
 // D8[b * dstride + pos + w * kpad]  (pos = digit offset of the term inside the proof's block, kpad = padded terms of its MSM)
@@ -117,31 +119,32 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t wid, W& wv) {
   const BJob job = a.jobs[jb];
   const uint32_t K = job.count, kpad = job.kpad;
   uint32_t* cnt = wv.lds;                         // [0 .. 128]: terms per |digit|
-  uint32_t* cur = wv.lds + 132;                   // scatter cursors
+  uint32_t* cur = wv.lds + 132;                   // scatter cursors; after the scatter: the lanes' bucket assignment
   uint16_t* ix = reinterpret_cast<uint16_t*>(wv.lds + BK_HDR);              // sorted term indices | sign << 15
-  uint32_t* dgw = wv.lds + BK_HDR + kpad / 2;                                 // staged digits (bytes)
-  const int8_t* dg = reinterpret_cast<const int8_t*>(dgw);
   uint32_t* xch = wv.lds + BK_HDR;                                            // point exchange (after the sort arrays are dead)
+  // the window's digits: K bytes (kpad a multiple of 64), read twice as words of four -- 4 KB that stay in the L1/L2
   const uint32_t* src = reinterpret_cast<const uint32_t*>(a.D8 + (size_t)b * a.dstride + job.dig_off + (size_t)w * kpad);
 
-  // A: stage the digits, clear the histogram
+  // A: clear the histogram
   wv.lanes([&](uint32_t lane) {
     for (uint32_t i = lane; i < 132; i += 64) cnt[i] = 0;
-    for (uint32_t i = lane; i < kpad / 4; i += 64) dgw[i] = src[i];
   });
   wv.sync();
   // B: histogram of |d|
   wv.lanes([&](uint32_t lane) {
-    for (uint32_t t = lane; t < K; t += 64) {
-      const int d = dg[t];
-      wv.atomic_add(&cnt[d < 0 ? -d : d], 1u);
+    for (uint32_t i = lane; i < kpad / 4; i += 64) {
+      const uint32_t four = src[i];
+#pragma unroll
+      for (uint32_t q = 0; q < 4; ++q) {
+        const int d = (int8_t)(four >> (8 * q));
+        if (4 * i + q < K) wv.atomic_add(&cnt[d < 0 ? -d : d], 1u);
+      }
     }
   });
   wv.sync();
   // C: offsets of the counting sort (wavefront prefix sum over the lanes' two-bucket counts)
   PerLane<uint32_t> lo1, lo2, end, pair;
   wv.lanes([&](uint32_t lane) { pair[lane] = cnt[2 * lane + 1] + cnt[2 * lane + 2]; });
-  const uint32_t maxpair = wv.max(pair);
   wv.excl_scan(pair);
   wv.lanes([&](uint32_t lane) {
     const uint32_t c1 = cnt[2 * lane + 1], c2 = cnt[2 * lane + 2];
@@ -160,35 +163,61 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t wid, W& wv) {
   const uint32_t T = off[129];
   // D: scatter (zero digits take no part)
   wv.lanes([&](uint32_t lane) {
-    for (uint32_t t = lane; t < K; t += 64) {
-      const int d = dg[t];
-      if (d != 0) {
-        const uint32_t pos = wv.atomic_add(&cur[d < 0 ? -d : d], 1u);
-        ix[pos] = (uint16_t)(t | (d < 0 ? 0x8000u : 0u));
+    for (uint32_t i = lane; i < kpad / 4; i += 64) {
+      const uint32_t four = src[i];
+#pragma unroll
+      for (uint32_t q = 0; q < 4; ++q) {
+        const int d = (int8_t)(four >> (8 * q));
+        const uint32_t t = 4 * i + q;
+        if (t < K && d != 0) {
+          const uint32_t pos = wv.atomic_add(&cur[d < 0 ? -d : d], 1u);
+          ix[pos] = (uint16_t)(t | (d < 0 ? 0x8000u : 0u));
+        }
       }
     }
   });
   wv.sync();
-  // E: accumulation.  Every lane walks a segment [s0, s1) of the sorted list from the top; whenever it crosses into the next
-  // lower bucket it adds the running sum to acc (the first time acc is still the identity and the addition is a copy), so that
-  // at the end  sum_t d_t P_t over the segment = lo * run + acc  with lo the lowest bucket reached.
-  //   pair mode     the segment is the lane's two buckets {2l+1, 2l+2}: one switch per lane, never a real addition, lo = 2l+1;
-  //   balanced mode (a window whose digits crowd into few buckets -- the top window of a 252-bit scalar has 8): equal
-  //                 shares of the sorted list; the buckets are long there, so a segment still crosses at most one boundary.
+  // E: accumulation, one mixed addition per term: run += +-P_t.
+  //   pair mode     every lane takes one odd and one even bucket -- the r-th fullest odd one with the r-th emptiest even one, so
+  //                 that the lanes' shares differ by a term or two instead of by the +-2.4 sigma of the fullest pair {2l+1, 2l+2}
+  //                 (78 against 59.5 terms on average at 3 808 terms: the wave waits for its slowest lane) -- and sums them one
+  //                 after the other (acc = the odd bucket's sum, run = the even one's); the sums then change lanes through LDS
+  //                 (stage F) to where the reduction wants them;
+  //   balanced mode (a window whose digits crowd into few buckets -- the top window of a 252-bit scalar has 8): equal shares of
+  //                 the sorted list, walked from the top; whenever a lane crosses into the next lower bucket it adds the running
+  //                 sum to acc, so that at the end  sum_t d_t P_t over the share = lo * run + acc  with lo the lowest bucket reached
+  //                 (the buckets are long there, so a share crosses at most one boundary or so).
+  PerLane<uint32_t> n, nA, oA, oB, s1, cb;
+  wv.lanes([&](uint32_t lane) {              // ranks by counting: 2 x 64 broadcast reads per lane
+    const uint32_t co = lo2[lane] - lo1[lane], ce = end[lane] - lo2[lane];
+    uint32_t ro = 0, re = 0;
+    for (uint32_t l = 0; l < 64; ++l) {
+      const uint32_t o = off[2 * l + 2] - off[2 * l + 1], e = off[2 * l + 3] - off[2 * l + 2];
+      ro += (o > co || (o == co && l < lane)) ? 1u : 0u;
+      re += (e > ce || (e == ce && l < lane)) ? 1u : 0u;
+    }
+    cur[ro] = lane;                          // cur[r] = the lane whose odd bucket is the r-th fullest,
+    cur[64 + 63 - re] = lane;                // cur[64 + r] = the lane whose even bucket is the r-th emptiest
+  });
+  wv.sync();
+  wv.lanes([&](uint32_t lane) {
+    const uint32_t A = 2 * cur[lane] + 1, B2 = 2 * cur[64 + lane] + 2;
+    oA[lane] = off[A];
+    nA[lane] = off[A + 1] - off[A];
+    oB[lane] = off[B2];
+    n[lane] = nA[lane] + off[B2 + 1] - off[B2];
+  });
 #ifdef MP_EXP_BK_BALANCED  // experiment hook (tools/ab_build.py): every window in balanced mode
   const bool balanced = true;
 #else
-  const bool balanced = maxpair > T / 64 + T / 128 + 32;
+  const bool balanced = wv.max(n) > T / 64 + T / 128 + 32;
 #endif
   PerLane<Xyzz<C>> run, acc;
-  PerLane<uint32_t> n, s1, cb;
   wv.lanes([&](uint32_t lane) {
     run[lane] = xyzz_inf<C>();
     acc[lane] = xyzz_inf<C>();
-    uint32_t s0 = lo1[lane], hb = 2 * lane + 2;
-    s1[lane] = end[lane];
     if (balanced) {
-      s0 = (uint32_t)(((uint64_t)T * lane) >> 6);
+      const uint32_t s0 = (uint32_t)(((uint64_t)T * lane) >> 6);
       s1[lane] = (uint32_t)(((uint64_t)T * (lane + 1)) >> 6);
       uint32_t lo_b = 1, hi_b = 128;                    // largest bucket whose first position is <= s1 - 1
       const uint32_t last = s1[lane] ? s1[lane] - 1 : 0;
@@ -196,19 +225,27 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t wid, W& wv) {
         const uint32_t mid = (lo_b + hi_b + 1) >> 1;
         if (off[mid] <= last) lo_b = mid; else hi_b = mid - 1;
       }
-      hb = lo_b;
+      n[lane] = s1[lane] - s0;
+      cb[lane] = lo_b;
     }
-    n[lane] = s1[lane] - s0;
-    cb[lane] = hb;
   });
   const uint32_t iters = wv.max(n);
   for (uint32_t i = 0; i < iters; ++i) {
     wv.lanes([&](uint32_t lane) {
       if (i < n[lane]) {
-        const uint32_t p = s1[lane] - 1 - i;
-        while (p < off[cb[lane]]) {                     // into the next lower bucket
-          xyzz_add_ip<C>(acc[lane], run[lane]);
-          cb[lane] -= 1;
+        uint32_t p;
+        if (balanced) {
+          p = s1[lane] - 1 - i;
+          while (p < off[cb[lane]]) {                   // into the next lower bucket
+            xyzz_add_ip<C>(acc[lane], run[lane]);
+            cb[lane] -= 1;
+          }
+        } else {
+          if (i == nA[lane]) {                          // the odd bucket is done
+            acc[lane] = run[lane];
+            run[lane] = xyzz_inf<C>();
+          }
+          p = i < nA[lane] ? oA[lane] + i : oB[lane] + (i - nA[lane]);
         }
         const uint32_t e = ix[p];
         const uint32_t tb = a.bterms[job.begin + (e & 0x7FFFu)].b;
@@ -218,15 +255,27 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t wid, W& wv) {
     });
   }
   wv.sync();                                                          // the sort arrays are dead from here on
-  // F: sum over the lanes of lo_l * run_l + acc_l
+  // F: sum over the buckets of k S_k
   if (!balanced) {
-    // lo_l = 2l + 1:  sum_l (2l+1) run_l = Suf_0 + 2 sum_{l>=1} Suf_l with the inclusive suffix sums Suf_l = sum_{l'>=l} run_l'
-    wv.lanes([&](uint32_t lane) {                                     // lanes whose low bucket is empty never switched
-      while (cb[lane] > 2 * lane + 1) {
-        xyzz_add_ip<C>(acc[lane], run[lane]);
-        cb[lane] -= 1;
+    // the sums go home: lane l wants S_{2l+2} and S_{2l+1} (two rounds through the 64 exchange slots, even buckets first)
+    wv.lanes([&](uint32_t lane) {
+      if (n[lane] <= nA[lane]) {                                      // (an empty even bucket: the loop never switched)
+        acc[lane] = run[lane];
+        run[lane] = xyzz_inf<C>();
       }
+      xyzz_to_words<C>(run[lane], xch + cur[64 + lane] * XW);
     });
+    wv.sync();
+    wv.lanes([&](uint32_t lane) { run[lane] = xyzz_from_words<C>(xch + lane * XW); });
+    wv.sync();
+    wv.lanes([&](uint32_t lane) { xyzz_to_words<C>(acc[lane], xch + cur[lane] * XW); });
+    wv.sync();
+    wv.lanes([&](uint32_t lane) {                                     // acc = S_{2l+2}, run = S_{2l+2} + S_{2l+1}:
+      acc[lane] = run[lane];                                          // (2l+2) S_{2l+2} + (2l+1) S_{2l+1} = (2l+1) run + acc
+      xyzz_add_ip<C>(run[lane], xyzz_from_words<C>(xch + lane * XW));
+    });
+    wv.sync();
+    // sum_l (2l+1) run_l = Suf_0 + 2 sum_{l>=1} Suf_l with the inclusive suffix sums Suf_l = sum_{l'>=l} run_l'
     for (uint32_t s = 1; s < 64; s <<= 1) {
       wv.lanes([&](uint32_t lane) { xyzz_to_words<C>(run[lane], xch + lane * XW); });
       wv.sync();
