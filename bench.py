@@ -689,7 +689,7 @@ def main():
         if table.group_size(Bs):
             table.set_group_verify(0, 0)
             extras["per_proof_screen_value"] = timed_step(step)  # one merged equation per PROOF (Straus), the headline of rounds 1-3
-            table.set_group_verify(3808, 6144)
+            table.set_group_verify(30464, 6144)
         free_b, _ = torch.cuda.mem_get_info()
         if free_b > 40e9:
             k1000 = make_keys(1000, B)

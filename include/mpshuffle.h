@@ -213,22 +213,28 @@ int mp_set_plan_thresholds(mp_table* t, size_t finest, size_t small, size_t late
  * FIRST failing check is reported by name exactly as the reference does [REF tests.rs:223-225].  off: always evaluate
  * the equations one by one.  Results (status words) are identical in both modes. */
 int mp_set_merged_verify(mp_table* t, int on);
-/* Group verification (round 4; on by default for decks whose own verifier equation is below the bucket kernel's threshold: up to ~500
- * cards).  The screening pass of a batch of at least `min_batch` x 52 / N proofs (default 6 144 for 52-card decks) adds the merged equations of a GROUP of proofs with
- * weights derived from every proof of the group and evaluates the sum on the bucket-method kernel (LDS-staged digits, counting sort by
- * wavefront prefix sum, wave-wide bucket reduction): 33 additions per point instead of 51 plus window tables and doubling chains, and the
- * fixed bases once per group (52-card decks: 521 k -> 591 k proofs/s at 262 144 in flight).  `points_per_group` (default 3 808) is the size
- * of a group's equation aimed at: a proof brings 4N + 11m + 8 points, so 16 proofs of a 52-card deck, 3 of a 300-card one; the group size
- * is the divisor of the batch size nearest to that (between half and twice it; a batch without one keeps the per-proof screen).  A batch in
- * which some group fails is re-evaluated equation by equation: status words are identical to every other strategy.  0 switches it off.
- * Needs merged verification on.  mp_group_size: the group size a batch of B proofs takes under the table's own key (0: per-proof screen). */
+/* Group verification (round 4; on by default).  The screening pass of a batch of at least `min_batch` x 52 / N proofs (default 6 144 for
+ * 52-card decks) adds the merged equations of a GROUP of proofs with weights derived from every proof of the group and evaluates the sum
+ * on the bucket-method kernel (counting sort by wavefront prefix sum, balanced bucket shares, wave-wide bucket reduction): 26 to 33
+ * additions per point instead of 51 plus window tables and doubling chains, and the fixed bases once per group (52-card decks:
+ * 521 k -> 660 k proofs/s at 262 144 in flight).  `points_per_group` (default 30 464) is the size of a group's equation aimed at: a proof
+ * brings 4N + 11m + 8 points, so 128 proofs of a 52-card deck, 7 of a 1 024-card one -- but a batch takes no fewer than 2/13 `min_batch`
+ * groups (945: a dozen windows for each of the kernel's 2 048 persistent waves), i.e. 16 proofs per group at 16 384 in flight.  The group
+ * size is the divisor of the batch size nearest to that (between half and twice it; a batch without one keeps the per-proof screen).  A
+ * batch in which some group fails is re-evaluated equation by equation: status words are identical to every other strategy.
+ * points_per_group = 0 switches it off.  Needs merged verification on.  mp_group_size: the group size a batch of B proofs takes under the
+ * table's own key (0: per-proof screen). */
 int mp_set_group_verify(mp_table* t, uint32_t points_per_group, size_t min_batch);
 uint32_t mp_group_size(const mp_table* t, size_t B);
 /* Variable-base MSMs with at least `terms` terms (default 2048: the verifier's products over a 1024-card deck) run on the
- * wave-cooperative bucket-method kernel (LDS-staged digits, counting sort by wavefront prefix sum, wave-wide bucket reduction),
+ * wave-cooperative bucket-method kernel (counting sort by wavefront prefix sum, balanced bucket shares, wave-wide bucket reduction),
  * smaller ones on the Straus kernel with per-proof window tables; 0 = never.  Results are identical; the split is a property of
  * the table's static plans, which this call rebuilds. */
 int mp_set_bucket_min(mp_table* t, size_t terms);
+/* Window width of the bucket method: 8, 9 or 10 bits (128, 256 or 512 buckets per window; 32, 29 or 26 windows per 252-bit scalar), or
+ * 0 (default) = by the size of the MSM (8 bits below 6 000 terms, 9 below 12 000, 10 from there on -- the equation of a group of
+ * proofs, mp_set_group_verify).  Results are identical; rebuilds the static plans like mp_set_bucket_min. */
+int mp_set_bucket_bits(mp_table* t, uint32_t bits);
 /* Chain verification (mp_verify_shuffle_chain*): at most `links` links share one chain equation; longer chains are verified as
  * consecutive sub-chains.  0 (default) = as many as fit the 32 767 points of one equation (293 links of a 52-card deck).  A smaller
  * value bounds the LDS a chain equation needs and the work that is repeated link by link when a chain fails.  Verdicts are the same. */

@@ -255,6 +255,15 @@ int mp_set_bucket_min(mp_table* t, size_t terms) {
   return MP_OK;
   MP_CATCH
 }
+int mp_set_bucket_bits(mp_table* t, uint32_t bits) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_bits: null table");
+  if (bits != 0 && (bits < 8 || bits > 10)) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_bits: 0 (by size), 8, 9 or 10");
+  MP_TRY
+  rt::set_device(t->ctx->device);
+  t->set_bucket_bits(bits);
+  return MP_OK;
+  MP_CATCH
+}
 int mp_set_chain_max_links(mp_table* t, uint32_t links) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_chain_max_links: null table");
   t->chain_max_links = links;
@@ -447,7 +456,7 @@ int mp_verify_shuffle_chain_dev(mp_table* t, size_t tables, uint32_t links, cons
   const size_t pb = t->point_bytes, deck_bytes = (size_t)2 * t->N * pb, psz = proof_size_bytes(t->m, t->n, (uint32_t)pb);
   // (one link always fits: 4N + 11m + 9 <= 32 767 for every table mp_table_create accepts, m n <= 4096)
   if (fixed_part + per_link > 32767) return fail(MP_ERR_INTERNAL, "mp_verify_shuffle_chain_dev: deck too large for one chain equation");
-  uint32_t lmax = (uint32_t)((32767 - fixed_part) / per_link);
+  uint32_t lmax = std::min<uint32_t>((uint32_t)((32767 - fixed_part) / per_link), 1022u);      // (links 0 .. L in 10 bits of a sorted entry: kernels_bucket.hpp)
   if (t->chain_max_links) lmax = std::max(1u, std::min(lmax, t->chain_max_links));
   for (uint32_t j0 = 0; j0 < links; j0 += lmax) {
     const uint32_t lc = std::min(lmax, links - j0);

@@ -129,6 +129,12 @@ struct mp_ctx {
   uint32_t sq_geom[4] = {0, 0, 0, 0};     // S, w, k, bits of the fixed exponent; S = 0: not built yet
   uint32_t sq_exp[12] = {0};
   mp::Profiler prof;
+  // persistent waves of the bucket kernel (kernels_bucket.hpp): 8 per CU -- two workgroups of four, what its registers allow
+  uint32_t bk_slots = 0;
+  uint32_t bucket_slots() {
+    if (!bk_slots) bk_slots = 8u * mp::rt::cu_count();
+    return bk_slots;
+  }
 };
 namespace mp {
 // for the duration of a pipelined verify call the context's stream / side stream / events ARE the verify lane's
@@ -193,6 +199,7 @@ struct mp_table {
   uint32_t point_bytes = 64;   // wire size of a point on this table's curve (Geo<C>::PB)
   uint32_t fb_bits = 8;        // window width of the fixed-base tables (mp_table_window_bits)
   bool keyless = false;        // created from the parameters alone (mp_table_create_params): keyed entry points only
+  uint32_t bucket_bits = 0;       // window width of the bucket method (0 = by the size of the MSM: kernels_bucket.hpp bk_bits_for; mp_set_bucket_bits)
   uint32_t chain_max_links = 0;   // links per chain equation (0 = as many as fit 32 767 points; mp_set_chain_max_links)
   uint32_t fs_lanes = 0;          // lanes per transcript hash: 1, 4, or 0 = by batch size (mp_set_transcript_lanes)
   uint32_t group_lanes = 0;       // lanes per group operation of the MSM chains: 1, 4, or 0 = by batch size (mp_set_group_lanes)
@@ -206,6 +213,7 @@ struct mp_table {
   virtual void set_merged_verify(bool on) = 0;
   virtual void set_subgroup_check(bool on) = 0;
   virtual void set_bucket_min(uint32_t terms) = 0;
+  virtual void set_bucket_bits(uint32_t bits) = 0;
   virtual void set_toom_cook(bool on) = 0;
   virtual void set_group_verify(uint32_t links, size_t min_batch) = 0;
   virtual uint32_t group_size_of(size_t B) const = 0;

@@ -26,7 +26,7 @@ struct PhaseDev {
   DevBuf<Term> wcterms;
   DevBuf<BJob> wjobs;       // and the fold of an MSM's range sums
   uint32_t vsplit = 1, n_wc = 0, n_w = 0;
-  uint32_t n_b = 0, n_bterms = 0, b_dig_bytes = 0, b_kpad_max = 0;
+  uint32_t n_b = 0, n_bterms = 0, b_dig_bytes = 0, b_kpad_max = 0, b_bits = 8;
   uint32_t n_recode = 0, n_tables = 0, n_f = 0, n_v = 0, n_c = 0, n_c2 = 0, n_c0 = 0, n_tslots = 0, n_dslots = 0;
   std::vector<std::pair<uint32_t, uint32_t>> normalize;
   void upload(const Phase& ph, rt::Stream s) {
@@ -57,6 +57,7 @@ struct PhaseDev {
     n_bterms = (uint32_t)ph.bterms.size();
     b_dig_bytes = ph.b_dig_bytes;
     b_kpad_max = ph.b_kpad_max;
+    b_bits = ph.b_bits;
     n_recode = (uint32_t)ph.recode.size();
     n_tables = (uint32_t)ph.tables.size();
     n_f = (uint32_t)ph.fjobs.size();
@@ -76,8 +77,16 @@ struct Workspace {
   DevBuf<uint32_t> S, P, J, T, NS, NS2, stage, seed, direct;      // NS2: inversion scratch of the main stream while `side` has NS (prove_dev: m points per proof, allocated by reserve_ws for batches that fork)
   DevBuf<uint32_t> W;       // wire words of the loaded decks, [slot][word][Bpad] (what the transcript hashes; LoadPointsArgs::W)
   DevBuf<int8_t> D;
-  DevBuf<int8_t> D8;        // bucket-method digits, proof-major: [b][d8_bytes]
+  DevBuf<int16_t> D16;      // bucket-method digits, proof-major: [b][d8_bytes] (d8_bytes counts digits)
   uint32_t d8_bytes = 0;
+  // scratch rows of the bucket kernel's persistent waves (kernels_bucket.hpp): the sorted point references of the window a wave is
+  // working on, and its parked bucket sums -- at most 2 048 x (128 KB + 64 KB), whatever the batch
+  DevBuf<uint32_t> bk_sorted, bk_park, bk_counter, bk_timing;
+  void ensure_bucket(uint32_t nslots, uint32_t kpad_max, uint32_t bits, uint32_t xw, rt::Stream s) {
+    bk_sorted.alloc((size_t)nslots * kpad_max, s, false);
+    bk_park.alloc((size_t)nslots * bk_buckets(bits) * xw, s, false);
+    bk_counter.alloc(1, s);
+  }
   DevBuf<int32_t> status;
   // The arenas are slot-major with the lane stride Bpad.  Bpad follows the batch (B rounded up to a wave), whatever the arenas were
   // allocated for (`cap` lanes): a 1 024-proof batch laid out with the stride of an earlier 262 144-proof one touches 32 KB out of
@@ -97,9 +106,9 @@ struct Workspace {
       // re-allocate everything (capacity grows monotonically); zero-filled so padding lanes hold valid data
       S.n = P.n = J.n = T.n = NS.n = stage.n = seed.n = direct.n = 0;
       D.n = 0;
-      D8.n = 0;
+      D16.n = 0;
       d8_bytes = std::max(d8_bytes, d8_bytes_);
-      D8.alloc((size_t)std::max(d8_bytes, 4u) * cap, s);      // zero-filled: the padding digits of an MSM stay zero
+      D16.alloc((size_t)std::max(d8_bytes, 4u) * cap, s);      // zero-filled: the padding digits of an MSM stay zero
       status.n = 0;
       S.alloc((size_t)nS * cap * 8, s);
       P.alloc((size_t)nP * cap * 2 * fw, s);
@@ -117,7 +126,7 @@ struct Workspace {
     }
     if (Bpad != need) {
       Bpad = need;
-      rt::dzero(J.p, (size_t)nJ * Bpad * 3 * fw * sizeof(uint32_t), s);      // (the bucket digits D8 are proof-major: no stride in them)
+      rt::dzero(J.p, (size_t)nJ * Bpad * 3 * fw * sizeof(uint32_t), s);      // (the bucket digits D16 are proof-major: no stride in them)
     }
   }
 };
@@ -296,6 +305,17 @@ struct Table : mp_table {
     psk_ready = false;
     rt::stream_sync(ctx->stream);
   }
+  void set_bucket_bits(uint32_t bits) override {
+    if (bits == bucket_bits) return;
+    bucket_bits = bits;
+    flush();
+    rt::stream_sync(ctx->stream);
+    build_plans(ps, false);
+    psk_ready = false;
+    chain.L = 0;                     // (the chain and group equations are rebuilt with the new width on their next use)
+    gplan.L = 0;
+    rt::stream_sync(ctx->stream);
+  }
   uint32_t cur_table_group = TABLE_GROUP;
   uint32_t cur_norm_chunk = NORM_CHUNK;          // points per inversion in k_normalize: a property of the plan in use
   DevBuf<uint32_t> fbpts;    // (n+5) affine base points
@@ -339,8 +359,9 @@ struct Table : mp_table {
       const uint32_t bmin = (bucket_min && k == 3) ? std::min(bucket_min, BUCKET_MIN_SMALL_BATCH) : bucket_min;
       // Toom-Cook adds two dependent stages (operand evaluation, interpolation): a win when the batch fills the chip (throughput and
       // medium plans), a loss for a handful of proofs, where the small-batch plans keep Karatsuba (BLS12-377 (6,50), one proof: 78 vs 94 ms)
-      q.pplan = make_prove_plan(m, n, pp.fch, pp.vch, G_::PB, keyed, bmin, bk_windows(R::BITS), toom_cook && (k == 0 || k == 2 || k == 4), pp.vsp);
-      q.vplan = make_verify_plan(m, n, pp.fch, pp.vch, G_::PB, keyed, bmin, bk_windows(R::BITS), pp.vsp);
+      const uint32_t pbits = bucket_bits_of(4 * N + 11 * m + 9);      // (the merged equation: the largest MSM a proof brings)
+      q.pplan = make_prove_plan(m, n, pp.fch, pp.vch, G_::PB, keyed, bmin, bk_windows(R::BITS, pbits), toom_cook && (k == 0 || k == 2 || k == 4), pp.vsp, pbits);
+      q.vplan = make_verify_plan(m, n, pp.fch, pp.vch, G_::PB, keyed, bmin, bk_windows(R::BITS, pbits), pp.vsp, pbits);
       q.table_group = pp.grp;
       q.norm_chunk = pp.nch;       // fewer points per serial inversion chain when lanes are idle
       for (int i = 0; i < 6; ++i) q.pph[i].upload(q.pplan.ph[i], s);
@@ -610,6 +631,48 @@ struct Table : mp_table {
       MP_RUN(k_table, C, B, (ph.n_tables + cur_table_group - 1) / cur_table_group, a);
     }
   }
+
+  // the bucket method over a phase's large MSMs: digits, the persistent wave kernel (one wave per (equation, MSM, window) at a time),
+  // the fold of the window results.  `count` equations -- proofs, or chain / group equations -- whose scalars lie in S with lane stride
+  // sstride and whose digits go to D (dstride per equation)
+  void run_bucket(Workspace& w, PhaseDev& ph, const uint32_t* S, uint32_t sstride, int16_t* D, size_t dstride, uint32_t count,
+                  uint32_t link_stride, const char* too_large) {
+    rt::Stream s = ctx->stream;
+    const uint32_t c = ph.b_bits, bw = bk_windows(R::BITS, c);
+    if ((uint64_t)count * ph.n_bterms >= ((uint64_t)1 << 32) || (uint64_t)count * ph.n_b * bw >= ((uint64_t)1 << 32)) throw std::runtime_error(too_large);
+    BRecodeArgs ra{S, D, ph.bterms.p, ph.bpos.p, sstride, bw, ph.n_bterms, dstride, c};
+    MP_RUN(k_bucket_recode, C, count * ph.n_bterms, 1, ra);
+    const uint32_t nitems = count * ph.n_b * bw, nslots = std::min(nitems, ctx->bucket_slots());
+    w.ensure_bucket(ctx->bucket_slots(), ph.b_kpad_max, c, XyzzWords<C>::N, s);
+    rt::dzero(w.bk_counter.p, 4, s);
+    BucketArgs ba{D, w.P.p, w.J.p, ph.bjobs.p, ph.bterms.p, w.Bpad, bw, ph.n_b, dstride, link_stride, c, nitems, nslots, w.bk_counter.p,
+                  w.bk_sorted.p, w.bk_park.p, ph.b_kpad_max, nullptr};
+#ifdef MP_EXP_BK_TIMING
+    w.bk_timing.alloc((size_t)ctx->bucket_slots() * 8, s);
+    ba.timing = w.bk_timing.p;
+#endif
+    ctx->prof.begin("k_bucket_msm", s);
+    MP_WAVE_LAUNCH(k_bucket_msm, C, s, nslots, bk_lds_words(c, XyzzWords<C>::N), ba);
+    ctx->prof.end(s);
+#ifdef MP_EXP_BK_TIMING     // experiment (tools/ab_build.py --units=curve_stark_msm.hip,curve_stark.hip): mean cycles per phase and wave
+    {
+      std::vector<unsigned long long> tm((size_t)nslots * 4);
+      rt::d2h(tm.data(), w.bk_timing.p, tm.size() * 8, s);
+      rt::stream_sync(s);
+      double sum[4] = {0, 0, 0, 0};
+      for (size_t i = 0; i < tm.size(); ++i) sum[i & 3] += (double)tm[i];
+      fprintf(stderr, "k_bucket_msm items %u slots %u bits %u kpad %u: cycles/wave sort %.0f ranks %.0f additions %.0f reduction %.0f\n", nitems, nslots, c,
+              ph.b_kpad_max, sum[0] / nslots, sum[1] / nslots, sum[2] / nslots, sum[3] / nslots);
+    }
+#endif
+    BFoldArgs fa{w.J.p, ph.bjobs.p, w.Bpad, bw, 0u, c};
+    if (quad_ops(count, ph.n_b)) {          // few equations: the fold's ~256 dependent doublings on four lanes each
+      BFoldQuadArgs qa{fa, count, ph.n_b};
+      MP_WAVE_RUN(k_bucket_fold_q, C, quad_waves(count, ph.n_b), 0, qa);
+    } else {
+      MP_RUN(k_bucket_fold, C, count, ph.n_b, fa);
+    }
+  }
   void run_msms(PhaseDev& ph, Workspace& w, uint32_t B) {
     if (ph.n_f) {
       FixedArgs a{w.S.p, w.J.p, FB.p, ph.fjobs.p, ph.fterms.p, w.Bpad, fbg, w.Bpad};
@@ -640,7 +703,7 @@ struct Table : mp_table {
         run_combine(ca, B, ph.n_wc);
       }
       if (ph.n_w) {       // ... and the fold R = sum_r 2^(5 lo(r)) S_r, once per MSM
-        BFoldArgs fa{w.J.p, ph.wjobs.p, w.Bpad, 0u, nwin};
+        BFoldArgs fa{w.J.p, ph.wjobs.p, w.Bpad, 0u, nwin, 0u};
         if (quad_ops(B, ph.n_w)) {
           BFoldQuadArgs qa{fa, B, ph.n_w};
           ctx->prof.begin("k_wfold_q", ctx->stream);
@@ -653,23 +716,7 @@ struct Table : mp_table {
         }
       }
     }
-    if (ph.n_b) {   // large MSMs: bucket method, one wave per (proof, MSM, window)
-      const uint32_t bw = bk_windows(R::BITS);
-      if ((uint64_t)B * ph.n_bterms >= ((uint64_t)1 << 32)) throw std::runtime_error("bucket recode: batch too large for one launch");
-      BRecodeArgs ra{w.S.p, w.D8.p, ph.bterms.p, ph.bpos.p, w.Bpad, bw, ph.n_bterms, (size_t)w.d8_bytes};
-      MP_RUN(k_bucket_recode, C, B * ph.n_bterms, 1, ra);
-      BucketArgs ba{w.D8.p, w.P.p, w.J.p, ph.bjobs.p, ph.bterms.p, w.Bpad, bw, ph.n_b, (size_t)w.d8_bytes, 0u};
-      ctx->prof.begin("k_bucket_msm", ctx->stream);
-      MP_WAVE_LAUNCH(k_bucket_msm, C, ctx->stream, B * ph.n_b * bw, bk_lds_words(ph.b_kpad_max, XyzzWords<C>::N), ba);
-      ctx->prof.end(ctx->stream);
-      BFoldArgs fa{w.J.p, ph.bjobs.p, w.Bpad, bw};
-      if (quad_ops(B, ph.n_b)) {
-        BFoldQuadArgs qa{fa, B, ph.n_b};
-        MP_WAVE_RUN(k_bucket_fold_q, C, quad_waves(B, ph.n_b), 0, qa);
-      } else {
-        MP_RUN(k_bucket_fold, C, B, ph.n_b, fa);
-      }
-    }
+    if (ph.n_b) run_bucket(w, ph, w.S.p, w.Bpad, w.D16.p, (size_t)w.d8_bytes, B, 0u, "bucket recode: batch too large for one launch");
     if (ph.n_c0) {   // group sums of MSMs with many partials
       CombineArgs a{w.J.p, w.P.p, ph.cjobs0.p, ph.cterms0.p, w.Bpad};
       run_combine(a, B, ph.n_c0);
@@ -1191,7 +1238,7 @@ struct Table : mp_table {
   ChainPlan chain;
   Workspace cws;                      // lean workspace of chain verification: no window tables, no digit planes
   DevBuf<uint32_t> chain_cw, chain_cs;
-  DevBuf<int8_t> chain_d8;
+  DevBuf<int16_t> chain_d8;
   void build_chain_plan(uint32_t L, bool keyed) {
     if (chain.L == L && chain.keyed == keyed) return;
     if (keyed) ensure_keyed();
@@ -1202,7 +1249,8 @@ struct Table : mp_table {
     chain.L = L;
     chain.keyed = keyed;
     uint32_t next_partial = 1;                  // J slot 0 = the chain equation's value
-    PhaseBuilder pb(chain.ph, next_partial, FCHUNK, VCHUNK, 1u, bk_windows(R::BITS));
+    const uint32_t cbits = bucket_bits_of((L + 1) * 2 * N + L * (l.pk - l.cA) + (keyed ? 1u : 0u));
+    PhaseBuilder pb(chain.ph, next_partial, FCHUNK, VCHUNK, 1u, bk_windows(R::BITS, cbits), 1u, cbits);
     pb.begin(0);
     auto var = [&](ChainTerm ct, uint32_t pslot, uint32_t link) {
       pb.var((uint32_t)chain.cterms.size(), pslot | (link << 20));
@@ -1267,7 +1315,7 @@ struct Table : mp_table {
       MP_RUN(k_verify_merge, C, B, (uint32_t)q.vplan.mjobs.size(), ma);
     }
     // the chain equation: weights, one scalar per distinct point / fixed base, ONE bucket MSM + fixed-base part per table
-    const uint32_t nterms = chain.K + chain.nfix, bw = bk_windows(R::BITS);
+    const uint32_t nterms = chain.K + chain.nfix;
     chain_cw.alloc((size_t)L * Tpad * 8, s, false);
     chain_cs.alloc((size_t)nterms * Tpad * 8, s);
     chain_d8.alloc((size_t)chain.dev.b_dig_bytes * Tpad, s);
@@ -1276,15 +1324,7 @@ struct Table : mp_table {
     ChainScalArgs ca{w.S.p, chain_cw.p, chain_cs.p, chain.dterms.p, w.Bpad, Tpad, T};
     MP_RUN(k_chain_scalars, C, T, nterms, ca);
     PhaseDev& ph = chain.dev;
-    if ((uint64_t)T * ph.n_bterms >= ((uint64_t)1 << 32)) throw std::runtime_error("chain verification: too many tables for one launch");
-    BRecodeArgs ra{chain_cs.p, chain_d8.p, ph.bterms.p, ph.bpos.p, Tpad, bw, ph.n_bterms, (size_t)ph.b_dig_bytes};
-    MP_RUN(k_bucket_recode, C, T * ph.n_bterms, 1, ra);
-    BucketArgs ba{chain_d8.p, w.P.p, w.J.p, ph.bjobs.p, ph.bterms.p, w.Bpad, bw, ph.n_b, (size_t)ph.b_dig_bytes, T};
-    ctx->prof.begin("k_bucket_msm", s);
-    MP_WAVE_LAUNCH(k_bucket_msm, C, s, T * ph.n_b * bw, bk_lds_words(ph.b_kpad_max, XyzzWords<C>::N), ba);
-    ctx->prof.end(s);
-    BFoldArgs fa{w.J.p, ph.bjobs.p, w.Bpad, bw};
-    MP_RUN(k_bucket_fold, C, T, ph.n_b, fa);
+    run_bucket(w, ph, chain_cs.p, Tpad, chain_d8.p, (size_t)ph.b_dig_bytes, T, T, "chain verification: too many tables for one launch");
     FixedArgs fx{chain_cs.p, w.J.p, FB.p, ph.fjobs.p, ph.fterms.p, w.Bpad, fbg, Tpad};
     MP_RUN(k_fixed_msm, C, T, ph.n_f, fx);
     if (ph.n_c0) {
@@ -1324,11 +1364,14 @@ struct Table : mp_table {
   // = j T + t with T = B / L groups: the members of a group are T proofs apart.
   ChainPlan gplan;
   Workspace gws;                      // lean workspace of the group pass: no window tables, no digit planes (68 KB per proof)
-  // (measured on 52-card decks, proofs/s at 262 144 / 65 536 / 16 384 / 8 192 / 4 096 in flight: off 521 / 495 / 437 / 383 / 315 k; groups of
-  // 8: 538 / 517 / 443 / 389 / 305 k; of 16: 591 / 565 / 471 / 401 / 314 k; of 32: 574 / 545 / 455 / - / 287 k; of 64: 494 / 474 / 395 k -- a
-  // wave of the bucket kernel sorts the whole equation in LDS, 12.5 KB at 16 proofs, and larger equations cost occupancy)
-  uint32_t group_points = 3808;       // points per group equation aimed at (mp_set_group_verify; 0 = off): 16 proofs of a 52-card deck
-  uint32_t group_min_batch = 6144;    // smaller batches (in 52-card proofs: x 52 / N) keep the per-proof screen (the bucket kernel wants T x 33 waves)
+  // Group size: the wave-wide reduction of a window costs ~40 additions whatever the equation holds, and 10-bit windows (26 per scalar
+  // instead of 32) want ~60 terms per bucket -- as many proofs as fit the 32 767 points of one bucket job when the batch is large
+  // (128 proofs of a 52-card deck, 7 of a 1 024-card one); but the kernel's 2 048 persistent waves want a dozen (equation, window) items
+  // each, so a smaller batch takes smaller groups: no fewer than 2/13 of the minimum batch (945 at the default 6 144: 12 x 2 048 / 26).
+  // window width of the bucket method for an MSM of K terms (mp_set_bucket_bits; 0 = by size)
+  uint32_t bucket_bits_of(uint32_t K) const { return bucket_bits ? bucket_bits : bk_bits_for(K); }
+  uint32_t group_points = 30464;      // points per group equation aimed at (mp_set_group_verify; 0 = off): 128 proofs of a 52-card deck
+  uint32_t group_min_batch = 6144;    // smaller batches (in 52-card proofs: x 52 / N) keep the per-proof screen
   void set_group_verify(uint32_t points, size_t min_batch) override {
     group_points = points;
     group_min_batch = (uint32_t)std::min<size_t>(min_batch, 0x7FFFFFFFu);
@@ -1338,16 +1381,17 @@ struct Table : mp_table {
   uint32_t group_size_of(size_t B) const override { return B < 0x7FFFFFFFu ? group_size((uint32_t)B, false) : 0; }
   uint32_t group_size(uint32_t B, bool keyed) const {
     const uint32_t per = 4 * N + 11 * m + 8 + (keyed ? 1u : 0u);
-    // (a proof whose own equation already runs on the bucket kernel -- 1024-card decks -- gains nothing from a group)
     // (the minimum counts lanes like the work-split thresholds: a proof of N cards brings N / 52 times the points of a 52-card one)
-    if (!group_points || !merged_verify || (uint64_t)B * N < (uint64_t)group_min_batch * 52u || (bucket_min && per >= bucket_min)) return 0;
-    // as many proofs per group as bring its equation nearest to group_points points (3 808: what a wave of the bucket kernel sorts
-    // comfortably in LDS -- 16 proofs of a 52-card deck, 3 of a 300-card one)
-    const uint32_t want = std::max<uint32_t>(2u, (group_points + per / 2) / per);
+    if (!group_points || !merged_verify || (uint64_t)B * N < (uint64_t)group_min_batch * 52u) return 0;
+    // as many proofs per group as bring its equation nearest to group_points points, but no fewer groups than keep the persistent
+    // waves busy
+    const uint32_t groups_min = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)group_min_batch * 2u) / 13u));
+    const uint32_t want = std::min<uint32_t>((group_points + per / 2) / per, B / groups_min);
+    if (want < 2) return 0;
     for (uint32_t d = 0; d <= want; ++d)
       for (int sgn = 1; sgn >= -1; sgn -= 2) {
         const int64_t L = (int64_t)want + sgn * (int64_t)d;
-        if (L < 2 || 2 * L < (int64_t)want || L > 2 * (int64_t)want || (uint64_t)L * per > 32767u) continue;
+        if (L < 2 || 2 * L < (int64_t)want || L > 2 * (int64_t)want || (uint64_t)L * per > 32767u || L > 1023) continue;      // (10 bits of link in a sorted entry: kernels_bucket.hpp)
         if (B % (uint32_t)L == 0) return (uint32_t)L;
       }
     return 0;
@@ -1362,7 +1406,8 @@ struct Table : mp_table {
     gplan.L = L;
     gplan.keyed = keyed;
     uint32_t next_partial = 1;                  // J slot 0 = the group equation's value
-    PhaseBuilder pb(gplan.ph, next_partial, FCHUNK, VCHUNK, 1u, bk_windows(R::BITS));
+    const uint32_t gbits = bucket_bits_of(L * (l.pk + (keyed ? 1u : 0u)));
+    PhaseBuilder pb(gplan.ph, next_partial, FCHUNK, VCHUNK, 1u, bk_windows(R::BITS, gbits), 1u, gbits);
     pb.begin(0);
     for (uint32_t j = 0; j < L; ++j)
       for (uint32_t slot = 0; slot < l.pk + (keyed ? 1u : 0u); ++slot) {      // decks, proof points [, the proof's own key]
@@ -1420,7 +1465,7 @@ struct Table : mp_table {
       VerifyMergeArgs ma{w.S.p, q.mjobs.p, q.mpairs.p, w.Bpad};
       MP_RUN(k_verify_merge, C, B, (uint32_t)q.vplan.mjobs.size(), ma);
     }
-    const uint32_t nterms = gplan.K + gplan.nfix, bw = bk_windows(R::BITS);
+    const uint32_t nterms = gplan.K + gplan.nfix;
     chain_cw.alloc((size_t)L * Tpad * 8, s, false);
     chain_cs.alloc((size_t)nterms * Tpad * 8, s);
     chain_d8.alloc((size_t)gplan.dev.b_dig_bytes * Tpad, s);
@@ -1429,20 +1474,7 @@ struct Table : mp_table {
     ChainScalArgs ca{w.S.p, chain_cw.p, chain_cs.p, gplan.dterms.p, w.Bpad, Tpad, T};
     MP_RUN(k_chain_scalars, C, T, nterms, ca);
     PhaseDev& ph = gplan.dev;
-    if ((uint64_t)T * ph.n_bterms >= ((uint64_t)1 << 32)) throw std::runtime_error("group verification: too many groups for one launch");
-    BRecodeArgs ra{chain_cs.p, chain_d8.p, ph.bterms.p, ph.bpos.p, Tpad, bw, ph.n_bterms, (size_t)ph.b_dig_bytes};
-    MP_RUN(k_bucket_recode, C, T * ph.n_bterms, 1, ra);
-    BucketArgs ba{chain_d8.p, w.P.p, w.J.p, ph.bjobs.p, ph.bterms.p, w.Bpad, bw, ph.n_b, (size_t)ph.b_dig_bytes, T};
-    ctx->prof.begin("k_bucket_msm", s);
-    MP_WAVE_LAUNCH(k_bucket_msm, C, s, T * ph.n_b * bw, bk_lds_words(ph.b_kpad_max, XyzzWords<C>::N), ba);
-    ctx->prof.end(s);
-    BFoldArgs fa{w.J.p, ph.bjobs.p, w.Bpad, bw};
-    if (quad_ops(T, ph.n_b)) {              // few groups: the fold's 256 dependent doublings on four lanes each
-      BFoldQuadArgs qa{fa, T, ph.n_b};
-      MP_WAVE_RUN(k_bucket_fold_q, C, quad_waves(T, ph.n_b), 0, qa);
-    } else {
-      MP_RUN(k_bucket_fold, C, T, ph.n_b, fa);
-    }
+    run_bucket(w, ph, chain_cs.p, Tpad, chain_d8.p, (size_t)ph.b_dig_bytes, T, T, "group verification: too many groups for one launch");
     FixedArgs fx{chain_cs.p, w.J.p, FB.p, ph.fjobs.p, ph.fterms.p, w.Bpad, fbg, Tpad};
     MP_RUN(k_fixed_msm, C, T, ph.n_f, fx);
     if (ph.n_c0) {
@@ -1510,7 +1542,8 @@ struct Table : mp_table {
     Adhoc ad;
     uint32_t next_partial = K + 1;
     {
-      PhaseBuilder pb(ad.ph, next_partial, FCHUNK, VCHUNK, bucket_min, bk_windows(R::BITS));
+      const uint32_t abits = bucket_bits_of(K);
+      PhaseBuilder pb(ad.ph, next_partial, FCHUNK, VCHUNK, bucket_min, bk_windows(R::BITS, abits), 1u, abits);
       pb.begin(K);
       for (uint32_t t = 0; t < K; ++t) pb.var(t, t);
       pb.end();
@@ -1673,8 +1706,9 @@ struct Table : mp_table {
       ops += (uint64_t)ph.tables.size() * (VB_ENTRIES - 1);                 // table construction (affine additions)
       ops += ph.cterms.size() + ph.cterms2.size() + ph.cterms0.size();      // combines
       terms += ph.bterms.size();
-      ops += (uint64_t)ph.bterms.size() * bk_windows(R::BITS);              // bucket method: one mixed addition per term and window
-      ops += (uint64_t)ph.bjobs.size() * bk_windows(R::BITS) * (14 + BK_BITS + 1);   // wave-wide reduction + fold
+      const uint32_t bwin = bk_windows(R::BITS, ph.b_bits), bnb = bk_buckets(ph.b_bits) / 64;
+      ops += (uint64_t)ph.bterms.size() * bwin;                             // bucket method: one mixed addition per term and window
+      ops += (uint64_t)ph.bjobs.size() * bwin * (13 + 2 * bnb - 3 + ph.b_bits + 1);   // wave-wide reduction + fold
     };
     uint64_t t = 0, o = 0;
     for (int i = 0; i < 6; ++i) count(ps[0].pplan.ph[i], t, o);

@@ -1,26 +1,32 @@
-// Bucket-method (Pippenger) multi-scalar multiplication for the LARGE per-proof MSMs -- the verifier's products over a
-// 1024-card deck (4N + 11m + 9 = 4193 terms in one equation at m = 8, n = 128) -- as a WAVE-COOPERATIVE kernel: one 64-lane
-// wave owns one (proof, MSM, window) and computes sum_t d_t P_t for the window's signed 8-bit digits d_t:
+// Bucket-method (Pippenger) multi-scalar multiplication for the LARGE MSMs -- the verifier's products over a 1024-card deck
+// (4N + 11m + 9 = 4193 terms in one equation at m = 8, n = 128), a chain's equation, the ONE equation a group of up to 128 proofs is
+// screened by (30 464 terms at 52 cards) -- as a WAVE-COOPERATIVE kernel: one 64-lane wave owns one (proof, MSM, window) at a time and
+// computes sum_t d_t P_t for the window's signed c-bit digits d_t (c = 8, 9 or 10: 2^(c-1) buckets |d|, NB = 2^(c-1) / 64 per lane):
 //
-//   A  the window's K digits are read as words of four from the proof-major digit array (twice: B and D; 4 KB that stay in cache);
-//   B  histogram of |d| over the 128 buckets (LDS atomics);
-//   C  bucket offsets: an exclusive wavefront prefix sum over the pair counts {2l+1, 2l+2} gives the offsets of a counting sort;
-//   D  scatter: term indices (sign in bit 15) sorted by bucket into LDS;
-//   E  accumulation: every lane sums two buckets, run += +-P_t (XYZZ + affine, 8M+2S; the points come from the P arena, once
-//      per window and L2-resident across the windows of a proof).  WHICH two is a matter of balance -- the wave waits for its
-//      slowest lane: the r-th fullest odd bucket goes with the r-th emptiest even one (ranks by counting, round 4), so the lanes'
-//      shares differ by a term or two; a window whose digits crowd into a few buckets (the top window of a 252-bit scalar has 8)
-//      is cut into equal shares of the sorted list instead;
-//   F  bucket reduction across the wave: the sums travel through LDS to the lanes that own the pairs {2l+1, 2l+2}; there
-//      (2l+2) S_{2l+2} + (2l+1) S_{2l+1} = (2l+1) run_l + acc_l with run_l = S_{2l+2} + S_{2l+1}, acc_l = S_{2l+2} (one addition, NO
-//      multiplication by a bucket number, no bucket array in memory) and
-//      sum_l [(2l+1) run_l + acc_l] = sum_l acc_l + Suf_0 + 2 sum_{l>=1} Suf_l with the inclusive suffix sums
-//      Suf_l = sum_{l'>=l} run_l' -- a 6-step wavefront suffix scan and a 6-step tree reduction of XYZZ points exchanged through
-//      LDS (15 point additions per window instead of the 2 x 128 of the serial running sum).
+//   A  the window's K digits (int16) are read as words of two from the proof-major digit array (twice: B and D; they stay in cache);
+//   B  histogram of |d| over the buckets (LDS atomics);
+//   C  bucket offsets: an exclusive wavefront prefix sum over the lanes' NB-bucket totals gives the offsets of a counting sort;
+//   D  scatter: the terms' point references (sign in bit 31) sorted by bucket -- into a scratch row in GLOBAL memory that belongs to
+//      the wave (round 4: with the list in LDS a wave could sort ~7 600 terms before the CU ran out of LDS for two waves per SIMD;
+//      the equation of 128 proofs spreads the wave-wide reduction F over four times as many terms and affords 10-bit windows,
+//      26 instead of 32 per scalar).  The waves are persistent -- 8 per CU, each with one scratch row, drawing items from a counter --
+//      so the scratch is 2 048 rows whatever the batch, written and read back by the same CU;
+//   E  accumulation: every lane sums NB buckets one after the other, run += +-P_t (XYZZ + affine, 8M+2S), and parks every finished
+//      sum in the wave's second scratch row (2^(c-1) XYZZ slots, global).  WHICH buckets is a matter of balance -- the wave waits
+//      for its slowest lane: of the 64 buckets j mod NB the lane takes the r-th fullest for even j and the r-th emptiest for odd j
+//      (ranks by counting), so the lanes' shares differ by a term or two instead of by the +-2.4 sigma of a fixed assignment; a
+//      window whose digits crowd into a few buckets (the top window of a 252-bit scalar has 4 or 8) is cut into equal shares of
+//      the sorted list instead;
+//   F  bucket reduction across the wave: lane l reads the sums of ITS buckets NB l + 1 .. NB l + NB back, top first:
+//      sum_j (NB l + j) S_j = (NB l + 1) R_l + A_l with R_l the sum of all NB and A_l the sum of the first NB - 1 running sums
+//      (2 NB - 3 additions, NO multiplication by a bucket number), and
+//      sum_l [(NB l + 1) R_l + A_l] = sum_l A_l + Suf_0 + NB sum_{l>=1} Suf_l with the inclusive suffix sums Suf_l = sum_{l'>=l} R_l'
+//      -- a 6-step wavefront suffix scan, log2 NB doublings and a 6-step tree reduction of XYZZ points exchanged through LDS
+//      (13 + 2 NB - 3 point additions per window instead of the 2 x 2^(c-1) of the serial running sum).
 //
-// The W window results of an MSM are folded (8 doublings + 1 addition per window) by k_bucket_fold; its output slot joins
+// The W window results of an MSM are folded (c doublings + 1 addition per window) by k_bucket_fold; its output slot joins
 // the MSM's other partial sums in k_combine exactly like a Straus sub-job's.  Per term and window this is one mixed
-// addition plus (load imbalance + 15 wave-wide additions) / terms-per-lane -- 33 windows instead of Straus' 51 and no
+// addition plus (load imbalance + the wave-wide additions of F) / terms-per-lane -- 26 to 33 windows instead of Straus' 51 and no
 // per-base window tables at all (no k_table work, no 1 KB of table per base): it wins from ~2 000 terms per MSM on
 // (DESIGN.md "bucket MSM"); below that the Straus kernel (kernels_msm.hpp) stays.
 // Replaces ark-ec 0.3 `VariableBaseMSM::multi_scalar_mul` (the bucket method, sequential on the CPU) inside the
@@ -30,22 +36,25 @@
 
 namespace mp {
 
-static const int BK_BITS = 8;                    // signed windows: digits in [-128, 127]
-static const uint32_t BK_BUCKETS = 128;          // |d| = 1 .. 128: two buckets per lane
-static const uint32_t BK_HDR = 272;              // LDS words in front of the sort arrays: counts[132] + cursors[132] (+ pad)
-static inline uint32_t bk_windows(int scalar_bits) { return (uint32_t)(scalar_bits + BK_BITS) / BK_BITS; }
-// LDS words one wave needs for an MSM of kpad (multiple of 64) terms on a curve whose XYZZ point is xw words
-static inline uint32_t bk_lds_words(uint32_t kpad, uint32_t xw) { return BK_HDR + std::max(kpad / 2u, 64u * xw); }
+static const uint32_t BK_BITS_MIN = 8, BK_BITS_MAX = 10;     // signed windows: digits in [-2^(c-1), 2^(c-1) - 1]
+static const uint32_t BK_WAVES_PER_CU = 8;                   // persistent waves (MP_WAVE_KERNEL: 2 workgroups of 4 per CU)
+static inline uint32_t bk_windows(int scalar_bits, uint32_t c) { return ((uint32_t)scalar_bits + c) / c; }
+MP_HD uint32_t bk_buckets(uint32_t c) { return 1u << (c - 1); }
+// window width for an MSM of K terms: the reduction F costs ~(20 + 4 NB) additions per window, a narrower window K / (c (c + 1)) more
+static inline uint32_t bk_bits_for(uint32_t K) { return K >= 12000u ? 10u : (K >= 6000u ? 9u : 8u); }
+// LDS words one wave needs: counts + cursors of the buckets, 64 XYZZ exchange slots of xw words, the sink of the cache touches
+static inline uint32_t bk_lds_words(uint32_t c, uint32_t xw) { return 2u * (bk_buckets(c) + 4u) + 64u * xw + 64u; }
 
-// ---- digits: canonical scalar -> W signed bytes, d_w in [-128, 127] (top window non-negative), proof-major:
-// D8[b * dstride + pos + w * kpad]  (pos = digit offset of the term inside the proof's block, kpad = padded terms of its MSM)
+// ---- digits: canonical scalar -> W signed digits, d_w in [-2^(c-1), 2^(c-1) - 1] (top window non-negative), proof-major:
+// D16[b * dstride + pos + w * kpad]  (pos = digit offset of the term inside the proof's block, kpad = padded terms of its MSM)
 struct BRecodeArgs {
   const uint32_t* S;
-  int8_t* D8;
+  int16_t* D16;
   const Term* bterms;      // {S slot, P slot}
   const BTermPos* bpos;
   uint32_t Bpad, nwin, nterms;
   size_t dstride;
+  uint32_t bits;
 };
 template <class C>
 MP_HD void body_bucket_recode(const BRecodeArgs& a, uint32_t xx, uint32_t) {
@@ -53,19 +62,22 @@ MP_HD void body_bucket_recode(const BRecodeArgs& a, uint32_t xx, uint32_t) {
   const uint32_t x = xx % a.nterms, b = xx / a.nterms;
   const Term t = a.bterms[x];
   const BTermPos ps = a.bpos[x];
-  uint32_t k[9];
+  uint32_t k[10];
   fe_to_canonical<R>(ld_fe<R>(a.S + s_off(t.s, a.Bpad, b)), k);
-  k[8] = 0;
-  int8_t* out = a.D8 + (size_t)b * a.dstride + ps.pos;
+  k[8] = k[9] = 0;
+  int16_t* out = a.D16 + (size_t)b * a.dstride + ps.pos;
+  const uint32_t c = a.bits, half = 1u << (c - 1), mask = (1u << c) - 1u;
   uint32_t carry = 0;
   for (uint32_t w = 0; w < a.nwin; ++w) {
-    uint32_t raw = ((k[w >> 2] >> (8 * (w & 3))) & 0xFFu) + carry;
+    const uint32_t bit = c * w, wd = bit >> 5, sh = bit & 31u;
+    const uint64_t two = (uint64_t)k[wd] | ((uint64_t)k[wd + 1] << 32);
+    uint32_t raw = ((uint32_t)(two >> sh) & mask) + carry;
     carry = 0;
-    if (w + 1 < a.nwin && raw >= 128u) {
-      raw -= 256u;
+    if (w + 1 < a.nwin && raw >= half) {
+      raw -= 1u << c;
       carry = 1;
     }
-    out[(size_t)w * ps.kpad] = (int8_t)(int32_t)raw;
+    out[(size_t)w * ps.kpad] = (int16_t)(int32_t)raw;
   }
 }
 // thread = proof * nterms + bucket term of the phase (the term is the fast axis: the digit stores of a wave are contiguous)
@@ -73,7 +85,7 @@ MP_KERNEL(k_bucket_recode, BRecodeArgs, body_bucket_recode)
 
 // ---- the bucket kernel ----------------------------------------------------------------------------------------
 struct BucketArgs {
-  const int8_t* D8;
+  const int16_t* D16;
   const uint32_t* P;       // affine points, slot-major arena
   uint32_t* J;
   const BJob* jobs;
@@ -81,8 +93,19 @@ struct BucketArgs {
   uint32_t Bpad, nwin, njobs;
   size_t dstride;
   uint32_t link_stride;    // chain verification: term.b = P slot | link << 20, the point lives in lane b + link * link_stride
+  uint32_t bits;           // window width c
+  uint32_t nitems, nslots; // (proof, MSM, window) items for nslots persistent waves
+  uint32_t* counter;       // the next item to hand out (zero at launch)
+  uint32_t* sorted;        // scratch [nslots][kpad_max]: the window's point references (term.b | sign << 31) sorted by bucket
+  uint32_t* park;          // scratch [nslots][2^(c-1)][XYZZ words]: the bucket sums on their way to the lanes that reduce them
+  uint32_t kpad_max;
+  uint32_t* timing;        // MP_EXP_BK_TIMING builds: [nslots][4] cycle counts (64-bit)
+};
+struct alignas(16) Quad32 {
+  uint32_t v[4];
 };
 static const uint32_t BK_SLOT_MASK = 0xFFFFFu;
+static const uint32_t BK_LINK_MASK = 0x3FFu;     // (bit 31 of a sorted entry is the sign: 1 023 links)
 template <class C>
 MP_HD void xyzz_to_words(const Xyzz<C>& p, uint32_t* w) {
   constexpr int L = sizeof(p.X.v) / 4;
@@ -113,224 +136,327 @@ struct XyzzWords {
 };
 
 template <class C, class W>
-MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t wid, W& wv) {
+MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
   constexpr uint32_t XW = XyzzWords<C>::N;
-  const uint32_t w = wid % a.nwin, jb = (wid / a.nwin) % a.njobs, b = wid / (a.nwin * a.njobs);
-  const BJob job = a.jobs[jb];
-  const uint32_t K = job.count, kpad = job.kpad;
-  uint32_t* cnt = wv.lds;                         // [0 .. 128]: terms per |digit|
-  uint32_t* cur = wv.lds + 132;                   // scatter cursors; after the scatter: the lanes' bucket assignment
-  uint16_t* ix = reinterpret_cast<uint16_t*>(wv.lds + BK_HDR);              // sorted term indices | sign << 15
-  uint32_t* xch = wv.lds + BK_HDR;                                            // point exchange (after the sort arrays are dead)
-  // the window's digits: K bytes (kpad a multiple of 64), read twice as words of four -- 4 KB that stay in the L1/L2
-  const uint32_t* src = reinterpret_cast<const uint32_t*>(a.D8 + (size_t)b * a.dstride + job.dig_off + (size_t)w * kpad);
-
-  // A: clear the histogram
-  wv.lanes([&](uint32_t lane) {
-    for (uint32_t i = lane; i < 132; i += 64) cnt[i] = 0;
-  });
-  wv.sync();
-  // B: histogram of |d|
-  wv.lanes([&](uint32_t lane) {
-    for (uint32_t i = lane; i < kpad / 4; i += 64) {
-      const uint32_t four = src[i];
-#pragma unroll
-      for (uint32_t q = 0; q < 4; ++q) {
-        const int d = (int8_t)(four >> (8 * q));
-        if (4 * i + q < K) wv.atomic_add(&cnt[d < 0 ? -d : d], 1u);
-      }
-    }
-  });
-  wv.sync();
-  // C: offsets of the counting sort (wavefront prefix sum over the lanes' two-bucket counts)
-  PerLane<uint32_t> lo1, lo2, end, pair;
-  wv.lanes([&](uint32_t lane) { pair[lane] = cnt[2 * lane + 1] + cnt[2 * lane + 2]; });
-  wv.excl_scan(pair);
-  wv.lanes([&](uint32_t lane) {
-    const uint32_t c1 = cnt[2 * lane + 1], c2 = cnt[2 * lane + 2];
-    lo1[lane] = pair[lane];
-    lo2[lane] = pair[lane] + c1;
-    end[lane] = pair[lane] + c1 + c2;
-  });
-  wv.sync();
-  wv.lanes([&](uint32_t lane) {            // cnt[] becomes off[]: first sorted position of every bucket, off[129] = total
-    cnt[2 * lane + 1] = cur[2 * lane + 1] = lo1[lane];
-    cnt[2 * lane + 2] = cur[2 * lane + 2] = lo2[lane];
-    if (lane == 63) cnt[129] = end[lane];
-  });
-  wv.sync();
-  const uint32_t* off = cnt;
-  const uint32_t T = off[129];
-  // D: scatter (zero digits take no part)
-  wv.lanes([&](uint32_t lane) {
-    for (uint32_t i = lane; i < kpad / 4; i += 64) {
-      const uint32_t four = src[i];
-#pragma unroll
-      for (uint32_t q = 0; q < 4; ++q) {
-        const int d = (int8_t)(four >> (8 * q));
-        const uint32_t t = 4 * i + q;
-        if (t < K && d != 0) {
-          const uint32_t pos = wv.atomic_add(&cur[d < 0 ? -d : d], 1u);
-          ix[pos] = (uint16_t)(t | (d < 0 ? 0x8000u : 0u));
-        }
-      }
-    }
-  });
-  wv.sync();
-  // E: accumulation, one mixed addition per term: run += +-P_t.
-  //   pair mode     every lane takes one odd and one even bucket -- the r-th fullest odd one with the r-th emptiest even one, so
-  //                 that the lanes' shares differ by a term or two instead of by the +-2.4 sigma of the fullest pair {2l+1, 2l+2}
-  //                 (78 against 59.5 terms on average at 3 808 terms: the wave waits for its slowest lane) -- and sums them one
-  //                 after the other (acc = the odd bucket's sum, run = the even one's); the sums then change lanes through LDS
-  //                 (stage F) to where the reduction wants them;
-  //   balanced mode (a window whose digits crowd into few buckets -- the top window of a 252-bit scalar has 8): equal shares of
-  //                 the sorted list, walked from the top; whenever a lane crosses into the next lower bucket it adds the running
-  //                 sum to acc, so that at the end  sum_t d_t P_t over the share = lo * run + acc  with lo the lowest bucket reached
-  //                 (the buckets are long there, so a share crosses at most one boundary or so).
-  PerLane<uint32_t> n, nA, oA, oB, s1, cb;
-  wv.lanes([&](uint32_t lane) {              // ranks by counting: 2 x 64 broadcast reads per lane
-    const uint32_t co = lo2[lane] - lo1[lane], ce = end[lane] - lo2[lane];
-    uint32_t ro = 0, re = 0;
-    for (uint32_t l = 0; l < 64; ++l) {
-      const uint32_t o = off[2 * l + 2] - off[2 * l + 1], e = off[2 * l + 3] - off[2 * l + 2];
-      ro += (o > co || (o == co && l < lane)) ? 1u : 0u;
-      re += (e > ce || (e == ce && l < lane)) ? 1u : 0u;
-    }
-    cur[ro] = lane;                          // cur[r] = the lane whose odd bucket is the r-th fullest,
-    cur[64 + 63 - re] = lane;                // cur[64 + r] = the lane whose even bucket is the r-th emptiest
-  });
-  wv.sync();
-  wv.lanes([&](uint32_t lane) {
-    const uint32_t A = 2 * cur[lane] + 1, B2 = 2 * cur[64 + lane] + 2;
-    oA[lane] = off[A];
-    nA[lane] = off[A + 1] - off[A];
-    oB[lane] = off[B2];
-    n[lane] = nA[lane] + off[B2 + 1] - off[B2];
-  });
-#ifdef MP_EXP_BK_BALANCED  // experiment hook (tools/ab_build.py): every window in balanced mode
-  const bool balanced = true;
-#else
-  const bool balanced = wv.max(n) > T / 64 + T / 128 + 32;
+  const uint32_t NBK = bk_buckets(a.bits), NB = NBK >> 6, LOGNB = a.bits - 7u, HW = NBK + 4u;
+  uint32_t* cnt = wv.lds;                         // [0 .. NBK]: terms per |digit|; then off[]: first sorted position per bucket
+  uint32_t* cur = wv.lds + HW;                    // scatter cursors; after the scatter: the lanes' bucket assignment [class][lane]
+  uint32_t* xch = wv.lds + 2 * HW;                // point exchange of the reduction
+  uint32_t* sink = xch + 64 * XW;                 // 64 words nobody reads (WaveCtx::touch)
+  uint32_t* ix = a.sorted + (size_t)slot * a.kpad_max;
+  uint32_t* park = a.park + (size_t)slot * NBK * XW;
+#ifdef MP_EXP_BK_STAGGER
+  wv.stagger(MP_EXP_BK_STAGGER);
 #endif
-  PerLane<Xyzz<C>> run, acc;
-  wv.lanes([&](uint32_t lane) {
-    run[lane] = xyzz_inf<C>();
-    acc[lane] = xyzz_inf<C>();
-    if (balanced) {
-      const uint32_t s0 = (uint32_t)(((uint64_t)T * lane) >> 6);
-      s1[lane] = (uint32_t)(((uint64_t)T * (lane + 1)) >> 6);
-      uint32_t lo_b = 1, hi_b = 128;                    // largest bucket whose first position is <= s1 - 1
-      const uint32_t last = s1[lane] ? s1[lane] - 1 : 0;
-      while (lo_b < hi_b) {
-        const uint32_t mid = (lo_b + hi_b + 1) >> 1;
-        if (off[mid] <= last) lo_b = mid; else hi_b = mid - 1;
-      }
-      n[lane] = s1[lane] - s0;
-      cb[lane] = lo_b;
-    }
-  });
-  const uint32_t iters = wv.max(n);
-  for (uint32_t i = 0; i < iters; ++i) {
+#ifdef MP_EXP_BK_TIMING     // experiment: cycles per phase (sort, ranks, additions, reduction), summed per wave into the tail of its park row
+  unsigned long long tm_[5] = {0, 0, 0, 0, 0}, t0_ = 0;
+#define MP_BK_T0() t0_ = __builtin_readcyclecounter()
+#define MP_BK_T(i) do { const unsigned long long t1_ = __builtin_readcyclecounter(); tm_[i] += t1_ - t0_; t0_ = t1_; } while (0)
+#else
+#define MP_BK_T0() do {} while (0)
+#define MP_BK_T(i) do {} while (0)
+#endif
+  // (items are handed out by a counter, not dealt in advance: the windows of an MSM do not take the same time -- the top one is short --
+  // and neither do the XCDs; with 2 048 x 256 items dealt in advance the last wave finished 15 % behind the average)
+#pragma unroll 1
+  for (uint32_t item = wv.next_item(a.counter); item < a.nitems; item = wv.next_item(a.counter)) {
+    MP_BK_T0();
+    const uint32_t w = item % a.nwin, jb = (item / a.nwin) % a.njobs, b = item / (a.nwin * a.njobs);
+    const BJob job = a.jobs[jb];
+    const uint32_t K = job.count, kpad = job.kpad;
+    // (kpad and every offset in front of a window's digits are multiples of 64 digits: 16-byte loads of eight digits)
+    const Quad32* src = reinterpret_cast<const Quad32*>(a.D16 + (size_t)b * a.dstride + job.dig_off + (size_t)w * kpad);
+
+    const uint32_t* off = cnt;
+    uint32_t T = 0;
+#ifdef MP_EXP_BK_SORT2     // experiment: the sort phases twice (their share of the kernel)
+    for (int rep_ = 0; rep_ < 2; ++rep_) {
+#endif
+    // A: clear the histogram
     wv.lanes([&](uint32_t lane) {
-      if (i < n[lane]) {
-        uint32_t p;
-        if (balanced) {
-          p = s1[lane] - 1 - i;
-          while (p < off[cb[lane]]) {                   // into the next lower bucket
-            xyzz_add_ip<C>(acc[lane], run[lane]);
-            cb[lane] -= 1;
-          }
-        } else {
-          if (i == nA[lane]) {                          // the odd bucket is done
-            acc[lane] = run[lane];
-            run[lane] = xyzz_inf<C>();
-          }
-          p = i < nA[lane] ? oA[lane] + i : oB[lane] + (i - nA[lane]);
+      for (uint32_t i = lane; i < HW; i += 64) cnt[i] = 0;
+    });
+    wv.sync();
+    // B: histogram of |d|.  B and D are latency, not work: their loops are branch-free (the padding of the row counts as zero digits,
+    // sorted behind every bucket; the last iteration loads its own words once more) with the next iteration's loads in flight over the atomics
+    const uint32_t nq = kpad / 8;
+    wv.lanes([&](uint32_t lane) {
+      Quad32 next = src[lane < nq ? lane : nq - 1];
+      for (uint32_t i = lane; i < nq; i += 64) {
+        const Quad32 eight = next;
+        next = src[i + 64 < nq ? i + 64 : nq - 1];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q) {
+          const int d = 8 * i + q < K ? (int16_t)(eight.v[q >> 1] >> (16 * (q & 1))) : 0;
+          wv.atomic_add(&cnt[d < 0 ? -d : d], 1u);
         }
-        const uint32_t e = ix[p];
-        const uint32_t tb = a.bterms[job.begin + (e & 0x7FFFu)].b;
-        const Aff<C> q = ld_aff<C>(a.P + p_off<C>(tb & BK_SLOT_MASK, a.Bpad, b + (tb >> 20) * a.link_stride));
-        xyzz_madd_signed_ip<C>(run[lane], q, (e & 0x8000u) != 0);
       }
     });
-  }
-  wv.sync();                                                          // the sort arrays are dead from here on
-  // F: sum over the buckets of k S_k
-  if (!balanced) {
-    // the sums go home: lane l wants S_{2l+2} and S_{2l+1} (two rounds through the 64 exchange slots, even buckets first)
+    wv.sync();
+    // C: offsets of the counting sort (wavefront prefix sum over the lanes' NB-bucket totals)
+    PerLane<uint32_t> tot;
     wv.lanes([&](uint32_t lane) {
-      if (n[lane] <= nA[lane]) {                                      // (an empty even bucket: the loop never switched)
-        acc[lane] = run[lane];
-        run[lane] = xyzz_inf<C>();
+      uint32_t t = 0;
+      for (uint32_t j = 0; j < NB; ++j) t += cnt[NB * lane + 1 + j];
+      tot[lane] = t;
+    });
+    wv.excl_scan(tot);
+    wv.sync();
+    wv.lanes([&](uint32_t lane) {            // cnt[] becomes off[]: first sorted position of every bucket, off[NBK + 1] = total
+      uint32_t o = tot[lane];
+      for (uint32_t j = 0; j < NB; ++j) {
+        const uint32_t k = NB * lane + 1 + j, c = cnt[k];
+        cnt[k] = cur[k] = o;
+        o += c;
       }
-      xyzz_to_words<C>(run[lane], xch + cur[64 + lane] * XW);
+      if (lane == 63) cnt[NBK + 1] = cur[0] = o;      // (the zero digits: sorted behind every bucket, never visited)
     });
     wv.sync();
-    wv.lanes([&](uint32_t lane) { run[lane] = xyzz_from_words<C>(xch + lane * XW); });
-    wv.sync();
-    wv.lanes([&](uint32_t lane) { xyzz_to_words<C>(acc[lane], xch + cur[lane] * XW); });
-    wv.sync();
-    wv.lanes([&](uint32_t lane) {                                     // acc = S_{2l+2}, run = S_{2l+2} + S_{2l+1}:
-      acc[lane] = run[lane];                                          // (2l+2) S_{2l+2} + (2l+1) S_{2l+1} = (2l+1) run + acc
-      xyzz_add_ip<C>(run[lane], xyzz_from_words<C>(xch + lane * XW));
+    T = off[NBK + 1];
+    // D: scatter: every term of the padded row goes to its place (one store each: the waits can count them)
+    wv.lanes([&](uint32_t lane) {
+      const Term* terms = a.bterms + job.begin;
+      Quad32 next = src[lane < nq ? lane : nq - 1];
+      uint32_t nref[8];
+#pragma unroll
+      for (uint32_t q = 0; q < 8; ++q) nref[q] = terms[8 * lane + q < K ? 8 * lane + q : K - 1].b;
+      for (uint32_t i = lane; i < nq; i += 64) {
+        const Quad32 eight = next;
+        uint32_t ref[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q) ref[q] = nref[q];
+        const uint32_t j = i + 64 < nq ? i + 64 : nq - 1;
+        next = src[j];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q) nref[q] = terms[8 * j + q < K ? 8 * j + q : K - 1].b;
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q) {
+          const int d = 8 * i + q < K ? (int16_t)(eight.v[q >> 1] >> (16 * (q & 1))) : 0;
+          const uint32_t at = wv.atomic_add(&cur[d < 0 ? -d : d], 1u);
+          ix[at] = ref[q] | (d < 0 ? 0x80000000u : 0u);
+        }
+      }
     });
     wv.sync();
-    // sum_l (2l+1) run_l = Suf_0 + 2 sum_{l>=1} Suf_l with the inclusive suffix sums Suf_l = sum_{l'>=l} run_l'
-    for (uint32_t s = 1; s < 64; s <<= 1) {
-      wv.lanes([&](uint32_t lane) { xyzz_to_words<C>(run[lane], xch + lane * XW); });
+#ifdef MP_EXP_BK_SORT2
+    }
+#endif
+    MP_BK_T(0);
+    // E: accumulation, one mixed addition per term: run += +-P_t.  The lane's walk through the sorted list runs two terms ahead of
+    // the additions: the entry of term i + 2 is requested while term i is added, so that only the point itself is waited for.
+    PerLane<uint32_t> n, seg, pos, rem;        // the fetch side (balanced mode: pos = one past the share's top position, rem = the bucket the additions are in)
+    PerLane<uint32_t> mseg, e0, e1, nb0, nb1;  // the additions' side: class of the bucket being summed; entries of terms i and i + 1, and whether
+                                               // they open a new bucket (kept apart from the entry: nothing may wait for the load before its turn)
+    wv.lanes([&](uint32_t lane) {              // ranks by counting: NB x 64 broadcast reads per lane
+      for (uint32_t j = 0; j < NB; ++j) {
+        const uint32_t mine = off[NB * lane + 2 + j] - off[NB * lane + 1 + j];
+        uint32_t r = 0;
+        for (uint32_t l = 0; l < 64; ++l) {
+          const uint32_t o = off[NB * l + 2 + j] - off[NB * l + 1 + j];
+          r += (o > mine || (o == mine && l < lane)) ? 1u : 0u;
+        }
+        cur[j * 64 + ((j & 1u) ? 63u - r : r)] = lane;      // worker lane -> the home lane of its bucket of class j
+      }
+    });
+    wv.sync();
+    wv.sync_global();                          // (the sorted list is read by other lanes than wrote it)
+    wv.lanes([&](uint32_t lane) {
+      uint32_t t = 0;
+      for (uint32_t j = 0; j < NB; ++j) {
+        const uint32_t k = NB * cur[j * 64 + lane] + 1 + j;
+        t += off[k + 1] - off[k];
+      }
+      n[lane] = t;
+    });
+#ifdef MP_EXP_BK_BALANCED  // experiment hook (tools/ab_build.py): every window in balanced mode
+    const bool balanced = true;
+#else
+    const bool balanced = wv.max(n) > T / 64 + T / 128 + 32;
+#endif
+    // the position of the next entry of the lane's walk (only called while terms remain); fresh: it is the first term of a new bucket
+    auto advance = [&](uint32_t lane, uint32_t j, uint32_t& fresh) -> uint32_t {
+      fresh = 0;
+      if (balanced) return pos[lane] - 1 - j;
+      while (rem[lane] == 0) {                 // on to the lane's bucket of the next class (empty ones are passed over)
+        seg[lane] += 1;
+        const uint32_t k = NB * cur[seg[lane] * 64 + lane] + 1 + seg[lane];
+        pos[lane] = off[k];
+        rem[lane] = off[k + 1] - off[k];
+        fresh = 1;
+      }
+      pos[lane] += 1;
+      rem[lane] -= 1;
+      return pos[lane] - 1;
+    };
+    auto point_of = [&](uint32_t e) -> const uint32_t* {
+      return a.P + p_off<C>(e & BK_SLOT_MASK, a.Bpad, b + ((e >> 20) & BK_LINK_MASK) * a.link_stride);
+    };
+    // (acc is not needed while the pair-mode loop runs; the balanced walk keeps it in the lane's exchange slot in LDS -- 32 registers less
+    // across the mixed addition)
+    PerLane<Xyzz<C>> run;
+    wv.lanes([&](uint32_t lane) {
+      run[lane] = xyzz_inf<C>();
+      seg[lane] = 0;
+      mseg[lane] = 0;
+      if (balanced) {
+        xyzz_to_words<C>(run[lane], xch + lane * XW);
+        // equal shares of the sorted list, walked from the top; whenever a lane crosses into the next lower bucket it adds the running
+        // sum to acc, so that at the end  sum_t d_t P_t over the share = lo * run + acc  with lo the lowest bucket reached
+        const uint32_t s0 = (uint32_t)(((uint64_t)T * lane) >> 6), s1 = (uint32_t)(((uint64_t)T * (lane + 1)) >> 6);
+        uint32_t lo_b = 1, hi_b = NBK;                    // largest bucket whose first position is <= s1 - 1
+        const uint32_t last = s1 ? s1 - 1 : 0;
+        while (lo_b < hi_b) {
+          const uint32_t mid = (lo_b + hi_b + 1) >> 1;
+          if (off[mid] <= last) lo_b = mid; else hi_b = mid - 1;
+        }
+        n[lane] = s1 - s0;
+        pos[lane] = s1;
+        rem[lane] = lo_b;
+      } else {
+        const uint32_t k = NB * cur[lane] + 1;
+        pos[lane] = off[k];
+        rem[lane] = off[k + 1] - off[k];
+      }
+      e0[lane] = e1[lane] = nb1[lane] = 0;
+      uint32_t first = 0;
+      if (n[lane] > 0) e0[lane] = ix[advance(lane, 0, first)];            // (empty classes in front of the first term: mseg below)
+      if (n[lane] > 1) e1[lane] = ix[advance(lane, 1, nb1[lane])];
+      nb0[lane] = 0;
+#ifdef MP_EXP_BK_TOUCH
+      if (n[lane] > 0) wv.touch(point_of(e0[lane]), sink);
+#endif
+      if (!balanced && n[lane] > 0)
+        while (off[NB * cur[mseg[lane] * 64 + lane] + 2 + mseg[lane]] == off[NB * cur[mseg[lane] * 64 + lane] + 1 + mseg[lane]]) mseg[lane] += 1;
+    });
+    const uint32_t iters = wv.max(n);
+    MP_BK_T(1);
+#pragma unroll 1
+    for (uint32_t i = 0; i < iters; ++i) {
+      wv.lanes([&](uint32_t lane) {
+        if (i < n[lane]) {
+          const uint32_t e = e0[lane];
+#ifdef MP_EXP_BK_TOUCH   // experiment (tools/ab_build.py): pull the next point's cache line towards the CU through an LDS sink -- slower: the LDS reads behind it wait for it
+          if (i + 1 < n[lane]) wv.touch(point_of(e1[lane]), sink);
+#endif
+          const uint32_t fresh = nb0[lane];
+          if (balanced) {
+            const uint32_t p = pos[lane] - 1 - i;
+            while (p < off[rem[lane]]) {                  // into the next lower bucket
+              Xyzz<C> t = xyzz_from_words<C>(xch + lane * XW);
+              xyzz_add_ip<C>(t, run[lane]);
+              xyzz_to_words<C>(t, xch + lane * XW);
+              rem[lane] -= 1;
+            }
+          } else if (fresh) {                             // the bucket before this term is done: park its sum
+            xyzz_to_words<C>(run[lane], park + (size_t)(NB * cur[mseg[lane] * 64 + lane] + mseg[lane]) * XW);
+            run[lane] = xyzz_inf<C>();
+            do mseg[lane] += 1;
+            while (off[NB * cur[mseg[lane] * 64 + lane] + 2 + mseg[lane]] == off[NB * cur[mseg[lane] * 64 + lane] + 1 + mseg[lane]]);
+          }
+#ifdef MP_EXP_BK_NOPOINT   // experiment: every point out of 256 cache-resident ones (wrong sums; how much of the kernel is memory latency)
+          const Aff<C> q = ld_aff<C>(a.P + p_off<C>(e & 0xFFu, a.Bpad, b));
+#else
+          const Aff<C> q = ld_aff<C>(point_of(e));
+#endif
+          // (the entry of term i + 2 is requested BEHIND the point of term i: loads come back in order, and the addition waits for its
+          // point with this one still in flight)
+          // (... and by ONE load instruction on every path: the wait for the point counts the loads behind it)
+          e0[lane] = e1[lane];
+          nb0[lane] = nb1[lane];
+          uint32_t at = 0;
+          if (i + 2 < n[lane]) at = advance(lane, i + 2, nb1[lane]);
+          e1[lane] = ix[at];
+          xyzz_madd_signed_ip<C>(run[lane], q, (e >> 31) != 0);
+        }
+      });
+    }
+    wv.sync();
+    MP_BK_T(2);
+    // F: sum over the buckets of k S_k
+    PerLane<Xyzz<C>> acc;
+    if (!balanced) {
+      wv.lanes([&](uint32_t lane) {                                     // the last sum (empty buckets have no parked sum: the reader knows)
+        if (n[lane] > 0) xyzz_to_words<C>(run[lane], park + (size_t)(NB * cur[mseg[lane] * 64 + lane] + mseg[lane]) * XW);
+      });
+      wv.sync_global();
+      wv.lanes([&](uint32_t lane) {                                     // the sums come home: R = sum of the lane's NB buckets,
+        const uint32_t* mine = park + (size_t)NB * lane * XW;           // A = sum of the first NB - 1 running sums from the top
+        const uint32_t* o = off + NB * lane + 1;
+        run[lane] = o[NB] != o[NB - 1] ? xyzz_from_words<C>(mine + (size_t)(NB - 1) * XW) : xyzz_inf<C>();
+        for (int j = (int)NB - 2; j >= 0; --j) {
+          if (j == (int)NB - 2) acc[lane] = run[lane]; else xyzz_add_ip<C>(acc[lane], run[lane]);
+          if (o[j + 1] != o[j]) xyzz_add_ip<C>(run[lane], xyzz_from_words<C>(mine + (size_t)j * XW));
+        }
+      });
+      // sum_l (NB l + 1) R_l = Suf_0 + NB sum_{l>=1} Suf_l with the inclusive suffix sums Suf_l = sum_{l'>=l} R_l'
+      for (uint32_t s = 1; s < 64; s <<= 1) {
+        wv.lanes([&](uint32_t lane) { xyzz_to_words<C>(run[lane], xch + lane * XW); });
+        wv.sync();
+        wv.lanes([&](uint32_t lane) {
+          if (lane + s < 64) xyzz_add_ip<C>(run[lane], xyzz_from_words<C>(xch + (lane + s) * XW));
+        });
+        wv.sync();
+      }
+      wv.lanes([&](uint32_t lane) {
+        Xyzz<C> t = run[lane];
+        if (lane >= 1)
+          for (uint32_t q = 0; q < LOGNB; ++q) xyzz_dbl_ip<C>(t);
+        xyzz_add_ip<C>(acc[lane], t);
+      });
+    } else {
+      // arbitrary small lo_l: lo_l * run_l by double-and-add over the bits of the largest lo (wave-uniform trip count)
+      wv.lanes([&](uint32_t lane) { acc[lane] = xyzz_from_words<C>(xch + lane * XW); });
+      wv.sync();
+      const uint32_t lomax = wv.max(rem);
+      int nb = 0;
+      while ((lomax >> nb) != 0) ++nb;
+      PerLane<Xyzz<C>> prod;
+      wv.lanes([&](uint32_t lane) { prod[lane] = xyzz_inf<C>(); });
+      for (int bit = nb - 1; bit >= 0; --bit) {
+        wv.lanes([&](uint32_t lane) {
+          xyzz_dbl_ip<C>(prod[lane]);
+          if ((rem[lane] >> bit) & 1u) xyzz_add_ip<C>(prod[lane], run[lane]);
+        });
+      }
+      wv.lanes([&](uint32_t lane) { xyzz_add_ip<C>(acc[lane], prod[lane]); });
+    }
+    for (uint32_t s = 32; s >= 1; s >>= 1) {                            // tree reduction
+      wv.lanes([&](uint32_t lane) { xyzz_to_words<C>(acc[lane], xch + lane * XW); });
       wv.sync();
       wv.lanes([&](uint32_t lane) {
-        if (lane + s < 64) xyzz_add_ip<C>(run[lane], xyzz_from_words<C>(xch + (lane + s) * XW));
+        if (lane < s) xyzz_add_ip<C>(acc[lane], xyzz_from_words<C>(xch + (lane + s) * XW));
       });
       wv.sync();
     }
     wv.lanes([&](uint32_t lane) {
-      Xyzz<C> t = run[lane];
-      if (lane >= 1) xyzz_dbl_ip<C>(t);
-      xyzz_add_ip<C>(acc[lane], t);
+      if (lane == 0) st_jac<C>(a.J + j_off<C>(job.win_first + w, a.Bpad, b), xyzz_to_jac<C>(acc[lane]));
     });
-  } else {
-    // arbitrary small lo_l: lo_l * run_l by double-and-add over the bits of the largest lo (wave-uniform trip count)
-    const uint32_t lomax = wv.max(cb);
-    int nb = 0;
-    while ((lomax >> nb) != 0) ++nb;
-    PerLane<Xyzz<C>> prod;
-    wv.lanes([&](uint32_t lane) { prod[lane] = xyzz_inf<C>(); });
-    for (int bit = nb - 1; bit >= 0; --bit) {
-      wv.lanes([&](uint32_t lane) {
-        xyzz_dbl_ip<C>(prod[lane]);
-        if ((cb[lane] >> bit) & 1u) xyzz_add_ip<C>(prod[lane], run[lane]);
-      });
-    }
-    wv.lanes([&](uint32_t lane) { xyzz_add_ip<C>(acc[lane], prod[lane]); });
+    wv.sync_global();                          // (the next item's scatter and parking overwrite what other lanes have just read)
+    MP_BK_T(3);
   }
-  for (uint32_t s = 32; s >= 1; s >>= 1) {                            // tree reduction
-    wv.lanes([&](uint32_t lane) { xyzz_to_words<C>(acc[lane], xch + lane * XW); });
-    wv.sync();
-    wv.lanes([&](uint32_t lane) {
-      if (lane < s) xyzz_add_ip<C>(acc[lane], xyzz_from_words<C>(xch + (lane + s) * XW));
-    });
-    wv.sync();
-  }
+#ifdef MP_EXP_BK_TIMING
   wv.lanes([&](uint32_t lane) {
-    if (lane == 0) st_jac<C>(a.J + j_off<C>(job.win_first + w, a.Bpad, b), xyzz_to_jac<C>(acc[lane]));
+    if (lane == 0)
+      for (int i = 0; i < 4; ++i) reinterpret_cast<unsigned long long*>(a.timing)[(size_t)slot * 4 + i] = tm_[i];
   });
+#endif
 }
 MP_WAVE_KERNEL(k_bucket_msm, BucketArgs, body_bucket_msm)
 
-// ---- fold the window results: R = sum_w 2^(8w) R_w (x = proof, y = bucket job)
+// ---- fold the window results: R = sum_w 2^(c w) R_w (x = proof, y = bucket job)
 // The same kernel folds the range sums of window-split Straus jobs (layout.hpp vsplit_lo; vb_nwin != 0): job.count parts, part w
 // starts at the 5-bit window vsplit_lo(w, job.count, vb_nwin), R = sum_w 2^(5 vsplit_lo(w)) R_w.
 struct BFoldArgs {
   uint32_t* J;
   const BJob* jobs;
   uint32_t Bpad, nwin;
-  uint32_t vb_nwin;      // 0: bucket windows (nwin parts, BK_BITS apart); else the Straus windows a split job's parts share
+  uint32_t vb_nwin;      // 0: bucket windows (nwin parts, `bits` apart); else the Straus windows a split job's parts share
+  uint32_t bits;         // the bucket method's window width
 };
 MP_HD uint32_t fold_parts(const BFoldArgs& a, const BJob& job) { return a.vb_nwin ? job.count : a.nwin; }
 // doublings between part w + 1 and part w
 MP_HD uint32_t fold_bits(const BFoldArgs& a, const BJob& job, uint32_t w) {
-  return a.vb_nwin ? (uint32_t)VB_WINDOW_BITS * (vsplit_lo(w + 1, job.count, a.vb_nwin) - vsplit_lo(w, job.count, a.vb_nwin)) : (uint32_t)BK_BITS;
+  return a.vb_nwin ? (uint32_t)VB_WINDOW_BITS * (vsplit_lo(w + 1, job.count, a.vb_nwin) - vsplit_lo(w, job.count, a.vb_nwin)) : a.bits;
 }
 template <class C>
 MP_HD void body_bucket_fold(const BFoldArgs& a, uint32_t b, uint32_t y) {

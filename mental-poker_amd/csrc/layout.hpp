@@ -37,7 +37,7 @@ struct BJob {
   uint32_t begin;      // first term
   uint32_t count;      // number of terms K
   uint32_t kpad;       // K rounded up to a multiple of 64
-  uint32_t dig_off;    // byte offset of the job's digits inside a proof's digit block (window w at + w * kpad)
+  uint32_t dig_off;    // offset (in digits) of the job's digits inside a proof's digit block (window w at + w * kpad)
 };
 struct BTermPos {
   uint32_t pos;        // dig_off of the job + index of the term in the job
@@ -92,21 +92,24 @@ struct Phase {
   std::vector<BJob> bjobs;    // MSMs large enough for the bucket method
   std::vector<Term> bterms;   // {S slot, P slot}
   std::vector<BTermPos> bpos;
-  uint32_t b_dig_bytes = 0;   // bytes of bucket digits per proof
+  uint32_t b_dig_bytes = 0;   // bucket digits (int16 each) per proof
   uint32_t b_kpad_max = 0;
+  uint32_t b_bits = 8;        // window width of the phase's bucket jobs (kernels_bucket.hpp: 8 .. 10)
 };
 
 static const size_t COMBINE_TREE_MIN = 12;
+static const size_t BUCKET_TERMS_MAX = 32767;      // terms of one bucket job (one wave sorts a window's digits; uint16 counters nowhere, but the scratch row is sized by it)
 // Host-side builder: msm(out) { fixed(..) var(..) addend(..) } -> chunked sub-jobs + one combine job.
 class PhaseBuilder {
  public:
-  // bucket_min: MSMs with at least this many variable-base terms go to the bucket kernel (0 = never); bwin = its windows
+  // bucket_min: MSMs with at least this many variable-base terms go to the bucket kernel (0 = never); bwin = its windows of bbits bits
   // vsplit: lanes per variable-base (Straus) sub-job, each with a share of the windows (1 = one lane runs all of them)
   PhaseBuilder(Phase& ph, uint32_t& next_partial, uint32_t fchunk, uint32_t vchunk, uint32_t bucket_min = 0, uint32_t bwin = 0,
-               uint32_t vsplit = 1)
+               uint32_t vsplit = 1, uint32_t bbits = 8)
       : ph_(ph), next_partial_(next_partial), fchunk_(fchunk), vchunk_(vchunk), bucket_min_(bucket_min), bwin_(bwin),
         vsplit_(vsplit < 1 ? 1 : (vsplit > VSPLIT_MAX ? VSPLIT_MAX : vsplit)) {
     ph_.vsplit = vsplit_;
+    ph_.b_bits = bbits;
   }
   void begin(uint32_t out_slot) {
     out_ = out_slot;
@@ -128,7 +131,7 @@ class PhaseBuilder {
     // the one the split was meant to shorten -- cap the partials per MSM and kind.
     const size_t MAXP = 128;
     size_t fchunk_ = this->fchunk_, vchunk_ = this->vchunk_;
-    const bool bucket = bucket_min_ && v_.size() >= bucket_min_ && v_.size() < 32768;
+    const bool bucket = bucket_min_ && v_.size() >= bucket_min_ && v_.size() <= BUCKET_TERMS_MAX;
     if (!bucket)
       for (Term& t : v_) t = Term{dslot(t.s), tslot(t.b)};
     if ((f_.size() + fchunk_ - 1) / fchunk_ > MAXP) fchunk_ = (f_.size() + MAXP - 1) / MAXP;
@@ -496,7 +499,7 @@ static inline std::vector<KLeaf> k_merge(const std::vector<KLeaf>& in) {
 // variable-base terms (the re-encryption uses the key's own window tables, kernels_msm.hpp body_remask)
 static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk, uint32_t point_bytes = 64,
                                         bool keyed = false, uint32_t bucket_min = 0, uint32_t bwin = 0, bool toom_cook = true,
-                                        uint32_t vsplit = 1) {
+                                        uint32_t vsplit = 1, uint32_t bbits = 8) {
   ProvePlan pl;
   pl.lay = make_prove_lay(m, n);
   pl.lay.toom = m == 2 ? 1u : 0u;
@@ -569,13 +572,13 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
     B.end();
   };
   {  // phase A: c_A (the re-encryption itself is the dedicated remask kernel)
-    PhaseBuilder B(pl.ph[0], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit);
+    PhaseBuilder B(pl.ph[0], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit, bbits);
     for (uint32_t k = 0; k < m; ++k) commit(B, l.cA + k, l.a + k * n, n, l.r + k);
     B.normalize(l.shuf, 2 * l.N);
     B.normalize(l.cA, m);
   }
   if (pl.lay.toom) {  // phase A2 (m = 2): D+ = C'_1 + C'_2, D- = C'_2 - C'_1 (affine + affine, then normalised)
-    PhaseBuilder B(pl.ph[4], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit);
+    PhaseBuilder B(pl.ph[4], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit, bbits);
     for (uint32_t t = 0; t < n; ++t)
       for (uint32_t c = 0; c < 2; ++c) {
         B.begin(l.tDp + 2 * t + c);
@@ -590,7 +593,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
     B.normalize(l.tDp, 4 * n);
   }
   if (karatsuba && l.nP > kP0) {  // phase A2 (m >= 3): sums of ciphertext rows used as Karatsuba operands
-    PhaseBuilder B(pl.ph[4], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit);
+    PhaseBuilder B(pl.ph[4], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit, bbits);
     for (auto& kv : cvec) {
       if (kv.first.size() == 1) continue;
       for (uint32_t t = 0; t < n; ++t)
@@ -603,7 +606,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
     B.normalize(kP0, l.nP - kP0);
   }
   {  // phase B: c_B, multi-exponentiation first message
-    PhaseBuilder B(pl.ph[1], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit);
+    PhaseBuilder B(pl.ph[1], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit, bbits);
     for (uint32_t k = 0; k < m; ++k) commit(B, l.cB + k, l.b + k * n, n, l.s + k);
     commit(B, l.mecA0, l.mea0, n, l.mer0);
     for (uint32_t k = 0; k < 2 * m; ++k) commit(B, l.mecB + k, l.meb + k, 1, l.mes + k);
@@ -705,7 +708,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
   }
   if (toomk) {  // phase B2: E_k = E(b_k gen; tau_k) + sum_e W[k][e] P_e  (E_0 = P_0 and E_{2m-1} = P_inf exactly)
     const ToomPlan& T = pl.toom;
-    PhaseBuilder B(pl.ph[5], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit);
+    PhaseBuilder B(pl.ph[5], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit, bbits);
     for (uint32_t k = 0; k < 2 * m; ++k)
       for (uint32_t c = 0; c < 2; ++c) {
         B.begin(l.meE + 2 * k + c);
@@ -727,7 +730,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
     B.normalize(l.meE, 4 * m);
   }
   {  // phase C: product-argument first messages that do not depend on later challenges
-    PhaseBuilder B(pl.ph[2], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit);
+    PhaseBuilder B(pl.ph[2], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit, bbits);
     commit(B, l.cb, l.bp + (m - 1) * n, n, l.sb);
     commit(B, l.hB + 0, l.dz, n, l.t);                       // = c_A[0] of the product statement (c_D0 + c_{-z})
     for (uint32_t i = 1; i + 1 < m; ++i) commit(B, l.hB + i, l.bp + i * n, n, l.hs + i);
@@ -739,7 +742,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
     B.normalize(l.svcd, 3);
   }
   {  // phase D: zero-argument first message
-    PhaseBuilder B(pl.ph[3], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit);
+    PhaseBuilder B(pl.ph[3], next_partial, fchunk, vchunk, bucket_min, bwin, vsplit, bbits);
     commit(B, l.zcA0, l.za0, n, l.zr0);
     commit(B, l.zcBm, l.zbm, n, l.zsm);
     for (uint32_t k = 0; k < 2 * m + 1; ++k) commit(B, l.zcD + k, l.zd + k, 1, l.zt + k);
@@ -978,7 +981,8 @@ struct MergeSink {
 };
 
 static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk, uint32_t point_bytes = 64,
-                                          bool keyed = false, uint32_t bucket_min = 0, uint32_t bwin = 0, uint32_t vsplit = 1) {
+                                          bool keyed = false, uint32_t bucket_min = 0, uint32_t bwin = 0, uint32_t vsplit = 1,
+                                          uint32_t bbits = 8) {
   VerifyPlan pl;
   pl.lay = make_verify_lay(m, n);
   const VerifyLay& l = pl.lay;
@@ -986,7 +990,7 @@ static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchun
   const VCoefMap& c = pl.cm;
   {
     uint32_t next_partial = l.chk_first + l.n_chk;
-    PhaseBuilder B(pl.ph, next_partial, fchunk, vchunk, bucket_min, bwin, vsplit);
+    PhaseBuilder B(pl.ph, next_partial, fchunk, vchunk, bucket_min, bwin, vsplit, bbits);
     PerCheckSink sink{B, l.chk_first};
     describe_verify(l, c, sink, keyed);
     pl.nJ = next_partial;
@@ -998,7 +1002,7 @@ static inline VerifyPlan make_verify_plan(uint32_t m, uint32_t n, uint32_t fchun
     MergeSink ms{l.mr};
     describe_verify(l, c, ms, keyed);
     uint32_t next_partial = l.chk_first + l.n_chk;
-    PhaseBuilder B(pl.mph, next_partial, fchunk, vchunk, bucket_min, bwin, vsplit);
+    PhaseBuilder B(pl.mph, next_partial, fchunk, vchunk, bucket_min, bwin, vsplit, bbits);
     B.begin(l.chk_merged);
     auto job = [&](uint32_t dst, const std::vector<MergePair>& v) {
       pl.mjobs.push_back(MergeJob{dst, (uint32_t)pl.mpairs.size(), (uint32_t)v.size()});

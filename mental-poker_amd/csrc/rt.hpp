@@ -70,6 +70,12 @@ inline void event_sync(Event e) { check(hipEventSynchronize(e), "event sync"); }
 // page-locked host memory: DMA at PCIe speed and truly asynchronous copies (pageable buffers go through the runtime's
 // bounce buffers at ~9 GB/s and block the calling thread)
 inline void mem_info(size_t* free_b, size_t* total_b) { check(hipMemGetInfo(free_b, total_b), "hipMemGetInfo"); }
+inline uint32_t cu_count() {
+  int dev = 0, n = 0;
+  check(hipGetDevice(&dev), "hipGetDevice");
+  check(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute(CUs)");
+  return n > 0 ? (uint32_t)n : 1u;
+}
 inline void* host_alloc(size_t bytes) {
   void* p = nullptr;
   check(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault), "hipHostMalloc");
@@ -188,6 +194,23 @@ struct WaveCtx {
 #pragma unroll
     for (size_t i = 0; i < sizeof(T) / 4; ++i) d[i] = dpp_keep((uint32_t)__builtin_amdgcn_update_dpp(0, (int)s[i], ctrl, 0xF, 0xF, true));
     return r;
+  }
+  // the next work item of a persistent wave: one atomic on a global counter, the same value in every lane
+  __device__ __forceinline__ uint32_t next_item(uint32_t* counter) {
+    uint32_t v = 0;
+    if (lane == 0) v = atomicAdd(counter, 1u);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+  }
+  // persistent waves that share a SIMD run the same phases at the same time -- and stall at the same time; every second workgroup of
+  // a CU (workgroups are dealt to the 8 XCDs x 32 CUs round-robin: b and b + 256 meet) starts `units` x 64 cycles late
+  __device__ __forceinline__ void stagger(uint32_t units) {
+    if ((blockIdx.x >> 8) & 1u)
+      for (uint32_t i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(1);
+  }
+  // pull the cache line of a global word towards the CU without holding a register for it: a one-word load straight into LDS
+  // (global_load_lds_dword; `sink` = 64 words of the wave's LDS that nobody reads, the same for every lane)
+  __device__ __forceinline__ void touch(const uint32_t* p, uint32_t* sink) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p, (__attribute__((address_space(3))) void*)sink, 4, 0, 0);
   }
   // global-memory words written by any lane of the wave before are visible to every lane of the wave afterwards
   __device__ __forceinline__ void sync_global() {

@@ -472,7 +472,8 @@ def test_bucket_method_kernel_under_emulation_matches_golden(emu, name):
 
 
 def test_bucket_msm_edge_scalars_under_emulation(emu, coracle):
-    """0, 1, q - 1, +-128 boundaries of the signed 8-bit recoding, repeated and opposite points, the point at infinity"""
+    """0, 1, q - 1, +-128 boundaries of the signed 8-bit recoding, repeated and opposite points, the point at infinity; the same through
+    9- and 10-bit windows (mp_set_bucket_bits)"""
     import random
     cvn = "stark"
     q = 0x0800000000000010ffffffffffffffffb781126dcae7b2321e66a241adc64d2f
@@ -489,11 +490,25 @@ def test_bucket_msm_edge_scalars_under_emulation(emu, coracle):
     sc[0:12] = [0, 1, q - 1, 128, 127, 129, 2 ** 248, 2 ** 251, 255, 256 * 128, q - 128, q - 129]
     sc[6], sc[7] = 5, q - 5                            # P and -P cancel inside one bucket
     scb = b"".join(s.to_bytes(32, "little") for s in sc)
-    assert t.msm(1, K, scb, bytes(pts)) == coracle.msm(cvn, scb, bytes(pts))
+    want = coracle.msm(cvn, scb, bytes(pts))
     same = b"".join((77).to_bytes(32, "little") for _ in range(K))      # every term in ONE bucket of one window
-    assert t.msm(1, K, same, bytes(pts)) == coracle.msm(cvn, same, bytes(pts))
+    want_same = coracle.msm(cvn, same, bytes(pts))
     zero = bytes(32 * K)
-    assert t.msm(1, K, zero, bytes(pts)) == bytes(64)
+    for bits in (0, 8, 9, 10):                           # window widths of the bucket method (0: by size = 8 here); 2, 4, 8 buckets per lane
+        t.set_bucket_bits(bits)
+        assert t.msm(1, K, scb, bytes(pts)) == want, bits
+        assert t.msm(1, K, same, bytes(pts)) == want_same, bits
+        assert t.msm(1, K, zero, bytes(pts)) == bytes(64), bits
+    # the boundaries of the 9- and 10-bit signed recodings, and more MSMs than the emulator has persistent waves (items wrap around)
+    t.set_bucket_bits(10)
+    sc[12:20] = [511, 512, 513, 2 ** 250 + 511, (1 << 252) - 1 - (q - (1 << 251)) % 7, q - 512, q - 513, 256]
+    nm = 3
+    many = b"".join(((s * (i + 1)) % q).to_bytes(32, "little") for i in range(nm) for s in sc)
+    got = t.msm(nm, K, many, bytes(pts) * nm)
+    for i in range(nm):
+        assert got[64 * i:64 * (i + 1)] == coracle.msm(cvn, many[32 * K * i:32 * K * (i + 1)], bytes(pts)), i
+    with pytest.raises(Exception):
+        t.set_bucket_bits(11)
 
 
 @pytest.mark.parametrize("name", ["shuffle_stark_m3_n4_s11.json", "shuffle_stark_m4_n13_s9.json", "shuffle_secp256k1_m3_n3_s5.json"])
@@ -638,7 +653,8 @@ def test_emulated_group_verification(emu, coracle, cv, keyed):
     cases = {"good": (ref[0], ref[1]), "badproof": (ref[0], bytes(bad_p)), "badpoint": (bytes(bad_d), ref[1]), "rotated": (rot, ref[1])}
     want = {k: verify(args[0], d, p) for k, (d, p) in cases.items()}
     assert want["good"] == [0] * B and want["badproof"][4] > 0 and want["badpoint"][1] < 0 and all(v > 0 for v in want["rotated"])
-    for links in (3, 2, 6):
+    for links, bits in ((3, 0), (2, 10), (6, 9)):         # (the group equation through 8-, 10- and 9-bit windows: mp_set_bucket_bits)
+        t.set_bucket_bits(bits)
         t.set_group_verify(links * (4 * m * n + 11 * m + 8 + (1 if keyed else 0)), 0)
         eng.profile_enable(True)
         for k, (d, p) in cases.items():
@@ -646,6 +662,7 @@ def test_emulated_group_verification(emu, coracle, cv, keyed):
         rep = eng.profile_report()
         eng.profile_enable(False)
         assert "k_chain_scalars" in rep and "k_bucket_msm" in rep
+    t.set_bucket_bits(0)
     if not keyed:                                          # pipelined: the group pass is the deferred screen
         buf = lambda b: (ctypes.c_uint8 * len(b)).from_buffer_copy(b)
         addr = ctypes.addressof
@@ -662,6 +679,6 @@ def test_emulated_group_verification(emu, coracle, cv, keyed):
         for k, st, _, _ in held:
             assert list(st) == want[k], k
         t.set_pipeline(0)
-    t.set_group_verify(3808, 6144)
+    t.set_group_verify(30464, 6144)
     t.set_work_split(-1)
     t.close()

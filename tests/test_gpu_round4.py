@@ -386,14 +386,14 @@ def test_group_verification_status_words(mp, coracle, cv, m, n):
 
 
 def test_group_verification_at_full_size(mp, coracle):
-    """a size the oracle cannot cover: 8 192 proofs (512 groups of 16): every proof accepted; ONE tampered proof anywhere makes exactly that
+    """a size the oracle cannot cover: 8 192 proofs (1 024 groups of 8, then 64 groups of 128 -- 30 464 points each, 10-bit windows): every proof accepted; ONE tampered proof anywhere makes exactly that
     proof fail with the reference's check name, as without groups"""
     import torch
     cv, m, n, B = "stark", 2, 26, 8192
     eng = mp._native.Engine(cv, 0)
     g0 = coracle.gen_inputs(cv, m, n, 5900)
     t = eng.table(m, n, g0["params"], g0["pk"], fb_bits=16)
-    assert t.group_size(B) == 16
+    assert t.group_size(B) == 8 and t.group_size(16384) == 16 and t.group_size(65536) == 64 and t.group_size(262144) == 128      # (no fewer than 945 groups)
     gpu = torch.device("cuda", 0)
     gen = torch.Generator(device=gpu)
     gen.manual_seed(5)
@@ -408,15 +408,26 @@ def test_group_verification_at_full_size(mp, coracle):
     sp = torch.empty(B, dtype=torch.int32, device=gpu)
     sv = torch.empty(B, dtype=torch.int32, device=gpu)
     t.shuffle_and_remask_batch_dev(B, decks.data_ptr(), rho.data_ptr(), perm.data_ptr(), seeds.data_ptr(), od.data_ptr(), op.data_ptr(), sp.data_ptr())
-    t.verify_shuffle_batch_dev(B, decks.data_ptr(), od.data_ptr(), op.data_ptr(), sv.data_ptr())
-    eng.sync()
-    assert int(sp.abs().sum().item()) == 0 and int(sv.abs().sum().item()) == 0
+    sizes = [(None, 8), ((30464, 0), 128), ((7616, 0), 32), ((30464, 0), 128)]      # 8-bit, 10-bit, 9-bit windows (the last one with 9 forced on 30 464 points)
+    for k, (cfg, L) in enumerate(sizes):
+        if cfg:
+            t.set_group_verify(*cfg)
+        t.set_bucket_bits(9 if k == 3 else 0)
+        assert t.group_size(B) == L
+        sv.fill_(55)
+        t.verify_shuffle_batch_dev(B, decks.data_ptr(), od.data_ptr(), op.data_ptr(), sv.data_ptr())
+        eng.sync()
+        assert int(sp.abs().sum().item()) == 0 and int(sv.abs().sum().item()) == 0, L
     op[4321, t.proof_bytes - 31] ^= 2
     od[77, 0:64] = od[78, 0:64]                             # card 0 of deck 77 replaced by a neighbour's: a valid point, a wrong statement
-    t.verify_shuffle_batch_dev(B, decks.data_ptr(), od.data_ptr(), op.data_ptr(), sv.data_ptr())
-    eng.sync()
-    st = sv.cpu().tolist()
-    assert [i for i, v in enumerate(st) if v] == [77, 4321]
-    assert eng.check_name(st[77]) == "Hadamard Product (5.1)" and st[4321] > 0
+    for k, (cfg, L) in enumerate(sizes):
+        t.set_group_verify(*(cfg or (30464, 6144)))
+        t.set_bucket_bits(9 if k == 3 else 0)
+        sv.fill_(55)
+        t.verify_shuffle_batch_dev(B, decks.data_ptr(), od.data_ptr(), op.data_ptr(), sv.data_ptr())
+        eng.sync()
+        st = sv.cpu().tolist()
+        assert [i for i, v in enumerate(st) if v] == [77, 4321], L
+        assert eng.check_name(st[77]) == "Hadamard Product (5.1)" and st[4321] > 0
     t.close()
     eng.close()

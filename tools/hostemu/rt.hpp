@@ -52,6 +52,7 @@ inline void launch_check(const char*) {}
 inline void stream_wait(Stream, Event) {}
 inline void event_sync(Event) {}
 inline void mem_info(size_t* free_b, size_t* total_b) { *free_b = *total_b = 0; }      // (auto-sized tables fall back to 8-bit windows)
+inline uint32_t cu_count() { return 2; }                                                   // (16 'persistent waves': items wrap around in tests)
 inline void* host_alloc(size_t bytes) { return dmalloc(bytes); }
 inline void host_free(void* p) { free(p); }
 inline void* host_alloc_mapped(size_t bytes, void** dev_ptr) {
@@ -128,6 +129,14 @@ struct WaveCtx {
   }
   template <int K, class T>
   T quad_read(const PerLane<T>& x, uint32_t l) const { return x.v[(l & ~3u) + K]; }
+  void touch(const uint32_t*, uint32_t*) {}
+  void stagger(uint32_t) {}
+  uint32_t next_item(uint32_t* counter) {
+    uint32_t v;
+    _Pragma("omp atomic capture")
+    { v = *counter; *counter += 1; }
+    return v;
+  }
   void sync_global() {}
 };
 }  // namespace mp
