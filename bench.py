@@ -801,12 +801,28 @@ def main():
     gl = 0
     if workload in ("pairs", "mixed") and not args.per_equation and args.keyed == 0:
         gl = table.group_size(Bs if workload == "pairs" else B // 2)
+    SCALAR_BITS = {"stark": 252, "bn254": 254, "secp256k1": 256, "bls12_377": 253}[curve]
+
+    def bucket_geometry(K):
+        """window width the engine picks for a bucket-method MSM of K terms (kernels_bucket.hpp bk_bits_for), its windows per scalar,
+        buckets per lane and the point additions of the wave-wide reduction of one window"""
+        c = 10 if K >= 12000 else (9 if K >= 6000 else 8)
+        nb = (1 << (c - 1)) // 64
+        return {"bits": c, "windows": (SCALAR_BITS + c) // c, "buckets_per_lane": nb, "reduction_adds": 13 + 2 * nb - 3}
+    per_proof_pts = 4 * N + 11 * m + 8
+    geo_own = bucket_geometry(per_proof_pts + 1)          # a proof's own bucket jobs (large decks: the merged equation and the prover's long products)
+    geo_grp = None
     if gl:
-        per_proof_pts = 4 * N + 11 * m + 8
+        geo_grp = bucket_geometry(gl * per_proof_pts)
+        # (large decks: the per-proof screen ran the merged equation as a bucket job of its own; the group equation replaces it)
+        own_terms = stats.get("bucket_terms", 0) - (per_proof_pts + 1 if stats["verify"].get("var_terms", 0) == 0 and stats.get("bucket_terms", 0) >= per_proof_pts else 0)
+        own_jobs = stats.get("bucket_jobs", 0) - (1 if own_terms != stats.get("bucket_terms", 0) else 0)
         stats["verify"] = {"fixed_terms": (n + 5) / gl, "var_terms": 0, "fixed_jobs": 4.0 / gl, "var_jobs": 0, "table_bases": 0, "combine_terms": 5.0 / gl}
-        stats["bucket_terms"] = stats.get("bucket_terms", 0) + per_proof_pts
-        stats["bucket_jobs"] = stats.get("bucket_jobs", 0) + 1.0 / gl
+        stats["bucket_terms"], stats["bucket_jobs"] = max(own_terms, 0), max(own_jobs, 0)
+        stats["group_terms"] = per_proof_pts
+        stats["group_jobs"] = 1.0 / gl
         stats["verify_group_size"] = gl
+        stats["group_bucket_geometry"] = geo_grp
     dom = max(prof.items(), key=lambda kv: kv[1][1])
     dom_name, (dom_count, dom_ms) = dom
     kernel_ms_total = sum(v[1] for v in prof.values())
@@ -818,7 +834,7 @@ def main():
         if kernel == "k_var_msm":
             return sum(s["var_terms"] * (32 + PB) + s["var_jobs"] * 3 * PB // 2 for s in pv)
         if kernel == "k_bucket_msm":
-            return stats.get("bucket_terms", 0) * (32 + PB) + stats.get("bucket_jobs", 0) * 3 * PB // 2
+            return (stats.get("bucket_terms", 0) + stats.get("group_terms", 0)) * (32 + PB) + (stats.get("bucket_jobs", 0) + stats.get("group_jobs", 0)) * 3 * PB // 2
         if kernel == "k_fixed_msm":
             return sum(s["fixed_terms"] * 32 + s["fixed_jobs"] * 3 * PB // 2 for s in pv)
         if kernel == "k_table":
@@ -879,19 +895,21 @@ def main():
                 steps_ = top_even // 2 + (top_odd - 1) // 2
                 per_pos += steps_ * (mul_small(x_ * x_) + jmadd) + mul_small(x_) + 2 * mc["jac"]
             mads_per_proof += 2 * n * per_pos + (2 * tm - 2) * 2 * n * mc["norm"]        # + normalisation of the evaluated vectors
-        # bucket-method MSMs: one mixed addition per term and window; per (MSM, window) a 14-step wave-wide reduction on 64 lanes
-        # (XYZZ + XYZZ, 12M+2S) and the fold (8 doublings + 1 addition)
-        bw = {"stark": 32, "bn254": 32, "secp256k1": 33, "bls12_377": 32}.get(curve, 32)
+        # bucket-method MSMs: one mixed addition per term and window; per (MSM, window) the wave-wide reduction on 64 lanes
+        # (XYZZ + XYZZ, 12M+2S; 13 + 2 NB - 3 of them) and the fold (c doublings + 1 addition)
+        bw = geo_own["windows"]
         fm = mc["field"]
         xyzz_add = 12 * fm["mul"] + 2 * fm["sqr"]
-        mads_per_proof += stats.get("bucket_terms", 0) * bw * mc["madd"]
-        mads_per_proof += stats.get("bucket_jobs", 0) * bw * (14 * 64 * xyzz_add + 8 * mc["dbl"] + mc["jac"])
+        for terms_k, jobs_k, geo in (("bucket_terms", "bucket_jobs", geo_own), ("group_terms", "group_jobs", geo_grp)):
+            if geo:
+                mads_per_proof += stats.get(terms_k, 0) * geo["windows"] * mc["madd"]
+                mads_per_proof += stats.get(jobs_k, 0) * geo["windows"] * (geo["reduction_adds"] * 64 * xyzz_add + geo["bits"] * mc["dbl"] + mc["jac"])
         mads = mads_per_proof * total_proofs / world
         int_mul = {"bound": "v_mad_u64_u32 issue", "achieved": round(mads / (kernel_ms_total * 1e-3) / 1e9, 1),
                    "peak": INT_MAD_PEAK_G, "unit": "Gmad/s",
                    "frac": mads / (kernel_ms_total * 1e-3) / 1e9 / INT_MAD_PEAK_G,
                    "mads_per_proof": int(mads_per_proof), "mads_per_op": {k: v for k, v in mc.items() if k not in ("field", "a1", "issue")},
-                   "plan_stats": stats, "bucket_windows": bw,
+                   "plan_stats": stats, "bucket_windows": (geo_grp or geo_own)["windows"],
                    "mads_per_field_op": mc["field"],
                    "note": "32x32+64 multiply-adds (v_mad_u64_u32 + v_mad_i64_i32) counted in the gfx950 assembly of THIS build "
                            "(mental-poker_amd/mad_counts.json, tools/gen_mad_counts.py) x static plan, over the kernel time of the WHOLE step; "
@@ -916,15 +934,17 @@ def main():
         elif dom_name == "k_remask":
             ops = {"madd": 2 * N * (fw + 1)}
         elif dom_name == "k_bucket_msm" and "xadd" in iss:
-            bw_ = {"secp256k1": 33}.get(curve, 32)
             if workload == "chain32" and not args.per_link_verify:
                 L_ = args.players
-                terms_, jobs_ = ((L_ + 1) * 2 * N + L_ * (11 * m + 7) + 1) / L_, 1.0 / L_
+                kc_ = (L_ + 1) * 2 * N + L_ * (11 * m + 7) + 1
+                parts_ = [(kc_ / L_, 1.0 / L_, bucket_geometry(kc_))]
             else:
-                terms_, jobs_ = stats.get("bucket_terms", 0), stats.get("bucket_jobs", 0)
+                parts_ = [(stats.get("bucket_terms", 0), stats.get("bucket_jobs", 0), geo_own)]
+                if geo_grp:
+                    parts_.append((stats["group_terms"], stats["group_jobs"], geo_grp))
             # one mixed addition per term and window (64 lanes share a window's terms evenly at best); per (MSM, window) the wave-wide
-            # reduction is 14 full additions on all 64 lanes
-            ops = {"madd": terms_ * bw_, "xadd": jobs_ * bw_ * 14 * 64}
+            # reduction is 13 + 2 NB - 3 full additions on all 64 lanes
+            ops = {"madd": sum(t_ * g_["windows"] for t_, j_, g_ in parts_), "xadd": sum(j_ * g_["windows"] * g_["reduction_adds"] * 64 for t_, j_, g_ in parts_)}
         if ops and sum(ops.values()) > 0:       # (plan_stats describes the throughput plan: small batches on the finer splits have no entry)
             cyc_per_proof = sum(ops[k] * iss[k]["cycles"] for k in ops)                     # lane-level issue cycles x 1 lane
             waves_cycles = cyc_per_proof * (total_proofs / world) / 64.0                        # wave-level instructions issue for 64 lanes at once

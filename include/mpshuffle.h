@@ -213,12 +213,12 @@ int mp_set_plan_thresholds(mp_table* t, size_t finest, size_t small, size_t late
  * FIRST failing check is reported by name exactly as the reference does [REF tests.rs:223-225].  off: always evaluate
  * the equations one by one.  Results (status words) are identical in both modes. */
 int mp_set_merged_verify(mp_table* t, int on);
-/* Group verification (round 4; on by default).  The screening pass of a batch of at least `min_batch` x 52 / N proofs (default 6 144 for
+/* Group verification (round 4; on by default except on BLS12-377, where it only draws level).  The screening pass of a batch of at least `min_batch` x 52 / N proofs (default 6 144 for
  * 52-card decks) adds the merged equations of a GROUP of proofs with weights derived from every proof of the group and evaluates the sum
  * on the bucket-method kernel (counting sort by wavefront prefix sum, balanced bucket shares, wave-wide bucket reduction): 26 to 33
  * additions per point instead of 51 plus window tables and doubling chains, and the fixed bases once per group (52-card decks:
  * 521 k -> 660 k proofs/s at 262 144 in flight).  `points_per_group` (default 30 464) is the size of a group's equation aimed at: a proof
- * brings 4N + 11m + 8 points, so 128 proofs of a 52-card deck, 7 of a 1 024-card one -- but a batch takes no fewer than 2/13 `min_batch`
+ * brings 4N + 11m + 8 points, so 128 proofs of a 52-card deck, 8 of a 1 024-card one -- but a batch takes no fewer than 2/13 `min_batch`
  * groups (945: a dozen windows for each of the kernel's 2 048 persistent waves), i.e. 16 proofs per group at 16 384 in flight.  The group
  * size is the divisor of the batch size nearest to that (between half and twice it; a batch without one keeps the per-proof screen).  A
  * batch in which some group fails is re-evaluated equation by equation: status words are identical to every other strategy.
@@ -237,7 +237,7 @@ int mp_set_bucket_min(mp_table* t, size_t terms);
 int mp_set_bucket_bits(mp_table* t, uint32_t bits);
 /* Chain verification (mp_verify_shuffle_chain*): at most `links` links share one chain equation; longer chains are verified as
  * consecutive sub-chains.  0 (default) = as many as fit the 32 767 points of one equation (293 links of a 52-card deck).  A smaller
- * value bounds the LDS a chain equation needs and the work that is repeated link by link when a chain fails.  Verdicts are the same. */
+ * value bounds the work that is repeated link by link when a chain fails.  Verdicts are the same. */
 int mp_set_chain_max_links(mp_table* t, uint32_t links);
 /* Lanes per Fiat-Shamir transcript.  A proof's transcript is one BLAKE2s chain (13.6 KB of statement for a 52-card deck): 1 = one
  * lane per proof (what a batch that fills the chip wants), 4 = the four G functions of a half-round on four adjacent lanes (2.7x

@@ -1363,21 +1363,23 @@ struct Table : mp_table {
   // fails is re-verified equation by equation, so the status words are exactly those of the other paths.  Lane of (member j, group t)
   // = j T + t with T = B / L groups: the members of a group are T proofs apart.
   ChainPlan gplan;
-  Workspace gws;                      // lean workspace of the group pass: no window tables, no digit planes (68 KB per proof)
+  Workspace gws;                      // lean workspace of the pipelined group pass: no window tables, no digit planes (68 KB per proof)
   // Group size: the wave-wide reduction of a window costs ~40 additions whatever the equation holds, and 10-bit windows (26 per scalar
-  // instead of 32) want ~60 terms per bucket -- as many proofs as fit the 32 767 points of one bucket job when the batch is large
-  // (128 proofs of a 52-card deck, 7 of a 1 024-card one); but the kernel's 2 048 persistent waves want a dozen (equation, window) items
+  // instead of 32) want ~60 terms per bucket -- ~30 000 points per equation when the batch is large
+  // (128 proofs of a 52-card deck, 8 of a 1 024-card one); but the kernel's 2 048 persistent waves want a dozen (equation, window) items
   // each, so a smaller batch takes smaller groups: no fewer than 2/13 of the minimum batch (945 at the default 6 144: 12 x 2 048 / 26).
   // window width of the bucket method for an MSM of K terms (mp_set_bucket_bits; 0 = by size)
   uint32_t bucket_bits_of(uint32_t K) const { return bucket_bits ? bucket_bits : bk_bits_for(K); }
-  uint32_t group_points = 30464;      // points per group equation aimed at (mp_set_group_verify; 0 = off): 128 proofs of a 52-card deck
+  // (BLS12-377: the bucket kernel's additions over a 377-bit field spill ~200 registers at two waves per SIMD and only draw level with the
+  // Straus screen -- 13.1 k against 13.1 k proofs/s at (10,30) --, so groups are off there unless mp_set_group_verify asks for them)
+  uint32_t group_points = G_::FW > 8 ? 0u : 30464u;      // points per group equation aimed at (mp_set_group_verify; 0 = off): 128 proofs of a 52-card deck
   uint32_t group_min_batch = 6144;    // smaller batches (in 52-card proofs: x 52 / N) keep the per-proof screen
   void set_group_verify(uint32_t points, size_t min_batch) override {
     group_points = points;
     group_min_batch = (uint32_t)std::min<size_t>(min_batch, 0x7FFFFFFFu);
   }
   // proofs per group for a batch of B: the divisor of B nearest to the wanted size (between half and twice it) whose equation
-  // fits the 32 767 points of one bucket job; 0 = this batch takes the per-proof screen
+  // fits one bucket job (65 535 points); 0 = this batch takes the per-proof screen
   uint32_t group_size_of(size_t B) const override { return B < 0x7FFFFFFFu ? group_size((uint32_t)B, false) : 0; }
   uint32_t group_size(uint32_t B, bool keyed) const {
     const uint32_t per = 4 * N + 11 * m + 8 + (keyed ? 1u : 0u);
@@ -1391,7 +1393,7 @@ struct Table : mp_table {
     for (uint32_t d = 0; d <= want; ++d)
       for (int sgn = 1; sgn >= -1; sgn -= 2) {
         const int64_t L = (int64_t)want + sgn * (int64_t)d;
-        if (L < 2 || 2 * L < (int64_t)want || L > 2 * (int64_t)want || (uint64_t)L * per > 32767u || L > 1023) continue;      // (10 bits of link in a sorted entry: kernels_bucket.hpp)
+        if (L < 2 || 2 * L < (int64_t)want || L > 2 * (int64_t)want || (uint64_t)L * per > BUCKET_TERMS_MAX || L > 1023) continue;      // (10 bits of link in a sorted entry: kernels_bucket.hpp)
         if (B % (uint32_t)L == 0) return (uint32_t)L;
       }
     return 0;
@@ -1436,7 +1438,9 @@ struct Table : mp_table {
     PlanSet& q = (keyed ? psk : ps)[0];
     const VerifyLay& l = q.vplan.lay;
     rt::Stream s = ctx->stream;
-    Workspace& w = gws;
+    // (on the caller's stream the pass borrows the prover's arenas, as the per-proof screen does: nothing of a prove call outlives it;
+    // the verify lane has lean arenas of its own)
+    Workspace& w = vlane ? gws : ws;
     w.fw = G_::FW;
     w.ensure(B, l.nS, l.nP, std::max(gplan.nJ, 8u), 0, 0, nwin, stage_words_needed(), s, 0);
     rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);

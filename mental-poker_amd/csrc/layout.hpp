@@ -98,7 +98,7 @@ struct Phase {
 };
 
 static const size_t COMBINE_TREE_MIN = 12;
-static const size_t BUCKET_TERMS_MAX = 32767;      // terms of one bucket job (one wave sorts a window's digits; uint16 counters nowhere, but the scratch row is sized by it)
+static const size_t BUCKET_TERMS_MAX = 65535;      // terms of one bucket job (one wave sorts a window's digits into a scratch row of that many words)
 // Host-side builder: msm(out) { fixed(..) var(..) addend(..) } -> chunked sub-jobs + one combine job.
 class PhaseBuilder {
  public:
