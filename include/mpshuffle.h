@@ -231,9 +231,9 @@ uint32_t mp_group_size(const mp_table* t, size_t B);
  * smaller ones on the Straus kernel with per-proof window tables; 0 = never.  Results are identical; the split is a property of
  * the table's static plans, which this call rebuilds. */
 int mp_set_bucket_min(mp_table* t, size_t terms);
-/* Window width of the bucket method: 8, 9 or 10 bits (128, 256 or 512 buckets per window; 32, 29 or 26 windows per 252-bit scalar), or
- * 0 (default) = by the size of the MSM (8 bits below 6 000 terms, 9 below 12 000, 10 from there on -- the equation of a group of
- * proofs, mp_set_group_verify).  Results are identical; rebuilds the static plans like mp_set_bucket_min. */
+/* Window width of the bucket method: 8 to 11 bits (128 to 1 024 buckets per window; 32, 29, 26 or 23 windows per 252-bit scalar), or
+ * 0 (default) = by the size of the MSM (8 bits below 6 000 terms, 9 below 12 000, 10 below 40 000 -- the equation of a group of
+ * proofs, mp_set_group_verify --, 11 from there on).  Results are identical; rebuilds the static plans like mp_set_bucket_min. */
 int mp_set_bucket_bits(mp_table* t, uint32_t bits);
 /* Chain verification (mp_verify_shuffle_chain*): at most `links` links share one chain equation; longer chains are verified as
  * consecutive sub-chains.  0 (default) = as many as fit the 32 767 points of one equation (293 links of a 52-card deck).  A smaller

@@ -257,7 +257,7 @@ int mp_set_bucket_min(mp_table* t, size_t terms) {
 }
 int mp_set_bucket_bits(mp_table* t, uint32_t bits) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_bits: null table");
-  if (bits != 0 && (bits < 8 || bits > 10)) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_bits: 0 (by size), 8, 9 or 10");
+  if (bits != 0 && (bits < 8 || bits > 11)) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_bits: 0 (by size) or 8 .. 11");
   MP_TRY
   rt::set_device(t->ctx->device);
   t->set_bucket_bits(bits);
@@ -289,7 +289,7 @@ int mp_set_work_split(mp_table* t, int split) {
 }
 int mp_set_group_verify(mp_table* t, uint32_t points_per_group, size_t min_batch) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_verify: null table");
-  if (points_per_group > 32767) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_verify: 0 (off) or up to 32 767 points per group equation");
+  if (points_per_group > 65535) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_verify: 0 (off) or up to 65 535 points per group equation");
   MP_TRY
   rt::set_device(t->ctx->device);
   t->flush();

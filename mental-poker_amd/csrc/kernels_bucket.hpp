@@ -1,7 +1,7 @@
 // Bucket-method (Pippenger) multi-scalar multiplication for the LARGE MSMs -- the verifier's products over a 1024-card deck
 // (4N + 11m + 9 = 4193 terms in one equation at m = 8, n = 128), a chain's equation, the ONE equation a group of up to 128 proofs is
 // screened by (30 464 terms at 52 cards) -- as a WAVE-COOPERATIVE kernel: one 64-lane wave owns one (proof, MSM, window) at a time and
-// computes sum_t d_t P_t for the window's signed c-bit digits d_t (c = 8, 9 or 10: 2^(c-1) buckets |d|, NB = 2^(c-1) / 64 per lane):
+// computes sum_t d_t P_t for the window's signed c-bit digits d_t (c = 8 .. 11: 2^(c-1) buckets |d|, NB = 2^(c-1) / 64 per lane):
 //
 //   A  the window's K digits (int16) are read as words of two from the proof-major digit array (twice: B and D; they stay in cache);
 //   B  histogram of |d| over the buckets (LDS atomics);
@@ -36,14 +36,14 @@
 
 namespace mp {
 
-static const uint32_t BK_BITS_MIN = 8, BK_BITS_MAX = 10;     // signed windows: digits in [-2^(c-1), 2^(c-1) - 1]
+static const uint32_t BK_BITS_MIN = 8, BK_BITS_MAX = 11;     // signed windows: digits in [-2^(c-1), 2^(c-1) - 1]
 static const uint32_t BK_WAVES_PER_CU = 8;                   // persistent waves (MP_WAVE_KERNEL: 2 workgroups of 4 per CU)
 static inline uint32_t bk_windows(int scalar_bits, uint32_t c) { return ((uint32_t)scalar_bits + c) / c; }
 MP_HD uint32_t bk_buckets(uint32_t c) { return 1u << (c - 1); }
 // window width for an MSM of K terms: the reduction F costs ~(20 + 4 NB) additions per window, a narrower window K / (c (c + 1)) more
-static inline uint32_t bk_bits_for(uint32_t K) { return K >= 12000u ? 10u : (K >= 6000u ? 9u : 8u); }
-// LDS words one wave needs: counts + cursors of the buckets, 64 XYZZ exchange slots of xw words, the sink of the cache touches
-static inline uint32_t bk_lds_words(uint32_t c, uint32_t xw) { return 2u * (bk_buckets(c) + 4u) + 64u * xw + 64u; }
+static inline uint32_t bk_bits_for(uint32_t K) { return K >= 40000u ? 11u : (K >= 12000u ? 10u : (K >= 6000u ? 9u : 8u)); }
+// LDS words one wave needs: counts + cursors of the buckets, 64 XYZZ exchange slots of xw words
+static inline uint32_t bk_lds_words(uint32_t c, uint32_t xw) { return 2u * (bk_buckets(c) + 4u) + 64u * xw; }
 
 // ---- digits: canonical scalar -> W signed digits, d_w in [-2^(c-1), 2^(c-1) - 1] (top window non-negative), proof-major:
 // D16[b * dstride + pos + w * kpad]  (pos = digit offset of the term inside the proof's block, kpad = padded terms of its MSM)
@@ -142,12 +142,8 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
   uint32_t* cnt = wv.lds;                         // [0 .. NBK]: terms per |digit|; then off[]: first sorted position per bucket
   uint32_t* cur = wv.lds + HW;                    // scatter cursors; after the scatter: the lanes' bucket assignment [class][lane]
   uint32_t* xch = wv.lds + 2 * HW;                // point exchange of the reduction
-  uint32_t* sink = xch + 64 * XW;                 // 64 words nobody reads (WaveCtx::touch)
   uint32_t* ix = a.sorted + (size_t)slot * a.kpad_max;
   uint32_t* park = a.park + (size_t)slot * NBK * XW;
-#ifdef MP_EXP_BK_STAGGER
-  wv.stagger(MP_EXP_BK_STAGGER);
-#endif
 #ifdef MP_EXP_BK_TIMING     // experiment: cycles per phase (sort, ranks, additions, reduction), summed per wave into the tail of its park row
   unsigned long long tm_[5] = {0, 0, 0, 0, 0}, t0_ = 0;
 #define MP_BK_T0() t0_ = __builtin_readcyclecounter()
@@ -322,9 +318,6 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
       if (n[lane] > 0) e0[lane] = ix[advance(lane, 0, first)];            // (empty classes in front of the first term: mseg below)
       if (n[lane] > 1) e1[lane] = ix[advance(lane, 1, nb1[lane])];
       nb0[lane] = 0;
-#ifdef MP_EXP_BK_TOUCH
-      if (n[lane] > 0) wv.touch(point_of(e0[lane]), sink);
-#endif
       if (!balanced && n[lane] > 0)
         while (off[NB * cur[mseg[lane] * 64 + lane] + 2 + mseg[lane]] == off[NB * cur[mseg[lane] * 64 + lane] + 1 + mseg[lane]]) mseg[lane] += 1;
     });
@@ -335,9 +328,6 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
       wv.lanes([&](uint32_t lane) {
         if (i < n[lane]) {
           const uint32_t e = e0[lane];
-#ifdef MP_EXP_BK_TOUCH   // experiment (tools/ab_build.py): pull the next point's cache line towards the CU through an LDS sink -- slower: the LDS reads behind it wait for it
-          if (i + 1 < n[lane]) wv.touch(point_of(e1[lane]), sink);
-#endif
           const uint32_t fresh = nb0[lane];
           if (balanced) {
             const uint32_t p = pos[lane] - 1 - i;

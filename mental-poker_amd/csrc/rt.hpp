@@ -201,17 +201,6 @@ struct WaveCtx {
     if (lane == 0) v = atomicAdd(counter, 1u);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
   }
-  // persistent waves that share a SIMD run the same phases at the same time -- and stall at the same time; every second workgroup of
-  // a CU (workgroups are dealt to the 8 XCDs x 32 CUs round-robin: b and b + 256 meet) starts `units` x 64 cycles late
-  __device__ __forceinline__ void stagger(uint32_t units) {
-    if ((blockIdx.x >> 8) & 1u)
-      for (uint32_t i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(1);
-  }
-  // pull the cache line of a global word towards the CU without holding a register for it: a one-word load straight into LDS
-  // (global_load_lds_dword; `sink` = 64 words of the wave's LDS that nobody reads, the same for every lane)
-  __device__ __forceinline__ void touch(const uint32_t* p, uint32_t* sink) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p, (__attribute__((address_space(3))) void*)sink, 4, 0, 0);
-  }
   // global-memory words written by any lane of the wave before are visible to every lane of the wave afterwards
   __device__ __forceinline__ void sync_global() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -494,7 +494,7 @@ def test_bucket_msm_edge_scalars_under_emulation(emu, coracle):
     same = b"".join((77).to_bytes(32, "little") for _ in range(K))      # every term in ONE bucket of one window
     want_same = coracle.msm(cvn, same, bytes(pts))
     zero = bytes(32 * K)
-    for bits in (0, 8, 9, 10):                           # window widths of the bucket method (0: by size = 8 here); 2, 4, 8 buckets per lane
+    for bits in (0, 8, 9, 10, 11):                       # window widths of the bucket method (0: by size = 8 here); 2, 4, 8, 16 buckets per lane
         t.set_bucket_bits(bits)
         assert t.msm(1, K, scb, bytes(pts)) == want, bits
         assert t.msm(1, K, same, bytes(pts)) == want_same, bits
@@ -508,7 +508,7 @@ def test_bucket_msm_edge_scalars_under_emulation(emu, coracle):
     for i in range(nm):
         assert got[64 * i:64 * (i + 1)] == coracle.msm(cvn, many[32 * K * i:32 * K * (i + 1)], bytes(pts)), i
     with pytest.raises(Exception):
-        t.set_bucket_bits(11)
+        t.set_bucket_bits(12)
 
 
 @pytest.mark.parametrize("name", ["shuffle_stark_m3_n4_s11.json", "shuffle_stark_m4_n13_s9.json", "shuffle_secp256k1_m3_n3_s5.json"])
@@ -653,7 +653,7 @@ def test_emulated_group_verification(emu, coracle, cv, keyed):
     cases = {"good": (ref[0], ref[1]), "badproof": (ref[0], bytes(bad_p)), "badpoint": (bytes(bad_d), ref[1]), "rotated": (rot, ref[1])}
     want = {k: verify(args[0], d, p) for k, (d, p) in cases.items()}
     assert want["good"] == [0] * B and want["badproof"][4] > 0 and want["badpoint"][1] < 0 and all(v > 0 for v in want["rotated"])
-    for links, bits in ((3, 0), (2, 10), (6, 9)):         # (the group equation through 8-, 10- and 9-bit windows: mp_set_bucket_bits)
+    for links, bits in ((3, 0), (2, 10), (6, 9), (3, 11)):      # (the group equation through 8-, 10-, 9- and 11-bit windows: mp_set_bucket_bits)
         t.set_bucket_bits(bits)
         t.set_group_verify(links * (4 * m * n + 11 * m + 8 + (1 if keyed else 0)), 0)
         eng.profile_enable(True)

@@ -129,8 +129,6 @@ struct WaveCtx {
   }
   template <int K, class T>
   T quad_read(const PerLane<T>& x, uint32_t l) const { return x.v[(l & ~3u) + K]; }
-  void touch(const uint32_t*, uint32_t*) {}
-  void stagger(uint32_t) {}
   uint32_t next_item(uint32_t* counter) {
     uint32_t v;
     _Pragma("omp atomic capture")
