@@ -1,5 +1,5 @@
 set +x
-O=gpurun_out/r04d; mkdir -p $O
+O=gpurun_out/r04f; mkdir -p $O
 X="--no-extras --no-cpu-baseline --steps 2 --warmup 1"
 python bench.py $X --curve secp256k1 > $O/secp256k1.json 2>$O/err.txt
 python bench.py $X --curve bn254 > $O/bn254.json 2>>$O/err.txt
