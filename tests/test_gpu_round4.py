@@ -431,3 +431,37 @@ def test_group_verification_at_full_size(mp, coracle):
         assert eng.check_name(st[77]) == "Hadamard Product (5.1)" and st[4321] > 0
     t.close()
     eng.close()
+
+
+def test_group_verification_of_large_decks(mp, coracle):
+    """512-card decks (m = 4, n = 128): a proof's own merged equation (2 100 points) already runs on the bucket kernel; groups of 4 and 2
+    such proofs (8 400 points through 9-bit windows, 4 200 through 8- and forced 10-bit ones) give the status words of the per-proof
+    screen -- all accepted; one bad response scalar and one swapped deck named; the first proof's bytes are the oracle's"""
+    cv, m, n, B = "stark", 4, 128, 8
+    eng = mp._native.Engine(cv, 0)
+    ins, args = _inputs(coracle, cv, m, n, B, 6100)
+    g0 = ins[0]
+    t = eng.table(m, n, g0["params"], g0["pk"], fb_bits=8)
+    out = t.shuffle_and_remask_batch(*args)
+    dsz, psz = len(g0["deck"]), t.proof_bytes
+    assert (out[0][:dsz], out[1][:psz]) == _expected(coracle, cv, m, n, g0, ins[:1])
+    per = 4 * m * n + 11 * m + 8
+    bad_p = bytearray(out[1])
+    bad_p[6 * psz - 31] ^= 2                              # proof 5: its last response scalar
+    swapped = out[0][dsz:2 * dsz] + out[0][:dsz] + out[0][2 * dsz:]      # decks 0 and 1 exchanged
+    cases = {"good": (out[0], out[1]), "badproof": (out[0], bytes(bad_p)), "swapped": (swapped, out[1])}
+    t.set_group_verify(0, 0)
+    want = {k: t.verify_shuffle_batch(args[0], d, p) for k, (d, p) in cases.items()}
+    assert want["good"] == [0] * B and [i for i, v in enumerate(want["badproof"]) if v] == [5] and [i for i, v in enumerate(want["swapped"]) if v] == [0, 1]
+    for links, bits in ((4, 0), (2, 0), (2, 10)):
+        t.set_bucket_bits(bits)
+        t.set_group_verify(links * per, 0)
+        assert t.group_size(B) == links
+        eng.profile_enable(True)
+        got = {k: t.verify_shuffle_batch(args[0], d, p) for k, (d, p) in cases.items()}
+        rep = eng.profile_report()
+        eng.profile_enable(False)
+        assert got == want, (links, bits)
+        assert "k_chain_scalars" in rep and "k_bucket_msm" in rep
+    t.close()
+    eng.close()
