@@ -806,7 +806,7 @@ def main():
     def bucket_geometry(K):
         """window width the engine picks for a bucket-method MSM of K terms (kernels_bucket.hpp bk_bits_for), its windows per scalar,
         buckets per lane and the point additions of the wave-wide reduction of one window"""
-        c = 10 if K >= 12000 else (9 if K >= 6000 else 8)
+        c = 11 if K >= 40000 else (10 if K >= 12000 else (9 if K >= 6000 else 8))
         nb = (1 << (c - 1)) // 64
         return {"bits": c, "windows": (SCALAR_BITS + c) // c, "buckets_per_lane": nb, "reduction_adds": 13 + 2 * nb - 3}
     per_proof_pts = 4 * N + 11 * m + 8

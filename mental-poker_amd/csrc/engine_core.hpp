@@ -639,7 +639,8 @@ struct Table : mp_table {
                   uint32_t link_stride, const char* too_large) {
     rt::Stream s = ctx->stream;
     const uint32_t c = ph.b_bits, bw = bk_windows(R::BITS, c);
-    if ((uint64_t)count * ph.n_bterms >= ((uint64_t)1 << 32) || (uint64_t)count * ph.n_b * bw >= ((uint64_t)1 << 32)) throw std::runtime_error(too_large);
+    // (the item counter runs past the last item by one draw per persistent wave)
+    if ((uint64_t)count * ph.n_bterms >= ((uint64_t)1 << 32) || (uint64_t)count * ph.n_b * bw + ctx->bucket_slots() >= ((uint64_t)1 << 32)) throw std::runtime_error(too_large);
     BRecodeArgs ra{S, D, ph.bterms.p, ph.bpos.p, sstride, bw, ph.n_bterms, dstride, c};
     MP_RUN(k_bucket_recode, C, count * ph.n_bterms, 1, ra);
     const uint32_t nitems = count * ph.n_b * bw, nslots = std::min(nitems, ctx->bucket_slots());
