@@ -446,7 +446,7 @@ def test_points_outside_the_prime_order_subgroup_are_rejected(emu, native):
                                   "shuffle_bls12_377_m2_n3_s13.json"])
 def test_bucket_method_kernel_under_emulation_matches_golden(emu, name):
     """mp_set_bucket_min forces every variable-base MSM of >= 4 terms through the wave-cooperative bucket kernel
-    (kernels_bucket.hpp: LDS-staged digits, counting sort, two buckets per lane, wave-wide reduction): same bytes, same verdicts"""
+    (kernels_bucket.hpp: LDS histogram, counting sort, two buckets per lane dealt by rank, wave-wide reduction): same bytes, same verdicts"""
     g = load_json(os.path.join(GOLDEN, name))
     eng = emu(g["curve"])
     m, n = g["m"], g["n"]
