@@ -465,3 +465,35 @@ def test_group_verification_of_large_decks(mp, coracle):
         assert "k_chain_scalars" in rep and "k_bucket_msm" in rep
     t.close()
     eng.close()
+
+
+def test_bucket_msm_at_the_term_limit(mp, coracle):
+    """ONE multi-scalar multiplication of 65 535 terms -- the most a bucket job takes (11-bit windows, 16 buckets per lane, a 256 KB
+    scratch row per wave) -- and of 40 000 and 12 000 (10-bit) and 6 000 terms (9-bit), against the oracle: the points repeat with
+    period 509, so the oracle's MSM of 509 terms with the summed scalars is the same group element"""
+    import random
+    cv = "stark"
+    q = 0x0800000000000010ffffffffffffffffb781126dcae7b2321e66a241adc64d2f
+    eng = mp._native.Engine(cv, 0)
+    g0 = coracle.gen_inputs(cv, 2, 3, 6200)
+    t = eng.table(2, 3, g0["params"], g0["pk"])
+    per = 509
+    base = eng.setup(2, per - 3, bytes([11] * 32))[:64 * per]
+    assert len(base) == 64 * per
+    random.seed(62)
+    for K in (65535, 40000, 12000, 6000):
+        sc = [random.randrange(q) for _ in range(K)]
+        sc[:4] = [0, 1, q - 1, (1 << 251) + 1]
+        pts = (base * (K // per + 1))[:64 * K]
+        folded = [0] * per
+        for i, s in enumerate(sc):
+            folded[i % per] = (folded[i % per] + s) % q
+        want = coracle.msm(cv, b"".join(s.to_bytes(32, "little") for s in folded), base)
+        eng.profile_enable(True)
+        got = t.msm(1, K, b"".join(s.to_bytes(32, "little") for s in sc), pts)
+        rep = eng.profile_report()
+        eng.profile_enable(False)
+        assert got == want, K
+        assert "k_bucket_msm" in rep, K
+    t.close()
+    eng.close()
