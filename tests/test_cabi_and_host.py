@@ -509,6 +509,16 @@ def test_bucket_msm_edge_scalars_under_emulation(emu, coracle):
         assert got[64 * i:64 * (i + 1)] == coracle.msm(cvn, many[32 * K * i:32 * K * (i + 1)], bytes(pts)), i
     with pytest.raises(Exception):
         t.set_bucket_bits(12)
+    # the width the engine picks by size: 9 bits from 6 000 terms, 10 from 12 000 (the points repeat: the oracle folds the scalars)
+    t.set_bucket_bits(0)
+    base = bytes(pts)
+    for big in (6100, 12100):
+        scs = [random.randrange(q) for _ in range(big)]
+        folded = [0] * K
+        for i, s_ in enumerate(scs):
+            folded[i % K] = (folded[i % K] + s_) % q
+        got = t.msm(1, big, b"".join(s_.to_bytes(32, "little") for s_ in scs), (base * (big // K + 1))[:64 * big])
+        assert got == coracle.msm(cvn, b"".join(s_.to_bytes(32, "little") for s_ in folded), base), big
 
 
 @pytest.mark.parametrize("name", ["shuffle_stark_m3_n4_s11.json", "shuffle_stark_m4_n13_s9.json", "shuffle_secp256k1_m3_n3_s5.json"])
