@@ -58,7 +58,7 @@ typedef struct mp_table mp_table;   /* shared parameters + shared key of one car
 
 /* ---- context ---------------------------------------------------------------------------------------- */
 int mp_ctx_create(int curve_id, int device, mp_ctx** out);
-void mp_ctx_destroy(mp_ctx* ctx);
+void mp_ctx_destroy(mp_ctx* ctx);                 /* tables of the context that are still alive keep it alive: it goes with the last of them */
 const char* mp_last_error(void);                 /* thread-local text of the last error */
 const char* mp_check_name(int code);             /* "Ok", "Hadamard Product (5.1)", ... */
 size_t mp_proof_size(uint32_t m, uint32_t n);    /* (11m+8) points + (5n+9) scalars, 64-byte points (the 256-bit curves) */
@@ -221,11 +221,21 @@ int mp_set_merged_verify(mp_table* t, int on);
  * brings 4N + 11m + 8 points, so 128 proofs of a 52-card deck, 8 of a 1 024-card one -- but a batch takes no fewer than 2/13 `min_batch`
  * groups (945: a dozen windows for each of the kernel's 2 048 persistent waves), i.e. 16 proofs per group at 16 384 in flight.  The group
  * size is the divisor of the batch size nearest to that (between half and twice it; a batch without one keeps the per-proof screen).  A
- * batch in which some group fails is re-evaluated equation by equation: status words are identical to every other strategy.
+ * group whose equation fails is looked at more closely -- ITS members only (below): status words are identical to every other strategy.
  * points_per_group = 0 switches it off.  Needs merged verification on.  mp_group_size: the group size a batch of B proofs takes under the
  * table's own key (0: per-proof screen). */
 int mp_set_group_verify(mp_table* t, uint32_t points_per_group, size_t min_batch);
 uint32_t mp_group_size(const mp_table* t, size_t B);
+/* What a rejected proof costs (round 5).  A screen that fails -- the merged equation of one proof, the equation of a group of proofs,
+ * of a chain -- names the proofs it could not clear; only THEY are looked at again: their inputs are gathered into a contiguous
+ * sub-batch on the device, the sub-batch takes the next finer pass and its status words are written back over the screen's marks.
+ * Everybody else's verdict stands, as in the reference, where one call verifies one proof [REF src/discrete_log_cards/mod.rs:420-443].
+ * The members of failing groups go through equations of sub-groups of `points_per_subgroup` points (0 = default: an eighth of the group
+ * equation's -- 16 proofs of a 52-card deck) when there are at least `min_subgroups` of them (0 = default 128: enough to fill the bucket
+ * kernel), otherwise -- and the members of failing sub-groups always -- through the per-equation pass that names the first failing
+ * check.  mp_reverified_count: proofs that have taken a per-equation pass on this table because a screen could not clear them. */
+int mp_set_group_refine(mp_table* t, uint32_t points_per_subgroup, uint32_t min_subgroups);
+uint64_t mp_reverified_count(const mp_table* t);
 /* Variable-base MSMs with at least `terms` terms (default 2048: the verifier's products over a 1024-card deck) run on the
  * wave-cooperative bucket-method kernel (counting sort by wavefront prefix sum, balanced bucket shares, wave-wide bucket reduction),
  * smaller ones on the Straus kernel with per-proof window tables; 0 = never.  Results are identical; the split is a property of
@@ -236,7 +246,7 @@ int mp_set_bucket_min(mp_table* t, size_t terms);
  * proofs, mp_set_group_verify --, 11 from there on).  Results are identical; rebuilds the static plans like mp_set_bucket_min. */
 int mp_set_bucket_bits(mp_table* t, uint32_t bits);
 /* Chain verification (mp_verify_shuffle_chain*): at most `links` links share one chain equation; longer chains are verified as
- * consecutive sub-chains.  0 (default) = as many as fit the 32 767 points of one equation (293 links of a 52-card deck).  A smaller
+ * consecutive sub-chains.  0 (default) = as many as fit the 32 767 points of one equation (293 links of a 52-card deck; one link of a deck too large for that gets an equation of up to 65 535 points).  A smaller
  * value bounds the work that is repeated link by link when a chain fails.  Verdicts are the same. */
 int mp_set_chain_max_links(mp_table* t, uint32_t links);
 /* Lanes per Fiat-Shamir transcript.  A proof's transcript is one BLAKE2s chain (13.6 KB of statement for a 52-card deck): 1 = one
@@ -321,7 +331,8 @@ int mp_deck_deserialize_dev(mp_ctx* ctx, size_t decks, size_t cards, const void*
 
 /* ---- measurement hooks ---------------------------------------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by HIP events on the context's stream;
- * mp_profile_report writes "name count total_ms\n" lines (and resets) -- bench.py's roofline source. */
+ * mp_profile_report writes "name count total_ms items\n" lines (and resets) -- bench.py's roofline source; items = threads launched (waves
+ * for the wave-cooperative kernels, (equation, window) items for k_bucket_msm), summed over the launches of that name. */
 int mp_profile_enable(mp_ctx* ctx, int on);
 int mp_profile_report(mp_ctx* ctx, char* buf, size_t buf_len);
 /* static work census of one prove / verify for this table: number of scalar*point terms and point operations */

@@ -16,7 +16,7 @@ MP_ERR_BAD_ENCODING, MP_ERR_BAD_PERMUTATION, MP_ERR_BAD_ARGUMENT, MP_ERR_NO_DEVI
 
 SYMBOLS = [
     "mp_ctx_create", "mp_ctx_destroy", "mp_last_error", "mp_check_name", "mp_proof_size", "mp_params_size",
-    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_set_subgroup_check", "mp_set_bucket_min", "mp_set_bucket_bits", "mp_set_chain_max_links", "mp_set_transcript_lanes", "mp_set_group_lanes", "mp_set_work_split", "mp_set_group_verify", "mp_group_size", "mp_set_pipeline", "mp_set_plan_params", "mp_set_plan_thresholds", "mp_set_toom_cook", "mp_host_alloc", "mp_host_free", "mp_set_io_chunk", "mp_shuffle_and_remask_batch_keys", "mp_table_create_params",
+    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_set_subgroup_check", "mp_set_bucket_min", "mp_set_bucket_bits", "mp_set_chain_max_links", "mp_set_transcript_lanes", "mp_set_group_lanes", "mp_set_work_split", "mp_set_group_verify", "mp_group_size", "mp_set_group_refine", "mp_reverified_count", "mp_set_pipeline", "mp_set_plan_params", "mp_set_plan_thresholds", "mp_set_toom_cook", "mp_host_alloc", "mp_host_free", "mp_set_io_chunk", "mp_shuffle_and_remask_batch_keys", "mp_table_create_params",
     "mp_verify_shuffle_batch_keys", "mp_shuffle_and_remask_batch_keys_dev", "mp_verify_shuffle_batch_keys_dev",
     "mp_keyset_create", "mp_keyset_destroy", "mp_keyset_size", "mp_shuffle_and_remask_batch_keyset_dev", "mp_verify_shuffle_batch_keyset_dev",
     "mp_setup", "mp_table_create", "mp_table_create_ex", "mp_table_window_bits", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
@@ -133,6 +133,9 @@ def bind(cdll):
     cdll.mp_set_group_verify.argtypes = [c.c_void_p, c.c_uint32, c.c_size_t]
     cdll.mp_group_size.argtypes = [c.c_void_p, c.c_size_t]
     cdll.mp_group_size.restype = c.c_uint32
+    cdll.mp_set_group_refine.argtypes = [c.c_void_p, c.c_uint32, c.c_uint32]
+    cdll.mp_reverified_count.argtypes = [c.c_void_p]
+    cdll.mp_reverified_count.restype = c.c_uint64
     cdll.mp_set_pipeline.argtypes = [c.c_void_p, c.c_int]
     cdll.mp_set_plan_params.argtypes = [c.c_void_p, c.c_int] + [c.c_uint32] * 5
     cdll.mp_set_plan_thresholds.argtypes = [c.c_void_p] + [c.c_size_t] * 5
@@ -364,9 +367,12 @@ class Engine:
         buf = ctypes.create_string_buffer(1 << 16)
         self._chk(self.lib.mp_profile_report(self.h, buf, len(buf)))
         out = {}
+        self.last_profile_items = {}      # name -> threads launched (waves / (equation, window) items for the wave kernels)
         for line in buf.value.decode().splitlines():
-            name, cnt, ms = line.split()
-            out[name] = (int(cnt), float(ms))
+            f = line.split()
+            out[f[0]] = (int(f[1]), float(f[2]))
+            if len(f) > 3:
+                self.last_profile_items[f[0]] = int(f[3])
         return out
 
 
@@ -590,7 +596,7 @@ class Table:
         self.eng._chk(self.lib.mp_set_bucket_min(self.h, terms))
 
     def set_bucket_bits(self, bits):
-        """window width of the bucket method: 8, 9, 10, or 0 = by the size of the MSM (default)"""
+        """window width of the bucket method: 8 .. 11, or 0 = by the size of the MSM (default: 11 from 40 000 terms on)"""
         self.eng._chk(self.lib.mp_set_bucket_bits(self.h, bits))
 
     def set_chain_max_links(self, links):
@@ -617,6 +623,15 @@ class Table:
         """screening pass of large batches: one equation of ~points_per_group points per group of proofs on the bucket kernel (a proof
         brings 4N + 11m + 8 points; 0 = off)"""
         self.eng._chk(self.lib.mp_set_group_verify(self.h, points_per_group, min_batch))
+
+    def set_group_refine(self, points_per_subgroup=0, min_subgroups=0):
+        """what a failing group costs: its members go through equations of sub-groups of ~points_per_subgroup points (0 = an eighth of
+        the group equation's) when there are at least min_subgroups of them (0 = 128), else straight to the per-equation pass"""
+        self.eng._chk(self.lib.mp_set_group_refine(self.h, points_per_subgroup, min_subgroups))
+
+    def reverified_count(self):
+        """proofs that have taken a per-equation pass on this table because a screen could not clear them"""
+        return int(self.lib.mp_reverified_count(self.h))
 
     def set_pipeline(self, depth=1):
         """depth >= 1: device-resident verify calls run on the context's second lane beside the next prove call and do not wait for

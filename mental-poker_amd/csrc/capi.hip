@@ -136,13 +136,22 @@ int mp_ctx_create(int curve_id, int device, mp_ctx** out) {
   return MP_OK;
   MP_CATCH
 }
-void mp_ctx_destroy(mp_ctx* ctx) {
-  if (!ctx) return;
+static void ctx_release(mp_ctx* ctx) {
   for (rt::Stream st : {ctx->stream, ctx->side, ctx->vstream, ctx->vside})      // (h2d / d2h are the verify lane's)
     if (st) rt::stream_destroy(st);
   for (rt::Event e : {ctx->ev_fork, ctx->ev_shuf, ctx->ev_tab, ctx->ev_vfork, ctx->ev_vshuf, ctx->ev_vtab, ctx->ev_vin})
     if (e) rt::event_destroy(e);
   delete ctx;
+}
+void mp_ctx_destroy(mp_ctx* ctx) {
+  if (!ctx) return;
+  // tables hold a pointer to their context (streams, events, the registry mp_sync walks): a context that still has tables is only
+  // marked and goes with the last of them (mp_table_destroy), so the two destroy calls may come in either order
+  if (!ctx->tables.empty()) {
+    ctx->dying = true;
+    return;
+  }
+  ctx_release(ctx);
 }
 int mp_setup(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out_params) {
   if (!ctx || !seed || !out_params || m < 2 || n < 2) return fail(MP_ERR_BAD_ARGUMENT, "mp_setup: bad argument");
@@ -181,14 +190,33 @@ int mp_table_create_ex(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* param
   if (m < 2 || n < 2 || (uint64_t)m * n > 4096) return fail(MP_ERR_BAD_ARGUMENT, "mp_table_create: need m >= 2, n >= 2, m*n <= 4096");
   MP_TRY
   rt::set_device(ctx->device);
-  if (fb_window_bits == 0) fb_window_bits = auto_window_bits(ctx->curve, n);
-  int rc;
+  const bool auto_bits = fb_window_bits == 0;
+  if (auto_bits) fb_window_bits = auto_window_bits(ctx->curve, n);
+  int rc = MP_OK;
   mp_table* t = nullptr;
-  switch (ctx->curve) {
-    case 0: t = make_table_Stark(ctx, m, n, params, shared_key, fb_window_bits, &rc); break;
-    case 1: t = make_table_Bn254(ctx, m, n, params, shared_key, fb_window_bits, &rc); break;
-    case 3: t = make_table_Bls12_377(ctx, m, n, params, shared_key, fb_window_bits, &rc); break;
-    default: t = make_table_Secp256k1(ctx, m, n, params, shared_key, fb_window_bits, &rc); break;
+  auto make = [&](uint32_t bits) {
+    switch (ctx->curve) {
+      case 0: return make_table_Stark(ctx, m, n, params, shared_key, bits, &rc);
+      case 1: return make_table_Bn254(ctx, m, n, params, shared_key, bits, &rc);
+      case 3: return make_table_Bls12_377(ctx, m, n, params, shared_key, bits, &rc);
+      default: return make_table_Secp256k1(ctx, m, n, params, shared_key, bits, &rc);
+    }
+  };
+  if (!auto_bits) {
+    t = make(fb_window_bits);
+  } else {
+    // the width was chosen from ONE snapshot of the free memory: other ranks / contexts on this GPU may have taken it since (the
+    // build needs ~3.3x the table for a moment).  A build that runs out of memory is retried with the next narrower windows
+    for (;;) {
+      try {
+        t = make(fb_window_bits);
+        break;
+      } catch (const std::exception&) {
+        rt::clear_error();
+        if (fb_window_bits <= 8) throw;
+        fb_window_bits = fb_window_bits > 20 ? 20 : (fb_window_bits > 16 ? 16 : 8);
+      }
+    }
   }
   if (rc != MP_OK) {
     delete t;
@@ -212,7 +240,8 @@ void mp_table_destroy(mp_table* t) {
     t->flush();
   } catch (...) {
   }
-  auto& reg = t->ctx->tables;
+  mp_ctx* ctx = t->ctx;
+  auto& reg = ctx->tables;
   reg.erase(std::remove(reg.begin(), reg.end(), t), reg.end());
   for (auto& st : t->io) {
     if (st.up) rt::event_destroy(st.up);
@@ -220,6 +249,7 @@ void mp_table_destroy(mp_table* t) {
     if (st.down) rt::event_destroy(st.down);
   }
   delete t;
+  if (ctx->dying && reg.empty()) ctx_release(ctx);      // mp_ctx_destroy came first
 }
 void* mp_host_alloc(size_t bytes) {
   try {
@@ -247,6 +277,13 @@ int mp_set_merged_verify(mp_table* t, int on) {
   t->set_merged_verify(on != 0);
   return MP_OK;
 }
+int mp_set_group_refine(mp_table* t, uint32_t points_per_subgroup, uint32_t min_subgroups) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_refine: null table");
+  if (points_per_subgroup > BUCKET_TERMS_MAX) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_refine: at most 65 535 points per equation");
+  t->set_group_refine(points_per_subgroup, min_subgroups);
+  return MP_OK;
+}
+uint64_t mp_reverified_count(const mp_table* t) { return t ? t->reverified() : 0; }
 int mp_set_bucket_min(mp_table* t, size_t terms) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_min: null table");
   MP_TRY
@@ -454,9 +491,11 @@ int mp_verify_shuffle_chain_dev(mp_table* t, size_t tables, uint32_t links, cons
   // verified as consecutive sub-chains (the decks array is link-major, so a sub-chain is a contiguous slice)
   const size_t per_link = (size_t)2 * t->N + 11 * t->m + 8, fixed_part = (size_t)2 * t->N + 1;
   const size_t pb = t->point_bytes, deck_bytes = (size_t)2 * t->N * pb, psz = proof_size_bytes(t->m, t->n, (uint32_t)pb);
-  // (one link always fits: 4N + 11m + 9 <= 32 767 for every table mp_table_create accepts, m n <= 4096)
-  if (fixed_part + per_link > 32767) return fail(MP_ERR_INTERNAL, "mp_verify_shuffle_chain_dev: deck too large for one chain equation");
-  uint32_t lmax = std::min<uint32_t>((uint32_t)((32767 - fixed_part) / per_link), 1022u);      // (links 0 .. L in 10 bits of a sorted entry: kernels_bucket.hpp)
+  // (one link does not always fit 32 767 points -- m = 2048, n = 2: 4N + 11m + 9 = 38 921 -- but it fits one bucket job: the kernel sorts
+  // up to BUCKET_TERMS_MAX = 65 535 points per window, and 4N + 11m + 9 <= 38 921 for every table mp_table_create accepts, m n <= 4096)
+  const size_t eq_cap = fixed_part + per_link > 32767 ? BUCKET_TERMS_MAX : 32767;
+  if (fixed_part + per_link > eq_cap) return fail(MP_ERR_INTERNAL, "mp_verify_shuffle_chain_dev: deck too large for one chain equation");
+  uint32_t lmax = std::min<uint32_t>((uint32_t)((eq_cap - fixed_part) / per_link), 1022u);      // (links 0 .. L in 10 bits of a sorted entry: kernels_bucket.hpp)
   if (t->chain_max_links) lmax = std::max(1u, std::min(lmax, t->chain_max_links));
   for (uint32_t j0 = 0; j0 < links; j0 += lmax) {
     const uint32_t lc = std::min(lmax, links - j0);

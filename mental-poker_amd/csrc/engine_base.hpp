@@ -62,6 +62,7 @@ struct Profiler {
   struct Rec {
     const char* name;
     rt::Event a, b;
+    uint64_t items;      // threads (waves, for the wave kernels) of the launch
   };
   std::vector<Rec> recs;
   std::vector<rt::Event> pool;
@@ -73,9 +74,9 @@ struct Profiler {
     }
     return rt::event_create();
   }
-  void begin(const char* name, rt::Stream s) {
+  void begin(const char* name, rt::Stream s, uint64_t items = 0) {
     if (!on) return;
-    Rec r{name, get(), get()};
+    Rec r{name, get(), get(), items};
     rt::event_record(r.a, s);
     recs.push_back(r);
   }
@@ -85,18 +86,20 @@ struct Profiler {
   }
   std::string report() {
     std::map<std::string, std::pair<long, double>> acc;
+    std::map<std::string, uint64_t> items;
     std::vector<std::string> order;
     for (auto& r : recs) {
       float ms = rt::event_ms(r.a, r.b);
       if (!acc.count(r.name)) order.push_back(r.name);
       acc[r.name].first += 1;
       acc[r.name].second += ms;
+      items[r.name] += r.items;
       pool.push_back(r.a);
       pool.push_back(r.b);
     }
     recs.clear();
     std::ostringstream os;
-    for (auto& k : order) os << k << " " << acc[k].first << " " << acc[k].second << "\n";
+    for (auto& k : order) os << k << " " << acc[k].first << " " << acc[k].second << " " << items[k] << "\n";
     return os.str();
   }
   ~Profiler() {
@@ -124,6 +127,7 @@ struct mp_ctx {
   mp::rt::Stream vstream{}, vside{};
   mp::rt::Event ev_vfork{}, ev_vshuf{}, ev_vtab{}, ev_vin{};
   std::vector<mp_table*> tables;      // the tables of this context (mp_sync completes their deferred verification passes)
+  bool dying = false;                 // mp_ctx_destroy was called while tables were alive: the last mp_table_destroy releases the context
   // square-root tables of the curve's base field for on-device point decompression (kernels_decompress.hpp), built on first use
   mp::DevBuf<uint32_t> sq_ghalf, sq_hh, sq_rr, sq_chain;
   uint32_t sq_geom[4] = {0, 0, 0, 0};     // S, w, k, bits of the fixed exponent; S = 0: not built yet
@@ -163,13 +167,13 @@ static const uint32_t PROVE_INIT_WAVE_MAX = 32768;      // (the kernel itself: 0
 static const uint32_t OVERLAP_MAX_BATCH = 32768;
 #define MP_WAVE_RUN(NAME, C, nwaves, lds_words, args)                             \
   do {                                                                            \
-    ctx->prof.begin(#NAME, ctx->stream);                                          \
+    ctx->prof.begin(#NAME, ctx->stream, (uint64_t)(nwaves));                      \
     MP_WAVE_LAUNCH(NAME, C, ctx->stream, (nwaves), (lds_words), (args));          \
     ctx->prof.end(ctx->stream);                                                   \
   } while (0)
 #define MP_RUN(NAME, C, nx, ny, args)                      \
   do {                                                     \
-    ctx->prof.begin(#NAME, ctx->stream);                   \
+    ctx->prof.begin(#NAME, ctx->stream, (uint64_t)(nx) * (ny)); \
     MP_LAUNCH(NAME, C, ctx->stream, (nx), (ny), (args));   \
     ctx->prof.end(ctx->stream);                            \
   } while (0)
@@ -217,6 +221,8 @@ struct mp_table {
   virtual void set_toom_cook(bool on) = 0;
   virtual void set_group_verify(uint32_t links, size_t min_batch) = 0;
   virtual uint32_t group_size_of(size_t B) const = 0;
+  virtual void set_group_refine(uint32_t points, uint32_t min_groups) = 0;
+  virtual uint64_t reverified() const = 0;
   virtual int set_plan_params(int plan, uint32_t fch, uint32_t vch, uint32_t grp, uint32_t nch, uint32_t vsp) = 0;
   virtual void set_plan_thresholds(size_t tiny, size_t small, size_t latency, size_t medium, size_t wide) = 0;
   // keys: nullptr = the table's own aggregate key; otherwise one wire point per proof (device memory).

@@ -189,6 +189,7 @@ struct Table : mp_table {
     build_plans(ps, false);
     psk_ready = false;
     chain.L = 0;
+    gplans.clear();
     rt::stream_sync(ctx->stream);
     return MP_OK;
   }
@@ -313,7 +314,7 @@ struct Table : mp_table {
     build_plans(ps, false);
     psk_ready = false;
     chain.L = 0;                     // (the chain and group equations are rebuilt with the new width on their next use)
-    gplan.L = 0;
+    gplans.clear();
     rt::stream_sync(ctx->stream);
   }
   uint32_t cur_table_group = TABLE_GROUP;
@@ -331,7 +332,18 @@ struct Table : mp_table {
     SubgroupArgs a{w.P.p, w.status.p, w.Bpad, first};
     MP_RUN(k_subgroup_check, C, B, count, a);
   }
-  DevBuf<uint32_t> vflag;      // [1] "some proof of the batch needs the per-equation pass"
+  DevBuf<uint32_t> vflag;      // [2] "some proof of the batch needs a closer look" (word 0: the caller's lane, word 1: the verify lane)
+  uint32_t* flag_word(bool vlane, rt::Stream s) {
+    if (!vflag.n) vflag.alloc(2, s);
+    rt::dzero(vflag.p + (vlane ? 1 : 0), 4, s);
+    return vflag.p + (vlane ? 1 : 0);
+  }
+  bool read_flag(bool vlane) {
+    uint32_t flag = 0;
+    rt::d2h(&flag, vflag.p + (vlane ? 1 : 0), 4, ctx->stream);
+    rt::stream_sync(ctx->stream);
+    return flag != 0;
+  }
   uint32_t nwin = 0;
   FbGeom fbg{8, 32, 255};
   uint32_t init_seed[8];
@@ -652,7 +664,7 @@ struct Table : mp_table {
     w.bk_timing.alloc((size_t)ctx->bucket_slots() * 8, s);
     ba.timing = w.bk_timing.p;
 #endif
-    ctx->prof.begin("k_bucket_msm", s);
+    ctx->prof.begin("k_bucket_msm", s, nitems);
     MP_WAVE_LAUNCH(k_bucket_msm, C, s, nslots, bk_lds_words(c, XyzzWords<C>::N), ba);
     ctx->prof.end(s);
 #ifdef MP_EXP_BK_TIMING     // experiment (tools/ab_build.py --units=curve_stark_msm.hip,curve_stark.hip): mean cycles per phase and wave
@@ -1043,13 +1055,21 @@ struct Table : mp_table {
     uint32_t* h_flag = nullptr;      // host address
     uint32_t* d_flag = nullptr;      // the same word as the device sees it
     rt::Event ev = nullptr;
+    uint32_t gl = 0;                 // > 0: the screen was the equation of groups of gl proofs; their verdicts:
+    uint32_t *h_gbad = nullptr, *d_gbad = nullptr;      // [gbad_cap] page-locked words the device writes directly (k_chain_verdict)
+    size_t gbad_cap = 0;
   };
   std::deque<Pending> pend;          // oldest first; at most `pipeline` of them stay unexamined when a verify call returns
   std::vector<Pending> pend_pool;    // flag words and events for reuse
   Workspace vws;                     // the verify lane's arenas (pipelined mode: a prove call uses `ws` at the same time)
+  static void release(Pending& p_) {
+    if (p_.ev) rt::event_destroy(p_.ev);
+    rt::host_free(p_.h_flag);
+    rt::host_free(p_.h_gbad);
+  }
   ~Table() {
-    for (auto* q : {&pend_pool}) for (auto& p_ : *q) { if (p_.ev) rt::event_destroy(p_.ev); rt::host_free(p_.h_flag); }
-    for (auto& p_ : pend) { if (p_.ev) rt::event_destroy(p_.ev); rt::host_free(p_.h_flag); }
+    for (auto& p_ : pend_pool) release(p_);
+    for (auto& p_ : pend) release(p_);
   }
   // one pass over a batch on the context's CURRENT lane: merged = the screening equation, else equation by equation
   void verify_pass(Workspace& w, const VArgs& v, bool merged, bool vlane, uint32_t* host_flag = nullptr) {
@@ -1119,11 +1139,7 @@ struct Table : mp_table {
     run_phase(ph, w, B, vtab_forked ? (PH_ALL & ~PH_TABLES) : PH_ALL);
     if (merged) {
       uint32_t* fl = host_flag;      // (already zero)
-      if (!fl) {
-        if (!vflag.n) vflag.alloc(1, s);
-        rt::dzero(vflag.p, 4, s);
-        fl = vflag.p;
-      }
+      if (!fl) fl = flag_word(vlane, s);
       VerdictMergedArgs a{w.J.p, w.direct.p, w.status.p, fl, w.Bpad, l.chk_merged};
       MP_RUN(k_verdict_merged, C, B, 1, a);
     } else {
@@ -1140,6 +1156,116 @@ struct Table : mp_table {
     const int plan = plan_of(B);
     return merged_verify && (plan != 3 || pick(B, keyed).vmph.n_b);
   }
+  // ---- round 5: a failing screen costs what the rejected proofs cost, not what the batch costs.  Every screen says WHICH proofs it
+  // could not clear -- k_verdict_merged marks them 1, k_chain_verdict writes one word per group / chain --, their inputs are gathered
+  // into a contiguous sub-batch (k_gather_rows), the sub-batch takes the next finer pass and its status words are scattered back:
+  //   level 0  the suspects of failing groups: equations of sub-groups an eighth the size (16 proofs of a 52-card deck) when there are
+  //            enough of them to fill the bucket kernel (>= 128 sub-groups), else straight to level 1;
+  //   level 1  equation by equation: the FIRST failing check by name, exactly as the reference reports it [REF tests.rs:223-225].
+  // Everybody else's verdict stands.  One tampered proof among 262 144 re-verifies 128 proofs, not 262 144.
+  struct SubBatch {
+    DevBuf<uint32_t> decks, shuf, proofs, keys, kidx, idx;
+    DevBuf<int32_t> status;
+  };
+  SubBatch sub[2][2];                 // [lane][level]
+  DevBuf<uint32_t> gbad[2];           // per-group verdicts of a group / chain pass on the caller's lane, on the verify lane
+  uint32_t refine_points = 0;         // points per sub-group equation (mp_set_group_refine; 0 = an eighth of the group equation's)
+  uint32_t refine_min = 128;          // fewer sub-groups than this: straight to the per-equation pass
+  uint64_t n_reverified = 0;          // proofs that went through a per-equation pass because a screen could not clear them
+  void set_group_refine(uint32_t points, uint32_t min_groups) override {
+    refine_points = points;
+    refine_min = min_groups ? min_groups : 128u;
+  }
+  uint64_t reverified() const override { return n_reverified; }
+  uint32_t subgroup_size(size_t nsub, bool keyed) const {
+    const uint32_t per = 4 * N + 11 * m + 8 + (keyed ? 1u : 0u);
+    if (!group_points || !merged_verify) return 0;
+    const uint32_t pts = refine_points ? refine_points : group_points / 8;
+    const uint32_t want = (uint32_t)std::min<uint64_t>((pts + per / 2) / per, 1023u);
+    if (want < 2 || (uint64_t)want * per + n + 5 > BUCKET_TERMS_MAX || nsub < (uint64_t)refine_min * want) return 0;
+    return want;
+  }
+  void gather_rows(const void* src, DevBuf<uint32_t>& dst, const uint32_t* d_idx, size_t rows, size_t row_bytes) {
+    const uint32_t words = (uint32_t)(row_bytes / 4);
+    dst.alloc(rows * words, ctx->stream, false);
+    const size_t slice = std::max<size_t>(1, ((size_t)1 << 30) / words);      // (thread index: 32 bits)
+    for (size_t r0 = 0; r0 < rows; r0 += slice) {
+      const size_t rc = std::min(slice, rows - r0);
+      GatherRowsArgs ga{reinterpret_cast<const uint32_t*>(src), dst.p + r0 * words, d_idx + r0, words};
+      MP_RUN(k_gather_rows, C, (uint32_t)(rc * words), 1, ga);
+    }
+  }
+  // the positions of the non-zero words among `count` device (or mapped host) words, on the context's current lane
+  void read_words(const void* d_words, size_t count, std::vector<uint32_t>& host) {
+    host.resize(count);
+    rt::d2h(host.data(), d_words, count * 4, ctx->stream);
+    rt::stream_sync(ctx->stream);
+  }
+  // members of the failing groups (lane of (member j, group t) = j T + t)
+  static void group_members(const uint32_t* bad, uint32_t T, uint32_t L, std::vector<uint32_t>& idx) {
+    idx.clear();
+    for (uint32_t t = 0; t < T; ++t)
+      if (bad[t])
+        for (uint32_t j = 0; j < L; ++j) idx.push_back(j * T + t);
+    std::sort(idx.begin(), idx.end());
+  }
+  // the proofs idx[] of batch v (ascending) through the finer passes; their status words replace the screen's marks
+  void verify_subset(const VArgs& v, std::vector<uint32_t>& idx, int level, bool vlane) {
+    if (idx.empty()) return;
+    const bool keyed = v.keys != nullptr || v.kset != nullptr;
+    rt::Stream s = ctx->stream;
+    const uint32_t L2 = level == 0 ? subgroup_size(idx.size(), keyed) : 0u;
+    if (!L2) level = 1;
+    if (level == 1 && idx.size() == v.B) {      // (everybody: no gather)
+      Workspace& w = vlane ? vws : ws;
+      reserve_ws(w, v.B, keyed);
+      n_reverified += v.B;
+      verify_pass(w, v, false, vlane);
+      return;
+    }
+    if (L2)
+      while (idx.size() % L2) idx.push_back(idx[0]);      // (a suspect twice: the same verdict written twice)
+    const uint32_t nsub = (uint32_t)idx.size();
+    SubBatch& sb = sub[vlane ? 1 : 0][level];
+    sb.idx.upload(idx, s);
+    gather_rows(v.decks, sb.decks, sb.idx.p, nsub, (size_t)2 * N * G_::PB);
+    gather_rows(v.shuf, sb.shuf, sb.idx.p, nsub, (size_t)2 * N * G_::PB);
+    gather_rows(v.proofs, sb.proofs, sb.idx.p, nsub, proof_size_bytes(m, n, G_::PB));
+    if (v.kset) gather_rows(v.kidx, sb.kidx, sb.idx.p, nsub, 4);
+    else if (v.keys) gather_rows(v.keys, sb.keys, sb.idx.p, nsub, G_::PB);
+    sb.status.alloc(nsub, s, false);
+    const VArgs sv{nsub, reinterpret_cast<const uint8_t*>(sb.decks.p), reinterpret_cast<const uint8_t*>(sb.shuf.p),
+                   reinterpret_cast<const uint8_t*>(sb.proofs.p), sb.status.p,
+                   v.keys && !v.kset ? reinterpret_cast<const uint8_t*>(sb.keys.p) : nullptr, v.kset, v.kset ? sb.kidx.p : nullptr};
+    if (L2) {
+      const uint32_t T2 = nsub / L2;
+      DevBuf<uint32_t>& gb = gbad[vlane ? 1 : 0];
+      gb.alloc(T2, s, false);
+      verify_group_pass(sv, L2, vlane, nullptr, gb.p);
+      if (read_flag(vlane)) {
+        std::vector<uint32_t> bad, idx2;
+        read_words(gb.p, T2, bad);
+        group_members(bad.data(), T2, L2, idx2);
+        verify_subset(sv, idx2, 1, vlane);
+      }
+    } else {
+      Workspace& w = vlane ? vws : ws;
+      reserve_ws(w, nsub, keyed);
+      n_reverified += nsub;
+      verify_pass(w, sv, false, vlane);
+    }
+    ScatterStatusArgs sa{sb.status.p, v.status, sb.idx.p};
+    MP_RUN(k_scatter_status, C, nsub, 1, sa);
+    rt::stream_sync(s);      // (idx[] was uploaded from pageable memory and sb is reused by the next failing batch)
+  }
+  // the proofs a per-proof screen marked (status word 1) through the per-equation pass
+  void refine_marked(const VArgs& v, bool vlane) {
+    std::vector<uint32_t> st, idx;
+    read_words(v.status, v.B, st);
+    for (uint32_t b = 0; b < v.B; ++b)
+      if ((int32_t)st[b] == 1) idx.push_back(b);
+    verify_subset(v, idx, 1, vlane);
+  }
   void verify_dev(size_t B_, const uint8_t* decks, const uint8_t* shuf, const uint8_t* proofs, int32_t* status,
                   const uint8_t* keys, const mp_keyset* kset, const uint32_t* kidx) override {
     const VArgs v{(uint32_t)B_, decks, shuf, proofs, status, keys, kset, kidx};
@@ -1149,12 +1275,13 @@ struct Table : mp_table {
     if (pipeline) {
       // Pipelined mode: the call runs on the verify lane with arenas of its own and does NOT wait for its screening verdict, so the
       // caller's next prove call overlaps it on the chip.  The verdict of call k is looked at when call k + 1 comes in (or at
-      // mp_sync); only then -- and only if some proof failed the screen -- does the per-equation pass run.
+      // mp_sync); only then -- and only for the proofs the screen could not clear -- do the finer passes run.
       resolve_pending((size_t)pipeline - 1);      // this call makes it `pipeline` unexamined ones
-      if (!gl) reserve_ws(vws, v.B, keyed);
       rt::event_record(ctx->ev_vin, ctx->stream);
       LaneSwap lane(ctx);
       rt::stream_wait(ctx->stream, ctx->ev_vin);
+      // (the verify lane's arenas are sized ON the verify lane: a zero-fill of theirs must queue behind the verify work in flight)
+      if (!gl) reserve_ws(vws, v.B, keyed);
       if (!gl && !screens(v.B, keyed)) {
         verify_pass(vws, v, false, true);
         return;
@@ -1170,34 +1297,42 @@ struct Table : mp_table {
         pn.ev = rt::event_create();
       }
       pn.v = v;
+      pn.gl = gl;
       *pn.h_flag = 0;
+      if (gl && pn.gbad_cap < v.B / gl) {
+        rt::host_free(pn.h_gbad);
+        pn.h_gbad = nullptr;
+        pn.gbad_cap = 0;
+        void* dp = nullptr;
+        pn.h_gbad = (uint32_t*)rt::host_alloc_mapped((size_t)(v.B / gl) * 4, &dp);
+        pn.d_gbad = (uint32_t*)dp;
+        pn.gbad_cap = v.B / gl;
+      }
       pend.push_back(pn);                   // (before the launches: an exception on the way still leaves the slot owned)
-      if (gl) verify_group_pass(v, gl, true, pn.d_flag);
+      if (gl) verify_group_pass(v, gl, true, pn.d_flag, pn.d_gbad);
       else verify_pass(vws, v, true, true, pn.d_flag);
       rt::event_record(pn.ev, ctx->stream);
       return;
     }
     if (gl) {
-      verify_group_pass(v, gl, false, nullptr);
-      uint32_t flag = 0;
-      rt::d2h(&flag, vflag.p, 4, ctx->stream);
-      rt::stream_sync(ctx->stream);
-      if (!flag) return;                    // every group's equation holds
-      reserve_for(v.B, keyed);
-      verify_pass(ws, v, false, false);     // some group failed: name the first failing check of every proof
+      const uint32_t T = v.B / gl;
+      gbad[0].alloc(T, ctx->stream, false);
+      verify_group_pass(v, gl, false, nullptr, gbad[0].p);
+      if (!read_flag(false)) return;        // every group's equation holds
+      std::vector<uint32_t> bad, idx;
+      read_words(gbad[0].p, T, bad);
+      group_members(bad.data(), T, gl, idx);
+      verify_subset(v, idx, 0, false);      // the members of the failing groups, nobody else
       return;
     }
     reserve_for(v.B, keyed);
-    // Two passes.  (1) Screening; every honest batch ends here.  (2) Only if some proof failed the screen: the equations one by one
-    for (int pass = screens(v.B, keyed) ? 0 : 1; pass < 2; ++pass) {
-      verify_pass(ws, v, pass == 0, false);
-      if (pass == 0) {
-        uint32_t flag = 0;
-        rt::d2h(&flag, vflag.p, 4, ctx->stream);
-        rt::stream_sync(ctx->stream);
-        if (!flag) break;       // nobody needs a closer look
-      }
+    // Two passes.  (1) Screening; every honest batch ends here.  (2) The proofs the screen marked, equation by equation
+    if (!screens(v.B, keyed)) {
+      verify_pass(ws, v, false, false);
+      return;
     }
+    verify_pass(ws, v, true, false);
+    if (read_flag(false)) refine_marked(v, false);
   }
   // look at the screening verdicts of all but the `keep` most recent pipelined verify calls
   void resolve_pending(size_t keep) {
@@ -1208,8 +1343,13 @@ struct Table : mp_table {
       rt::event_sync(pn.ev);
       if (!*pn.h_flag) continue;
       LaneSwap lane(ctx);
-      reserve_ws(vws, pn.v.B, pn.v.keys != nullptr || pn.v.kset != nullptr);
-      verify_pass(vws, pn.v, false, true);      // some proof failed the screen: name the first failing check of each
+      if (pn.gl) {
+        std::vector<uint32_t> idx;
+        group_members(pn.h_gbad, pn.v.B / pn.gl, pn.gl, idx);
+        verify_subset(pn.v, idx, 0, true);
+      } else {
+        refine_marked(pn.v, true);          // the proofs the screen marked: the first failing check of each
+      }
       rt::stream_sync(ctx->stream);
     }
   }
@@ -1334,22 +1474,18 @@ struct Table : mp_table {
     }
     CombineArgs cb{w.J.p, w.P.p, ph.cjobs.p, ph.cterms.p, w.Bpad};
     MP_RUN(k_combine, C, T, ph.n_c, cb);
-    if (!vflag.n) vflag.alloc(1, s);
-    rt::dzero(vflag.p, 4, s);
-    ChainVerdictArgs va{w.J.p, w.direct.p, w.status.p, vflag.p, w.Bpad, T, L, 0u, w.P.p, keyed ? l.pk : NO_SLOT};
+    gbad[0].alloc(T, s, false);
+    ChainVerdictArgs va{w.J.p, w.direct.p, w.status.p, flag_word(false, s), gbad[0].p, w.Bpad, T, L, 0u, w.P.p, keyed ? l.pk : NO_SLOT};
     MP_RUN(k_chain_verdict, C, T, 1, va);
-    uint32_t flag = 0;
-    rt::d2h(&flag, vflag.p, 4, s);
-    rt::stream_sync(s);
-    if (!flag) {
-      rt::dzero(status, (size_t)B * 4, s);           // every link of every table passed
-      return;
-    }
-    // some table failed: the per-link verifier gives every link its exact status
-    const size_t psz = proof_size_bytes(m, n, G_::PB);
-    for (uint32_t j = 0; j < L; ++j)
-      verify_dev(T, decks + (size_t)j * T * deck_bytes, decks + (size_t)(j + 1) * T * deck_bytes, proofs + (size_t)j * T * psz,
-                 status + (size_t)j * T, keyed ? keys + (size_t)j * T * G_::PB : nullptr, nullptr, nullptr);
+    rt::dzero(status, (size_t)B * 4, s);             // every link of every table whose chain equation holds has passed
+    if (!read_flag(false)) return;
+    // some table failed: the per-link verifier gives every link of THAT table its exact status (link j of table t: deck row j T + t,
+    // shuffled deck row (j + 1) T + t -- the same index into the array one deck further on); the other tables' verdicts stand
+    std::vector<uint32_t> bad, idx;
+    read_words(gbad[0].p, T, bad);
+    group_members(bad.data(), T, L, idx);
+    const VArgs cv{B, decks, decks + (size_t)T * deck_bytes, proofs, status, keys, nullptr, nullptr};
+    verify_subset(cv, idx, 0, false);
   }
 
   // ---------------------------------------------------------------- group verification (round 4)
@@ -1363,7 +1499,7 @@ struct Table : mp_table {
   // proofs)): an error in one proof cannot cancel against another's except with probability ~2^-250).  A batch in which some group
   // fails is re-verified equation by equation, so the status words are exactly those of the other paths.  Lane of (member j, group t)
   // = j T + t with T = B / L groups: the members of a group are T proofs apart.
-  ChainPlan gplan;
+  std::map<std::pair<uint32_t, bool>, std::unique_ptr<ChainPlan>> gplans;      // by (proofs per group, keyed): a failing batch alternates between two sizes
   Workspace gws;                      // lean workspace of the pipelined group pass: no window tables, no digit planes (68 KB per proof)
   // Group size: the wave-wide reduction of a window costs ~40 additions whatever the equation holds, and 10-bit windows (26 per scalar
   // instead of 32) want ~60 terms per bucket -- ~30 000 points per equation when the batch is large
@@ -1394,13 +1530,23 @@ struct Table : mp_table {
     for (uint32_t d = 0; d <= want; ++d)
       for (int sgn = 1; sgn >= -1; sgn -= 2) {
         const int64_t L = (int64_t)want + sgn * (int64_t)d;
-        if (L < 2 || 2 * L < (int64_t)want || L > 2 * (int64_t)want || (uint64_t)L * per > BUCKET_TERMS_MAX || L > 1023) continue;      // (10 bits of link in a sorted entry: kernels_bucket.hpp)
+        if (L < 2 || 2 * L < (int64_t)want || L > 2 * (int64_t)want || (uint64_t)L * per + n + 5 > BUCKET_TERMS_MAX || L > 1023) continue;      // (10 bits of link in a sorted entry: kernels_bucket.hpp)
         if (B % (uint32_t)L == 0) return (uint32_t)L;
       }
     return 0;
   }
-  void build_group_plan(uint32_t L, bool keyed) {
-    if (gplan.L == L && gplan.keyed == keyed) return;
+  ChainPlan& build_group_plan(uint32_t L, bool keyed) {
+    const std::pair<uint32_t, bool> key(L, keyed);
+    auto it = gplans.find(key);
+    if (it != gplans.end()) return *it->second;
+    if (gplans.size() >= 8) {      // (sizes come and go with the batch size: keep a handful)
+      rt::stream_sync(ctx->stream);
+      if (ctx->vstream) rt::stream_sync(ctx->vstream);
+      gplans.clear();
+    }
+    std::unique_ptr<ChainPlan>& fresh = gplans[key];
+    fresh.reset(new ChainPlan());
+    ChainPlan& gplan = *fresh;
     if (keyed) ensure_keyed();
     PlanSet& q = (keyed ? psk : ps)[0];
     const VerifyLay& l = q.vplan.lay;
@@ -1429,13 +1575,15 @@ struct Table : mp_table {
     gplan.nJ = next_partial;
     gplan.dev.upload(gplan.ph, ctx->stream);
     gplan.dterms.upload(gplan.cterms, ctx->stream);
+    return gplan;
   }
   // the group pass on the context's CURRENT lane; the flag word (host_flag, or vflag) is raised if some group needs a closer look
-  void verify_group_pass(const VArgs& v, uint32_t L, bool vlane, uint32_t* host_flag) {
+  // and gbad[t] says which (null: nobody asks)
+  void verify_group_pass(const VArgs& v, uint32_t L, bool vlane, uint32_t* host_flag, uint32_t* gbad_out) {
     const uint32_t B = v.B, T = B / L, Tpad = (T + 63u) & ~63u;
     const bool keyed = v.keys != nullptr || v.kset != nullptr;
     const uint8_t* keys = v.keys;
-    build_group_plan(L, keyed);
+    ChainPlan& gplan = build_group_plan(L, keyed);
     PlanSet& q = (keyed ? psk : ps)[0];
     const VerifyLay& l = q.vplan.lay;
     rt::Stream s = ctx->stream;
@@ -1489,12 +1637,8 @@ struct Table : mp_table {
     CombineArgs cb{w.J.p, w.P.p, ph.cjobs.p, ph.cterms.p, w.Bpad};
     MP_RUN(k_combine, C, T, ph.n_c, cb);
     uint32_t* fl = host_flag;
-    if (!fl) {
-      if (!vflag.n) vflag.alloc(1, s);
-      rt::dzero(vflag.p, 4, s);
-      fl = vflag.p;
-    }
-    ChainVerdictArgs va{w.J.p, w.direct.p, w.status.p, fl, w.Bpad, T, L, 0u, w.P.p, NO_SLOT};
+    if (!fl) fl = flag_word(vlane, s);
+    ChainVerdictArgs va{w.J.p, w.direct.p, w.status.p, fl, gbad_out, w.Bpad, T, L, 0u, w.P.p, NO_SLOT};
     MP_RUN(k_chain_verdict, C, T, 1, va);
     rt::d2d(v.status, w.status.p, (size_t)B * 4, s);      // zeros unless an input was refused (final if the flag stays down)
   }

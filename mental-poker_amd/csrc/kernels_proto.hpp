@@ -1256,6 +1256,7 @@ struct ChainVerdictArgs {
   const uint32_t* direct;
   int32_t* status;         // [L T] (lane order)
   uint32_t* flag;
+  uint32_t* gbad;          // [T] (may be null): 1 = this table / group needs a closer look -- only ITS members are re-verified (round 5)
   uint32_t Bpad, T, L, j_final;
   // keyed chains: the chain equation carries ONE key term per table (link 0's key with the summed key scalars of all links), which
   // is only the sum of the per-link equations if every link of the table was given the same key.  A table whose links name
@@ -1278,9 +1279,38 @@ MP_HD void body_chain_verdict(const ChainVerdictArgs& a, uint32_t t, uint32_t y)
       bad = bad || d != 0;
     }
   }
+  if (a.gbad) a.gbad[t] = bad ? 1u : 0u;
   if (bad) a.flag[0] = 1u;
 }
 MP_KERNEL(k_chain_verdict, ChainVerdictArgs, body_chain_verdict)
+
+// ---- re-verification of the proofs a screen could not clear (engine_core.hpp verify_subset, round 5): a failing screen -- the merged
+// equation of one proof, the equation of a group, of a chain -- says WHICH proofs need a closer look; their inputs are gathered into a
+// contiguous sub-batch, the sub-batch goes through the next finer pass, and its status words are scattered back.  Everybody else's
+// verdict stands: what a rejected proof costs does not depend on how many honest proofs shared its batch
+// [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:420-443: one call, one proof].
+struct GatherRowsArgs {
+  const uint32_t* src;     // rows of `words` 32-bit words
+  uint32_t* dst;           // dst row i = src row idx[i]
+  const uint32_t* idx;
+  uint32_t words;
+};
+template <class C>
+MP_HD void body_gather_rows(const GatherRowsArgs& a, uint32_t x, uint32_t y) {
+  const uint32_t row = x / a.words, c = x % a.words;
+  a.dst[(size_t)row * a.words + c] = a.src[(size_t)a.idx[row] * a.words + c];
+}
+MP_KERNEL(k_gather_rows, GatherRowsArgs, body_gather_rows)
+struct ScatterStatusArgs {
+  const int32_t* src;
+  int32_t* dst;            // dst[idx[i]] = src[i]
+  const uint32_t* idx;
+};
+template <class C>
+MP_HD void body_scatter_status(const ScatterStatusArgs& a, uint32_t i, uint32_t y) {
+  a.dst[a.idx[i]] = a.src[i];
+}
+MP_KERNEL(k_scatter_status, ScatterStatusArgs, body_scatter_status)
 
 #undef MP_LD
 #undef MP_ST

@@ -94,7 +94,7 @@ struct Phase {
   std::vector<BTermPos> bpos;
   uint32_t b_dig_bytes = 0;   // bucket digits (int16 each) per proof
   uint32_t b_kpad_max = 0;
-  uint32_t b_bits = 8;        // window width of the phase's bucket jobs (kernels_bucket.hpp: 8 .. 10)
+  uint32_t b_bits = 8;        // window width of the phase's bucket jobs (kernels_bucket.hpp: 8 .. 11)
 };
 
 static const size_t COMBINE_TREE_MIN = 12;

@@ -65,6 +65,7 @@ inline float event_ms(Event a, Event b) {
   return ms;
 }
 inline void launch_check(const char* name) { check(hipGetLastError(), name); }
+inline void clear_error() { (void)hipGetLastError(); }      // after a failed allocation that is going to be retried smaller
 inline void stream_wait(Stream s, Event e) { check(hipStreamWaitEvent(s, e, 0), "stream wait event"); }
 inline void event_sync(Event e) { check(hipEventSynchronize(e), "event sync"); }
 // page-locked host memory: DMA at PCIe speed and truly asynchronous copies (pageable buffers go through the runtime's

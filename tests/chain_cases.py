@@ -39,7 +39,9 @@ def run_chain_cases(eng, coracle, cvn, m, n, L, T, keyed):
     # break link 1 of table 0 (swap in another table's proof) and one deck point of the last link of table T-1
     bad = [row[:] for row in proofs]
     bad[1 % L][0] = proofs[1 % L][(0 + 1) % T]
+    looked = table.reverified_count()
     st = table.verify_shuffle_chain(T, L, decks, b"".join(b"".join(row) for row in bad), keys)
+    assert table.reverified_count() - looked == L      # (round 5) the L links of the failing table were looked at again, nobody else's
     exp = []
     for j in range(L):
         ks = b"".join(keys_t) if keyed else None

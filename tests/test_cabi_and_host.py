@@ -692,3 +692,79 @@ def test_emulated_group_verification(emu, coracle, cv, keyed):
     t.set_group_verify(30464, 6144)
     t.set_work_split(-1)
     t.close()
+
+
+def test_emulated_rejection_costs_only_the_rejected(emu, coracle):
+    """round 5: a failing screen re-verifies the proofs it could not clear and nobody else -- group -> sub-group -> per-equation pass,
+    the per-proof screen -> per-equation pass, waiting and pipelined (depth 3, batch sizes that alternate, so the verify lane's arenas
+    change their stride under calls in flight); status words as without any screen; the launch sizes say who was looked at"""
+    import ctypes
+    cv, m, n, B = "stark", 2, 3, 8
+    per = 4 * m * n + 11 * m + 8
+    eng = emu(cv)
+    ins = [coracle.gen_inputs(cv, m, n, 7300 + b) for b in range(B)]
+    g0 = ins[0]
+    t = eng.table(m, n, g0["params"], g0["pk"])
+    args = (b"".join(g["deck"] for g in ins), b"".join(g["rho"] for g in ins), [v for g in ins for v in g["perm"]],
+            b"".join(g["prover_seed"] for g in ins))
+    t.set_work_split(0)
+    t.set_group_verify(0, 0)
+    t.set_merged_verify(False)
+    out_d, out_p, st0 = t.shuffle_and_remask_batch(*args)
+    assert st0 == [0] * B
+    dsz, psz = len(g0["deck"]), t.proof_bytes
+    bad_p = bytearray(out_p)
+    bad_p[6 * psz - 31] ^= 2                               # proof 5: one bit of its last response scalar
+    bad_p = bytes(bad_p)
+    want = t.verify_shuffle_batch(args[0], out_d, bad_p)   # equation by equation, no screen at all
+    assert [w != 0 for w in want] == [b == 5 for b in range(B)]
+    assert coracle.verify_shuffle(cv, m, n, g0["params"], g0["pk"], ins[5]["deck"], out_d[5 * dsz:6 * dsz], bad_p[5 * psz:6 * psz]) == want[5]
+    t.set_merged_verify(True)
+
+    def looked_at(fn):
+        before = t.reverified_count()
+        eng.profile_enable(True)
+        got = fn()
+        rep = eng.profile_report()
+        eng.profile_enable(False)
+        return got, t.reverified_count() - before, rep, dict(eng.last_profile_items)
+
+    # (a) per-proof screen: only the marked proof takes the per-equation pass
+    got, n_re, rep, items = looked_at(lambda: t.verify_shuffle_batch(args[0], out_d, bad_p))
+    assert got == want and n_re == 1 and items["k_verdict"] == 1 and items["k_verdict_merged"] == B
+    got, n_re, rep, items = looked_at(lambda: t.verify_shuffle_batch(args[0], out_d, out_p))
+    assert got == [0] * B and n_re == 0 and "k_verdict" not in rep
+    # (b) groups of 4: the failing group's 4 members, straight to the equations (too few suspects for sub-groups)
+    t.set_group_verify(4 * per, 0)
+    assert t.group_size(B) == 4
+    got, n_re, rep, items = looked_at(lambda: t.verify_shuffle_batch(args[0], out_d, bad_p))
+    assert got == want and n_re == 4 and items["k_verdict"] == 4 and items["k_gather_rows"] > 0 and rep["k_bucket_msm"][0] == 1
+    # (c) ... through sub-groups of 2 first: the failing sub-group's 2 members reach the equations
+    t.set_group_refine(2 * per, 1)
+    got, n_re, rep, items = looked_at(lambda: t.verify_shuffle_batch(args[0], out_d, bad_p))
+    assert got == want and n_re == 2 and items["k_verdict"] == 2 and rep["k_bucket_msm"][0] == 2 and rep["k_chain_verdict"][0] == 2
+    # a bad point encoding in another group: that proof keeps its usage error, its group is looked at, the rest is not
+    bad_d = bytearray(out_d)
+    bad_d[2 * dsz + 5] ^= 1                                # (lane of (member j, group t) = 2 j + t: proof 2 is in group 0, proof 5 in group 1)
+    want2 = list(want)
+    want2[2] = t.verify_shuffle_batch(args[0][2 * dsz:3 * dsz], bytes(bad_d[2 * dsz:3 * dsz]), out_p[2 * psz:3 * psz])[0]
+    assert want2[2] < 0
+    got, n_re, rep, items = looked_at(lambda: t.verify_shuffle_batch(args[0], bytes(bad_d), bad_p))
+    assert got == want2 and n_re == 4                      # both groups fail; sub-groups {2, 6} and {1, 5} reach the equations
+    # (d) pipelined, depth 3, batch sizes 8 / 4 / 8 / 4 / 8 with the bad proof in the 8s
+    buf = lambda b: (ctypes.c_uint8 * len(b)).from_buffer_copy(b)
+    addr = ctypes.addressof
+    decks, good_d, good_p, badp = buf(args[0]), buf(out_d), buf(out_p), buf(bad_p)
+    t.set_pipeline(3)
+    calls = []
+    for k, (nb, pbuf) in enumerate(((8, badp), (4, good_p), (8, good_p), (4, badp), (8, badp))):
+        st = (ctypes.c_int32 * nb)(*([66] * nb))
+        calls.append((nb, pbuf is badp, st))
+        t.verify_shuffle_batch_dev(nb, addr(decks), addr(good_d), addr(pbuf), addr(st))
+    eng.sync()
+    for nb, bad, st in calls:
+        assert list(st) == (want[:nb] if bad else [0] * nb), (nb, bad, list(st))
+    t.set_pipeline(0)
+    # the two destroy calls in either order (the context goes with its last table)
+    eng.close()
+    t.close()

@@ -49,6 +49,7 @@ inline void event_record(Event e, Stream) {
 }
 inline float event_ms(Event a, Event b) { return (float)(*b - *a); }
 inline void launch_check(const char*) {}
+inline void clear_error() {}
 inline void stream_wait(Stream, Event) {}
 inline void event_sync(Event) {}
 inline void mem_info(size_t* free_b, size_t* total_b) { *free_b = *total_b = 0; }      // (auto-sized tables fall back to 8-bit windows)
