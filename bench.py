@@ -268,6 +268,9 @@ def main():
                          "(mp_*_batch_keys_dev); 0 = every proof under the table's own key")
     ap.add_argument("--bucket-min", type=int, default=None,
                     help="variable-base MSMs of at least this many terms run on the bucket-method kernel (engine default 2048; 0 = never)")
+    ap.add_argument("--bucket-bits", type=int, default=None, help="window width of the bucket method (8 .. 11; default: by the size of the MSM)")
+    ap.add_argument("--group-points", type=int, default=None,
+                    help="points per group equation of the verifier's screen (default 30464 = 128 proofs of a 52-card deck; 0 = per-proof screen)")
     ap.add_argument("--transcript-lanes", type=int, default=None, choices=[0, 1, 4],
                     help="lanes per Fiat-Shamir transcript hash (mp_set_transcript_lanes; default: by batch size)")
     ap.add_argument("--group-lanes", type=int, default=None, choices=[0, 1, 4],
@@ -371,6 +374,10 @@ def main():
             t.set_merged_verify(False)
         if args.bucket_min is not None:
             t.set_bucket_min(args.bucket_min)
+        if args.bucket_bits is not None:
+            t.set_bucket_bits(args.bucket_bits)
+        if args.group_points is not None:
+            t.set_group_verify(args.group_points, 6144)
         if args.transcript_lanes is not None:
             t.set_transcript_lanes(args.transcript_lanes)
         if args.work_split is not None:
@@ -690,6 +697,45 @@ def main():
             table.set_group_verify(0, 0)
             extras["per_proof_screen_value"] = timed_step(step)  # one merged equation per PROOF (Straus), the headline of rounds 1-3
             table.set_group_verify(30464, 6144)
+        # ---- what a rejected proof costs.  The same step with tampered proofs in the batch: the prover runs as in
+        # the timed region, one byte of the last response scalar of the chosen proofs is flipped in HBM, the verifier must reject exactly
+        # those (by the name of their first failing check) and accept the rest.  one_bad: 1 proof of the batch; pct1_bad: 1 % of it,
+        # evenly spread.  A failing group's members are looked at again, nobody else (mp_set_group_refine).
+        def rejection(Bc, nbad):
+            idx = (torch.arange(nbad, device=gpu, dtype=torch.int64) * (Bc // max(nbad, 1)) + (Bc // max(nbad, 1)) // 2)
+            od, op_, sv = out_sets[0]
+
+            def one():
+                table.shuffle_and_remask_batch_dev(Bc, decks.data_ptr(), factors.data_ptr(), perms.data_ptr(), seeds.data_ptr(),
+                                                   od.data_ptr(), op_.data_ptr(), st_p.data_ptr())
+                eng.sync()
+                op_[idx, proof_bytes - 31] ^= 2
+                torch.cuda.synchronize()
+                table.verify_shuffle_batch_dev(Bc, decks.data_ptr(), od.data_ptr(), op_.data_ptr(), sv.data_ptr())
+                eng.sync()
+            one()
+            looked = table.reverified_count()
+            reps = 1 if Bc >= 65536 else 8
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                one()
+            dt = time.perf_counter() - t1
+            looked = (table.reverified_count() - looked) // reps
+            want = torch.zeros(Bc, dtype=torch.bool, device=gpu)
+            want[idx] = True
+            assert torch.equal(sv[:Bc] != 0, want), "rejection: the verifier did not reject exactly the tampered proofs"
+            assert nbad == 0 or (int((sv[:Bc][idx] != sv[idx[0]]).sum().item()) == 0 and int(sv[idx[0]].item()) > 0)
+            return round(Bc * reps / dt, 1), int(looked)
+        if not args.pipeline:
+            for tag, Bc in (("", B), ("_16384", 16384)):
+                if Bc > B or (tag and Bc == B):
+                    continue
+                if tag:
+                    extras["none_bad%s_value" % tag] = rejection(Bc, 0)[0]      # the same calls, nobody tampered with: what the two below compare to
+                extras["one_bad%s_value" % tag], extras["one_bad%s_reverified" % tag] = rejection(Bc, 1)
+                extras["pct1_bad%s_value" % tag], extras["pct1_bad%s_reverified" % tag] = rejection(Bc, max(1, Bc // 100))
+            step()                                                # (the output buffers hold honest proofs again)
+            eng.sync()
         free_b, _ = torch.cuda.mem_get_info()
         if free_b > 40e9:
             k1000 = make_keys(1000, B)
@@ -999,6 +1045,28 @@ def main():
         "engine_src": src_hash,
     }
 
+    # one row per kernel that takes >= 3 % of the step: per-launch time, algorithmic bytes per launch and their fraction of the HBM peak,
+    # and -- from the PMC pass of THIS build at THIS configuration, if one is committed under profiles/ -- the VALU issue slots it used,
+    # its clock and the bytes the counters saw per launch
+    rows_k = []
+    for k_, (cnt_, ms_) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+        if ms_ < 0.03 * kernel_ms_total or not cnt_:
+            continue
+        ab = alg_bytes_per_proof(k_)
+        row = {"kernel": k_, "share": round(ms_ / kernel_ms_total, 4), "ms": round(ms_ / cnt_, 3), "launches_per_step": round(cnt_ / args.steps, 2),
+               "alg_bytes": None if ab is None else int(ab * total_proofs / world / cnt_),
+               "hbm_frac": None if ab is None else round(ab * total_proofs / world / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+               "valu_slots": None, "clock_mhz": None, "pmc_bytes": None}
+        e_ = (pmc or {}).get("kernels", {}).get(k_) if pmc else None
+        if e_:
+            row["valu_slots"] = e_.get("valu_slot_utilisation")
+            row["clock_mhz"] = e_.get("clock_mhz")
+            pb_ = e_.get("hbm_bytes_per_proof_per_step", e_.get("hbm_bytes_per_proof_per_step_corrected"))
+            row["pmc_bytes"] = None if pb_ is None else int(pb_ * (total_proofs / world) / cnt_)
+        rows_k.append(row)
+    roofline["kernels"] = rows_k
+    roofline["kernels_pmc_source"] = pmc_path if pmc else None
+
     # ---- CPU baseline: the oracle's C++ restatement (port), single thread, bounded sample
     cpu = None
     if not args.no_cpu_baseline:                  # rank 0 only (the other ranks have returned); N > 1 lines carry it too
@@ -1081,6 +1149,18 @@ def main():
               "per_rank_seconds": [round(r[2], 4) for r in rows],
               "parity_vs_oracle": parity}
     config.update(extras)
+    # flat scalars of the nested extras (a driver that keeps only scalar fields still sees them)
+    for Bh_, v_ in (extras.get("api_host_value") or {}).items():
+        tag_ = "" if int(Bh_) == min(B, 262144) else "_%s" % Bh_
+        config["api_host_pinned%s_value" % tag_] = v_["pinned"]
+        config["api_host_pageable%s_value" % tag_] = v_["pageable"]
+    for Bc_, v_ in (extras.get("batch_curve") or {}).items():
+        config["batch_%s_serial" % Bc_] = v_["serial"]
+        config["batch_%s_pipelined" % Bc_] = v_["pipelined"]
+    for r_ in rows_k[:4]:
+        config["%s_ms" % r_["kernel"]] = r_["ms"]
+        if r_["valu_slots"] is not None:
+            config["%s_valu_slots" % r_["kernel"]] = r_["valu_slots"]
     if digests is not None:
         config["digests"] = digests
     out = {

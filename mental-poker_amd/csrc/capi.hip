@@ -544,12 +544,17 @@ int mp_sync(mp_ctx* ctx) {
 // context's stream, chunk k+1 is uploaded on a second stream and the results of chunk k-1 are downloaded on a third
 // (PCIe is full duplex).  Staging buffers are persistent (two chunks in flight).  With page-locked caller buffers
 // (mp_host_alloc) every copy is an asynchronous DMA; with pageable buffers the runtime stages them and the overlap is partial.
-static const size_t IO_CHUNK = 65536;   // default proofs per chunk: the kernels need ~64 k lanes to run at full rate
+static const size_t IO_CHUNK = 65536;   // default proofs per chunk: the kernels need ~64 k lanes to run at full rate ...
+static const size_t IO_CHUNK_LARGE = 131072;   // ... and calls of 262 144 proofs or more take chunks of twice that (round 5: the copies are
+// hidden either way; what the chunked call loses against one batch is kernel efficiency -- 474 ms of kernels against 385 with 65 536-proof
+// chunks, profiles/r04_pcie_inclusive.txt -- the screen of a 131 072-proof chunk runs on groups of 128 proofs, that of 65 536 on groups of 64)
+static size_t io_chunk_of(const mp_table* t, size_t B) { return std::min(B, t->io_chunk ? t->io_chunk : (B >= 2 * IO_CHUNK_LARGE ? IO_CHUNK_LARGE : IO_CHUNK)); }
 // The chunks of one call: full chunks in the middle, a ramp of C/8 and 3C/8 at either end -- the first upload and the last download
 // are the only transfers nothing overlaps, so the first and the last chunk are small (262 144 proofs: 22 + 34 ms of exposed copies per
 // prove call with four equal chunks, 3 + 4 ms with the ramp, for ~15 ms of less efficient small-batch kernels).  Calls of less
-// than three chunks are cut evenly as before.
-static std::vector<size_t> io_schedule(size_t B, size_t C) {
+// than three chunks are cut evenly as before.  tail_ramp = false (verification: all that comes back is a status word per proof): no
+// ramp at the end, the remainder joins the last chunk's neighbours
+static std::vector<size_t> io_schedule(size_t B, size_t C, bool tail_ramp = true) {
   std::vector<size_t> v;
   if (B < 2 * C || C < 8) {
     for (size_t o = 0; o < B; o += C) v.push_back(std::min(C, B - o));
@@ -558,13 +563,17 @@ static std::vector<size_t> io_schedule(size_t B, size_t C) {
   const size_t r0 = C / 8, r1 = 3 * C / 8;
   v.push_back(r0);
   v.push_back(r1);
-  for (size_t left = B - 2 * (r0 + r1); left;) {
-    const size_t c = std::min(C, left);
-    v.push_back(c);
-    left -= c;
+  size_t left = B - (r0 + r1) * (tail_ramp ? 2 : 1);
+  // (a short remainder goes first: the last chunk of a verify call should be a full one, nothing of it is exposed)
+  if (left % C) {
+    v.push_back(left % C);
+    left -= left % C;
   }
-  v.push_back(r1);
-  v.push_back(r0);
+  for (; left; left -= C) v.push_back(C);
+  if (tail_ramp) {
+    v.push_back(r1);
+    v.push_back(r0);
+  }
   return v;
 }
 static void io_events(mp_io_stage& st) {
@@ -585,7 +594,7 @@ static int prove_batch_host(mp_table* t, size_t B, const uint8_t* keys, const ui
   rt::set_device(t->ctx->device);
   rt::Stream s = t->ctx->stream, up = t->ctx->h2d, down = t->ctx->d2h;
   const size_t N = t->N, psz = proof_size_bytes(t->m, t->n, t->point_bytes), dsz = N * 2 * t->point_bytes;
-  const size_t chunk = std::min(B, t->io_chunk ? t->io_chunk : IO_CHUNK);
+  const size_t chunk = io_chunk_of(t, B);
   const std::vector<size_t> sched = io_schedule(B, chunk);
   std::vector<size_t> first(sched.size() + 1, 0);
   for (size_t k = 0; k < sched.size(); ++k) first[k + 1] = first[k] + sched[k];
@@ -639,8 +648,8 @@ static int verify_batch_host(mp_table* t, size_t B, const uint8_t* keys, const u
   NoPipeline nopipe(t);
   rt::Stream s = t->ctx->stream, up = t->ctx->h2d, down = t->ctx->d2h;
   const size_t N = t->N, psz = proof_size_bytes(t->m, t->n, t->point_bytes), dsz = N * 2 * t->point_bytes;
-  const size_t chunk = std::min(B, t->io_chunk ? t->io_chunk : IO_CHUNK);
-  const std::vector<size_t> sched = io_schedule(B, chunk);
+  const size_t chunk = io_chunk_of(t, B);
+  const std::vector<size_t> sched = io_schedule(B, chunk, false);
   std::vector<size_t> first(sched.size() + 1, 0);
   for (size_t k = 0; k < sched.size(); ++k) first[k + 1] = first[k] + sched[k];
   const size_t nchunks = sched.size();

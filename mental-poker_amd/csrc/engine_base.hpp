@@ -134,11 +134,7 @@ struct mp_ctx {
   uint32_t sq_exp[12] = {0};
   mp::Profiler prof;
   // persistent waves of the bucket kernel (kernels_bucket.hpp): 8 per CU -- two workgroups of four, what its registers allow
-  uint32_t bk_slots = 0;
-  uint32_t bucket_slots() {
-    if (!bk_slots) bk_slots = 8u * mp::rt::cu_count();
-    return bk_slots;
-  }
+  uint32_t bk_slots = 0;              // (engine_core.hpp bucket_slots(): BK_WAVES_PER_CU x CUs, queried once)
 };
 namespace mp {
 // for the duration of a pipelined verify call the context's stream / side stream / events ARE the verify lane's

@@ -85,7 +85,7 @@ struct Workspace {
   void ensure_bucket(uint32_t nslots, uint32_t kpad_max, uint32_t bits, uint32_t xw, rt::Stream s) {
     bk_sorted.alloc((size_t)nslots * kpad_max, s, false);
     bk_park.alloc((size_t)nslots * bk_buckets(bits) * xw, s, false);
-    bk_counter.alloc(1, s);
+    bk_counter.alloc(8, s);
   }
   DevBuf<int32_t> status;
   // The arenas are slot-major with the lane stride Bpad.  Bpad follows the batch (B rounded up to a wave), whatever the arenas were
@@ -647,21 +647,27 @@ struct Table : mp_table {
   // the bucket method over a phase's large MSMs: digits, the persistent wave kernel (one wave per (equation, MSM, window) at a time),
   // the fold of the window results.  `count` equations -- proofs, or chain / group equations -- whose scalars lie in S with lane stride
   // sstride and whose digits go to D (dstride per equation)
+  uint32_t bucket_slots() {
+    if (!ctx->bk_slots) ctx->bk_slots = BK_WAVES_PER_CU * rt::cu_count();
+    return ctx->bk_slots;
+  }
+  // tile / tile_K: group verification -- the points of equation e as one contiguous run (k_group_tile), terms carry their index in it
   void run_bucket(Workspace& w, PhaseDev& ph, const uint32_t* S, uint32_t sstride, int16_t* D, size_t dstride, uint32_t count,
-                  uint32_t link_stride, const char* too_large) {
+                  uint32_t link_stride, const char* too_large, const uint32_t* tile = nullptr, uint32_t tile_K = 0) {
     rt::Stream s = ctx->stream;
     const uint32_t c = ph.b_bits, bw = bk_windows(R::BITS, c);
     // (the item counter runs past the last item by one draw per persistent wave)
-    if ((uint64_t)count * ph.n_bterms >= ((uint64_t)1 << 32) || (uint64_t)count * ph.n_b * bw + ctx->bucket_slots() >= ((uint64_t)1 << 32)) throw std::runtime_error(too_large);
+    if ((uint64_t)count * ph.n_bterms >= ((uint64_t)1 << 32) || (uint64_t)count * ph.n_b * bw + 8ull * bucket_slots() >= ((uint64_t)1 << 32)) throw std::runtime_error(too_large);
     BRecodeArgs ra{S, D, ph.bterms.p, ph.bpos.p, sstride, bw, ph.n_bterms, dstride, c};
     MP_RUN(k_bucket_recode, C, count * ph.n_bterms, 1, ra);
-    const uint32_t nitems = count * ph.n_b * bw, nslots = std::min(nitems, ctx->bucket_slots());
-    w.ensure_bucket(ctx->bucket_slots(), ph.b_kpad_max, c, XyzzWords<C>::N, s);
-    rt::dzero(w.bk_counter.p, 4, s);
+    const uint32_t nitems = count * ph.n_b * bw, nslots = std::min(nitems, bucket_slots());
+    w.ensure_bucket(bucket_slots(), ph.b_kpad_max, c, XyzzWords<C>::N, s);
+    rt::dzero(w.bk_counter.p, 8 * 4, s);
     BucketArgs ba{D, w.P.p, w.J.p, ph.bjobs.p, ph.bterms.p, w.Bpad, bw, ph.n_b, dstride, link_stride, c, nitems, nslots, w.bk_counter.p,
+                  count, bk_xcd_affine && count >= 8u ? 8u : 1u, tile, tile_K, bk_stage ? 1u : 0u,
                   w.bk_sorted.p, w.bk_park.p, ph.b_kpad_max, nullptr};
 #ifdef MP_EXP_BK_TIMING
-    w.bk_timing.alloc((size_t)ctx->bucket_slots() * 8, s);
+    w.bk_timing.alloc((size_t)bucket_slots() * 8, s);
     ba.timing = w.bk_timing.p;
 #endif
     ctx->prof.begin("k_bucket_msm", s, nitems);
@@ -1177,12 +1183,13 @@ struct Table : mp_table {
     refine_min = min_groups ? min_groups : 128u;
   }
   uint64_t reverified() const override { return n_reverified; }
-  uint32_t subgroup_size(size_t nsub, bool keyed) const {
+  // proofs per sub-group for the nsub suspects a screen with groups of l1 proofs left (l1 = 0: no groups above, e.g. a chain)
+  uint32_t subgroup_size(size_t nsub, bool keyed, uint32_t l1) const {
     const uint32_t per = 4 * N + 11 * m + 8 + (keyed ? 1u : 0u);
     if (!group_points || !merged_verify) return 0;
-    const uint32_t pts = refine_points ? refine_points : group_points / 8;
+    const uint32_t pts = refine_points ? refine_points : (l1 ? l1 * per : group_points) / 8;
     const uint32_t want = (uint32_t)std::min<uint64_t>((pts + per / 2) / per, 1023u);
-    if (want < 2 || (uint64_t)want * per + n + 5 > BUCKET_TERMS_MAX || nsub < (uint64_t)refine_min * want) return 0;
+    if (want < 2 || (l1 && want >= l1) || (uint64_t)want * per + n + 5 > BUCKET_TERMS_MAX || nsub < (uint64_t)refine_min * want) return 0;
     return want;
   }
   void gather_rows(const void* src, DevBuf<uint32_t>& dst, const uint32_t* d_idx, size_t rows, size_t row_bytes) {
@@ -1210,11 +1217,11 @@ struct Table : mp_table {
     std::sort(idx.begin(), idx.end());
   }
   // the proofs idx[] of batch v (ascending) through the finer passes; their status words replace the screen's marks
-  void verify_subset(const VArgs& v, std::vector<uint32_t>& idx, int level, bool vlane) {
+  void verify_subset(const VArgs& v, std::vector<uint32_t>& idx, int level, bool vlane, uint32_t l1 = 0) {
     if (idx.empty()) return;
     const bool keyed = v.keys != nullptr || v.kset != nullptr;
     rt::Stream s = ctx->stream;
-    const uint32_t L2 = level == 0 ? subgroup_size(idx.size(), keyed) : 0u;
+    const uint32_t L2 = level == 0 ? subgroup_size(idx.size(), keyed, l1) : 0u;
     if (!L2) level = 1;
     if (level == 1 && idx.size() == v.B) {      // (everybody: no gather)
       Workspace& w = vlane ? vws : ws;
@@ -1322,7 +1329,7 @@ struct Table : mp_table {
       std::vector<uint32_t> bad, idx;
       read_words(gbad[0].p, T, bad);
       group_members(bad.data(), T, gl, idx);
-      verify_subset(v, idx, 0, false);      // the members of the failing groups, nobody else
+      verify_subset(v, idx, 0, false, gl);  // the members of the failing groups, nobody else
       return;
     }
     reserve_for(v.B, keyed);
@@ -1346,7 +1353,7 @@ struct Table : mp_table {
       if (pn.gl) {
         std::vector<uint32_t> idx;
         group_members(pn.h_gbad, pn.v.B / pn.gl, pn.gl, idx);
-        verify_subset(pn.v, idx, 0, true);
+        verify_subset(pn.v, idx, 0, true, pn.gl);
       } else {
         refine_marked(pn.v, true);          // the proofs the screen marked: the first failing check of each
       }
@@ -1499,6 +1506,13 @@ struct Table : mp_table {
   // proofs)): an error in one proof cannot cancel against another's except with probability ~2^-250).  A batch in which some group
   // fails is re-verified equation by equation, so the status words are exactly those of the other paths.  Lane of (member j, group t)
   // = j T + t with T = B / L groups: the members of a group are T proofs apart.
+  // round 5, the bucket kernel's memory side (kernels_bucket.hpp): contiguous point runs per group, XCD-affine items, LDS-staged points
+  static bool exp_flag(const char* name, bool dflt) {      // (A/B hooks of the round: MP_BK_TILE / MP_BK_XCD / MP_BK_STAGE = 0 | 1)
+    const char* v = getenv(name);
+    return v && *v ? *v != '0' : dflt;
+  }
+  bool bk_tile = exp_flag("MP_BK_TILE", true), bk_xcd_affine = exp_flag("MP_BK_XCD", true), bk_stage = exp_flag("MP_BK_STAGE", true);
+  DevBuf<uint32_t> gtile[2];          // [lane] the group equations' point runs: T x K x 64 bytes (4 GB at 262 144 proofs of 52 cards)
   std::map<std::pair<uint32_t, bool>, std::unique_ptr<ChainPlan>> gplans;      // by (proofs per group, keyed): a failing batch alternates between two sizes
   Workspace gws;                      // lean workspace of the pipelined group pass: no window tables, no digit planes (68 KB per proof)
   // Group size: the wave-wide reduction of a window costs ~40 additions whatever the equation holds, and 10-bit windows (26 per scalar
@@ -1560,7 +1574,8 @@ struct Table : mp_table {
     pb.begin(0);
     for (uint32_t j = 0; j < L; ++j)
       for (uint32_t slot = 0; slot < l.pk + (keyed ? 1u : 0u); ++slot) {      // decks, proof points [, the proof's own key]
-        pb.var((uint32_t)gplan.cterms.size(), slot | (j << 20));
+        // (a term's point: its index in the group's contiguous run, or the P slot | member whose lane holds it)
+        pb.var((uint32_t)gplan.cterms.size(), bk_tile ? (uint32_t)gplan.cterms.size() : (slot | (j << 20)));
         gplan.cterms.push_back(ChainTerm{l.mvar + slot, j, 1, NO_SLOT});
       }
     gplan.K = (uint32_t)gplan.cterms.size();
@@ -1627,7 +1642,16 @@ struct Table : mp_table {
     ChainScalArgs ca{w.S.p, chain_cw.p, chain_cs.p, gplan.dterms.p, w.Bpad, Tpad, T};
     MP_RUN(k_chain_scalars, C, T, nterms, ca);
     PhaseDev& ph = gplan.dev;
-    run_bucket(w, ph, chain_cs.p, Tpad, chain_d8.p, (size_t)ph.b_dig_bytes, T, T, "group verification: too many groups for one launch");
+    const uint32_t* tile = nullptr;
+    if (bk_tile) {
+      const uint32_t per = l.pk + (keyed ? 1u : 0u);
+      DevBuf<uint32_t>& gt = gtile[vlane ? 1 : 0];
+      gt.alloc((size_t)T * gplan.K * G_::PW, s, false);
+      GroupTileArgs ta{w.P.p, gt.p, w.Bpad, T, per, gplan.K};
+      MP_RUN(k_group_tile, C, B, per, ta);
+      tile = gt.p;
+    }
+    run_bucket(w, ph, chain_cs.p, Tpad, chain_d8.p, (size_t)ph.b_dig_bytes, T, T, "group verification: too many groups for one launch", tile, gplan.K);
     FixedArgs fx{chain_cs.p, w.J.p, FB.p, ph.fjobs.p, ph.fterms.p, w.Bpad, fbg, Tpad};
     MP_RUN(k_fixed_msm, C, T, ph.n_f, fx);
     if (ph.n_c0) {

@@ -24,6 +24,11 @@
 //      -- a 6-step wavefront suffix scan, log2 NB doublings and a 6-step tree reduction of XYZZ points exchanged through LDS
 //      (13 + 2 NB - 3 point additions per window instead of the 2 x 2^(c-1) of the serial running sum).
 //
+// Round 5 (the kernel was at 0.855 of its issue slots with 3.7 TB/s of 64-byte gathers beside it): (1) the points of
+// a group equation are gathered ONCE into a contiguous run per equation (k_group_tile: 2 MB for 128 proofs of a 52-card deck, two points
+// per 128-byte line, one page instead of 238 x 128 pieces of a 4 GB arena) and the sorted entries index that run; (2) the (equation,
+// window) items are handed out XCD-affine -- one counter per XCD over whole equations, so that the 26 windows of an equation meet in ONE
+// L2; (3) the point of term i + 1 travels global -> LDS (global_load_lds_dwordx4, no registers) while term i is added.
 // The W window results of an MSM are folded (c doublings + 1 addition per window) by k_bucket_fold; its output slot joins
 // the MSM's other partial sums in k_combine exactly like a Straus sub-job's.  Per term and window this is one mixed
 // addition plus (load imbalance + the wave-wide additions of F) / terms-per-lane -- 26 to 33 windows instead of Straus' 51 and no
@@ -37,7 +42,11 @@
 namespace mp {
 
 static const uint32_t BK_BITS_MIN = 8, BK_BITS_MAX = 11;     // signed windows: digits in [-2^(c-1), 2^(c-1) - 1]
+#ifdef MP_EXP_BK_OCC
+static const uint32_t BK_WAVES_PER_CU = 4 * MP_EXP_BK_OCC;   // persistent waves: MP_EXP_BK_OCC workgroups of 4 per CU
+#else
 static const uint32_t BK_WAVES_PER_CU = 8;                   // persistent waves (MP_WAVE_KERNEL: 2 workgroups of 4 per CU)
+#endif
 static inline uint32_t bk_windows(int scalar_bits, uint32_t c) { return ((uint32_t)scalar_bits + c) / c; }
 MP_HD uint32_t bk_buckets(uint32_t c) { return 1u << (c - 1); }
 // window width for an MSM of K terms: the reduction F costs ~(20 + 4 NB) additions per window, a narrower window K / (c (c + 1)) more
@@ -95,7 +104,13 @@ struct BucketArgs {
   uint32_t link_stride;    // chain verification: term.b = P slot | link << 20, the point lives in lane b + link * link_stride
   uint32_t bits;           // window width c
   uint32_t nitems, nslots; // (proof, MSM, window) items for nslots persistent waves
-  uint32_t* counter;       // the next item to hand out (zero at launch)
+  uint32_t* counter;       // [8] the next item to hand out, per partition of the equations (zero at launch)
+  uint32_t count;          // equations (proofs, chains, groups)
+  uint32_t parts;          // 8: equation e belongs to XCD e mod 8 -- its windows are drawn by waves of that XCD first, so that its points
+                           // stay in ONE L2 (the L2s are per XCD); 1: one counter for everybody
+  const uint32_t* tile;    // group verification: the points of equation e as ONE contiguous run [e][term] (k_group_tile); a sorted
+  uint32_t tile_K;         // entry then is the term's index in the run instead of a P slot | link.  null: gather from the P arena
+  uint32_t stage;          // != 0: the point of term i + 1 travels global -> LDS while term i is added (pair mode)
   uint32_t* sorted;        // scratch [nslots][kpad_max]: the window's point references (term.b | sign << 31) sorted by bucket
   uint32_t* park;          // scratch [nslots][2^(c-1)][XYZZ words]: the bucket sums on their way to the lanes that reduce them
   uint32_t kpad_max;
@@ -154,10 +169,21 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
 #endif
   // (items are handed out by a counter, not dealt in advance: the windows of an MSM do not take the same time -- the top one is short --
   // and neither do the XCDs; with 2 048 x 256 items dealt in advance the last wave finished 15 % behind the average)
+  // XCD-affine since round 5: the equations are dealt to a.parts partitions (e mod parts), one counter each; a wave draws from the
+  // partition of its own XCD until that is empty and then helps the next one.  The windows of an equation are consecutive items of
+  // one partition: they run at about the same time on one XCD and find each other's points in its L2
+  const uint32_t per_eq = a.nwin * a.njobs;
+  uint32_t part = a.parts > 1 ? wv.xcd() % a.parts : 0u, tried = 0;
 #pragma unroll 1
-  for (uint32_t item = wv.next_item(a.counter); item < a.nitems; item = wv.next_item(a.counter)) {
+  for (;;) {
+    const uint32_t li = wv.next_item(a.counter + part);
+    if (li >= ((a.count + a.parts - 1u - part) / a.parts) * per_eq) {      // this partition is handed out: on to the next
+      if (++tried >= a.parts) break;
+      part = part + 1 == a.parts ? 0u : part + 1;
+      continue;
+    }
     MP_BK_T0();
-    const uint32_t w = item % a.nwin, jb = (item / a.nwin) % a.njobs, b = item / (a.nwin * a.njobs);
+    const uint32_t w = li % a.nwin, jb = (li / a.nwin) % a.njobs, b = (li / per_eq) * a.parts + part;
     const BJob job = a.jobs[jb];
     const uint32_t K = job.count, kpad = job.kpad;
     // (kpad and every offset in front of a window's digits are multiples of 64 digits: 16-byte loads of eight digits)
@@ -284,9 +310,13 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
       rem[lane] -= 1;
       return pos[lane] - 1;
     };
+    const uint32_t* const tile = a.tile ? a.tile + (size_t)b * a.tile_K * Geo<C>::PW : nullptr;
     auto point_of = [&](uint32_t e) -> const uint32_t* {
+      if (tile) return tile + (size_t)(e & 0xFFFFu) * Geo<C>::PW;
       return a.P + p_off<C>(e & BK_SLOT_MASK, a.Bpad, b + ((e >> 20) & BK_LINK_MASK) * a.link_stride);
     };
+    // pair mode: the exchange area is idle during the additions -- it stages the next point (4 KB of its 9)
+    const bool staged = a.stage != 0 && !balanced;
     // (acc is not needed while the pair-mode loop runs; the balanced walk keeps it in the lane's exchange slot in LDS -- 32 registers less
     // across the mixed addition)
     PerLane<Xyzz<C>> run;
@@ -320,6 +350,7 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
       nb0[lane] = 0;
       if (!balanced && n[lane] > 0)
         while (off[NB * cur[mseg[lane] * 64 + lane] + 2 + mseg[lane]] == off[NB * cur[mseg[lane] * 64 + lane] + 1 + mseg[lane]]) mseg[lane] += 1;
+      if (staged && n[lane] > 0) wv.template stage<Geo<C>::PW>(xch, point_of(e0[lane]), lane);
     });
     const uint32_t iters = wv.max(n);
     MP_BK_T(1);
@@ -346,7 +377,15 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
 #ifdef MP_EXP_BK_NOPOINT   // experiment: every point out of 256 cache-resident ones (wrong sums; how much of the kernel is memory latency)
           const Aff<C> q = ld_aff<C>(a.P + p_off<C>(e & 0xFFu, a.Bpad, b));
 #else
-          const Aff<C> q = ld_aff<C>(point_of(e));
+          Aff<C> q;
+          if (staged) {                                   // requested one addition ago: it has landed
+            uint32_t pw[Geo<C>::PW];
+            wv.template take<Geo<C>::PW>(xch, pw, lane);
+            q.x = fe_unpack<typename C::FqP>(pw);
+            q.y = fe_unpack<typename C::FqP>(pw + Geo<C>::FW);
+          } else {
+            q = ld_aff<C>(point_of(e));
+          }
 #endif
           // (the entry of term i + 2 is requested BEHIND the point of term i: loads come back in order, and the addition waits for its
           // point with this one still in flight)
@@ -356,6 +395,7 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
           uint32_t at = 0;
           if (i + 2 < n[lane]) at = advance(lane, i + 2, nb1[lane]);
           e1[lane] = ix[at];
+          if (staged && i + 1 < n[lane]) wv.template stage<Geo<C>::PW>(xch, point_of(e0[lane]), lane);      // the point of term i + 1
           xyzz_madd_signed_ip<C>(run[lane], q, (e >> 31) != 0);
         }
       });
@@ -431,7 +471,13 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
   });
 #endif
 }
-MP_WAVE_KERNEL(k_bucket_msm, BucketArgs, body_bucket_msm)
+// waves per SIMD the kernel is compiled for: 2 (256 registers); MP_EXP_BK_OCC=3 (168 registers) on the 256-bit curves is an A/B hook
+#ifdef MP_EXP_BK_OCC
+#define MP_BK_OCC(C) (Geo<C>::FW > 8 ? 2 : MP_EXP_BK_OCC)
+#else
+#define MP_BK_OCC(C) 2
+#endif
+MP_WAVE_KERNEL_OCC(k_bucket_msm, BucketArgs, body_bucket_msm, MP_BK_OCC(C))
 
 // ---- fold the window results: R = sum_w 2^(c w) R_w (x = proof, y = bucket job)
 // The same kernel folds the range sums of window-split Straus jobs (layout.hpp vsplit_lo; vb_nwin != 0): job.count parts, part w

@@ -1289,6 +1289,25 @@ MP_KERNEL(k_chain_verdict, ChainVerdictArgs, body_chain_verdict)
 // contiguous sub-batch, the sub-batch goes through the next finer pass, and its status words are scattered back.  Everybody else's
 // verdict stands: what a rejected proof costs does not depend on how many honest proofs shared its batch
 // [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:420-443: one call, one proof].
+// ---- group verification: the points of a group equation gathered ONCE into a contiguous run per group (round 5).  In the P arena the
+// 128 members of a group lie T lanes apart in each of 238 slots -- 30 464 pieces of 64 bytes scattered over 4 GB, each sharing its
+// 128-byte line with a stranger; the bucket kernel read every one of them 26 times (once per window), in bucket order.  As ONE run of
+// K x 64 bytes (2 MB) the lines are fully used, the run is a page or two, and the windows of the group find it in the L2 of their XCD.
+// x = proof lane b = j T + t, y = P slot; term index in the run = j `per` + slot (the order the group plan lists its points in)
+struct GroupTileArgs {
+  const uint32_t* P;
+  uint32_t* tile;          // [T][K][PW]
+  uint32_t Bpad, T, per, K;
+};
+template <class C>
+MP_HD void body_group_tile(const GroupTileArgs& a, uint32_t b, uint32_t y) {
+  const uint32_t t = b % a.T, j = b / a.T;
+  uint32_t w[Geo<C>::PW];
+  ld_words<Geo<C>::PW>(a.P + p_off<C>(y, a.Bpad, b), w);
+  st_words<Geo<C>::PW>(a.tile + ((size_t)t * a.K + (size_t)j * a.per + y) * Geo<C>::PW, w);
+}
+MP_KERNEL(k_group_tile, GroupTileArgs, body_group_tile)
+
 struct GatherRowsArgs {
   const uint32_t* src;     // rows of `words` 32-bit words
   uint32_t* dst;           // dst row i = src row idx[i]

@@ -202,6 +202,28 @@ struct WaveCtx {
     if (lane == 0) v = atomicAdd(counter, 1u);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
   }
+  // the XCD this wave runs on (0 .. 7; each XCD has an L2 of its own): hwreg(HW_REG_XCC_ID, 0, 4)
+  __device__ __forceinline__ uint32_t xcd() const { return (uint32_t)__builtin_amdgcn_s_getreg(6164) & 7u; }
+  // Asynchronous gather into LDS: N words (a multiple of 4) per lane from global memory straight into this wave's staging area, no
+  // registers in between (global_load_lds_dwordx4: the 16-byte chunk c of lane l lands at area[c * 256 + 4 l]); take() reads a lane's
+  // words back.  What was read from the area before must have arrived (LGKM) before the next stage() may overwrite it.
+  template <int N>
+  __device__ __forceinline__ void stage(uint32_t* area, const uint32_t* g, uint32_t) {
+    static_assert(N % 4 == 0, "whole 16-byte chunks");
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the previous take() has its data
+#pragma unroll
+    for (int c = 0; c < N / 4; ++c)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 4 * c),
+                                       (__attribute__((address_space(3))) void*)(area + c * 256), 16, 0, 0);
+  }
+  template <int N>
+  __device__ __forceinline__ void take(const uint32_t* area, uint32_t* w, uint32_t) const {
+#pragma unroll
+    for (int c = 0; c < N / 4; ++c) {
+      const uint4 t = *reinterpret_cast<const uint4*>(area + c * 256 + 4 * lane);
+      w[4 * c] = t.x; w[4 * c + 1] = t.y; w[4 * c + 2] = t.z; w[4 * c + 3] = t.w;
+    }
+  }
   // global-memory words written by any lane of the wave before are visible to every lane of the wave afterwards
   __device__ __forceinline__ void sync_global() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -211,9 +233,10 @@ struct WaveCtx {
 };
 }  // namespace mp
 // a workgroup holds up to 4 waves (= 4 independent work items); `lds_words` 32-bit words of dynamic LDS per wave
-#define MP_WAVE_KERNEL(NAME, ARGS, BODY)                                                       \
+#define MP_WAVE_KERNEL(NAME, ARGS, BODY) MP_WAVE_KERNEL_OCC(NAME, ARGS, BODY, 2)
+#define MP_WAVE_KERNEL_OCC(NAME, ARGS, BODY, WAVES)                                            \
   template <class C>                                                                           \
-  MP_GLOBAL void __launch_bounds__(256, 2) NAME(ARGS a, uint32_t nwaves, uint32_t lds_words) { \
+  MP_GLOBAL void __launch_bounds__(256, WAVES) NAME(ARGS a, uint32_t nwaves, uint32_t lds_words) { \
     extern __shared__ uint32_t mp_dyn_lds[];                                                   \
     const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                  \
     if (wid >= nwaves) return;                                                                 \

@@ -743,6 +743,14 @@ def test_emulated_rejection_costs_only_the_rejected(emu, coracle):
     t.set_group_refine(2 * per, 1)
     got, n_re, rep, items = looked_at(lambda: t.verify_shuffle_batch(args[0], out_d, bad_p))
     assert got == want and n_re == 2 and items["k_verdict"] == 2 and rep["k_bucket_msm"][0] == 2 and rep["k_chain_verdict"][0] == 2
+    # 16 proofs (the 8 twice) in 8 groups of 2: the (group, window) items of the bucket kernel are dealt to 8 partitions, one per XCD
+    t.set_group_verify(2 * per, 0)
+    t.set_group_refine(0, 0)
+    assert t.group_size(16) == 2
+    got, n_re, rep, items = looked_at(lambda: t.verify_shuffle_batch(args[0] * 2, out_d * 2, bad_p + out_p))
+    assert got == want + [0] * B and n_re == 2 and rep["k_group_tile"][0] == 1
+    t.set_group_verify(4 * per, 0)
+    t.set_group_refine(2 * per, 1)
     # a bad point encoding in another group: that proof keeps its usage error, its group is looked at, the rest is not
     bad_d = bytearray(out_d)
     bad_d[2 * dsz + 5] ^= 1                                # (lane of (member j, group t) = 2 j + t: proof 2 is in group 0, proof 5 in group 1)

@@ -107,3 +107,21 @@ def test_two_ranks_other_workloads(workload, extra, per_rank):
     assert d["config"]["per_rank_proofs"] == [per_rank, per_rank] and d["config"]["per_rank_failed"] == [0, 0]
     assert d["config"]["parity_vs_oracle"] is True
     assert d["cpu_baseline"] is not None and d["cpu_baseline"]["kind"] == "port" and d["roofline"]["kernel"].startswith("k_")
+
+
+def test_eight_ranks_weak_and_strong_equal_unsharded():
+    """the world size the driver will use: 8 self-launched ranks (all on the one GPU of the test box, collectives over gloo), weak
+    (192 proofs per rank) and strong (1 536 in total); every rank reports, every proof is accepted, and the concatenated digests are
+    those of ONE unsharded run of the same 1 536 proofs"""
+    env = {"MP_BENCH_FORCE_DEVICE": "0", "MP_BENCH_BACKEND": "gloo"}
+    weak = run_bench("--gpus", "8", "--batch", "192", *COMMON, env=env)
+    strong = run_bench("--gpus", "8", "--scaling", "strong", "--batch", "1536", *COMMON, env=env)
+    single = run_bench("--gpus", "1", "--batch", "1536", *COMMON)
+    for d, scaling in ((weak, "weak"), (strong, "strong")):
+        c = d["config"]
+        assert d["n_gpus"] == 8 and d["scaling"] == scaling and c["rccl_world"] == 8 and c["collective_backend"] == "gloo"
+        assert c["per_rank_proofs"] == [192] * 8 and c["per_rank_failed"] == [0] * 8 and len(c["per_rank_seconds"]) == 8
+        assert abs(d["value"] - 1536 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+        assert c["rccl_smoke"]["rccl_world"] == 8 and c["parity_vs_oracle"] is True
+        flat = [x for per_rank in c["digests"] for x in per_rank]
+        assert flat == single["config"]["digests"][0] and len(flat) == 8 and len(set(flat)) == 8

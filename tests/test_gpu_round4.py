@@ -357,11 +357,17 @@ def test_group_verification_status_words(mp, coracle, cv, m, n):
         t.set_group_verify(links * (4 * m * n + 11 * m + 8), 0)
         assert t.group_size(B) == expect_group
         eng.profile_enable(True)
-        got = {k: t.verify_shuffle_batch(args[0], d, p) for k, (d, p) in cases.items()}
+        got, looked = {}, {}
+        for k, (d, p) in cases.items():
+            before = t.reverified_count()
+            got[k] = t.verify_shuffle_batch(args[0], d, p)
+            looked[k] = t.reverified_count() - before
         rep = eng.profile_report()
         eng.profile_enable(False)
         assert got == want, links
         assert "k_chain_scalars" in rep and "k_bucket_msm" in rep
+        # (round 5) exactly the members of the failing groups took the per-equation pass: one group for one bad proof / one bad point
+        assert looked == {"good": 0, "badproof": expect_group, "badpoint": expect_group, "rotated": B}, (links, looked)
     t.set_group_verify(4 * (4 * m * n + 11 * m + 8), 60)    # batch below the minimum (60 x 52 / N proofs): per-proof screen
     assert t.group_size(B) == 0
     assert t.verify_shuffle_batch(args[0], out[0], out[1]) == [0] * B
@@ -424,11 +430,89 @@ def test_group_verification_at_full_size(mp, coracle):
         t.set_group_verify(*(cfg or (30464, 6144)))
         t.set_bucket_bits(9 if k == 3 else 0)
         sv.fill_(55)
+        before = t.reverified_count()
+        eng.profile_enable(True)
         t.verify_shuffle_batch_dev(B, decks.data_ptr(), od.data_ptr(), op.data_ptr(), sv.data_ptr())
         eng.sync()
+        rep = eng.profile_report()
+        eng.profile_enable(False)
         st = sv.cpu().tolist()
         assert [i for i, v in enumerate(st) if v] == [77, 4321], L
         assert eng.check_name(st[77]) == "Hadamard Product (5.1)" and st[4321] > 0
+        # (round 5) the two failing groups' members were looked at again -- 2 L proofs, not 8 192 (launch sizes of the per-equation pass)
+        assert t.reverified_count() - before == 2 * L and eng.last_profile_items["k_verdict"] == 2 * L, (L, eng.last_profile_items)
+        assert rep["k_bucket_msm"][0] == 1
+    # ... through sub-groups of 16 first when asked to (mp_set_group_refine): 2 x 16 proofs reach the equations
+    t.set_bucket_bits(0)
+    t.set_group_verify(30464, 0)
+    t.set_group_refine(16 * 238, 1)
+    before = t.reverified_count()
+    sv.fill_(55)
+    t.verify_shuffle_batch_dev(B, decks.data_ptr(), od.data_ptr(), op.data_ptr(), sv.data_ptr())
+    eng.sync()
+    assert [i for i, v in enumerate(sv.cpu().tolist()) if v] == [77, 4321] and t.reverified_count() - before == 32
+    # 1 % of the batch tampered, evenly spread (82 proofs, in most of the 64 groups): exactly those rejected; sub-groups by default
+    # (>= 128 of them), pipelined too
+    t.set_group_refine(0, 0)
+    t.shuffle_and_remask_batch_dev(B, decks.data_ptr(), rho.data_ptr(), perm.data_ptr(), seeds.data_ptr(), od.data_ptr(), op.data_ptr(), sp.data_ptr())
+    eng.sync()
+    idx = torch.arange(82, device=gpu) * 99 + 50
+    op[idx, t.proof_bytes - 31] ^= 2
+    want = torch.zeros(B, dtype=torch.bool, device=gpu)
+    want[idx] = True
+    for depth in (0, 2):
+        t.set_pipeline(depth)
+        before = t.reverified_count()
+        svs = [torch.full((B,), 55, dtype=torch.int32, device=gpu) for _ in range(3)]
+        for sv_ in svs:
+            t.verify_shuffle_batch_dev(B, decks.data_ptr(), od.data_ptr(), op.data_ptr(), sv_.data_ptr())
+        eng.sync()
+        for sv_ in svs:
+            assert torch.equal(sv_ != 0, want), depth
+        looked = (t.reverified_count() - before) // 3
+        assert 82 <= looked <= 82 * 16, (depth, looked)       # the members of the failing sub-groups of 16
+    t.set_pipeline(0)
+    t.close()
+    eng.close()
+
+
+def test_one_full_group_against_the_oracle(mp, coracle):
+    """the group screen at its production size against the ORACLE, not only against properties: 8 192 proofs of a 52-card deck in 64 groups of
+    128 (30 464 points per equation, 10-bit windows); the 128 members of one group -- one of them tampered -- are verified by the CPU oracle
+    proof by proof next to the engine's verdicts: same accept / reject, same check name"""
+    import torch
+    cv, m, n, B, L = "stark", 2, 26, 8192, 128
+    eng = mp._native.Engine(cv, 0)
+    g0 = coracle.gen_inputs(cv, m, n, 5950)
+    t = eng.table(m, n, g0["params"], g0["pk"], fb_bits=16)
+    t.set_group_verify(30464, 0)
+    assert t.group_size(B) == L
+    gpu = torch.device("cuda", 0)
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(11)
+    N = m * n
+    decks = torch.frombuffer(bytearray(g0["deck"]), dtype=torch.uint8).to(gpu).repeat(B, 1).contiguous()
+    rho = torch.randint(0, 256, (B, N, 32), dtype=torch.uint8, device=gpu, generator=gen)
+    rho[:, :, 31] &= 7
+    perm = torch.argsort(torch.rand(B, N, device=gpu, generator=gen), dim=1).to(torch.int32).contiguous()
+    seeds = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device=gpu, generator=gen)
+    od = torch.empty(B, len(g0["deck"]), dtype=torch.uint8, device=gpu)
+    op = torch.empty(B, t.proof_bytes, dtype=torch.uint8, device=gpu)
+    sp = torch.empty(B, dtype=torch.int32, device=gpu)
+    sv = torch.full((B,), 55, dtype=torch.int32, device=gpu)
+    t.shuffle_and_remask_batch_dev(B, decks.data_ptr(), rho.data_ptr(), perm.data_ptr(), seeds.data_ptr(), od.data_ptr(), op.data_ptr(), sp.data_ptr())
+    eng.sync()
+    T, grp = B // L, 13
+    members = [j * T + grp for j in range(L)]                # lane of (member j, group t) = j T + t
+    op[members[40], (11 * m + 8) * 64 + 10 * 32 + 2] ^= 1     # one byte of a response scalar of member 40 (a tampered POINT would be refused as an encoding error before any equation is looked at)
+    t.verify_shuffle_batch_dev(B, decks.data_ptr(), od.data_ptr(), op.data_ptr(), sv.data_ptr())
+    eng.sync()
+    st = sv.cpu().tolist()
+    assert int(sp.abs().sum().item()) == 0 and [i for i, v in enumerate(st) if v] == [members[40]]
+    deck_b = bytes(g0["deck"])
+    od_c, op_c = od[members].cpu().numpy(), op[members].cpu().numpy()
+    for k, b in enumerate(members):
+        assert coracle.verify_shuffle(cv, m, n, g0["params"], g0["pk"], deck_b, od_c[k].tobytes(), op_c[k].tobytes()) == st[b], (k, b)
     t.close()
     eng.close()
 

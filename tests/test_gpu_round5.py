@@ -1,0 +1,51 @@
+"""GPU tests of round 5 (run on the MI355X box): the `round` flow end to end [REF examples/round.rs:228-436], fixed-base tables sized
+under memory pressure (co-resident ranks), and the host-buffer entry points at their new chunking."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_round_example_runs_end_to_end():
+    """BASELINE config 1 as a script: 4 players, 52 cards, keygen + key proofs, aggregate key, masked deck, one shuffle per player (proved
+    and verified), one private card each opened with the others' reveal tokens -- four DISTINCT cards and `round ok`
+    [REF examples/round.rs:430-433]"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "round.py")], cwd=ROOT, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    text = out.stdout.decode()
+    holds = re.findall(r"^(\S+) holds the (.+)$", text, flags=re.M)
+    assert len(holds) == 4 and len({c for _, c in holds}) == 4 and len({p for p, _ in holds}) == 4, text
+    assert "4 shuffles proved and verified" in text and text.strip().endswith("round ok")
+
+
+def test_table_create_under_memory_pressure_takes_narrower_windows(mp, coracle):
+    """mp_table_create sizes the fixed-base windows by the free HBM; with most of the memory taken (8 ranks on one GPU, another context's
+    tables) it must come back with narrower windows -- and the same proofs -- instead of failing"""
+    import torch
+    cv, m, n = "stark", 2, 26
+    g = coracle.gen_inputs(cv, m, n, 8100)
+    eng = mp._native.Engine(cv, 0)
+    free_b, total_b = torch.cuda.mem_get_info(0)
+    wide = eng.table(m, n, g["params"], g["pk"])
+    bits_free = wide.fb_bits
+    wide.close()
+    torch.cuda.empty_cache()
+    free_b, _ = torch.cuda.mem_get_info(0)
+    hog = torch.empty(int(free_b * 0.86), dtype=torch.uint8, device="cuda:0")      # 86 % of what is free: < 41 GB left on a 288 GB part
+    t = eng.table(m, n, g["params"], g["pk"])
+    assert t.fb_bits < bits_free or bits_free == 8, (t.fb_bits, bits_free)
+    assert t.fb_bits in (8, 16, 20)
+    perm = list(g["perm"])
+    d, p, st = t.shuffle_and_remask_batch(g["deck"], g["rho"], perm, g["prover_seed"])
+    assert st == [0] and (d, p) == coracle.shuffle_and_remask(cv, m, n, g["params"], g["pk"], g["deck"], g["rho"], perm, g["prover_seed"])
+    assert t.verify_shuffle_batch(g["deck"], d, p) == [0]
+    del hog
+    t.close()
+    eng.close()

@@ -85,6 +85,18 @@ struct PerLane {
 };
 struct WaveCtx {
   uint32_t* lds;
+  uint32_t id = 0;      // index of the (emulated) persistent wave
+  uint32_t xcd() const { return id & 7u; }
+  template <int N>
+  void stage(uint32_t* area, const uint32_t* g, uint32_t lane) {
+    for (int c = 0; c < N / 4; ++c)
+      for (int i = 0; i < 4; ++i) area[c * 256 + 4 * lane + i] = g[4 * c + i];
+  }
+  template <int N>
+  void take(const uint32_t* area, uint32_t* w, uint32_t lane) const {
+    for (int c = 0; c < N / 4; ++c)
+      for (int i = 0; i < 4; ++i) w[4 * c + i] = area[c * 256 + 4 * lane + i];
+  }
   template <class Fn>
   void lanes(Fn f) {
     for (uint32_t l = 0; l < 64; ++l) f(l);
@@ -145,10 +157,11 @@ struct WaveCtx {
     _Pragma("omp parallel for schedule(dynamic, 1)")                       \
     for (uint32_t wid = 0; wid < nwaves; ++wid) {                          \
       std::vector<uint32_t> lds(lds_words);                                \
-      mp::WaveCtx wv{lds.data()};                                          \
+      mp::WaveCtx wv{lds.data(), wid};                                       \
       BODY<C>(a, wid, wv);                                                 \
     }                                                                      \
   }
+#define MP_WAVE_KERNEL_OCC(NAME, ARGS, BODY, WAVES) MP_WAVE_KERNEL(NAME, ARGS, BODY)
 #define MP_WAVE_KERNEL_INST(X, NAME, ARGS, C) X void NAME<C>(const ARGS&, uint32_t, uint32_t);
 #define MP_WAVE_LAUNCH(NAME, C, stream, nwaves, lds_words, args) NAME<C>((args), (uint32_t)(nwaves), (uint32_t)(lds_words))
 // explicit instantiation / extern declaration of kernel NAME for curve C (X = `template` or `extern template`)
