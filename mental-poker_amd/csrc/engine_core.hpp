@@ -14,7 +14,7 @@ static const uint32_t FCHUNK = 8;     // fixed-base terms per sub-job (8 x 13..3
 static const uint32_t VCHUNK = 64;    // variable-base terms per sub-job: the terms of a job share one 250-doubling chain
 static const uint32_t NORM_CHUNK = 64;   // points per Fermat inversion in k_normalize
 static const uint32_t BUCKET_MIN = 2048; // variable-base terms from which an MSM runs on the bucket kernel (kernels_bucket.hpp)
-static const uint32_t BUCKET_MIN_SMALL_BATCH = 128;   // ... in the plans for small batches (latency, not throughput)
+static const uint32_t BUCKET_MIN_SMALL_BATCH = 512;   // ... in the finest split (latency, not throughput): the merged equation of a 300-card proof (1 239 terms), not that of a 52-card one (239: Straus verifies one proof in 1.4 ms, the rebuilt bucket kernel in 1.6; profiles/r05d_latency.txt)
 
 struct PhaseDev {
   DevBuf<Term> recode, tables, fterms, vterms, cterms, cterms2, cterms0;
@@ -365,8 +365,9 @@ struct Table : mp_table {
       PlanSet& q = set[k];
       const PlanParams& pp = pprm[k];
       // the finest split serves batches too small to fill the chip with one lane per Straus job: there the bucket kernel
-      // (windows x 64 lanes per MSM) already pays from 128 terms on -- the merged verifier equation of a 52-card proof has 239
-      // (one proof: verify 4.4 -> 3.6 ms, profiles/r02_latency.txt).  The latency split had it too until the end of round 3: from ~1 000
+      // (windows x 64 lanes per MSM) pays from ~500 terms on -- the merged equation of a 300-card proof (1 239 terms), no longer that of a
+      // 52-card one (239: since the quad-lane Straus chains of round 3 and the kernel's rebuild in round 4, Straus verifies one proof in 1.4 ms,
+      // the bucket kernel in 1.6, 64 proofs in 1.7 against 2.1; profiles/r05d_latency.txt).  The latency split had it too until the end of round 3: from ~1 000
       // proofs on the fixed 14-addition reduction per window is 3x the work of Straus (2 048 proofs: 164 k -> 184 k/s without it)
       const uint32_t bmin = (bucket_min && k == 3) ? std::min(bucket_min, BUCKET_MIN_SMALL_BATCH) : bucket_min;
       // Toom-Cook adds two dependent stages (operand evaluation, interpolation): a win when the batch fills the chip (throughput and

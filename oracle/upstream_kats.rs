@@ -2,7 +2,7 @@
 //! geometryresearch/proof-toolbox drops it into the REFERENCE crate to settle, in one run, every arkworks / proof-toolbox convention this
 //! build restates from memory (oracle/README.md rows 1-9) and whether upstream's prover reproduces this build's golden proof.
 //!   cp oracle/upstream_kats.rs <ref>/barnett-smart-card-protocol/src/discrete_log_cards/upstream_kats.rs
-//!   cp tests/golden/{fs_kats,curve_kats,shuffle_stark_m2_n26_s7}.json <ref>/barnett-smart-card-protocol/src/discrete_log_cards/
+//!   cp tests/golden/{fs_kats,curve_kats,shuffle_stark_m2_n26_s7,shuffle_stark_m4_n13_s9,chain_stark_m2_n3_L3_s21}.json <ref>/barnett-smart-card-protocol/src/discrete_log_cards/
 //!   mod.rs: add `#[cfg(test)] mod upstream_kats;` next to `mod tests;` [REF mod.rs:27-31]
 //!   Cargo.toml [dev-dependencies]: serde_json = "1", hex = "0.4", rand_chacha = "0.3"
 //!   cargo test --release upstream_kats -- --nocapture --test-threads 1
@@ -107,33 +107,66 @@ fn remask_known_answer() {
     assert_eq!(hex::encode([point_wire(&out.0), point_wire(&out.1)].concat()), r["out"].as_str().unwrap());
 }
 
-/// rows 4, 5, 6: upstream's prover on this build's golden inputs, prover randomness from ChaCha20Rng::from_seed(prover_seed).  Equal
-/// bytes => transcript order, draw order and proof contents agree and "parity unpinned" is lifted; unequal: both are printed
+fn table_params(raw: &[u8], m: usize, n: usize) -> Parameters<Curve> {
+    let pt = |i: usize| wire_point(&raw[64 * i..64 * (i + 1)]); // G | ck_0..ck_{n-1} | H | gen
+    let ck = pedersen::CommitKey::<Curve>::new((1..=n).map(pt).collect(), pt(n + 1));
+    Parameters::<Curve>::new(m, n, el_gamal::Parameters { generator: pt(0) }, ck, pt(n + 2)) // [REF mod.rs:37-61]
+}
+fn wire_deck(b: &[u8]) -> Vec<MaskedCard<Curve>> {
+    b.chunks(128).map(|c| el_gamal::Ciphertext(wire_point(&c[..64]), wire_point(&c[64..]))).collect()
+}
+fn deck_wire(d: &[MaskedCard<Curve>]) -> String {
+    hex::encode(d.iter().flat_map(|c| [point_wire(&c.0), point_wire(&c.1)].concat()).collect::<Vec<u8>>())
+}
+/// one shuffle_and_remask + verify_shuffle of upstream on fixture inputs [REF mod.rs:380-443]; prover randomness from
+/// ChaCha20Rng::from_seed(prover_seed).  Returns the re-encrypted deck (wire v1, hex) and upstream's proof
+fn upstream_link(pp: &Parameters<Curve>, pk: &Affine, deck: &[MaskedCard<Curve>], link: &Value) -> (String, ZKProofShuffle<Curve>) {
+    let rho: Vec<Fr> = unhex(&link["rho"]).chunks(32).map(Fr::from_le_bytes_mod_order).collect();
+    let perm: Vec<usize> = link["perm"].as_array().unwrap().iter().map(|v| v.as_u64().unwrap() as usize).collect();
+    let mut rng = ChaCha20Rng::from_seed(seed32(&unhex(&link["prover_seed"])));
+    let (shuffled, proof) = DLCards::<Curve>::shuffle_and_remask(&mut rng, pp, pk, &deck.to_vec(), &rho, &Permutation::from(&perm)).unwrap();
+    assert!(DLCards::<Curve>::verify_shuffle(pp, pk, &deck.to_vec(), &shuffled, &proof).is_ok());
+    (deck_wire(&shuffled), proof)
+}
+
+/// rows 4, 5, 6: upstream's prover on this build's golden inputs -- the headline shape (2, 26) and the reference's OWN test shape
+/// (4, 13) [REF tests.rs:178-179].  Equal bytes => transcript order, draw order and proof contents agree and "parity unpinned" is
+/// lifted; unequal: both are printed
 #[test]
 fn rows4_5_6_golden_proof() {
-    let g = fixture("shuffle_stark_m2_n26_s7.json");
+    for name in ["shuffle_stark_m2_n26_s7.json", "shuffle_stark_m4_n13_s9.json"] {
+        let g = fixture(name);
+        let (m, n) = (g["m"].as_u64().unwrap() as usize, g["n"].as_u64().unwrap() as usize);
+        let pp = table_params(&unhex(&g["params"]), m, n);
+        let pk = wire_point(&unhex(&g["pk"]));
+        let (got, proof) = upstream_link(&pp, &pk, &wire_deck(&unhex(&g["deck"])), &g);
+        assert_eq!(got, g["shuffled"].as_str().unwrap(), "{}: re-encrypted deck (must agree: SURVEY.md 8c4)", name);
+        // row 6: this build's grouping gives mp_serialized_proof_size(STARK, m, n); upstream's struct decides the real figure
+        println!("{}: proof.serialized_size() = {}", name, proof.serialized_size()); // [REF examples/parameter_selection.rs:95]
+        let mut bytes = Vec::new();
+        proof.serialize_uncompressed(&mut bytes).unwrap();
+        // wire v1 = every group element x || y uncompressed, every scalar 32 B LE, in the order of DESIGN.md section 2: project
+        // upstream's struct fields into that order once they are in front of you and compare with g["proof"]
+        println!("upstream proof (serialize_uncompressed, {} B): {}", bytes.len(), hex::encode(&bytes));
+        println!("this build's wire v1 proof ({} B): {}", g["proof"].as_str().unwrap().len() / 2, g["proof"].as_str().unwrap());
+    }
+}
+
+/// the chain fixture: one table, three dependent shuffles under one aggregate key, deck j + 1 = output of link j
+/// [REF examples/round.rs:268-350]; every deck of the chain must agree (the decks do not depend on the transcript)
+#[test]
+fn chain_fixture() {
+    let g = fixture("chain_stark_m2_n3_L3_s21.json");
     let (m, n) = (g["m"].as_u64().unwrap() as usize, g["n"].as_u64().unwrap() as usize);
-    let raw = unhex(&g["params"]); // G | ck_0..ck_{n-1} | H | gen
-    let pt = |i: usize| wire_point(&raw[64 * i..64 * (i + 1)]);
-    let ck = pedersen::CommitKey::<Curve>::new((1..=n).map(pt).collect(), pt(n + 1));
-    let pp = Parameters::<Curve>::new(m, n, el_gamal::Parameters { generator: pt(0) }, ck, pt(n + 2)); // [REF mod.rs:37-61]
+    let pp = table_params(&unhex(&g["params"]), m, n);
     let pk = wire_point(&unhex(&g["pk"]));
-    let deck: Vec<MaskedCard<Curve>> =
-        unhex(&g["deck"]).chunks(128).map(|c| el_gamal::Ciphertext(wire_point(&c[..64]), wire_point(&c[64..]))).collect();
-    let rho: Vec<Fr> = unhex(&g["rho"]).chunks(32).map(Fr::from_le_bytes_mod_order).collect();
-    let perm: Vec<usize> = g["perm"].as_array().unwrap().iter().map(|v| v.as_u64().unwrap() as usize).collect();
-    let mut rng = ChaCha20Rng::from_seed(seed32(&unhex(&g["prover_seed"])));
-    let (shuffled, proof) =
-        DLCards::<Curve>::shuffle_and_remask(&mut rng, &pp, &pk, &deck, &rho, &Permutation::from(&perm)).unwrap(); // [REF mod.rs:380-418]
-    let got: Vec<u8> = shuffled.iter().flat_map(|c| [point_wire(&c.0), point_wire(&c.1)].concat()).collect();
-    assert_eq!(hex::encode(&got), g["shuffled"].as_str().unwrap(), "re-encrypted deck (must agree: SURVEY.md 8c4)");
-    assert!(DLCards::<Curve>::verify_shuffle(&pp, &pk, &deck, &shuffled, &proof).is_ok()); // [REF mod.rs:420-443]
-    // row 6: this build's grouping gives mp_serialized_proof_size(STARK, 2, 26); upstream's struct decides the real figure
-    println!("proof.serialized_size() = {}", proof.serialized_size()); // [REF examples/parameter_selection.rs:95]
-    let mut bytes = Vec::new();
-    proof.serialize_uncompressed(&mut bytes).unwrap();
-    // wire v1 = every group element x || y uncompressed, every scalar 32 B LE, in the order of DESIGN.md section 2: project upstream's
-    // struct fields into that order once they are in front of you and compare with g["proof"]
-    println!("upstream proof (serialize_uncompressed, {} B): {}", bytes.len(), hex::encode(&bytes));
-    println!("this build's wire v1 proof ({} B): {}", g["proof"].as_str().unwrap().len() / 2, g["proof"].as_str().unwrap());
+    let mut deck = wire_deck(&unhex(&g["decks"][0]));
+    for (j, link) in g["chain"].as_array().unwrap().iter().enumerate() {
+        let (got, proof) = upstream_link(&pp, &pk, &deck, link);
+        assert_eq!(got, g["decks"][j + 1].as_str().unwrap(), "deck {} of the chain", j + 1);
+        let mut bytes = Vec::new();
+        proof.serialize_uncompressed(&mut bytes).unwrap();
+        println!("link {}: upstream {} | wire v1 {}", j, hex::encode(&bytes), link["proof"].as_str().unwrap());
+        deck = wire_deck(&hex::decode(&got).unwrap());
+    }
 }

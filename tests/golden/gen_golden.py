@@ -67,7 +67,29 @@ def _case_dict(curve, m, n, seed, pp, pk, deck, rho, perm, ps, sh, pf):
                 prover_seed=hx(ps), shuffled=hx(po.deck_to_bytes(sh)), proof=hx(po.proof_to_bytes(pf)))
 
 
+def chain_case(curve, m, n, L, seed):
+    """one card table's shuffle chain [REF examples/round.rs:268-350]: L dependent shuffles under ONE aggregate key, the deck of link
+    j + 1 is the output of link j; witness and prover seed of link j from gen_inputs(seed + 1 + j)"""
+    cv = po.CURVES[curve]
+    pp, pk, deck, _, _, _ = po.gen_inputs(cv, m, n, seed)
+    decks, links = [deck], []
+    for j in range(L):
+        _, _, _, rho, perm, ps = po.gen_inputs(cv, m, n, seed + 1 + j)
+        sh, pf = po.shuffle_and_remask(pp, pk, decks[-1], rho, perm, ps)
+        assert po.verify_shuffle(pp, pk, decks[-1], sh, pf) == 0
+        with po.curve_ctx(cv):
+            links.append(dict(rho=hx(b"".join(po.fe_bytes(r) for r in rho)), perm=perm, prover_seed=hx(ps), proof=hx(po.proof_to_bytes(pf))))
+        decks.append(sh)
+    with po.curve_ctx(cv):
+        return dict(curve=curve, m=m, n=n, links=L, seed=seed, params=hx(po.params_to_bytes(pp)), pk=hx(po.pt_wire(pk)),
+                    decks=[hx(po.deck_to_bytes(d)) for d in decks], chain=links)
+
+
 def main():
+    with open(os.path.join(HERE, "chain_stark_m2_n3_L3_s21.json"), "w") as f:
+        json.dump(chain_case("stark", 2, 3, 3, 21), f, indent=1)
+    if "--chain-only" in sys.argv:
+        return
     with open(os.path.join(HERE, "curve_kats.json"), "w") as f:
         json.dump(curve_kats(), f, indent=1)
     with open(os.path.join(HERE, "fs_kats.json"), "w") as f:

@@ -49,3 +49,28 @@ def test_table_create_under_memory_pressure_takes_narrower_windows(mp, coracle):
     del hog
     t.close()
     eng.close()
+
+
+def test_chain_fixture_on_the_hip_engine(mp):
+    """tests/golden/chain_stark_m2_n3_L3_s21.json (one table, three dependent shuffles, one key): the HIP engine proves every link byte
+    for byte, verifies the chain with ONE equation (mp_verify_shuffle_chain) and link by link; a chain whose middle proof is replaced is
+    rejected at exactly that link"""
+    from conftest import GOLDEN, load_json
+    g = load_json(os.path.join(GOLDEN, "chain_stark_m2_n3_L3_s21.json"))
+    cv, m, n, L = g["curve"], g["m"], g["n"], g["links"]
+    eng = mp._native.Engine(cv, 0)
+    t = eng.table(m, n, bytes.fromhex(g["params"]), bytes.fromhex(g["pk"]))
+    decks = [bytes.fromhex(d) for d in g["decks"]]
+    proofs = []
+    for j, link in enumerate(g["chain"]):
+        d, p, st = t.shuffle_and_remask_batch(decks[j], bytes.fromhex(link["rho"]), link["perm"], bytes.fromhex(link["prover_seed"]))
+        assert st == [0] and d == decks[j + 1] and p.hex() == link["proof"], j
+        assert t.verify_shuffle_batch(decks[j], d, p) == [0]
+        proofs.append(p)
+    assert t.verify_shuffle_chain(1, L, b"".join(decks), b"".join(proofs), None) == [0] * L
+    bad = list(proofs)
+    bad[1] = proofs[2]
+    st = t.verify_shuffle_chain(1, L, b"".join(decks), b"".join(bad), None)
+    assert st[0] == 0 and st[1] > 0 and st[2] == 0
+    t.close()
+    eng.close()

@@ -102,6 +102,22 @@ def test_c_oracle_matches_golden(coracle, path):
     assert coracle.CHECK_NAMES[rc] == "Hadamard Product (5.1)"
 
 
+def test_c_oracle_matches_the_chain_fixture(coracle):
+    """chain_stark_m2_n3_L3_s21.json: three dependent shuffles of one table under one key [REF examples/round.rs:268-350] -- the C++ restatement
+    reproduces every deck and proof of the Python oracle's chain and verifies every link"""
+    g = load_json(os.path.join(GOLDEN, "chain_stark_m2_n3_L3_s21.json"))
+    cv, m, n = g["curve"], g["m"], g["n"]
+    params, pk = bytes.fromhex(g["params"]), bytes.fromhex(g["pk"])
+    assert len(g["decks"]) == g["links"] + 1 == len(g["chain"]) + 1
+    for j, link in enumerate(g["chain"]):
+        deck = bytes.fromhex(g["decks"][j])
+        sh, pf = coracle.shuffle_and_remask(cv, m, n, params, pk, deck, bytes.fromhex(link["rho"]), link["perm"], bytes.fromhex(link["prover_seed"]))
+        assert sh.hex() == g["decks"][j + 1] and pf.hex() == link["proof"], j
+        assert coracle.verify_shuffle(cv, m, n, params, pk, deck, sh, pf) == 0
+        if j:       # a link verified against the wrong input deck (the chain's first) is rejected by name [REF tests.rs:213-226]
+            assert coracle.CHECK_NAMES[coracle.verify_shuffle(cv, m, n, params, pk, bytes.fromhex(g["decks"][0]), sh, pf)] == "Hadamard Product (5.1)"
+
+
 @pytest.mark.parametrize("name", ["shuffle_stark_m2_n3_s1.json", "shuffle_bn254_m2_n4_s3.json",
                                   "shuffle_secp256k1_m3_n3_s5.json", "shuffle_bls12_377_m2_n3_s13.json"])
 def test_python_oracle_matches_golden(name):

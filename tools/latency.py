@@ -10,8 +10,8 @@ m, n = 2, 26
 g = co.gen_inputs("stark", m, n, 7)
 eng = mp.Engine("stark", 0)
 t = eng.table(m, n, g["params"], g["pk"], fb_bits=16)
-for name, lb, bm, lanes in (("finest split, Straus only", 8192, 0, 0), ("finest split, one-lane transcripts", 8192, 2048, 1),
-                            ("finest split (default: bucket kernel from 128 terms, 4-lane transcripts)", 8192, 2048, 0),
+for name, lb, bm, lanes in (("finest split, Straus only (the default for 52 cards since round 5)", 8192, 2048, 0), ("finest split, one-lane transcripts", 8192, 2048, 1),
+                            ("finest split, bucket kernel from 128 terms (the default of rounds 2-4)", 8192, 128, 0),
                             ("throughput plan", 0, 2048, 0)):
     t.set_latency_batch(lb)
     t.set_bucket_min(bm)
