@@ -552,28 +552,47 @@ static size_t io_chunk_of(const mp_table* t, size_t B) { return std::min(B, t->i
 // The chunks of one call: full chunks in the middle, a ramp of C/8 and 3C/8 at either end -- the first upload and the last download
 // are the only transfers nothing overlaps, so the first and the last chunk are small (262 144 proofs: 22 + 34 ms of exposed copies per
 // prove call with four equal chunks, 3 + 4 ms with the ramp, for ~15 ms of less efficient small-batch kernels).  Calls of less
-// than three chunks are cut evenly as before.  tail_ramp = false (verification: all that comes back is a status word per proof): no
-// ramp at the end, the remainder joins the last chunk's neighbours
+// than three chunks are cut evenly as before.  tail_ramp = false (verification: all that comes back is a status word per proof): see below
 static std::vector<size_t> io_schedule(size_t B, size_t C, bool tail_ramp = true) {
   std::vector<size_t> v;
   if (B < 2 * C || C < 8) {
     for (size_t o = 0; o < B; o += C) v.push_back(std::min(C, B - o));
     return v;
   }
+  static const bool slow_ramp = [] { const char* e = getenv("MP_IO_RAMP"); return !(e && *e == '0'); }();      // (A/B hook of round 5)
+  if (!tail_ramp && !slow_ramp) {      // round 4's schedule without its tail: C/8, 3C/8, then full chunks
+    v.push_back(C / 8);
+    v.push_back(3 * C / 8);
+    for (size_t left = B - C / 2; left;) {
+      const size_t c = std::min(C, left);
+      v.push_back(c);
+      left -= c;
+    }
+    return v;
+  }
+  if (!tail_ramp) {
+    // Verification uploads 19.7 KB per proof (both decks and the proof) for ~0.5 us of kernels: at PCIe rates the copy of chunk k + 1
+    // takes about as long as the kernels of chunk k, so the chunks can only grow slowly -- by half from one to the next, starting at C / 8;
+    // whatever is left when the next step would overshoot is the last chunk (nothing of a verify call is exposed at its end)
+    size_t left = B;
+    for (size_t c = C / 8; left; c = std::min(C, (c + c / 2 + 1023) / 1024 * 1024)) {
+      // (no sliver at the end: what is left below 1.5 c goes as one chunk, or as two halves if that would exceed C)
+      const size_t take = left >= c + c / 2 ? c : (left <= C ? left : (left + 1) / 2);
+      v.push_back(take);
+      left -= take;
+    }
+    return v;
+  }
   const size_t r0 = C / 8, r1 = 3 * C / 8;
   v.push_back(r0);
   v.push_back(r1);
-  size_t left = B - (r0 + r1) * (tail_ramp ? 2 : 1);
-  // (a short remainder goes first: the last chunk of a verify call should be a full one, nothing of it is exposed)
-  if (left % C) {
-    v.push_back(left % C);
-    left -= left % C;
+  for (size_t left = B - 2 * (r0 + r1); left;) {
+    const size_t c = std::min(C, left);
+    v.push_back(c);
+    left -= c;
   }
-  for (; left; left -= C) v.push_back(C);
-  if (tail_ramp) {
-    v.push_back(r1);
-    v.push_back(r0);
-  }
+  v.push_back(r1);
+  v.push_back(r0);
   return v;
 }
 static void io_events(mp_io_stage& st) {

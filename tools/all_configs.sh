@@ -1,5 +1,5 @@
 set +x
-O=gpurun_out/r04f; mkdir -p $O
+O=${MP_CONFIGS_OUT:-gpurun_out/r05f}; mkdir -p $O
 X="--no-extras --no-cpu-baseline --steps 2 --warmup 1"
 python bench.py $X --curve secp256k1 > $O/secp256k1.json 2>$O/err.txt
 python bench.py $X --curve bn254 > $O/bn254.json 2>>$O/err.txt

@@ -99,6 +99,7 @@ def main():
         F = counters(os.path.join(src, "pmc_FETCH"), grid, skip).get("FETCH_SIZE", {})
         W = counters(os.path.join(src, "pmc_WRITE"), grid, skip).get("WRITE_SIZE", {})
         SQ = counters(os.path.join(src, "pmc_SQ"), grid, skip)
+        TCC = counters(os.path.join(src, "pmc_TCC"), grid, skip)
         kernels = {}
         for k in sorted(F, key=lambda k: -(2 * F[k][0] + W.get(k, [0, 0])[0])):
             f, w = F[k][0], W.get(k, [0.0, 0])[0]
@@ -110,6 +111,10 @@ def main():
             for c, per in SQ.items():
                 if k in per and not c.startswith("__"):
                     e[c + "_per_launch"] = per[k][0] / max(per[k][1], 1)
+            hit, miss = TCC.get("TCC_HIT_sum", {}).get(k), TCC.get("TCC_MISS_sum", {}).get(k)
+            if hit and miss and hit[0] + miss[0] > 0:      # L2 (all 8 XCDs): hits / (hits + misses) over the kernel's launches
+                e["TCC_HIT_per_launch"], e["TCC_MISS_per_launch"] = hit[0] / max(hit[1], 1), miss[0] / max(miss[1], 1)
+                e["l2_hit_rate"] = hit[0] / (hit[0] + miss[0])
             dur = SQ.get("__duration_ns", {}).get(k)
             if dur and dur[1] and "GRBM_GUI_ACTIVE_per_launch" in e:
                 e["duration_ms_per_launch_sq_pass"] = dur[0] / dur[1] * 1e-6
@@ -141,6 +146,8 @@ def main():
             extra = ""
             if "valu_slot_utilisation" in v:
                 extra = "  clock %.0f MHz  VALU issue slots used %.3f" % (v["clock_mhz"], v["valu_slot_utilisation"])
+                if "l2_hit_rate" in v:
+                    extra += "  L2 hit rate %.3f" % v["l2_hit_rate"]
             elif "SQ_INSTS_VALU_per_launch" in v and "SQ_BUSY_CYCLES_per_launch" in v:
                 extra = "  VALU insts/launch %.3g  wave-cycles %.3g  wait_any %.3g  wait_inst %.3g" % (
                     v["SQ_INSTS_VALU_per_launch"], v.get("SQ_WAVE_CYCLES_per_launch", 0), v.get("SQ_WAIT_ANY_per_launch", 0),
