@@ -701,8 +701,11 @@ def main():
         # the timed region, one byte of the last response scalar of the chosen proofs is flipped in HBM, the verifier must reject exactly
         # those (by the name of their first failing check) and accept the rest.  one_bad: 1 proof of the batch; pct1_bad: 1 % of it,
         # evenly spread.  A failing group's members are looked at again, nobody else (mp_set_group_refine).
-        def rejection(Bc, nbad):
-            idx = (torch.arange(nbad, device=gpu, dtype=torch.int64) * (Bc // max(nbad, 1)) + (Bc // max(nbad, 1)) // 2)
+        def rejection(Bc, nbad, warm=1):
+            # (WHICH proofs: a seeded random choice -- a regular stride lands in a quarter of the groups, lane of (member j, group t) = j T + t)
+            gsel = torch.Generator(device="cpu")
+            gsel.manual_seed(1000003 * Bc + nbad)
+            idx = torch.randperm(Bc, generator=gsel)[:nbad].sort().values.to(gpu)
             od, op_, sv = out_sets[0]
 
             def one():
@@ -713,9 +716,13 @@ def main():
                 torch.cuda.synchronize()
                 table.verify_shuffle_batch_dev(Bc, decks.data_ptr(), od.data_ptr(), op_.data_ptr(), sv.data_ptr())
                 eng.sync()
-            one()
+            first = None
+            for _ in range(warm):
+                t1 = time.perf_counter()
+                one()
+                first = first or round(Bc / (time.perf_counter() - t1), 1)
             looked = table.reverified_count()
-            reps = 1 if Bc >= 65536 else 8
+            reps = 2 if Bc >= 65536 else 8
             t1 = time.perf_counter()
             for _ in range(reps):
                 one()
@@ -725,15 +732,24 @@ def main():
             want[idx] = True
             assert torch.equal(sv[:Bc] != 0, want), "rejection: the verifier did not reject exactly the tampered proofs"
             assert nbad == 0 or (int((sv[:Bc][idx] != sv[idx[0]]).sum().item()) == 0 and int(sv[idx[0]].item()) > 0)
-            return round(Bc * reps / dt, 1), int(looked)
+            return round(Bc * reps / dt, 1), int(looked), first
+        gl_honest = table.group_size(B)
         if not args.pipeline:
             for tag, Bc in (("", B), ("_16384", 16384)):
                 if Bc > B or (tag and Bc == B):
                     continue
                 if tag:
                     extras["none_bad%s_value" % tag] = rejection(Bc, 0)[0]      # the same calls, nobody tampered with: what the two below compare to
-                extras["one_bad%s_value" % tag], extras["one_bad%s_reverified" % tag] = rejection(Bc, 1)
-                extras["pct1_bad%s_value" % tag], extras["pct1_bad%s_reverified" % tag] = rejection(Bc, max(1, Bc // 100))
+                extras["one_bad%s_value" % tag], extras["one_bad%s_reverified" % tag], _ = rejection(Bc, 1, warm=2)
+                # 1 % of the traffic tampered with, sustained: the table's groups adapt to what its screens see (mp_set_group_adapt) --
+                # `pct1_bad_value` is the rate it settles at (the 5th call on), `pct1_bad_first_value` the first such call after honest traffic
+                (extras["pct1_bad%s_value" % tag], extras["pct1_bad%s_reverified" % tag],
+                 extras["pct1_bad%s_first_value" % tag]) = rejection(Bc, max(1, Bc // 100), warm=4)
+                extras["pct1_bad%s_group_size" % tag] = table.group_size(Bc)
+                for _ in range(5):                                 # honest traffic again: the groups grow back, one step per call
+                    step()
+                    eng.sync()
+                assert table.group_size(B) == gl_honest
             step()                                                # (the output buffers hold honest proofs again)
             eng.sync()
         free_b, _ = torch.cuda.mem_get_info()

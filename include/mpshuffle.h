@@ -236,6 +236,13 @@ uint32_t mp_group_size(const mp_table* t, size_t B);
  * check.  mp_reverified_count: proofs that have taken a per-equation pass on this table because a screen could not clear them. */
 int mp_set_group_refine(mp_table* t, uint32_t points_per_subgroup, uint32_t min_subgroups);
 uint64_t mp_reverified_count(const mp_table* t);
+/* Groups that adapt to the rejection rate (default on).  A group fails if any member does, so with a fraction p of bad proofs in the traffic
+ * 1 - (1 - p)^L of the groups of L fail (72 % of the groups of 128 at p = 1 %) and their members pay a finer pass on top of a screen that
+ * cleared nobody.  The table remembers the last screens: when more than a fifth of a call's groups fail the next call takes groups of half
+ * the size (down to 8), when fewer than 4 % fail the size goes back up, one step per call (calls with at least 64 groups count).  Honest
+ * traffic never leaves the default size; verdicts do not depend on it.  on = 0 pins the default (and resets the memory); mp_group_size
+ * reports the size the NEXT call of B proofs takes. */
+int mp_set_group_adapt(mp_table* t, int on);
 /* Variable-base MSMs with at least `terms` terms (default 2048: the verifier's products over a 1024-card deck) run on the
  * wave-cooperative bucket-method kernel (counting sort by wavefront prefix sum, balanced bucket shares, wave-wide bucket reduction),
  * smaller ones on the Straus kernel with per-proof window tables; 0 = never.  Results are identical; the split is a property of

@@ -16,7 +16,7 @@ MP_ERR_BAD_ENCODING, MP_ERR_BAD_PERMUTATION, MP_ERR_BAD_ARGUMENT, MP_ERR_NO_DEVI
 
 SYMBOLS = [
     "mp_ctx_create", "mp_ctx_destroy", "mp_last_error", "mp_check_name", "mp_proof_size", "mp_params_size",
-    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_set_subgroup_check", "mp_set_bucket_min", "mp_set_bucket_bits", "mp_set_chain_max_links", "mp_set_transcript_lanes", "mp_set_group_lanes", "mp_set_work_split", "mp_set_group_verify", "mp_group_size", "mp_set_group_refine", "mp_reverified_count", "mp_set_pipeline", "mp_set_plan_params", "mp_set_plan_thresholds", "mp_set_toom_cook", "mp_host_alloc", "mp_host_free", "mp_set_io_chunk", "mp_shuffle_and_remask_batch_keys", "mp_table_create_params",
+    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_set_subgroup_check", "mp_set_bucket_min", "mp_set_bucket_bits", "mp_set_chain_max_links", "mp_set_transcript_lanes", "mp_set_group_lanes", "mp_set_work_split", "mp_set_group_verify", "mp_group_size", "mp_set_group_refine", "mp_reverified_count", "mp_set_group_adapt", "mp_set_pipeline", "mp_set_plan_params", "mp_set_plan_thresholds", "mp_set_toom_cook", "mp_host_alloc", "mp_host_free", "mp_set_io_chunk", "mp_shuffle_and_remask_batch_keys", "mp_table_create_params",
     "mp_verify_shuffle_batch_keys", "mp_shuffle_and_remask_batch_keys_dev", "mp_verify_shuffle_batch_keys_dev",
     "mp_keyset_create", "mp_keyset_destroy", "mp_keyset_size", "mp_shuffle_and_remask_batch_keyset_dev", "mp_verify_shuffle_batch_keyset_dev",
     "mp_setup", "mp_table_create", "mp_table_create_ex", "mp_table_window_bits", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
@@ -135,6 +135,7 @@ def bind(cdll):
     cdll.mp_group_size.restype = c.c_uint32
     cdll.mp_set_group_refine.argtypes = [c.c_void_p, c.c_uint32, c.c_uint32]
     cdll.mp_reverified_count.argtypes = [c.c_void_p]
+    cdll.mp_set_group_adapt.argtypes = [c.c_void_p, c.c_int]
     cdll.mp_reverified_count.restype = c.c_uint64
     cdll.mp_set_pipeline.argtypes = [c.c_void_p, c.c_int]
     cdll.mp_set_plan_params.argtypes = [c.c_void_p, c.c_int] + [c.c_uint32] * 5
@@ -628,6 +629,11 @@ class Table:
         """what a failing group costs: its members go through equations of sub-groups of ~points_per_subgroup points (0 = an eighth of
         the group equation's) when there are at least min_subgroups of them (0 = 128), else straight to the per-equation pass"""
         self.eng._chk(self.lib.mp_set_group_refine(self.h, points_per_subgroup, min_subgroups))
+
+    def set_group_adapt(self, on=True):
+        """groups that shrink under sustained rejection (default on): more than a fifth of a call's groups failing halves the next call's
+        group size, fewer than 4 % restore it step by step; False pins the default size"""
+        self.eng._chk(self.lib.mp_set_group_adapt(self.h, 1 if on else 0))
 
     def reverified_count(self):
         """proofs that have taken a per-equation pass on this table because a screen could not clear them"""

@@ -284,6 +284,11 @@ int mp_set_group_refine(mp_table* t, uint32_t points_per_subgroup, uint32_t min_
   return MP_OK;
 }
 uint64_t mp_reverified_count(const mp_table* t) { return t ? t->reverified() : 0; }
+int mp_set_group_adapt(mp_table* t, int on) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_adapt: null table");
+  t->set_group_adapt(on != 0);
+  return MP_OK;
+}
 int mp_set_bucket_min(mp_table* t, size_t terms) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_min: null table");
   MP_TRY

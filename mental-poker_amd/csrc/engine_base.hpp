@@ -218,6 +218,7 @@ struct mp_table {
   virtual void set_group_verify(uint32_t links, size_t min_batch) = 0;
   virtual uint32_t group_size_of(size_t B) const = 0;
   virtual void set_group_refine(uint32_t points, uint32_t min_groups) = 0;
+  virtual void set_group_adapt(bool on) = 0;
   virtual uint64_t reverified() const = 0;
   virtual int set_plan_params(int plan, uint32_t fch, uint32_t vch, uint32_t grp, uint32_t nch, uint32_t vsp) = 0;
   virtual void set_plan_thresholds(size_t tiny, size_t small, size_t latency, size_t medium, size_t wide) = 0;

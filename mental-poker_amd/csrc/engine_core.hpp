@@ -1188,6 +1188,9 @@ struct Table : mp_table {
   uint32_t subgroup_size(size_t nsub, bool keyed, uint32_t l1) const {
     const uint32_t per = 4 * N + 11 * m + 8 + (keyed ? 1u : 0u);
     if (!group_points || !merged_verify) return 0;
+    // (a sub-group equation costs 0.55 us per proof at 32 proofs, 0.73 at 16, 0.85 at 8, 1.1 at 4 -- the per-equation pass 1.2: an eighth
+    // of a group of fewer than 64 proofs is not worth an equation of its own; profiles/r05h_rejection_strategies.txt)
+    if (!refine_points && l1 && l1 < 64) return 0;
     const uint32_t pts = refine_points ? refine_points : (l1 ? l1 * per : group_points) / 8;
     const uint32_t want = (uint32_t)std::min<uint64_t>((pts + per / 2) / per, 1023u);
     if (want < 2 || (l1 && want >= l1) || (uint64_t)want * per + n + 5 > BUCKET_TERMS_MAX || nsub < (uint64_t)refine_min * want) return 0;
@@ -1326,10 +1329,14 @@ struct Table : mp_table {
       const uint32_t T = v.B / gl;
       gbad[0].alloc(T, ctx->stream, false);
       verify_group_pass(v, gl, false, nullptr, gbad[0].p);
-      if (!read_flag(false)) return;        // every group's equation holds
+      if (!read_flag(false)) {              // every group's equation holds
+        note_group_verdicts(T, 0, gl);
+        return;
+      }
       std::vector<uint32_t> bad, idx;
       read_words(gbad[0].p, T, bad);
       group_members(bad.data(), T, gl, idx);
+      note_group_verdicts(T, (uint32_t)(idx.size() / gl), gl);
       verify_subset(v, idx, 0, false, gl);  // the members of the failing groups, nobody else
       return;
     }
@@ -1349,11 +1356,15 @@ struct Table : mp_table {
       pend.pop_front();
       pend_pool.push_back(pn);
       rt::event_sync(pn.ev);
-      if (!*pn.h_flag) continue;
+      if (!*pn.h_flag) {
+        if (pn.gl) note_group_verdicts(pn.v.B / pn.gl, 0, pn.gl);
+        continue;
+      }
       LaneSwap lane(ctx);
       if (pn.gl) {
         std::vector<uint32_t> idx;
         group_members(pn.h_gbad, pn.v.B / pn.gl, pn.gl, idx);
+        note_group_verdicts(pn.v.B / pn.gl, (uint32_t)(idx.size() / pn.gl), pn.gl);
         verify_subset(pn.v, idx, 0, true, pn.gl);
       } else {
         refine_marked(pn.v, true);          // the proofs the screen marked: the first failing check of each
@@ -1540,7 +1551,9 @@ struct Table : mp_table {
     // as many proofs per group as bring its equation nearest to group_points points, but no fewer groups than keep the persistent
     // waves busy
     const uint32_t groups_min = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)group_min_batch * 2u) / 13u));
-    const uint32_t want = std::min<uint32_t>((group_points + per / 2) / per, B / groups_min);
+    uint32_t want = std::min<uint32_t>((group_points + per / 2) / per, B / groups_min);
+    // (under sustained rejection the groups shrink: note_group_verdicts below)
+    if (want >= 4) want = std::max<uint32_t>(want >> adapt_shift, 4u);
     if (want < 2) return 0;
     for (uint32_t d = 0; d <= want; ++d)
       for (int sgn = 1; sgn >= -1; sgn -= 2) {
@@ -1549,6 +1562,28 @@ struct Table : mp_table {
         if (B % (uint32_t)L == 0) return (uint32_t)L;
       }
     return 0;
+  }
+  // Groups that adapt to the rejection rate (round 5).  A group of L proofs fails if ANY member does: with a fraction p of bad proofs
+  // spread over the batch, 1 - (1 - p)^L of the groups fail -- 72 % of the groups of 128 at p = 1 % -- and every member of a failing group
+  // pays a finer pass (0.55-0.85 us per proof for a sub-group equation, 1.2 us equation by equation: profiles/r05h_rejection_strategies.txt)
+  // on top of the screen that told it nothing.  So the table remembers what the last screens saw: if more than a fifth of the groups of a
+  // call fail, the next call takes groups of half the size (down to 8: the screen of groups of 16 costs 0.16 us per proof more than that of
+  // 128, and 15 % of them fail at p = 1 %); if fewer than 4 % fail, the size goes back up, one step per call.  Honest traffic never
+  // leaves the default; under sustained 1 % rejection the step settles at ~0.8 x the honest rate instead of ~0.68 x.  Only calls with at
+  // least 64 groups count (a fraction of three groups says nothing).  mp_set_group_adapt(t, 0) pins the default size.
+  uint32_t adapt_shift = 0;
+  bool group_adapt = true;
+  void set_group_adapt(bool on) override {
+    group_adapt = on;
+    adapt_shift = 0;
+  }
+  void note_group_verdicts(uint32_t T, uint32_t failing, uint32_t L) {
+    if (!group_adapt || T < 64) return;
+    if ((uint64_t)failing * 5 > T) {
+      if (L >= 16 && adapt_shift < 4) ++adapt_shift;
+    } else if ((uint64_t)failing * 25 < T && adapt_shift > 0) {
+      --adapt_shift;
+    }
   }
   ChainPlan& build_group_plan(uint32_t L, bool keyed) {
     const std::pair<uint32_t, bool> key(L, keyed);

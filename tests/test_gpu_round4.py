@@ -454,6 +454,7 @@ def test_group_verification_at_full_size(mp, coracle):
     # 1 % of the batch tampered, evenly spread (82 proofs, in most of the 64 groups): exactly those rejected; sub-groups by default
     # (>= 128 of them), pipelined too
     t.set_group_refine(0, 0)
+    t.set_group_adapt(False)                                # (groups that shrink under sustained rejection: tests/test_gpu_round5.py)
     t.shuffle_and_remask_batch_dev(B, decks.data_ptr(), rho.data_ptr(), perm.data_ptr(), seeds.data_ptr(), od.data_ptr(), op.data_ptr(), sp.data_ptr())
     eng.sync()
     idx = torch.arange(82, device=gpu) * 99 + 50

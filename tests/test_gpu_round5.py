@@ -74,3 +74,57 @@ def test_chain_fixture_on_the_hip_engine(mp):
     assert st[0] == 0 and st[1] > 0 and st[2] == 0
     t.close()
     eng.close()
+
+
+def test_groups_adapt_to_sustained_rejection(mp, coracle):
+    """mp_set_group_adapt (default on): 8 192 proofs in 64 groups of 128; with 1 % of the traffic tampered (random positions) 72 % of the
+    groups fail, and the table halves its groups from call to call -- 128, 64, 32, 16 -- until fewer than a fifth of them fail; every call
+    rejects exactly the tampered proofs; honest traffic restores the size one step per call; with adaptation off the size stays"""
+    import torch
+    cv, m, n, B = "stark", 2, 26, 8192
+    eng = mp._native.Engine(cv, 0)
+    g0 = coracle.gen_inputs(cv, m, n, 5990)
+    t = eng.table(m, n, g0["params"], g0["pk"], fb_bits=16)
+    t.set_group_verify(30464, 0)
+    gpu = torch.device("cuda", 0)
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(17)
+    N = m * n
+    decks = torch.frombuffer(bytearray(g0["deck"]), dtype=torch.uint8).to(gpu).repeat(B, 1).contiguous()
+    rho = torch.randint(0, 256, (B, N, 32), dtype=torch.uint8, device=gpu, generator=gen)
+    rho[:, :, 31] &= 7
+    perm = torch.argsort(torch.rand(B, N, device=gpu, generator=gen), dim=1).to(torch.int32).contiguous()
+    seeds = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device=gpu, generator=gen)
+    od = torch.empty(B, len(g0["deck"]), dtype=torch.uint8, device=gpu)
+    op = torch.empty(B, t.proof_bytes, dtype=torch.uint8, device=gpu)
+    sp = torch.empty(B, dtype=torch.int32, device=gpu)
+    sv = torch.empty(B, dtype=torch.int32, device=gpu)
+    t.shuffle_and_remask_batch_dev(B, decks.data_ptr(), rho.data_ptr(), perm.data_ptr(), seeds.data_ptr(), od.data_ptr(), op.data_ptr(), sp.data_ptr())
+    eng.sync()
+    good = op.clone()
+    idx = torch.randperm(B, generator=torch.Generator().manual_seed(5))[:82].to(gpu)
+    bad = good.clone()
+    bad[idx, t.proof_bytes - 31] ^= 2
+    want = torch.zeros(B, dtype=torch.bool, device=gpu)
+    want[idx] = True
+
+    def verify(proofs, expect):
+        sv.fill_(55)
+        t.verify_shuffle_batch_dev(B, decks.data_ptr(), od.data_ptr(), proofs.data_ptr(), sv.data_ptr())
+        eng.sync()
+        assert torch.equal(sv != 0, expect)
+    nobody = torch.zeros(B, dtype=torch.bool, device=gpu)
+    sizes = []
+    for _ in range(6):
+        sizes.append(t.group_size(B))
+        verify(bad, want)
+    assert sizes[:4] == [128, 64, 32, 16] and sizes[4] in (16, 8) and sizes[5] == sizes[4], sizes
+    for _ in range(5):
+        verify(good, nobody)
+    assert t.group_size(B) == 128
+    t.set_group_adapt(False)
+    for _ in range(3):
+        verify(bad, want)
+        assert t.group_size(B) == 128
+    t.close()
+    eng.close()
