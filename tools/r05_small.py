@@ -22,6 +22,14 @@ if "--group" in argv:                     # --group POINTS MIN_BATCH: mp_set_gro
     argv = argv[:i] + argv[i + 3:]
     t.set_group_verify(*GROUP)
     print("group verification: %d points per equation from %d proofs on" % GROUP)
+if "--plan" in argv:                      # --plan SPLIT FCH VCH GRP NCH VSP: mp_set_plan_params for the run
+    i = argv.index("--plan")
+    pp = [int(x) for x in argv[i + 1:i + 7]]
+    argv = argv[:i] + argv[i + 7:]
+    t.set_plan_params(*pp)
+    print("plan %d: %s" % (pp[0], pp[1:]))
+QUIET = "--quiet" in argv
+argv = [a for a in argv if a != "--quiet"]
 for B in [int(a) for a in argv] or [1024]:
     gen = torch.Generator(device=gpu); gen.manual_seed(3)
     decks = torch.frombuffer(bytearray(g["deck"]), dtype=torch.uint8).to(gpu).repeat(B, 1).contiguous()
@@ -52,7 +60,7 @@ for B in [int(a) for a in argv] or [1024]:
     assert int(sp.abs().sum()) == 0 and int(sv.abs().sum()) == 0
     print("group size %d" % t.group_size(B))
     print("B=%d: prove %.3f ms, verify %.3f ms, prove+verify %.3f ms -> %.0f proofs/s" % (B, 1e3 * tp, 1e3 * tv, 1e3 * tb, B / tb))
-    for name, fn in (("prove", prove), ("verify", verify)):
+    for name, fn in (() if QUIET else (("prove", prove), ("verify", verify))):
         eng.profile_enable(True); fn(); rep = eng.profile_report(); eng.profile_enable(False)
         print("  %s: kernel sum %.3f ms in %d launches; %s" % (name, sum(v[1] for v in rep.values()), sum(v[0] for v in rep.values()),
               ", ".join("%s x%d %.3f" % (k, v[0], v[1]) for k, v in sorted(rep.items(), key=lambda kv: -kv[1][1])[:10])))
