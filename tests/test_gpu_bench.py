@@ -74,6 +74,13 @@ def test_json_line_contract_and_extras():
     api = d["config"]["api_host_value"]["16384"]
     assert api["pinned"] > 0 and api["pageable"] > 0
     assert d["config"]["default_table_value"] > 0 and d["config"]["default_table_window_bits"] in (16, 20, 21)
+    # round 5: what rejection costs, as flat scalars beside the headline; one row per kernel >= 3 % of the step; flat copies of the nested extras
+    c = d["config"]
+    assert 0 < c["pct1_bad_value"] <= c["one_bad_value"] * 1.05 and c["one_bad_reverified"] >= 1 and c["pct1_bad_first_value"] > 0
+    assert c["api_host_pinned_value"] == api["pinned"] and c["api_host_pageable_value"] == api["pageable"]
+    rows = r["kernels"]
+    assert rows and rows[0]["kernel"] == r["kernel"] and all(row["share"] >= 0.03 and row["ms"] > 0 for row in rows)
+    assert abs(sum(row["share"] for row in rows) - 1.0) < 0.35 and "%s_ms" % rows[0]["kernel"] in c
 
 
 def test_batch_curve_on_the_line():
