@@ -156,7 +156,7 @@ struct Table : mp_table {
   // the verify calls pipelined (profiles/r04_plan_sweep.txt):
   //   [3] finest      1 / 1 / 2 / 4 / 1     up to ~128 proofs in flight (plus the bucket kernel for the merged verifier equation)
   //   [5] small       1 / 8 / 2 / 4 / 8     up to ~768      (256: 83 k against 55 k on the finest split, 512: 137 k against 90 k)
-  //   [1] latency     2 / 16 / 4 / 8 / 8    up to ~2 560    (1 024: 188-200 k; round 3's 2 / 4 / 8 / 8 / 1: 122 k)
+  //   [1] latency     1 / 16 / 4 / 8 / 16   up to ~2 560    (1 024: 168 k serial, 200 k pipelined; 2 048: 253 k; round 4's 2 / 16 / 4 / 8 / 8: 240 k at 2 048)
   //   [2] medium      4 / 32 / 8 / 16 / 4   up to ~6 144    (4 096: 338 k; round 3's 4 / 16 / 16 / 32 / 1: 242-255 k)
   //   [4] wide        4 / 64 / 16 / 32 / 16 up to ~49 152   (16 384: 462 k, 32 768: 483 k; round 3's 4 / 32 / 16 / 32 / 1: 402 k, 440 k)
   //   [0] throughput  8 / 64 / 64 / 64 / 1  beyond: fewest operations
@@ -175,7 +175,7 @@ struct Table : mp_table {
     // BLS12-377 (30,10) 90 -> 117 ms.)
     const uint32_t tiny_v = N <= 128 ? 1u : 2u, tiny_g = N <= 128 ? 2u : 4u;
     pprm[0] = PlanParams{FCHUNK, VCHUNK, TABLE_GROUP, NORM_CHUNK, 1};
-    pprm[1] = PlanParams{2, 16, 4, 8, 8};
+    pprm[1] = PlanParams{1, 16, 4, 8, 16};      // (round 5 re-sweep, profiles/r05k_plan_sweep_small.txt: 2 048 proofs 240 k -> 253 k/s against 2 / 16 / 4 / 8 / 8, 1 024 unchanged)
     pprm[2] = PlanParams{4, 32, 8, 16, 4};
     pprm[3] = PlanParams{1, tiny_v, tiny_g, 4, 1};
     pprm[4] = PlanParams{4, 64, 16, 32, 16};

@@ -128,3 +128,82 @@ def test_groups_adapt_to_sustained_rejection(mp, coracle):
         assert t.group_size(B) == 128
     t.close()
     eng.close()
+
+
+@pytest.mark.parametrize("cv,m,n,B", [("stark", 2, 26, 3000), ("secp256k1", 2, 7, 2304), ("stark", 4, 13, 1536)])
+def test_rejection_fuzz_every_strategy_gives_the_per_equation_verdicts(mp, coracle, cv, m, n, B):
+    """randomised rejection: a batch with a random mix of tampered response scalars, swapped decks and broken point encodings is
+    verified (a) equation by equation with no screen at all -- the reference's order of evaluation, the expected status words --, then
+    with the per-proof screen, with groups of several sizes with and without sub-groups, with adapting groups, waiting and pipelined
+    (depth 1 and 2, three calls each).  Every strategy must return exactly the status words of (a); a sample of them is checked against
+    the CPU oracle proof by proof."""
+    import random
+    import torch
+    rnd = random.Random(1234 + B)
+    eng = mp._native.Engine(cv, 0)
+    g0 = coracle.gen_inputs(cv, m, n, 8800)
+    t = eng.table(m, n, g0["params"], g0["pk"], fb_bits=8)
+    gpu = torch.device("cuda", 0)
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(B)
+    N, pb = m * n, eng.point_bytes
+    per = 4 * N + 11 * m + 8
+    decks = torch.frombuffer(bytearray(g0["deck"]), dtype=torch.uint8).to(gpu).repeat(B, 1).contiguous()
+    rho = torch.randint(0, 256, (B, N, 32), dtype=torch.uint8, device=gpu, generator=gen)
+    rho[:, :, 31] &= 7
+    perm = torch.argsort(torch.rand(B, N, device=gpu, generator=gen), dim=1).to(torch.int32).contiguous()
+    seeds = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device=gpu, generator=gen)
+    od = torch.empty(B, len(g0["deck"]), dtype=torch.uint8, device=gpu)
+    op = torch.empty(B, t.proof_bytes, dtype=torch.uint8, device=gpu)
+    sp = torch.empty(B, dtype=torch.int32, device=gpu)
+    t.shuffle_and_remask_batch_dev(B, decks.data_ptr(), rho.data_ptr(), perm.data_ptr(), seeds.data_ptr(), od.data_ptr(), op.data_ptr(), sp.data_ptr())
+    eng.sync()
+    assert int(sp.abs().sum().item()) == 0
+    # tamper: ~4 % of the proofs, three kinds
+    victims = rnd.sample(range(B), max(6, B // 25))
+    kinds = {}
+    for b in victims:
+        kind = rnd.choice(("scalar", "deck", "encoding"))
+        kinds[b] = kind
+        if kind == "scalar":
+            op[b, (11 * m + 8) * pb + 32 * rnd.randrange(5 * n + 9) + rnd.randrange(8)] ^= 1 << rnd.randrange(8)
+        elif kind == "deck":                                   # another proof's output deck: valid points, wrong statement
+            od[b] = od[(b + 1) % B].clone()
+        else:                                                  # a coordinate that is not on the curve (or not canonical) any more
+            od[b, rnd.randrange(2 * N) * pb + rnd.randrange(pb)] ^= 1 << rnd.randrange(8)
+    torch.cuda.synchronize()
+
+    def verify(depth=0, calls=1):
+        t.set_pipeline(depth)
+        outs = [torch.full((B,), 55, dtype=torch.int32, device=gpu) for _ in range(calls)]
+        for sv in outs:
+            t.verify_shuffle_batch_dev(B, decks.data_ptr(), od.data_ptr(), op.data_ptr(), sv.data_ptr())
+        eng.sync()
+        t.set_pipeline(0)
+        return [sv.cpu().tolist() for sv in outs]
+    t.set_merged_verify(False)
+    want = verify()[0]
+    t.set_merged_verify(True)
+    bad = [b for b, v in enumerate(want) if v]
+    assert sorted(bad) == sorted(victims)
+    assert all(want[b] < 0 for b in victims if kinds[b] == "encoding") and all(want[b] > 0 for b in victims if kinds[b] == "deck")
+    assert all(want[b] != 0 for b in victims if kinds[b] == "scalar")      # (> 0, or < 0 if the flipped scalar is no longer canonical)
+    deck_b = bytes(g0["deck"])
+    for b in rnd.sample(bad, 4) + rnd.sample(range(B), 4):
+        if want[b] >= 0:                                       # (the oracle has no encoding errors: it takes points as they come)
+            got = coracle.verify_shuffle(cv, m, n, g0["params"], g0["pk"], deck_b, od[b].cpu().numpy().tobytes(), op[b].cpu().numpy().tobytes())
+            assert got == want[b], (b, kinds.get(b))
+    configs = [("per-proof screen", (0, 0), (0, 0), True)]
+    for L in (4, 16, 64):
+        configs.append(("groups of %d" % L, (L * per, 0), (0, 1 << 30), False))
+        configs.append(("groups of %d, sub-groups of %d" % (L, max(2, L // 4)), (L * per, 0), (max(2, L // 4) * per, 1), False))
+    configs.append(("groups of 64, adapting", (64 * per, 0), (0, 0), True))
+    for name, gv, gr, adapt in configs:
+        t.set_group_verify(*gv)
+        t.set_group_refine(*gr)
+        t.set_group_adapt(adapt)
+        for depth, calls in ((0, 2), (1, 3), (2, 3)):
+            for got in verify(depth, calls):
+                assert got == want, (name, depth, [(b, got[b], want[b]) for b in range(B) if got[b] != want[b]][:5])
+    t.close()
+    eng.close()
