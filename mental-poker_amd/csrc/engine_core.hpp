@@ -1175,6 +1175,7 @@ struct Table : mp_table {
     DevBuf<int32_t> status;
   };
   SubBatch sub[2][2];                 // [lane][level]
+  Workspace rws[2];                   // [lane] arenas of the per-equation passes over sub-batches (sized by the sub-batch, not by the batch)
   DevBuf<uint32_t> gbad[2];           // per-group verdicts of a group / chain pass on the caller's lane, on the verify lane
   uint32_t refine_points = 0;         // points per sub-group equation (mp_set_group_refine; 0 = an eighth of the group equation's)
   uint32_t refine_min = 128;          // fewer sub-groups than this: straight to the per-equation pass
@@ -1227,11 +1228,31 @@ struct Table : mp_table {
     rt::Stream s = ctx->stream;
     const uint32_t L2 = level == 0 ? subgroup_size(idx.size(), keyed, l1) : 0u;
     if (!L2) level = 1;
+    // The equations of a sub-batch run on arenas of their OWN (rws), in slices of at most 32 768 52-card proofs: the work split follows
+    // the size of the sub-batch (128 suspects take the finest split), and a split with more table / digit slots per proof than the
+    // caller's must not grow the caller's arenas -- those are laid out for 262 144 lanes, and re-allocating them cost the first rejected
+    // proof of a session 3.5 s (measured).  Bounded memory (~20 GB at the most), cost proportional to the suspects.
+    auto per_equation = [&](const VArgs& a) {
+      Workspace& w = rws[vlane ? 1 : 0];
+      const uint32_t slice = std::max<uint32_t>(64u, (uint32_t)(((uint64_t)32768 * 52u / N) & ~63ull));
+      const size_t dsz = (size_t)2 * N * G_::PB, psz = proof_size_bytes(m, n, G_::PB);
+      n_reverified += a.B;
+      for (uint32_t s0 = 0; s0 < a.B; s0 += slice) {
+        const uint32_t sc = std::min(slice, a.B - s0);
+        const VArgs ss{sc, a.decks + (size_t)s0 * dsz, a.shuf + (size_t)s0 * dsz, a.proofs + (size_t)s0 * psz, a.status + s0,
+                       a.keys ? a.keys + (size_t)s0 * G_::PB : nullptr, a.kset, a.kidx ? a.kidx + s0 : nullptr};
+        reserve_ws(w, sc, keyed);
+        verify_pass(w, ss, false, vlane);
+      }
+    };
     if (level == 1 && idx.size() == v.B) {      // (everybody: no gather)
-      Workspace& w = vlane ? vws : ws;
-      reserve_ws(w, v.B, keyed);
-      n_reverified += v.B;
-      verify_pass(w, v, false, vlane);
+      if (vlane) {                              // (the verify lane has no arenas of the batch's size for the equations: slices)
+        per_equation(v);
+      } else {                                  // (the caller's arenas are laid out for this batch and its work split already)
+        reserve_ws(ws, v.B, keyed);
+        n_reverified += v.B;
+        verify_pass(ws, v, false, false);
+      }
       return;
     }
     if (L2)
@@ -1260,10 +1281,7 @@ struct Table : mp_table {
         verify_subset(sv, idx2, 1, vlane);
       }
     } else {
-      Workspace& w = vlane ? vws : ws;
-      reserve_ws(w, nsub, keyed);
-      n_reverified += nsub;
-      verify_pass(w, sv, false, vlane);
+      per_equation(sv);
     }
     ScatterStatusArgs sa{sb.status.p, v.status, sb.idx.p};
     MP_RUN(k_scatter_status, C, nsub, 1, sa);
