@@ -72,7 +72,9 @@ size_t mp_params_size_curve(int curve_id, uint32_t n);            /* (n+3) * mp_
  * runtime's staging speed.  NULL on failure (mp_last_error). */
 void* mp_host_alloc(size_t bytes);
 void mp_host_free(void* p);
-/* proofs per pipelined chunk of the host-buffer entry points (default 65536; 0 restores the default) */
+/* proofs per pipelined chunk of the host-buffer entry points (0 restores the default: 65 536, and 131 072 for calls of 262 144 proofs or
+ * more; the first chunks of a call are smaller -- the first upload and the last download are the copies nothing overlaps -- and the chunks
+ * of a verify call grow by half from one to the next, because the copy of chunk k + 1 takes about as long as the kernels of chunk k) */
 int mp_set_io_chunk(mp_table* t, size_t proofs);
 
 /* ---- DLCards::setup [REF barnett-smart-card-protocol/src/discrete_log_cards/mod.rs:105-121] ---------------------------
@@ -209,9 +211,9 @@ int mp_set_plan_params(mp_table* t, int split, uint32_t fixed_terms, uint32_t va
 int mp_set_plan_thresholds(mp_table* t, size_t finest, size_t small, size_t latency, size_t medium, size_t wide);
 /* Verification strategy.  on (default): the verifier first evaluates ALL group equations of a proof merged into one
  * multi-scalar multiplication with random weights derived from the whole proof (soundness loss ~2^-250); a batch in which
- * every proof passes ends there.  Only if some proof fails is the batch re-evaluated equation by equation, so that the
- * FIRST failing check is reported by name exactly as the reference does [REF tests.rs:223-225].  off: always evaluate
- * the equations one by one.  Results (status words) are identical in both modes. */
+ * every proof passes ends there.  The proofs that fail it -- they and nobody else (round 5, mp_set_group_refine below) -- are evaluated
+ * equation by equation, so that the FIRST failing check is reported by name exactly as the reference does [REF tests.rs:223-225].
+ * off: always evaluate the equations one by one.  Results (status words) are identical in both modes. */
 int mp_set_merged_verify(mp_table* t, int on);
 /* Group verification (round 4; on by default except on BLS12-377, where it only draws level).  The screening pass of a batch of at least `min_batch` x 52 / N proofs (default 6 144 for
  * 52-card decks) adds the merged equations of a GROUP of proofs with weights derived from every proof of the group and evaluates the sum
