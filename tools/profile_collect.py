@@ -41,7 +41,8 @@ def last_json(path):
 
 def counters(dirpath, min_grid, skip):
     """{counter: {kernel: [sum, dispatches]}} over the batch-sized dispatches, skipping the first skip[kernel] (priming)"""
-    files = glob.glob(os.path.join(dirpath, "**", "*counter_collection.csv"), recursive=True)
+    # (gpurun merges every pass into the same directories: the NEWEST file is this pass's)
+    files = sorted(glob.glob(os.path.join(dirpath, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime, reverse=True)
     out = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
     if not files:
         return out
@@ -71,7 +72,7 @@ def main():
         print("value %.0f %s, %.1f ms/step" % (bench["value"], bench["unit"], bench["ms_per_step"]))
     # ---- kernel trace
     tb = last_json(os.path.join(src, "trace_bench.json")) or bench
-    tr = glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True)
+    tr = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime, reverse=True)
     if tr and tb:
         batch = tb["config"]["proofs_per_gpu_per_step"]
         d = collections.defaultdict(list)

@@ -11,8 +11,8 @@ for v in "MP_BK_XCD=0" "MP_BK_TILE=0 MP_BK_XCD=0"; do
   tag=$(echo "$v" | tr ' =' '__')
   env $v rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/${T}_tcc_$tag -- python bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${T}_tcc_$tag.err
   python - "$v" gpurun_out/${T}_tcc_$tag <<'PY'
-import csv, glob, sys
-f = glob.glob(sys.argv[2] + "/**/*counter_collection.csv", recursive=True)
+import csv, glob, os, sys
+f = sorted(glob.glob(sys.argv[2] + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime, reverse=True)
 acc = {}
 for r in csv.DictReader(open(f[0])) if f else []:
     if "k_bucket_msm" in r["Kernel_Name"]:
