@@ -901,6 +901,8 @@ def main():
             return sum(s["fixed_terms"] * 32 + s["fixed_jobs"] * 3 * PB // 2 for s in pv)
         if kernel == "k_table":
             return sum(s["table_bases"] * (PB + 16 * PB) for s in pv)
+        if kernel == "k_remask":          # the deck, one masking factor per card, the re-encrypted deck as Jacobian points
+            return 2 * N * PB + N * 32 + 2 * N * 3 * PB // 2
         if kernel == "k_normalize":
             return sum(s["table_bases"] * 16 * (3 * PB // 2 + PB) for s in pv)
         return None
