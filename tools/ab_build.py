@@ -31,6 +31,13 @@ def main():
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
              "-mllvm", "-pragma-unroll-threshold=1000000"] + extra    # same flags as mental-poker_amd/_native.py
+    for a in sys.argv[2:]:
+        if a.startswith("--sched="):      # another scheduling strategy for the variant's units (default: the product's max-ilp; "default" = LLVM's)
+            i = flags.index("-amdgpu-sched-strategy=max-ilp")
+            if a == "--sched=default":
+                del flags[i - 1:i + 1]
+            else:
+                flags[i] = "-amdgpu-sched-strategy=" + a.split("=", 1)[1]
 
     def cc(u):
         obj = os.path.join(objdir, u.replace(".hip", ".o"))
