@@ -286,6 +286,10 @@ def main():
     ap.add_argument("--per-link-verify", action="store_true",
                     help="chain32: verify every link on its own (mp_verify_shuffle_batch_keys_dev) instead of one chain equation per table "
                          "(mp_verify_shuffle_chain_dev)")
+    ap.add_argument("--chain-max-links", type=int, default=None,
+                    help="chain32: links per chain equation (mp_set_chain_max_links; a chain of --players links is verified as consecutive "
+                         "sub-chains, whose 68 KB of workspace per link in flight is what bounds the tables per GPU; default: 32 up to 49 152 "
+                         "tables, 8 beyond)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = --batch proofs per GPU per step (default); strong = --batch proofs per step in total, 1/N per GPU")
     ap.add_argument("--pipeline", type=int, default=0,
@@ -557,6 +561,9 @@ def main():
             G -= 1
         kk = keys.repeat(G, 1).contiguous()
         keyless.reserve(T if chain_verify else max(T, G * T))
+        chain_links = args.chain_max_links if args.chain_max_links is not None else (L if T <= 49152 else 8)
+        if chain_verify and chain_links < L:
+            keyless.set_chain_max_links(chain_links)
         kset = None
         if not args.no_keyset:
             kset = make_keyset(keyless, T, T)       # one key per table, prepared once (a table keeps its key across hands)

@@ -258,6 +258,20 @@ int mp_set_bucket_bits(mp_table* t, uint32_t bits);
  * consecutive sub-chains.  0 (default) = as many as fit the 32 767 points of one equation (293 links of a 52-card deck; one link of a deck too large for that gets an equation of up to 65 535 points).  A smaller
  * value bounds the work that is repeated link by link when a chain fails.  Verdicts are the same. */
 int mp_set_chain_max_links(mp_table* t, uint32_t links);
+/* Chain verification of many tables at once: the chain equations of `tables_per_equation` tables are added up (with weights that
+ * depend on every proof of every member, as in mp_set_group_verify) into ONE equation -- 6 tables x 4 424 points for 32 links of a
+ * 52-card deck: 10-bit windows instead of 8-bit ones, the wave-wide reduction of a window spread over six times the points, the fixed
+ * bases once per six tables.  0 (default) = by size: the divisor of `tables` that brings the equation nearest to the group equation's
+ * points (mp_set_group_verify; none while fewer than ~1 000 equations would be left); 1 = every table on its own (rounds 2-4); other
+ * values = the divisor of `tables` nearest to it.  Tables g (tables / G) + e, g < G, share equation e.  If an equation fails, the
+ * links of ITS tables are re-verified one by one: status words are identical in every setting. */
+int mp_set_chain_group(mp_table* t, uint32_t tables_per_equation);
+/* Chain verification in passes of `tables_per_pass` tables.  The workspace of chain verification is ~68 KB per link in flight (52-card
+ * decks: 107 GB for 49 152 tables x 32 links), far more than the 13 KB of deck and proof a link occupies, while the prover wants as many
+ * tables per call as there are (link j of every table is one batch).  0 (default) = one pass if the workspace fits the free device
+ * memory, equal passes of whole thousands of tables otherwise; the rows of a pass are gathered from the link-major arrays on the device
+ * (one copy per link and array).  Verdicts do not depend on it. */
+int mp_set_chain_slice(mp_table* t, size_t tables_per_pass);
 /* Lanes per Fiat-Shamir transcript.  A proof's transcript is one BLAKE2s chain (13.6 KB of statement for a 52-card deck): 1 = one
  * lane per proof (what a batch that fills the chip wants), 4 = the four G functions of a half-round on four adjacent lanes (2.7x
  * fewer instructions in the chain: what a single proof or a few thousand large decks wait for), 0 (default) = 4 for batches of up

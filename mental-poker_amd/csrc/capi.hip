@@ -311,6 +311,17 @@ int mp_set_chain_max_links(mp_table* t, uint32_t links) {
   t->chain_max_links = links;
   return MP_OK;
 }
+int mp_set_chain_slice(mp_table* t, size_t tables_per_pass) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_chain_slice: null table");
+  t->chain_slice = tables_per_pass;
+  return MP_OK;
+}
+int mp_set_chain_group(mp_table* t, uint32_t tables_per_equation) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_chain_group: null table");
+  if (tables_per_equation > 1022) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_chain_group: at most 1 022 tables per equation");
+  t->chain_group = tables_per_equation;
+  return MP_OK;
+}
 int mp_set_transcript_lanes(mp_table* t, uint32_t lanes) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_transcript_lanes: null table");
   if (lanes != 0 && lanes != 1 && lanes != 4) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_transcript_lanes: 0 (by batch size), 1 or 4");
@@ -502,10 +513,56 @@ int mp_verify_shuffle_chain_dev(mp_table* t, size_t tables, uint32_t links, cons
   if (fixed_part + per_link > eq_cap) return fail(MP_ERR_INTERNAL, "mp_verify_shuffle_chain_dev: deck too large for one chain equation");
   uint32_t lmax = std::min<uint32_t>((uint32_t)((eq_cap - fixed_part) / per_link), 1022u);      // (links 0 .. L in 10 bits of a sorted entry: kernels_bucket.hpp)
   if (t->chain_max_links) lmax = std::max(1u, std::min(lmax, t->chain_max_links));
-  for (uint32_t j0 = 0; j0 < links; j0 += lmax) {
-    const uint32_t lc = std::min(lmax, links - j0);
-    t->verify_chain_dev(tables, lc, (const uint8_t*)d_decks + (size_t)j0 * tables * deck_bytes, (const uint8_t*)d_proofs + (size_t)j0 * tables * psz,
-                        (int32_t*)d_status + (size_t)j0 * tables, d_keys ? (const uint8_t*)d_keys + (size_t)j0 * tables * pb : nullptr);
+  auto sub_chains = [&](size_t T, const uint8_t* decks, const uint8_t* proofs, int32_t* status, const uint8_t* keys) {
+    for (uint32_t j0 = 0; j0 < links; j0 += lmax) {
+      const uint32_t lc = std::min(lmax, links - j0);
+      t->verify_chain_dev(T, lc, decks + (size_t)j0 * T * deck_bytes, proofs + (size_t)j0 * T * psz, status + (size_t)j0 * T, keys ? keys + (size_t)j0 * T * pb : nullptr);
+    }
+  };
+  // Tables per pass (round 5).  The chain workspace is ~68 KB per link in flight (52 cards): 49 152 tables x 32 links are 107 GB, and the
+  // tables a caller holds are bounded by that long before its decks and proofs fill the HBM -- while the PROVER wants many tables per
+  // launch (a link of every table is one batch).  So a call whose links do not fit the memory that is free (or the workspace that is
+  // there already) is verified in passes of `slice` tables: their rows of the link-major arrays are gathered into the staging buffers
+  // of the host-buffer calls (one copy per link and array: 13 KB per proof, ~10 ns at HBM rates), verified as a call of `slice` tables,
+  // and their status words scattered back.  mp_set_chain_slice pins the number; verdicts do not depend on it.
+  size_t slice = tables;
+  const uint32_t lcmax = std::min(lmax, links);
+  if (t->chain_slice) {
+    slice = std::min(tables, t->chain_slice);
+  } else if ((size_t)tables * lcmax > t->chain_lanes_held()) {
+    size_t free_b = 0, total_b = 0;
+    rt::mem_info(&free_b, &total_b);
+    const size_t lane = t->chain_lane_bytes(lcmax, d_keys != nullptr);
+    // (what is free now plus what the workspace gives back when it is re-allocated; 60 % of it: the bucket kernel's rows, the equation's
+    // scalars and digits, the staging buffers below and the per-link fallback of a failing equation come on top)
+    const size_t room = (size_t)(0.6 * (double)(free_b + t->chain_lanes_held() * lane));
+    if (total_b && (size_t)tables * lcmax * lane > room) {
+      slice = std::max<size_t>(1024, room / ((size_t)lcmax * lane) / 1024 * 1024);
+      // (no sliver at the end: equal passes, whole multiples of 1 024 tables where that is possible)
+      const size_t passes = (tables + slice - 1) / slice;
+      slice = std::min(tables, ((tables + passes - 1) / passes + 1023) / 1024 * 1024);
+    }
+  }
+  if (slice >= tables) {
+    sub_chains(tables, (const uint8_t*)d_decks, (const uint8_t*)d_proofs, (int32_t*)d_status, (const uint8_t*)d_keys);
+    return MP_OK;
+  }
+  rt::Stream s = t->ctx->stream;
+  mp_io_stage& st = t->io[0];
+  st.in0.alloc((size_t)(links + 1) * slice * deck_bytes, s, false);
+  st.out1.alloc((size_t)links * slice * psz, s, false);
+  st.status.alloc((size_t)links * slice, s, false);
+  if (d_keys) st.keys.alloc((size_t)links * slice * pb, s, false);
+  for (size_t t0 = 0; t0 < tables; t0 += slice) {
+    const size_t ts = std::min(slice, tables - t0);
+    for (uint32_t j = 0; j <= links; ++j)
+      rt::d2d(st.in0.p + (size_t)j * ts * deck_bytes, (const uint8_t*)d_decks + ((size_t)j * tables + t0) * deck_bytes, ts * deck_bytes, s);
+    for (uint32_t j = 0; j < links; ++j) {
+      rt::d2d(st.out1.p + (size_t)j * ts * psz, (const uint8_t*)d_proofs + ((size_t)j * tables + t0) * psz, ts * psz, s);
+      if (d_keys) rt::d2d(st.keys.p + (size_t)j * ts * pb, (const uint8_t*)d_keys + ((size_t)j * tables + t0) * pb, ts * pb, s);
+    }
+    sub_chains(ts, st.in0.p, st.out1.p, st.status.p, d_keys ? st.keys.p : nullptr);
+    for (uint32_t j = 0; j < links; ++j) rt::d2d((int32_t*)d_status + (size_t)j * tables + t0, st.status.p + (size_t)j * ts, ts * 4, s);
   }
   return MP_OK;
   MP_CATCH

@@ -201,6 +201,8 @@ struct mp_table {
   bool keyless = false;        // created from the parameters alone (mp_table_create_params): keyed entry points only
   uint32_t bucket_bits = 0;       // window width of the bucket method (0 = by the size of the MSM: kernels_bucket.hpp bk_bits_for; mp_set_bucket_bits)
   uint32_t chain_max_links = 0;   // links per chain equation (0 = as many as fit 32 767 points; mp_set_chain_max_links)
+  size_t chain_slice = 0;         // tables per pass of chain verification (0 = as many as the free memory holds; mp_set_chain_slice)
+  uint32_t chain_group = 0;       // tables per chain equation (0 = by size, as the groups of mp_set_group_verify; 1 = one table each; mp_set_chain_group)
   uint32_t fs_lanes = 0;          // lanes per transcript hash: 1, 4, or 0 = by batch size (mp_set_transcript_lanes)
   uint32_t group_lanes = 0;       // lanes per group operation of the MSM chains: 1, 4, or 0 = by batch size (mp_set_group_lanes)
   int forced_split = -1;          // work split every batch takes: 0 throughput, 1 latency, 2 medium, 3 finest, 4 wide, 5 small; -1 = by batch size (mp_set_work_split)
@@ -233,6 +235,9 @@ struct mp_table {
   // chain verification: T tables x L links, decks [(L + 1)][T], proofs / status / keys [L][T] (device memory)
   virtual void verify_chain_dev(size_t T, uint32_t L, const uint8_t* decks, const uint8_t* proofs, int32_t* status,
                                 const uint8_t* keys = nullptr) = 0;
+  // bytes of chain workspace a link in flight needs, and the links the workspace holds already (mp_verify_shuffle_chain_dev sizes its passes by them)
+  virtual size_t chain_lane_bytes(uint32_t L, bool keyed) = 0;
+  virtual size_t chain_lanes_held() const = 0;
   virtual void remask_host(size_t count, const uint8_t* cards, const uint8_t* rho, uint8_t* out) = 0;
   virtual void msm_host(size_t n_msm, size_t k, const uint8_t* scalars, const uint8_t* points, uint8_t* out) = 0;
   virtual void commit_host(size_t count, size_t len, const uint8_t* values, const uint8_t* r, uint8_t* out) = 0;

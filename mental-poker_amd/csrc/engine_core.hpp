@@ -1405,7 +1405,7 @@ struct Table : mp_table {
   // MSM (4 424 terms for 32 links of a 52-card deck) is long enough for the bucket kernel.  A table whose chain fails is re-verified
   // link by link, so the per-link status words are exactly those of verify_dev.  T tables, lane of (link j, table t) = j T + t.
   struct ChainPlan {
-    uint32_t L = 0;
+    uint32_t L = 0, G = 0;
     bool keyed = false;
     Phase ph;
     PhaseDev dev;
@@ -1417,38 +1417,68 @@ struct Table : mp_table {
   Workspace cws;                      // lean workspace of chain verification: no window tables, no digit planes
   DevBuf<uint32_t> chain_cw, chain_cs;
   DevBuf<int16_t> chain_d8;
-  void build_chain_plan(uint32_t L, bool keyed) {
-    if (chain.L == L && chain.keyed == keyed) return;
+  // Tables per chain equation (round 5).  One table's chain is 4 424 points for 32 links of a 52-card deck: 8-bit windows (32 per
+  // scalar) and a wave-wide reduction per window that is a sixth of its additions.  The chains of G tables added up with the same kind
+  // of weights (they depend on every proof of every member) are ONE equation of G x 4 424 points: 10-bit windows (26 per scalar), the
+  // reduction spread over G times the terms, the fixed bases once per G tables -- what group verification does for independent proofs.
+  // Member g of equation e is table g (T / G) + e, so that link j of member g is lane (j G + g)(T / G) + e: the plan below is the
+  // chain plan with "links" j G + g and a chain's consecutive links G apart; kernels and lane formula are unchanged.  A failing
+  // equation sends ITS G x L links through the per-link verifier.  G = the divisor of T that brings the equation nearest to the
+  // group equation's size (mp_set_group_verify), with enough equations left to keep the persistent waves busy; 1 = a table on its own.
+  uint32_t chain_points_per_table(uint32_t L, bool keyed) const { return (L + 1) * 2 * N + L * (11 * m + 8) + (keyed ? 1u : 0u); }
+  uint32_t chain_group_of(uint32_t T, uint32_t L, bool keyed) const {
+    if (chain_group == 1 || !group_points) return 1;
+    const uint32_t per = chain_points_per_table(L, keyed);
+    uint32_t want = chain_group;
+    if (!want) {
+      const uint32_t eq_min = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)group_min_batch * 2u) / 13u));
+      want = std::min<uint32_t>((group_points + per / 2) / per, T / eq_min);
+    }
+    if (want < 2) return 1;
+    for (uint32_t d = 0; d <= want; ++d)
+      for (int sgn = 1; sgn >= -1; sgn -= 2) {
+        const int64_t G = (int64_t)want + sgn * (int64_t)d;
+        if (G < 2 || 2 * G < (int64_t)want || G > 2 * (int64_t)want || (uint64_t)G * per + n + 5 > BUCKET_TERMS_MAX || (uint64_t)G * L > 1022) continue;
+        if (T % (uint32_t)G == 0) return (uint32_t)G;
+      }
+    return 1;
+  }
+  void build_chain_plan(uint32_t L, bool keyed, uint32_t G = 1) {
+    if (chain.L == L && chain.keyed == keyed && chain.G == G) return;
     if (keyed) ensure_keyed();
     PlanSet& q = (keyed ? psk : ps)[0];
     const VerifyLay& l = q.vplan.lay;
     chain.ph = Phase();
     chain.cterms.clear();
     chain.L = L;
+    chain.G = G;
     chain.keyed = keyed;
     uint32_t next_partial = 1;                  // J slot 0 = the chain equation's value
-    const uint32_t cbits = bucket_bits_of((L + 1) * 2 * N + L * (l.pk - l.cA) + (keyed ? 1u : 0u));
+    const uint32_t cbits = bucket_bits_of(G * ((L + 1) * 2 * N + L * (l.pk - l.cA) + (keyed ? 1u : 0u)));
     PhaseBuilder pb(chain.ph, next_partial, FCHUNK, VCHUNK, 1u, bk_windows(R::BITS, cbits), 1u, cbits);
     pb.begin(0);
     auto var = [&](ChainTerm ct, uint32_t pslot, uint32_t link) {
       pb.var((uint32_t)chain.cterms.size(), pslot | (link << 20));
       chain.cterms.push_back(ct);
     };
-    for (uint32_t j = 0; j <= L; ++j)
-      for (uint32_t i = 0; i < 2 * N; ++i) {
-        if (j == 0) var(ChainTerm{l.mvar + l.deck + i, 0, 1, NO_SLOT}, l.deck + i, 0);
-        else if (j < L) var(ChainTerm{l.mvar + l.deck + i, j, 1, l.mvar + l.shuf + i}, l.deck + i, j);
-        else var(ChainTerm{l.mvar + l.shuf + i, L - 1, 1, NO_SLOT}, l.shuf + i, L - 1);
-      }
-    for (uint32_t j = 0; j < L; ++j)
-      for (uint32_t slot = l.cA; slot < l.pk; ++slot) var(ChainTerm{l.mvar + slot, j, 1, NO_SLOT}, slot, j);
-    if (keyed) var(ChainTerm{l.mvar + l.pk, 0, L, NO_SLOT}, l.pk, 0);
+    // ("link" j G + g of the equation = link j of member g)
+    for (uint32_t g = 0; g < G; ++g)
+      for (uint32_t j = 0; j <= L; ++j)
+        for (uint32_t i = 0; i < 2 * N; ++i) {
+          if (j == 0) var(ChainTerm{l.mvar + l.deck + i, g, 1, NO_SLOT, G}, l.deck + i, g);
+          else if (j < L) var(ChainTerm{l.mvar + l.deck + i, j * G + g, 1, l.mvar + l.shuf + i, G}, l.deck + i, j * G + g);
+          else var(ChainTerm{l.mvar + l.shuf + i, (L - 1) * G + g, 1, NO_SLOT, G}, l.shuf + i, (L - 1) * G + g);
+        }
+    for (uint32_t j = 0; j < L * G; ++j)
+      for (uint32_t slot = l.cA; slot < l.pk; ++slot) var(ChainTerm{l.mvar + slot, j, 1, NO_SLOT, 1}, slot, j);
+    if (keyed)
+      for (uint32_t g = 0; g < G; ++g) var(ChainTerm{l.mvar + l.pk, g, L, NO_SLOT, G}, l.pk, g);      // one key term per member
     chain.K = (uint32_t)chain.cterms.size();
     FixedBases fb{n};
     for (uint32_t f = 0; f < fb.count(); ++f) {
       if (keyed && f == fb.pk()) continue;
       pb.fixed((uint32_t)chain.cterms.size(), f);
-      chain.cterms.push_back(ChainTerm{l.mfix + f, 0, L, NO_SLOT});
+      chain.cterms.push_back(ChainTerm{l.mfix + f, 0, L * G, NO_SLOT, 1});
     }
     chain.nfix = (uint32_t)chain.cterms.size() - chain.K;
     pb.end();
@@ -1456,10 +1486,20 @@ struct Table : mp_table {
     chain.dev.upload(chain.ph, ctx->stream);
     chain.dterms.upload(chain.cterms, ctx->stream);
   }
+  size_t chain_lane_bytes(uint32_t L, bool keyed) override {
+    build_chain_plan(L, keyed, 1);
+    const VerifyLay& l = (keyed ? psk : ps)[0].vplan.lay;
+    const size_t fwb = (size_t)G_::FW * 4, nJ = std::max(chain.nJ, 8u);
+    // (Workspace::ensure: S, P, J, one window-table row and digit plane it always keeps, inversion scratch, stage, seed, direct, status, digits)
+    return (size_t)l.nS * 32 + (size_t)l.nP * 2 * fwb + nJ * 3 * fwb + nwin + (size_t)VB_ENTRIES * 2 * fwb + nJ * fwb + (size_t)stage_words_needed() * 4 + 32 + 8 + 4 + 8;
+  }
+  size_t chain_lanes_held() const override { return cws.cap; }
   void verify_chain_dev(size_t T_, uint32_t L, const uint8_t* decks, const uint8_t* proofs, int32_t* status, const uint8_t* keys) override {
-    const uint32_t T = (uint32_t)T_, B = T * L, Tpad = (T + 63u) & ~63u;
+    const uint32_t T = (uint32_t)T_, B = T * L;
     const bool keyed = keys != nullptr;
-    build_chain_plan(L, keyed);
+    // G tables per equation: Tq equations of Lq "links" each, lane of (link, equation) = link Tq + equation as before
+    const uint32_t G = chain_group_of(T, L, keyed), Tq = T / G, Lq = L * G, Tpad = (Tq + 63u) & ~63u;
+    build_chain_plan(L, keyed, G);
     PlanSet& q = (keyed ? psk : ps)[0];
     const VerifyLay& l = q.vplan.lay;
     rt::Stream s = ctx->stream;
@@ -1494,33 +1534,33 @@ struct Table : mp_table {
     }
     // the chain equation: weights, one scalar per distinct point / fixed base, ONE bucket MSM + fixed-base part per table
     const uint32_t nterms = chain.K + chain.nfix;
-    chain_cw.alloc((size_t)L * Tpad * 8, s, false);
+    chain_cw.alloc((size_t)Lq * Tpad * 8, s, false);
     chain_cs.alloc((size_t)nterms * Tpad * 8, s);
     chain_d8.alloc((size_t)chain.dev.b_dig_bytes * Tpad, s);
-    ChainWeightsArgs wa{w.seed.p, chain_cw.p, w.Bpad, Tpad, T, L};
-    MP_RUN(k_chain_weights, C, T, 1, wa);
-    ChainScalArgs ca{w.S.p, chain_cw.p, chain_cs.p, chain.dterms.p, w.Bpad, Tpad, T};
-    MP_RUN(k_chain_scalars, C, T, nterms, ca);
+    ChainWeightsArgs wa{w.seed.p, chain_cw.p, w.Bpad, Tpad, Tq, Lq};
+    MP_RUN(k_chain_weights, C, Tq, 1, wa);
+    ChainScalArgs ca{w.S.p, chain_cw.p, chain_cs.p, chain.dterms.p, w.Bpad, Tpad, Tq};
+    MP_RUN(k_chain_scalars, C, Tq, nterms, ca);
     PhaseDev& ph = chain.dev;
-    run_bucket(w, ph, chain_cs.p, Tpad, chain_d8.p, (size_t)ph.b_dig_bytes, T, T, "chain verification: too many tables for one launch");
+    run_bucket(w, ph, chain_cs.p, Tpad, chain_d8.p, (size_t)ph.b_dig_bytes, Tq, Tq, "chain verification: too many tables for one launch");
     FixedArgs fx{chain_cs.p, w.J.p, FB.p, ph.fjobs.p, ph.fterms.p, w.Bpad, fbg, Tpad};
-    MP_RUN(k_fixed_msm, C, T, ph.n_f, fx);
+    MP_RUN(k_fixed_msm, C, Tq, ph.n_f, fx);
     if (ph.n_c0) {
       CombineArgs cb0{w.J.p, w.P.p, ph.cjobs0.p, ph.cterms0.p, w.Bpad};
-      MP_RUN(k_combine, C, T, ph.n_c0, cb0);
+      MP_RUN(k_combine, C, Tq, ph.n_c0, cb0);
     }
     CombineArgs cb{w.J.p, w.P.p, ph.cjobs.p, ph.cterms.p, w.Bpad};
-    MP_RUN(k_combine, C, T, ph.n_c, cb);
-    gbad[0].alloc(T, s, false);
-    ChainVerdictArgs va{w.J.p, w.direct.p, w.status.p, flag_word(false, s), gbad[0].p, w.Bpad, T, L, 0u, w.P.p, keyed ? l.pk : NO_SLOT};
-    MP_RUN(k_chain_verdict, C, T, 1, va);
+    MP_RUN(k_combine, C, Tq, ph.n_c, cb);
+    gbad[0].alloc(Tq, s, false);
+    ChainVerdictArgs va{w.J.p, w.direct.p, w.status.p, flag_word(false, s), gbad[0].p, w.Bpad, Tq, Lq, 0u, w.P.p, keyed ? l.pk : NO_SLOT, G};
+    MP_RUN(k_chain_verdict, C, Tq, 1, va);
     rt::dzero(status, (size_t)B * 4, s);             // every link of every table whose chain equation holds has passed
     if (!read_flag(false)) return;
-    // some table failed: the per-link verifier gives every link of THAT table its exact status (link j of table t: deck row j T + t,
+    // some equation failed: the per-link verifier gives every link of ITS tables its exact status (link j of table t: deck row j T + t,
     // shuffled deck row (j + 1) T + t -- the same index into the array one deck further on); the other tables' verdicts stand
     std::vector<uint32_t> bad, idx;
-    read_words(gbad[0].p, T, bad);
-    group_members(bad.data(), T, L, idx);
+    read_words(gbad[0].p, Tq, bad);
+    group_members(bad.data(), Tq, Lq, idx);
     const VArgs cv{B, decks, decks + (size_t)T * deck_bytes, proofs, status, keys, nullptr, nullptr};
     verify_subset(cv, idx, 0, false);
   }
@@ -1630,14 +1670,14 @@ struct Table : mp_table {
       for (uint32_t slot = 0; slot < l.pk + (keyed ? 1u : 0u); ++slot) {      // decks, proof points [, the proof's own key]
         // (a term's point: its index in the group's contiguous run, or the P slot | member whose lane holds it)
         pb.var((uint32_t)gplan.cterms.size(), bk_tile ? (uint32_t)gplan.cterms.size() : (slot | (j << 20)));
-        gplan.cterms.push_back(ChainTerm{l.mvar + slot, j, 1, NO_SLOT});
+        gplan.cterms.push_back(ChainTerm{l.mvar + slot, j, 1, NO_SLOT, 1});
       }
     gplan.K = (uint32_t)gplan.cterms.size();
     FixedBases fb{n};
     for (uint32_t f = 0; f < fb.count(); ++f) {
       if (keyed && f == fb.pk()) continue;
       pb.fixed((uint32_t)gplan.cterms.size(), f);
-      gplan.cterms.push_back(ChainTerm{l.mfix + f, 0, L, NO_SLOT});
+      gplan.cterms.push_back(ChainTerm{l.mfix + f, 0, L, NO_SLOT, 1});
     }
     gplan.nfix = (uint32_t)gplan.cterms.size() - gplan.K;
     pb.end();
@@ -1734,7 +1774,7 @@ struct Table : mp_table {
     MP_RUN(k_combine, C, T, ph.n_c, cb);
     uint32_t* fl = host_flag;
     if (!fl) fl = flag_word(vlane, s);
-    ChainVerdictArgs va{w.J.p, w.direct.p, w.status.p, fl, gbad_out, w.Bpad, T, L, 0u, w.P.p, NO_SLOT};
+    ChainVerdictArgs va{w.J.p, w.direct.p, w.status.p, fl, gbad_out, w.Bpad, T, L, 0u, w.P.p, NO_SLOT, 1u};
     MP_RUN(k_chain_verdict, C, T, 1, va);
     rt::d2d(v.status, w.status.p, (size_t)B * 4, s);      // zeros unless an input was refused (final if the flag stays down)
   }

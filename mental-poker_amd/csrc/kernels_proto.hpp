@@ -1225,10 +1225,12 @@ MP_HD void body_chain_weights(const ChainWeightsArgs& a, uint32_t t, uint32_t y)
   for (uint32_t j = 0; j < a.L; ++j) st_fe<R>(a.CW + ((size_t)j * a.Tpad + t) * 8, frstream_next<R>(fs));
 }
 MP_KERNEL(k_chain_weights, ChainWeightsArgs, body_chain_weights)
-// (2) scalars of the chain equation: CS[i][t] = sum_{j = j0}^{j0 + cnt - 1} rho_j S[s][lane(j,t)]  (+ rho_{j0-1} S[s2][lane(j0-1,t)]):
-//     a deck between two links carries the scalar of its role as "shuffled deck" of the earlier link plus that as "deck" of the later
+// (2) scalars of the chain equation: CS[i][t] = sum_{k < cnt} rho_j S[s][lane(j,t)], j = j0 + k step  (+ rho_{j0-step} S[s2][lane(j0-step,t)]):
+//     a deck between two links carries the scalar of its role as "shuffled deck" of the earlier link plus that as "deck" of the later.
+//     step = 1: one table per equation.  step = G > 1 (round 5): the chains of G tables share one equation -- link j of member g is
+//     "link" j G + g of the equation, so a chain's consecutive links lie G apart and the lane formula j T + t stays what it is.
 struct ChainTerm {
-  uint32_t s, j0, cnt, s2;
+  uint32_t s, j0, cnt, s2, step;
 };
 struct ChainScalArgs {
   const uint32_t* S;
@@ -1242,11 +1244,11 @@ MP_HD void body_chain_scalars(const ChainScalArgs& a, uint32_t t, uint32_t y) {
   typedef typename C::FrP R;
   const ChainTerm ct = a.terms[y];
   Fe<R> acc = fe_zero<R>();
-  for (uint32_t j = ct.j0; j < ct.j0 + ct.cnt; ++j)
+  for (uint32_t k = 0, j = ct.j0; k < ct.cnt; ++k, j += ct.step)
     acc = fe_add<R>(acc, fe_mul<R>(ld_fe<R>(a.CW + ((size_t)j * a.Tpad + t) * 8), ld_fe<R>(a.S + s_off(ct.s, a.Bpad, j * a.T + t))));
   if (ct.s2 != NO_SLOT)
-    acc = fe_add<R>(acc, fe_mul<R>(ld_fe<R>(a.CW + ((size_t)(ct.j0 - 1) * a.Tpad + t) * 8),
-                                   ld_fe<R>(a.S + s_off(ct.s2, a.Bpad, (ct.j0 - 1) * a.T + t))));
+    acc = fe_add<R>(acc, fe_mul<R>(ld_fe<R>(a.CW + ((size_t)(ct.j0 - ct.step) * a.Tpad + t) * 8),
+                                   ld_fe<R>(a.S + s_off(ct.s2, a.Bpad, (ct.j0 - ct.step) * a.T + t))));
   st_fe<R>(a.CS + ((size_t)y * a.Tpad + t) * 8, acc);
 }
 MP_KERNEL(k_chain_scalars, ChainScalArgs, body_chain_scalars)
@@ -1263,6 +1265,7 @@ struct ChainVerdictArgs {
   // different keys takes the per-link path, where every link is checked against its own key.
   const uint32_t* P;
   uint32_t p_pk;           // NO_SLOT: not keyed
+  uint32_t kstep;          // tables per equation: link j belongs to member j % kstep, whose first link is j % kstep (1: every link to link 0)
 };
 template <class C>
 MP_HD void body_chain_verdict(const ChainVerdictArgs& a, uint32_t t, uint32_t y) {
@@ -1270,8 +1273,8 @@ MP_HD void body_chain_verdict(const ChainVerdictArgs& a, uint32_t t, uint32_t y)
   for (uint32_t j = 0; j < a.L; ++j) bad = bad || a.status[(size_t)j * a.T + t] != 0 || (a.direct[(size_t)j * a.T + t] | a.direct[(size_t)a.Bpad + (size_t)j * a.T + t]) != 0;
   if (a.p_pk != NO_SLOT) {
     uint32_t k0[Geo<C>::PW], kj[Geo<C>::PW];
-    ld_words<Geo<C>::PW>(a.P + p_off<C>(a.p_pk, a.Bpad, t), k0);
-    for (uint32_t j = 1; j < a.L; ++j) {
+    for (uint32_t j = a.kstep; j < a.L; ++j) {
+      ld_words<Geo<C>::PW>(a.P + p_off<C>(a.p_pk, a.Bpad, (j % a.kstep) * a.T + t), k0);
       ld_words<Geo<C>::PW>(a.P + p_off<C>(a.p_pk, a.Bpad, j * a.T + t), kj);
       uint32_t d = 0;
 #pragma unroll

@@ -2,15 +2,20 @@
 against the HIP engine on the GPU box (tests/test_gpu_round4.py) -- same cases, same expectations."""
 
 
-def run_chain_cases(eng, coracle, cvn, m, n, L, T, keyed):
+def run_chain_cases(eng, coracle, cvn, m, n, L, T, keyed, group=0):
     """mp_verify_shuffle_chain: honest chains pass; a bad link gets exactly the per-link verifier's status words; errors that would
     cancel under equal weights are caught; links of one table may name different keys; and a cheating prover whose inner link is made
-    under the table's key while its transcript absorbs another key is rejected exactly as it is link by link."""
+    under the table's key while its transcript absorbs another key is rejected exactly as it is link by link.
+    group > 1 (round 5): the chains of `group` tables share one equation (mp_set_chain_group) -- same verdicts, and a failing equation
+    sends the links of ITS tables through the per-link verifier."""
     N, pb = m * n, eng.point_bytes
     g0 = coracle.gen_inputs(cvn, m, n, 50)
     params = g0["params"]
     keys_t = [coracle.gen_inputs(cvn, m, n, 60 + t)["pk"] for t in range(T)] if keyed else [g0["pk"]] * T
     table = eng.table(m, n, params, None if keyed else g0["pk"])
+    if group > 1:
+        assert T % group == 0
+        table.set_chain_group(group)
     chain = [[coracle.gen_inputs(cvn, m, n, 70 + t)["deck"] for t in range(T)]]     # deck 0 of every table
     proofs = []
     for j in range(L):
@@ -41,7 +46,8 @@ def run_chain_cases(eng, coracle, cvn, m, n, L, T, keyed):
     bad[1 % L][0] = proofs[1 % L][(0 + 1) % T]
     looked = table.reverified_count()
     st = table.verify_shuffle_chain(T, L, decks, b"".join(b"".join(row) for row in bad), keys)
-    assert table.reverified_count() - looked == L      # (round 5) the L links of the failing table were looked at again, nobody else's
+    # (round 5) the L links of the failing table -- of the `group` tables that share its equation -- were looked at again, nobody else's
+    assert table.reverified_count() - looked == L * max(1, group)
     exp = []
     for j in range(L):
         ks = b"".join(keys_t) if keyed else None
@@ -49,6 +55,14 @@ def run_chain_cases(eng, coracle, cvn, m, n, L, T, keyed):
                table.verify_shuffle_batch(b"".join(chain[j]), b"".join(chain[j + 1]), b"".join(bad[j])))
         exp += row
     assert st == exp and st[(1 % L) * T + 0] > 0 and sum(1 for v in st if v) == 1
+    if T > 1:
+        # (round 5) the same call in two passes of T - 1 tables and one (mp_set_chain_slice: rows gathered from the link-major arrays)
+        table.set_chain_slice(T - 1)
+        try:
+            assert table.verify_shuffle_chain(T, L, decks, pf, keys) == [0] * (L * T)
+            assert table.verify_shuffle_chain(T, L, decks, b"".join(b"".join(row) for row in bad), keys) == exp
+        finally:
+            table.set_chain_slice(0)
     # errors that cancel between two links under equal weights are caught: the weights depend on every proof of the chain
     tam = bytearray(decks)
     tam[(1 * T + 0) * N * 2 * pb] ^= 1                 # first byte of deck 1 of table 0: not a curve point any more (or another one)

@@ -544,12 +544,14 @@ def test_toom_cook_and_karatsuba_give_the_same_proof(emu, name):
             assert t.verify_shuffle(args[0], deck, proof) == 0
 
 
-@pytest.mark.parametrize("cvn,m,n,L,T,keyed", [("stark", 2, 3, 4, 3, False), ("stark", 3, 2, 3, 2, True), ("secp256k1", 2, 3, 2, 2, False)])
-def test_chain_verification_under_emulation(emu, coracle, cvn, m, n, L, T, keyed):
+@pytest.mark.parametrize("cvn,m,n,L,T,keyed,group", [("stark", 2, 3, 4, 3, False, 0), ("stark", 3, 2, 3, 2, True, 0), ("secp256k1", 2, 3, 2, 2, False, 0),
+                                                     ("stark", 2, 3, 3, 4, True, 2), ("stark", 2, 3, 4, 3, False, 3)])
+def test_chain_verification_under_emulation(emu, coracle, cvn, m, n, L, T, keyed, group):
     """mp_verify_shuffle_chain: T tables x L dependent shuffles verified as one equation per table (every inner deck a base once);
-    honest chains pass, a chain with one bad link gets exactly the per-link verifier's status words"""
+    honest chains pass, a chain with one bad link gets exactly the per-link verifier's status words; the same with the chains of
+    `group` tables in one equation (mp_set_chain_group)"""
     from chain_cases import run_chain_cases
-    run_chain_cases(emu(cvn), coracle, cvn, m, n, L, T, keyed)
+    run_chain_cases(emu(cvn), coracle, cvn, m, n, L, T, keyed, group)
 
 
 def test_emulated_window_lanes_and_pipelined_verification(emu, coracle):

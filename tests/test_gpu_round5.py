@@ -207,3 +207,75 @@ def test_rejection_fuzz_every_strategy_gives_the_per_equation_verdicts(mp, corac
                 assert got == want, (name, depth, [(b, got[b], want[b]) for b in range(B) if got[b] != want[b]][:5])
     t.close()
     eng.close()
+
+
+@pytest.mark.parametrize("cvn,m,n,L,T,keyed,group", [("stark", 2, 3, 3, 4, True, 2), ("stark", 2, 3, 4, 3, False, 3), ("secp256k1", 2, 3, 2, 4, False, 4)])
+def test_grouped_chain_cases_on_the_hip_engine(mp, coracle, cvn, m, n, L, T, keyed, group):
+    """mp_set_chain_group: the chains of `group` tables in ONE equation -- every case of the chain tests (honest chains, a replaced proof,
+    a tampered inner deck, links of a table under different keys, the cheating prover whose transcript absorbs another key) gives the
+    per-link verifier's status words, and a failing equation sends the links of ITS tables, nobody else's, through the per-link pass"""
+    from chain_cases import run_chain_cases
+    eng = mp._native.Engine(cvn, 0)
+    run_chain_cases(eng, coracle, cvn, m, n, L, T, keyed, group)
+    eng.close()
+
+
+def test_grouped_chains_of_52_card_tables(mp, coracle):
+    """96 tables x 8 dependent shuffles of a 52-card deck, one key per table, the engine's own prover: chain equations of 6 tables each
+    (5 640 points: 8-bit windows), of 24 (22 560: 10-bit windows), by size (nothing to group at 96 tables) and table by table give the
+    same verdicts as the per-link verifier -- all zero for the honest chains, and exactly the replaced proof / the tampered deck's two
+    links otherwise; one link of one table is checked against the oracle"""
+    import random
+    cv, m, n, L, T = "stark", 2, 26, 8, 96
+    N = m * n
+    g0 = coracle.gen_inputs(cv, m, n, 9300)
+    eng = mp._native.Engine(cv, 0)
+    pb = eng.point_bytes
+    t = eng.table(m, n, g0["params"], None)
+    rnd = random.Random(93)
+    keys_t = [coracle.gen_inputs(cv, 2, 2, 9400 + i)["pk"] for i in range(T)]
+    keys = b"".join(keys_t)
+    chain = [b"".join(coracle.gen_inputs(cv, m, n, 9500 + (i % 4))["deck"] for i in range(T))]
+    proofs, wit = [], []
+    for j in range(L):
+        rho = b"".join((rnd.getrandbits(248)).to_bytes(32, "little") for _ in range(T * N))
+        perm = []
+        for _ in range(T):
+            p = list(range(N))
+            rnd.shuffle(p)
+            perm += p
+        seeds = bytes(rnd.getrandbits(8) for _ in range(32 * T))
+        d, p, st = t.shuffle_and_remask_batch_keys(keys, chain[j], rho, perm, seeds)
+        assert st == [0] * T
+        chain.append(d)
+        proofs.append(p)
+        wit.append((rho, perm, seeds))
+    dsz, psz = N * 2 * pb, len(proofs[0]) // T
+    tt, jj = 37, 5
+    rho, perm, seeds = wit[jj]
+    exp = coracle.shuffle_and_remask(cv, m, n, g0["params"], keys_t[tt], chain[jj][tt * dsz:(tt + 1) * dsz], rho[tt * N * 32:(tt + 1) * N * 32],
+                                     perm[tt * N:(tt + 1) * N], seeds[tt * 32:(tt + 1) * 32])
+    assert exp == (chain[jj + 1][tt * dsz:(tt + 1) * dsz], proofs[jj][tt * psz:(tt + 1) * psz])
+    decks, pf, kk = b"".join(chain), b"".join(proofs), keys * L
+    bad = bytearray(pf)
+    o = (3 * T + 50) * psz
+    bad[o:o + psz] = pf[(3 * T + 51) * psz:(3 * T + 52) * psz]          # link 3 of table 50 carries table 51's proof
+    tam = bytearray(decks)
+    tam[(2 * T + 7) * dsz + 40] ^= 4                                     # deck 2 of table 7: links 1 and 2 of that table
+    per_link = []
+    for j in range(L):
+        per_link += t.verify_shuffle_batch_keys(keys, bytes(tam[j * T * dsz:(j + 1) * T * dsz]), bytes(tam[(j + 1) * T * dsz:(j + 2) * T * dsz]),
+                                                bytes(bad[j * T * psz:(j + 1) * T * psz]))
+    assert per_link[3 * T + 50] > 0 and per_link[1 * T + 7] != 0 and per_link[2 * T + 7] != 0 and sum(1 for v in per_link if v) == 3
+    for group, tables_looked_at in ((6, 12), (24, 48), (0, 2), (1, 2)):
+        t.set_chain_group(group)
+        eng.profile_enable(True)
+        assert t.verify_shuffle_chain(T, L, decks, pf, kk) == [0] * (T * L), group
+        rep = eng.profile_report()
+        eng.profile_enable(False)
+        assert rep["k_bucket_msm"][0] == 1 and "k_var_msm" not in rep, (group, rep)
+        looked = t.reverified_count()
+        assert t.verify_shuffle_chain(T, L, bytes(tam), bytes(bad), kk) == per_link, group
+        assert t.reverified_count() - looked == tables_looked_at * L, (group, t.reverified_count() - looked)
+    t.close()
+    eng.close()
