@@ -288,8 +288,12 @@ def main():
                          "(mp_verify_shuffle_chain_dev)")
     ap.add_argument("--chain-max-links", type=int, default=None,
                     help="chain32: links per chain equation (mp_set_chain_max_links; a chain of --players links is verified as consecutive "
-                         "sub-chains, whose 68 KB of workspace per link in flight is what bounds the tables per GPU; default: 32 up to 49 152 "
-                         "tables, 8 beyond)")
+                         "sub-chains; default: the whole chain)")
+    ap.add_argument("--chain-slice", type=int, default=None,
+                    help="chain32: tables per pass of chain verification (mp_set_chain_slice; default: the library's rule -- one pass if the "
+                         "workspace fits the free memory)")
+    ap.add_argument("--chain-group", type=int, default=None,
+                    help="chain32: tables per chain equation (mp_set_chain_group; default: by size, 1 = every table on its own)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = --batch proofs per GPU per step (default); strong = --batch proofs per step in total, 1/N per GPU")
     ap.add_argument("--pipeline", type=int, default=0,
@@ -333,7 +337,7 @@ def main():
     curve = args.curve or ("secp256k1" if workload == "mixed" else "stark")
     m, n = args.m, args.n
     N = m * n
-    B = args.batch if args.batch is not None else (49152 if workload == "chain32" else 262144)
+    B = args.batch if args.batch is not None else (65536 if workload == "chain32" else 262144)
     # (--scaling strong: the batch is the WHOLE job's, every rank takes its contiguous 1/N of the proof indices)
     B, args.seed_block = scaled_batch(B, world, args.scaling, args.seed_block)
     if args.fb_bits is None:
@@ -561,9 +565,14 @@ def main():
             G -= 1
         kk = keys.repeat(G, 1).contiguous()
         keyless.reserve(T if chain_verify else max(T, G * T))
-        chain_links = args.chain_max_links if args.chain_max_links is not None else (L if T <= 49152 else 8)
+        chain_links = args.chain_max_links if args.chain_max_links is not None else L
         if chain_verify and chain_links < L:
             keyless.set_chain_max_links(chain_links)
+        if args.chain_slice is not None:
+            keyless.set_chain_slice(args.chain_slice)
+        if args.chain_group is not None:
+            keyless.set_chain_group(args.chain_group)
+        extras["chain_links_per_equation"] = min(L, chain_links) if chain_verify else None
         kset = None
         if not args.no_keyset:
             kset = make_keyset(keyless, T, T)       # one key per table, prepared once (a table keeps its key across hands)
@@ -591,7 +600,7 @@ def main():
         proofs_per_step = T * L
         units = ("prove+verify pairs (%d tables x %d dependent shuffles, %d proofs per prove launch; keys: %s; verification: %s)"
                  % (T, L, T, "one key set of %d keys prepared before the timed region (mp_keyset_create)" % T if kset is not None
-                    else "passed with every call", "one chain equation per table (mp_verify_shuffle_chain_dev)" if chain_verify
+                    else "passed with every call", "chain equations over all links, the chains of several tables per equation (mp_verify_shuffle_chain_dev; config.chain_tables_per_equation)" if chain_verify
                     else "%d proofs per launch, link by link" % (G * T)))
 
         def check():
@@ -870,6 +879,13 @@ def main():
     gl = 0
     if workload in ("pairs", "mixed") and not args.per_equation and args.keyed == 0:
         gl = table.group_size(Bs if workload == "pairs" else B // 2)
+    # chain verification (mp_set_chain_group / mp_set_chain_slice): the chains of chain_G tables share one equation, a call's tables go in
+    # passes of chain_pass tables (what the free memory holds of the 68 KB of workspace per link in flight)
+    chain_G, chain_pass = 1, None
+    if workload == "chain32" and not args.per_link_verify:
+        chain_pass = table.chain_last_slice() or B
+        chain_G = max(1, table.chain_group_size(chain_pass, extras["chain_links_per_equation"], True))
+        extras["chain_tables_per_equation"], extras["chain_tables_per_pass"] = chain_G, chain_pass
     SCALAR_BITS = {"stark": 252, "bn254": 254, "secp256k1": 256, "bls12_377": 253}[curve]
 
     def bucket_geometry(K):
@@ -930,12 +946,15 @@ def main():
             if side == "verify" and chain_eq:
                 # one chain equation per table instead of L per-link equations (engine_core.hpp build_chain_plan): a bucket MSM
                 # over the (L+1) decks, the L proofs' points and the key, plus one fixed-base term per shared generator
-                L_ = args.players
-                k_terms = (L_ + 1) * 2 * N + L_ * (11 * m + 7) + 1
-                bwc = {"secp256k1": 33}.get(curve, 32)
+                # (round 5: the chains of chain_G tables in one equation; a chain longer than --chain-max-links in consecutive sub-chains)
+                L_, lc_ = args.players, extras["chain_links_per_equation"]
+                nsub_ = (L_ + lc_ - 1) // lc_
+                k_terms = (lc_ + 1) * 2 * N + lc_ * (11 * m + 7) + 1
+                geo_c = bucket_geometry(chain_G * k_terms)
+                bwc = geo_c["windows"]
                 fmc = mc["field"]
-                red = 14 * 64 * (12 * fmc["mul"] + 2 * fmc["sqr"]) + 8 * mc["dbl"] + mc["jac"]
-                mads_per_proof += (k_terms * bwc * mc["madd"] + bwc * red + (n + 2) * fw * mc["madd"]) / L_
+                red = geo_c["reduction_adds"] * 64 * (12 * fmc["mul"] + 2 * fmc["sqr"]) + geo_c["bits"] * mc["dbl"] + mc["jac"]
+                mads_per_proof += nsub_ * (k_terms * bwc * mc["madd"] + (bwc * red + (n + 2) * fw * mc["madd"]) / chain_G) / L_
                 continue
             fixed_madds = st_["fixed_terms"] * fw
             if side == "prove":
@@ -1006,9 +1025,10 @@ def main():
             ops = {"madd": 2 * N * (fw + 1)}
         elif dom_name == "k_bucket_msm" and "xadd" in iss:
             if workload == "chain32" and not args.per_link_verify:
-                L_ = args.players
-                kc_ = (L_ + 1) * 2 * N + L_ * (11 * m + 7) + 1
-                parts_ = [(kc_ / L_, 1.0 / L_, bucket_geometry(kc_))]
+                L_, lc_ = args.players, extras["chain_links_per_equation"]
+                nsub_ = (L_ + lc_ - 1) // lc_
+                kc_ = (lc_ + 1) * 2 * N + lc_ * (11 * m + 7) + 1
+                parts_ = [(nsub_ * kc_ / L_, nsub_ / (chain_G * L_), bucket_geometry(chain_G * kc_))]
             else:
                 parts_ = [(stats.get("bucket_terms", 0), stats.get("bucket_jobs", 0), geo_own)]
                 if geo_grp:

@@ -272,6 +272,10 @@ int mp_set_chain_group(mp_table* t, uint32_t tables_per_equation);
  * memory, equal passes of whole thousands of tables otherwise; the rows of a pass are gathered from the link-major arrays on the device
  * (one copy per link and array).  Verdicts do not depend on it. */
 int mp_set_chain_slice(mp_table* t, size_t tables_per_pass);
+/* What a chain call does under the current settings: tables per equation for a pass of `tables` tables x `links` links (1 = every table
+ * on its own), and the tables per pass the last mp_verify_shuffle_chain[_dev] call on this table took (0 = none yet). */
+uint32_t mp_chain_group_size(const mp_table* t, size_t tables, uint32_t links, int keyed);
+size_t mp_chain_last_slice(const mp_table* t);
 /* Lanes per Fiat-Shamir transcript.  A proof's transcript is one BLAKE2s chain (13.6 KB of statement for a 52-card deck): 1 = one
  * lane per proof (what a batch that fills the chip wants), 4 = the four G functions of a half-round on four adjacent lanes (2.7x
  * fewer instructions in the chain: what a single proof or a few thousand large decks wait for), 0 (default) = 4 for batches of up

@@ -16,7 +16,7 @@ MP_ERR_BAD_ENCODING, MP_ERR_BAD_PERMUTATION, MP_ERR_BAD_ARGUMENT, MP_ERR_NO_DEVI
 
 SYMBOLS = [
     "mp_ctx_create", "mp_ctx_destroy", "mp_last_error", "mp_check_name", "mp_proof_size", "mp_params_size",
-    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_set_subgroup_check", "mp_set_bucket_min", "mp_set_bucket_bits", "mp_set_chain_max_links", "mp_set_chain_group", "mp_set_chain_slice", "mp_set_transcript_lanes", "mp_set_group_lanes", "mp_set_work_split", "mp_set_group_verify", "mp_group_size", "mp_set_group_refine", "mp_reverified_count", "mp_set_group_adapt", "mp_set_pipeline", "mp_set_plan_params", "mp_set_plan_thresholds", "mp_set_toom_cook", "mp_host_alloc", "mp_host_free", "mp_set_io_chunk", "mp_shuffle_and_remask_batch_keys", "mp_table_create_params",
+    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_set_subgroup_check", "mp_set_bucket_min", "mp_set_bucket_bits", "mp_set_chain_max_links", "mp_set_chain_group", "mp_set_chain_slice", "mp_chain_group_size", "mp_chain_last_slice", "mp_set_transcript_lanes", "mp_set_group_lanes", "mp_set_work_split", "mp_set_group_verify", "mp_group_size", "mp_set_group_refine", "mp_reverified_count", "mp_set_group_adapt", "mp_set_pipeline", "mp_set_plan_params", "mp_set_plan_thresholds", "mp_set_toom_cook", "mp_host_alloc", "mp_host_free", "mp_set_io_chunk", "mp_shuffle_and_remask_batch_keys", "mp_table_create_params",
     "mp_verify_shuffle_batch_keys", "mp_shuffle_and_remask_batch_keys_dev", "mp_verify_shuffle_batch_keys_dev",
     "mp_keyset_create", "mp_keyset_destroy", "mp_keyset_size", "mp_shuffle_and_remask_batch_keyset_dev", "mp_verify_shuffle_batch_keyset_dev",
     "mp_setup", "mp_table_create", "mp_table_create_ex", "mp_table_window_bits", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
@@ -129,6 +129,10 @@ def bind(cdll):
     cdll.mp_set_chain_max_links.argtypes = [c.c_void_p, c.c_uint32]
     cdll.mp_set_chain_group.argtypes = [c.c_void_p, c.c_uint32]
     cdll.mp_set_chain_slice.argtypes = [c.c_void_p, c.c_size_t]
+    cdll.mp_chain_group_size.argtypes = [c.c_void_p, c.c_size_t, c.c_uint32, c.c_int]
+    cdll.mp_chain_group_size.restype = c.c_uint32
+    cdll.mp_chain_last_slice.argtypes = [c.c_void_p]
+    cdll.mp_chain_last_slice.restype = c.c_size_t
     cdll.mp_set_transcript_lanes.argtypes = [c.c_void_p, c.c_uint32]
     cdll.mp_set_group_lanes.argtypes = [c.c_void_p, c.c_uint32]
     cdll.mp_set_work_split.argtypes = [c.c_void_p, c.c_int]
@@ -609,6 +613,14 @@ class Table:
     def set_chain_slice(self, tables_per_pass):
         """chain verification in passes of this many tables (0 = one pass if its workspace fits the free memory)"""
         self.eng._chk(self.lib.mp_set_chain_slice(self.h, tables_per_pass))
+
+    def chain_group_size(self, tables, links, keyed=False):
+        """tables per chain equation a pass of `tables` tables x `links` links takes under the current settings"""
+        return int(self.lib.mp_chain_group_size(self.h, tables, links, 1 if keyed else 0))
+
+    def chain_last_slice(self):
+        """tables per pass of the last chain verification call on this table"""
+        return int(self.lib.mp_chain_last_slice(self.h))
 
     def set_chain_group(self, tables_per_equation):
         """chain verification: tables per chain equation (0 = by size, 1 = every table on its own)"""

@@ -351,6 +351,17 @@ int mp_set_group_verify(mp_table* t, uint32_t points_per_group, size_t min_batch
   MP_CATCH
 }
 uint32_t mp_group_size(const mp_table* t, size_t B) { return t ? t->group_size_of(B) : 0; }
+uint32_t mp_chain_group_size(const mp_table* t, size_t tables, uint32_t links, int keyed) {
+  if (!t || !tables || !links) return 0;
+  // (as mp_verify_shuffle_chain_dev cuts the chain: the sub-chains of a long chain are equations of their own)
+  const size_t per_link = (size_t)2 * t->N + 11 * t->m + 8, fixed_part = (size_t)2 * t->N + 1;
+  const size_t eq_cap = fixed_part + per_link > 32767 ? BUCKET_TERMS_MAX : 32767;
+  if (fixed_part + per_link > eq_cap) return 0;
+  uint32_t lmax = std::min<uint32_t>((uint32_t)((eq_cap - fixed_part) / per_link), 1022u);
+  if (t->chain_max_links) lmax = std::max(1u, std::min(lmax, t->chain_max_links));
+  return t->chain_group_size(tables, std::min(lmax, links), keyed != 0);
+}
+size_t mp_chain_last_slice(const mp_table* t) { return t ? t->chain_last_slice : 0; }
 int mp_set_pipeline(mp_table* t, int depth) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_pipeline: null table");
   MP_TRY
@@ -543,6 +554,7 @@ int mp_verify_shuffle_chain_dev(mp_table* t, size_t tables, uint32_t links, cons
       slice = std::min(tables, ((tables + passes - 1) / passes + 1023) / 1024 * 1024);
     }
   }
+  t->chain_last_slice = std::min(slice, tables);
   if (slice >= tables) {
     sub_chains(tables, (const uint8_t*)d_decks, (const uint8_t*)d_proofs, (int32_t*)d_status, (const uint8_t*)d_keys);
     return MP_OK;

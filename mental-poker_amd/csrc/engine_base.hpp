@@ -238,6 +238,8 @@ struct mp_table {
   // bytes of chain workspace a link in flight needs, and the links the workspace holds already (mp_verify_shuffle_chain_dev sizes its passes by them)
   virtual size_t chain_lane_bytes(uint32_t L, bool keyed) = 0;
   virtual size_t chain_lanes_held() const = 0;
+  virtual uint32_t chain_group_size(size_t T, uint32_t L, bool keyed) const = 0;
+  size_t chain_last_slice = 0;    // tables per pass of the last mp_verify_shuffle_chain_dev call (mp_chain_plan)
   virtual void remask_host(size_t count, const uint8_t* cards, const uint8_t* rho, uint8_t* out) = 0;
   virtual void msm_host(size_t n_msm, size_t k, const uint8_t* scalars, const uint8_t* points, uint8_t* out) = 0;
   virtual void commit_host(size_t count, size_t len, const uint8_t* values, const uint8_t* r, uint8_t* out) = 0;

@@ -1494,6 +1494,7 @@ struct Table : mp_table {
     return (size_t)l.nS * 32 + (size_t)l.nP * 2 * fwb + nJ * 3 * fwb + nwin + (size_t)VB_ENTRIES * 2 * fwb + nJ * fwb + (size_t)stage_words_needed() * 4 + 32 + 8 + 4 + 8;
   }
   size_t chain_lanes_held() const override { return cws.cap; }
+  uint32_t chain_group_size(size_t T, uint32_t L, bool keyed) const override { return T < 0x7FFFFFFFu ? chain_group_of((uint32_t)T, L, keyed) : 1u; }
   void verify_chain_dev(size_t T_, uint32_t L, const uint8_t* decks, const uint8_t* proofs, int32_t* status, const uint8_t* keys) override {
     const uint32_t T = (uint32_t)T_, B = T * L;
     const bool keyed = keys != nullptr;

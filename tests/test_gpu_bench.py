@@ -96,12 +96,15 @@ def test_batch_curve_on_the_line():
 
 @pytest.mark.parametrize("workload,extra", [("chain32", ["--batch", "256", "--players", "4"]),
                                             ("chain32", ["--batch", "256", "--players", "4", "--per-link-verify"]),
+                                            ("chain32", ["--batch", "256", "--players", "4", "--chain-slice", "96", "--chain-group", "4"]),
                                             ("mixed", ["--batch", "512"])])
 def test_workload_modes(workload, extra):
     d = run_bench("--workload", workload, "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--fb-bits", "8", *extra)
     assert d["config"]["workload"].startswith(workload) and d["config"]["parity_vs_oracle"] is True and d["value"] > 0
     if workload == "mixed":
         assert "secp256k1" in d["config"]["workload"]
+    if "--chain-group" in extra:      # (round 5) passes of 96, 96 and 64 tables, the chains of 4 tables per equation
+        assert d["config"]["chain_tables_per_equation"] == 4 and d["config"]["chain_tables_per_pass"] == 96
 
 
 @pytest.mark.parametrize("workload,extra,per_rank", [("chain32", ["--batch", "96", "--players", "32"], 96 * 32), ("mixed", ["--batch", "384"], 192)])
