@@ -286,6 +286,10 @@ def main():
     ap.add_argument("--per-link-verify", action="store_true",
                     help="chain32: verify every link on its own (mp_verify_shuffle_batch_keys_dev) instead of one chain equation per table "
                          "(mp_verify_shuffle_chain_dev)")
+    ap.add_argument("--no-subgroup-check", action="store_true",
+                    help="curves with a cofactor (bls12_377): skip the per-point subgroup test of the wire points (mp_set_subgroup_check off) -- the "
+                         "reference's shuffle_and_remask / verify_shuffle take typed points that were validated when they were deserialised "
+                         "[REF examples/parameter_selection.rs:78-91], so this is its like-for-like; the default keeps the test")
     ap.add_argument("--chain-max-links", type=int, default=None,
                     help="chain32: links per chain equation (mp_set_chain_max_links; a chain of --players links is verified as consecutive "
                          "sub-chains; default: the whole chain)")
@@ -392,6 +396,8 @@ def main():
             t.set_work_split(args.work_split)
         if args.group_lanes is not None:
             t.set_group_lanes(args.group_lanes)
+        if args.no_subgroup_check:
+            t.set_subgroup_check(False)
     table = tables[0]
     proof_bytes = table.proof_bytes
 
@@ -1188,6 +1194,7 @@ def main():
               "parallelism": "%d rank(s), proofs sharded, no data-path collective; parameters broadcast once (%s)" % (world, backend),
               "rccl_world": (dist.get_world_size() if world > 1 else 1), "collective_backend": backend if world > 1 else None,
               "rccl_smoke": smoke_log, "pipeline_depth": args.pipeline,
+              "subgroup_check": (not args.no_subgroup_check) if curve == "bls12_377" else None,
               "table_build_s": round(table_build_s, 3),
               "hbm_per_rank_gb": hbm_used_gb,
               "per_rank_proofs": [int(r[0]) for r in rows], "per_rank_failed": [int(r[1]) for r in rows],

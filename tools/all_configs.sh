@@ -12,6 +12,9 @@ python bench.py $X --m 16 --n 64 --batch 16384 > $O/s16_64.json 2>>$O/err.txt
 python bench.py $X --m 32 --n 32 --batch 8192 > $O/s32_32.json 2>>$O/err.txt
 python bench.py $X --curve bls12_377 --m 10 --n 30 --batch 4096 > $O/bls_10_30.json 2>>$O/err.txt
 python bench.py $X --curve bls12_377 --m 10 --n 30 --batch 4096 --pipeline 1 > $O/bls_10_30_p1.json 2>>$O/err.txt
+# (the reference's like-for-like: its verify_shuffle takes typed points, validated when they were deserialised -- no subgroup test in the call)
+python bench.py $X --curve bls12_377 --m 10 --n 30 --batch 4096 --no-subgroup-check > $O/bls_10_30_nosub.json 2>>$O/err.txt
+python bench.py $X --curve bls12_377 --m 10 --n 30 --batch 4096 --no-subgroup-check --group-points 30464 > $O/bls_10_30_nosub_groups.json 2>>$O/err.txt
 python tools/latency.py > $O/latency.txt 2>>$O/err.txt
 python examples/parameter_selection.py > $O/parameter_selection.txt 2>>$O/err.txt
 python - <<PY
