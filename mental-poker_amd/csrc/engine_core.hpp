@@ -989,6 +989,12 @@ struct Table : mp_table {
       FillConstArgs fa{w.S.p, q.consts.p, w.Bpad, tk.w_first, tk.w_const_first};
       MP_RUN(k_fill_consts, C, B, tk.E * tk.E, fa);
     }
+    if (keyed) {      // tau_k pk, k < 2m, from the key's own tables (the proof's, or its key set's): finished partial sums of the E_k
+      KeyTermsArgs ka{w.S.p, w.J.p, w.Bpad, l.metau, q.pplan.jkey, kset ? 2u : 1u, w.T.p, key_t_first, nwin,
+                      kset ? kset->FB.p : nullptr, kidx, kset ? FbGeom{kset->bits, kset->windows, kset->entries} : FbGeom{8, 32, 255},
+                      kset ? (uint32_t)kset->K : 0u};
+      MP_RUN(k_key_terms, C, B, 2 * m, ka);
+    }
     if (overlap) {
       rt::stream_wait(s, ctx->ev_tab);
       side_guard.joined = true;

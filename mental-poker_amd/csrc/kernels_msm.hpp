@@ -242,6 +242,58 @@ MP_HD void body_remask(const RemaskArgs& a, uint32_t b, uint32_t y) {
 }
 MP_KERNEL_OCC(k_remask, RemaskArgs, body_remask, Geo<C>::OCC4)
 
+// ---- keyed batches: the products tau_k pk of the multi-exponentiation diagonals E_k (round 5) ---------------------------------
+// A keyed proof's aggregate key is a per-proof point.  Its 2m products tau_k pk used to be one-term Straus jobs -- a 16-entry table and
+// 250 doublings each for 51 additions, + 7 % on k_var_msm of every keyed batch (chain32, --keyed).  The key's multiples are there
+// already: the proof's own window tables (entries 1 .. 16 of 2^(5w) pk, built for the re-encryption) or the key set's fixed-base
+// tables.  y = k; the sum goes to J slot j_first + k, which the plan adds to E_k as a finished partial sum (layout.hpp, jkey).
+struct KeyTermsArgs {
+  const uint32_t* S;
+  uint32_t* J;
+  uint32_t Bpad, s_first, j_first;
+  uint32_t keyed;        // 1: the proof's own window tables T[t_first + w]; 2: the key set's tables KFB[kidx[b]]
+  const uint32_t* T;
+  uint32_t t_first, nwin;
+  const uint32_t* KFB;
+  const uint32_t* kidx;
+  FbGeom kg;
+  uint32_t nkeys;
+};
+template <class C>
+MP_HD void body_key_terms(const KeyTermsArgs& a, uint32_t b, uint32_t y) {
+  typedef typename C::FrP R;
+  uint32_t k[8];
+  fe_to_canonical<R>(ld_fe<R>(a.S + s_off(a.s_first + y, a.Bpad, b)), k);
+  Xyzz<C> acc = xyzz_inf<C>();
+  if (a.keyed == 2) {
+    uint32_t key = a.kidx[b];
+    if (key >= a.nkeys) key = 0;      // reported through the status word (k_gather_keys)
+#pragma unroll 1
+    for (uint32_t w = 0; w < a.kg.windows; ++w) {
+      const uint32_t d = fb_digit(k, a.kg, w);
+      if (d) xyzz_madd_ip<C>(acc, ld_aff<C>(fb_entry<C>(a.KFB, a.kg, key, w, d)));
+    }
+  } else {
+    // signed 5-bit digits on the fly: v = window + carry in [0, 32]; v > 16 becomes v - 32 with a carry into the next window
+    uint32_t carry = 0;
+#pragma unroll 1
+    for (uint32_t w = 0; w < a.nwin; ++w) {
+      const uint32_t bit = w * VB_WINDOW_BITS, word = bit >> 5, off = bit & 31;
+      uint32_t v = word < 8 ? k[word] >> off : 0u;
+      if (off + VB_WINDOW_BITS > 32 && word < 7) v |= k[word + 1] << (32 - off);
+      v = (v & ((1u << VB_WINDOW_BITS) - 1u)) + carry;
+      carry = v > (1u << (VB_WINDOW_BITS - 1)) ? 1u : 0u;
+      const int d = carry ? (int)v - (1 << VB_WINDOW_BITS) : (int)v;
+      if (d != 0) {
+        const uint32_t e = (uint32_t)(d < 0 ? -d : d) - 1;
+        xyzz_madd_signed_ip<C>(acc, ld_aff<C>(a.T + p_off<C>((a.t_first + w) * VB_ENTRIES + e, a.Bpad, b)), d < 0);
+      }
+    }
+  }
+  st_jac<C>(a.J + j_off<C>(a.j_first + y, a.Bpad, b), xyzz_to_jac<C>(acc));
+}
+MP_KERNEL_OCC(k_key_terms, KeyTermsArgs, body_key_terms, Geo<C>::OCC4)
+
 // ---- key sets: the wire bytes of key kidx[b] for proof b (x = proof, y = 32-bit word of the point)
 struct GatherKeysArgs {
   const uint32_t* wire;   // [nkeys][PB / 4]
@@ -766,6 +818,7 @@ MP_KERNEL(k_fb_widen, FbWidenArgs, body_fb_widen)
   MP_KERNEL_INST(X, k_fixed_msm, FixedArgs, C) \
   MP_KERNEL_INST(X, k_remask, RemaskArgs, C) \
   MP_KERNEL_INST(X, k_key_windows, KeyWinArgs, C) \
+  MP_KERNEL_INST(X, k_key_terms, KeyTermsArgs, C) \
   MP_KERNEL_INST(X, k_gather_keys, GatherKeysArgs, C) \
   MP_KERNEL_INST(X, k_recode, RecodeArgs, C) \
   MP_KERNEL_INST(X, k_table, TableArgs, C) \

@@ -410,6 +410,7 @@ struct ProvePlan {
   Phase ph[6];          // A (cA), B (cB + multi-exp first message), C (product first messages), D (zero argument),
                         // [4] = A2: Toom-Cook / Karatsuba operand sums, run between A and B; [5] = B2: Toom-Cook interpolation
   uint32_t nJ;          // J arena slots (nP + partial sums)
+  uint32_t jkey = NO_SLOT;   // keyed plans: J slots of tau_k pk, k < 2m (k_key_terms, before phase B)
   std::vector<uint32_t> draws;
   std::vector<ProofElem> wire;
 };
@@ -495,8 +496,10 @@ static inline std::vector<KLeaf> k_merge(const std::vector<KLeaf>& in) {
   return out;
 }
 
-// keyed: the aggregate key is a per-proof point (P slot lay.pk) instead of the table's fixed base: its terms become
-// variable-base terms (the re-encryption uses the key's own window tables, kernels_msm.hpp body_remask)
+// keyed: the aggregate key is a per-proof point (P slot lay.pk) instead of the table's fixed base.  The re-encryption uses the key's
+// own window tables (kernels_msm.hpp body_remask), and so do the 2m products tau_k pk of the multi-exponentiation diagonals since
+// round 5 (k_key_terms writes them to the J slots jkey + k before phase B; until then each was a one-term Straus job with a
+// 250-doubling chain of its own: + 7 % on k_var_msm of every keyed batch)
 static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk, uint32_t vchunk, uint32_t point_bytes = 64,
                                         bool keyed = false, uint32_t bucket_min = 0, uint32_t bwin = 0, bool toom_cook = true,
                                         uint32_t vsplit = 1, uint32_t bbits = 8) {
@@ -565,6 +568,10 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
   const ProveLay& l = pl.lay;
   FixedBases fb{n};
   uint32_t next_partial = l.nP;
+  if (keyed) {
+    pl.jkey = next_partial;
+    next_partial += 2 * m;
+  }
   auto commit = [&](PhaseBuilder& B, uint32_t out, uint32_t vec, uint32_t len, uint32_t rslot) {
     B.begin(out);
     for (uint32_t j = 0; j < len; ++j) B.fixed(vec + j, fb.ck(j));
@@ -635,7 +642,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
             B.fixed(l.metau + k, fb.G());
           } else {
             B.fixed(l.meb + k, fb.gen());
-            if (keyed) B.var(l.metau + k, l.pk); else B.fixed(l.metau + k, fb.pk());
+            if (keyed) B.addend_j(pl.jkey + k); else B.fixed(l.metau + k, fb.pk());
           }
           if (k == 0) B.addend_j(v0);
           if (k == 3) B.addend_j(vinf);
@@ -672,7 +679,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
             B.fixed(l.metau + k, fb.G());
           } else {
             B.fixed(l.meb + k, fb.gen());
-            if (keyed) B.var(l.metau + k, l.pk); else B.fixed(l.metau + k, fb.pk());
+            if (keyed) B.addend_j(pl.jkey + k); else B.fixed(l.metau + k, fb.pk());
           }
           for (size_t i = 0; i < leaves.size(); ++i) {
             auto it = leaves[i].contrib.find(k);
@@ -691,7 +698,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
           B.fixed(l.metau + k, fb.G());
         } else {
           B.fixed(l.meb + k, fb.gen());
-          if (keyed) B.var(l.metau + k, l.pk); else B.fixed(l.metau + k, fb.pk());
+          if (keyed) B.addend_j(pl.jkey + k); else B.fixed(l.metau + k, fb.pk());
         }
         for (uint32_t i = 1; i <= m; ++i) {
           int64_t j = (int64_t)k - (int64_t)m + (int64_t)i;
@@ -716,7 +723,7 @@ static inline ProvePlan make_prove_plan(uint32_t m, uint32_t n, uint32_t fchunk,
           B.fixed(l.metau + k, fb.G());
         } else {
           B.fixed(l.meb + k, fb.gen());
-          if (keyed) B.var(l.metau + k, l.pk); else B.fixed(l.metau + k, fb.pk());
+          if (keyed) B.addend_j(pl.jkey + k); else B.fixed(l.metau + k, fb.pk());
         }
         if (k == 0) {
           B.addend(T.pp_first + c);
