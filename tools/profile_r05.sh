@@ -6,6 +6,10 @@ T=r05
 bash tools/profile_round.sh ${T}_default all -- --steps 3 --warmup 1 > gpurun_out/${T}_default.log 2>&1
 bash tools/profile_round.sh ${T}_default_steps20 bench -- --steps 20 --warmup 3 >> gpurun_out/${T}_default.log 2>&1
 bash tools/profile_round.sh ${T}_s8_128 all -- --m 8 --n 128 --batch 16384 --steps 2 --warmup 1 --no-extras > gpurun_out/${T}_s8_128.log 2>&1
+# BASELINE config 3 (chain32: 65 536 tables x 32 links, 8 tables per chain equation, passes of ~22 000 tables)
+bash tools/profile_round.sh ${T}_chain32 all -- --workload chain32 --steps 1 --warmup 1 --no-extras > gpurun_out/${T}_chain32.log 2>&1
+# the default step with the verify calls on the second lane (mp_set_pipeline): what filling the tails of the large launches is worth
+python bench.py --pipeline 1 --no-extras --no-cpu-baseline > gpurun_out/${T}_default_pipelined_bench.json 2> /dev/null
 # the bucket kernel's L2 hit rate without the XCD-affine items / without the contiguous point runs (same box, same pass)
 for v in "MP_BK_XCD=0" "MP_BK_TILE=0 MP_BK_XCD=0"; do
   tag=$(echo "$v" | tr ' =' '__')
