@@ -1492,10 +1492,12 @@ struct Table : mp_table {
     chain.dev.upload(chain.ph, ctx->stream);
     chain.dterms.upload(chain.cterms, ctx->stream);
   }
-  size_t chain_lane_bytes(uint32_t L, bool keyed) override {
-    build_chain_plan(L, keyed, 1);
+  size_t chain_lane_bytes(uint32_t, bool keyed) override {
+    if (keyed) ensure_keyed();
     const VerifyLay& l = (keyed ? psk : ps)[0].vplan.lay;
-    const size_t fwb = (size_t)G_::FW * 4, nJ = std::max(chain.nJ, 8u);
+    // J slots of a chain plan: the equation's value, the bucket job's result and one partial sum per window (at most 33 of 8 bits), the
+    // fixed-base part -- whatever the number of links or of tables per equation (build_chain_plan; Workspace::ensure takes at least 8)
+    const size_t fwb = (size_t)G_::FW * 4, nJ = 4 + bk_windows(R::BITS, 8);
     // (Workspace::ensure: S, P, J, one window-table row and digit plane it always keeps, inversion scratch, stage, seed, direct, status, digits)
     return (size_t)l.nS * 32 + (size_t)l.nP * 2 * fwb + nJ * 3 * fwb + nwin + (size_t)VB_ENTRIES * 2 * fwb + nJ * fwb + (size_t)stage_words_needed() * 4 + 32 + 8 + 4 + 8;
   }
