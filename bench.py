@@ -312,6 +312,8 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
+    # (the host driver only supports dmabuf IPC: without this RCCL fails with hipIpcGetMemHandle; exported on the GPU boxes, set here too)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     rank, world, local = dist_info()
