@@ -13,9 +13,11 @@ def run_chain_cases(eng, coracle, cvn, m, n, L, T, keyed, group=0):
     params = g0["params"]
     keys_t = [coracle.gen_inputs(cvn, m, n, 60 + t)["pk"] for t in range(T)] if keyed else [g0["pk"]] * T
     table = eng.table(m, n, params, None if keyed else g0["pk"])
+    assert table.chain_group_size(T, L, keyed) == 1       # by size: a handful of tables has nothing to group
     if group > 1:
         assert T % group == 0
         table.set_chain_group(group)
+        assert table.chain_group_size(T, L, keyed) == group
     chain = [[coracle.gen_inputs(cvn, m, n, 70 + t)["deck"] for t in range(T)]]     # deck 0 of every table
     proofs = []
     for j in range(L):
@@ -61,6 +63,7 @@ def run_chain_cases(eng, coracle, cvn, m, n, L, T, keyed, group=0):
         try:
             assert table.verify_shuffle_chain(T, L, decks, pf, keys) == [0] * (L * T)
             assert table.verify_shuffle_chain(T, L, decks, b"".join(b"".join(row) for row in bad), keys) == exp
+            assert table.chain_last_slice() == T - 1
         finally:
             table.set_chain_slice(0)
     # errors that cancel between two links under equal weights are caught: the weights depend on every proof of the chain
