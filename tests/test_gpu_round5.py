@@ -279,3 +279,15 @@ def test_grouped_chains_of_52_card_tables(mp, coracle):
         assert t.reverified_count() - looked == tables_looked_at * L, (group, t.reverified_count() - looked)
     t.close()
     eng.close()
+
+
+@pytest.mark.parametrize("extra", [[], ["--keyset"], ["--chain-verify", "--keyset"]])
+def test_tournament_example_runs(extra):
+    """BASELINE config 3 as a script (examples/tournament.py): 384 card tables x 4 players, one aggregate key per table (passed with
+    every call, or prepared once as a key set), every shuffle proved and verified -- link by link, or the tables' chains at the end
+    (one chain equation per table at this size: groups of tables from ~2 000 tables on) -- and table 0's chain byte-identical to the CPU oracle under that table's key"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "tournament.py"), "--tables", "384", "--players", "4", "--check"] + extra,
+                         cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    text = out.stdout.decode()
+    assert "1536 shuffles proved and verified" in text and "table 0: all 4 shuffles byte-identical to the CPU oracle" in text, text
