@@ -291,3 +291,16 @@ def test_tournament_example_runs(extra):
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     text = out.stdout.decode()
     assert "1536 shuffles proved and verified" in text and "table 0: all 4 shuffles byte-identical to the CPU oracle" in text, text
+
+
+def test_parameter_selection_example_runs():
+    """the reference's only benchmark harness [REF examples/parameter_selection.rs:25-96] as a script on the engine (row f3): BLS12-377,
+    300 cards, the five (m, n) pairs; every pair proves and verifies, and the proof is smallest at (10, 30) -- 10 840 bytes of
+    compressed points -- as the reference's doc comment predicts [REF parameter_selection.rs:10]"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "parameter_selection.py"), "--batch", "32"], cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    rows = [ln.split() for ln in out.stdout.decode().splitlines() if re.match(r"^\s*\d+\s+\d+\s+\|", ln)]
+    sizes = {(int(r[0]), int(r[1])): int(r[7]) for r in rows}
+    assert sorted(sizes) == [(2, 150), (6, 50), (10, 30), (12, 25), (30, 10)], rows
+    assert min(sizes, key=sizes.get) == (10, 30) and sizes[(10, 30)] == 10840, sizes
