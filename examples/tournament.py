@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--chain-verify", action="store_true",
                     help="keep every deck and proof in HBM and verify all tables' chains at the end with ONE equation per table "
                          "(mp_verify_shuffle_chain_dev) instead of link by link as the proofs are produced")
+    ap.add_argument("--fb-bits", type=int, default=20, help="window width of the fixed-base tables of the shared parameters (8, 16, 20, 21)")
     ap.add_argument("--keyset", action="store_true",
                     help="hand the tables' aggregate keys over once as a key set (mp_keyset_create) and name them by index, instead of "
                          "passing one key per proof with every call")
@@ -37,7 +38,7 @@ def main():
     gpu = torch.device("cuda:0")
     eng = mp.Engine(curve, device=0)
     params = eng.setup(m, n, bytes([1] * 32))
-    t = eng.table(m, n, params, None, fb_bits=20)          # parameters only: every proof brings its own aggregate key
+    t = eng.table(m, n, params, None, fb_bits=args.fb_bits)          # parameters only: every proof brings its own aggregate key
     gen = torch.Generator(device=gpu)
     gen.manual_seed(1)
 

@@ -49,6 +49,7 @@ def test_table_create_under_memory_pressure_takes_narrower_windows(mp, coracle):
     del hog
     t.close()
     eng.close()
+    torch.cuda.empty_cache()      # (the caching allocator would keep the 86 % for this process: later tests launch other processes)
 
 
 def test_chain_fixture_on_the_hip_engine(mp):
@@ -286,7 +287,10 @@ def test_tournament_example_runs(extra):
     """BASELINE config 3 as a script (examples/tournament.py): 384 card tables x 4 players, one aggregate key per table (passed with
     every call, or prepared once as a key set), every shuffle proved and verified -- link by link, or the tables' chains at the end
     (one chain equation per table at this size: groups of tables from ~2 000 tables on) -- and table 0's chain byte-identical to the CPU oracle under that table's key"""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "tournament.py"), "--tables", "384", "--players", "4", "--check"] + extra,
+    import torch
+    torch.cuda.empty_cache()      # (this process's cached device memory is not available to the script's process)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "tournament.py"), "--tables", "384", "--players", "4", "--check",
+                          "--fb-bits", "16"] + extra,
                          cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     text = out.stdout.decode()
@@ -297,6 +301,8 @@ def test_parameter_selection_example_runs():
     """the reference's only benchmark harness [REF examples/parameter_selection.rs:25-96] as a script on the engine (row f3): BLS12-377,
     300 cards, the five (m, n) pairs; every pair proves and verifies, and the proof is smallest at (10, 30) -- 10 840 bytes of
     compressed points -- as the reference's doc comment predicts [REF parameter_selection.rs:10]"""
+    import torch
+    torch.cuda.empty_cache()
     out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "parameter_selection.py"), "--batch", "32"], cwd=ROOT,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
