@@ -161,6 +161,7 @@ static const uint32_t FSQ_MAX_BATCH = 32768;
 static const uint32_t PROVE_INIT_WAVE_MAX = 32768;      // (the kernel itself: 0.67 -> 0.19 ms at 4 096 proofs, 0.70 -> 0.23 ms at 32 768)
 // batches of up to this many proofs overlap the two halves of the prover's first stretch on two streams (prove_dev)
 static const uint32_t OVERLAP_MAX_BATCH = 32768;
+static const uint32_t SCAL3D_SPLIT_MAX_BATCH = 4096;     // up to here the zero argument's d_k are summed in column ranges first (k_prove_scal3d_part)
 #define MP_WAVE_RUN(NAME, C, nwaves, lds_words, args)                             \
   do {                                                                            \
     ctx->prof.begin(#NAME, ctx->stream, (uint64_t)(nwaves));                      \

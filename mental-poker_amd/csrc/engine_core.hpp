@@ -1025,7 +1025,16 @@ struct Table : mp_table {
       run_fs_round(a, B);
     }
     MP_RUN(k_prove_scal3, C, B, n + 1, sc);
-    MP_RUN(k_prove_scal3d, C, B, 2 * m + 1, sc);
+    {      // small batches: the d_k as partial sums over column ranges first (kernels_proto.hpp; 0.1 -> 0.03 ms of a single proof)
+      ProveScalArgs sd = sc;
+      sd.d_parts = B <= SCAL3D_SPLIT_MAX_BATCH ? scal3d_parts(m, n) : 0u;
+      if (sd.d_parts >= 2) {
+        MP_RUN(k_prove_scal3d_part, C, B, (2 * m + 1) * sd.d_parts, sd);
+      } else {
+        sd.d_parts = 0;
+      }
+      MP_RUN(k_prove_scal3d, C, B, 2 * m + 1, sd);
+    }
     run_phase(pph[3], w, B);
     {
       FsRoundArgs a{};

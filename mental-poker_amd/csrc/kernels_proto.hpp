@@ -476,6 +476,7 @@ struct ProveScalArgs {
   const LinJob* lin;          // scalar-row sums of the Karatsuba plan (layout.hpp), evaluated at the end of scal1
   const uint32_t* lin_src;
   uint32_t n_lin;
+  uint32_t d_parts;           // k_prove_scal3d: column ranges whose partial sums k_prove_scal3d_part left behind (0 = none: sum everything)
 };
 #define MP_LD(slot) ld_fe<R>(a.S + s_off((slot), a.Bpad, b))
 #define MP_ST(slot, val) st_fe<R>(a.S + s_off((slot), a.Bpad, b), (val))
@@ -690,9 +691,17 @@ MP_HD void body_prove_scal3(const ProveScalArgs& a, uint32_t b, uint32_t y_) {
 }
 MP_KERNEL(k_prove_scal3, ProveScalArgs, body_prove_scal3)
 
-// d_k = sum_{i,jj : k = m - jj + i} Aa[i] . wb[jj]   (y = k in [0, 2m]): O(m n) per lane instead of O(m^2 n) in one lane
+// d_k = sum_{i,jj : k = m - jj + i} Aa[i] . wb[jj]   (y = k in [0, 2m]): O(m n) per lane instead of O(m^2 n) in one lane.
+// Small batches (round 5): the (m + 1) n products of a d_k in one lane were 0.1 ms of a single 52-card proof -- 78 dependent
+// multiply-adds on five lanes; k_prove_scal3d_part first leaves the sums over d_parts column ranges (y = k d_parts + p) behind the wb
+// rows in tmp, and the lane of d_k adds those up.  (Field addition is exact: the value does not depend on the association.)
+MP_HD uint32_t scal3d_parts(uint32_t m, uint32_t n) {      // column ranges that fit the free tail of tmp (layout.hpp make_prove_lay)
+  const uint32_t room = (n + m + m * n + 7u) / (2u * m + 1u);
+  const uint32_t p = n < 8u ? n : 8u;
+  return p < room ? p : room;
+}
 template <class C>
-MP_HD void body_prove_scal3d(const ProveScalArgs& a, uint32_t b, uint32_t k) {
+MP_HD Fe<typename C::FrP> scal3d_range(const ProveScalArgs& a, uint32_t b, uint32_t k, uint32_t j0, uint32_t j1) {
   typedef typename C::FrP R;
   const ProveLay& l = a.l;
   const uint32_t m = l.m, n = l.n;
@@ -701,9 +710,31 @@ MP_HD void body_prove_scal3d(const ProveScalArgs& a, uint32_t b, uint32_t k) {
   for (uint32_t i = 0; i <= m; ++i) {
     const int64_t jj = (int64_t)m + (int64_t)i - (int64_t)k;
     if (jj < 0 || jj > (int64_t)m) continue;
-    for (uint32_t j = 0; j < n; ++j) d = fe_add<R>(d, fe_mul<R>(zero_Aa<C>(a, b, i, j), MP_LD(t_wb + (uint32_t)jj * n + j)));
+    for (uint32_t j = j0; j < j1; ++j) d = fe_add<R>(d, fe_mul<R>(zero_Aa<C>(a, b, i, j), MP_LD(t_wb + (uint32_t)jj * n + j)));
   }
-  MP_ST(l.zd + k, d);
+  return d;
+}
+template <class C>
+MP_HD void body_prove_scal3d_part(const ProveScalArgs& a, uint32_t b, uint32_t y) {
+  typedef typename C::FrP R;
+  const ProveLay& l = a.l;
+  const uint32_t k = y / a.d_parts, p = y % a.d_parts;
+  const uint32_t t_part = l.tmp + l.m + 1 + l.n + (l.m + 1) * l.n;
+  MP_ST(t_part + y, scal3d_range<C>(a, b, k, p * l.n / a.d_parts, (p + 1) * l.n / a.d_parts));
+}
+MP_KERNEL(k_prove_scal3d_part, ProveScalArgs, body_prove_scal3d_part)
+template <class C>
+MP_HD void body_prove_scal3d(const ProveScalArgs& a, uint32_t b, uint32_t k) {
+  typedef typename C::FrP R;
+  const ProveLay& l = a.l;
+  if (a.d_parts) {
+    const uint32_t t_part = l.tmp + l.m + 1 + l.n + (l.m + 1) * l.n;
+    Fe<R> d = MP_LD(t_part + k * a.d_parts);
+    for (uint32_t p = 1; p < a.d_parts; ++p) d = fe_add<R>(d, MP_LD(t_part + k * a.d_parts + p));
+    MP_ST(l.zd + k, d);
+    return;
+  }
+  MP_ST(l.zd + k, scal3d_range<C>(a, b, k, 0, l.n));
 }
 MP_KERNEL(k_prove_scal3d, ProveScalArgs, body_prove_scal3d)
 
