@@ -268,9 +268,10 @@ def main():
                          "(mp_*_batch_keys_dev); 0 = every proof under the table's own key")
     ap.add_argument("--bucket-min", type=int, default=None,
                     help="variable-base MSMs of at least this many terms run on the bucket-method kernel (engine default 2048; 0 = never)")
-    ap.add_argument("--bucket-bits", type=int, default=None, help="window width of the bucket method (8 .. 11; default: by the size of the MSM)")
+    ap.add_argument("--bucket-bits", type=int, default=None, help="window width of the bucket method (8 .. 13; default: by the size of the MSM)")
     ap.add_argument("--group-points", type=int, default=None,
-                    help="points per group equation of the verifier's screen (default 30464 = 128 proofs of a 52-card deck; 0 = per-proof screen)")
+                    help="points per group equation of the verifier's screen (default 243712 = 1 024 proofs of a 52-card deck on the split bucket pipeline; "
+                         "30464 = the 128 proofs of rounds 4-5 on one wave per window; 0 = per-proof screen)")
     ap.add_argument("--transcript-lanes", type=int, default=None, choices=[0, 1, 4],
                     help="lanes per Fiat-Shamir transcript hash (mp_set_transcript_lanes; default: by batch size)")
     ap.add_argument("--group-lanes", type=int, default=None, choices=[0, 1, 4],
@@ -720,7 +721,7 @@ def main():
         if table.group_size(Bs):
             table.set_group_verify(0, 0)
             extras["per_proof_screen_value"] = timed_step(step)  # one merged equation per PROOF (Straus), the headline of rounds 1-3
-            table.set_group_verify(30464, 6144)
+            table.set_group_verify(args.group_points if args.group_points is not None else 243712, 6144)      # (back to the run's own setting: 243 712 = the engine's default)
         # ---- what a rejected proof costs.  The same step with tampered proofs in the batch: the prover runs as in
         # the timed region, one byte of the last response scalar of the chosen proofs is flipped in HBM, the verifier must reject exactly
         # those (by the name of their first failing check) and accept the rest.  one_bad: 1 proof of the batch; pct1_bad: 1 % of it,
@@ -899,7 +900,7 @@ def main():
     def bucket_geometry(K):
         """window width the engine picks for a bucket-method MSM of K terms (kernels_bucket.hpp bk_bits_for), its windows per scalar,
         buckets per lane and the point additions of the wave-wide reduction of one window"""
-        c = 11 if K >= 40000 else (10 if K >= 12000 else (9 if K >= 6000 else 8))
+        c = 13 if K >= 200000 else (12 if K >= 50000 else (11 if K >= 40000 else (10 if K >= 12000 else (9 if K >= 6000 else 8))))      # (12 and 13: the split pipeline, one reducing wave per window)
         nb = (1 << (c - 1)) // 64
         return {"bits": c, "windows": (SCALAR_BITS + c) // c, "buckets_per_lane": nb, "reduction_adds": 13 + 2 * nb - 3}
     per_proof_pts = 4 * N + 11 * m + 8
@@ -926,7 +927,7 @@ def main():
         pv = [stats["prove"], stats["verify"]]
         if kernel == "k_var_msm":
             return sum(s["var_terms"] * (32 + PB) + s["var_jobs"] * 3 * PB // 2 for s in pv)
-        if kernel == "k_bucket_msm":
+        if kernel in ("k_bucket_msm", "k_bucket_acc"):
             return (stats.get("bucket_terms", 0) + stats.get("group_terms", 0)) * (32 + PB) + (stats.get("bucket_jobs", 0) + stats.get("group_jobs", 0)) * 3 * PB // 2
         if kernel == "k_fixed_msm":
             return sum(s["fixed_terms"] * 32 + s["fixed_jobs"] * 3 * PB // 2 for s in pv)
@@ -1031,7 +1032,7 @@ def main():
             ops = {"madd": sum(stats[s_]["fixed_terms"] for s_ in ("prove", "verify")) * fw - N * (fw - 1)}
         elif dom_name == "k_remask":
             ops = {"madd": 2 * N * (fw + 1)}
-        elif dom_name == "k_bucket_msm" and "xadd" in iss:
+        elif dom_name in ("k_bucket_msm", "k_bucket_acc") and "xadd" in iss:
             if workload == "chain32" and not args.per_link_verify:
                 L_, lc_ = args.players, extras["chain_links_per_equation"]
                 nsub_ = (L_ + lc_ - 1) // lc_

@@ -28,8 +28,15 @@
  *       proof            mp_proof_size(m, n) bytes, element order in DESIGN.md ("proof wire order")
  *   - prover randomness is an explicit 32-byte seed: the prover draws `Fr::rand` from
  *     ChaCha20Rng::from_seed(seed) in the documented order (the reference takes `rng: &mut R`, mod.rs:381).
- *   - thread-safety: a context owns one HIP stream; calls on one context/table are serialised by the caller.
- *     Different contexts may be used from different host threads.
+ *   - thread-safety (round 6; the reference's trait members are associated functions without `self` or global state [REF src/lib.rs:74-197],
+ *     so any number of host threads may prove and verify at once): every entry point that takes a context, a table or a key set holds
+ *     the CONTEXT's lock for the length of the call.  Calls from several host threads on one context (or on tables of one context) are
+ *     therefore safe and run one after the other, in the order the threads get the lock -- a prove or verify call of 2 048 proofs is a few
+ *     milliseconds; calls on DIFFERENT contexts share nothing (streams, arenas, tables and profiler are per context) and run side by
+ *     side on the device.  mp_last_error is per thread.  What stays with the caller: a buffer handed to a call is not written by
+ *     another thread until the call has returned (pipelined verification, mp_set_pipeline: until mp_sync or `depth` further verify
+ *     calls have), and no call is in flight on a context or table that is being destroyed.  The library reads no environment variable
+ *     and keeps no mutable global.  tests/test_gpu_round6.py::test_four_host_threads_* and tests/test_threads_tsan.py hold it to that.
  */
 #ifndef MPSHUFFLE_H
 #define MPSHUFFLE_H
@@ -250,10 +257,17 @@ int mp_set_group_adapt(mp_table* t, int on);
  * smaller ones on the Straus kernel with per-proof window tables; 0 = never.  Results are identical; the split is a property of
  * the table's static plans, which this call rebuilds. */
 int mp_set_bucket_min(mp_table* t, size_t terms);
-/* Window width of the bucket method: 8 to 11 bits (128 to 1 024 buckets per window; 32, 29, 26 or 23 windows per 252-bit scalar), or
- * 0 (default) = by the size of the MSM (8 bits below 6 000 terms, 9 below 12 000, 10 below 40 000 -- the equation of a group of
- * proofs, mp_set_group_verify --, 11 from there on).  Results are identical; rebuilds the static plans like mp_set_bucket_min. */
+/* Window width of the bucket method: 8 to 13 bits (128 to 4 096 buckets per window; 32, 29, 26, 23, 22 or 20 windows per 252-bit
+ * scalar), or 0 (default) = by the size of the MSM (8 bits below 6 000 terms, 9 below 12 000, 10 below 40 000, 11 below 100 000, 12
+ * below 200 000, 13 from there on -- the equation of a group of 1 024 52-card proofs, mp_set_group_verify).  Results are identical;
+ * rebuilds the static plans like mp_set_bucket_min. */
 int mp_set_bucket_bits(mp_table* t, uint32_t bits);
+/* Round 6.  Bucket jobs whose windows are at least `min_bits` wide (default 12: equations of 100 000 points and more -- the screen of
+ * 512 .. 2 048 52-card proofs) run as THREE kernels instead of one wave per (equation, window): k_bucket_sort (a workgroup per 24 576
+ * terms: counting sort inside LDS, the sorted run written in whole lines), k_bucket_acc (a wave per range of 256 buckets, four per lane
+ * dealt by rank, one mixed addition per term; equal shares of the list instead where a window's digits crowd into a few buckets) and
+ * k_bucket_reduce (a wave per window).  8 = every bucket job, 14 = none.  Results are identical. */
+int mp_set_bucket_split(mp_table* t, uint32_t min_bits);
 /* Chain verification (mp_verify_shuffle_chain*): at most `links` links share one chain equation; longer chains are verified as
  * consecutive sub-chains.  0 (default) = as many as fit the 32 767 points of one equation (293 links of a 52-card deck; one link of a deck too large for that gets an equation of up to 65 535 points).  A smaller
  * value bounds the work that is repeated link by link when a chain fails.  Verdicts are the same. */

@@ -16,6 +16,10 @@ static inline size_t proof_size_bytes_(uint32_t m, uint32_t n) { return proof_si
 
 using namespace mp;
 
+// the context's lock for the length of the call + its device for this host thread (engine_base.hpp mp_ctx::mu)
+#define MP_ENTER(CTX)                                          \
+  std::lock_guard<std::recursive_mutex> mp_lock_((CTX)->mu);   \
+  rt::set_device((CTX)->device)
 #define MP_TRY try {
 #define MP_CATCH                                                                     \
   }                                                                                  \
@@ -147,16 +151,19 @@ void mp_ctx_destroy(mp_ctx* ctx) {
   if (!ctx) return;
   // tables hold a pointer to their context (streams, events, the registry mp_sync walks): a context that still has tables is only
   // marked and goes with the last of them (mp_table_destroy), so the two destroy calls may come in either order
-  if (!ctx->tables.empty()) {
-    ctx->dying = true;
-    return;
+  {
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    if (!ctx->tables.empty()) {
+      ctx->dying = true;
+      return;
+    }
   }
   ctx_release(ctx);
 }
 int mp_setup(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out_params) {
   if (!ctx || !seed || !out_params || m < 2 || n < 2) return fail(MP_ERR_BAD_ARGUMENT, "mp_setup: bad argument");
   MP_TRY
-  rt::set_device(ctx->device);
+  MP_ENTER(ctx);
   switch (ctx->curve) {
     case 0: return setup_Stark(ctx, m, n, seed, out_params);
     case 1: return setup_Bn254(ctx, m, n, seed, out_params);
@@ -189,7 +196,7 @@ int mp_table_create_ex(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* param
   if (!ctx || !params || !shared_key || !out) return fail(MP_ERR_BAD_ARGUMENT, "mp_table_create: null pointer");
   if (m < 2 || n < 2 || (uint64_t)m * n > 4096) return fail(MP_ERR_BAD_ARGUMENT, "mp_table_create: need m >= 2, n >= 2, m*n <= 4096");
   MP_TRY
-  rt::set_device(ctx->device);
+  MP_ENTER(ctx);
   const bool auto_bits = fb_window_bits == 0;
   if (auto_bits) fb_window_bits = auto_window_bits(ctx->curve, n);
   int rc = MP_OK;
@@ -236,20 +243,25 @@ int mp_table_create_params(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* p
 void mp_table_destroy(mp_table* t) {
   if (!t) return;
   try {
-    rt::set_device(t->ctx->device);
+    MP_ENTER(t->ctx);
     t->flush();
   } catch (...) {
   }
   mp_ctx* ctx = t->ctx;
-  auto& reg = ctx->tables;
-  reg.erase(std::remove(reg.begin(), reg.end(), t), reg.end());
-  for (auto& st : t->io) {
-    if (st.up) rt::event_destroy(st.up);
-    if (st.done) rt::event_destroy(st.done);
-    if (st.down) rt::event_destroy(st.down);
+  bool last = false;
+  {
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    auto& reg = ctx->tables;
+    reg.erase(std::remove(reg.begin(), reg.end(), t), reg.end());
+    for (auto& st : t->io) {
+      if (st.up) rt::event_destroy(st.up);
+      if (st.done) rt::event_destroy(st.done);
+      if (st.down) rt::event_destroy(st.down);
+    }
+    delete t;
+    last = ctx->dying && reg.empty();
   }
-  delete t;
-  if (ctx->dying && reg.empty()) ctx_release(ctx);      // mp_ctx_destroy came first
+  if (last) ctx_release(ctx);      // mp_ctx_destroy came first (the lock is not held: it goes with the context)
 }
 void* mp_host_alloc(size_t bytes) {
   try {
@@ -264,87 +276,108 @@ void mp_host_free(void* p) { rt::host_free(p); }
 uint32_t mp_table_window_bits(const mp_table* t) { return t ? t->fb_bits : 0; }
 int mp_set_latency_batch(mp_table* t, size_t B) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_latency_batch: null table");
+  std::lock_guard<std::recursive_mutex> mp_lock_(t->ctx->mu);
   t->set_latency_batch(B);
   return MP_OK;
 }
 int mp_set_io_chunk(mp_table* t, size_t proofs) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_io_chunk: null table");
+  std::lock_guard<std::recursive_mutex> mp_lock_(t->ctx->mu);
   t->io_chunk = proofs;
   return MP_OK;
 }
 int mp_set_merged_verify(mp_table* t, int on) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_merged_verify: null table");
+  std::lock_guard<std::recursive_mutex> mp_lock_(t->ctx->mu);
   t->set_merged_verify(on != 0);
   return MP_OK;
 }
 int mp_set_group_refine(mp_table* t, uint32_t points_per_subgroup, uint32_t min_subgroups) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_refine: null table");
-  if (points_per_subgroup > BUCKET_TERMS_MAX) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_refine: at most 65 535 points per equation");
+  if (points_per_subgroup > BUCKET_TERMS_MAX - 4096) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_refine: at most 585 728 points per equation");
+  std::lock_guard<std::recursive_mutex> mp_lock_(t->ctx->mu);
   t->set_group_refine(points_per_subgroup, min_subgroups);
   return MP_OK;
 }
 uint64_t mp_reverified_count(const mp_table* t) { return t ? t->reverified() : 0; }
 int mp_set_group_adapt(mp_table* t, int on) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_adapt: null table");
+  std::lock_guard<std::recursive_mutex> mp_lock_(t->ctx->mu);
   t->set_group_adapt(on != 0);
   return MP_OK;
 }
 int mp_set_bucket_min(mp_table* t, size_t terms) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_min: null table");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   t->set_bucket_min((uint32_t)std::min<size_t>(terms, 0x7FFFFFFFu));
   return MP_OK;
   MP_CATCH
 }
 int mp_set_bucket_bits(mp_table* t, uint32_t bits) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_bits: null table");
-  if (bits != 0 && (bits < 8 || bits > 11)) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_bits: 0 (by size) or 8 .. 11");
+  if (bits != 0 && (bits < 8 || bits > 13)) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_bits: 0 (by size) or 8 .. 13");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   t->set_bucket_bits(bits);
+  return MP_OK;
+  MP_CATCH
+}
+int mp_set_bucket_split(mp_table* t, uint32_t min_bits) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_split: null table");
+  if (min_bits < 8 || min_bits > 14) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_split: 8 (every bucket job) .. 14 (none)");
+  MP_TRY
+  MP_ENTER(t->ctx);
+  t->flush();
+  t->bucket_split_bits = min_bits;
   return MP_OK;
   MP_CATCH
 }
 int mp_set_chain_max_links(mp_table* t, uint32_t links) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_chain_max_links: null table");
+  std::lock_guard<std::recursive_mutex> mp_lock_(t->ctx->mu);
   t->chain_max_links = links;
   return MP_OK;
 }
 int mp_set_chain_slice(mp_table* t, size_t tables_per_pass) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_chain_slice: null table");
+  std::lock_guard<std::recursive_mutex> mp_lock_(t->ctx->mu);
   t->chain_slice = tables_per_pass;
   return MP_OK;
 }
 int mp_set_chain_group(mp_table* t, uint32_t tables_per_equation) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_chain_group: null table");
   if (tables_per_equation > 1022) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_chain_group: at most 1 022 tables per equation");
+  std::lock_guard<std::recursive_mutex> mp_lock_(t->ctx->mu);
   t->chain_group = tables_per_equation;
   return MP_OK;
 }
 int mp_set_transcript_lanes(mp_table* t, uint32_t lanes) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_transcript_lanes: null table");
   if (lanes != 0 && lanes != 1 && lanes != 4) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_transcript_lanes: 0 (by batch size), 1 or 4");
+  std::lock_guard<std::recursive_mutex> mp_lock_(t->ctx->mu);
   t->fs_lanes = lanes;
   return MP_OK;
 }
 int mp_set_group_lanes(mp_table* t, uint32_t lanes) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_lanes: null table");
   if (lanes != 0 && lanes != 1 && lanes != 4) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_lanes: 0 (by batch size), 1 or 4");
+  std::lock_guard<std::recursive_mutex> mp_lock_(t->ctx->mu);
   t->group_lanes = lanes;
   return MP_OK;
 }
 int mp_set_work_split(mp_table* t, int split) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_work_split: null table");
   if (split < -1 || split > 5) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_work_split: -1 (by batch size) or 0 .. 5");
+  std::lock_guard<std::recursive_mutex> mp_lock_(t->ctx->mu);
   t->forced_split = split;
   return MP_OK;
 }
 int mp_set_group_verify(mp_table* t, uint32_t points_per_group, size_t min_batch) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_verify: null table");
-  if (points_per_group > 65535) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_verify: 0 (off) or up to 65 535 points per group equation");
+  if (points_per_group > BUCKET_TERMS_MAX - 4096) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_group_verify: 0 (off) or up to 585 728 points per group equation");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   t->flush();
   t->set_group_verify(points_per_group, min_batch);
   return MP_OK;
@@ -355,7 +388,7 @@ uint32_t mp_chain_group_size(const mp_table* t, size_t tables, uint32_t links, i
   if (!t || !tables || !links) return 0;
   // (as mp_verify_shuffle_chain_dev cuts the chain: the sub-chains of a long chain are equations of their own)
   const size_t per_link = (size_t)2 * t->N + 11 * t->m + 8, fixed_part = (size_t)2 * t->N + 1;
-  const size_t eq_cap = fixed_part + per_link > 32767 ? BUCKET_TERMS_MAX : 32767;
+  const size_t eq_cap = fixed_part + per_link > 32767 ? (size_t)65535 : 32767;
   if (fixed_part + per_link > eq_cap) return 0;
   uint32_t lmax = std::min<uint32_t>((uint32_t)((eq_cap - fixed_part) / per_link), 1022u);
   if (t->chain_max_links) lmax = std::max(1u, std::min(lmax, t->chain_max_links));
@@ -365,7 +398,7 @@ size_t mp_chain_last_slice(const mp_table* t) { return t ? t->chain_last_slice :
 int mp_set_pipeline(mp_table* t, int depth) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_pipeline: null table");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   if (depth < 0 || depth > 8) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_pipeline: depth 0 (off) .. 8");
   t->flush();
   t->pipeline = depth;
@@ -376,7 +409,7 @@ int mp_set_plan_params(mp_table* t, int split, uint32_t fixed_terms, uint32_t va
                        uint32_t window_lanes) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_plan_params: null table");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   if (t->set_plan_params(split, fixed_terms, var_terms, table_group, norm_chunk, window_lanes) != MP_OK)
     return fail(MP_ERR_BAD_ARGUMENT, "mp_set_plan_params: split 0 .. 5, sizes >= 1, table_group <= 64, window_lanes <= 16");
   return MP_OK;
@@ -386,26 +419,28 @@ int mp_set_plan_thresholds(mp_table* t, size_t finest, size_t small, size_t late
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_plan_thresholds: null table");
   if (finest > small || small > latency || latency > medium || medium > wide)
     return fail(MP_ERR_BAD_ARGUMENT, "mp_set_plan_thresholds: finest <= small <= latency <= medium <= wide");
+  std::lock_guard<std::recursive_mutex> mp_lock_(t->ctx->mu);
   t->set_plan_thresholds(finest, small, latency, medium, wide);
   return MP_OK;
 }
 int mp_set_toom_cook(mp_table* t, int on) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_toom_cook: null table");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   t->set_toom_cook(on != 0);
   return MP_OK;
   MP_CATCH
 }
 int mp_set_subgroup_check(mp_table* t, int on) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_subgroup_check: null table");
+  std::lock_guard<std::recursive_mutex> mp_lock_(t->ctx->mu);
   t->set_subgroup_check(on != 0);
   return MP_OK;
 }
 int mp_reserve(mp_table* t, size_t B) {
   if (!t || !B) return fail(MP_ERR_BAD_ARGUMENT, "mp_reserve: bad argument");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   t->reserve(B);
   rt::stream_sync(t->ctx->stream);
   return MP_OK;
@@ -419,7 +454,7 @@ int mp_shuffle_and_remask_batch_dev(mp_table* t, size_t B, const void* d_decks, 
     return fail(MP_ERR_BAD_ARGUMENT, "mp_shuffle_and_remask_batch_dev: bad argument");
   if (t->keyless) return fail(MP_ERR_BAD_ARGUMENT, "this table has no aggregate key: use the _keys entry points");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   t->prove_dev(B, (const uint8_t*)d_decks, (const uint8_t*)d_masking_factors, (const uint32_t*)d_permutations,
                (const uint8_t*)d_prover_seeds, (uint8_t*)d_out_decks, (uint8_t*)d_out_proofs, (int32_t*)d_status);
   return MP_OK;
@@ -431,7 +466,7 @@ int mp_verify_shuffle_batch_dev(mp_table* t, size_t B, const void* d_decks, cons
     return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_batch_dev: bad argument");
   if (t->keyless) return fail(MP_ERR_BAD_ARGUMENT, "this table has no aggregate key: use the _keys entry points");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   t->verify_dev(B, (const uint8_t*)d_decks, (const uint8_t*)d_shuffled_decks, (const uint8_t*)d_proofs, (int32_t*)d_status);
   return MP_OK;
   MP_CATCH
@@ -442,7 +477,7 @@ int mp_shuffle_and_remask_batch_keys_dev(mp_table* t, size_t B, const void* d_ke
   if (!t || !B || !d_keys || !d_decks || !d_masking_factors || !d_permutations || !d_prover_seeds || !d_out_decks || !d_out_proofs || !d_status)
     return fail(MP_ERR_BAD_ARGUMENT, "mp_shuffle_and_remask_batch_keys_dev: bad argument");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   t->prove_dev(B, (const uint8_t*)d_decks, (const uint8_t*)d_masking_factors, (const uint32_t*)d_permutations,
                (const uint8_t*)d_prover_seeds, (uint8_t*)d_out_decks, (uint8_t*)d_out_proofs, (int32_t*)d_status, (const uint8_t*)d_keys);
   return MP_OK;
@@ -453,7 +488,7 @@ int mp_verify_shuffle_batch_keys_dev(mp_table* t, size_t B, const void* d_keys, 
   if (!t || !B || !d_keys || !d_decks || !d_shuffled_decks || !d_proofs || !d_status)
     return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_batch_keys_dev: bad argument");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   t->verify_dev(B, (const uint8_t*)d_decks, (const uint8_t*)d_shuffled_decks, (const uint8_t*)d_proofs, (int32_t*)d_status,
                 (const uint8_t*)d_keys);
   return MP_OK;
@@ -462,7 +497,7 @@ int mp_verify_shuffle_batch_keys_dev(mp_table* t, size_t B, const void* d_keys, 
 int mp_keyset_create(mp_table* t, size_t n_keys, const uint8_t* keys, mp_keyset** out) {
   if (!t || !n_keys || !keys || !out) return fail(MP_ERR_BAD_ARGUMENT, "mp_keyset_create: bad argument");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   std::unique_ptr<mp_keyset> ks(new mp_keyset());
   ks->owner = t;
   const int rc = t->keyset_build(*ks, n_keys, keys);
@@ -474,7 +509,7 @@ int mp_keyset_create(mp_table* t, size_t n_keys, const uint8_t* keys, mp_keyset*
 void mp_keyset_destroy(mp_keyset* ks) {
   if (!ks) return;
   try {
-    rt::set_device(ks->owner->ctx->device);
+    MP_ENTER(ks->owner->ctx);
     delete ks;
   } catch (...) {
   }
@@ -487,7 +522,7 @@ int mp_shuffle_and_remask_batch_keyset_dev(mp_table* t, const mp_keyset* ks, siz
       !d_out_proofs || !d_status)
     return fail(MP_ERR_BAD_ARGUMENT, "mp_shuffle_and_remask_batch_keyset_dev: bad argument (the key set must belong to this table)");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   t->prove_dev(B, (const uint8_t*)d_decks, (const uint8_t*)d_masking_factors, (const uint32_t*)d_permutations,
                (const uint8_t*)d_prover_seeds, (uint8_t*)d_out_decks, (uint8_t*)d_out_proofs, (int32_t*)d_status, nullptr, ks,
                (const uint32_t*)d_key_index);
@@ -499,7 +534,7 @@ int mp_verify_shuffle_batch_keyset_dev(mp_table* t, const mp_keyset* ks, size_t 
   if (!t || !ks || ks->owner != t || !B || !d_key_index || !d_decks || !d_shuffled_decks || !d_proofs || !d_status)
     return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_batch_keyset_dev: bad argument (the key set must belong to this table)");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   t->verify_dev(B, (const uint8_t*)d_decks, (const uint8_t*)d_shuffled_decks, (const uint8_t*)d_proofs, (int32_t*)d_status, nullptr, ks,
                 (const uint32_t*)d_key_index);
   return MP_OK;
@@ -512,7 +547,7 @@ int mp_verify_shuffle_chain_dev(mp_table* t, size_t tables, uint32_t links, cons
   if (t->keyless && !d_keys) return fail(MP_ERR_BAD_ARGUMENT, "this table has no aggregate key: pass one key per link");
   if ((uint64_t)tables * links >= ((uint64_t)1 << 31)) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_chain_dev: too many proofs for one call");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   NoPipeline nopipe(t);
   // one chain equation holds at most 32 767 distinct points ((L + 1) 2N decks + L (11m + 8) proof elements + key): longer chains are
   // verified as consecutive sub-chains (the decks array is link-major, so a sub-chain is a contiguous slice)
@@ -520,7 +555,7 @@ int mp_verify_shuffle_chain_dev(mp_table* t, size_t tables, uint32_t links, cons
   const size_t pb = t->point_bytes, deck_bytes = (size_t)2 * t->N * pb, psz = proof_size_bytes(t->m, t->n, (uint32_t)pb);
   // (one link does not always fit 32 767 points -- m = 2048, n = 2: 4N + 11m + 9 = 38 921 -- but it fits one bucket job: the kernel sorts
   // up to BUCKET_TERMS_MAX = 65 535 points per window, and 4N + 11m + 9 <= 38 921 for every table mp_table_create accepts, m n <= 4096)
-  const size_t eq_cap = fixed_part + per_link > 32767 ? BUCKET_TERMS_MAX : 32767;
+  const size_t eq_cap = fixed_part + per_link > 32767 ? (size_t)65535 : 32767;
   if (fixed_part + per_link > eq_cap) return fail(MP_ERR_INTERNAL, "mp_verify_shuffle_chain_dev: deck too large for one chain equation");
   uint32_t lmax = std::min<uint32_t>((uint32_t)((eq_cap - fixed_part) / per_link), 1022u);      // (links 0 .. L in 10 bits of a sorted entry: kernels_bucket.hpp)
   if (t->chain_max_links) lmax = std::max(1u, std::min(lmax, t->chain_max_links));
@@ -584,7 +619,7 @@ int mp_verify_shuffle_chain(mp_table* t, size_t tables, uint32_t links, const ui
                             int32_t* status) {
   if (!t || !tables || !links || !decks || !proofs || !status) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_chain: bad argument");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   rt::Stream s = t->ctx->stream;
   const size_t B = tables * links, pb = t->point_bytes, deck_bytes = (size_t)2 * t->N * pb, psz = proof_size_bytes(t->m, t->n, (uint32_t)pb);
   DevBuf<uint8_t> dd, dp, dk;
@@ -608,7 +643,7 @@ int mp_verify_shuffle_chain(mp_table* t, size_t tables, uint32_t links, const ui
 int mp_sync(mp_ctx* ctx) {
   if (!ctx) return fail(MP_ERR_BAD_ARGUMENT, "mp_sync: null");
   MP_TRY
-  rt::set_device(ctx->device);
+  MP_ENTER(ctx);
   rt::stream_sync(ctx->stream);
   for (mp_table* t : ctx->tables) t->flush();      // pipelined verify calls: deferred per-equation passes, then the verify lane
   return MP_OK;
@@ -634,7 +669,10 @@ static std::vector<size_t> io_schedule(size_t B, size_t C, bool tail_ramp = true
     for (size_t o = 0; o < B; o += C) v.push_back(std::min(C, B - o));
     return v;
   }
-  static const bool slow_ramp = [] { const char* e = getenv("MP_IO_RAMP"); return !(e && *e == '0'); }();      // (A/B hook of round 5)
+#ifndef MP_EXP_IO_RAMP      // (A/B hook of round 5, compile-time: profiles/r05g_ab_verify_upload_ramp.txt; no environment variable steers the library)
+#define MP_EXP_IO_RAMP 1
+#endif
+  constexpr bool slow_ramp = MP_EXP_IO_RAMP != 0;
   if (!tail_ramp && !slow_ramp) {      // round 4's schedule without its tail: C/8, 3C/8, then full chunks
     v.push_back(C / 8);
     v.push_back(3 * C / 8);
@@ -685,7 +723,7 @@ static int prove_batch_host(mp_table* t, size_t B, const uint8_t* keys, const ui
     return fail(MP_ERR_BAD_ARGUMENT, "mp_shuffle_and_remask_batch: bad argument");
   if (t->keyless && !keys) return fail(MP_ERR_BAD_ARGUMENT, "this table has no aggregate key: use the _keys entry points");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   rt::Stream s = t->ctx->stream, up = t->ctx->h2d, down = t->ctx->d2h;
   const size_t N = t->N, psz = proof_size_bytes(t->m, t->n, t->point_bytes), dsz = N * 2 * t->point_bytes;
   const size_t chunk = io_chunk_of(t, B);
@@ -738,7 +776,7 @@ static int verify_batch_host(mp_table* t, size_t B, const uint8_t* keys, const u
   if (!t || !B || !decks || !shuffled_decks || !proofs || !status) return fail(MP_ERR_BAD_ARGUMENT, "mp_verify_shuffle_batch: bad argument");
   if (t->keyless && !keys) return fail(MP_ERR_BAD_ARGUMENT, "this table has no aggregate key: use the _keys entry points");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   NoPipeline nopipe(t);
   rt::Stream s = t->ctx->stream, up = t->ctx->h2d, down = t->ctx->d2h;
   const size_t N = t->N, psz = proof_size_bytes(t->m, t->n, t->point_bytes), dsz = N * 2 * t->point_bytes;
@@ -825,7 +863,7 @@ int mp_verify_shuffle(mp_table* t, const uint8_t* deck, const uint8_t* shuffled_
 int mp_remask_batch(mp_table* t, size_t count, const uint8_t* cards, const uint8_t* masking_factors, uint8_t* out) {
   if (!t || !count || !cards || !masking_factors || !out) return fail(MP_ERR_BAD_ARGUMENT, "mp_remask_batch: bad argument");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   t->remask_host(count, cards, masking_factors, out);
   return MP_OK;
   MP_CATCH
@@ -833,7 +871,7 @@ int mp_remask_batch(mp_table* t, size_t count, const uint8_t* cards, const uint8
 int mp_msm(mp_table* t, size_t n_msm, size_t k, const uint8_t* scalars, const uint8_t* points, uint8_t* out) {
   if (!t || !n_msm || !k || !scalars || !points || !out) return fail(MP_ERR_BAD_ARGUMENT, "mp_msm: bad argument");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   t->msm_host(n_msm, k, scalars, points, out);
   return MP_OK;
   MP_CATCH
@@ -841,7 +879,7 @@ int mp_msm(mp_table* t, size_t n_msm, size_t k, const uint8_t* scalars, const ui
 int mp_commit_batch(mp_table* t, size_t count, size_t len, const uint8_t* values, const uint8_t* r, uint8_t* out) {
   if (!t || !count || !r || !out || (len && !values) || len > t->n) return fail(MP_ERR_BAD_ARGUMENT, "mp_commit_batch: bad argument");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   t->commit_host(count, len, values, r, out);
   return MP_OK;
   MP_CATCH
@@ -850,6 +888,7 @@ int mp_commit_batch(mp_table* t, size_t count, size_t len, const uint8_t* values
 int mp_profile_enable(mp_ctx* ctx, int on) {
   if (!ctx) return fail(MP_ERR_BAD_ARGUMENT, "null ctx");
   MP_TRY
+  std::lock_guard<std::recursive_mutex> mp_lock_(ctx->mu);
   rt::stream_sync(ctx->stream);
   ctx->prof.report();
   ctx->prof.on = on != 0;
@@ -859,6 +898,7 @@ int mp_profile_enable(mp_ctx* ctx, int on) {
 int mp_profile_report(mp_ctx* ctx, char* buf, size_t buf_len) {
   if (!ctx || !buf || !buf_len) return fail(MP_ERR_BAD_ARGUMENT, "mp_profile_report: bad argument");
   MP_TRY
+  std::lock_guard<std::recursive_mutex> mp_lock_(ctx->mu);
   rt::stream_sync(ctx->stream);
   std::string r = ctx->prof.report();
   if (r.size() + 1 > buf_len) r.resize(buf_len - 1);
@@ -868,6 +908,7 @@ int mp_profile_report(mp_ctx* ctx, char* buf, size_t buf_len) {
 }
 int mp_work_census(mp_table* t, uint64_t* prove_terms, uint64_t* verify_terms, uint64_t* prove_point_ops, uint64_t* verify_point_ops) {
   if (!t || !prove_terms || !verify_terms || !prove_point_ops || !verify_point_ops) return fail(MP_ERR_BAD_ARGUMENT, "mp_work_census: bad argument");
+  std::lock_guard<std::recursive_mutex> mp_lock_(t->ctx->mu);
   t->census(prove_terms, verify_terms, prove_point_ops, verify_point_ops);
   return MP_OK;
 }
@@ -895,7 +936,7 @@ int mp_sigma_prove_batch(mp_table* t, size_t B, uint32_t nbases, const uint8_t* 
   if (!t || !B || (nbases != 1 && nbases != 2) || !bases || !publics || !witness || !fs_init || !prover_seeds || !out_proofs || !status)
     return fail(MP_ERR_BAD_ARGUMENT, "mp_sigma_prove_batch: bad argument");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   t->sigma_host(true, B, nbases, bases, publics, witness, fs_init, prover_seeds, out_proofs, status);
   return MP_OK;
   MP_CATCH
@@ -905,7 +946,7 @@ int mp_sigma_verify_batch(mp_table* t, size_t B, uint32_t nbases, const uint8_t*
   if (!t || !B || (nbases != 1 && nbases != 2) || !bases || !publics || !proofs || !fs_init || !status)
     return fail(MP_ERR_BAD_ARGUMENT, "mp_sigma_verify_batch: bad argument");
   MP_TRY
-  rt::set_device(t->ctx->device);
+  MP_ENTER(t->ctx);
   t->sigma_host(false, B, nbases, bases, publics, nullptr, fs_init, nullptr, const_cast<uint8_t*>(proofs), status);
   return MP_OK;
   MP_CATCH
@@ -913,6 +954,7 @@ int mp_sigma_verify_batch(mp_table* t, size_t B, uint32_t nbases, const uint8_t*
 
 int mp_plan_stats(mp_table* t, uint64_t out[16]) {
   if (!t || !out) return fail(MP_ERR_BAD_ARGUMENT, "mp_plan_stats: bad argument");
+  std::lock_guard<std::recursive_mutex> mp_lock_(t->ctx->mu);
   t->plan_stats(out);
   return MP_OK;
 }
@@ -991,7 +1033,7 @@ int mp_params_deserialize(int curve_id, const uint8_t* data, size_t len, size_t 
 // ---- on-device decompression: compressed arkworks points in HBM -> wire v1 in HBM (kernels_decompress.hpp)
 static int decompress_dev(mp_ctx* ctx, size_t groups, uint32_t per_group, uint32_t prefix, const void* d_in, void* d_out, void* d_status) {
   MP_TRY
-  rt::set_device(ctx->device);
+  MP_ENTER(ctx);
   switch (ctx->curve) {
     case 0: return decompress_dev_Stark(ctx, groups, per_group, prefix, (const uint8_t*)d_in, (uint8_t*)d_out, (int32_t*)d_status);
     case 1: return decompress_dev_Bn254(ctx, groups, per_group, prefix, (const uint8_t*)d_in, (uint8_t*)d_out, (int32_t*)d_status);

@@ -21,6 +21,7 @@
 #include <memory>
 #include <sstream>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/mpshuffle.h"
@@ -114,6 +115,11 @@ struct Profiler {
 }  // namespace mp
 
 struct mp_ctx {
+  // Round 6, the threading contract (include/mpshuffle.h): every entry point that takes this context or one of its tables holds this
+  // lock for the length of the call, so calls from several host threads on ONE context run one after the other; different contexts
+  // share nothing (streams, arenas, tables, profiler are all per context; mp_last_error is per thread) and run side by side.
+  // Recursive: the host-buffer entry points call the device-pointer ones.
+  std::recursive_mutex mu;
   int curve = 0;
   int device = 0;
   mp::rt::Stream stream{};      // all kernels
@@ -201,6 +207,7 @@ struct mp_table {
   uint32_t fb_bits = 8;        // window width of the fixed-base tables (mp_table_window_bits)
   bool keyless = false;        // created from the parameters alone (mp_table_create_params): keyed entry points only
   uint32_t bucket_bits = 0;       // window width of the bucket method (0 = by the size of the MSM: kernels_bucket.hpp bk_bits_for; mp_set_bucket_bits)
+  uint32_t bucket_split_bits = 12;   // windows of at least this many bits run sort / additions / reduction as three kernels (kernels_bucket.hpp, round 6; mp_set_bucket_split)
   uint32_t chain_max_links = 0;   // links per chain equation (0 = as many as fit 32 767 points; mp_set_chain_max_links)
   size_t chain_slice = 0;         // tables per pass of chain verification (0 = as many as the free memory holds; mp_set_chain_slice)
   uint32_t chain_group = 0;       // tables per chain equation (0 = by size, as the groups of mp_set_group_verify; 1 = one table each; mp_set_chain_group)

@@ -82,6 +82,7 @@ struct Workspace {
   // scratch rows of the bucket kernel's persistent waves (kernels_bucket.hpp): the sorted point references of the window a wave is
   // working on, and its parked bucket sums -- at most 2 048 x (128 KB + 64 KB), whatever the batch
   DevBuf<uint32_t> bk_sorted, bk_park, bk_counter, bk_timing;
+  DevBuf<uint16_t> bk_offs;           // the split pipeline's bucket offsets per (item, chunk)
   void ensure_bucket(uint32_t nslots, uint32_t kpad_max, uint32_t bits, uint32_t xw, rt::Stream s) {
     bk_sorted.alloc((size_t)nslots * kpad_max, s, false);
     bk_park.alloc((size_t)nslots * bk_buckets(bits) * xw, s, false);
@@ -648,6 +649,8 @@ struct Table : mp_table {
   // the bucket method over a phase's large MSMs: digits, the persistent wave kernel (one wave per (equation, MSM, window) at a time),
   // the fold of the window results.  `count` equations -- proofs, or chain / group equations -- whose scalars lie in S with lane stride
   // sstride and whose digits go to D (dstride per equation)
+  uint32_t bk_pass_eqs = 0;           // the split pipeline's equations per pass and what they were sized for (run_bucket)
+  size_t bk_pass_bytes = 0;
   uint32_t bucket_slots() {
     if (!ctx->bk_slots) ctx->bk_slots = BK_WAVES_PER_CU * rt::cu_count();
     return ctx->bk_slots;
@@ -661,6 +664,48 @@ struct Table : mp_table {
     if ((uint64_t)count * ph.n_bterms >= ((uint64_t)1 << 32) || (uint64_t)count * ph.n_b * bw + 8ull * bucket_slots() >= ((uint64_t)1 << 32)) throw std::runtime_error(too_large);
     BRecodeArgs ra{S, D, ph.bterms.p, ph.bpos.p, sstride, bw, ph.n_bterms, dstride, c};
     MP_RUN(k_bucket_recode, C, count * ph.n_bterms, 1, ra);
+    if (c >= bucket_split_bits) {
+      // windows of 12 bits and more: sort / additions / reduction as three kernels (kernels_bucket.hpp, round 6).  Their scratch
+      // (sorted runs, offsets, parked sums: ~1.7 MB per (equation, window) at 13 bits and 243 712 points) holds all items of a PASS of
+      // equations: as many as fit a quarter of the free memory, 12 GB at the most
+      const uint32_t NBK = bk_buckets(c), XW = XyzzWords<C>::N, gmax = bk_chunks(ph.b_kpad_max), units = bk_units(c);
+      if (gmax > BK_CHUNKS_MAX) throw std::runtime_error("bucket method: more than 589 824 terms in one multi-scalar multiplication with windows of 12 bits or more");
+      const size_t per_item = ((size_t)ph.b_kpad_max + (size_t)NBK * XW) * 4 + (size_t)gmax * bk_offs_row(c) * 2, per_eq = per_item * ph.n_b * bw;
+      if (!bk_pass_eqs || bk_pass_bytes != per_eq) {
+        size_t free_b = 0, total_b = 0;
+        rt::mem_info(&free_b, &total_b);
+        // (what the scratch already holds counts as free; the emulator reports no memory: one gigabyte)
+        const size_t have = (w.bk_sorted.n + w.bk_park.n) * 4 + w.bk_offs.n * 2;
+        const size_t budget = total_b ? std::min<size_t>((size_t)12 << 30, (free_b + have) / 4) : (size_t)1 << 30;
+        bk_pass_eqs = (uint32_t)std::max<size_t>(1, std::min<size_t>(budget / per_eq, 0x7FFFFFFFu));
+        bk_pass_bytes = per_eq;
+      }
+      const uint32_t pass = std::min(count, std::max(bk_pass_eqs, 1u));
+      const size_t items_max = (size_t)pass * ph.n_b * bw;
+      if (items_max * units >= ((uint64_t)1 << 32)) throw std::runtime_error(too_large);
+      w.bk_sorted.alloc(items_max * ph.b_kpad_max, s, false);
+      w.bk_offs.alloc(items_max * gmax * bk_offs_row(c), s, false);
+      w.bk_park.alloc(items_max * NBK * XW, s, false);
+      for (uint32_t e0 = 0; e0 < count; e0 += pass) {
+        const uint32_t ne = std::min(pass, count - e0), items = ne * ph.n_b * bw;
+        const uint32_t acc_lds = bk_acc_lds_words(c, gmax, XW, G_::PW), wpb = rt::waves_per_block(acc_lds), wgs = (items * units + wpb - 1) / wpb;
+        BSplitArgs sa{D, w.P.p, w.J.p, ph.bjobs.p, ph.bterms.p, w.Bpad, bw, ph.n_b, dstride, link_stride, c, e0, ne, tile, tile_K,
+                      w.bk_sorted.p, w.bk_offs.p, w.bk_park.p, ph.b_kpad_max, gmax, units, wpb, wgs};
+        ctx->prof.begin("k_bucket_sort", s, (uint64_t)items * gmax);
+        MP_BLOCK_LAUNCH(k_bucket_sort, C, s, items * gmax, NBK + 2u + BK_CHUNK / 2u, sa);
+        ctx->prof.end(s);
+        MP_WAVE_RUN(k_bucket_acc, C, (wgs + 7u) / 8u * 8u * wpb, acc_lds, sa);      // (8 XCDs x their share of the workgroups: bk_unit_of_wave)
+        MP_WAVE_RUN(k_bucket_reduce, C, items, 64u * XW, sa);
+      }
+      BFoldArgs fa{w.J.p, ph.bjobs.p, w.Bpad, bw, 0u, c};
+      if (quad_ops(count, ph.n_b)) {
+        BFoldQuadArgs qa{fa, count, ph.n_b};
+        MP_WAVE_RUN(k_bucket_fold_q, C, quad_waves(count, ph.n_b), 0, qa);
+      } else {
+        MP_RUN(k_bucket_fold, C, count, ph.n_b, fa);
+      }
+      return;
+    }
     const uint32_t nitems = count * ph.n_b * bw, nslots = std::min(nitems, bucket_slots());
     w.ensure_bucket(bucket_slots(), ph.b_kpad_max, c, XyzzWords<C>::N, s);
     rt::dzero(w.bk_counter.p, 8 * 4, s);
@@ -1430,7 +1475,15 @@ struct Table : mp_table {
   };
   ChainPlan chain;
   Workspace cws;                      // lean workspace of chain verification: no window tables, no digit planes
-  DevBuf<uint32_t> chain_cw, chain_cs;
+  DevBuf<uint32_t> chain_cw, chain_cs, chain_dig;
+  // the weights of T chain / group equations of L links each (kernels_proto.hpp: block digests, then table key, block key, 64 weights per lane)
+  void run_chain_weights(Workspace& w, uint32_t Tpad, uint32_t T, uint32_t L) {
+    const uint32_t nb = (L + CW_BLOCK - 1) / CW_BLOCK;
+    chain_dig.alloc((size_t)nb * 8 * Tpad, ctx->stream, false);
+    ChainWeightsArgs wa{w.seed.p, chain_cw.p, chain_dig.p, w.Bpad, Tpad, T, L};
+    MP_RUN(k_chain_digest, C, T, nb, wa);
+    MP_RUN(k_chain_weights, C, T, nb, wa);
+  }
   DevBuf<int16_t> chain_d8;
   // Tables per chain equation (round 5).  One table's chain is 4 424 points for 32 links of a 52-card deck: 8-bit windows (32 per
   // scalar) and a wave-wide reduction per window that is a sixth of its additions.  The chains of G tables added up with the same kind
@@ -1555,8 +1608,7 @@ struct Table : mp_table {
     chain_cw.alloc((size_t)Lq * Tpad * 8, s, false);
     chain_cs.alloc((size_t)nterms * Tpad * 8, s);
     chain_d8.alloc((size_t)chain.dev.b_dig_bytes * Tpad, s);
-    ChainWeightsArgs wa{w.seed.p, chain_cw.p, w.Bpad, Tpad, Tq, Lq};
-    MP_RUN(k_chain_weights, C, Tq, 1, wa);
+    run_chain_weights(w, Tpad, Tq, Lq);
     ChainScalArgs ca{w.S.p, chain_cw.p, chain_cs.p, chain.dterms.p, w.Bpad, Tpad, Tq};
     MP_RUN(k_chain_scalars, C, Tq, nterms, ca);
     PhaseDev& ph = chain.dev;
@@ -1595,11 +1647,18 @@ struct Table : mp_table {
   // fails is re-verified equation by equation, so the status words are exactly those of the other paths.  Lane of (member j, group t)
   // = j T + t with T = B / L groups: the members of a group are T proofs apart.
   // round 5, the bucket kernel's memory side (kernels_bucket.hpp): contiguous point runs per group, XCD-affine items, LDS-staged points
-  static bool exp_flag(const char* name, bool dflt) {      // (A/B hooks of the round: MP_BK_TILE / MP_BK_XCD / MP_BK_STAGE = 0 | 1)
-    const char* v = getenv(name);
-    return v && *v ? *v != '0' : dflt;
-  }
-  bool bk_tile = exp_flag("MP_BK_TILE", true), bk_xcd_affine = exp_flag("MP_BK_XCD", true), bk_stage = exp_flag("MP_BK_STAGE", true);
+  // (A/B hooks of round 5, compile-time like the others -- tools/ab_build.py -DMP_EXP_BK_TILE=0 ...; the product library reads no
+  // environment variable.  profiles/r05b_bucket_ab.txt has what each bought)
+#ifndef MP_EXP_BK_TILE
+#define MP_EXP_BK_TILE 1
+#endif
+#ifndef MP_EXP_BK_XCD
+#define MP_EXP_BK_XCD 1
+#endif
+#ifndef MP_EXP_BK_STAGE
+#define MP_EXP_BK_STAGE 1
+#endif
+  static constexpr bool bk_tile = MP_EXP_BK_TILE != 0, bk_xcd_affine = MP_EXP_BK_XCD != 0, bk_stage = MP_EXP_BK_STAGE != 0;
   DevBuf<uint32_t> gtile[2];          // [lane] the group equations' point runs: T x K x 64 bytes (4 GB at 262 144 proofs of 52 cards)
   std::map<std::pair<uint32_t, bool>, std::unique_ptr<ChainPlan>> gplans;      // by (proofs per group, keyed): a failing batch alternates between two sizes
   Workspace gws;                      // lean workspace of the pipelined group pass: no window tables, no digit planes (68 KB per proof)
@@ -1611,10 +1670,22 @@ struct Table : mp_table {
   uint32_t bucket_bits_of(uint32_t K) const { return bucket_bits ? bucket_bits : bk_bits_for(K); }
   // (BLS12-377: the bucket kernel's additions over a 377-bit field spill ~200 registers at two waves per SIMD and only draw level with the
   // Straus screen -- 13.1 k against 13.1 k proofs/s at (10,30) --, so groups are off there unless mp_set_group_verify asks for them)
-  uint32_t group_points = G_::FW > 8 ? 0u : 30464u;      // points per group equation aimed at (mp_set_group_verify; 0 = off): 128 proofs of a 52-card deck
+  // Round 6: two sizes.  group_points (30 464: 128 proofs of a 52-card deck, 10-bit windows on one wave per window, 26 additions per
+  // point) is what a batch of fewer than 32 768 proofs takes under the rule below; a batch that leaves at least min_batch / 48 (128)
+  // equations of at least GROUP_WG_POINTS_MIN points takes equations of up to group_points_wg points (243 712: 1 024 proofs of a 52-card
+  // deck) instead -- 12- and 13-bit windows on the split pipeline (kernels_bucket.hpp k_bucket_sort / _acc / _reduce: 22 and 20
+  // additions per point; its units are a sixteenth of a window, so 128 equations keep the chip busy).  Whole steps on one box
+  // (profiles/r06i_batches.txt): 262 144 proofs 663 -> 694 k/s (1 024 per equation), 131 072: 644 -> 673 k (512 or 1 024), 65 536:
+  // 610 -> 638 k (256 or 512), 32 768: 550 -> 566 k (256).
+  static const uint32_t GROUP_POINTS_WAVE = 30464u, GROUP_POINTS_WG = 243712u, GROUP_WG_POINTS_MIN = 50000u;
+  uint32_t group_points = G_::FW > 8 ? 0u : GROUP_POINTS_WAVE;      // points per group equation aimed at (mp_set_group_verify; 0 = off)
+  uint32_t group_points_wg = G_::FW > 8 ? 0u : GROUP_POINTS_WG;     // ... by the batches large enough for the workgroup kernel (0 = never)
   uint32_t group_min_batch = 6144;    // smaller batches (in 52-card proofs: x 52 / N) keep the per-proof screen
   void set_group_verify(uint32_t points, size_t min_batch) override {
-    group_points = points;
+    // (one knob: up to 65 535 points = equations of that size at the most, under the rule of rounds 4-5; more = the split pipeline's
+    // equations for the batches large enough, the default size below them)
+    group_points = std::min(points, points > 65535u ? GROUP_POINTS_WAVE : 65535u);
+    group_points_wg = points > 65535u ? points : 0u;
     group_min_batch = (uint32_t)std::min<size_t>(min_batch, 0x7FFFFFFFu);
   }
   // proofs per group for a batch of B: the divisor of B nearest to the wanted size (between half and twice it) whose equation
@@ -1628,13 +1699,17 @@ struct Table : mp_table {
     // waves busy
     const uint32_t groups_min = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)group_min_batch * 2u) / 13u));
     uint32_t want = std::min<uint32_t>((group_points + per / 2) / per, B / groups_min);
+    // (large batches: the split pipeline's equations, if at least min_batch / 48 of at least GROUP_WG_POINTS_MIN points are left)
+    const uint32_t want_wg = std::min<uint32_t>((group_points_wg + per / 2) / per, B / std::max<uint32_t>(1u, group_min_batch / 48u));
+    if (group_points_wg && (uint64_t)want_wg * per >= GROUP_WG_POINTS_MIN) want = std::max(want, want_wg);
     // (under sustained rejection the groups shrink: note_group_verdicts below)
     if (want >= 4) want = std::max<uint32_t>(want >> adapt_shift, 4u);
     if (want < 2) return 0;
     for (uint32_t d = 0; d <= want; ++d)
       for (int sgn = 1; sgn >= -1; sgn -= 2) {
         const int64_t L = (int64_t)want + sgn * (int64_t)d;
-        if (L < 2 || 2 * L < (int64_t)want || L > 2 * (int64_t)want || (uint64_t)L * per + n + 5 > BUCKET_TERMS_MAX || L > 1023) continue;      // (10 bits of link in a sorted entry: kernels_bucket.hpp)
+        // (without the contiguous run of k_group_tile a sorted entry names member and slot: 10 bits of link -- kernels_bucket.hpp)
+        if (L < 2 || 2 * L < (int64_t)want || L > 2 * (int64_t)want || (uint64_t)L * per + n + 5 > BUCKET_TERMS_MAX || (!bk_tile && L > 1023)) continue;
         if (B % (uint32_t)L == 0) return (uint32_t)L;
       }
     return 0;
@@ -1656,7 +1731,7 @@ struct Table : mp_table {
   void note_group_verdicts(uint32_t T, uint32_t failing, uint32_t L) {
     if (!group_adapt || T < 64) return;
     if ((uint64_t)failing * 5 > T) {
-      if (L >= 16 && adapt_shift < 4) ++adapt_shift;
+      if (L >= 16 && adapt_shift < 7) ++adapt_shift;
     } else if ((uint64_t)failing * 25 < T && adapt_shift > 0) {
       --adapt_shift;
     }
@@ -1691,11 +1766,15 @@ struct Table : mp_table {
         gplan.cterms.push_back(ChainTerm{l.mvar + slot, j, 1, NO_SLOT, 1});
       }
     gplan.K = (uint32_t)gplan.cterms.size();
+    // (the scalar of a fixed base is a sum over the members, one lane adding them up in k_chain_scalars: in runs of at most 64 members --
+    // a base then appears ceil(L / 64) times in the fixed-base part -- so that no lane of that kernel runs 1 024 products in a row)
     FixedBases fb{n};
     for (uint32_t f = 0; f < fb.count(); ++f) {
       if (keyed && f == fb.pk()) continue;
-      pb.fixed((uint32_t)gplan.cterms.size(), f);
-      gplan.cterms.push_back(ChainTerm{l.mfix + f, 0, L, NO_SLOT, 1});
+      for (uint32_t j0 = 0; j0 < L; j0 += 64u) {
+        pb.fixed((uint32_t)gplan.cterms.size(), f);
+        gplan.cterms.push_back(ChainTerm{l.mfix + f, j0, std::min(64u, L - j0), NO_SLOT, 1});
+      }
     }
     gplan.nfix = (uint32_t)gplan.cterms.size() - gplan.K;
     pb.end();
@@ -1758,8 +1837,7 @@ struct Table : mp_table {
           ~Restore() { c->stream = keep; }
         } restore{ctx, s};
         ctx->stream = ctx->side;
-        ChainWeightsArgs wa{w.seed.p, chain_cw.p, w.Bpad, Tpad, T, L};
-        MP_RUN(k_chain_weights, C, T, 1, wa);
+        run_chain_weights(w, Tpad, T, L);
         rt::event_record(ctx->ev_tab, ctx->side);
       }
       VerifyScalArgs sa{w.S.p, w.P.p, w.direct.p, l, q.vplan.cm, w.Bpad};

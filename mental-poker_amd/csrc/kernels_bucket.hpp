@@ -41,7 +41,8 @@
 
 namespace mp {
 
-static const uint32_t BK_BITS_MIN = 8, BK_BITS_MAX = 11;     // signed windows: digits in [-2^(c-1), 2^(c-1) - 1]
+static const uint32_t BK_BITS_MIN = 8, BK_BITS_MAX = 13;     // signed windows: digits in [-2^(c-1), 2^(c-1) - 1]
+// (windows of 12 bits and more: the split pipeline at the end of this file, round 6)
 #ifdef MP_EXP_BK_OCC
 static const uint32_t BK_WAVES_PER_CU = 4 * MP_EXP_BK_OCC;   // persistent waves: MP_EXP_BK_OCC workgroups of 4 per CU
 #else
@@ -50,9 +51,13 @@ static const uint32_t BK_WAVES_PER_CU = 8;                   // persistent waves
 static inline uint32_t bk_windows(int scalar_bits, uint32_t c) { return ((uint32_t)scalar_bits + c) / c; }
 MP_HD uint32_t bk_buckets(uint32_t c) { return 1u << (c - 1); }
 // window width for an MSM of K terms: the reduction F costs ~(20 + 4 NB) additions per window, a narrower window K / (c (c + 1)) more
-static inline uint32_t bk_bits_for(uint32_t K) { return K >= 40000u ? 11u : (K >= 12000u ? 10u : (K >= 6000u ? 9u : 8u)); }
-// LDS words one wave needs: counts + cursors of the buckets, 64 XYZZ exchange slots of xw words
-static inline uint32_t bk_lds_words(uint32_t c, uint32_t xw) { return 2u * (bk_buckets(c) + 4u) + 64u * xw; }
+// (12 bits and more: the split pipeline at the end of this file; measured on whole steps, profiles/r06i_batches.txt: 256 proofs of a
+// 52-card deck -- 60 928 points -- are better off with 12 bits there than with 11 on one wave per window)
+static inline uint32_t bk_bits_for(uint32_t K) {
+  return K >= 200000u ? 13u : (K >= 50000u ? 12u : (K >= 40000u ? 11u : (K >= 12000u ? 10u : (K >= 6000u ? 9u : 8u))));
+}
+// LDS words one item's lanes need: counts + cursors of the buckets, one XYZZ exchange slot of xw words per lane
+static inline uint32_t bk_lds_words(uint32_t c, uint32_t xw, uint32_t lanes = 64u) { return 2u * (bk_buckets(c) + 4u) + lanes * xw; }
 
 // ---- digits: canonical scalar -> W signed digits, d_w in [-2^(c-1), 2^(c-1) - 1] (top window non-negative), proof-major:
 // D16[b * dstride + pos + w * kpad]  (pos = digit offset of the term inside the proof's block, kpad = padded terms of its MSM)
@@ -121,6 +126,7 @@ struct alignas(16) Quad32 {
 };
 static const uint32_t BK_SLOT_MASK = 0xFFFFFu;
 static const uint32_t BK_LINK_MASK = 0x3FFu;     // (bit 31 of a sorted entry is the sign: 1 023 links)
+static const uint32_t BK_TILE_MASK = 0xFFFFFFu;  // ... or the term's index in the equation's contiguous run (k_group_tile)
 template <class C>
 MP_HD void xyzz_to_words(const Xyzz<C>& p, uint32_t* w) {
   constexpr int L = sizeof(p.X.v) / 4;
@@ -152,8 +158,8 @@ struct XyzzWords {
 
 template <class C, class W>
 MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
-  constexpr uint32_t XW = XyzzWords<C>::N;
-  const uint32_t NBK = bk_buckets(a.bits), NB = NBK >> 6, LOGNB = a.bits - 7u, HW = NBK + 4u;
+  constexpr uint32_t XW = XyzzWords<C>::N, NL = W::NL, LOG_NL = W::LOG_NL;      // NL lanes share the item: a wave (64) or a workgroup (256)
+  const uint32_t NBK = bk_buckets(a.bits), NB = NBK >> LOG_NL, LOGNB = a.bits - 1u - LOG_NL, HW = NBK + 4u;
   uint32_t* cnt = wv.lds;                         // [0 .. NBK]: terms per |digit|; then off[]: first sorted position per bucket
   uint32_t* cur = wv.lds + HW;                    // scatter cursors; after the scatter: the lanes' bucket assignment [class][lane]
   uint32_t* xch = wv.lds + 2 * HW;                // point exchange of the reduction
@@ -196,7 +202,7 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
 #endif
     // A: clear the histogram
     wv.lanes([&](uint32_t lane) {
-      for (uint32_t i = lane; i < HW; i += 64) cnt[i] = 0;
+      for (uint32_t i = lane; i < HW; i += NL) cnt[i] = 0;
     });
     wv.sync();
     // B: histogram of |d|.  B and D are latency, not work: their loops are branch-free (the padding of the row counts as zero digits,
@@ -204,9 +210,9 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
     const uint32_t nq = kpad / 8;
     wv.lanes([&](uint32_t lane) {
       Quad32 next = src[lane < nq ? lane : nq - 1];
-      for (uint32_t i = lane; i < nq; i += 64) {
+      for (uint32_t i = lane; i < nq; i += NL) {
         const Quad32 eight = next;
-        next = src[i + 64 < nq ? i + 64 : nq - 1];
+        next = src[i + NL < nq ? i + NL : nq - 1];
 #pragma unroll
         for (uint32_t q = 0; q < 8; ++q) {
           const int d = 8 * i + q < K ? (int16_t)(eight.v[q >> 1] >> (16 * (q & 1))) : 0;
@@ -216,7 +222,7 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
     });
     wv.sync();
     // C: offsets of the counting sort (wavefront prefix sum over the lanes' NB-bucket totals)
-    PerLane<uint32_t> tot;
+    typename W::template PL<uint32_t> tot;
     wv.lanes([&](uint32_t lane) {
       uint32_t t = 0;
       for (uint32_t j = 0; j < NB; ++j) t += cnt[NB * lane + 1 + j];
@@ -231,7 +237,7 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
         cnt[k] = cur[k] = o;
         o += c;
       }
-      if (lane == 63) cnt[NBK + 1] = cur[0] = o;      // (the zero digits: sorted behind every bucket, never visited)
+      if (lane == NL - 1) cnt[NBK + 1] = cur[0] = o;      // (the zero digits: sorted behind every bucket, never visited)
     });
     wv.sync();
     T = off[NBK + 1];
@@ -242,12 +248,12 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
       uint32_t nref[8];
 #pragma unroll
       for (uint32_t q = 0; q < 8; ++q) nref[q] = terms[8 * lane + q < K ? 8 * lane + q : K - 1].b;
-      for (uint32_t i = lane; i < nq; i += 64) {
+      for (uint32_t i = lane; i < nq; i += NL) {
         const Quad32 eight = next;
         uint32_t ref[8];
 #pragma unroll
         for (uint32_t q = 0; q < 8; ++q) ref[q] = nref[q];
-        const uint32_t j = i + 64 < nq ? i + 64 : nq - 1;
+        const uint32_t j = i + NL < nq ? i + NL : nq - 1;
         next = src[j];
 #pragma unroll
         for (uint32_t q = 0; q < 8; ++q) nref[q] = terms[8 * j + q < K ? 8 * j + q : K - 1].b;
@@ -266,18 +272,18 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
     MP_BK_T(0);
     // E: accumulation, one mixed addition per term: run += +-P_t.  The lane's walk through the sorted list runs two terms ahead of
     // the additions: the entry of term i + 2 is requested while term i is added, so that only the point itself is waited for.
-    PerLane<uint32_t> n, seg, pos, rem;        // the fetch side (balanced mode: pos = one past the share's top position, rem = the bucket the additions are in)
-    PerLane<uint32_t> mseg, e0, e1, nb0, nb1;  // the additions' side: class of the bucket being summed; entries of terms i and i + 1, and whether
+    typename W::template PL<uint32_t> n, seg, pos, rem;        // the fetch side (balanced mode: pos = one past the share's top position, rem = the bucket the additions are in)
+    typename W::template PL<uint32_t> mseg, e0, e1, nb0, nb1;  // the additions' side: class of the bucket being summed; entries of terms i and i + 1, and whether
                                                // they open a new bucket (kept apart from the entry: nothing may wait for the load before its turn)
-    wv.lanes([&](uint32_t lane) {              // ranks by counting: NB x 64 broadcast reads per lane
+    wv.lanes([&](uint32_t lane) {              // ranks by counting: NB x NL broadcast reads per lane
       for (uint32_t j = 0; j < NB; ++j) {
         const uint32_t mine = off[NB * lane + 2 + j] - off[NB * lane + 1 + j];
         uint32_t r = 0;
-        for (uint32_t l = 0; l < 64; ++l) {
+        for (uint32_t l = 0; l < NL; ++l) {
           const uint32_t o = off[NB * l + 2 + j] - off[NB * l + 1 + j];
           r += (o > mine || (o == mine && l < lane)) ? 1u : 0u;
         }
-        cur[j * 64 + ((j & 1u) ? 63u - r : r)] = lane;      // worker lane -> the home lane of its bucket of class j
+        cur[j * NL + ((j & 1u) ? NL - 1u - r : r)] = lane;      // worker lane -> the home lane of its bucket of class j
       }
     });
     wv.sync();
@@ -285,7 +291,7 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
     wv.lanes([&](uint32_t lane) {
       uint32_t t = 0;
       for (uint32_t j = 0; j < NB; ++j) {
-        const uint32_t k = NB * cur[j * 64 + lane] + 1 + j;
+        const uint32_t k = NB * cur[j * NL + lane] + 1 + j;
         t += off[k + 1] - off[k];
       }
       n[lane] = t;
@@ -293,7 +299,7 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
 #ifdef MP_EXP_BK_BALANCED  // experiment hook (tools/ab_build.py): every window in balanced mode
     const bool balanced = true;
 #else
-    const bool balanced = wv.max(n) > T / 64 + T / 128 + 32;
+    const bool balanced = wv.max(n) > T / NL + T / (2 * NL) + 32;
 #endif
     // the position of the next entry of the lane's walk (only called while terms remain); fresh: it is the first term of a new bucket
     auto advance = [&](uint32_t lane, uint32_t j, uint32_t& fresh) -> uint32_t {
@@ -301,7 +307,7 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
       if (balanced) return pos[lane] - 1 - j;
       while (rem[lane] == 0) {                 // on to the lane's bucket of the next class (empty ones are passed over)
         seg[lane] += 1;
-        const uint32_t k = NB * cur[seg[lane] * 64 + lane] + 1 + seg[lane];
+        const uint32_t k = NB * cur[seg[lane] * NL + lane] + 1 + seg[lane];
         pos[lane] = off[k];
         rem[lane] = off[k + 1] - off[k];
         fresh = 1;
@@ -312,14 +318,14 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
     };
     const uint32_t* const tile = a.tile ? a.tile + (size_t)b * a.tile_K * Geo<C>::PW : nullptr;
     auto point_of = [&](uint32_t e) -> const uint32_t* {
-      if (tile) return tile + (size_t)(e & 0xFFFFu) * Geo<C>::PW;
+      if (tile) return tile + (size_t)(e & BK_TILE_MASK) * Geo<C>::PW;
       return a.P + p_off<C>(e & BK_SLOT_MASK, a.Bpad, b + ((e >> 20) & BK_LINK_MASK) * a.link_stride);
     };
     // pair mode: the exchange area is idle during the additions -- it stages the next point (4 KB of its 9)
     const bool staged = a.stage != 0 && !balanced;
     // (acc is not needed while the pair-mode loop runs; the balanced walk keeps it in the lane's exchange slot in LDS -- 32 registers less
     // across the mixed addition)
-    PerLane<Xyzz<C>> run;
+    typename W::template PL<Xyzz<C>> run;
     wv.lanes([&](uint32_t lane) {
       run[lane] = xyzz_inf<C>();
       seg[lane] = 0;
@@ -328,7 +334,7 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
         xyzz_to_words<C>(run[lane], xch + lane * XW);
         // equal shares of the sorted list, walked from the top; whenever a lane crosses into the next lower bucket it adds the running
         // sum to acc, so that at the end  sum_t d_t P_t over the share = lo * run + acc  with lo the lowest bucket reached
-        const uint32_t s0 = (uint32_t)(((uint64_t)T * lane) >> 6), s1 = (uint32_t)(((uint64_t)T * (lane + 1)) >> 6);
+        const uint32_t s0 = (uint32_t)(((uint64_t)T * lane) >> LOG_NL), s1 = (uint32_t)(((uint64_t)T * (lane + 1)) >> LOG_NL);
         uint32_t lo_b = 1, hi_b = NBK;                    // largest bucket whose first position is <= s1 - 1
         const uint32_t last = s1 ? s1 - 1 : 0;
         while (lo_b < hi_b) {
@@ -349,7 +355,7 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
       if (n[lane] > 1) e1[lane] = ix[advance(lane, 1, nb1[lane])];
       nb0[lane] = 0;
       if (!balanced && n[lane] > 0)
-        while (off[NB * cur[mseg[lane] * 64 + lane] + 2 + mseg[lane]] == off[NB * cur[mseg[lane] * 64 + lane] + 1 + mseg[lane]]) mseg[lane] += 1;
+        while (off[NB * cur[mseg[lane] * NL + lane] + 2 + mseg[lane]] == off[NB * cur[mseg[lane] * NL + lane] + 1 + mseg[lane]]) mseg[lane] += 1;
       if (staged && n[lane] > 0) wv.template stage<Geo<C>::PW>(xch, point_of(e0[lane]), lane);
     });
     const uint32_t iters = wv.max(n);
@@ -369,10 +375,10 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
               rem[lane] -= 1;
             }
           } else if (fresh) {                             // the bucket before this term is done: park its sum
-            xyzz_to_words<C>(run[lane], park + (size_t)(NB * cur[mseg[lane] * 64 + lane] + mseg[lane]) * XW);
+            xyzz_to_words<C>(run[lane], park + (size_t)(NB * cur[mseg[lane] * NL + lane] + mseg[lane]) * XW);
             run[lane] = xyzz_inf<C>();
             do mseg[lane] += 1;
-            while (off[NB * cur[mseg[lane] * 64 + lane] + 2 + mseg[lane]] == off[NB * cur[mseg[lane] * 64 + lane] + 1 + mseg[lane]]);
+            while (off[NB * cur[mseg[lane] * NL + lane] + 2 + mseg[lane]] == off[NB * cur[mseg[lane] * NL + lane] + 1 + mseg[lane]]);
           }
 #ifdef MP_EXP_BK_NOPOINT   // experiment: every point out of 256 cache-resident ones (wrong sums; how much of the kernel is memory latency)
           const Aff<C> q = ld_aff<C>(a.P + p_off<C>(e & 0xFFu, a.Bpad, b));
@@ -403,10 +409,10 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
     wv.sync();
     MP_BK_T(2);
     // F: sum over the buckets of k S_k
-    PerLane<Xyzz<C>> acc;
+    typename W::template PL<Xyzz<C>> acc;
     if (!balanced) {
       wv.lanes([&](uint32_t lane) {                                     // the last sum (empty buckets have no parked sum: the reader knows)
-        if (n[lane] > 0) xyzz_to_words<C>(run[lane], park + (size_t)(NB * cur[mseg[lane] * 64 + lane] + mseg[lane]) * XW);
+        if (n[lane] > 0) xyzz_to_words<C>(run[lane], park + (size_t)(NB * cur[mseg[lane] * NL + lane] + mseg[lane]) * XW);
       });
       wv.sync_global();
       wv.lanes([&](uint32_t lane) {                                     // the sums come home: R = sum of the lane's NB buckets,
@@ -419,11 +425,11 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
         }
       });
       // sum_l (NB l + 1) R_l = Suf_0 + NB sum_{l>=1} Suf_l with the inclusive suffix sums Suf_l = sum_{l'>=l} R_l'
-      for (uint32_t s = 1; s < 64; s <<= 1) {
+      for (uint32_t s = 1; s < NL; s <<= 1) {
         wv.lanes([&](uint32_t lane) { xyzz_to_words<C>(run[lane], xch + lane * XW); });
         wv.sync();
         wv.lanes([&](uint32_t lane) {
-          if (lane + s < 64) xyzz_add_ip<C>(run[lane], xyzz_from_words<C>(xch + (lane + s) * XW));
+          if (lane + s < NL) xyzz_add_ip<C>(run[lane], xyzz_from_words<C>(xch + (lane + s) * XW));
         });
         wv.sync();
       }
@@ -440,7 +446,7 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
       const uint32_t lomax = wv.max(rem);
       int nb = 0;
       while ((lomax >> nb) != 0) ++nb;
-      PerLane<Xyzz<C>> prod;
+      typename W::template PL<Xyzz<C>> prod;
       wv.lanes([&](uint32_t lane) { prod[lane] = xyzz_inf<C>(); });
       for (int bit = nb - 1; bit >= 0; --bit) {
         wv.lanes([&](uint32_t lane) {
@@ -450,7 +456,7 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
       }
       wv.lanes([&](uint32_t lane) { xyzz_add_ip<C>(acc[lane], prod[lane]); });
     }
-    for (uint32_t s = 32; s >= 1; s >>= 1) {                            // tree reduction
+    for (uint32_t s = NL / 2; s >= 1; s >>= 1) {                        // tree reduction
       wv.lanes([&](uint32_t lane) { xyzz_to_words<C>(acc[lane], xch + lane * XW); });
       wv.sync();
       wv.lanes([&](uint32_t lane) {
@@ -478,6 +484,476 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
 #define MP_BK_OCC(C) 2
 #endif
 MP_WAVE_KERNEL_OCC(k_bucket_msm, BucketArgs, body_bucket_msm, MP_BK_OCC(C))
+
+// ================================================================================================================================
+// Round 6: the SPLIT pipeline -- windows of BK_SPLIT_BITS bits and more (equations of >= 100 000 points: the screen of 512 .. 1 024
+// proofs of a 52-card deck, of 32 .. 64 proofs of a 1 024-card one, the chains of 32 .. 64 tables).
+//
+// One wave per (equation, window) caps the kernel above at 11 bits: 2^(c-1) buckets on 64 lanes are 16 per lane and a 42-addition
+// reduction per window at c = 11, which cancels the gain of 23 windows over 26.  Giving the window to a 256-lane workgroup instead
+// (measured first, profiles/r06a_wg_kernel_sweep.txt) executed 22 % fewer instructions and was 10 % faster, not 25 %: an item of
+// 243 712 points is a tenth of what a persistent workgroup does in the launch, so the launch waited 9 % of its time for the last items;
+// the sort of an item ran at two waves per SIMD (the register budget of the additions) and took 11 % of it -- its scatter writes four
+// bytes at a time into a 1 MB row, 512 rows in flight: every store a read-modify-write of a 64-byte line in HBM --; and the ranks by
+// counting cost 256 comparisons per bucket.  So the three phases are three kernels, each with the parallelism and the registers IT
+// wants, the sorted list leaves the chip in whole lines, and the additions are handed out in pieces a twentieth the size:
+//
+//   k_bucket_sort    one 256-lane workgroup per (item, CHUNK of BK_CHUNK = 24 576 terms), ~32 registers, two workgroups per CU:
+//                    histogram of |d| (LDS atomics), exclusive scan (wavefront prefix sums, the four waves joined through LDS),
+//                    counting sort of the chunk's point references INSIDE LDS, then one contiguous copy to the chunk's run of `sorted`;
+//                    the bucket offsets inside the run go to `offs` as 16-bit words, with the largest bucket of the chunk in front.
+//                    A bucket's terms are then G = ceil(K / 24 576) short runs, one per chunk, instead of one long one;
+//   k_bucket_acc     one WAVE per unit = (item, one of P bucket ranges of 64 x NB2 buckets): the lanes take NB2 = 4 buckets each,
+//                    dealt by rank inside the unit (64 comparisons per bucket), and walk a bucket's G runs one after the other -- one
+//                    mixed addition per term with the next point staged global -> LDS as above, every bucket sum parked in the item's
+//                    row of `park` (the point at infinity for an empty bucket: the reduction reads no offsets).  A unit is ~240
+//                    additions per lane: 81 920 units for the 5 120 items of 262 144 52-card proofs, 40 per wave slot -- the
+//                    hardware's own workgroup dispatcher hands them out, and the launch ends within one unit (0.8 ms) of its average.
+//                    LIST mode, for a window whose digits crowd into a few buckets (the top window of a 252-bit scalar holds 17
+//                    values at c = 13; an MSM whose scalars are all equal): unit g takes chunk g's run in 64 equal shares and
+//                    leaves ONE sum.  An item is in list mode if a chunk's largest bucket exceeds eight times its share (+ 32);
+//   k_bucket_reduce  one wave per item: sum_k k S_k over the 2^(c-1) parked sums as in F above with NB = 2^(c-1) / 64 buckets per
+//                    lane (2 NB - 3 + 13 additions: 8 % fewer wave-additions than four waves of NB / 4), or the sum of the G list sums.
+//
+// `sorted`, `offs` and `park` hold every item of a pass at once (1.6 MB per item at c = 13: the engine cuts a call into passes of
+// equations that fit its scratch budget).  Results are canonical group elements: bit-identical to the kernel above.
+static const uint32_t BK_SPLIT_BITS = 12;
+#ifndef MP_EXP_BK_CHUNK     // (A/B hook, tools/ab_build.py)
+#define MP_EXP_BK_CHUNK 24576
+#endif
+static const uint32_t BK_CHUNK = MP_EXP_BK_CHUNK;       // terms per sorted run (48 KB of LDS -- 16-bit local indices -- beside the 16 KB of counters at c = 13; < 32 768: sign in bit 15)
+static const uint32_t BK_CHUNKS_MAX = 24;     // runs per bucket (their offsets sit in the accumulating wave's LDS): 589 824 terms per job
+static_assert((size_t)BK_CHUNKS_MAX * MP_EXP_BK_CHUNK >= BUCKET_TERMS_MAX || MP_EXP_BK_CHUNK != 24576, "layout.hpp BUCKET_TERMS_MAX");
+#ifndef MP_EXP_BK_UNIT_NB
+#define MP_EXP_BK_UNIT_NB 4
+#endif
+MP_HD uint32_t bk_unit_nb(uint32_t c) { return bk_buckets(c) >= 64u * MP_EXP_BK_UNIT_NB ? (uint32_t)MP_EXP_BK_UNIT_NB : bk_buckets(c) / 64u; }      // buckets per lane and unit
+MP_HD uint32_t bk_units(uint32_t c) { return bk_buckets(c) / (64u * bk_unit_nb(c)); }                    // bucket ranges per item (P <= 64)
+MP_HD uint32_t bk_chunks(uint32_t kpad) { return (kpad + BK_CHUNK - 1u) / BK_CHUNK; }
+// offs row of (item, chunk), 16-bit words: [0] largest bucket of the chunk, [k] first position of bucket k inside the run (k = 1 ..
+// NBK), [NBK + 1] the chunk's terms with a non-zero digit; rows of NBK + 2 words
+MP_HD uint32_t bk_offs_row(uint32_t c) { return bk_buckets(c) + 2u; }
+MP_HD bool bk_crowded(uint32_t largest, uint32_t c) { return largest > 8u * (BK_CHUNK / bk_buckets(c)) + 32u; }
+struct BSplitArgs {
+  const int16_t* D16;
+  const uint32_t* P;
+  uint32_t* J;
+  const BJob* jobs;
+  const Term* bterms;
+  uint32_t Bpad, nwin, njobs;
+  size_t dstride;
+  uint32_t link_stride, bits;
+  uint32_t eq0, neq;       // this pass: equations [eq0, eq0 + neq) of the call; item = ((e - eq0) njobs + job) nwin + window
+  const uint32_t* tile;
+  uint32_t tile_K;
+  uint32_t* sorted;        // [items][kpad_max]: chunk g's run starts at g BK_CHUNK
+  uint16_t* offs;          // [items][gmax][2^(c-1) + 2]
+  uint32_t* park;          // [items][2^(c-1)][XYZZ words] bucket sums (list mode: the first G slots hold the chunks' sums)
+  uint32_t kpad_max, gmax; // gmax = bk_chunks(kpad_max)
+  uint32_t units;          // units per item: its bucket ranges, bk_units(bits)
+  uint32_t wpb, wgs;       // k_bucket_acc: waves per workgroup of the launch, workgroups that hold units
+};
+// k_bucket_acc: which unit a wave of the launch takes.  Workgroup i of a launch runs on XCD i mod 8 (observed; the hardware deals
+// workgroups round-robin and statically), and consecutive units belong to the same item: dealt as they come, the units of every other
+// window -- and with them all the list-mode windows, which are slower -- met on the same half of the XCDs, and the launch waited for
+// that half (-10 %: profiles/r06g_xcd_placement.txt).  So XCD r gets the r-th EIGHTH of the units, whole equations: an equation's
+// windows share one L2 again (the XCD-affine items of round 5), and every XCD holds the same mix of windows.
+MP_HD uint32_t bk_unit_of_wave(const BSplitArgs& a, uint32_t wave, uint32_t nunits) {
+  const uint32_t i = wave / a.wpb, lane_wave = wave % a.wpb, per = (a.wgs + 7u) / 8u;
+  const uint32_t j = (i % 8u) * per + i / 8u;
+  if (j >= a.wgs) return 0xFFFFFFFFu;
+  const uint32_t u = j * a.wpb + lane_wave;
+  return u < nunits ? u : 0xFFFFFFFFu;
+}
+struct BItem {
+  uint32_t w, jb, b;
+};
+MP_HD BItem bk_item(const BSplitArgs& a, uint32_t it) {
+  BItem r;
+  r.w = it % a.nwin;
+  r.jb = (it / a.nwin) % a.njobs;
+  r.b = a.eq0 + it / (a.nwin * a.njobs);
+  return r;
+}
+// is the item summed in list mode?  (every unit of the item and its reduction ask the same question of the same words)
+MP_HD bool bk_list_mode(const BSplitArgs& a, uint32_t it, uint32_t G) {
+  const uint16_t* og = a.offs + (size_t)it * a.gmax * bk_offs_row(a.bits);
+  uint32_t largest = 0;
+  for (uint32_t g = 0; g < G; ++g) {
+    const uint32_t m = og[(size_t)g * bk_offs_row(a.bits)];
+    largest = m > largest ? m : largest;
+  }
+  return bk_crowded(largest, a.bits);
+}
+
+// ---- k_bucket_sort: W = BlockCtx (256 lanes), x = item * gmax + chunk; wv.lds = 2^(c-1) + 2 + BK_CHUNK words
+template <class C, class W>
+MP_HD void body_bucket_sort(const BSplitArgs& a, uint32_t x, W& wv) {
+  constexpr uint32_t NL = W::NL;
+  const uint32_t NBK = bk_buckets(a.bits), ROW = bk_offs_row(a.bits);
+  const uint32_t it = x / a.gmax, g = x % a.gmax;
+  const BItem id = bk_item(a, it);
+  const BJob job = a.jobs[id.jb];
+  if (g >= bk_chunks(job.kpad)) return;            // (a shorter job of the phase)
+  const uint32_t K = job.count, t0 = g * BK_CHUNK, t1 = job.kpad < t0 + BK_CHUNK ? job.kpad : t0 + BK_CHUNK;      // the chunk's terms [t0, t1) of the padded row
+  const uint32_t q0 = t0 / 8, nq = (t1 - t0) / 8;
+  const Quad32* src = reinterpret_cast<const Quad32*>(a.D16 + (size_t)id.b * a.dstride + job.dig_off + (size_t)id.w * job.kpad) + q0;
+  uint32_t* cnt = wv.lds;                          // [0 .. NBK + 1]: terms per |digit|, then the scatter cursors
+  uint16_t* buf = reinterpret_cast<uint16_t*>(wv.lds + NBK + 2u);      // the chunk's sorted run: index of the term inside the chunk, sign in bit 15
+  uint16_t* og = a.offs + ((size_t)it * a.gmax + g) * ROW;
+  uint32_t* ix = a.sorted + (size_t)it * a.kpad_max + t0;
+  wv.lanes([&](uint32_t lane) {
+    for (uint32_t i = lane; i < NBK + 2u; i += NL) cnt[i] = 0;
+  });
+  wv.sync();
+  wv.lanes([&](uint32_t lane) {
+    Quad32 next = src[lane < nq ? lane : nq - 1];
+    for (uint32_t i = lane; i < nq; i += NL) {
+      const Quad32 eight = next;
+      next = src[i + NL < nq ? i + NL : nq - 1];
+#pragma unroll
+      for (uint32_t q = 0; q < 8; ++q) {
+        const int d = t0 + 8 * i + q < K ? (int16_t)(eight.v[q >> 1] >> (16 * (q & 1))) : 0;
+        if (d != 0) wv.atomic_add(&cnt[d < 0 ? -d : d], 1u);
+      }
+    }
+  });
+  wv.sync();
+  // offsets: lane l owns the buckets [lo, hi) of 1 .. NBK (a share of NBK / NL, or none when there are fewer buckets than lanes)
+  typename W::template PL<uint32_t> tot, big;
+  wv.lanes([&](uint32_t lane) {
+    const uint32_t lo = 1u + (uint32_t)(((uint64_t)NBK * lane) / NL), hi = 1u + (uint32_t)(((uint64_t)NBK * (lane + 1)) / NL);
+    uint32_t t = 0, m = 0;
+    for (uint32_t k = lo; k < hi; ++k) {
+      const uint32_t c = cnt[k];
+      t += c;
+      m = c > m ? c : m;
+    }
+    tot[lane] = t;
+    big[lane] = m;
+  });
+  wv.excl_scan(tot);
+  const uint32_t maxc = wv.max(big);
+  wv.lanes([&](uint32_t lane) {
+    const uint32_t lo = 1u + (uint32_t)(((uint64_t)NBK * lane) / NL), hi = 1u + (uint32_t)(((uint64_t)NBK * (lane + 1)) / NL);
+    uint32_t o = tot[lane];
+    for (uint32_t k = lo; k < hi; ++k) {
+      const uint32_t c = cnt[k];
+      cnt[k] = o;
+      og[k] = (uint16_t)o;
+      o += c;
+    }
+    if (lane == NL - 1) {
+      og[0] = (uint16_t)maxc;
+      og[NBK + 1] = (uint16_t)o;                   // the chunk's terms with a non-zero digit
+      cnt[NBK + 1] = o;
+    }
+  });
+  wv.sync();
+  wv.lanes([&](uint32_t lane) {
+    Quad32 next = src[lane < nq ? lane : nq - 1];
+    for (uint32_t i = lane; i < nq; i += NL) {
+      const Quad32 eight = next;
+      next = src[i + NL < nq ? i + NL : nq - 1];
+#pragma unroll
+      for (uint32_t q = 0; q < 8; ++q) {
+        const int d = t0 + 8 * i + q < K ? (int16_t)(eight.v[q >> 1] >> (16 * (q & 1))) : 0;
+        if (d != 0) {
+          const uint32_t at = wv.atomic_add(&cnt[d < 0 ? -d : d], 1u);
+          buf[at] = (uint16_t)((8 * i + q) | (d < 0 ? 0x8000u : 0u));
+        }
+      }
+    }
+  });
+  wv.sync();
+  const uint32_t Tg = cnt[NBK + 1];
+  wv.lanes([&](uint32_t lane) {                    // the run leaves in whole lines, as point references (the terms' table stays in the L2;
+    const Term* terms = a.bterms + job.begin + t0; // eight lookups in flight per lane: one at a time the loop waited 2 us per entry)
+    for (uint32_t i = lane; i < Tg; i += 8 * NL) {
+      uint32_t v[8], r[8];
+#pragma unroll
+      for (uint32_t q = 0; q < 8; ++q) v[q] = i + q * NL < Tg ? buf[i + q * NL] : 0u;
+#pragma unroll
+      for (uint32_t q = 0; q < 8; ++q) r[q] = terms[v[q] & 0x7FFFu].b;
+#pragma unroll
+      for (uint32_t q = 0; q < 8; ++q)
+        if (i + q * NL < Tg) ix[i + q * NL] = r[q] | ((v[q] & 0x8000u) << 16);
+    }
+  });
+}
+MP_BLOCK_KERNEL_OCC(k_bucket_sort, BSplitArgs, body_bucket_sort, 4)
+
+// ---- k_bucket_acc: W = WaveCtx; wv.lds = bk_acc_lds_words(c, gmax, XW, PW)
+static inline uint32_t bk_acc_lds_words(uint32_t c, uint32_t gmax, uint32_t xw, uint32_t pw) {
+  const uint32_t nbp = 64u * bk_unit_nb(c);
+  // offsets of the unit's buckets in every chunk (16-bit, rows of nbp + 2), bucket totals, assignment, staging / exchange
+  // (list mode needs none of the tables: its 64 XYZZ slots lie over them)
+  return std::max(gmax * (nbp + 2u) / 2u + nbp + nbp + 64u * pw, 64u * xw);
+}
+template <class C, class W>
+MP_HD void body_bucket_acc(const BSplitArgs& a, uint32_t wave, W& wv) {
+  constexpr uint32_t XW = XyzzWords<C>::N;
+  const uint32_t NBK = bk_buckets(a.bits), ROW = bk_offs_row(a.bits), NB = bk_unit_nb(a.bits), NBP = 64u * NB, OR = NBP + 2u;
+  const uint32_t unit = bk_unit_of_wave(a, wave, a.neq * a.njobs * a.nwin * a.units);
+  if (unit == 0xFFFFFFFFu) return;
+  const uint32_t it = unit / a.units, p = unit % a.units;
+  const BItem id = bk_item(a, it);
+  const uint32_t b = id.b;
+  const uint32_t G = bk_chunks(a.jobs[id.jb].kpad);
+  const uint16_t* og = a.offs + (size_t)it * a.gmax * ROW;
+  const uint32_t* ix = a.sorted + (size_t)it * a.kpad_max;
+  uint32_t* park = a.park + (size_t)it * NBK * XW;
+  uint16_t* o16 = reinterpret_cast<uint16_t*>(wv.lds);      // [G][OR]: o16[g][i] = first position of the unit's bucket i inside run g, i = 0 .. NBP
+  uint32_t* tot = wv.lds + a.gmax * OR / 2u;                // [NBP]: terms per bucket (all runs)
+  uint32_t* cur = tot + NBP;                                // [NB][64]: worker lane -> home lane of its bucket of class j
+  uint32_t* xch = cur + NBP;                                // the staged point (bucket mode)
+  const bool list = bk_list_mode(a, it, G);
+  const uint32_t* const tile = a.tile ? a.tile + (size_t)b * a.tile_K * Geo<C>::PW : nullptr;
+  auto point_of = [&](uint32_t e) -> const uint32_t* {
+    if (tile) return tile + (size_t)(e & BK_TILE_MASK) * Geo<C>::PW;
+    return a.P + p_off<C>(e & BK_SLOT_MASK, a.Bpad, b + ((e >> 20) & BK_LINK_MASK) * a.link_stride);
+  };
+  typename W::template PL<Xyzz<C>> run;
+  if (!list) {
+    // ---- bucket mode: the buckets base .. base + NBP - 1, NB per lane
+    const uint32_t base = 1u + p * NBP;
+    wv.lanes([&](uint32_t lane) {
+      for (uint32_t g = 0; g < G; ++g)
+        for (uint32_t i = lane; i <= NBP; i += 64) o16[g * OR + i] = og[(size_t)g * ROW + base + i];
+    });
+    wv.sync();
+    wv.lanes([&](uint32_t lane) {
+      for (uint32_t k = lane; k < NBP; k += 64) {
+        uint32_t t = 0;
+        for (uint32_t g = 0; g < G; ++g) t += (uint32_t)o16[g * OR + k + 1] - (uint32_t)o16[g * OR + k];
+        tot[k] = t;
+      }
+    });
+    wv.sync();
+    wv.lanes([&](uint32_t lane) {                  // ranks by counting inside the unit; the empty buckets' sums are written right away
+      for (uint32_t j = 0; j < NB; ++j) {
+        const uint32_t mine = tot[NB * lane + j];
+        uint32_t r = 0;
+        for (uint32_t l = 0; l < 64; ++l) {
+          const uint32_t o = tot[NB * l + j];
+          r += (o > mine || (o == mine && l < lane)) ? 1u : 0u;
+        }
+        cur[j * 64 + ((j & 1u) ? 63u - r : r)] = lane;
+        if (mine == 0) xyzz_to_words<C>(xyzz_inf<C>(), park + (size_t)(base - 1u + NB * lane + j) * XW);
+      }
+    });
+    wv.sync();
+    typename W::template PL<uint32_t> n, seg, gi, pos, rem, mseg, e0, e1, nb0, nb1;
+    auto bucket_of = [&](uint32_t lane, uint32_t j) -> uint32_t { return NB * cur[j * 64 + lane] + j; };      // the lane's local bucket of class j
+    wv.lanes([&](uint32_t lane) {
+      uint32_t t = 0;
+      for (uint32_t j = 0; j < NB; ++j) t += tot[bucket_of(lane, j)];
+      n[lane] = t;
+    });
+    // the position of the next entry of the lane's walk (only called while terms remain): run after run of a bucket, bucket after bucket;
+    // fresh: it is the first term of a new bucket
+    auto advance = [&](uint32_t lane, uint32_t& fresh) -> uint32_t {
+      fresh = 0;
+      while (rem[lane] == 0) {
+        gi[lane] += 1;
+        if (gi[lane] == G) {
+          gi[lane] = 0;
+          seg[lane] += 1;
+          fresh = 1;
+        }
+        const uint32_t k = bucket_of(lane, seg[lane]), lo = o16[gi[lane] * OR + k];
+        pos[lane] = gi[lane] * BK_CHUNK + lo;
+        rem[lane] = (uint32_t)o16[gi[lane] * OR + k + 1] - lo;
+      }
+      pos[lane] += 1;
+      rem[lane] -= 1;
+      return pos[lane] - 1;
+    };
+    wv.lanes([&](uint32_t lane) {
+      run[lane] = xyzz_inf<C>();
+      seg[lane] = 0;
+      gi[lane] = 0;
+      mseg[lane] = 0;
+      {
+        const uint32_t k = bucket_of(lane, 0), lo = o16[k];
+        pos[lane] = lo;
+        rem[lane] = (uint32_t)o16[k + 1] - lo;
+      }
+      e0[lane] = e1[lane] = nb1[lane] = 0;
+      uint32_t first = 0;
+      if (n[lane] > 0) e0[lane] = ix[advance(lane, first)];
+      if (n[lane] > 0) mseg[lane] = seg[lane];     // the class of the first non-empty bucket
+      if (n[lane] > 1) e1[lane] = ix[advance(lane, nb1[lane])];
+      nb0[lane] = 0;
+      if (n[lane] > 0) wv.template stage<Geo<C>::PW>(xch, point_of(e0[lane]), lane);
+    });
+    const uint32_t iters = wv.max(n);
+#pragma unroll 1
+    for (uint32_t i = 0; i < iters; ++i) {
+      wv.lanes([&](uint32_t lane) {
+        if (i < n[lane]) {
+          const uint32_t e = e0[lane];
+          if (nb0[lane]) {                         // the bucket before this term is done: park its sum
+            xyzz_to_words<C>(run[lane], park + (size_t)(base - 1u + bucket_of(lane, mseg[lane])) * XW);
+            run[lane] = xyzz_inf<C>();
+            do mseg[lane] += 1;
+            while (tot[bucket_of(lane, mseg[lane])] == 0);
+          }
+          Aff<C> q;
+          {
+            uint32_t pw[Geo<C>::PW];
+            wv.template take<Geo<C>::PW>(xch, pw, lane);
+            q.x = fe_unpack<typename C::FqP>(pw);
+            q.y = fe_unpack<typename C::FqP>(pw + Geo<C>::FW);
+          }
+          e0[lane] = e1[lane];
+          nb0[lane] = nb1[lane];
+          uint32_t at = 0;
+          if (i + 2 < n[lane]) at = advance(lane, nb1[lane]);
+          e1[lane] = ix[at];
+          if (i + 1 < n[lane]) wv.template stage<Geo<C>::PW>(xch, point_of(e0[lane]), lane);      // the point of term i + 1
+          xyzz_madd_signed_ip<C>(run[lane], q, (e >> 31) != 0);
+        }
+      });
+    }
+    wv.lanes([&](uint32_t lane) {                  // the last sum
+      if (n[lane] > 0) xyzz_to_words<C>(run[lane], park + (size_t)(base - 1u + bucket_of(lane, mseg[lane])) * XW);
+    });
+    return;
+  }
+  // ---- list mode: the runs p, p + P, ... of the item, each in 64 equal shares walked from the top; whenever a lane crosses into the
+  // next lower bucket it adds the running sum to acc (kept in LDS), so that  sum_t d_t P_t over the share = lo * run + acc.  The entry
+  // of term i + 2 and the point of term i + 1 are requested while term i is added
+  xch = wv.lds;                                    // the lanes' second accumulator and the final exchange
+  wv.lanes([&](uint32_t lane) { xyzz_to_words<C>(xyzz_inf<C>(), xch + lane * XW); });
+  for (uint32_t g = p; g < G; g += a.units) {
+    const uint16_t* oc = og + (size_t)g * ROW;     // (read where it lies: one item in twenty takes this path)
+    const uint32_t* ixc = ix + (size_t)g * BK_CHUNK;
+    const uint32_t Tu = oc[NBK + 1];
+    typename W::template PL<uint32_t> n, pos, rem, e0, e1;
+    typename W::template PL<Aff<C>> q0;
+    wv.lanes([&](uint32_t lane) {
+      run[lane] = xyzz_inf<C>();
+      const uint32_t s0 = (uint32_t)(((uint64_t)Tu * lane) >> 6), s1 = (uint32_t)(((uint64_t)Tu * (lane + 1)) >> 6);
+      uint32_t lo_b = 1, hi_b = NBK;               // largest bucket whose first position is <= s1 - 1
+      const uint32_t last = s1 ? s1 - 1 : 0;
+      while (lo_b < hi_b) {
+        const uint32_t mid = (lo_b + hi_b + 1) >> 1;
+        if (oc[mid] <= last) lo_b = mid; else hi_b = mid - 1;
+      }
+      n[lane] = s1 - s0;
+      pos[lane] = s1;
+      rem[lane] = s1 > s0 ? lo_b : 0u;
+      e0[lane] = n[lane] > 0 ? ixc[s1 - 1] : 0u;
+      e1[lane] = n[lane] > 1 ? ixc[s1 - 2] : 0u;
+      q0[lane] = ld_aff<C>(point_of(e0[lane]));
+    });
+    const uint32_t iters = wv.max(n);
+#pragma unroll 1
+    for (uint32_t i = 0; i < iters; ++i) {
+      wv.lanes([&](uint32_t lane) {
+        if (i < n[lane]) {
+          const uint32_t at = pos[lane] - 1 - i, e = e0[lane];
+          const Aff<C> q = q0[lane];
+          e0[lane] = e1[lane];
+          e1[lane] = i + 2 < n[lane] ? ixc[at - 2] : 0u;
+          if (i + 1 < n[lane]) q0[lane] = ld_aff<C>(point_of(e0[lane]));
+          while (at < oc[rem[lane]]) {             // into the next lower bucket
+            Xyzz<C> t = xyzz_from_words<C>(xch + lane * XW);
+            xyzz_add_ip<C>(t, run[lane]);
+            xyzz_to_words<C>(t, xch + lane * XW);
+            rem[lane] -= 1;
+          }
+          xyzz_madd_signed_ip<C>(run[lane], q, (e >> 31) != 0);
+        }
+      });
+    }
+    // acc += lo * run (double-and-add over the bits of the largest lo: wave-uniform trip count)
+    const uint32_t lomax = wv.max(rem);
+    int nbits = 0;
+    while ((lomax >> nbits) != 0) ++nbits;
+    typename W::template PL<Xyzz<C>> prod;
+    wv.lanes([&](uint32_t lane) { prod[lane] = xyzz_inf<C>(); });
+    for (int bit = nbits - 1; bit >= 0; --bit) {
+      wv.lanes([&](uint32_t lane) {
+        xyzz_dbl_ip<C>(prod[lane]);
+        if ((rem[lane] >> bit) & 1u) xyzz_add_ip<C>(prod[lane], run[lane]);
+      });
+    }
+    wv.lanes([&](uint32_t lane) {
+      Xyzz<C> t = xyzz_from_words<C>(xch + lane * XW);
+      xyzz_add_ip<C>(t, prod[lane]);
+      xyzz_to_words<C>(t, xch + lane * XW);
+    });
+  }
+  typename W::template PL<Xyzz<C>> acc;
+  wv.sync();
+  wv.lanes([&](uint32_t lane) { acc[lane] = xyzz_from_words<C>(xch + lane * XW); });
+  wv.sync();
+  for (uint32_t s = 32; s >= 1; s >>= 1) {
+    wv.lanes([&](uint32_t lane) { xyzz_to_words<C>(acc[lane], xch + lane * XW); });
+    wv.sync();
+    wv.lanes([&](uint32_t lane) {
+      if (lane < s) xyzz_add_ip<C>(acc[lane], xyzz_from_words<C>(xch + (lane + s) * XW));
+    });
+    wv.sync();
+  }
+  wv.lanes([&](uint32_t lane) {
+    if (lane == 0) xyzz_to_words<C>(acc[lane], park + (size_t)p * XW);
+  });
+}
+MP_WAVE_KERNEL_OCC(k_bucket_acc, BSplitArgs, body_bucket_acc, 2)
+
+// ---- k_bucket_reduce: W = WaveCtx; wv.lds = 64 XW words
+template <class C, class W>
+MP_HD void body_bucket_reduce(const BSplitArgs& a, uint32_t it, W& wv) {
+  constexpr uint32_t XW = XyzzWords<C>::N;
+  const uint32_t NBK = bk_buckets(a.bits), NB = NBK >> 6, LOGNB = a.bits - 7u;
+  const BItem id = bk_item(a, it);
+  const BJob job = a.jobs[id.jb];
+  const uint32_t G = bk_chunks(job.kpad);
+  const uint32_t* park = a.park + (size_t)it * NBK * XW;
+  uint32_t* xch = wv.lds;
+  typename W::template PL<Xyzz<C>> run, acc;
+  if (bk_list_mode(a, it, G)) {                    // list mode: the sums of the item's units
+    wv.lanes([&](uint32_t lane) { acc[lane] = lane < a.units ? xyzz_from_words<C>(park + (size_t)lane * XW) : xyzz_inf<C>(); });
+  } else {
+    wv.lanes([&](uint32_t lane) {                  // R = sum of the lane's NB buckets, A = sum of the first NB - 1 running sums from the top
+      const uint32_t* mine = park + (size_t)NB * lane * XW;
+      run[lane] = xyzz_from_words<C>(mine + (size_t)(NB - 1) * XW);
+      for (int j = (int)NB - 2; j >= 0; --j) {
+        if (j == (int)NB - 2) acc[lane] = run[lane]; else xyzz_add_ip<C>(acc[lane], run[lane]);
+        xyzz_add_ip<C>(run[lane], xyzz_from_words<C>(mine + (size_t)j * XW));
+      }
+    });
+    for (uint32_t s = 1; s < 64; s <<= 1) {
+      wv.lanes([&](uint32_t lane) { xyzz_to_words<C>(run[lane], xch + lane * XW); });
+      wv.sync();
+      wv.lanes([&](uint32_t lane) {
+        if (lane + s < 64) xyzz_add_ip<C>(run[lane], xyzz_from_words<C>(xch + (lane + s) * XW));
+      });
+      wv.sync();
+    }
+    wv.lanes([&](uint32_t lane) {
+      Xyzz<C> t = run[lane];
+      if (lane >= 1)
+        for (uint32_t q = 0; q < LOGNB; ++q) xyzz_dbl_ip<C>(t);
+      xyzz_add_ip<C>(acc[lane], t);
+    });
+  }
+  for (uint32_t s = 32; s >= 1; s >>= 1) {
+    wv.lanes([&](uint32_t lane) { xyzz_to_words<C>(acc[lane], xch + lane * XW); });
+    wv.sync();
+    wv.lanes([&](uint32_t lane) {
+      if (lane < s) xyzz_add_ip<C>(acc[lane], xyzz_from_words<C>(xch + (lane + s) * XW));
+    });
+    wv.sync();
+  }
+  wv.lanes([&](uint32_t lane) {
+    if (lane == 0) st_jac<C>(a.J + j_off<C>(job.win_first + id.w, a.Bpad, id.b), xyzz_to_jac<C>(acc[lane]));
+  });
+}
+MP_WAVE_KERNEL_OCC(k_bucket_reduce, BSplitArgs, body_bucket_reduce, 2)
 
 // ---- fold the window results: R = sum_w 2^(c w) R_w (x = proof, y = bucket job)
 // The same kernel folds the range sums of window-split Straus jobs (layout.hpp vsplit_lo; vb_nwin != 0): job.count parts, part w
@@ -515,6 +991,9 @@ MP_KERNEL_OCC(k_bucket_fold, BFoldArgs, body_bucket_fold, Geo<C>::OCC4)
 #define MP_BUCKET_KERNELS(X, C)                          \
   MP_KERNEL_INST(X, k_bucket_recode, BRecodeArgs, C)     \
   MP_WAVE_KERNEL_INST(X, k_bucket_msm, BucketArgs, C)    \
+  MP_WAVE_KERNEL_INST(X, k_bucket_sort, BSplitArgs, C)   \
+  MP_WAVE_KERNEL_INST(X, k_bucket_acc, BSplitArgs, C)    \
+  MP_WAVE_KERNEL_INST(X, k_bucket_reduce, BSplitArgs, C) \
   MP_KERNEL_INST(X, k_bucket_fold, BFoldArgs, C)         \
   MP_WAVE_KERNEL_INST(X, k_var_msm_q, VarQuadArgs, C)    \
   MP_WAVE_KERNEL_INST(X, k_bucket_fold_q, BFoldQuadArgs, C) \

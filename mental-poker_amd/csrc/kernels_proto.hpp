@@ -1231,29 +1231,66 @@ MP_KERNEL(k_verdict_merged, VerdictMergedArgs, body_verdict_merged)
 // every shuffle is verified].  Lane layout: link j of table t is lane j T + t; its merged scalars (k_verify_merge) are already in S.
 // (1) weights: rho_j = Fr::rand of ChaCha20(Blake2s(final transcript seeds of all L links of the table)) -- they depend on every
 //     byte of every proof of the chain;
+//     Round 6: in two levels, so that a group of 1 024 proofs does not hash 1 024 seeds and draw 1 024 weights on ONE lane (19 ms at 256
+//     groups): k_chain_digest -- one lane per (table, block of CW_BLOCK = 64 links) -- hashes the block's seeds; k_chain_weights -- the
+//     same lanes -- hashes the table's block digests into the table's key (every lane of a table does that: L / 128 compressions),
+//     derives the block's own key = Blake2s(table key || block number) and draws the block's 64 weights from ChaCha20(block key).
+//     A weight is still a function of every byte of every proof of its table and of nothing an adversary controls afterwards.
+static const uint32_t CW_BLOCK = 64;
 struct ChainWeightsArgs {
   const uint32_t* seed;    // [8][Bpad]: last transcript state per link (k_verify_fs)
   uint32_t* CW;            // [L][Tpad] Fr
+  uint32_t* dig;           // [blocks][8][Tpad]: the blocks' digests
   uint32_t Bpad, Tpad, T, L;
 };
+// x = table, y = block
 template <class C>
-MP_HD void body_chain_weights(const ChainWeightsArgs& a, uint32_t t, uint32_t y) {
-  typedef typename C::FrP R;
+MP_HD void body_chain_digest(const ChainWeightsArgs& a, uint32_t t, uint32_t k) {
   Blake2sState st;
   blake2s_init(st);
   uint32_t m[16];
-  for (uint32_t j = 0; j < a.L; j += 2) {
+  const uint32_t j0 = k * CW_BLOCK, j1 = j0 + CW_BLOCK < a.L ? j0 + CW_BLOCK : a.L;
+  for (uint32_t j = j0; j < j1; j += 2) {
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
       m[w] = a.seed[(size_t)w * a.Bpad + (size_t)j * a.T + t];
-      m[8 + w] = j + 1 < a.L ? a.seed[(size_t)w * a.Bpad + (size_t)(j + 1) * a.T + t] : 0u;
+      m[8 + w] = j + 1 < j1 ? a.seed[(size_t)w * a.Bpad + (size_t)(j + 1) * a.T + t] : 0u;
     }
-    const bool last = j + 2 >= a.L;
-    blake2s_compress(st, m, last ? 32ull * a.L : 32ull * (j + 2), last);
+    const bool last = j + 2 >= j1;
+    blake2s_compress(st, m, last ? 32ull * (j1 - j0) : 32ull * (j + 2 - j0), last);
   }
+#pragma unroll
+  for (int w = 0; w < 8; ++w) a.dig[((size_t)k * 8 + w) * a.Tpad + t] = st.h[w];
+}
+MP_KERNEL(k_chain_digest, ChainWeightsArgs, body_chain_digest)
+template <class C>
+MP_HD void body_chain_weights(const ChainWeightsArgs& a, uint32_t t, uint32_t k) {
+  typedef typename C::FrP R;
+  const uint32_t nb = (a.L + CW_BLOCK - 1) / CW_BLOCK;
+  Blake2sState st;
+  blake2s_init(st);
+  uint32_t m[16];
+  for (uint32_t i = 0; i < nb; i += 2) {           // the table's key: the digests of all its blocks
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      m[w] = a.dig[((size_t)i * 8 + w) * a.Tpad + t];
+      m[8 + w] = i + 1 < nb ? a.dig[((size_t)(i + 1) * 8 + w) * a.Tpad + t] : 0u;
+    }
+    const bool last = i + 2 >= nb;
+    blake2s_compress(st, m, last ? 32ull * nb : 32ull * (i + 2), last);
+  }
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    m[w] = st.h[w];
+    m[8 + w] = 0u;
+  }
+  m[8] = k;                                        // the block's key: Blake2s(table key || block number)
+  blake2s_init(st);
+  blake2s_compress(st, m, 36ull, true);
   FrStream fs;
   frstream_init(fs, st.h);
-  for (uint32_t j = 0; j < a.L; ++j) st_fe<R>(a.CW + ((size_t)j * a.Tpad + t) * 8, frstream_next<R>(fs));
+  const uint32_t j0 = k * CW_BLOCK, j1 = j0 + CW_BLOCK < a.L ? j0 + CW_BLOCK : a.L;
+  for (uint32_t j = j0; j < j1; ++j) st_fe<R>(a.CW + ((size_t)j * a.Tpad + t) * 8, frstream_next<R>(fs));
 }
 MP_KERNEL(k_chain_weights, ChainWeightsArgs, body_chain_weights)
 // (2) scalars of the chain equation: CS[i][t] = sum_{k < cnt} rho_j S[s][lane(j,t)], j = j0 + k step  (+ rho_{j0-step} S[s2][lane(j0-step,t)]):

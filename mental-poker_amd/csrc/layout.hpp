@@ -98,7 +98,7 @@ struct Phase {
 };
 
 static const size_t COMBINE_TREE_MIN = 12;
-static const size_t BUCKET_TERMS_MAX = 65535;      // terms of one bucket job (one wave sorts a window's digits into a scratch row of that many words)
+static const size_t BUCKET_TERMS_MAX = 589824;      // terms of one bucket job: 24 sorted runs of 24 576 terms (kernels_bucket.hpp BK_CHUNKS_MAX x BK_CHUNK; a sorted entry holds 24 bits of term index); larger MSMs stay on the Straus kernel
 // Host-side builder: msm(out) { fixed(..) var(..) addend(..) } -> chunked sub-jobs + one combine job.
 class PhaseBuilder {
  public:

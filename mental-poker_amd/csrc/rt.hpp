@@ -131,6 +131,9 @@ struct PerLane {
   __device__ __forceinline__ const T& operator[](uint32_t) const { return v; }
 };
 struct WaveCtx {
+  static constexpr uint32_t NL = 64, LOG_NL = 6;      // lanes of one work item
+  template <class T>
+  using PL = PerLane<T>;
   uint32_t lane;
   uint32_t* lds;
   template <class Fn>
@@ -231,7 +234,110 @@ struct WaveCtx {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
 };
+// ---- workgroup-cooperative kernels: one 256-lane workgroup (4 waves) = one work item (kernels_bucket.hpp, windows of 12 bits and more:
+// 2^(c-1) buckets dealt to 256 lanes instead of 64).  The same interface as WaveCtx with NL = 256: sync() is the workgroup barrier, the
+// scans and maxima go wave-wide through DPP and across the four waves through a few words of LDS (`scratch`, in front of `lds`).
+// Every sync / scan / max / next_item must be reached by all four waves (workgroup-uniform control flow).
+struct BlockCtx {
+  static constexpr uint32_t NL = 256, LOG_NL = 8;
+  static constexpr uint32_t SCRATCH_WORDS = 16;
+  template <class T>
+  using PL = PerLane<T>;
+  uint32_t lane;
+  uint32_t* lds;
+  uint32_t* scratch;
+  template <class Fn>
+  __device__ __forceinline__ void lanes(Fn f) {
+    f(lane);
+  }
+  __device__ __forceinline__ void sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  __device__ __forceinline__ void sync_global() { sync(); }
+  __device__ __forceinline__ uint32_t atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+  __device__ __forceinline__ void excl_scan(PerLane<uint32_t>& x) {
+    uint32_t incl = x.v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const uint32_t up = __shfl_up(incl, s, 64);
+      if ((lane & 63u) >= (uint32_t)s) incl += up;
+    }
+    if ((lane & 63u) == 63u) scratch[lane >> 6] = incl;
+    sync();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < (lane >> 6); ++w) base += scratch[w];
+    sync();
+    x.v = base + incl - x.v;
+  }
+  __device__ __forceinline__ uint32_t max(const PerLane<uint32_t>& x) {
+    uint32_t m = x.v;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+      const uint32_t o = __shfl_xor(m, s, 64);
+      m = o > m ? o : m;
+    }
+    if ((lane & 63u) == 0u) scratch[4 + (lane >> 6)] = m;
+    sync();
+    m = scratch[4];
+#pragma unroll
+    for (uint32_t w = 1; w < 4; ++w) m = scratch[4 + w] > m ? scratch[4 + w] : m;
+    sync();
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+  }
+  __device__ __forceinline__ uint32_t next_item(uint32_t* counter) {
+    if (lane == 0) scratch[8] = atomicAdd(counter, 1u);
+    sync();
+    const uint32_t v = scratch[8];
+    sync();
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+  }
+  __device__ __forceinline__ uint32_t xcd() const { return (uint32_t)__builtin_amdgcn_s_getreg(6164) & 7u; }
+  // as WaveCtx::stage / take, with one staging area of N x 64 words per wave of the workgroup
+  template <int N>
+  __device__ __forceinline__ void stage(uint32_t* area, const uint32_t* g, uint32_t) {
+    static_assert(N % 4 == 0, "whole 16-byte chunks");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    uint32_t* mine = area + (lane >> 6) * (N * 64);
+#pragma unroll
+    for (int c = 0; c < N / 4; ++c)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 4 * c),
+                                       (__attribute__((address_space(3))) void*)(mine + c * 256), 16, 0, 0);
+  }
+  template <int N>
+  __device__ __forceinline__ void take(const uint32_t* area, uint32_t* w, uint32_t) const {
+    const uint32_t* mine = area + (lane >> 6) * (N * 64);
+#pragma unroll
+    for (int c = 0; c < N / 4; ++c) {
+      const uint4 t = *reinterpret_cast<const uint4*>(mine + c * 256 + 4 * (lane & 63u));
+      w[4 * c] = t.x; w[4 * c + 1] = t.y; w[4 * c + 2] = t.z; w[4 * c + 3] = t.w;
+    }
+  }
+};
 }  // namespace mp
+// one 256-lane workgroup per work item, `lds_words` words of dynamic LDS for the body (+ BlockCtx::SCRATCH_WORDS for the context)
+#define MP_BLOCK_KERNEL_OCC(NAME, ARGS, BODY, WAVES)                                           \
+  template <class C>                                                                           \
+  MP_GLOBAL void __launch_bounds__(256, WAVES) NAME(ARGS a, uint32_t nblocks, uint32_t lds_words) { \
+    extern __shared__ uint32_t mp_dyn_lds[];                                                   \
+    mp::BlockCtx wv{threadIdx.x, mp_dyn_lds + mp::BlockCtx::SCRATCH_WORDS, mp_dyn_lds};        \
+    BODY<C>(a, blockIdx.x, wv);                                                                \
+  }
+#define MP_BLOCK_LAUNCH(NAME, C, stream, nblocks, lds_words, args)                                                            \
+  do {                                                                                                                        \
+    if ((nblocks) > 0) {                                                                                                      \
+      const size_t bytes_ = ((size_t)(lds_words) + mp::BlockCtx::SCRATCH_WORDS) * 4, cap_ = mp::rt::lds_per_workgroup();      \
+      if (bytes_ > cap_)                                                                                                      \
+        throw std::runtime_error(#NAME ": one work item needs " + std::to_string(bytes_) + " bytes of LDS, the device offers " + \
+                                 std::to_string(cap_) + " per workgroup (narrower windows)");                                 \
+      if (bytes_ > 64u * 1024u)                                                                                               \
+        mp::rt::check(hipFuncSetAttribute(reinterpret_cast<const void*>(&NAME<C>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          (int)bytes_), "LDS size attribute");                                                \
+      hipLaunchKernelGGL((NAME<C>), dim3((nblocks)), dim3(256), bytes_, (stream), (args), (uint32_t)(nblocks), (uint32_t)(lds_words)); \
+      mp::rt::launch_check(#NAME);                                                                                            \
+    }                                                                                                                         \
+  } while (0)
 // a workgroup holds up to 4 waves (= 4 independent work items); `lds_words` 32-bit words of dynamic LDS per wave
 #define MP_WAVE_KERNEL(NAME, ARGS, BODY) MP_WAVE_KERNEL_OCC(NAME, ARGS, BODY, 2)
 #define MP_WAVE_KERNEL_OCC(NAME, ARGS, BODY, WAVES)                                            \
@@ -248,24 +354,32 @@ struct WaveCtx {
 namespace mp {
 namespace rt {
 inline size_t lds_per_workgroup() {
-  static size_t v = 0;
-  if (!v) {
+  static const size_t v = [] {      // (initialised once, whichever host thread comes first)
     int dev = 0, b = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&b, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || b <= 0)
       b = 64 * 1024;
-    v = (size_t)b;
-  }
+    return (size_t)b;
+  }();
   return v;
 }
 }  // namespace rt
 }  // namespace mp
 // waves per workgroup: as many (<= 4) as fit twice into the CU's LDS
+namespace mp {
+namespace rt {
+inline uint32_t waves_per_block(size_t lds_words) {
+  const size_t bytes = lds_words * 4, cap = lds_per_workgroup();
+  uint32_t wpb = 4;
+  while (wpb > 1 && wpb * bytes > cap / 2) wpb >>= 1;
+  return wpb;
+}
+}  // namespace rt
+}  // namespace mp
 #define MP_WAVE_LAUNCH(NAME, C, stream, nwaves, lds_words, args)                                                              \
   do {                                                                                                                        \
     if ((nwaves) > 0) {                                                                                                       \
       const size_t bytes_ = (size_t)(lds_words) * 4, cap_ = mp::rt::lds_per_workgroup();                                      \
-      uint32_t wpb_ = 4;                                                                                                      \
-      while (wpb_ > 1 && wpb_ * bytes_ > cap_ / 2) wpb_ >>= 1;                                                                \
+      const uint32_t wpb_ = mp::rt::waves_per_block(lds_words);                                                               \
       if (wpb_ * bytes_ > cap_)                                                                                               \
         throw std::runtime_error(#NAME ": one work item needs " + std::to_string(bytes_) + " bytes of LDS, the device offers " + \
                                  std::to_string(cap_) + " per workgroup (fewer terms per MSM / links per chain equation)");      \

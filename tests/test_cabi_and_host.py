@@ -494,7 +494,7 @@ def test_bucket_msm_edge_scalars_under_emulation(emu, coracle):
     same = b"".join((77).to_bytes(32, "little") for _ in range(K))      # every term in ONE bucket of one window
     want_same = coracle.msm(cvn, same, bytes(pts))
     zero = bytes(32 * K)
-    for bits in (0, 8, 9, 10, 11):                       # window widths of the bucket method (0: by size = 8 here); 2, 4, 8, 16 buckets per lane
+    for bits in (0, 8, 9, 10, 11, 12, 13):               # window widths of the bucket method (0: by size = 8 here); 2, 4, 8, 16 buckets per lane of a wave, the split pipeline from 12 bits on (round 6)
         t.set_bucket_bits(bits)
         assert t.msm(1, K, scb, bytes(pts)) == want, bits
         assert t.msm(1, K, same, bytes(pts)) == want_same, bits
@@ -507,18 +507,31 @@ def test_bucket_msm_edge_scalars_under_emulation(emu, coracle):
     got = t.msm(nm, K, many, bytes(pts) * nm)
     for i in range(nm):
         assert got[64 * i:64 * (i + 1)] == coracle.msm(cvn, many[32 * K * i:32 * K * (i + 1)], bytes(pts)), i
+    # ... of the 12- and 13-bit ones (256 lanes per window)
+    for bits, edge in ((12, 2048), (13, 4096)):
+        t.set_bucket_bits(bits)
+        sc[12:20] = [edge - 1, edge, edge + 1, 2 ** 250 + edge - 1, (1 << 252) - 1 - (q - (1 << 251)) % 7, q - edge, q - edge - 1, 2 * edge]
+        many = b"".join(((s * (i + 1)) % q).to_bytes(32, "little") for i in range(nm) for s in sc)
+        got = t.msm(nm, K, many, bytes(pts) * nm)
+        for i in range(nm):
+            assert got[64 * i:64 * (i + 1)] == coracle.msm(cvn, many[32 * K * i:32 * K * (i + 1)], bytes(pts)), (bits, i)
     with pytest.raises(Exception):
-        t.set_bucket_bits(12)
+        t.set_bucket_bits(14)
     # the width the engine picks by size: 9 bits from 6 000 terms, 10 from 12 000 (the points repeat: the oracle folds the scalars)
-    t.set_bucket_bits(0)
     base = bytes(pts)
-    for big in (6100, 12100):
+    # (... 12 and 13 bits on the split pipeline with three sorted runs per bucket: 24 576 terms per run; the last scalars all equal --
+    # they do not make the window crowded, the 13-bit top window of a 252-bit scalar is: both modes in one MSM)
+    for big, bits in ((6100, 0), (12100, 0), (60000, 12), (52000, 13)):
+        t.set_bucket_bits(bits)
         scs = [random.randrange(q) for _ in range(big)]
+        if bits:
+            scs[-40:] = [77] * 40
         folded = [0] * K
         for i, s_ in enumerate(scs):
             folded[i % K] = (folded[i % K] + s_) % q
         got = t.msm(1, big, b"".join(s_.to_bytes(32, "little") for s_ in scs), (base * (big // K + 1))[:64 * big])
         assert got == coracle.msm(cvn, b"".join(s_.to_bytes(32, "little") for s_ in folded), base), big
+    t.set_bucket_bits(0)
 
 
 @pytest.mark.parametrize("name", ["shuffle_stark_m3_n4_s11.json", "shuffle_stark_m4_n13_s9.json", "shuffle_secp256k1_m3_n3_s5.json"])
@@ -665,7 +678,8 @@ def test_emulated_group_verification(emu, coracle, cv, keyed):
     cases = {"good": (ref[0], ref[1]), "badproof": (ref[0], bytes(bad_p)), "badpoint": (bytes(bad_d), ref[1]), "rotated": (rot, ref[1])}
     want = {k: verify(args[0], d, p) for k, (d, p) in cases.items()}
     assert want["good"] == [0] * B and want["badproof"][4] > 0 and want["badpoint"][1] < 0 and all(v > 0 for v in want["rotated"])
-    for links, bits in ((3, 0), (2, 10), (6, 9), (3, 11)):      # (the group equation through 8-, 10-, 9- and 11-bit windows: mp_set_bucket_bits)
+    # (the group equation through 8-, 10-, 9- and 11-bit windows on the wave kernel, 12- and 13-bit ones on the split pipeline (k_bucket_sort / _acc / _reduce): mp_set_bucket_bits)
+    for links, bits in ((3, 0), (2, 10), (6, 9), (3, 11), (3, 12), (6, 13)):
         t.set_bucket_bits(bits)
         t.set_group_verify(links * (4 * m * n + 11 * m + 8 + (1 if keyed else 0)), 0)
         eng.profile_enable(True)
@@ -673,7 +687,7 @@ def test_emulated_group_verification(emu, coracle, cv, keyed):
             assert verify(args[0], d, p) == want[k], (links, k)
         rep = eng.profile_report()
         eng.profile_enable(False)
-        assert "k_chain_scalars" in rep and "k_bucket_msm" in rep
+        assert "k_chain_scalars" in rep and ("k_bucket_acc" if bits >= 12 else "k_bucket_msm") in rep
     t.set_bucket_bits(0)
     if not keyed:                                          # pipelined: the group pass is the deferred screen
         buf = lambda b: (ctypes.c_uint8 * len(b)).from_buffer_copy(b)

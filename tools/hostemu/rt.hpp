@@ -53,6 +53,7 @@ inline void clear_error() {}
 inline void stream_wait(Stream, Event) {}
 inline void event_sync(Event) {}
 inline void mem_info(size_t* free_b, size_t* total_b) { *free_b = *total_b = 0; }      // (auto-sized tables fall back to 8-bit windows)
+inline uint32_t waves_per_block(size_t) { return 4; }
 inline uint32_t cu_count() { return 2; }                                                   // (16 'persistent waves': items wrap around in tests)
 inline void* host_alloc(size_t bytes) { return dmalloc(bytes); }
 inline void host_free(void* p) { free(p); }
@@ -84,6 +85,9 @@ struct PerLane {
   const T& operator[](uint32_t l) const { return v[l]; }
 };
 struct WaveCtx {
+  static constexpr uint32_t NL = 64, LOG_NL = 6;
+  template <class T>
+  using PL = PerLane<T>;
   uint32_t* lds;
   uint32_t id = 0;      // index of the (emulated) persistent wave
   uint32_t xcd() const { return id & 7u; }
@@ -151,6 +155,77 @@ struct WaveCtx {
   void sync_global() {}
 };
 }  // namespace mp
+// workgroup-cooperative kernels (product rt.hpp BlockCtx): the 256 lanes of a workgroup run one after the other between sync points
+namespace mp {
+template <class T>
+struct PerLaneB {
+  T v[256];
+  T& operator[](uint32_t l) { return v[l]; }
+  const T& operator[](uint32_t l) const { return v[l]; }
+};
+struct BlockCtx {
+  static constexpr uint32_t NL = 256, LOG_NL = 8;
+  static constexpr uint32_t SCRATCH_WORDS = 16;
+  template <class T>
+  using PL = PerLaneB<T>;
+  uint32_t* lds;
+  uint32_t id = 0;
+  uint32_t xcd() const { return id & 7u; }
+  template <int N>
+  void stage(uint32_t* area, const uint32_t* g, uint32_t lane) {
+    uint32_t* mine = area + (lane >> 6) * (N * 64);
+    for (int c = 0; c < N / 4; ++c)
+      for (int i = 0; i < 4; ++i) mine[c * 256 + 4 * (lane & 63u) + i] = g[4 * c + i];
+  }
+  template <int N>
+  void take(const uint32_t* area, uint32_t* w, uint32_t lane) const {
+    const uint32_t* mine = area + (lane >> 6) * (N * 64);
+    for (int c = 0; c < N / 4; ++c)
+      for (int i = 0; i < 4; ++i) w[4 * c + i] = mine[c * 256 + 4 * (lane & 63u) + i];
+  }
+  template <class Fn>
+  void lanes(Fn f) {
+    for (uint32_t l = 0; l < NL; ++l) f(l);
+  }
+  void sync() {}
+  void sync_global() {}
+  uint32_t atomic_add(uint32_t* p, uint32_t v) {
+    const uint32_t old = *p;
+    *p = old + v;
+    return old;
+  }
+  void excl_scan(PerLaneB<uint32_t>& x) {
+    uint32_t run = 0;
+    for (uint32_t l = 0; l < NL; ++l) {
+      const uint32_t t = x.v[l];
+      x.v[l] = run;
+      run += t;
+    }
+  }
+  uint32_t max(const PerLaneB<uint32_t>& x) {
+    uint32_t m = 0;
+    for (uint32_t l = 0; l < NL; ++l) m = x.v[l] > m ? x.v[l] : m;
+    return m;
+  }
+  uint32_t next_item(uint32_t* counter) {
+    uint32_t v;
+    _Pragma("omp atomic capture")
+    { v = *counter; *counter += 1; }
+    return v;
+  }
+};
+}  // namespace mp
+#define MP_BLOCK_KERNEL_OCC(NAME, ARGS, BODY, WAVES)                       \
+  template <class C>                                                       \
+  void NAME(const ARGS& a, uint32_t nblocks, uint32_t lds_words) {         \
+    _Pragma("omp parallel for schedule(dynamic, 1)")                       \
+    for (uint32_t bid = 0; bid < nblocks; ++bid) {                         \
+      std::vector<uint32_t> lds(lds_words);                                \
+      mp::BlockCtx wv{lds.data(), bid};                                    \
+      BODY<C>(a, bid, wv);                                                 \
+    }                                                                      \
+  }
+#define MP_BLOCK_LAUNCH(NAME, C, stream, nblocks, lds_words, args) NAME<C>((args), (uint32_t)(nblocks), (uint32_t)(lds_words))
 #define MP_WAVE_KERNEL(NAME, ARGS, BODY)                                   \
   template <class C>                                                       \
   void NAME(const ARGS& a, uint32_t nwaves, uint32_t lds_words) {          \

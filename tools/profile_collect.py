@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # on its exactly known table reads (profiles/r02_fetch_calibration.txt: raw / expected = 0.955 on seven launches of three shapes);
 # k_remask likewise (raw 92.8 KB per proof against 104 x 13 entries + 104 deck points = 93.2 KB); k_fixed_msm and k_bucket_msm gather
 # 64-byte entries / points the same way (k_fixed_msm: raw 251 KB against <= 320 KB of table entries, some of them L2 hits)
-FETCH_CAL = {"k_var_msm": 1.0, "k_bucket_msm": 1.0, "k_remask": 1.0, "k_fixed_msm": 1.0}
+FETCH_CAL = {"k_var_msm": 1.0, "k_bucket_msm": 1.0, "k_bucket_acc": 1.0, "k_remask": 1.0, "k_fixed_msm": 1.0}
 
 
 def kname(s):
