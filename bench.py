@@ -902,7 +902,7 @@ def main():
         buckets per lane and the point additions of the wave-wide reduction of one window"""
         c = 13 if K >= 200000 else (12 if K >= 50000 else (11 if K >= 40000 else (10 if K >= 12000 else (9 if K >= 6000 else 8))))      # (12 and 13: the split pipeline, one reducing wave per window)
         nb = (1 << (c - 1)) // 64
-        return {"bits": c, "windows": (SCALAR_BITS + c) // c, "buckets_per_lane": nb, "reduction_adds": 13 + 2 * nb - 3}
+        return {"bits": c, "windows": (SCALAR_BITS + c - 1) // c, "buckets_per_lane": nb, "reduction_adds": 13 + 2 * nb - 3}      # (round 6: min(k, q - k) is recoded: ceil(bits / c) windows)
     per_proof_pts = 4 * N + 11 * m + 8
     geo_own = bucket_geometry(per_proof_pts + 1)          # a proof's own bucket jobs (large decks: the merged equation and the prover's long products)
     geo_grp = None

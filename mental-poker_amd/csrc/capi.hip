@@ -218,9 +218,10 @@ int mp_table_create_ex(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* param
       try {
         t = make(fb_window_bits);
         break;
-      } catch (const std::exception&) {
+      } catch (const std::exception& e) {
         rt::clear_error();
-        if (fb_window_bits <= 8) throw;
+        // (only a failed allocation is worth narrower windows: anything else would fail again)
+        if (fb_window_bits <= 8 || (!strstr(e.what(), "hipMalloc") && !strstr(e.what(), "memory"))) throw;
         fb_window_bits = fb_window_bits > 20 ? 20 : (fb_window_bits > 16 ? 16 : 8);
       }
     }
@@ -316,7 +317,7 @@ int mp_set_bucket_min(mp_table* t, size_t terms) {
 }
 int mp_set_bucket_bits(mp_table* t, uint32_t bits) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_bits: null table");
-  if (bits != 0 && (bits < 8 || bits > 13)) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_bits: 0 (by size) or 8 .. 13");
+  if (bits != 0 && (bits < 8 || bits > 14)) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_bits: 0 (by size) or 8 .. 14");
   MP_TRY
   MP_ENTER(t->ctx);
   t->set_bucket_bits(bits);
@@ -347,7 +348,7 @@ int mp_set_chain_slice(mp_table* t, size_t tables_per_pass) {
 }
 int mp_set_chain_group(mp_table* t, uint32_t tables_per_equation) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_chain_group: null table");
-  if (tables_per_equation > 1022) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_chain_group: at most 1 022 tables per equation");
+  if (tables_per_equation > 4094) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_chain_group: at most 4 094 tables per equation");
   std::lock_guard<std::recursive_mutex> mp_lock_(t->ctx->mu);
   t->chain_group = tables_per_equation;
   return MP_OK;

@@ -1282,10 +1282,22 @@ struct Table : mp_table {
     std::sort(idx.begin(), idx.end());
   }
   // the proofs idx[] of batch v (ascending) through the finer passes; their status words replace the screen's marks
-  void verify_subset(const VArgs& v, std::vector<uint32_t>& idx, int level, bool vlane, uint32_t l1 = 0) {
+  // own_arenas: the caller's arenas (ws) are laid out for batch v (verify_dev); a chain call's are not (its lean workspace is cws)
+  void verify_subset(const VArgs& v, std::vector<uint32_t>& idx, int level, bool vlane, uint32_t l1 = 0, bool own_arenas = true) {
     if (idx.empty()) return;
     const bool keyed = v.keys != nullptr || v.kset != nullptr;
     rt::Stream s = ctx->stream;
+    // Bounded memory whatever the number of suspects (one bad link per chain equation sends all T x L links of a call here):
+    // at most 131 072 52-card proofs' worth of them are gathered and looked at at a time (2.6 GB of decks and proofs, arenas of the passes
+    // below for that many lanes); the slices are sub-batches of their own, any partition of the suspects gives the same status words
+    const size_t sub_max = std::max<size_t>(4096, ((size_t)131072 * 52u / N) & ~(size_t)1023);
+    if (!(level == 1 && idx.size() == v.B && (vlane || own_arenas)) && idx.size() > sub_max) {
+      for (size_t o = 0; o < idx.size(); o += sub_max) {
+        std::vector<uint32_t> part(idx.begin() + o, idx.begin() + std::min(idx.size(), o + sub_max));
+        verify_subset(v, part, level, vlane, l1, own_arenas);
+      }
+      return;
+    }
     const uint32_t L2 = level == 0 ? subgroup_size(idx.size(), keyed, l1) : 0u;
     if (!L2) level = 1;
     // The equations of a sub-batch run on arenas of their OWN (rws), in slices of at most 32 768 52-card proofs: the work split follows
@@ -1306,7 +1318,7 @@ struct Table : mp_table {
       }
     };
     if (level == 1 && idx.size() == v.B) {      // (everybody: no gather)
-      if (vlane) {                              // (the verify lane has no arenas of the batch's size for the equations: slices)
+      if (vlane || !own_arenas) {               // (no arenas of the batch's size for the equations on the verify lane or under a chain call: slices)
         per_equation(v);
       } else {                                  // (the caller's arenas are laid out for this batch and its work split already)
         reserve_ws(ws, v.B, keyed);
@@ -1315,6 +1327,7 @@ struct Table : mp_table {
       }
       return;
     }
+    const uint32_t distinct = (uint32_t)idx.size();
     if (L2)
       while (idx.size() % L2) idx.push_back(idx[0]);      // (a suspect twice: the same verdict written twice)
     const uint32_t nsub = (uint32_t)idx.size();
@@ -1339,6 +1352,8 @@ struct Table : mp_table {
         read_words(gb.p, T2, bad);
         group_members(bad.data(), T2, L2, idx2);
         verify_subset(sv, idx2, 1, vlane);
+        for (uint32_t i2 : idx2)                          // (mp_reverified_count counts proofs, not the copies that fill the last sub-group)
+          if (i2 >= distinct) n_reverified -= 1;
       }
     } else {
       per_equation(sv);
@@ -1472,10 +1487,21 @@ struct Table : mp_table {
     std::vector<ChainTerm> cterms;
     DevBuf<ChainTerm> dterms;
     uint32_t K = 0, nfix = 0, nJ = 0;
+    std::vector<uint32_t> tile_src;     // chain equations (round 6): slot | link << 20 of term i -- where k_chain_tile finds the point of entry i of the equation's run
+    DevBuf<uint32_t> dtile_src;
   };
   ChainPlan chain;
   Workspace cws;                      // lean workspace of chain verification: no window tables, no digit planes
-  DevBuf<uint32_t> chain_cw, chain_cs, chain_dig;
+  DevBuf<uint32_t> chain_cw, chain_cs, chain_dig, chain_part;
+  // the verdicts of T chain / group equations of L links (kernels_proto.hpp: per link, per equation, then the caller's status words)
+  void run_chain_verdict(ChainVerdictArgs va) {
+    chain_part.alloc(va.T, ctx->stream, false);
+    rt::dzero(chain_part.p, (size_t)va.T * 4, ctx->stream);
+    va.part = chain_part.p;
+    MP_RUN(k_chain_check, C, va.T * va.L, 1, va);
+    MP_RUN(k_chain_verdict, C, va.T, 1, va);
+    if (va.out) MP_RUN(k_chain_mark, C, va.T * va.L, 1, va);
+  }
   // the weights of T chain / group equations of L links each (kernels_proto.hpp: block digests, then table key, block key, 64 weights per lane)
   void run_chain_weights(Workspace& w, uint32_t Tpad, uint32_t T, uint32_t L) {
     const uint32_t nb = (L + CW_BLOCK - 1) / CW_BLOCK;
@@ -1495,18 +1521,24 @@ struct Table : mp_table {
   // group equation's size (mp_set_group_verify), with enough equations left to keep the persistent waves busy; 1 = a table on its own.
   uint32_t chain_points_per_table(uint32_t L, bool keyed) const { return (L + 1) * 2 * N + L * (11 * m + 8) + (keyed ? 1u : 0u); }
   uint32_t chain_group_of(uint32_t T, uint32_t L, bool keyed) const {
-    if (chain_group == 1 || !group_points) return 1;
+    // (an explicit mp_set_chain_group is honoured whatever mp_set_group_verify says; the automatic rule follows the group equations')
+    if (chain_group == 1 || (!chain_group && !group_points)) return 1;
     const uint32_t per = chain_points_per_table(L, keyed);
     uint32_t want = chain_group;
     if (!want) {
       const uint32_t eq_min = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)group_min_batch * 2u) / 13u));
       want = std::min<uint32_t>((group_points + per / 2) / per, T / eq_min);
+      // (round 6, as group_size: equations for the split pipeline if at least min_batch / 48 of them, of at least 50 000 points, are left
+      // -- 64 tables x 4 392 points for 32 links of a 52-card deck)
+      const uint32_t want_wg = std::min<uint32_t>((group_points_wg + per / 2) / per, T / std::max<uint32_t>(1u, group_min_batch / 48u));
+      if (group_points_wg && (uint64_t)want_wg * per >= GROUP_WG_POINTS_MIN) want = std::max(want, want_wg);
     }
     if (want < 2) return 1;
     for (uint32_t d = 0; d <= want; ++d)
       for (int sgn = 1; sgn >= -1; sgn -= 2) {
         const int64_t G = (int64_t)want + sgn * (int64_t)d;
-        if (G < 2 || 2 * G < (int64_t)want || G > 2 * (int64_t)want || (uint64_t)G * per + n + 5 > BUCKET_TERMS_MAX || (uint64_t)G * L > 1022) continue;
+        // (12 bits of link in a term's tile source: k_chain_tile)
+        if (G < 2 || 2 * G < (int64_t)want || G > 2 * (int64_t)want || (uint64_t)G * per + n + 5 > BUCKET_TERMS_MAX || (uint64_t)G * (L + 1) > 4094) continue;
         if (T % (uint32_t)G == 0) return (uint32_t)G;
       }
     return 1;
@@ -1518,6 +1550,7 @@ struct Table : mp_table {
     const VerifyLay& l = q.vplan.lay;
     chain.ph = Phase();
     chain.cterms.clear();
+    chain.tile_src.clear();
     chain.L = L;
     chain.G = G;
     chain.keyed = keyed;
@@ -1525,8 +1558,10 @@ struct Table : mp_table {
     const uint32_t cbits = bucket_bits_of(G * ((L + 1) * 2 * N + L * (l.pk - l.cA) + (keyed ? 1u : 0u)));
     PhaseBuilder pb(chain.ph, next_partial, FCHUNK, VCHUNK, 1u, bk_windows(R::BITS, cbits), 1u, cbits);
     pb.begin(0);
+    // (a term's point: its index in the equation's contiguous run -- k_chain_tile copies it there from slot | link << 20)
     auto var = [&](ChainTerm ct, uint32_t pslot, uint32_t link) {
-      pb.var((uint32_t)chain.cterms.size(), pslot | (link << 20));
+      pb.var((uint32_t)chain.cterms.size(), (uint32_t)chain.cterms.size());
+      chain.tile_src.push_back(pslot | (link << 20));
       chain.cterms.push_back(ct);
     };
     // ("link" j G + g of the equation = link j of member g)
@@ -1542,17 +1577,21 @@ struct Table : mp_table {
     if (keyed)
       for (uint32_t g = 0; g < G; ++g) var(ChainTerm{l.mvar + l.pk, g, L, NO_SLOT, G}, l.pk, g);      // one key term per member
     chain.K = (uint32_t)chain.cterms.size();
+    // (the scalar of a fixed base: a sum over the equation's L G links, in runs of at most 64 -- as in the group plan below)
     FixedBases fb{n};
     for (uint32_t f = 0; f < fb.count(); ++f) {
       if (keyed && f == fb.pk()) continue;
-      pb.fixed((uint32_t)chain.cterms.size(), f);
-      chain.cterms.push_back(ChainTerm{l.mfix + f, 0, L * G, NO_SLOT, 1});
+      for (uint32_t j0 = 0; j0 < L * G; j0 += 64u) {
+        pb.fixed((uint32_t)chain.cterms.size(), f);
+        chain.cterms.push_back(ChainTerm{l.mfix + f, j0, std::min(64u, L * G - j0), NO_SLOT, 1});
+      }
     }
     chain.nfix = (uint32_t)chain.cterms.size() - chain.K;
     pb.end();
     chain.nJ = next_partial;
     chain.dev.upload(chain.ph, ctx->stream);
     chain.dterms.upload(chain.cterms, ctx->stream);
+    chain.dtile_src.upload(chain.tile_src, ctx->stream);
   }
   size_t chain_lane_bytes(uint32_t, bool keyed) override {
     if (keyed) ensure_keyed();
@@ -1612,7 +1651,12 @@ struct Table : mp_table {
     ChainScalArgs ca{w.S.p, chain_cw.p, chain_cs.p, chain.dterms.p, w.Bpad, Tpad, Tq};
     MP_RUN(k_chain_scalars, C, Tq, nterms, ca);
     PhaseDev& ph = chain.dev;
-    run_bucket(w, ph, chain_cs.p, Tpad, chain_d8.p, (size_t)ph.b_dig_bytes, Tq, Tq, "chain verification: too many tables for one launch");
+    DevBuf<uint32_t>& gt = gtile[0];
+    gt.alloc((size_t)Tq * chain.K * G_::PW, s, false);
+    ChainTileArgs ta{w.P.p, gt.p, chain.dtile_src.p, w.Bpad, Tq, chain.K};
+    if ((uint64_t)Tq * chain.K >= ((uint64_t)1 << 32)) throw std::runtime_error("chain verification: too many tables for one launch");
+    MP_RUN(k_chain_tile, C, Tq * chain.K, 1, ta);
+    run_bucket(w, ph, chain_cs.p, Tpad, chain_d8.p, (size_t)ph.b_dig_bytes, Tq, Tq, "chain verification: too many tables for one launch", gt.p, chain.K);
     FixedArgs fx{chain_cs.p, w.J.p, FB.p, ph.fjobs.p, ph.fterms.p, w.Bpad, fbg, Tpad};
     MP_RUN(k_fixed_msm, C, Tq, ph.n_f, fx);
     if (ph.n_c0) {
@@ -1622,9 +1666,10 @@ struct Table : mp_table {
     CombineArgs cb{w.J.p, w.P.p, ph.cjobs.p, ph.cterms.p, w.Bpad};
     MP_RUN(k_combine, C, Tq, ph.n_c, cb);
     gbad[0].alloc(Tq, s, false);
-    ChainVerdictArgs va{w.J.p, w.direct.p, w.status.p, flag_word(false, s), gbad[0].p, w.Bpad, Tq, Lq, 0u, w.P.p, keyed ? l.pk : NO_SLOT, G};
-    MP_RUN(k_chain_verdict, C, Tq, 1, va);
-    rt::dzero(status, (size_t)B * 4, s);             // every link of every table whose chain equation holds has passed
+    // (the caller's words: 0 for every link of every table whose chain equation holds, MP_ERR_INTERNAL for the others until the per-link
+    // verifier below has looked at them)
+    ChainVerdictArgs va{w.J.p, w.direct.p, w.status.p, flag_word(false, s), gbad[0].p, w.Bpad, Tq, Lq, 0u, w.P.p, keyed ? l.pk : NO_SLOT, G, status, nullptr};
+    run_chain_verdict(va);
     if (!read_flag(false)) return;
     // some equation failed: the per-link verifier gives every link of ITS tables its exact status (link j of table t: deck row j T + t,
     // shuffled deck row (j + 1) T + t -- the same index into the array one deck further on); the other tables' verdicts stand
@@ -1632,7 +1677,7 @@ struct Table : mp_table {
     read_words(gbad[0].p, Tq, bad);
     group_members(bad.data(), Tq, Lq, idx);
     const VArgs cv{B, decks, decks + (size_t)T * deck_bytes, proofs, status, keys, nullptr, nullptr};
-    verify_subset(cv, idx, 0, false);
+    verify_subset(cv, idx, 0, false, 0, false);
   }
 
   // ---------------------------------------------------------------- group verification (round 4)
@@ -1870,9 +1915,10 @@ struct Table : mp_table {
     MP_RUN(k_combine, C, T, ph.n_c, cb);
     uint32_t* fl = host_flag;
     if (!fl) fl = flag_word(vlane, s);
-    ChainVerdictArgs va{w.J.p, w.direct.p, w.status.p, fl, gbad_out, w.Bpad, T, L, 0u, w.P.p, NO_SLOT, 1u};
-    MP_RUN(k_chain_verdict, C, T, 1, va);
-    rt::d2d(v.status, w.status.p, (size_t)B * 4, s);      // zeros unless an input was refused (final if the flag stays down)
+    // (the caller's words: zeros for the members of the groups whose equation holds -- final --, MP_ERR_INTERNAL for those of the others
+    // until the finer passes have given each its own word)
+    ChainVerdictArgs va{w.J.p, w.direct.p, w.status.p, fl, gbad_out, w.Bpad, T, L, 0u, w.P.p, NO_SLOT, 1u, v.status, nullptr};
+    run_chain_verdict(va);
   }
 
   // ---------------------------------------------------------------- building blocks (ad-hoc plans)
@@ -2221,9 +2267,9 @@ static int decompress_device(mp_ctx* ctx, size_t groups, uint32_t per_group, uin
   namespace mp {                                                                                               \
   mp_table* make_table_##NAME(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t* params, const uint8_t* pk,  \
                               uint32_t fb_bits, int* rc) {                                                     \
-    auto* p = new Table<NAME>();                                                                               \
+    std::unique_ptr<Table<NAME>> p(new Table<NAME>());      /* (an init that throws -- out of memory -- gives everything back) */ \
     *rc = p->init(ctx, m, n, params, pk, fb_bits);                                                             \
-    return p;                                                                                                  \
+    return p.release();                                                                                        \
   }                                                                                                            \
   int setup_##NAME(mp_ctx* ctx, uint32_t m, uint32_t n, const uint8_t seed[32], uint8_t* out) {                \
     return setup_device<NAME>(ctx, m, n, seed, out);                                                           \

@@ -41,14 +41,17 @@
 
 namespace mp {
 
-static const uint32_t BK_BITS_MIN = 8, BK_BITS_MAX = 13;     // signed windows: digits in [-2^(c-1), 2^(c-1) - 1]
+static const uint32_t BK_BITS_MIN = 8, BK_BITS_MAX = 14;     // signed windows: digits in [-2^(c-1), 2^(c-1)]
 // (windows of 12 bits and more: the split pipeline at the end of this file, round 6)
 #ifdef MP_EXP_BK_OCC
 static const uint32_t BK_WAVES_PER_CU = 4 * MP_EXP_BK_OCC;   // persistent waves: MP_EXP_BK_OCC workgroups of 4 per CU
 #else
 static const uint32_t BK_WAVES_PER_CU = 8;                   // persistent waves (MP_WAVE_KERNEL: 2 workgroups of 4 per CU)
 #endif
-static inline uint32_t bk_windows(int scalar_bits, uint32_t c) { return ((uint32_t)scalar_bits + c) / c; }
+// Round 6: a scalar k is recoded as min(k, q - k) with the signs of its digits flipped in the second case: the value is below
+// 2^(bits - 1), the top window never carries out, and ceil(bits / c) windows do -- 18 of 14 bits, 21 of 12 for a 252-bit order instead of
+// 19 and 22 (rounds 2-5 recoded k itself: (bits + c) / c windows)
+static inline uint32_t bk_windows(int scalar_bits, uint32_t c) { return ((uint32_t)scalar_bits + c - 1u) / c; }
 MP_HD uint32_t bk_buckets(uint32_t c) { return 1u << (c - 1); }
 // window width for an MSM of K terms: the reduction F costs ~(20 + 4 NB) additions per window, a narrower window K / (c (c + 1)) more
 // (12 bits and more: the split pipeline at the end of this file; measured on whole steps, profiles/r06i_batches.txt: 256 proofs of a
@@ -79,6 +82,24 @@ MP_HD void body_bucket_recode(const BRecodeArgs& a, uint32_t xx, uint32_t) {
   uint32_t k[10];
   fe_to_canonical<R>(ld_fe<R>(a.S + s_off(t.s, a.Bpad, b)), k);
   k[8] = k[9] = 0;
+  // k or q - k, whichever is smaller (k = 0 stays: q - 0 is not smaller)
+  uint32_t u[8];
+  uint32_t br = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t d = (uint64_t)R::MOD[i] - k[i] - br;
+    u[i] = (uint32_t)d;
+    br = (uint32_t)(d >> 63);
+  }
+  bool flip = false, decided = false;
+#pragma unroll
+  for (int i = 7; i >= 0; --i)
+    if (!decided && u[i] != k[i]) {
+      flip = u[i] < k[i];
+      decided = true;
+    }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) k[i] = flip ? u[i] : k[i];
   int16_t* out = a.D16 + (size_t)b * a.dstride + ps.pos;
   const uint32_t c = a.bits, half = 1u << (c - 1), mask = (1u << c) - 1u;
   uint32_t carry = 0;
@@ -91,7 +112,8 @@ MP_HD void body_bucket_recode(const BRecodeArgs& a, uint32_t xx, uint32_t) {
       raw -= 1u << c;
       carry = 1;
     }
-    out[(size_t)w * ps.kpad] = (int16_t)(int32_t)raw;
+    const int32_t d = (int32_t)raw;              // (the top window: 0 .. 2^(c-1), the last bucket included)
+    out[(size_t)w * ps.kpad] = (int16_t)(flip ? -d : d);
   }
 }
 // thread = proof * nterms + bucket term of the phase (the term is the fast axis: the digit stores of a wave are contiguous)

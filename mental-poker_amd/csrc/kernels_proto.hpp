@@ -1334,26 +1334,44 @@ struct ChainVerdictArgs {
   const uint32_t* P;
   uint32_t p_pk;           // NO_SLOT: not keyed
   uint32_t kstep;          // tables per equation: link j belongs to member j % kstep, whose first link is j % kstep (1: every link to link 0)
+  // the CALLER's status words (lane order; may be null): 0 for every member of an equation that holds, MP_ERR_INTERNAL for the members of
+  // one that does not -- until the finer passes have given each of them its own word.  A call that fails on its way there (out of memory
+  // in a refinement) then leaves no word that reads "accepted" for a proof nobody cleared
+  int32_t* out;
+  uint32_t* part;          // [T] scratch, zero at launch: what the links of equation t found on their own
 };
+// Three launches since round 6 (an equation of 64 tables x 32 links is 2 048 links: one lane walking them took 10 ms per step):
+// k_chain_check -- x = lane of (link, equation): the link's own findings, OR-ed into the equation's word part[t]; k_chain_verdict -- x =
+// equation: the equation's value and part[t] give gbad[t] and the flag; k_chain_mark -- x = lane: the caller's status words.
+template <class C>
+MP_HD void body_chain_check(const ChainVerdictArgs& a, uint32_t x, uint32_t) {
+  const uint32_t t = x % a.T, j = x / a.T;
+  bool bad = a.status[x] != 0 || (a.direct[x] | a.direct[(size_t)a.Bpad + x]) != 0;
+  if (a.p_pk != NO_SLOT && j >= a.kstep) {
+    uint32_t k0[Geo<C>::PW], kj[Geo<C>::PW];
+    ld_words<Geo<C>::PW>(a.P + p_off<C>(a.p_pk, a.Bpad, (j % a.kstep) * a.T + t), k0);
+    ld_words<Geo<C>::PW>(a.P + p_off<C>(a.p_pk, a.Bpad, x), kj);
+    uint32_t d = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < Geo<C>::PW; ++i) d |= k0[i] ^ kj[i];
+    bad = bad || d != 0;
+  }
+  if (bad) a.part[t] = 1u;       // (the same value from every lane that writes: no atomic needed)
+}
+MP_KERNEL(k_chain_check, ChainVerdictArgs, body_chain_check)
 template <class C>
 MP_HD void body_chain_verdict(const ChainVerdictArgs& a, uint32_t t, uint32_t y) {
-  bool bad = !fe_is_zero(ld_fe<typename C::FqP>(a.J + j_off<C>(a.j_final, a.Bpad, t) + 2 * Geo<C>::FW));
-  for (uint32_t j = 0; j < a.L; ++j) bad = bad || a.status[(size_t)j * a.T + t] != 0 || (a.direct[(size_t)j * a.T + t] | a.direct[(size_t)a.Bpad + (size_t)j * a.T + t]) != 0;
-  if (a.p_pk != NO_SLOT) {
-    uint32_t k0[Geo<C>::PW], kj[Geo<C>::PW];
-    for (uint32_t j = a.kstep; j < a.L; ++j) {
-      ld_words<Geo<C>::PW>(a.P + p_off<C>(a.p_pk, a.Bpad, (j % a.kstep) * a.T + t), k0);
-      ld_words<Geo<C>::PW>(a.P + p_off<C>(a.p_pk, a.Bpad, j * a.T + t), kj);
-      uint32_t d = 0;
-#pragma unroll
-      for (uint32_t i = 0; i < Geo<C>::PW; ++i) d |= k0[i] ^ kj[i];
-      bad = bad || d != 0;
-    }
-  }
+  const bool bad = a.part[t] != 0 || !fe_is_zero(ld_fe<typename C::FqP>(a.J + j_off<C>(a.j_final, a.Bpad, t) + 2 * Geo<C>::FW));
+  a.part[t] = bad ? 1u : 0u;
   if (a.gbad) a.gbad[t] = bad ? 1u : 0u;
   if (bad) a.flag[0] = 1u;
 }
 MP_KERNEL(k_chain_verdict, ChainVerdictArgs, body_chain_verdict)
+template <class C>
+MP_HD void body_chain_mark(const ChainVerdictArgs& a, uint32_t x, uint32_t) {
+  a.out[x] = a.part[x % a.T] ? -5 : 0;
+}
+MP_KERNEL(k_chain_mark, ChainVerdictArgs, body_chain_mark)
 
 // ---- re-verification of the proofs a screen could not clear (engine_core.hpp verify_subset, round 5): a failing screen -- the merged
 // equation of one proof, the equation of a group, of a chain -- says WHICH proofs need a closer look; their inputs are gathered into a
@@ -1378,6 +1396,27 @@ MP_HD void body_group_tile(const GroupTileArgs& a, uint32_t b, uint32_t y) {
   st_words<Geo<C>::PW>(a.tile + ((size_t)t * a.K + (size_t)j * a.per + y) * Geo<C>::PW, w);
 }
 MP_KERNEL(k_group_tile, GroupTileArgs, body_group_tile)
+
+// ... and the same for a chain equation (round 6): its distinct points -- the L + 1 decks of each member table, the proofs' points, the
+// members' keys -- lie in the P arena at (slot, lane of the link that brought them); term i of the equation's plan names them as
+// src[i] = slot | link << 20.  Copied once into the run [e][i], the sorted entries of the bucket kernels index the run, a chain equation
+// may span more than the 1 022 "links" ten bits of a sorted entry could name (64 tables x 32 links), and its windows gather from one
+// contiguous page instead of 4 424 x 64 pieces of the arena.  x = equation, y = term
+struct ChainTileArgs {
+  const uint32_t* P;
+  uint32_t* tile;          // [T][K][PW]
+  const uint32_t* src;     // [K]
+  uint32_t Bpad, T, K;
+};
+template <class C>
+MP_HD void body_chain_tile(const ChainTileArgs& a, uint32_t x, uint32_t) {
+  const uint32_t e = x % a.T, y = x / a.T;       // (flat: a pass may hold a few hundred equations -- a workgroup per term would be half empty)
+  const uint32_t s = a.src[y];
+  uint32_t w[Geo<C>::PW];
+  ld_words<Geo<C>::PW>(a.P + p_off<C>(s & 0xFFFFFu, a.Bpad, e + (s >> 20) * a.T), w);
+  st_words<Geo<C>::PW>(a.tile + ((size_t)e * a.K + y) * Geo<C>::PW, w);
+}
+MP_KERNEL(k_chain_tile, ChainTileArgs, body_chain_tile)
 
 struct GatherRowsArgs {
   const uint32_t* src;     // rows of `words` 32-bit words

@@ -494,7 +494,7 @@ def test_bucket_msm_edge_scalars_under_emulation(emu, coracle):
     same = b"".join((77).to_bytes(32, "little") for _ in range(K))      # every term in ONE bucket of one window
     want_same = coracle.msm(cvn, same, bytes(pts))
     zero = bytes(32 * K)
-    for bits in (0, 8, 9, 10, 11, 12, 13):               # window widths of the bucket method (0: by size = 8 here); 2, 4, 8, 16 buckets per lane of a wave, the split pipeline from 12 bits on (round 6)
+    for bits in (0, 8, 9, 10, 11, 12, 13, 14):             # window widths of the bucket method (0: by size = 8 here); 2, 4, 8, 16 buckets per lane of a wave, the split pipeline from 12 bits on (round 6)
         t.set_bucket_bits(bits)
         assert t.msm(1, K, scb, bytes(pts)) == want, bits
         assert t.msm(1, K, same, bytes(pts)) == want_same, bits
@@ -508,7 +508,7 @@ def test_bucket_msm_edge_scalars_under_emulation(emu, coracle):
     for i in range(nm):
         assert got[64 * i:64 * (i + 1)] == coracle.msm(cvn, many[32 * K * i:32 * K * (i + 1)], bytes(pts)), i
     # ... of the 12- and 13-bit ones (256 lanes per window)
-    for bits, edge in ((12, 2048), (13, 4096)):
+    for bits, edge in ((12, 2048), (13, 4096), (14, 8192)):
         t.set_bucket_bits(bits)
         sc[12:20] = [edge - 1, edge, edge + 1, 2 ** 250 + edge - 1, (1 << 252) - 1 - (q - (1 << 251)) % 7, q - edge, q - edge - 1, 2 * edge]
         many = b"".join(((s * (i + 1)) % q).to_bytes(32, "little") for i in range(nm) for s in sc)
@@ -516,7 +516,7 @@ def test_bucket_msm_edge_scalars_under_emulation(emu, coracle):
         for i in range(nm):
             assert got[64 * i:64 * (i + 1)] == coracle.msm(cvn, many[32 * K * i:32 * K * (i + 1)], bytes(pts)), (bits, i)
     with pytest.raises(Exception):
-        t.set_bucket_bits(14)
+        t.set_bucket_bits(15)
     # the width the engine picks by size: 9 bits from 6 000 terms, 10 from 12 000 (the points repeat: the oracle folds the scalars)
     base = bytes(pts)
     # (... 12 and 13 bits on the split pipeline with three sorted runs per bucket: 24 576 terms per run; the last scalars all equal --
