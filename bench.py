@@ -147,6 +147,65 @@ def pin_to_gpu_numa_node(local):
         return {"numa_node": None, "note": "%s: %s" % (type(e).__name__, e)}
 
 
+class Telemetry:
+    """shader clock and board power of THIS rank's GPU, sampled from its amdgpu hwmon files every 20 ms by a host thread while the timed
+    region runs (as tools/microbench/roof.hip does): the first suspects if a multi-GPU line falls short of N x the single-GPU one --
+    a node power limit shows as per_rank_power_w / per_rank_sclk_mhz below the N = 1 run's on every rank, a slow rank as one outlier
+    (DESIGN.md section 5).  Best effort: None where the sysfs files are missing."""
+
+    def __init__(self, local):
+        import glob
+        self.power_path = self.sclk_path = None
+        self.power, self.sclk = [], []
+        self._stop = None
+        self._thread = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(local)
+            base = "/sys/bus/pci/devices/%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            for name in ("power1_average", "power1_input"):
+                hit = sorted(glob.glob(base + "/hwmon/hwmon*/" + name))
+                if hit:
+                    self.power_path = hit[0]
+                    break
+            hit = sorted(glob.glob(base + "/hwmon/hwmon*/freq1_input"))
+            self.sclk_path = hit[0] if hit else None
+        except Exception:      # noqa: BLE001 -- telemetry never fails the run
+            pass
+
+    @staticmethod
+    def _read(path):
+        try:
+            return float(open(path).read().strip())
+        except Exception:      # noqa: BLE001
+            return None
+
+    def start(self):
+        import threading
+        if not (self.power_path or self.sclk_path):
+            return
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                p = self._read(self.power_path) if self.power_path else None
+                f = self._read(self.sclk_path) if self.sclk_path else None
+                if p is not None:
+                    self.power.append(p * 1e-6)      # microwatts
+                if f is not None:
+                    self.sclk.append(f * 1e-6)       # hertz
+                self._stop.wait(0.02)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._thread:
+            self._stop.set()
+            self._thread.join()
+        mean = lambda v: (sum(v) / len(v)) if v else -1.0
+        return mean(self.sclk), mean(self.power), float(len(self.power) or len(self.sclk))
+
+
 def scaled_batch(batch, world, scaling, seed_block):
     """proofs per rank per step and the seeding block: weak = `batch` each; strong = `batch` in total, a contiguous 1/N per rank, seeded
     per rank-sized block of the global batch so that the bytes are those of the unsharded run of the same proofs"""
@@ -291,6 +350,11 @@ def main():
                     help="curves with a cofactor (bls12_377): skip the per-point subgroup test of the wire points (mp_set_subgroup_check off) -- the "
                          "reference's shuffle_and_remask / verify_shuffle take typed points that were validated when they were deserialised "
                          "[REF examples/parameter_selection.rs:78-91], so this is its like-for-like; the default keeps the test")
+    ap.add_argument("--validated-once", action="store_true",
+                    help="pairs workload: every deck is validated exactly ONCE inside the timed step (mp_deck_validate_dev on the input decks and on "
+                         "the shuffled decks, as the party that receives them would) and the prove / verify calls are told so (mp_set_validated): the "
+                         "proofs' points are still tested in the verify call -- every point of a pair is tested once instead of the decks in every "
+                         "call that touches them (curves with a cofactor: bls12_377)")
     ap.add_argument("--chain-max-links", type=int, default=None,
                     help="chain32: links per chain equation (mp_set_chain_max_links; a chain of --players links is verified as consecutive "
                          "sub-chains; default: the whole chain)")
@@ -401,6 +465,8 @@ def main():
             t.set_group_lanes(args.group_lanes)
         if args.no_subgroup_check:
             t.set_subgroup_check(False)
+        if args.validated_once:
+            t.set_validated(t.VALIDATED_DECKS | t.VALIDATED_SHUFFLED)
     table = tables[0]
     proof_bytes = table.proof_bytes
 
@@ -493,6 +559,8 @@ def main():
                      torch.empty(B, dtype=torch.int32, device=gpu)) for _ in range(max(args.pipeline, 0) + 1)]
         out_decks, out_proofs, st_v = out_sets[0]
         st_p = torch.empty(B, dtype=torch.int32, device=gpu)
+        st_val = torch.zeros(B, dtype=torch.int32, device=gpu)       # --validated-once: the verdicts of mp_deck_validate_dev
+        st_val2 = torch.zeros(B, dtype=torch.int32, device=gpu)
         factors, perms, seeds = rand_factors(1), rand_perms(2), rand_seeds(3)
         torch.cuda.synchronize()
         if args.pipeline > 0:
@@ -522,14 +590,19 @@ def main():
                     continue
                 od, op_, sv = out_sets[rot["i"]]
                 rot["i"] = (rot["i"] + 1) % len(out_sets)
+                if args.validated_once:       # the input decks, once (the party that received them)
+                    t.deck_validate_dev(Bs, sl(decks, i), sl(st_val, i))
                 t.shuffle_and_remask_batch_dev(Bs, sl(decks, i), sl(factors, i), sl(perms, i), sl(seeds, i), sl(od, i), sl(op_, i), sl(st_p, i))
+                if args.validated_once:       # the shuffled decks, once (the verifier that receives them with the proof)
+                    t.deck_validate_dev(Bs, sl(od, i), sl(st_val2, i))
                 t.verify_shuffle_batch_dev(Bs, sl(decks, i), sl(od, i), sl(op_, i), sl(sv, i))
 
         proofs_per_step = B
         units = "prove+verify pairs"
 
         def check():
-            return int((st_p != 0).sum().item()) + sum(int((o[2] != 0).sum().item()) for o in out_sets)
+            return (int((st_p != 0).sum().item()) + sum(int((o[2] != 0).sum().item()) for o in out_sets) +
+                    (int((st_val != 0).sum().item()) + int((st_val2 != 0).sum().item()) if args.validated_once else 0))
 
         def parity_inputs():
             b = B // 2
@@ -671,11 +744,15 @@ def main():
     barrier()
     for e in engines:
         e.profile_enable(True)
+    tele = Telemetry(local)
+    tele.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    my_enqueue = time.perf_counter() - t0      # every call of the K steps has returned (a verify call returns with its screening verdict)
     barrier()
     my_elapsed = time.perf_counter() - t0
+    my_sclk, my_power, my_samples = tele.stop()
     prof = {}
     for e in engines:
         for k, (cnt, ms) in e.profile_report().items():
@@ -687,7 +764,7 @@ def main():
 
     # ---- correctness of what was timed (outside the timed region); verdicts gathered from every rank
     bad = check()
-    rows = gather_rows([proofs_per_step * args.steps, bad, my_elapsed], dev)
+    rows = gather_rows([proofs_per_step * args.steps, bad, my_elapsed, my_sclk, my_power, my_samples, table_build_s, my_enqueue], dev)
     total_proofs = sum(r[0] for r in rows)
     total_bad = int(sum(r[1] for r in rows))
     assert total_bad == 0, "%d proofs failed (per rank: %s)" % (total_bad, [int(r[1]) for r in rows])
@@ -900,7 +977,7 @@ def main():
     def bucket_geometry(K):
         """window width the engine picks for a bucket-method MSM of K terms (kernels_bucket.hpp bk_bits_for), its windows per scalar,
         buckets per lane and the point additions of the wave-wide reduction of one window"""
-        c = 13 if K >= 200000 else (12 if K >= 50000 else (11 if K >= 40000 else (10 if K >= 12000 else (9 if K >= 6000 else 8))))      # (12 and 13: the split pipeline, one reducing wave per window)
+        c = 14 if K >= 200000 else (12 if K >= 50000 else (11 if K >= 40000 else (10 if K >= 12000 else (9 if K >= 6000 else 8))))      # (12 and 13: the split pipeline, one reducing wave per window)
         nb = (1 << (c - 1)) // 64
         return {"bits": c, "windows": (SCALAR_BITS + c - 1) // c, "buckets_per_lane": nb, "reduction_adds": 13 + 2 * nb - 3}      # (round 6: min(k, q - k) is recoded: ceil(bits / c) windows)
     per_proof_pts = 4 * N + 11 * m + 8
@@ -1198,10 +1275,17 @@ def main():
               "rccl_world": (dist.get_world_size() if world > 1 else 1), "collective_backend": backend if world > 1 else None,
               "rccl_smoke": smoke_log, "pipeline_depth": args.pipeline,
               "subgroup_check": (not args.no_subgroup_check) if curve == "bls12_377" else None,
+              "validated_once": bool(args.validated_once),
               "table_build_s": round(table_build_s, 3),
               "hbm_per_rank_gb": hbm_used_gb,
               "per_rank_proofs": [int(r[0]) for r in rows], "per_rank_failed": [int(r[1]) for r in rows],
               "per_rank_seconds": [round(r[2], 4) for r in rows],
+              # telemetry of the timed region, per rank (Telemetry above; None = no hwmon file): what explains a scaling shortfall first
+              "per_rank_sclk_mhz": [round(r[3], 1) if r[3] >= 0 else None for r in rows],
+              "per_rank_power_w": [round(r[4], 1) if r[4] >= 0 else None for r in rows],
+              "per_rank_telemetry_samples": [int(r[5]) for r in rows],
+              "per_rank_table_build_s": [round(r[6], 3) for r in rows],
+              "per_rank_host_enqueue_ms_per_step": [round(1e3 * r[7] / args.steps, 3) for r in rows],
               "parity_vs_oracle": parity}
     config.update(extras)
     # flat scalars of the nested extras (a driver that keeps only scalar fields still sees them)

@@ -262,11 +262,25 @@ int mp_set_bucket_min(mp_table* t, size_t terms);
  * below 200 000, 13 from there on -- the equation of a group of 1 024 52-card proofs, mp_set_group_verify).  Results are identical;
  * rebuilds the static plans like mp_set_bucket_min. */
 int mp_set_bucket_bits(mp_table* t, uint32_t bits);
+/* Round 6: inputs the caller has validated ONCE are not validated again in every call that touches them.  The reference's trait takes
+ * typed arkworks points, validated when they were deserialised [REF examples/parameter_selection.rs:78-91]; this engine takes wire
+ * bytes and by default tests every point of every call for membership of the prime-order subgroup (curves with a cofactor: BLS12-377)
+ * -- a deck that passes along a chain of shuffles was tested in the call that proved it, the call that verified it and the call that
+ * shuffled it on.  `what` = OR of MP_VALIDATED_*: the table's following calls skip the subgroup test of those inputs (range, curve
+ * equation and permutation checks stay).  A deck is "validated" if it came out of mp_deck_deserialize_dev / mp_deck_deserialize with
+ * status 0, out of mp_deck_validate_dev with status 0, or out of this engine's own prover.  0 (default) = test everything. */
+#define MP_VALIDATED_DECKS 1u     /* the input decks of prove and verify calls */
+#define MP_VALIDATED_SHUFFLED 2u  /* the shuffled decks of verify calls */
+#define MP_VALIDATED_PROOFS 4u    /* the points of the proofs (only if they came through mp_proof_deserialize) */
+int mp_set_validated(mp_table* t, uint32_t what);
+/* `decks` wire-v1 decks of the table's size in DEVICE memory -> one int32 per deck in d_status: 0, or MP_ERR_BAD_ENCODING if a point is
+ * not canonical, not on the curve or outside the prime-order subgroup.  The once-per-deck validation that mp_set_validated relies on. */
+int mp_deck_validate_dev(mp_table* t, size_t decks, const void* d_wire_decks, void* d_status);
 /* Round 6.  Bucket jobs whose windows are at least `min_bits` wide (default 12: equations of 100 000 points and more -- the screen of
  * 512 .. 2 048 52-card proofs) run as THREE kernels instead of one wave per (equation, window): k_bucket_sort (a workgroup per 24 576
  * terms: counting sort inside LDS, the sorted run written in whole lines), k_bucket_acc (a wave per range of 256 buckets, four per lane
  * dealt by rank, one mixed addition per term; equal shares of the list instead where a window's digits crowd into a few buckets) and
- * k_bucket_reduce (a wave per window).  8 = every bucket job, 14 = none.  Results are identical. */
+ * k_bucket_reduce (a workgroup per window, a quarter of the buckets per wave).  10 .. 15 (= none).  Results are identical. */
 int mp_set_bucket_split(mp_table* t, uint32_t min_bits);
 /* Chain verification (mp_verify_shuffle_chain*): at most `links` links share one chain equation; longer chains are verified as
  * consecutive sub-chains.  0 (default) = as many as fit the 32 767 points of one equation (293 links of a 52-card deck; one link of a deck too large for that gets an equation of up to 65 535 points).  A smaller

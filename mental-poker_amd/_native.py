@@ -16,7 +16,7 @@ MP_ERR_BAD_ENCODING, MP_ERR_BAD_PERMUTATION, MP_ERR_BAD_ARGUMENT, MP_ERR_NO_DEVI
 
 SYMBOLS = [
     "mp_ctx_create", "mp_ctx_destroy", "mp_last_error", "mp_check_name", "mp_proof_size", "mp_params_size",
-    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_set_subgroup_check", "mp_set_bucket_min", "mp_set_bucket_bits", "mp_set_bucket_split", "mp_set_chain_max_links", "mp_set_chain_group", "mp_set_chain_slice", "mp_chain_group_size", "mp_chain_last_slice", "mp_set_transcript_lanes", "mp_set_group_lanes", "mp_set_work_split", "mp_set_group_verify", "mp_group_size", "mp_set_group_refine", "mp_reverified_count", "mp_set_group_adapt", "mp_set_pipeline", "mp_set_plan_params", "mp_set_plan_thresholds", "mp_set_toom_cook", "mp_host_alloc", "mp_host_free", "mp_set_io_chunk", "mp_shuffle_and_remask_batch_keys", "mp_table_create_params",
+    "mp_point_size", "mp_proof_size_curve", "mp_params_size_curve", "mp_set_merged_verify", "mp_set_subgroup_check", "mp_set_bucket_min", "mp_set_bucket_bits", "mp_set_bucket_split", "mp_set_validated", "mp_deck_validate_dev", "mp_set_chain_max_links", "mp_set_chain_group", "mp_set_chain_slice", "mp_chain_group_size", "mp_chain_last_slice", "mp_set_transcript_lanes", "mp_set_group_lanes", "mp_set_work_split", "mp_set_group_verify", "mp_group_size", "mp_set_group_refine", "mp_reverified_count", "mp_set_group_adapt", "mp_set_pipeline", "mp_set_plan_params", "mp_set_plan_thresholds", "mp_set_toom_cook", "mp_host_alloc", "mp_host_free", "mp_set_io_chunk", "mp_shuffle_and_remask_batch_keys", "mp_table_create_params",
     "mp_verify_shuffle_batch_keys", "mp_shuffle_and_remask_batch_keys_dev", "mp_verify_shuffle_batch_keys_dev",
     "mp_keyset_create", "mp_keyset_destroy", "mp_keyset_size", "mp_shuffle_and_remask_batch_keyset_dev", "mp_verify_shuffle_batch_keyset_dev",
     "mp_setup", "mp_table_create", "mp_table_create_ex", "mp_table_window_bits", "mp_table_destroy", "mp_shuffle_and_remask", "mp_verify_shuffle",
@@ -126,6 +126,8 @@ def bind(cdll):
     cdll.mp_set_bucket_min.argtypes = [c.c_void_p, c.c_size_t]
     cdll.mp_set_bucket_bits.argtypes = [c.c_void_p, c.c_uint32]
     cdll.mp_set_bucket_split.argtypes = [c.c_void_p, c.c_uint32]
+    cdll.mp_set_validated.argtypes = [c.c_void_p, c.c_uint32]
+    cdll.mp_deck_validate_dev.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p, c.c_void_p]
     cdll.mp_set_toom_cook.argtypes = [c.c_void_p, c.c_int]
     cdll.mp_set_chain_max_links.argtypes = [c.c_void_p, c.c_uint32]
     cdll.mp_set_chain_group.argtypes = [c.c_void_p, c.c_uint32]
@@ -607,8 +609,18 @@ class Table:
         """window width of the bucket method: 8 .. 13, or 0 = by the size of the MSM (default: 11 from 40 000 terms on, 12 from 100 000, 13 from 200 000)"""
         self.eng._chk(self.lib.mp_set_bucket_bits(self.h, bits))
 
+    VALIDATED_DECKS, VALIDATED_SHUFFLED, VALIDATED_PROOFS = 1, 2, 4
+
+    def set_validated(self, what):
+        """inputs the caller has validated once already (OR of VALIDATED_*): their subgroup test is not repeated in every call"""
+        self.eng._chk(self.lib.mp_set_validated(self.h, what))
+
+    def deck_validate_dev(self, decks, d_wire_decks, d_status):
+        """wire-v1 decks in device memory -> one int32 per deck (0 / MP_ERR_BAD_ENCODING): range, curve equation, prime-order subgroup"""
+        self.eng._chk(self.lib.mp_deck_validate_dev(self.h, decks, d_wire_decks, d_status))
+
     def set_bucket_split(self, min_bits):
-        """windows of at least `min_bits` bits run sort / additions / reduction as three kernels (default 12; 8 = always, 14 = never)"""
+        """windows of at least `min_bits` bits run sort / additions / reduction as three kernels (default 12; 10 .. 15 = never)"""
         self.eng._chk(self.lib.mp_set_bucket_split(self.h, min_bits))
 
     def set_chain_max_links(self, links):

@@ -326,11 +326,29 @@ int mp_set_bucket_bits(mp_table* t, uint32_t bits) {
 }
 int mp_set_bucket_split(mp_table* t, uint32_t min_bits) {
   if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_split: null table");
-  if (min_bits < 8 || min_bits > 14) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_split: 8 (every bucket job) .. 14 (none)");
+  if (min_bits < 10 || min_bits > 15) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_bucket_split: 10 .. 15 (none)");
   MP_TRY
   MP_ENTER(t->ctx);
   t->flush();
   t->bucket_split_bits = min_bits;
+  return MP_OK;
+  MP_CATCH
+}
+int mp_set_validated(mp_table* t, uint32_t what) {
+  if (!t) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_validated: null table");
+  if (what & ~(MP_VALIDATED_DECKS | MP_VALIDATED_SHUFFLED | MP_VALIDATED_PROOFS)) return fail(MP_ERR_BAD_ARGUMENT, "mp_set_validated: unknown flag");
+  MP_TRY
+  MP_ENTER(t->ctx);
+  t->flush();
+  t->validated = what;
+  return MP_OK;
+  MP_CATCH
+}
+int mp_deck_validate_dev(mp_table* t, size_t decks, const void* d_wire_decks, void* d_status) {
+  if (!t || !decks || !d_wire_decks || !d_status || decks >= ((size_t)1 << 31)) return fail(MP_ERR_BAD_ARGUMENT, "mp_deck_validate_dev: bad argument");
+  MP_TRY
+  MP_ENTER(t->ctx);
+  t->validate_decks_dev(decks, (const uint8_t*)d_wire_decks, (int32_t*)d_status);
   return MP_OK;
   MP_CATCH
 }

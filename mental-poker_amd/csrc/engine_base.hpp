@@ -207,6 +207,7 @@ struct mp_table {
   uint32_t fb_bits = 8;        // window width of the fixed-base tables (mp_table_window_bits)
   bool keyless = false;        // created from the parameters alone (mp_table_create_params): keyed entry points only
   uint32_t bucket_bits = 0;       // window width of the bucket method (0 = by the size of the MSM: kernels_bucket.hpp bk_bits_for; mp_set_bucket_bits)
+  uint32_t validated = 0;         // MP_VALIDATED_* (mp_set_validated): inputs the caller has validated once already -- their subgroup test is not repeated
   uint32_t bucket_split_bits = 12;   // windows of at least this many bits run sort / additions / reduction as three kernels (kernels_bucket.hpp, round 6; mp_set_bucket_split)
   uint32_t chain_max_links = 0;   // links per chain equation (0 = as many as fit 32 767 points; mp_set_chain_max_links)
   size_t chain_slice = 0;         // tables per pass of chain verification (0 = as many as the free memory holds; mp_set_chain_slice)
@@ -246,6 +247,7 @@ struct mp_table {
   // bytes of chain workspace a link in flight needs, and the links the workspace holds already (mp_verify_shuffle_chain_dev sizes its passes by them)
   virtual size_t chain_lane_bytes(uint32_t L, bool keyed) = 0;
   virtual size_t chain_lanes_held() const = 0;
+  virtual void validate_decks_dev(size_t count, const uint8_t* decks, int32_t* status) = 0;
   virtual uint32_t chain_group_size(size_t T, uint32_t L, bool keyed) const = 0;
   size_t chain_last_slice = 0;    // tables per pass of the last mp_verify_shuffle_chain_dev call (mp_chain_plan)
   virtual void remask_host(size_t count, const uint8_t* cards, const uint8_t* rho, uint8_t* out) = 0;

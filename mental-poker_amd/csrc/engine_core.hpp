@@ -81,7 +81,7 @@ struct Workspace {
   uint32_t d8_bytes = 0;
   // scratch rows of the bucket kernel's persistent waves (kernels_bucket.hpp): the sorted point references of the window a wave is
   // working on, and its parked bucket sums -- at most 2 048 x (128 KB + 64 KB), whatever the batch
-  DevBuf<uint32_t> bk_sorted, bk_park, bk_counter, bk_timing;
+  DevBuf<uint32_t> bk_sorted, bk_park, bk_counter, bk_timing, bk_quarters;
   DevBuf<uint16_t> bk_offs;           // the split pipeline's bucket offsets per (item, chunk)
   void ensure_bucket(uint32_t nslots, uint32_t kpad_max, uint32_t bits, uint32_t xw, rt::Stream s) {
     bk_sorted.alloc((size_t)nslots * kpad_max, s, false);
@@ -333,6 +333,40 @@ struct Table : mp_table {
     SubgroupArgs a{w.P.p, w.status.p, w.Bpad, first};
     MP_RUN(k_subgroup_check, C, B, count, a);
   }
+  // The wire points of a verify call: input deck, shuffled deck, the proof's points [, the proof's key] -- the P slots [0, pk (+ 1)).
+  // What the caller has validated already (mp_set_validated: a deck that came through mp_deck_deserialize_dev or mp_deck_validate_dev,
+  // as the reference's typed points came through CanonicalDeserialize [REF examples/parameter_selection.rs:78-91]) is not tested again:
+  // a deck that passes along a chain of shuffles used to be tested in every call that touched it (round 6).
+  void check_verify_inputs(Workspace& w, uint32_t B, const VerifyLay& l, bool keyed) {
+    if (!validated) {
+      check_subgroup(w, B, 0, l.pk + (keyed ? 1u : 0u));
+      return;
+    }
+    if (!(validated & MP_VALIDATED_DECKS)) check_subgroup(w, B, l.deck, 2 * N);
+    if (!(validated & MP_VALIDATED_SHUFFLED)) check_subgroup(w, B, l.shuf, 2 * N);
+    const uint32_t rest = std::max(l.deck, l.shuf) + 2 * N;      // (decks first, then the proof's points up to pk)
+    if (!(validated & MP_VALIDATED_PROOFS)) check_subgroup(w, B, rest, l.pk - rest);
+    if (keyed) check_subgroup(w, B, l.pk, 1);
+  }
+  // wire-v1 decks in HBM -> one status word per deck: 0, or MP_ERR_BAD_ENCODING if some point is not canonical, not on the curve or
+  // (curves with a cofactor) outside the prime-order subgroup -- whatever mp_set_subgroup_check says: this IS the validation
+  Workspace dws;
+  void validate_decks_dev(size_t count, const uint8_t* decks, int32_t* status) override {
+    rt::Stream s = ctx->stream;
+    const uint32_t B = (uint32_t)count;
+    Workspace& w = dws;
+    w.fw = G_::FW;
+    w.ensure(B, 1, 2 * N, 8, 0, 0, nwin, 4, s, 0);
+    rt::dzero(w.status.p, (size_t)w.Bpad * 4, s);
+    LoadPointsArgs a{decks, w.P.p, w.status.p, w.Bpad, 2 * N, 0};
+    MP_RUN(k_load_points, C, B, 2 * N, a);
+    if (!Cofactor<C>::ONE) {
+      SubgroupArgs sa{w.P.p, w.status.p, w.Bpad, 0};
+      MP_RUN(k_subgroup_check, C, B, 2 * N, sa);
+    }
+    rt::d2d(status, w.status.p, (size_t)B * 4, s);
+    rt::stream_sync(s);
+  }
   DevBuf<uint32_t> vflag;      // [2] "some proof of the batch needs a closer look" (word 0: the caller's lane, word 1: the verify lane)
   uint32_t* flag_word(bool vlane, rt::Stream s) {
     if (!vflag.n) vflag.alloc(2, s);
@@ -421,6 +455,7 @@ struct Table : mp_table {
     this->fb_bits = fb_bits;
     m = m_; n = n_; N = m * n;
     point_bytes = G_::PB;
+    if (G_::FW > 8) bucket_split_bits = 11;      // (BLS12-377: the one-wave-per-window kernel spills on the 14-limb field, the split pipeline's hot loop does not)
     // plan thresholds count lanes, and a proof of N cards brings ~N/52 times the lanes of a 52-card proof
     set_latency_batch(std::max<size_t>(40, (size_t)2560 * 52 / N));
     nwin = (uint32_t)vb_windows(R::BITS);
@@ -686,16 +721,19 @@ struct Table : mp_table {
       w.bk_sorted.alloc(items_max * ph.b_kpad_max, s, false);
       w.bk_offs.alloc(items_max * gmax * bk_offs_row(c), s, false);
       w.bk_park.alloc(items_max * NBK * XW, s, false);
+      w.bk_quarters.alloc(items_max * 8 * XW, s, false);
       for (uint32_t e0 = 0; e0 < count; e0 += pass) {
         const uint32_t ne = std::min(pass, count - e0), items = ne * ph.n_b * bw;
         const uint32_t acc_lds = bk_acc_lds_words(c, gmax, XW, G_::PW), wpb = rt::waves_per_block(acc_lds), wgs = (items * units + wpb - 1) / wpb;
         BSplitArgs sa{D, w.P.p, w.J.p, ph.bjobs.p, ph.bterms.p, w.Bpad, bw, ph.n_b, dstride, link_stride, c, e0, ne, tile, tile_K,
-                      w.bk_sorted.p, w.bk_offs.p, w.bk_park.p, ph.b_kpad_max, gmax, units, wpb, wgs};
+                      w.bk_sorted.p, w.bk_offs.p, w.bk_park.p, ph.b_kpad_max, gmax, units, wpb, wgs, w.bk_quarters.p};
         ctx->prof.begin("k_bucket_sort", s, (uint64_t)items * gmax);
-        MP_BLOCK_LAUNCH(k_bucket_sort, C, s, items * gmax, NBK + 2u + BK_CHUNK / 2u, sa);
+        MP_BLOCK_LAUNCH(k_bucket_sort, C, s, items * gmax, bk_sort_lds_words(c), sa);
         ctx->prof.end(s);
         MP_WAVE_RUN(k_bucket_acc, C, (wgs + 7u) / 8u * 8u * wpb, acc_lds, sa);      // (8 XCDs x their share of the workgroups: bk_unit_of_wave)
-        MP_WAVE_RUN(k_bucket_reduce, C, items, 64u * XW, sa);
+        MP_WAVE_RUN(k_bucket_list, C, (wgs + 7u) / 8u * 8u * wpb, acc_lds, sa);     // (the windows whose digits crowd into a few buckets: nothing to do for the others)
+        MP_WAVE_RUN(k_bucket_reduce, C, items * 4u, 64u * XW, sa);
+        MP_RUN(k_bucket_final, C, items, 1, sa);
       }
       BFoldArgs fa{w.J.p, ph.bjobs.p, w.Bpad, bw, 0u, c};
       if (quad_ops(count, ph.n_b)) {
@@ -960,7 +998,7 @@ struct Table : mp_table {
       if (!overlap) prove_init(ia, B);
       RemaskArgs ra{w.S.p, w.P.p, w.J.p, FB.p, perm, w.Bpad, N, l.rho, l.deck, l.shuf, fb.G(), fb.pk(), fbg,
                     0, w.D.p, w.T.p, key_d_first, key_t_first, nwin, nullptr, nullptr, FbGeom{8, 32, 255}, 0};
-      check_subgroup(w, B, l.deck, 2 * N);
+      if (!(validated & MP_VALIDATED_DECKS)) check_subgroup(w, B, l.deck, 2 * N);
       if (kset) {
         // the proof's key is a member of a key set: its multiples come from the set's tables, the key itself (transcript, its
         // own terms in the argument) from the set's copy of the wire bytes (validated when the set was built)
@@ -1163,7 +1201,7 @@ struct Table : mp_table {
         MP_RUN(k_load_points, C, B, 1, ka);
       }
       // decks and proof points are the P slots [0, pk); the key follows
-      check_subgroup(w, B, 0, l.pk + (keyed ? 1u : 0u));
+      check_verify_inputs(w, B, l, keyed);
     }
     // The window tables of the verifier's bases need the loaded points and nothing else: batches that do not fill the chip build
     // them on `side` while the main stream hashes the transcript and derives the scalars (the table kernel leans on HBM, the
@@ -1522,7 +1560,7 @@ struct Table : mp_table {
   uint32_t chain_points_per_table(uint32_t L, bool keyed) const { return (L + 1) * 2 * N + L * (11 * m + 8) + (keyed ? 1u : 0u); }
   uint32_t chain_group_of(uint32_t T, uint32_t L, bool keyed) const {
     // (an explicit mp_set_chain_group is honoured whatever mp_set_group_verify says; the automatic rule follows the group equations')
-    if (chain_group == 1 || (!chain_group && !group_points)) return 1;
+    if (chain_group == 1 || (!chain_group && !group_points && !group_points_wg)) return 1;
     const uint32_t per = chain_points_per_table(L, keyed);
     uint32_t want = chain_group;
     if (!want) {
@@ -1629,7 +1667,7 @@ struct Table : mp_table {
         LoadPointsArgs ka{keys, w.P.p, w.status.p, w.Bpad, 1, l.pk};
         MP_RUN(k_load_points, C, B, 1, ka);
       }
-      check_subgroup(w, B, 0, l.pk + (keyed ? 1u : 0u));
+      check_verify_inputs(w, B, l, keyed);
     }
     {
       VerifyFsArgs a{};
@@ -1722,9 +1760,13 @@ struct Table : mp_table {
   // additions per point; its units are a sixteenth of a window, so 128 equations keep the chip busy).  Whole steps on one box
   // (profiles/r06i_batches.txt): 262 144 proofs 663 -> 694 k/s (1 024 per equation), 131 072: 644 -> 673 k (512 or 1 024), 65 536:
   // 610 -> 638 k (256 or 512), 32 768: 550 -> 566 k (256).
-  static const uint32_t GROUP_POINTS_WAVE = 30464u, GROUP_POINTS_WG = 243712u, GROUP_WG_POINTS_MIN = 50000u;
+  // BLS12-377: the one-wave-per-window kernel spills 200 registers on the 14-limb field and only drew level with the Straus screen
+  // (round 4), so group_points stays 0 there; the split pipeline's hot loop is spill-free (213 registers, no scratch), takes 11-bit
+  // windows too on this curve (mp_set_bucket_split 11) and equations from 40 000 points on: 32 proofs of a 300-card deck at 4 096 in
+  // flight, 13.3 -> 14.5 k pairs/s with the subgroup test of every point still in the call (profiles/r06o_bls_groups.txt).
+  static const uint32_t GROUP_POINTS_WAVE = 30464u, GROUP_POINTS_WG = 243712u, GROUP_WG_POINTS_MIN = G_::FW > 8 ? 40000u : 50000u;
   uint32_t group_points = G_::FW > 8 ? 0u : GROUP_POINTS_WAVE;      // points per group equation aimed at (mp_set_group_verify; 0 = off)
-  uint32_t group_points_wg = G_::FW > 8 ? 0u : GROUP_POINTS_WG;     // ... by the batches large enough for the workgroup kernel (0 = never)
+  uint32_t group_points_wg = GROUP_POINTS_WG;                       // ... by the batches large enough for the split pipeline (0 = never)
   uint32_t group_min_batch = 6144;    // smaller batches (in 52-card proofs: x 52 / N) keep the per-proof screen
   void set_group_verify(uint32_t points, size_t min_batch) override {
     // (one knob: up to 65 535 points = equations of that size at the most, under the rule of rounds 4-5; more = the split pipeline's
@@ -1739,7 +1781,7 @@ struct Table : mp_table {
   uint32_t group_size(uint32_t B, bool keyed) const {
     const uint32_t per = 4 * N + 11 * m + 8 + (keyed ? 1u : 0u);
     // (the minimum counts lanes like the work-split thresholds: a proof of N cards brings N / 52 times the points of a 52-card one)
-    if (!group_points || !merged_verify || (uint64_t)B * N < (uint64_t)group_min_batch * 52u) return 0;
+    if ((!group_points && !group_points_wg) || !merged_verify || (uint64_t)B * N < (uint64_t)group_min_batch * 52u) return 0;
     // as many proofs per group as bring its equation nearest to group_points points, but no fewer groups than keep the persistent
     // waves busy
     const uint32_t groups_min = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)group_min_batch * 2u) / 13u));
@@ -1775,10 +1817,13 @@ struct Table : mp_table {
   }
   void note_group_verdicts(uint32_t T, uint32_t failing, uint32_t L) {
     if (!group_adapt || T < 64) return;
+    // (round 6: the default group is 1 024 proofs -- seven halvings down to 8.  When nineteen groups in twenty fail, the rate is far
+    // beyond what the next size could clear: three halvings at once; and a call in which no group fails at all grows back two steps)
     if ((uint64_t)failing * 5 > T) {
-      if (L >= 16 && adapt_shift < 7) ++adapt_shift;
+      const uint32_t by = (uint64_t)failing * 20 >= (uint64_t)T * 19 && L >= 128 ? 3u : 1u;
+      if (L >= 16) adapt_shift = std::min<uint32_t>(7u, adapt_shift + by);
     } else if ((uint64_t)failing * 25 < T && adapt_shift > 0) {
-      --adapt_shift;
+      adapt_shift -= failing == 0 && adapt_shift >= 2 ? 2u : 1u;
     }
   }
   ChainPlan& build_group_plan(uint32_t L, bool keyed) {
@@ -1856,7 +1901,7 @@ struct Table : mp_table {
         LoadPointsArgs ka{keys, w.P.p, w.status.p, w.Bpad, 1, l.pk};
         MP_RUN(k_load_points, C, B, 1, ka);
       }
-      check_subgroup(w, B, 0, l.pk + (keyed ? 1u : 0u));
+      check_verify_inputs(w, B, l, keyed);
     }
     {
       VerifyFsArgs a{};

@@ -55,9 +55,11 @@ static inline uint32_t bk_windows(int scalar_bits, uint32_t c) { return ((uint32
 MP_HD uint32_t bk_buckets(uint32_t c) { return 1u << (c - 1); }
 // window width for an MSM of K terms: the reduction F costs ~(20 + 4 NB) additions per window, a narrower window K / (c (c + 1)) more
 // (12 bits and more: the split pipeline at the end of this file; measured on whole steps, profiles/r06i_batches.txt: 256 proofs of a
-// 52-card deck -- 60 928 points -- are better off with 12 bits there than with 11 on one wave per window)
+// 52-card deck -- 60 928 points -- are better off with 12 bits there than with 11 on one wave per window.  From 200 000 points on 14
+// bits: 18 windows for a 252-bit order, all of them full -- 13-bit windows are 20, the top one holding 17 values and summed in list mode
+// --: 66.4 against 72.1 ms per launch for the 243 712-point equations of 262 144 proofs, profiles/r06r_bits14.txt)
 static inline uint32_t bk_bits_for(uint32_t K) {
-  return K >= 200000u ? 13u : (K >= 50000u ? 12u : (K >= 40000u ? 11u : (K >= 12000u ? 10u : (K >= 6000u ? 9u : 8u))));
+  return K >= 200000u ? 14u : (K >= 50000u ? 12u : (K >= 40000u ? 11u : (K >= 12000u ? 10u : (K >= 6000u ? 9u : 8u))));
 }
 // LDS words one item's lanes need: counts + cursors of the buckets, one XYZZ exchange slot of xw words per lane
 static inline uint32_t bk_lds_words(uint32_t c, uint32_t xw, uint32_t lanes = 64u) { return 2u * (bk_buckets(c) + 4u) + lanes * xw; }
@@ -534,8 +536,8 @@ MP_WAVE_KERNEL_OCC(k_bucket_msm, BucketArgs, body_bucket_msm, MP_BK_OCC(C))
 //                    LIST mode, for a window whose digits crowd into a few buckets (the top window of a 252-bit scalar holds 17
 //                    values at c = 13; an MSM whose scalars are all equal): unit g takes chunk g's run in 64 equal shares and
 //                    leaves ONE sum.  An item is in list mode if a chunk's largest bucket exceeds eight times its share (+ 32);
-//   k_bucket_reduce  one wave per item: sum_k k S_k over the 2^(c-1) parked sums as in F above with NB = 2^(c-1) / 64 buckets per
-//                    lane (2 NB - 3 + 13 additions: 8 % fewer wave-additions than four waves of NB / 4), or the sum of the G list sums.
+//   k_bucket_reduce  four waves per item, a quarter of the 2^(c-1) parked sums each: sum_j j S_j and sum_j S_j over the quarter as in F
+//                    above with NB = 2^(c-1) / 256 buckets per lane; k_bucket_final puts the quarters together (or takes the list sums).
 //
 // `sorted`, `offs` and `park` hold every item of a pass at once (1.6 MB per item at c = 13: the engine cuts a call into passes of
 // equations that fit its scratch budget).  Results are canonical group elements: bit-identical to the kernel above.
@@ -574,6 +576,7 @@ struct BSplitArgs {
   uint32_t kpad_max, gmax; // gmax = bk_chunks(kpad_max)
   uint32_t units;          // units per item: its bucket ranges, bk_units(bits)
   uint32_t wpb, wgs;       // k_bucket_acc: waves per workgroup of the launch, workgroups that hold units
+  uint32_t* quarters;      // [items][4][2][XYZZ words]: k_bucket_reduce's (A, R) per quarter of the buckets, for k_bucket_final
 };
 // k_bucket_acc: which unit a wave of the launch takes.  Workgroup i of a launch runs on XCD i mod 8 (observed; the hardware deals
 // workgroups round-robin and statically), and consecutive units belong to the same item: dealt as they come, the units of every other
@@ -608,11 +611,18 @@ MP_HD bool bk_list_mode(const BSplitArgs& a, uint32_t it, uint32_t G) {
   return bk_crowded(largest, a.bits);
 }
 
-// ---- k_bucket_sort: W = BlockCtx (256 lanes), x = item * gmax + chunk; wv.lds = 2^(c-1) + 2 + BK_CHUNK words
+// ---- k_bucket_sort: W = BlockCtx (256 lanes), x = item * gmax + chunk; wv.lds = bk_sort_lds_words(c) words.
+// The counters of more than 4 096 buckets (14-bit windows) are 16-bit halves of LDS words -- a chunk holds 24 576 terms, so neither a
+// count nor a cursor reaches 65 536, and an atomic add of 1 << 16 never carries out of its half: 16 KB of counters instead of 32, two
+// workgroups per CU as at 13 bits (one per CU took 8.6 ms per launch against 5.7)
+MP_HD bool bk_sort_packed(uint32_t c) { return bk_buckets(c) > 4096u; }
+MP_HD uint32_t bk_sort_counter_words(uint32_t c) { return bk_sort_packed(c) ? bk_buckets(c) / 2u + 2u : bk_buckets(c) + 2u; }
+static inline uint32_t bk_sort_lds_words(uint32_t c) { return bk_sort_counter_words(c) + BK_CHUNK / 2u; }
 template <class C, class W>
 MP_HD void body_bucket_sort(const BSplitArgs& a, uint32_t x, W& wv) {
   constexpr uint32_t NL = W::NL;
-  const uint32_t NBK = bk_buckets(a.bits), ROW = bk_offs_row(a.bits);
+  const uint32_t NBK = bk_buckets(a.bits), ROW = bk_offs_row(a.bits), CW = bk_sort_counter_words(a.bits);
+  const bool packed = bk_sort_packed(a.bits);
   const uint32_t it = x / a.gmax, g = x % a.gmax;
   const BItem id = bk_item(a, it);
   const BJob job = a.jobs[id.jb];
@@ -620,12 +630,19 @@ MP_HD void body_bucket_sort(const BSplitArgs& a, uint32_t x, W& wv) {
   const uint32_t K = job.count, t0 = g * BK_CHUNK, t1 = job.kpad < t0 + BK_CHUNK ? job.kpad : t0 + BK_CHUNK;      // the chunk's terms [t0, t1) of the padded row
   const uint32_t q0 = t0 / 8, nq = (t1 - t0) / 8;
   const Quad32* src = reinterpret_cast<const Quad32*>(a.D16 + (size_t)id.b * a.dstride + job.dig_off + (size_t)id.w * job.kpad) + q0;
-  uint32_t* cnt = wv.lds;                          // [0 .. NBK + 1]: terms per |digit|, then the scatter cursors
-  uint16_t* buf = reinterpret_cast<uint16_t*>(wv.lds + NBK + 2u);      // the chunk's sorted run: index of the term inside the chunk, sign in bit 15
+  uint32_t* cnt = wv.lds;                          // terms per |digit| (bucket k: word k, or half (k - 1) & 1 of word (k - 1) / 2), then the scatter cursors; the last word: the chunk's total
+  uint16_t* buf = reinterpret_cast<uint16_t*>(wv.lds + CW);      // the chunk's sorted run: index of the term inside the chunk, sign in bit 15
   uint16_t* og = a.offs + ((size_t)it * a.gmax + g) * ROW;
   uint32_t* ix = a.sorted + (size_t)it * a.kpad_max + t0;
+  // one more term in bucket k: its position (scatter pass) or nothing of interest (histogram pass)
+  auto bump = [&](uint32_t k) -> uint32_t {
+    if (!packed) return wv.atomic_add(&cnt[k], 1u);
+    const uint32_t sh = ((k - 1u) & 1u) << 4;
+    return (wv.atomic_add(&cnt[(k - 1u) >> 1], 1u << sh) >> sh) & 0xFFFFu;
+  };
+  auto get = [&](uint32_t k) -> uint32_t { return packed ? (cnt[(k - 1u) >> 1] >> (((k - 1u) & 1u) << 4)) & 0xFFFFu : cnt[k]; };
   wv.lanes([&](uint32_t lane) {
-    for (uint32_t i = lane; i < NBK + 2u; i += NL) cnt[i] = 0;
+    for (uint32_t i = lane; i < CW; i += NL) cnt[i] = 0;
   });
   wv.sync();
   wv.lanes([&](uint32_t lane) {
@@ -636,18 +653,19 @@ MP_HD void body_bucket_sort(const BSplitArgs& a, uint32_t x, W& wv) {
 #pragma unroll
       for (uint32_t q = 0; q < 8; ++q) {
         const int d = t0 + 8 * i + q < K ? (int16_t)(eight.v[q >> 1] >> (16 * (q & 1))) : 0;
-        if (d != 0) wv.atomic_add(&cnt[d < 0 ? -d : d], 1u);
+        if (d != 0) bump((uint32_t)(d < 0 ? -d : d));
       }
     }
   });
   wv.sync();
-  // offsets: lane l owns the buckets [lo, hi) of 1 .. NBK (a share of NBK / NL, or none when there are fewer buckets than lanes)
+  // offsets: lane l owns the buckets [lo, hi) of 1 .. NBK (a share of NBK / NL -- whole words of packed counters: NBK / NL = 32 --, or
+  // none when there are fewer buckets than lanes)
   typename W::template PL<uint32_t> tot, big;
   wv.lanes([&](uint32_t lane) {
     const uint32_t lo = 1u + (uint32_t)(((uint64_t)NBK * lane) / NL), hi = 1u + (uint32_t)(((uint64_t)NBK * (lane + 1)) / NL);
     uint32_t t = 0, m = 0;
     for (uint32_t k = lo; k < hi; ++k) {
-      const uint32_t c = cnt[k];
+      const uint32_t c = get(k);
       t += c;
       m = c > m ? c : m;
     }
@@ -659,16 +677,26 @@ MP_HD void body_bucket_sort(const BSplitArgs& a, uint32_t x, W& wv) {
   wv.lanes([&](uint32_t lane) {
     const uint32_t lo = 1u + (uint32_t)(((uint64_t)NBK * lane) / NL), hi = 1u + (uint32_t)(((uint64_t)NBK * (lane + 1)) / NL);
     uint32_t o = tot[lane];
-    for (uint32_t k = lo; k < hi; ++k) {
-      const uint32_t c = cnt[k];
-      cnt[k] = o;
-      og[k] = (uint16_t)o;
-      o += c;
+    if (packed) {
+      for (uint32_t k = lo; k < hi; k += 2) {      // (lo - 1 is even and the share is even: the lane's own words)
+        const uint32_t w = cnt[(k - 1u) >> 1], c0 = w & 0xFFFFu, c1 = w >> 16;
+        og[k] = (uint16_t)o;
+        og[k + 1] = (uint16_t)(o + c0);
+        cnt[(k - 1u) >> 1] = o | ((o + c0) << 16);
+        o += c0 + c1;
+      }
+    } else {
+      for (uint32_t k = lo; k < hi; ++k) {
+        const uint32_t c = cnt[k];
+        cnt[k] = o;
+        og[k] = (uint16_t)o;
+        o += c;
+      }
     }
     if (lane == NL - 1) {
       og[0] = (uint16_t)maxc;
       og[NBK + 1] = (uint16_t)o;                   // the chunk's terms with a non-zero digit
-      cnt[NBK + 1] = o;
+      cnt[CW - 1] = o;
     }
   });
   wv.sync();
@@ -681,14 +709,14 @@ MP_HD void body_bucket_sort(const BSplitArgs& a, uint32_t x, W& wv) {
       for (uint32_t q = 0; q < 8; ++q) {
         const int d = t0 + 8 * i + q < K ? (int16_t)(eight.v[q >> 1] >> (16 * (q & 1))) : 0;
         if (d != 0) {
-          const uint32_t at = wv.atomic_add(&cnt[d < 0 ? -d : d], 1u);
+          const uint32_t at = bump((uint32_t)(d < 0 ? -d : d));
           buf[at] = (uint16_t)((8 * i + q) | (d < 0 ? 0x8000u : 0u));
         }
       }
     }
   });
   wv.sync();
-  const uint32_t Tg = cnt[NBK + 1];
+  const uint32_t Tg = cnt[CW - 1];
   wv.lanes([&](uint32_t lane) {                    // the run leaves in whole lines, as point references (the terms' table stays in the L2;
     const Term* terms = a.bterms + job.begin + t0; // eight lookups in flight per lane: one at a time the loop waited 2 us per entry)
     for (uint32_t i = lane; i < Tg; i += 8 * NL) {
@@ -712,6 +740,8 @@ static inline uint32_t bk_acc_lds_words(uint32_t c, uint32_t gmax, uint32_t xw, 
   // (list mode needs none of the tables: its 64 XYZZ slots lie over them)
   return std::max(gmax * (nbp + 2u) / 2u + nbp + nbp + 64u * pw, 64u * xw);
 }
+// (bucket mode and list mode are two kernels: the full additions of the list walk would otherwise set the register budget of the hot loop
+// -- 92 spilled registers on the 14-limb field of BLS12-377; every wave of the launch that finds its item in the other mode leaves at once)
 template <class C, class W>
 MP_HD void body_bucket_acc(const BSplitArgs& a, uint32_t wave, W& wv) {
   constexpr uint32_t XW = XyzzWords<C>::N;
@@ -735,8 +765,9 @@ MP_HD void body_bucket_acc(const BSplitArgs& a, uint32_t wave, W& wv) {
     if (tile) return tile + (size_t)(e & BK_TILE_MASK) * Geo<C>::PW;
     return a.P + p_off<C>(e & BK_SLOT_MASK, a.Bpad, b + ((e >> 20) & BK_LINK_MASK) * a.link_stride);
   };
+  if (list) return;                                // (k_bucket_list)
   typename W::template PL<Xyzz<C>> run;
-  if (!list) {
+  {
     // ---- bucket mode: the buckets base .. base + NBP - 1, NB per lane
     const uint32_t base = 1u + p * NBP;
     wv.lanes([&](uint32_t lane) {
@@ -843,6 +874,33 @@ MP_HD void body_bucket_acc(const BSplitArgs& a, uint32_t wave, W& wv) {
     });
     return;
   }
+}
+MP_WAVE_KERNEL_OCC(k_bucket_acc, BSplitArgs, body_bucket_acc, 2)
+template <class C, class W>
+MP_HD void body_bucket_list(const BSplitArgs& a, uint32_t wave, W& wv) {
+  constexpr uint32_t XW = XyzzWords<C>::N;
+  const uint32_t NBK = bk_buckets(a.bits), ROW = bk_offs_row(a.bits), NB = bk_unit_nb(a.bits), NBP = 64u * NB, OR = NBP + 2u;
+  const uint32_t unit = bk_unit_of_wave(a, wave, a.neq * a.njobs * a.nwin * a.units);
+  if (unit == 0xFFFFFFFFu) return;
+  const uint32_t it = unit / a.units, p = unit % a.units;
+  const BItem id = bk_item(a, it);
+  const uint32_t b = id.b;
+  const uint32_t G = bk_chunks(a.jobs[id.jb].kpad);
+  const uint16_t* og = a.offs + (size_t)it * a.gmax * ROW;
+  const uint32_t* ix = a.sorted + (size_t)it * a.kpad_max;
+  uint32_t* park = a.park + (size_t)it * NBK * XW;
+  uint16_t* o16 = reinterpret_cast<uint16_t*>(wv.lds);      // [G][OR]: o16[g][i] = first position of the unit's bucket i inside run g, i = 0 .. NBP
+  uint32_t* tot = wv.lds + a.gmax * OR / 2u;                // [NBP]: terms per bucket (all runs)
+  uint32_t* cur = tot + NBP;                                // [NB][64]: worker lane -> home lane of its bucket of class j
+  uint32_t* xch = cur + NBP;                                // the staged point (bucket mode)
+  const bool list = bk_list_mode(a, it, G);
+  const uint32_t* const tile = a.tile ? a.tile + (size_t)b * a.tile_K * Geo<C>::PW : nullptr;
+  auto point_of = [&](uint32_t e) -> const uint32_t* {
+    if (tile) return tile + (size_t)(e & BK_TILE_MASK) * Geo<C>::PW;
+    return a.P + p_off<C>(e & BK_SLOT_MASK, a.Bpad, b + ((e >> 20) & BK_LINK_MASK) * a.link_stride);
+  };
+  if (!list) return;                               // (k_bucket_acc)
+  typename W::template PL<Xyzz<C>> run;
   // ---- list mode: the runs p, p + P, ... of the item, each in 64 equal shares walked from the top; whenever a lane crosses into the
   // next lower bucket it adds the running sum to acc (kept in LDS), so that  sum_t d_t P_t over the share = lo * run + acc.  The entry
   // of term i + 2 and the point of term i + 1 are requested while term i is added
@@ -924,31 +982,44 @@ MP_HD void body_bucket_acc(const BSplitArgs& a, uint32_t wave, W& wv) {
     if (lane == 0) xyzz_to_words<C>(acc[lane], park + (size_t)p * XW);
   });
 }
-MP_WAVE_KERNEL_OCC(k_bucket_acc, BSplitArgs, body_bucket_acc, 2)
+MP_WAVE_KERNEL_OCC(k_bucket_list, BSplitArgs, body_bucket_list, 2)
 
-// ---- k_bucket_reduce: W = WaveCtx; wv.lds = 64 XW words
+// ---- k_bucket_reduce: W = WaveCtx, FOUR waves per item (x = 4 item + quarter); wv.lds = 64 XW words.
+// sum_k k S_k over the item's 2^(c-1) parked sums.  Each wave takes a QUARTER of the buckets, base + 1 .. base + Q, and computes
+// A = sum_j j S_(base + j)  and  R = sum_j S_(base + j)  exactly as phase F of the wave kernel does with NB = Q / 64 buckets per lane
+// (2 NB - 3 additions, a 6-step suffix scan, log2 NB doublings, a 6-step tree); k_bucket_final then adds up
+//   sum_k k S_k = A_0 + A_1 + A_2 + A_3 + Q (R_1 + 2 R_2 + 3 R_3)
+// -- five additions, log2 Q doublings and four additions on one lane per item.  (Round 6 first ran one wave per item: 128 buckets per
+// lane at 14 bits, 5.5 ms per launch.  The empty buckets hold the point at infinity, so no offsets are read.)
 template <class C, class W>
-MP_HD void body_bucket_reduce(const BSplitArgs& a, uint32_t it, W& wv) {
+MP_HD void body_bucket_reduce(const BSplitArgs& a, uint32_t x, W& wv) {
   constexpr uint32_t XW = XyzzWords<C>::N;
-  const uint32_t NBK = bk_buckets(a.bits), NB = NBK >> 6, LOGNB = a.bits - 7u;
+  const uint32_t NBK = bk_buckets(a.bits), Q = NBK >> 2, NB = Q >> 6;      // (NBK >= 512 on this path: NB >= 2)
+  uint32_t LOGNB = 0;
+  while ((1u << LOGNB) < NB) ++LOGNB;
+  const uint32_t it = x >> 2, quarter = x & 3u;
   const BItem id = bk_item(a, it);
-  const BJob job = a.jobs[id.jb];
-  const uint32_t G = bk_chunks(job.kpad);
+  const uint32_t G = bk_chunks(a.jobs[id.jb].kpad);
   const uint32_t* park = a.park + (size_t)it * NBK * XW;
+  uint32_t* out = a.quarters + ((size_t)it * 4 + quarter) * 2 * XW;
   uint32_t* xch = wv.lds;
   typename W::template PL<Xyzz<C>> run, acc;
-  if (bk_list_mode(a, it, G)) {                    // list mode: the sums of the item's units
-    wv.lanes([&](uint32_t lane) { acc[lane] = lane < a.units ? xyzz_from_words<C>(park + (size_t)lane * XW) : xyzz_inf<C>(); });
+  const bool list = bk_list_mode(a, it, G);
+  if (list) {                                      // list mode: the sums of the item's units, on the first wave
+    wv.lanes([&](uint32_t lane) {
+      acc[lane] = quarter == 0 && lane < a.units ? xyzz_from_words<C>(park + (size_t)lane * XW) : xyzz_inf<C>();
+      run[lane] = xyzz_inf<C>();
+    });
   } else {
     wv.lanes([&](uint32_t lane) {                  // R = sum of the lane's NB buckets, A = sum of the first NB - 1 running sums from the top
-      const uint32_t* mine = park + (size_t)NB * lane * XW;
+      const uint32_t* mine = park + ((size_t)quarter * Q + (size_t)NB * lane) * XW;
       run[lane] = xyzz_from_words<C>(mine + (size_t)(NB - 1) * XW);
       for (int j = (int)NB - 2; j >= 0; --j) {
         if (j == (int)NB - 2) acc[lane] = run[lane]; else xyzz_add_ip<C>(acc[lane], run[lane]);
         xyzz_add_ip<C>(run[lane], xyzz_from_words<C>(mine + (size_t)j * XW));
       }
     });
-    for (uint32_t s = 1; s < 64; s <<= 1) {
+    for (uint32_t s = 1; s < 64; s <<= 1) {        // suffix sums
       wv.lanes([&](uint32_t lane) { xyzz_to_words<C>(run[lane], xch + lane * XW); });
       wv.sync();
       wv.lanes([&](uint32_t lane) {
@@ -956,6 +1027,7 @@ MP_HD void body_bucket_reduce(const BSplitArgs& a, uint32_t it, W& wv) {
       });
       wv.sync();
     }
+    // sum_l (NB l + 1) R_l = Suf_0 + NB sum_(l >= 1) Suf_l; Suf_0 = the quarter's R stays in run[] of lane 0
     wv.lanes([&](uint32_t lane) {
       Xyzz<C> t = run[lane];
       if (lane >= 1)
@@ -963,7 +1035,7 @@ MP_HD void body_bucket_reduce(const BSplitArgs& a, uint32_t it, W& wv) {
       xyzz_add_ip<C>(acc[lane], t);
     });
   }
-  for (uint32_t s = 32; s >= 1; s >>= 1) {
+  for (uint32_t s = 32; s >= 1; s >>= 1) {         // tree reduction
     wv.lanes([&](uint32_t lane) { xyzz_to_words<C>(acc[lane], xch + lane * XW); });
     wv.sync();
     wv.lanes([&](uint32_t lane) {
@@ -972,10 +1044,37 @@ MP_HD void body_bucket_reduce(const BSplitArgs& a, uint32_t it, W& wv) {
     wv.sync();
   }
   wv.lanes([&](uint32_t lane) {
-    if (lane == 0) st_jac<C>(a.J + j_off<C>(job.win_first + id.w, a.Bpad, id.b), xyzz_to_jac<C>(acc[lane]));
+    if (lane == 0) {
+      xyzz_to_words<C>(acc[lane], out);
+      xyzz_to_words<C>(run[lane], out + XW);
+    }
   });
 }
 MP_WAVE_KERNEL_OCC(k_bucket_reduce, BSplitArgs, body_bucket_reduce, 2)
+// x = item: the four quarters -> the window's sum
+template <class C>
+MP_HD void body_bucket_final(const BSplitArgs& a, uint32_t it, uint32_t) {
+  constexpr uint32_t XW = XyzzWords<C>::N;
+  const uint32_t Q = bk_buckets(a.bits) >> 2;
+  uint32_t LOGQ = 0;
+  while ((1u << LOGQ) < Q) ++LOGQ;
+  const BItem id = bk_item(a, it);
+  const BJob job = a.jobs[id.jb];
+  const uint32_t* qs = a.quarters + (size_t)it * 8 * XW;
+  Xyzz<C> tot = xyzz_from_words<C>(qs);
+  Xyzz<C> r3 = xyzz_from_words<C>(qs + 7 * XW), r2 = xyzz_from_words<C>(qs + 5 * XW), r1 = xyzz_from_words<C>(qs + 3 * XW);
+  xyzz_add_ip<C>(r2, r3);                          // R_2 + R_3
+  xyzz_add_ip<C>(r1, r2);                          // R_1 + R_2 + R_3
+  xyzz_add_ip<C>(r1, r2);
+  xyzz_add_ip<C>(r1, r3);                          // R_1 + 2 R_2 + 3 R_3  (list mode: every R is the point at infinity)
+#pragma unroll 1
+  for (uint32_t q = 0; q < LOGQ; ++q) xyzz_dbl_ip<C>(r1);
+  xyzz_add_ip<C>(tot, r1);
+#pragma unroll 1
+  for (uint32_t q = 1; q < 4; ++q) xyzz_add_ip<C>(tot, xyzz_from_words<C>(qs + 2 * q * XW));
+  st_jac<C>(a.J + j_off<C>(job.win_first + id.w, a.Bpad, id.b), xyzz_to_jac<C>(tot));
+}
+MP_KERNEL_OCC(k_bucket_final, BSplitArgs, body_bucket_final, Geo<C>::OCC4)
 
 // ---- fold the window results: R = sum_w 2^(c w) R_w (x = proof, y = bucket job)
 // The same kernel folds the range sums of window-split Straus jobs (layout.hpp vsplit_lo; vb_nwin != 0): job.count parts, part w
@@ -1015,7 +1114,9 @@ MP_KERNEL_OCC(k_bucket_fold, BFoldArgs, body_bucket_fold, Geo<C>::OCC4)
   MP_WAVE_KERNEL_INST(X, k_bucket_msm, BucketArgs, C)    \
   MP_WAVE_KERNEL_INST(X, k_bucket_sort, BSplitArgs, C)   \
   MP_WAVE_KERNEL_INST(X, k_bucket_acc, BSplitArgs, C)    \
+  MP_WAVE_KERNEL_INST(X, k_bucket_list, BSplitArgs, C)   \
   MP_WAVE_KERNEL_INST(X, k_bucket_reduce, BSplitArgs, C) \
+  MP_KERNEL_INST(X, k_bucket_final, BSplitArgs, C)       \
   MP_KERNEL_INST(X, k_bucket_fold, BFoldArgs, C)         \
   MP_WAVE_KERNEL_INST(X, k_var_msm_q, VarQuadArgs, C)    \
   MP_WAVE_KERNEL_INST(X, k_bucket_fold_q, BFoldQuadArgs, C) \

@@ -521,7 +521,7 @@ def test_bucket_msm_edge_scalars_under_emulation(emu, coracle):
     base = bytes(pts)
     # (... 12 and 13 bits on the split pipeline with three sorted runs per bucket: 24 576 terms per run; the last scalars all equal --
     # they do not make the window crowded, the 13-bit top window of a 252-bit scalar is: both modes in one MSM)
-    for big, bits in ((6100, 0), (12100, 0), (60000, 12), (52000, 13)):
+    for big, bits in ((6100, 0), (12100, 0), (60000, 12), (52000, 13), (52000, 14)):
         t.set_bucket_bits(bits)
         scs = [random.randrange(q) for _ in range(big)]
         if bits:
@@ -679,7 +679,7 @@ def test_emulated_group_verification(emu, coracle, cv, keyed):
     want = {k: verify(args[0], d, p) for k, (d, p) in cases.items()}
     assert want["good"] == [0] * B and want["badproof"][4] > 0 and want["badpoint"][1] < 0 and all(v > 0 for v in want["rotated"])
     # (the group equation through 8-, 10-, 9- and 11-bit windows on the wave kernel, 12- and 13-bit ones on the split pipeline (k_bucket_sort / _acc / _reduce): mp_set_bucket_bits)
-    for links, bits in ((3, 0), (2, 10), (6, 9), (3, 11), (3, 12), (6, 13)):
+    for links, bits in ((3, 0), (2, 10), (6, 9), (3, 11), (3, 12), (6, 13), (3, 14)):
         t.set_bucket_bits(bits)
         t.set_group_verify(links * (4 * m * n + 11 * m + 8 + (1 if keyed else 0)), 0)
         eng.profile_enable(True)

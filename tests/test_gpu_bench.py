@@ -25,6 +25,16 @@ def run_bench(*args, env=None):
     return json.loads(lines[0])
 
 
+def _telemetry_keys(c, world):
+    """round 6: every rank reports its shader clock and board power over the timed region, its table build and the
+    host time its calls took -- what explains a scaling shortfall first"""
+    for k in ("per_rank_sclk_mhz", "per_rank_power_w", "per_rank_telemetry_samples", "per_rank_table_build_s", "per_rank_host_enqueue_ms_per_step"):
+        assert len(c[k]) == world, k
+    assert all(v > 0 for v in c["per_rank_table_build_s"]) and all(v > 0 for v in c["per_rank_host_enqueue_ms_per_step"])
+    for f, p_, n_ in zip(c["per_rank_sclk_mhz"], c["per_rank_power_w"], c["per_rank_telemetry_samples"]):
+        assert (f is None or 100 < f < 3000) and (p_ is None or 10 < p_ < 2000) and n_ >= 0
+
+
 COMMON = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--fb-bits", "8", "--digest", "--seed-block", "192"]
 
 
@@ -33,6 +43,7 @@ def test_self_launch_two_ranks_equals_unsharded():
     assert sharded["n_gpus"] == 2
     assert sharded["config"]["per_rank_proofs"] == [192, 192] and sharded["config"]["per_rank_failed"] == [0, 0]
     assert len(sharded["config"]["per_rank_seconds"]) == 2
+    _telemetry_keys(sharded["config"], 2)
     assert abs(sharded["value"] - 384 / (sharded["ms_per_step"] * 1e-3)) < 1e-6 * sharded["value"]
     single = run_bench("--gpus", "1", "--batch", "384", *COMMON)
     assert single["n_gpus"] == 1
@@ -131,6 +142,7 @@ def test_eight_ranks_weak_and_strong_equal_unsharded():
         c = d["config"]
         assert d["n_gpus"] == 8 and d["scaling"] == scaling and c["rccl_world"] == 8 and c["collective_backend"] == "gloo"
         assert c["per_rank_proofs"] == [192] * 8 and c["per_rank_failed"] == [0] * 8 and len(c["per_rank_seconds"]) == 8
+        _telemetry_keys(c, 8)
         assert abs(d["value"] - 1536 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
         assert c["rccl_smoke"]["rccl_world"] == 8 and c["parity_vs_oracle"] is True
         flat = [x for per_rank in c["digests"] for x in per_rank]

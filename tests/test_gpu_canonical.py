@@ -168,3 +168,42 @@ def test_malformed_encodings(mp):
                 ac.dec_point(cv, bad)
             with pytest.raises(mp.NativeError):
                 ser.points_deserialize(bad)
+
+
+def test_decks_validated_once_are_not_validated_again(mp, engines):
+    """round 6: mp_deck_validate_dev is the once-per-deck validation -- it refuses a deck with a point outside the
+    prime-order subgroup, as k_subgroup_check inside a verify call does --, and a table told that its decks are validated
+    (mp_set_validated) does not test them again: the same bad deck then reaches the equations (and fails THEM: the statement is wrong),
+    while the proofs' points are still tested.  Honest inputs give 0 in every mode."""
+    import torch
+    cv = po.BLS12_377
+    Q = _small_order_point(cv)
+    g = load_json([p for p in golden_cases() if "bls12_377" in p][0])
+    m, n = g["m"], g["n"]
+    cards = engines("bls12_377")
+    P = mp.Parameters(m, n, bytes.fromhex(g["params"]))
+    t = cards.table(P, bytes.fromhex(g["pk"]))
+    with po.curve_ctx(cv):
+        mixed = po.pt_wire(po.pt_add(cv, Q, po.pt_mul(cv, 12345, cv.G)))
+    good_d, good_s, pf = bytes.fromhex(g["deck"]), bytes.fromhex(g["shuffled"]), bytes.fromhex(g["proof"])
+    bad_s = mixed + good_s[len(mixed):]
+    gpu = torch.device("cuda", 0)
+    dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(gpu)
+    decks = dev(good_s + bad_s + good_s)
+    st = torch.full((3,), 55, dtype=torch.int32, device=gpu)
+    t.deck_validate_dev(3, decks.data_ptr(), st.data_ptr())
+    assert st.cpu().tolist() == [0, -1, 0]
+    assert t.verify_shuffle_batch(good_d * 3, good_s + bad_s + good_s, pf * 3) == [0, -1, 0]
+    t.set_validated(t.VALIDATED_DECKS | t.VALIDATED_SHUFFLED)
+    got = t.verify_shuffle_batch(good_d * 3, good_s + bad_s + good_s, pf * 3)
+    assert got[0] == 0 and got[2] == 0 and got[1] > 0          # not refused as an encoding error any more: an equation fails instead
+    # the proof's points are still tested: an off-subgroup point in the proof is an encoding error
+    pb = cards.engine.point_bytes
+    bad_pf = mixed + pf[pb:]
+    assert t.verify_shuffle_batch(good_d, good_s, bad_pf) == [-1]
+    t.set_validated(t.VALIDATED_DECKS | t.VALIDATED_SHUFFLED | t.VALIDATED_PROOFS)
+    assert t.verify_shuffle_batch(good_d, good_s, bad_pf)[0] > 0
+    t.set_validated(0)
+    assert t.verify_shuffle_batch(good_d, good_s, bad_pf) == [-1]
+    with pytest.raises(mp.NativeError):
+        t.set_validated(8)

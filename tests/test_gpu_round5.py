@@ -80,7 +80,7 @@ def test_chain_fixture_on_the_hip_engine(mp):
 def test_groups_adapt_to_sustained_rejection(mp, coracle):
     """mp_set_group_adapt (default on): 8 192 proofs in 64 groups of 128; with 1 % of the traffic tampered (random positions) 72 % of the
     groups fail, and the table halves its groups from call to call -- 128, 64, 32, 16 -- until fewer than a fifth of them fail; every call
-    rejects exactly the tampered proofs; honest traffic restores the size one step per call; with adaptation off the size stays"""
+    rejects exactly the tampered proofs; honest traffic restores the size (one step per call, two when no group fails at all); with adaptation off the size stays"""
     import torch
     cv, m, n, B = "stark", 2, 26, 8192
     eng = mp._native.Engine(cv, 0)
