@@ -1272,7 +1272,7 @@ struct Table : mp_table {
     DevBuf<uint32_t> decks, shuf, proofs, keys, kidx, idx;
     DevBuf<int32_t> status;
   };
-  SubBatch sub[2][2];                 // [lane][level]
+  SubBatch sub[2][3];                 // [lane][depth of the refinement]
   Workspace rws[2];                   // [lane] arenas of the per-equation passes over sub-batches (sized by the sub-batch, not by the batch)
   DevBuf<uint32_t> gbad[2];           // per-group verdicts of a group / chain pass on the caller's lane, on the verify lane
   uint32_t refine_points = 0;         // points per sub-group equation (mp_set_group_refine; 0 = an eighth of the group equation's)
@@ -1284,13 +1284,15 @@ struct Table : mp_table {
   }
   uint64_t reverified() const override { return n_reverified; }
   // proofs per sub-group for the nsub suspects a screen with groups of l1 proofs left (l1 = 0: no groups above, e.g. a chain)
-  uint32_t subgroup_size(size_t nsub, bool keyed, uint32_t l1) const {
+  // `crowded`: (nearly) every group of the screen above failed -- the rate of bad proofs is beyond what an eighth of such a group could
+  // clear (round 6: 1 % of bad proofs fails every group of 1 024 and three in four of 128): a sixty-fourth instead
+  uint32_t subgroup_size(size_t nsub, bool keyed, uint32_t l1, bool crowded = false) const {
     const uint32_t per = 4 * N + 11 * m + 8 + (keyed ? 1u : 0u);
     if (!group_points || !merged_verify) return 0;
     // (a sub-group equation costs 0.55 us per proof at 32 proofs, 0.73 at 16, 0.85 at 8, 1.1 at 4 -- the per-equation pass 1.2: an eighth
     // of a group of fewer than 64 proofs is not worth an equation of its own; profiles/r05h_rejection_strategies.txt)
     if (!refine_points && l1 && l1 < 64) return 0;
-    const uint32_t pts = refine_points ? refine_points : (l1 ? l1 * per : group_points) / 8;
+    const uint32_t pts = refine_points ? refine_points : (l1 ? l1 * per : group_points) / (crowded && l1 >= 512 ? 64u : 8u);
     const uint32_t want = (uint32_t)std::min<uint64_t>((pts + per / 2) / per, 1023u);
     if (want < 2 || (l1 && want >= l1) || (uint64_t)want * per + n + 5 > BUCKET_TERMS_MAX || nsub < (uint64_t)refine_min * want) return 0;
     return want;
@@ -1321,7 +1323,12 @@ struct Table : mp_table {
   }
   // the proofs idx[] of batch v (ascending) through the finer passes; their status words replace the screen's marks
   // own_arenas: the caller's arenas (ws) are laid out for batch v (verify_dev); a chain call's are not (its lean workspace is cws)
-  void verify_subset(const VArgs& v, std::vector<uint32_t>& idx, int level, bool vlane, uint32_t l1 = 0, bool own_arenas = true) {
+  // depth: how many sub-batches lie above this one (each has gather buffers of its own: sub[lane][depth])
+  void verify_subset(const VArgs& v, std::vector<uint32_t>& idx, int level, bool vlane, uint32_t l1 = 0, bool own_arenas = true, uint32_t depth = 0,
+                     int crowd = -1) {
+    if (depth >= 2) level = 1;
+    // (the suspects are whole groups of l1: if they are nearly the whole batch, nearly every group failed -- judged before any slicing)
+    const bool crowded = crowd >= 0 ? crowd != 0 : (l1 != 0 && idx.size() * 20 >= (size_t)v.B * 19);
     if (idx.empty()) return;
     const bool keyed = v.keys != nullptr || v.kset != nullptr;
     rt::Stream s = ctx->stream;
@@ -1332,11 +1339,11 @@ struct Table : mp_table {
     if (!(level == 1 && idx.size() == v.B && (vlane || own_arenas)) && idx.size() > sub_max) {
       for (size_t o = 0; o < idx.size(); o += sub_max) {
         std::vector<uint32_t> part(idx.begin() + o, idx.begin() + std::min(idx.size(), o + sub_max));
-        verify_subset(v, part, level, vlane, l1, own_arenas);
+        verify_subset(v, part, level, vlane, l1, own_arenas, depth, crowded ? 1 : 0);
       }
       return;
     }
-    const uint32_t L2 = level == 0 ? subgroup_size(idx.size(), keyed, l1) : 0u;
+    const uint32_t L2 = level == 0 ? subgroup_size(idx.size(), keyed, l1, crowded) : 0u;
     if (!L2) level = 1;
     // The equations of a sub-batch run on arenas of their OWN (rws), in slices of at most 32 768 52-card proofs: the work split follows
     // the size of the sub-batch (128 suspects take the finest split), and a split with more table / digit slots per proof than the
@@ -1369,7 +1376,7 @@ struct Table : mp_table {
     if (L2)
       while (idx.size() % L2) idx.push_back(idx[0]);      // (a suspect twice: the same verdict written twice)
     const uint32_t nsub = (uint32_t)idx.size();
-    SubBatch& sb = sub[vlane ? 1 : 0][level];
+    SubBatch& sb = sub[vlane ? 1 : 0][depth];
     sb.idx.upload(idx, s);
     gather_rows(v.decks, sb.decks, sb.idx.p, nsub, (size_t)2 * N * G_::PB);
     gather_rows(v.shuf, sb.shuf, sb.idx.p, nsub, (size_t)2 * N * G_::PB);
@@ -1389,7 +1396,9 @@ struct Table : mp_table {
         std::vector<uint32_t> bad, idx2;
         read_words(gb.p, T2, bad);
         group_members(bad.data(), T2, L2, idx2);
-        verify_subset(sv, idx2, 1, vlane);
+        // (the members of the failing sub-groups: through sub-groups an eighth the size once more if there are enough of them -- 1 024 ->
+        // 128 -> 16 --, else equation by equation)
+        verify_subset(sv, idx2, L2 >= 64 ? 0 : 1, vlane, L2, true, depth + 1);
         for (uint32_t i2 : idx2)                          // (mp_reverified_count counts proofs, not the copies that fill the last sub-group)
           if (i2 >= distinct) n_reverified -= 1;
       }
@@ -1568,7 +1577,7 @@ struct Table : mp_table {
       want = std::min<uint32_t>((group_points + per / 2) / per, T / eq_min);
       // (round 6, as group_size: equations for the split pipeline if at least min_batch / 48 of them, of at least 50 000 points, are left
       // -- 64 tables x 4 392 points for 32 links of a 52-card deck)
-      const uint32_t want_wg = std::min<uint32_t>((group_points_wg + per / 2) / per, T / std::max<uint32_t>(1u, group_min_batch / 48u));
+      const uint32_t want_wg = std::min<uint32_t>((group_points_wg + per / 2) / per, T / std::max<uint32_t>(1u, group_min_batch / 512u));
       if (group_points_wg && (uint64_t)want_wg * per >= GROUP_WG_POINTS_MIN) want = std::max(want, want_wg);
     }
     if (want < 2) return 1;
@@ -1754,12 +1763,9 @@ struct Table : mp_table {
   // (BLS12-377: the bucket kernel's additions over a 377-bit field spill ~200 registers at two waves per SIMD and only draw level with the
   // Straus screen -- 13.1 k against 13.1 k proofs/s at (10,30) --, so groups are off there unless mp_set_group_verify asks for them)
   // Round 6: two sizes.  group_points (30 464: 128 proofs of a 52-card deck, 10-bit windows on one wave per window, 26 additions per
-  // point) is what a batch of fewer than 32 768 proofs takes under the rule below; a batch that leaves at least min_batch / 48 (128)
-  // equations of at least GROUP_WG_POINTS_MIN points takes equations of up to group_points_wg points (243 712: 1 024 proofs of a 52-card
-  // deck) instead -- 12- and 13-bit windows on the split pipeline (kernels_bucket.hpp k_bucket_sort / _acc / _reduce: 22 and 20
-  // additions per point; its units are a sixteenth of a window, so 128 equations keep the chip busy).  Whole steps on one box
-  // (profiles/r06i_batches.txt): 262 144 proofs 663 -> 694 k/s (1 024 per equation), 131 072: 644 -> 673 k (512 or 1 024), 65 536:
-  // 610 -> 638 k (256 or 512), 32 768: 550 -> 566 k (256).
+  // point) is what a batch of fewer than 16 384 proofs takes under the rule below; a larger one takes equations of up to group_points_wg
+  // points (243 712: 1 024 proofs of a 52-card deck) instead -- 14-bit windows on the split pipeline (kernels_bucket.hpp k_bucket_sort /
+  // _acc / _reduce: 18 additions per point; 12-bit ones, 21, from 50 000 points on).
   // BLS12-377: the one-wave-per-window kernel spills 200 registers on the 14-limb field and only drew level with the Straus screen
   // (round 4), so group_points stays 0 there; the split pipeline's hot loop is spill-free (213 registers, no scratch), takes 11-bit
   // windows too on this curve (mp_set_bucket_split 11) and equations from 40 000 points on: 32 proofs of a 300-card deck at 4 096 in
@@ -1786,9 +1792,13 @@ struct Table : mp_table {
     // waves busy
     const uint32_t groups_min = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)group_min_batch * 2u) / 13u));
     uint32_t want = std::min<uint32_t>((group_points + per / 2) / per, B / groups_min);
-    // (large batches: the split pipeline's equations, if at least min_batch / 48 of at least GROUP_WG_POINTS_MIN points are left)
-    const uint32_t want_wg = std::min<uint32_t>((group_points_wg + per / 2) / per, B / std::max<uint32_t>(1u, group_min_batch / 48u));
-    if (group_points_wg && (uint64_t)want_wg * per >= GROUP_WG_POINTS_MIN) want = std::max(want, want_wg);
+    // (batches of 8/3 min_batch -- 16 384 -- 52-card proofs and more: the split pipeline's equations, if at least min_batch / 512 (12)
+    // of at least GROUP_WG_POINTS_MIN points are left.  Its units are a thirty-second of a window, so sixteen equations of 1 024 proofs
+    // keep the chip busy: 482 -> 504 k proofs/s at 16 384 in flight, 550 -> 586 k at 32 768, 610 -> 661 k at 65 536, 644 -> 702 k at
+    // 131 072 (profiles/r06v_mid_batches.txt); below that the equations of rounds 4-5 or the per-proof screen are as fast or faster)
+    const uint32_t want_wg = std::min<uint32_t>((group_points_wg + per / 2) / per, B / std::max<uint32_t>(1u, group_min_batch / 512u));
+    if (group_points_wg && (uint64_t)want_wg * per >= GROUP_WG_POINTS_MIN && (uint64_t)B * N * 3u >= (uint64_t)group_min_batch * 52u * 8u)
+      want = std::max(want, want_wg);
     // (under sustained rejection the groups shrink: note_group_verdicts below)
     if (want >= 4) want = std::max<uint32_t>(want >> adapt_shift, 4u);
     if (want < 2) return 0;

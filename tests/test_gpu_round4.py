@@ -399,7 +399,7 @@ def test_group_verification_at_full_size(mp, coracle):
     eng = mp._native.Engine(cv, 0)
     g0 = coracle.gen_inputs(cv, m, n, 5900)
     t = eng.table(m, n, g0["params"], g0["pk"], fb_bits=16)
-    assert t.group_size(B) == 8 and t.group_size(16384) == 16 and t.group_size(65536) == 512 and t.group_size(262144) == 1024      # (no fewer than 945 groups of the rounds 4-5 kind; round 6: the split pipeline's equations from 32 768 proofs on)
+    assert t.group_size(B) == 8 and t.group_size(16384) == 1024 and t.group_size(65536) == 1024 and t.group_size(262144) == 1024      # (no fewer than 945 groups of the rounds 4-5 kind; round 6: the split pipeline's equations from 16 384 proofs on)
     gpu = torch.device("cuda", 0)
     gen = torch.Generator(device=gpu)
     gen.manual_seed(5)

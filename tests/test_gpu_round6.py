@@ -33,12 +33,12 @@ def _batch(mp, coracle, torch, cv, m, n, B, seed, fb_bits=16):
 
 
 def test_default_group_sizes(mp, coracle):
-    """what the screen of a batch takes by default (round 6): the split pipeline's equations from 32 768 52-card proofs on"""
+    """what the screen of a batch takes by default (round 6): the split pipeline's equations from 16 384 52-card proofs on"""
     cv, m, n = "stark", 2, 26
     eng = mp._native.Engine(cv, 0)
     g0 = coracle.gen_inputs(cv, m, n, 6001)
     t = eng.table(m, n, g0["params"], g0["pk"], fb_bits=8)
-    assert [t.group_size(B) for B in (4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288)] == [0, 8, 16, 256, 512, 1024, 1024, 1024]
+    assert [t.group_size(B) for B in (4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288)] == [0, 8, 1024, 1024, 1024, 1024, 1024, 1024]
     t.set_group_verify(30464, 6144)                        # rounds 4-5: at most 128 proofs per equation
     assert [t.group_size(B) for B in (16384, 65536, 262144)] == [16, 64, 128]
     t.close()
