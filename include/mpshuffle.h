@@ -222,17 +222,21 @@ int mp_set_plan_thresholds(mp_table* t, size_t finest, size_t small, size_t late
  * equation by equation, so that the FIRST failing check is reported by name exactly as the reference does [REF tests.rs:223-225].
  * off: always evaluate the equations one by one.  Results (status words) are identical in both modes. */
 int mp_set_merged_verify(mp_table* t, int on);
-/* Group verification (round 4; on by default except on BLS12-377, where it only draws level).  The screening pass of a batch of at least `min_batch` x 52 / N proofs (default 6 144 for
- * 52-card decks) adds the merged equations of a GROUP of proofs with weights derived from every proof of the group and evaluates the sum
- * on the bucket-method kernel (counting sort by wavefront prefix sum, balanced bucket shares, wave-wide bucket reduction): 26 to 33
- * additions per point instead of 51 plus window tables and doubling chains, and the fixed bases once per group (52-card decks:
- * 521 k -> 660 k proofs/s at 262 144 in flight).  `points_per_group` (default 30 464) is the size of a group's equation aimed at: a proof
- * brings 4N + 11m + 8 points, so 128 proofs of a 52-card deck, 8 of a 1 024-card one -- but a batch takes no fewer than 2/13 `min_batch`
- * groups (945: a dozen windows for each of the kernel's 2 048 persistent waves), i.e. 16 proofs per group at 16 384 in flight.  The group
- * size is the divisor of the batch size nearest to that (between half and twice it; a batch without one keeps the per-proof screen).  A
- * group whose equation fails is looked at more closely -- ITS members only (below): status words are identical to every other strategy.
- * points_per_group = 0 switches it off.  Needs merged verification on.  mp_group_size: the group size a batch of B proofs takes under the
- * table's own key (0: per-proof screen). */
+/* Group verification (round 4; on by default).  The screening pass of a batch of at least `min_batch` x 52 / N proofs (default 6 144 for
+ * 52-card decks) adds the merged equations of a GROUP of proofs with weights derived from every proof of the group and evaluates the
+ * sum as ONE multi-scalar multiplication by the bucket method: 18 to 32 additions per point instead of 51 plus window tables and
+ * doubling chains, and the fixed bases once per group.  Round 6: from 8/3 `min_batch` (16 384) proofs on, the equations hold up to
+ * `points_per_group` points (default 243 712: a proof brings 4N + 11m + 8, so 1 024 proofs of a 52-card deck, 64 of a 1 024-card one)
+ * and run on the split pipeline (mp_set_bucket_split: 14-bit windows, 18 additions per point) as long as min_batch / 512 (12)
+ * equations of at least 50 000 points are left; smaller batches take the rule of rounds 4-5 -- at most 30 464 points (128 proofs) and no
+ * fewer than 2/13 `min_batch` (945) groups: 8 proofs per group at 8 192 in flight, one wave per window.  points_per_group <= 65 535
+ * asks for that rule at every batch size (30 464 = the default of rounds 4-5).  The group size is the divisor of the batch size nearest
+ * to the target (between half and twice it; a batch without one keeps the per-proof screen).  BLS12-377: the split pipeline only (its
+ * hot loop is spill-free on the 14-limb field; equations from 40 000 points on, 11-bit windows included).  A group whose equation
+ * fails is looked at more closely -- ITS members only (below): status words are identical to every other strategy.  points_per_group
+ * = 0 switches it off.  Needs merged verification on.  mp_group_size: the group size a batch of B proofs takes under the table's own
+ * key (0: per-proof screen).  (52-card decks at 262 144 in flight: 524 k proofs/s without groups, 672 k with the groups of round 5,
+ * 717 k with those of round 6 on the same kind of box.) */
 int mp_set_group_verify(mp_table* t, uint32_t points_per_group, size_t min_batch);
 uint32_t mp_group_size(const mp_table* t, size_t B);
 /* What a rejected proof costs (round 5).  A screen that fails -- the merged equation of one proof, the equation of a group of proofs,
@@ -240,15 +244,20 @@ uint32_t mp_group_size(const mp_table* t, size_t B);
  * sub-batch on the device, the sub-batch takes the next finer pass and its status words are written back over the screen's marks.
  * Everybody else's verdict stands, as in the reference, where one call verifies one proof [REF src/discrete_log_cards/mod.rs:420-443].
  * The members of failing groups go through equations of sub-groups of `points_per_subgroup` points (0 = default: an eighth of the group
- * equation's -- 16 proofs of a 52-card deck) when there are at least `min_subgroups` of them (0 = default 128: enough to fill the bucket
- * kernel), otherwise -- and the members of failing sub-groups always -- through the per-equation pass that names the first failing
- * check.  mp_reverified_count: proofs that have taken a per-equation pass on this table because a screen could not clear them. */
+ * equation's -- 128 proofs of a 52-card deck under an equation of 1 024, and an eighth of THAT, 16, for the members of failing
+ * sub-groups; a sixty-fourth at once when nearly every group of the call failed) when there are at least `min_subgroups` of them (0 =
+ * default 128: enough to fill the bucket kernel), otherwise -- and after two such levels always -- through the per-equation pass that
+ * names the first failing check.  One tampered proof among 262 144 sends the 1 024 members of its equation through that pass: +2.7 ms
+ * on a 90 ms verify call.  The suspects are gathered and looked at in slices of at most 131 072 52-card proofs (bounded memory whatever
+ * their number), and until a suspect has its own word its status reads MP_ERR_INTERNAL, never 0.  mp_reverified_count: proofs that
+ * have taken a per-equation pass on this table because a screen could not clear them. */
 int mp_set_group_refine(mp_table* t, uint32_t points_per_subgroup, uint32_t min_subgroups);
 uint64_t mp_reverified_count(const mp_table* t);
 /* Groups that adapt to the rejection rate (default on).  A group fails if any member does, so with a fraction p of bad proofs in the traffic
  * 1 - (1 - p)^L of the groups of L fail (72 % of the groups of 128 at p = 1 %) and their members pay a finer pass on top of a screen that
  * cleared nobody.  The table remembers the last screens: when more than a fifth of a call's groups fail the next call takes groups of half
- * the size (down to 8), when fewer than 4 % fail the size goes back up, one step per call (calls with at least 64 groups count).  Honest
+ * the size (down to 8; by three halvings at once when nineteen groups in twenty fail), when fewer than 4 % fail the size goes back up,
+ * one step per call, two when no group failed (calls with at least 8 groups count, a step down needs four failing groups).  Honest
  * traffic never leaves the default size; verdicts do not depend on it.  on = 0 pins the default (and resets the memory); mp_group_size
  * reports the size the NEXT call of B proofs takes. */
 int mp_set_group_adapt(mp_table* t, int on);
@@ -257,10 +266,10 @@ int mp_set_group_adapt(mp_table* t, int on);
  * smaller ones on the Straus kernel with per-proof window tables; 0 = never.  Results are identical; the split is a property of
  * the table's static plans, which this call rebuilds. */
 int mp_set_bucket_min(mp_table* t, size_t terms);
-/* Window width of the bucket method: 8 to 13 bits (128 to 4 096 buckets per window; 32, 29, 26, 23, 22 or 20 windows per 252-bit
- * scalar), or 0 (default) = by the size of the MSM (8 bits below 6 000 terms, 9 below 12 000, 10 below 40 000, 11 below 100 000, 12
- * below 200 000, 13 from there on -- the equation of a group of 1 024 52-card proofs, mp_set_group_verify).  Results are identical;
- * rebuilds the static plans like mp_set_bucket_min. */
+/* Window width of the bucket method: 8 to 14 bits (128 to 8 192 buckets per window; 32, 28, 26, 23, 21, 20 or 18 windows per 252-bit
+ * scalar -- the smaller of k and q - k is recoded, signs flipped: ceil(bits / c) windows), or 0 (default) = by the size of the MSM (8
+ * bits below 6 000 terms, 9 below 12 000, 10 below 40 000, 11 below 50 000, 12 below 200 000, 14 from there on -- the equation of a
+ * group of 1 024 52-card proofs, mp_set_group_verify).  Results are identical; rebuilds the static plans like mp_set_bucket_min. */
 int mp_set_bucket_bits(mp_table* t, uint32_t bits);
 /* Round 6: inputs the caller has validated ONCE are not validated again in every call that touches them.  The reference's trait takes
  * typed arkworks points, validated when they were deserialised [REF examples/parameter_selection.rs:78-91]; this engine takes wire
@@ -276,23 +285,24 @@ int mp_set_validated(mp_table* t, uint32_t what);
 /* `decks` wire-v1 decks of the table's size in DEVICE memory -> one int32 per deck in d_status: 0, or MP_ERR_BAD_ENCODING if a point is
  * not canonical, not on the curve or outside the prime-order subgroup.  The once-per-deck validation that mp_set_validated relies on. */
 int mp_deck_validate_dev(mp_table* t, size_t decks, const void* d_wire_decks, void* d_status);
-/* Round 6.  Bucket jobs whose windows are at least `min_bits` wide (default 12: equations of 100 000 points and more -- the screen of
- * 512 .. 2 048 52-card proofs) run as THREE kernels instead of one wave per (equation, window): k_bucket_sort (a workgroup per 24 576
- * terms: counting sort inside LDS, the sorted run written in whole lines), k_bucket_acc (a wave per range of 256 buckets, four per lane
- * dealt by rank, one mixed addition per term; equal shares of the list instead where a window's digits crowd into a few buckets) and
- * k_bucket_reduce (a workgroup per window, a quarter of the buckets per wave).  10 .. 15 (= none).  Results are identical. */
+/* Round 6.  Bucket jobs whose windows are at least `min_bits` wide (default 12: equations of 50 000 points and more; 11 on BLS12-377)
+ * run as a pipeline of kernels instead of one wave per (equation, window): k_bucket_sort (a workgroup per 24 576 terms: counting sort
+ * inside LDS, the sorted run written in whole lines), k_bucket_acc (a wave per range of 256 buckets, four per lane dealt by rank, one
+ * mixed addition per term; k_bucket_list -- equal shares of the sorted list -- where a window's digits crowd into a few buckets),
+ * k_bucket_reduce (four waves per window, a quarter of the buckets each) and k_bucket_final.  10 .. 15 (= none).  Results are identical. */
 int mp_set_bucket_split(mp_table* t, uint32_t min_bits);
 /* Chain verification (mp_verify_shuffle_chain*): at most `links` links share one chain equation; longer chains are verified as
  * consecutive sub-chains.  0 (default) = as many as fit the 32 767 points of one equation (293 links of a 52-card deck; one link of a deck too large for that gets an equation of up to 65 535 points).  A smaller
  * value bounds the work that is repeated link by link when a chain fails.  Verdicts are the same. */
 int mp_set_chain_max_links(mp_table* t, uint32_t links);
 /* Chain verification of many tables at once: the chain equations of `tables_per_equation` tables are added up (with weights that
- * depend on every proof of every member, as in mp_set_group_verify) into ONE equation -- 6 tables x 4 424 points for 32 links of a
- * 52-card deck: 10-bit windows instead of 8-bit ones, the wave-wide reduction of a window spread over six times the points, the fixed
- * bases once per six tables.  0 (default) = by size: the divisor of `tables` that brings the equation nearest to the group equation's
- * points (mp_set_group_verify; none while fewer than ~1 000 equations would be left); 1 = every table on its own (rounds 2-4); other
- * values = the divisor of `tables` nearest to it.  Tables g (tables / G) + e, g < G, share equation e.  If an equation fails, the
- * links of ITS tables are re-verified one by one: status words are identical in every setting. */
+ * depend on every proof of every member, as in mp_set_group_verify) into ONE equation -- 64 tables x 4 392 points for 32 links of a
+ * 52-card deck (round 6; 8 tables in round 5): 14-bit windows on the split pipeline, the points of an equation copied once into a
+ * contiguous run (k_chain_tile), the fixed bases once per 64 tables.  0 (default) = by size: the divisor of `tables` that brings the
+ * equation nearest to the group equation's points (mp_set_group_verify, under the same rule of how many equations must be left); 1 =
+ * every table on its own (rounds 2-4); other values (up to 4 094, tables x (links + 1) <= 4 094) = the divisor of `tables` nearest to
+ * it, whatever mp_set_group_verify says.  Tables g (tables / G) + e, g < G, share equation e.  If an equation fails, the links of ITS
+ * tables are re-verified one by one: status words are identical in every setting. */
 int mp_set_chain_group(mp_table* t, uint32_t tables_per_equation);
 /* Chain verification in passes of `tables_per_pass` tables.  The workspace of chain verification is ~68 KB per link in flight (52-card
  * decks: 107 GB for 49 152 tables x 32 links), far more than the 13 KB of deck and proof a link occupies, while the prover wants as many

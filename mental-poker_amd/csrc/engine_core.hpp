@@ -1826,7 +1826,10 @@ struct Table : mp_table {
     adapt_shift = 0;
   }
   void note_group_verdicts(uint32_t T, uint32_t failing, uint32_t L) {
-    if (!group_adapt || T < 64) return;
+    // (a fraction of three groups says nothing -- but sixteen equations of 1 024 proofs that ALL fail do: from eight groups on, and a
+    // step down only on the evidence of at least four failing groups)
+    if (!group_adapt || T < 8) return;
+    if (T < 64 && failing > 0 && failing < 4) return;
     // (round 6: the default group is 1 024 proofs -- seven halvings down to 8.  When nineteen groups in twenty fail, the rate is far
     // beyond what the next size could clear: three halvings at once; and a call in which no group fails at all grows back two steps)
     if ((uint64_t)failing * 5 > T) {

@@ -510,37 +510,44 @@ MP_HD void body_bucket_msm(const BucketArgs& a, uint32_t slot, W& wv) {
 MP_WAVE_KERNEL_OCC(k_bucket_msm, BucketArgs, body_bucket_msm, MP_BK_OCC(C))
 
 // ================================================================================================================================
-// Round 6: the SPLIT pipeline -- windows of BK_SPLIT_BITS bits and more (equations of >= 100 000 points: the screen of 512 .. 1 024
-// proofs of a 52-card deck, of 32 .. 64 proofs of a 1 024-card one, the chains of 32 .. 64 tables).
+// Round 6: the SPLIT pipeline -- windows of 12 bits and more (mp_set_bucket_split; equations of >= 50 000 points: the screen of 256 ..
+// 2 048 proofs of a 52-card deck, of 16 .. 128 proofs of a 1 024-card one, the chains of 16 .. 128 tables; 11 bits too on BLS12-377).
 //
 // One wave per (equation, window) caps the kernel above at 11 bits: 2^(c-1) buckets on 64 lanes are 16 per lane and a 42-addition
 // reduction per window at c = 11, which cancels the gain of 23 windows over 26.  Giving the window to a 256-lane workgroup instead
-// (measured first, profiles/r06a_wg_kernel_sweep.txt) executed 22 % fewer instructions and was 10 % faster, not 25 %: an item of
-// 243 712 points is a tenth of what a persistent workgroup does in the launch, so the launch waited 9 % of its time for the last items;
-// the sort of an item ran at two waves per SIMD (the register budget of the additions) and took 11 % of it -- its scatter writes four
-// bytes at a time into a 1 MB row, 512 rows in flight: every store a read-modify-write of a 64-byte line in HBM --; and the ranks by
-// counting cost 256 comparisons per bucket.  So the three phases are three kernels, each with the parallelism and the registers IT
-// wants, the sorted list leaves the chip in whole lines, and the additions are handed out in pieces a twentieth the size:
+// (measured first, profiles/r06a_wg_kernel_sweep.txt, r06b_wg_kernel_phases.txt) executed 22 % fewer instructions and was 10 % faster,
+// not 25 %: an item of 243 712 points is a tenth of what a persistent workgroup does in the launch, so the launch waited 9 % of its time
+// for the last items; the sort of an item ran at two waves per SIMD (the register budget of the additions) and took 11 % of it -- its
+// scatter writes four bytes at a time into a 1 MB row, 512 rows in flight: every store a read-modify-write of a 64-byte line in HBM
+// (20 ms per launch when it first ran as a kernel of its own, r06c) --; and the ranks by counting cost 256 comparisons per bucket.  So
+// the phases are kernels of their own, each with the parallelism and the registers IT wants, the sorted list leaves the chip in whole
+// lines, and the additions are handed out in pieces a thirtieth the size:
 //
 //   k_bucket_sort    one 256-lane workgroup per (item, CHUNK of BK_CHUNK = 24 576 terms), ~32 registers, two workgroups per CU:
 //                    histogram of |d| (LDS atomics), exclusive scan (wavefront prefix sums, the four waves joined through LDS),
-//                    counting sort of the chunk's point references INSIDE LDS, then one contiguous copy to the chunk's run of `sorted`;
-//                    the bucket offsets inside the run go to `offs` as 16-bit words, with the largest bucket of the chunk in front.
-//                    A bucket's terms are then G = ceil(K / 24 576) short runs, one per chunk, instead of one long one;
-//   k_bucket_acc     one WAVE per unit = (item, one of P bucket ranges of 64 x NB2 buckets): the lanes take NB2 = 4 buckets each,
-//                    dealt by rank inside the unit (64 comparisons per bucket), and walk a bucket's G runs one after the other -- one
-//                    mixed addition per term with the next point staged global -> LDS as above, every bucket sum parked in the item's
-//                    row of `park` (the point at infinity for an empty bucket: the reduction reads no offsets).  A unit is ~240
-//                    additions per lane: 81 920 units for the 5 120 items of 262 144 52-card proofs, 40 per wave slot -- the
-//                    hardware's own workgroup dispatcher hands them out, and the launch ends within one unit (0.8 ms) of its average.
-//                    LIST mode, for a window whose digits crowd into a few buckets (the top window of a 252-bit scalar holds 17
-//                    values at c = 13; an MSM whose scalars are all equal): unit g takes chunk g's run in 64 equal shares and
-//                    leaves ONE sum.  An item is in list mode if a chunk's largest bucket exceeds eight times its share (+ 32);
+//                    counting sort of the chunk's terms INSIDE LDS (16-bit indices), then one contiguous copy to the chunk's run of
+//                    `sorted`; the bucket offsets inside the run go to `offs` as 16-bit words, with the largest bucket of the chunk in
+//                    front.  A bucket's terms are then G = ceil(K / 24 576) short runs, one per chunk, instead of one long one
+//                    (5.6 ms per launch for the 4 608 items of 262 144 52-card proofs);
+//   k_bucket_acc     one WAVE per unit = (item, one of P bucket ranges of 64 x 4 buckets): the lanes take four buckets each, dealt by
+//                    rank inside the unit (64 comparisons per bucket), and walk a bucket's G runs one after the other -- one mixed
+//                    addition per term with the next point staged global -> LDS as above, every bucket sum parked in the item's row of
+//                    `park` (the point at infinity for an empty bucket: the reduction reads no offsets).  A unit is ~120 additions per
+//                    lane at 14 bits: 147 456 units for 262 144 proofs, 70 per wave slot -- the hardware's own workgroup dispatcher
+//                    hands them out, XCD r taking the r-th eighth of them (bk_unit_of_wave), and the launch ends within one unit of
+//                    its average (55 ms per launch, 0.9 of the issue slots);
+//   k_bucket_list    the same launch shape for the items in LIST mode -- a window whose digits crowd into a few buckets (the top window
+//                    of a 252-bit scalar holds 9 values at c = 13; an MSM whose scalars are all equal): unit p takes the runs p, p + P,
+//                    ... in 64 equal shares each and leaves ONE sum.  An item is in list mode if a chunk's largest bucket exceeds eight
+//                    times its share (+ 32).  A kernel of its own: the full additions of the list walk would otherwise set the register
+//                    budget of k_bucket_acc's hot loop (92 spilled registers on BLS12-377; none now);
 //   k_bucket_reduce  four waves per item, a quarter of the 2^(c-1) parked sums each: sum_j j S_j and sum_j S_j over the quarter as in F
 //                    above with NB = 2^(c-1) / 256 buckets per lane; k_bucket_final puts the quarters together (or takes the list sums).
 //
-// `sorted`, `offs` and `park` hold every item of a pass at once (1.6 MB per item at c = 13: the engine cuts a call into passes of
-// equations that fit its scratch budget).  Results are canonical group elements: bit-identical to the kernel above.
+// 14-bit windows (the default from 200 000 points on) are 18 for a 252-bit order, all of them full -- no list-mode item in the
+// verifier's screen --, their 8 192 counters per chunk are 16-bit halves of LDS words (bk_sort_packed).  `sorted`, `offs` and `park` hold
+// every item of a pass at once (3 MB per item at c = 14 and 243 712 points: the engine cuts a call into passes of equations that fit its
+// scratch budget).  Results are canonical group elements: bit-identical to the kernel above.
 static const uint32_t BK_SPLIT_BITS = 12;
 #ifndef MP_EXP_BK_CHUNK     // (A/B hook, tools/ab_build.py)
 #define MP_EXP_BK_CHUNK 24576
@@ -581,7 +588,7 @@ struct BSplitArgs {
 // k_bucket_acc: which unit a wave of the launch takes.  Workgroup i of a launch runs on XCD i mod 8 (observed; the hardware deals
 // workgroups round-robin and statically), and consecutive units belong to the same item: dealt as they come, the units of every other
 // window -- and with them all the list-mode windows, which are slower -- met on the same half of the XCDs, and the launch waited for
-// that half (-10 %: profiles/r06g_xcd_placement.txt).  So XCD r gets the r-th EIGHTH of the units, whole equations: an equation's
+// that half (-10 %: profiles/r06g_xcd_placement_pmc.txt, r06h_ab_xcd_remap.txt).  So XCD r gets the r-th EIGHTH of the units, whole equations: an equation's
 // windows share one L2 again (the XCD-affine items of round 5), and every XCD holds the same mix of windows.
 MP_HD uint32_t bk_unit_of_wave(const BSplitArgs& a, uint32_t wave, uint32_t nunits) {
   const uint32_t i = wave / a.wpb, lane_wave = wave % a.wpb, per = (a.wgs + 7u) / 8u;
