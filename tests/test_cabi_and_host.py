@@ -469,6 +469,23 @@ def test_bucket_method_kernel_under_emulation_matches_golden(emu, name):
         if m == 2 and latency_batch == 0 and merged:
             nvar = rep.get("k_var_msm", (0,))[0] + rep.get("k_var_msm_q", (0,))[0]
             assert nvar < rep["k_bucket_msm"][0] + 3
+    if name == "shuffle_stark_m3_n4_s11.json":
+        # round 6: the same proof with every one of those MSMs on the SPLIT pipeline (12-bit windows: k_bucket_sort / _acc / _reduce /
+        # _final, several bucket jobs of different lengths per phase) -- same bytes, same verdicts
+        t.set_latency_batch(0)
+        t.set_merged_verify(True)
+        t.set_bucket_bits(12)
+        eng.profile_enable(True)
+        deck, proof = t.shuffle_and_remask(bytes.fromhex(g["deck"]), bytes.fromhex(g["rho"]), g["perm"], bytes.fromhex(g["prover_seed"]))
+        assert deck.hex() == g["shuffled"] and proof.hex() == g["proof"]
+        assert t.verify_shuffle(bytes.fromhex(g["deck"]), deck, proof) == 0
+        bad = bytearray(proof)
+        bad[-1] ^= 1
+        assert t.verify_shuffle(bytes.fromhex(g["deck"]), deck, bytes(bad)) != 0
+        rep = eng.profile_report()
+        eng.profile_enable(False)
+        assert rep["k_bucket_acc"][0] >= 2 and "k_bucket_final" in rep and "k_bucket_msm" not in rep
+        t.set_bucket_bits(0)
 
 
 def test_bucket_msm_edge_scalars_under_emulation(emu, coracle):
