@@ -17,4 +17,4 @@ python bench.py --no-extras --no-cpu-baseline --steps 2 --warmup 1 --curve bls12
 { python tools/pcie_inclusive.py 262144; python tools/pcie_inclusive.py 16384; } 2>&1 | grep -v amdgpu > gpurun_out/${T}_pcie_inclusive.txt
 python tools/r05_small.py 1 64 1024 4096 2>&1 | grep -v amdgpu > gpurun_out/${T}_small_batches.txt
 python tools/r06k_one_bad.py 2>&1 | grep -v amdgpu > gpurun_out/${T}_one_bad_strategies.txt
-tail -3 gpurun_out/${T}_*.log; cat gpurun_out/${T}_all_configs.txt gpurun_out/${T}_pcie_inclusive.txt | head -40
+for f in gpurun_out/${T}_*.log; do tail -n 3 "$f"; done; cat gpurun_out/${T}_all_configs.txt gpurun_out/${T}_pcie_inclusive.txt | head -40
